@@ -1,0 +1,185 @@
+/*
+ * pantheon_hip.h -- C ABI of libpantheon_hip.so: the MI355X (gfx950) rollout-buffer / GAE / PPO-update
+ * engine behind PantheonRL's OnPolicyAgent surface.
+ *
+ * The reference (Stanford-ILIAD/PantheonRL) is pure Python and delegates this path to
+ * stable-baselines3==1.7.0 (reference setup.py:17).  Every entry point below replaces one reference call
+ * site; the citation names it (paths relative to the reference root).  The reference-side binding a
+ * maintainer would add is a ctypes stub -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  Unless a parameter says "host", every pointer is a DEVICE
+ *     pointer (HBM) owned by the caller; the library never frees caller memory and only allocates its own
+ *     scratch inside ph_ctx (released by ph_ctx_destroy).
+ *   - every call is asynchronous on the context's HIP stream (ph_ctx_set_stream); ph_ctx_sync() waits.
+ *   - return value: 0 = ok, non-zero = error; ph_last_error() gives the thread-local message.  Nothing
+ *     here calls abort().  No re-entrancy on one ph_ctx.
+ *   - all floating point is IEEE float32 ("f32"), actions are stored float32 in the rollout buffer like
+ *     SB3 does, and handed to environments as int32.
+ *
+ * Rollout buffer layout in HBM (same as SB3 RolloutBuffer): time-major (T, E, ...) row-major
+ * float32 arrays; the PPO minibatch index n in [0, T*E) is SB3's env-major "swap_and_flatten" index
+ * n = e*T + t and is translated to the physical row t*E + e inside the kernels (no flattened copy is made).
+ *
+ * Parameter vector layout (float32, P = ph_layout.P entries; H = 64), weights input-major [in][out]
+ * (the transpose of torch.nn.Linear.weight):
+ *   pi_W1[F][H] pi_b1[H] pi_W2[H][H] pi_b2[H]  vf_W1[F][H] vf_b1[H] vf_W2[H][H] vf_b2[H]
+ *   act_W[H][L] act_b[L]  val_W[H] val_b[1]
+ */
+#ifndef PANTHEON_HIP_H
+#define PANTHEON_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PH_ABI_VERSION 1
+#define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
+#define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
+#define PH_MAX_LOGITS 64 /* max total policy logits L */
+#define PH_NSTAT 8       /* per-minibatch stats record, see ph_ppo_train */
+
+#define PH_SPACE_BOX 0      /* gym.spaces.Box, flattened length n                        */
+#define PH_SPACE_DISCRETE 1 /* Discrete(k) (n=1, nvec={k}) or MultiDiscrete(nvec) (n=len) */
+
+typedef struct ph_ctx ph_ctx;
+
+typedef struct ph_space {
+  int kind;              /* PH_SPACE_*                                                      */
+  int n;                 /* Box: length.  Discrete family: number of components             */
+  int nvec[PH_MAX_COMP]; /* Discrete family: categories per component                       */
+} ph_space;
+
+typedef struct ph_spec { /* observation_space / action_space of one agent (multiagentenv.py:72-79) */
+  ph_space obs;
+  ph_space act; /* must be PH_SPACE_DISCRETE: the categorical family PPO uses in every BASELINE config */
+} ph_spec;
+
+typedef struct ph_layout {
+  int D; /* stored obs length per transition   */
+  int F; /* feature length after one-hot       */
+  int A; /* stored action length               */
+  int L; /* total logits                       */
+  int P; /* parameter count                    */
+  int pi_W1, pi_b1, pi_W2, pi_b2, vf_W1, vf_b1, vf_W2, vf_b2, act_W, act_b, val_W, val_b; /* offsets */
+} ph_layout;
+
+typedef struct ph_rollout { /* SB3 RolloutBuffer storage; call sites agents.py:123-130,157,172-179,196-198 */
+  int T, E;
+  float *observations;   /* (T,E,D) */
+  float *actions;        /* (T,E,A) */
+  float *rewards;        /* (T,E)   */
+  float *episode_starts; /* (T,E)   */
+  float *values;         /* (T,E)   */
+  float *log_probs;      /* (T,E)   */
+  float *advantages;     /* (T,E)   */
+  float *returns;        /* (T,E)   */
+} ph_rollout;
+
+typedef struct ph_ppo_hyper { /* SB3 PPO defaults mirrored at adap_learn.py:90-103; Adam eps modular/policies.py:84-88 */
+  float learning_rate;      /* 3e-4 */
+  float clip_range;         /* 0.2  */
+  float clip_range_vf;      /* < 0 : None */
+  float ent_coef;           /* 0.0  */
+  float vf_coef;            /* 0.5  */
+  float max_grad_norm;      /* 0.5  */
+  float target_kl;          /* < 0 : None */
+  int normalize_advantage;  /* 1    */
+  float adam_beta1, adam_beta2, adam_eps; /* 0.9, 0.999, 1e-5 */
+} ph_ppo_hyper;
+
+typedef struct ph_opt_state {
+  float *params; /* (P) */
+  float *adam_m; /* (P) exp_avg    */
+  float *adam_v; /* (P) exp_avg_sq */
+  int *step;     /* (1) device counter: optimizer steps applied so far */
+} ph_opt_state;
+
+/* ---- library / context ------------------------------------------------------------------------------ */
+int ph_abi_version(void);
+const char *ph_last_error(void);
+int ph_device_count(int *n_out /* host */);
+/* create on HIP device `device`; fails (non-zero) when no gfx950 device is visible. <- PPO.__init__(device=) trainer.py:110,197 */
+int ph_ctx_create(int device, ph_ctx **out /* host */);
+int ph_ctx_destroy(ph_ctx *ctx);
+int ph_ctx_set_stream(ph_ctx *ctx, void *hip_stream /* hipStream_t, may be NULL = default */);
+int ph_ctx_sync(ph_ctx *ctx);
+/* hipGraph capture of everything enqueued between begin/end on the ctx stream (launch-bound rollout loops) */
+int ph_graph_begin(ph_ctx *ctx);
+int ph_graph_end(ph_ctx *ctx, int *graph_id_out /* host */);
+int ph_graph_launch(ph_ctx *ctx, int graph_id);
+/* HIP-event timing on the ctx stream (bench.py roofline: events must sit on the stream the kernels run on) */
+int ph_timer_start(ph_ctx *ctx);
+int ph_timer_stop(ph_ctx *ctx, float *ms_out /* host */); /* synchronises */
+
+/* ---- shapes --------------------------------------------------------------------------------------------- */
+int ph_layout_of(const ph_spec *spec /* host */, ph_layout *out /* host */);
+
+/* ---- K1: rollout buffer writes --------------------------------------------------------------------------- */
+/* RolloutBuffer.add(obs, action, reward=0, episode_start, value, log_prob) at row `pos` <- agents.py:172-179.
+ * Inputs are copied (SB3 copies too), so callers may reuse them. */
+int ph_buffer_add(ph_ctx *ctx, const ph_spec *spec, const ph_rollout *rb, int pos, const float *obs /* (E,D) */,
+                  const float *actions /* (E,A) f32 */, const float *episode_start /* (E) */,
+                  const float *values /* (E) */, const float *log_probs /* (E) */);
+/* buf.rewards[pos][e] += reward[e] for e with env_mask[e] != 0 (NULL = all) <- Agent.update, agents.py:198 */
+int ph_buffer_add_reward(ph_ctx *ctx, const ph_rollout *rb, int pos, const float *reward /* (E) */,
+                         const unsigned char *env_mask /* (E) or NULL */);
+/* RolloutBuffer.reset() <- agents.py:157 : zero-fills every array */
+int ph_buffer_reset(ph_ctx *ctx, const ph_spec *spec, const ph_rollout *rb);
+
+/* ---- K2: GAE ------------------------------------------------------------------------------------------------ */
+/* RolloutBuffer.compute_returns_and_advantage(last_values, dones) <- agents.py:127-130.
+ * gamma / gae_lambda are doubles because the reference multiplies them as Python floats before the
+ * float32 array arithmetic (gamma*gae_lambda is rounded to f32 once).
+ * mode 0 = auto, 1 = serial-in-T / one lane per env (summation order and rounding identical to the numpy
+ * loop: bit-exact), 2 = chunked wavefront suffix scan over T (fp32 tolerance). */
+int ph_gae(ph_ctx *ctx, const ph_rollout *rb, const float *last_values /* (E) */, const float *dones /* (E) */,
+           double gamma, double gae_lambda, int mode);
+
+/* ---- K4: policy forward --------------------------------------------------------------------------------------- */
+/* ActorCriticPolicy.forward(obs) -> (actions, values, log_probs) <- util.py:63-81 (action_from_policy), agents.py:162.
+ *  action_mask (n,L) u8 or NULL : logits -= 30*(1-mask)  (modular/policies.py:330-333)
+ *  uniforms (n,A) or NULL       : teacher-forced inverse-CDF sampling; NULL = Philox4x32-10 keyed (seed, counter, row, comp)
+ *  given_actions (n,A) f32 or NULL : evaluate these instead of sampling (evaluate_actions, modular/policies.py:364-383)
+ *  deterministic != 0           : argmax
+ * Outputs (any may be NULL): actions_i32 (n,A), actions_f32 (n,A), values (n), log_probs (n), entropy (n), logits (n,L).
+ * When rb != NULL the transition is also written at row `pos` of the rollout buffer (fused RolloutBuffer.add with
+ * reward 0 and episode_start = episode_start_in) -- n must equal rb->E. */
+int ph_policy_forward(ph_ctx *ctx, const ph_spec *spec, const float *params, const float *obs, int n,
+                      const unsigned char *action_mask, const float *uniforms, const float *given_actions,
+                      unsigned long long seed, unsigned long long counter, int deterministic, int *actions_i32,
+                      float *actions_f32, float *values, float *log_probs, float *entropy, float *logits,
+                      const ph_rollout *rb, int pos, const float *episode_start_in, int gemm_mode);
+
+/* env-side illegal-action fix-up: action not legal -> first legal index <- pettingzoo.py:81-82.  Integer, bit-exact. */
+int ph_fix_illegal_actions(ph_ctx *ctx, int *actions /* (n) in/out */, const unsigned char *action_mask /* (n,L) */,
+                           int n, int L);
+
+/* ---- K3+K5+K6: PPO.train() ------------------------------------------------------------------------------------ */
+/* PPO.train() <- agents.py:155 (SB3 semantics SURVEY.md A.3; in-tree witness adap_learn.py:229-371).
+ * For each epoch, for each consecutive slice of `batch_size` indices (last may be short): gather by index,
+ * advantage normalisation, clipped surrogate + value + entropy loss, backward, global-norm clip, Adam.
+ *   perms      (n_epochs, T*E) int32 env-major indices (teacher-forced np.random.permutation) or NULL = a keyed
+ *              Feistel permutation of [0,T*E) per epoch generated in-kernel from perm_seed.
+ *   stats      (n_epochs * ceil(T*E/batch_size), PH_NSTAT) f32 or NULL: per minibatch
+ *              {policy_loss, value_loss, entropy_loss, clip_fraction, approx_kl, loss, grad_norm, applied}.
+ *   gemm_mode  0 = MFMA v_mfma_f32_32x32x2_f32 (product path), 1 = VALU fmaf chain with the same tile order (debug).
+ * target_kl early stop is evaluated on the device; later minibatches become no-ops (applied = 0). */
+int ph_ppo_train(ph_ctx *ctx, const ph_spec *spec, const ph_opt_state *opt, const ph_rollout *rb,
+                 const ph_ppo_hyper *hyper /* host */, int n_epochs, int batch_size, const int *perms,
+                 unsigned long long perm_seed, float *stats, int gemm_mode);
+/* gradient of ONE minibatch (indices given, (nb) int32 env-major) without touching the optimizer state:
+ * grad_out (P) = d loss / d params before clipping; stats_out (PH_NSTAT) as above.  For parity tests. */
+int ph_ppo_minibatch_grad(ph_ctx *ctx, const ph_spec *spec, const float *params, const ph_rollout *rb,
+                          const ph_ppo_hyper *hyper /* host */, const int *indices, int nb, float *grad_out,
+                          float *stats_out, int gemm_mode);
+
+/* Host-side evaluation of the keyed Feistel permutation ph_ppo_train uses when perms == NULL: writes
+ * out[i] = perm_epoch(start + i) for i < count (env-major indices in [0, n)).  Pure CPU, needs no device;
+ * the kernels run the identical integer code, so this is the bit-exact statement of the minibatch order. */
+int ph_feistel_indices(int n, unsigned long long perm_seed, int epoch, int start, int count, int *out /* host */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANTHEON_HIP_H */

@@ -1,0 +1,418 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module.  ``pantheonrl_amd`` never does.
+
+What it is
+----------
+A from-scratch CPU restatement (numpy + torch-CPU, float32) of the arithmetic
+that PantheonRL's ``OnPolicyAgent`` delegates to ``stable-baselines3==1.7.0``
+(reference ``setup.py:17``): the rollout buffer, the GAE pass, the MlpPolicy
+forward / evaluate_actions and ``PPO.train()``.
+
+PARITY UNPINNED.  stable-baselines3 is not vendored under /root/reference and
+is not installed in this image, and the reference has no tests or golden
+vectors.  The restatement therefore follows
+
+* the in-tree copies of the SB3 code that PantheonRL carries:
+  ``pantheonrl/algos/adap/adap_learn.py:229-371`` (PPO.train),
+  ``adap_learn.py:400-473`` (collect_rollouts / GAE call),
+  ``pantheonrl/algos/modular/policies.py:84-88,112-114,214-241,273-290,364-383``
+  (Adam eps, net_arch, ortho gains, forward / evaluate_actions order),
+* SURVEY.md Appendix A (SB3 1.7.0 semantics restated from memory),
+* the closed-form known-answer tests of SURVEY.md Appendix C,
+
+and it is built from the *same torch primitives SB3 itself calls*
+(``torch.distributions.Categorical``, ``nn.init.orthogonal_``,
+``torch.optim.Adam``, ``clip_grad_norm_``, ``F.mse_loss``, autograd), so the
+only unpinned part is the call sequence, not the primitives.
+
+Everything here is executed "the way SB3 executes it": per-step ``add`` with
+host copies, a Python loop over T for GAE, an eager-autograd minibatch loop.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch as th
+from torch import nn
+from torch.nn import functional as F
+
+HIDDEN = 64  # SB3 MlpPolicy default net_arch=[dict(pi=[64,64], vf=[64,64])]  (modular/policies.py:112-114)
+
+
+# --------------------------------------------------------------------------------------
+# spaces (gym is absent): the minimal description the arithmetic needs
+# --------------------------------------------------------------------------------------
+@dataclass
+class SpaceSpec:
+    """kind in {"box","discrete","multidiscrete"}; nvec only for the discrete kinds."""
+    kind: str
+    dim: int = 0                      # Box: length
+    nvec: Tuple[int, ...] = ()        # Discrete(n) -> (n,), MultiDiscrete(nvec) -> nvec
+
+    @property
+    def stored_len(self) -> int:      # SB3 obs_shape / action_dim
+        return self.dim if self.kind == "box" else len(self.nvec)
+
+    @property
+    def flat_len(self) -> int:        # features after preprocess_obs / number of logits
+        return self.dim if self.kind == "box" else int(sum(self.nvec))
+
+
+def preprocess_obs(obs: th.Tensor, space: SpaceSpec) -> th.Tensor:
+    """SB3 ``preprocess_obs``: Box -> float; Discrete -> one-hot; MultiDiscrete -> concat one-hots."""
+    if space.kind == "box":
+        return obs.float()
+    obs = obs.long().reshape(obs.shape[0], len(space.nvec))
+    parts = [F.one_hot(obs[:, i], num_classes=int(n)).float() for i, n in enumerate(space.nvec)]
+    return th.cat(parts, dim=-1)
+
+
+# --------------------------------------------------------------------------------------
+# A.1 RolloutBuffer
+# --------------------------------------------------------------------------------------
+class RolloutBufferOracle:
+    """SB3 1.7.0 ``RolloutBuffer``; call sites agents.py:123-130,157,172-179,196-198."""
+
+    def __init__(self, n_steps: int, n_envs: int, obs_len: int, act_len: int,
+                 gamma: float = 0.99, gae_lambda: float = 0.95):
+        self.T, self.E, self.D, self.A = n_steps, n_envs, obs_len, act_len
+        self.gamma, self.gae_lambda = gamma, gae_lambda
+        self.reset()
+
+    def reset(self) -> None:
+        T, E = self.T, self.E
+        self.observations = np.zeros((T, E, self.D), np.float32)
+        self.actions = np.zeros((T, E, self.A), np.float32)
+        for name in ("rewards", "returns", "episode_starts", "values", "log_probs", "advantages"):
+            setattr(self, name, np.zeros((T, E), np.float32))
+        self.pos, self.full, self.generator_ready = 0, False, False
+
+    def add(self, obs, action, reward, episode_start, value, log_prob) -> None:
+        E = self.E
+        self.observations[self.pos] = np.array(obs, dtype=np.float32).reshape(E, self.D).copy()
+        self.actions[self.pos] = np.array(action, dtype=np.float32).reshape(E, self.A).copy()
+        self.rewards[self.pos] = np.array(reward, dtype=np.float32).copy()
+        self.episode_starts[self.pos] = np.array(episode_start, dtype=np.float32).copy()
+        self.values[self.pos] = th.as_tensor(value).clone().cpu().numpy().flatten()
+        self.log_probs[self.pos] = th.as_tensor(log_prob).clone().cpu().numpy().reshape(-1)
+        self.pos += 1
+        if self.pos == self.T:
+            self.full = True
+
+    def compute_returns_and_advantage(self, last_values, dones) -> None:
+        """SURVEY A.2 verbatim structure: Python loop over T, ~6 numpy vector ops per iteration."""
+        last_values = th.as_tensor(last_values).clone().cpu().numpy().flatten().astype(np.float32)
+        last_gae_lam = 0
+        for step in reversed(range(self.T)):
+            if step == self.T - 1:
+                next_non_terminal = 1.0 - dones
+                next_values = last_values
+            else:
+                next_non_terminal = 1.0 - self.episode_starts[step + 1]
+                next_values = self.values[step + 1]
+            delta = self.rewards[step] + self.gamma * next_values * next_non_terminal - self.values[step]
+            last_gae_lam = delta + self.gamma * self.gae_lambda * next_non_terminal * last_gae_lam
+            self.advantages[step] = last_gae_lam
+        self.returns = self.advantages + self.values
+
+    @staticmethod
+    def swap_and_flatten(arr: np.ndarray) -> np.ndarray:
+        shape = arr.shape
+        if len(shape) < 3:
+            shape = shape + (1,)
+        return arr.swapaxes(0, 1).reshape(shape[0] * shape[1], *shape[2:])
+
+    def flat(self):
+        """env-major flattening (row e*T + t) of everything ``get`` yields."""
+        f = self.swap_and_flatten
+        return dict(observations=f(self.observations), actions=f(self.actions),
+                    old_values=f(self.values).reshape(-1), old_log_prob=f(self.log_probs).reshape(-1),
+                    advantages=f(self.advantages).reshape(-1), returns=f(self.returns).reshape(-1))
+
+    def get(self, batch_size: Optional[int], indices: Optional[np.ndarray] = None):
+        assert self.full, "rollout buffer must be full"
+        n = self.T * self.E
+        if indices is None:
+            indices = np.random.permutation(n)
+        data = self.flat()
+        if batch_size is None:
+            batch_size = n
+        start = 0
+        while start < n:
+            sl = indices[start:start + batch_size]
+            yield {k: th.as_tensor(v[sl]) for k, v in data.items()}
+            start += batch_size
+
+
+def gae_reference(rewards, values, episode_starts, last_values, dones, gamma=0.99, gae_lambda=0.95):
+    """Functional form of A.2 on (T,E) float32 arrays.  Returns (advantages, returns)."""
+    T, E = rewards.shape
+    buf = RolloutBufferOracle(T, E, 1, 1, gamma, gae_lambda)
+    buf.rewards[:] = rewards
+    buf.values[:] = values
+    buf.episode_starts[:] = episode_starts
+    buf.compute_returns_and_advantage(np.asarray(last_values, np.float32), np.asarray(dones, np.float32))
+    return buf.advantages.copy(), buf.returns.copy()
+
+
+def gae_float64(rewards, values, episode_starts, last_values, dones, gamma=0.99, gae_lambda=0.95):
+    """Same recurrence in float64 -- used only to state fp32 tolerances."""
+    r, v, s = (np.asarray(a, np.float64) for a in (rewards, values, episode_starts))
+    T, E = r.shape
+    adv = np.zeros((T, E))
+    last = np.zeros(E)
+    for t in reversed(range(T)):
+        if t == T - 1:
+            nnt, nv = 1.0 - np.asarray(dones, np.float64), np.asarray(last_values, np.float64)
+        else:
+            nnt, nv = 1.0 - s[t + 1], v[t + 1]
+        delta = r[t] + gamma * nv * nnt - v[t]
+        last = delta + gamma * gae_lambda * nnt * last
+        adv[t] = last
+    return adv, adv + v
+
+
+# --------------------------------------------------------------------------------------
+# A.4 MlpPolicy
+# --------------------------------------------------------------------------------------
+class MlpPolicyOracle(nn.Module):
+    """SB3 ``ActorCriticPolicy`` with FlattenExtractor and the default MlpExtractor."""
+
+    def __init__(self, obs_space: SpaceSpec, act_space: SpaceSpec, lr: float = 3e-4, ortho_init: bool = True):
+        super().__init__()
+        assert act_space.kind in ("discrete", "multidiscrete"), "PPO hot path here is the categorical family"
+        self.obs_space, self.act_space = obs_space, act_space
+        Fdim, L = obs_space.flat_len, act_space.flat_len
+        self.policy_net = nn.Sequential(nn.Linear(Fdim, HIDDEN), nn.Tanh(), nn.Linear(HIDDEN, HIDDEN), nn.Tanh())
+        self.value_net_mlp = nn.Sequential(nn.Linear(Fdim, HIDDEN), nn.Tanh(), nn.Linear(HIDDEN, HIDDEN), nn.Tanh())
+        self.action_net = nn.Linear(HIDDEN, L)
+        self.value_net = nn.Linear(HIDDEN, 1)
+        if ortho_init:  # gains: modular/policies.py:229-241
+            for mod, gain in ((self.policy_net, np.sqrt(2)), (self.value_net_mlp, np.sqrt(2)),
+                              (self.action_net, 0.01), (self.value_net, 1.0)):
+                for m in mod.modules():
+                    if isinstance(m, nn.Linear):
+                        nn.init.orthogonal_(m.weight, gain=gain)
+                        m.bias.data.fill_(0.0)
+        # Adam eps=1e-5: modular/policies.py:84-88
+        self.optimizer = th.optim.Adam(self.parameters(), lr=lr, eps=1e-5)
+
+    # -- distribution helpers -------------------------------------------------------
+    def _split(self, logits: th.Tensor) -> List[th.Tensor]:
+        return list(th.split(logits, list(self.act_space.nvec), dim=1))
+
+    def _latents(self, obs: th.Tensor):
+        feats = preprocess_obs(obs, self.obs_space)
+        return self.policy_net(feats), self.value_net_mlp(feats)
+
+    def logits(self, obs: th.Tensor, action_mask: Optional[th.Tensor] = None) -> th.Tensor:
+        z = self.action_net(self._latents(obs)[0])
+        if action_mask is not None:  # modular/policies.py:330-333: logits -= 30 * (~mask)
+            z = z - 30.0 * (1.0 - action_mask.float())
+        return z
+
+    def forward(self, obs: th.Tensor, deterministic: bool = False, uniforms: Optional[th.Tensor] = None,
+                action_mask: Optional[th.Tensor] = None):
+        """-> (actions (n, A) int64, values (n,1), log_prob (n,)).  Order as modular/policies.py:273-290.
+
+        ``uniforms`` (n, n_components) teacher-forces sampling by inverse CDF so a device RNG can be
+        compared; without it ``Categorical.sample()`` is used like SB3.
+        """
+        latent_pi, latent_vf = self._latents(obs)
+        values = self.value_net(latent_vf)
+        z = self.action_net(latent_pi)
+        if action_mask is not None:
+            z = z - 30.0 * (1.0 - action_mask.float())
+        acts, logp = [], 0.0
+        for c, zc in enumerate(self._split(z)):
+            dist = th.distributions.Categorical(logits=zc)
+            if deterministic:
+                a = th.argmax(dist.probs, dim=1)
+            elif uniforms is not None:
+                a = inverse_cdf_sample(dist.probs, uniforms[:, c])
+            else:
+                a = dist.sample()
+            acts.append(a)
+            logp = logp + dist.log_prob(a)
+        return th.stack(acts, dim=1), values, logp
+
+    def evaluate_actions(self, obs: th.Tensor, actions: th.Tensor, action_mask: Optional[th.Tensor] = None):
+        """-> (values (n,1), log_prob (n,), entropy (n,)).  modular/policies.py:364-383."""
+        latent_pi, latent_vf = self._latents(obs)
+        z = self.action_net(latent_pi)
+        if action_mask is not None:
+            z = z - 30.0 * (1.0 - action_mask.float())
+        actions = actions.long().reshape(obs.shape[0], -1)
+        logp, ent = 0.0, 0.0
+        for c, zc in enumerate(self._split(z)):
+            dist = th.distributions.Categorical(logits=zc)
+            logp = logp + dist.log_prob(actions[:, c])
+            ent = ent + dist.entropy()
+        return self.value_net(latent_vf), logp, ent
+
+    def predict_values(self, obs: th.Tensor) -> th.Tensor:
+        return self.value_net(self._latents(obs)[1])
+
+    # -- flat parameter vector in the layout include/pantheon_hip.h documents ------------
+    def flat_params(self) -> np.ndarray:
+        """[pi_W1(F,H) pi_b1 pi_W2(H,H) pi_b2 vf_W1 vf_b1 vf_W2 vf_b2 act_W(H,L) act_b val_W(H) val_b];
+        weights stored input-major (the transpose of torch's [out][in])."""
+        out = []
+        for seq in (self.policy_net, self.value_net_mlp):
+            for idx in (0, 2):
+                out += [seq[idx].weight.detach().t().contiguous().reshape(-1), seq[idx].bias.detach()]
+        out += [self.action_net.weight.detach().t().contiguous().reshape(-1), self.action_net.bias.detach(),
+                self.value_net.weight.detach().reshape(-1), self.value_net.bias.detach()]
+        return th.cat(out).numpy().astype(np.float32).copy()
+
+    def load_flat_params(self, flat: np.ndarray) -> None:
+        flat = th.as_tensor(np.asarray(flat, np.float32))
+        o = 0
+
+        def take(n):
+            nonlocal o
+            v = flat[o:o + n]
+            o += n
+            return v
+        with th.no_grad():
+            for seq in (self.policy_net, self.value_net_mlp):
+                for idx in (0, 2):
+                    lin = seq[idx]
+                    lin.weight.copy_(take(lin.weight.numel()).reshape(lin.in_features, lin.out_features).t())
+                    lin.bias.copy_(take(lin.bias.numel()))
+            lin = self.action_net
+            lin.weight.copy_(take(lin.weight.numel()).reshape(lin.in_features, lin.out_features).t())
+            lin.bias.copy_(take(lin.bias.numel()))
+            self.value_net.weight.copy_(take(HIDDEN).reshape(1, HIDDEN))
+            self.value_net.bias.copy_(take(1))
+        assert o == flat.numel()
+
+    def flat_grads(self) -> np.ndarray:
+        out = []
+        for seq in (self.policy_net, self.value_net_mlp):
+            for idx in (0, 2):
+                out += [seq[idx].weight.grad.t().contiguous().reshape(-1), seq[idx].bias.grad]
+        out += [self.action_net.weight.grad.t().contiguous().reshape(-1), self.action_net.bias.grad,
+                self.value_net.weight.grad.reshape(-1), self.value_net.bias.grad]
+        return th.cat(out).numpy().astype(np.float32).copy()
+
+
+def inverse_cdf_sample(probs: th.Tensor, u: th.Tensor) -> th.Tensor:
+    """action = number of prefix sums (float32, left to right) that are <= u, clamped to n-1."""
+    n = probs.shape[1]
+    acc = th.zeros(probs.shape[0], dtype=th.float32)
+    a = th.zeros(probs.shape[0], dtype=th.long)
+    for k in range(n - 1):
+        acc = acc + probs[:, k].float()
+        a = a + (u.float() >= acc).long()
+    return a
+
+
+def fix_illegal_actions(actions: np.ndarray, masks: np.ndarray) -> np.ndarray:
+    """env-side fix-up, pettingzoo.py:81-82: illegal action -> first legal index.  Integer, bit-exact."""
+    actions = np.asarray(actions).astype(np.int64).copy()
+    masks = np.asarray(masks)
+    for e in range(actions.shape[0]):
+        if not masks[e][actions[e]]:
+            actions[e] = masks[e].tolist().index(1)
+    return actions
+
+
+# --------------------------------------------------------------------------------------
+# A.3 PPO.train()
+# --------------------------------------------------------------------------------------
+@dataclass
+class PPOHyper:
+    """defaults: adap_learn.py:90-103 (mirror of SB3's)."""
+    learning_rate: float = 3e-4
+    n_epochs: int = 10
+    batch_size: int = 64
+    clip_range: float = 0.2
+    clip_range_vf: Optional[float] = None
+    normalize_advantage: bool = True
+    ent_coef: float = 0.0
+    vf_coef: float = 0.5
+    max_grad_norm: float = 0.5
+    target_kl: Optional[float] = None
+
+
+def ppo_minibatch_loss(policy: MlpPolicyOracle, mb: dict, hp: PPOHyper):
+    """One minibatch of adap_learn.py:253-327 (without the ADAP context term).  Returns (loss, stats)."""
+    actions = mb["actions"]
+    if policy.act_space.kind == "discrete":
+        actions = actions.long().flatten()
+    values, log_prob, entropy = policy.evaluate_actions(mb["observations"], actions)
+    values = values.flatten()
+    advantages = mb["advantages"]
+    if hp.normalize_advantage and len(advantages) > 1:
+        advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+    ratio = th.exp(log_prob - mb["old_log_prob"])
+    policy_loss_1 = advantages * ratio
+    policy_loss_2 = advantages * th.clamp(ratio, 1 - hp.clip_range, 1 + hp.clip_range)
+    policy_loss = -th.min(policy_loss_1, policy_loss_2).mean()
+    clip_fraction = th.mean((th.abs(ratio - 1) > hp.clip_range).float()).item()
+    if hp.clip_range_vf is None:
+        values_pred = values
+    else:
+        values_pred = mb["old_values"] + th.clamp(values - mb["old_values"], -hp.clip_range_vf, hp.clip_range_vf)
+    value_loss = F.mse_loss(mb["returns"], values_pred)
+    entropy_loss = -th.mean(entropy)
+    loss = policy_loss + hp.ent_coef * entropy_loss + hp.vf_coef * value_loss
+    with th.no_grad():
+        log_ratio = log_prob - mb["old_log_prob"]
+        approx_kl = th.mean((th.exp(log_ratio) - 1) - log_ratio).item()
+    stats = dict(policy_loss=policy_loss.item(), value_loss=value_loss.item(), entropy_loss=entropy_loss.item(),
+                 clip_fraction=clip_fraction, approx_kl=approx_kl, loss=loss.item())
+    return loss, stats
+
+
+def ppo_train(policy: MlpPolicyOracle, buf: RolloutBufferOracle, hp: PPOHyper,
+              perms: Optional[Sequence[np.ndarray]] = None) -> List[dict]:
+    """SB3 ``PPO.train()``.  ``perms[epoch]`` teacher-forces ``np.random.permutation``."""
+    for g in policy.optimizer.param_groups:
+        g["lr"] = hp.learning_rate
+    all_stats: List[dict] = []
+    continue_training = True
+    for epoch in range(hp.n_epochs):
+        idx = None if perms is None else np.asarray(perms[epoch])
+        for mb in buf.get(hp.batch_size, idx):
+            loss, stats = ppo_minibatch_loss(policy, mb, hp)
+            if hp.target_kl is not None and stats["approx_kl"] > 1.5 * hp.target_kl:
+                continue_training = False
+                stats["stopped"] = True
+                all_stats.append(stats)
+                break
+            policy.optimizer.zero_grad()
+            loss.backward()
+            gn = th.nn.utils.clip_grad_norm_(policy.parameters(), hp.max_grad_norm)
+            stats["grad_norm"] = float(gn)
+            policy.optimizer.step()
+            all_stats.append(stats)
+        if not continue_training:
+            break
+    return all_stats
+
+
+# --------------------------------------------------------------------------------------
+# SB3-style rollout+update iteration on synthetic inputs: the cpu_baseline leg of bench.py
+# --------------------------------------------------------------------------------------
+def synthetic_iteration(policy: MlpPolicyOracle, buf: RolloutBufferOracle, hp: PPOHyper,
+                        obs_seq: np.ndarray, rew_seq: np.ndarray, done_seq: np.ndarray) -> None:
+    """One whole PPO iteration executed the way OnPolicyAgent + SB3 execute it (agents.py:111-203):
+    per step: no_grad forward, buffer.add with host copies, reward +=; then GAE loop; then train()."""
+    T, E = buf.T, buf.E
+    buf.reset()
+    last_starts = np.ones(E, np.float32)
+    values = None
+    for t in range(T):
+        with th.no_grad():
+            actions, values, logp = policy.forward(th.as_tensor(obs_seq[t]))
+        buf.add(obs_seq[t], actions.numpy(), np.zeros(E, np.float32), last_starts, values, logp)
+        buf.rewards[buf.pos - 1] += rew_seq[t]          # Agent.update: agents.py:198
+        last_starts = done_seq[t].astype(np.float32)    # agents.py:197
+    buf.compute_returns_and_advantage(values, last_starts)  # quirk D-1: V(o_{T-1})
+    ppo_train(policy, buf, hp)

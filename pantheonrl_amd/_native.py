@@ -1,0 +1,180 @@
+"""ctypes binding of libpantheon_hip.so (include/pantheon_hip.h).
+
+There is no CPU fallback: if the shared library cannot be loaded, or no gfx950 device is visible when a context is
+created, the engine raises.  Loading the library itself needs no GPU (the not-gpu tests check the exported symbols).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+PH_HIDDEN = 64
+PH_MAX_COMP = 256
+PH_MAX_LOGITS = 64
+PH_NSTAT = 8
+PH_SPACE_BOX = 0
+PH_SPACE_DISCRETE = 1
+STAT_NAMES = ("policy_loss", "value_loss", "entropy_loss", "clip_fraction", "approx_kl", "loss", "grad_norm", "applied")
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpantheon_hip.so")
+
+
+class NativeError(RuntimeError):
+    """Raised for any non-zero status from the C ABI (message from ph_last_error)."""
+
+
+class PhSpace(C.Structure):
+    _fields_ = [("kind", C.c_int), ("n", C.c_int), ("nvec", C.c_int * PH_MAX_COMP)]
+
+
+class PhSpec(C.Structure):
+    _fields_ = [("obs", PhSpace), ("act", PhSpace)]
+
+
+class PhLayout(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("D", "F", "A", "L", "P", "pi_W1", "pi_b1", "pi_W2", "pi_b2", "vf_W1", "vf_b1",
+                                        "vf_W2", "vf_b2", "act_W", "act_b", "val_W", "val_b")]
+
+
+class PhRollout(C.Structure):
+    _fields_ = [("T", C.c_int), ("E", C.c_int)] + [(k, C.c_void_p) for k in (
+        "observations", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns")]
+
+
+class PhPpoHyper(C.Structure):
+    _fields_ = [("learning_rate", C.c_float), ("clip_range", C.c_float), ("clip_range_vf", C.c_float),
+                ("ent_coef", C.c_float), ("vf_coef", C.c_float), ("max_grad_norm", C.c_float),
+                ("target_kl", C.c_float), ("normalize_advantage", C.c_int), ("adam_beta1", C.c_float),
+                ("adam_beta2", C.c_float), ("adam_eps", C.c_float)]
+
+
+class PhOptState(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("step", C.c_void_p)]
+
+
+_vp, _i, _ull, _d = C.c_void_p, C.c_int, C.c_ulonglong, C.c_double
+# name -> argtypes (restype is int except where noted); the single source the symbol test walks
+SIGNATURES = {
+    "ph_abi_version": [],
+    "ph_last_error": [],
+    "ph_device_count": [C.POINTER(_i)],
+    "ph_ctx_create": [_i, C.POINTER(_vp)],
+    "ph_ctx_destroy": [_vp],
+    "ph_ctx_set_stream": [_vp, _vp],
+    "ph_ctx_sync": [_vp],
+    "ph_graph_begin": [_vp],
+    "ph_graph_end": [_vp, C.POINTER(_i)],
+    "ph_graph_launch": [_vp, _i],
+    "ph_timer_start": [_vp],
+    "ph_timer_stop": [_vp, C.POINTER(C.c_float)],
+    "ph_layout_of": [C.POINTER(PhSpec), C.POINTER(PhLayout)],
+    "ph_buffer_add": [_vp, C.POINTER(PhSpec), C.POINTER(PhRollout), _i, _vp, _vp, _vp, _vp, _vp],
+    "ph_buffer_add_reward": [_vp, C.POINTER(PhRollout), _i, _vp, _vp],
+    "ph_buffer_reset": [_vp, C.POINTER(PhSpec), C.POINTER(PhRollout)],
+    "ph_gae": [_vp, C.POINTER(PhRollout), _vp, _vp, _d, _d, _i],
+    "ph_policy_forward": [_vp, C.POINTER(PhSpec), _vp, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, _vp, _vp,
+                          _vp, C.POINTER(PhRollout), _i, _vp, _i],
+    "ph_fix_illegal_actions": [_vp, _vp, _vp, _i, _i],
+    "ph_ppo_train": [_vp, C.POINTER(PhSpec), C.POINTER(PhOptState), C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i,
+                     _vp, _ull, _vp, _i],
+    "ph_ppo_minibatch_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _vp, _i, _vp,
+                              _vp, _i],
+    "ph_feistel_indices": [_i, _ull, _i, _i, _i, C.POINTER(_i)],
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """dlopen the engine; builds it in-tree with hipcc when the .so is absent or stale and hipcc is available."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing:
+        try:
+            from .csrc import build as _build
+            if _build.needs_build():
+                _build.build(verbose=False)
+        except Exception as exc:  # noqa: BLE001 -- reported below if the library is really unusable
+            if not os.path.exists(LIB_PATH):
+                raise NativeError(f"libpantheon_hip.so is missing and could not be built: {exc}") from exc
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(f"{LIB_PATH} not found: build it with `python -m pantheonrl_amd.csrc.build` "
+                          "(the MI355X engine has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "ph_last_error" else C.c_int
+    if lib.ph_abi_version() != 1:
+        raise NativeError("libpantheon_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = load().ph_last_error()
+        raise NativeError(msg.decode() if msg else f"pantheon_hip error {status}")
+
+
+def make_space(kind: int, n: int, nvec: Sequence[int] = ()) -> PhSpace:
+    s = PhSpace()
+    s.kind, s.n = int(kind), int(n)
+    if len(nvec) > PH_MAX_COMP:
+        raise NativeError("too many MultiDiscrete components")
+    for i, v in enumerate(nvec):
+        s.nvec[i] = int(v)
+    return s
+
+
+def layout_of(spec: PhSpec) -> PhLayout:
+    lay = PhLayout()
+    check(load().ph_layout_of(C.byref(spec), C.byref(lay)))
+    return lay
+
+
+def ptr(t) -> Optional[int]:
+    """device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+class Context:
+    """Owns one ph_ctx (workspace + stream binding) on one device."""
+
+    def __init__(self, device_index: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        check(self.lib.ph_ctx_create(int(device_index), C.byref(h)))
+        self.handle = h
+        self.device_index = int(device_index)
+
+    def set_stream(self, raw_stream: int) -> None:
+        check(self.lib.ph_ctx_set_stream(self.handle, C.c_void_p(raw_stream)))
+
+    def sync(self) -> None:
+        check(self.lib.ph_ctx_sync(self.handle))
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.ph_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def feistel_indices(n: int, perm_seed: int, epoch: int, start: int = 0, count: Optional[int] = None):
+    """host evaluation of the in-kernel minibatch permutation (bit-exact integer statement of the order)."""
+    import numpy as np
+    count = n - start if count is None else count
+    out = (C.c_int * count)()
+    check(load().ph_feistel_indices(int(n), int(perm_seed), int(epoch), int(start), int(count), out))
+    return np.frombuffer(out, dtype=np.int32).copy()

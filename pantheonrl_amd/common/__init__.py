@@ -1,0 +1,6 @@
+"""Host-side mirror of `pantheonrl.common` for the OnPolicyAgent / MultiAgentEnv hot path (same names, argument
+meaning and error behaviour as the reference; the arithmetic runs in libpantheon_hip.so)."""
+from .observation import Observation, extract_obs, extract_partial_obs  # noqa: F401
+from .agents import Agent, OnPolicyAgent, StaticPolicyAgent  # noqa: F401
+from .multiagentenv import (DummyEnv, MultiAgentEnv, PlayerException, SimultaneousEnv,  # noqa: F401
+                            TurnBasedEnv)

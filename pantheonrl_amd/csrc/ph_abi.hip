@@ -1,0 +1,601 @@
+// C ABI of libpantheon_hip.so (see include/pantheon_hip.h for the contract and the reference call sites).
+// Host side only: argument checking, workspace management, kernel launches on the context stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ph_launch.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& m) {
+  g_err = m;
+  return 1;
+}
+int fail_hip(const char* what, hipError_t e) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return 2;
+}
+#define PH_HIP(call)                                   \
+  do {                                                 \
+    hipError_t _e = (call);                            \
+    if (_e != hipSuccess) return fail_hip(#call, _e);  \
+  } while (0)
+
+struct SpecCache {
+  ph_spec spec;
+  int* obs_off = nullptr;  // device prefix sums
+  int* act_off = nullptr;
+};
+
+}  // namespace
+
+struct ph_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // workspace
+  float* slabs = nullptr;
+  size_t slabs_cap = 0;
+  float* statpart = nullptr;
+  size_t statpart_cap = 0;
+  float* grad = nullptr;
+  size_t grad_cap = 0;
+  float* blocksq = nullptr;
+  size_t blocksq_cap = 0;
+  float* advstats = nullptr;
+  size_t advstats_cap = 0;
+  float* scalars = nullptr;  // [4]
+  int* stop_flag = nullptr;  // [1]
+  std::vector<SpecCache> specs;
+  std::vector<hipGraphExec_t> graphs;
+  bool capturing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int num_cu = 256;
+};
+
+namespace {
+
+template <typename T>
+int ensure(T*& p, size_t& cap, size_t n) {
+  if (n <= cap) return 0;
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+  hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+  if (e != hipSuccess) return fail_hip("hipMalloc(workspace)", e);
+  cap = n;
+  return 0;
+}
+
+int check_space(const ph_space& s, const char* name) {
+  if (s.kind != PH_SPACE_BOX && s.kind != PH_SPACE_DISCRETE) return fail(std::string(name) + ": unknown space kind");
+  if (s.n <= 0) return fail(std::string(name) + ": empty space");
+  if (s.kind == PH_SPACE_DISCRETE) {
+    if (s.n > PH_MAX_COMP) return fail(std::string(name) + ": too many components");
+    for (int i = 0; i < s.n; ++i)
+      if (s.nvec[i] <= 0) return fail(std::string(name) + ": nvec entries must be positive");
+  }
+  return 0;
+}
+
+int layout_of(const ph_spec* spec, ph_layout* o) {
+  if (!spec || !o) return fail("null spec/layout");
+  if (check_space(spec->obs, "observation space")) return 1;
+  if (check_space(spec->act, "action space")) return 1;
+  if (spec->act.kind != PH_SPACE_DISCRETE) return fail("action space must be Discrete/MultiDiscrete (categorical PPO path)");
+  o->D = spec->obs.n;
+  o->F = 0;
+  if (spec->obs.kind == PH_SPACE_BOX) o->F = spec->obs.n;
+  else
+    for (int i = 0; i < spec->obs.n; ++i) o->F += spec->obs.nvec[i];
+  o->A = spec->act.n;
+  o->L = 0;
+  for (int i = 0; i < spec->act.n; ++i) o->L += spec->act.nvec[i];
+  if (o->L > PH_MAX_LOGITS) return fail("too many logits (PH_MAX_LOGITS)");
+  const int H = PH_HIDDEN;
+  int off = 0;
+  o->pi_W1 = off; off += o->F * H;
+  o->pi_b1 = off; off += H;
+  o->pi_W2 = off; off += H * H;
+  o->pi_b2 = off; off += H;
+  o->vf_W1 = off; off += o->F * H;
+  o->vf_b1 = off; off += H;
+  o->vf_W2 = off; off += H * H;
+  o->vf_b2 = off; off += H;
+  o->act_W = off; off += H * o->L;
+  o->act_b = off; off += o->L;
+  o->val_W = off; off += H;
+  o->val_b = off; off += 1;
+  o->P = off;
+  return 0;
+}
+
+// device-resident prefix sums of the nvec arrays, cached per distinct spec
+int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd) {
+  if (layout_of(spec, &nd->lay)) return 1;
+  SpecCache* hit = nullptr;
+  for (auto& c : ctx->specs)
+    if (std::memcmp(&c.spec, spec, sizeof(ph_spec)) == 0) { hit = &c; break; }
+  if (!hit) {
+    if (ctx->capturing) return fail("first use of a spec inside graph capture: call it once outside capture first");
+    SpecCache c;
+    std::memcpy(&c.spec, spec, sizeof(ph_spec));
+    std::vector<int> ao(spec->act.n + 1, 0);
+    for (int i = 0; i < spec->act.n; ++i) ao[i + 1] = ao[i] + spec->act.nvec[i];
+    PH_HIP(hipMalloc((void**)&c.act_off, ao.size() * sizeof(int)));
+    PH_HIP(hipMemcpy(c.act_off, ao.data(), ao.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (spec->obs.kind == PH_SPACE_DISCRETE) {
+      std::vector<int> oo(spec->obs.n + 1, 0);
+      for (int i = 0; i < spec->obs.n; ++i) oo[i + 1] = oo[i] + spec->obs.nvec[i];
+      PH_HIP(hipMalloc((void**)&c.obs_off, oo.size() * sizeof(int)));
+      PH_HIP(hipMemcpy(c.obs_off, oo.data(), oo.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    ctx->specs.push_back(c);
+    hit = &ctx->specs.back();
+  }
+  nd->obs_kind = spec->obs.kind;
+  nd->D = nd->lay.D;
+  nd->F = nd->lay.F;
+  nd->A = nd->lay.A;
+  nd->L = nd->lay.L;
+  nd->Lp = ((nd->L + 31) / 32) * 32;
+  nd->nchunk = (nd->F + PH_HIDDEN - 1) / PH_HIDDEN;
+  nd->obs_off = hit->obs_off;
+  nd->act_off = hit->act_off;
+  return 0;
+}
+
+int check_rb(const ph_rollout* rb) {
+  if (!rb) return fail("null rollout buffer");
+  if (rb->T <= 0 || rb->E <= 0) return fail("rollout buffer: T and E must be positive");
+  if (!rb->observations || !rb->actions || !rb->rewards || !rb->episode_starts || !rb->values || !rb->log_probs ||
+      !rb->advantages || !rb->returns)
+    return fail("rollout buffer: null array");
+  if ((long long)rb->T * rb->E >= (1ll << 31)) return fail("rollout buffer: T*E must fit in int32");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ph_abi_version(void) { return PH_ABI_VERSION; }
+const char* ph_last_error(void) { return g_err.c_str(); }
+
+int ph_device_count(int* n_out) {
+  if (!n_out) return fail("null n_out");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *n_out = 0;
+    return fail_hip("hipGetDeviceCount", e);
+  }
+  *n_out = n;
+  return 0;
+}
+
+int ph_ctx_create(int device, ph_ctx** out) {
+  if (!out) return fail("null out");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail("no HIP device visible: the PantheonRL MI355X engine has no CPU fallback");
+  if (device < 0 || device >= n) return fail("device index out of range");
+  PH_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  PH_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
+  ph_ctx* c = new ph_ctx();
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount;
+  if (hipMalloc((void**)&c->scalars, 4 * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&c->stop_flag, sizeof(int)) != hipSuccess) {
+    delete c;
+    return fail("hipMalloc(ctx scalars) failed");
+  }
+  (void)hipMemset(c->scalars, 0, 4 * sizeof(float));
+  (void)hipMemset(c->stop_flag, 0, sizeof(int));
+  (void)hipEventCreate(&c->ev0);
+  (void)hipEventCreate(&c->ev1);
+  *out = c;
+  return 0;
+}
+
+int ph_ctx_destroy(ph_ctx* ctx) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto g : ctx->graphs)
+    if (g) (void)hipGraphExecDestroy(g);
+  for (auto& s : ctx->specs) {
+    if (s.obs_off) (void)hipFree(s.obs_off);
+    if (s.act_off) (void)hipFree(s.act_off);
+  }
+  void* ptrs[] = {ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->scalars, ctx->stop_flag};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  delete ctx;
+  return 0;
+}
+
+int ph_ctx_set_stream(ph_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail("null ctx");
+  ctx->stream = (hipStream_t)hip_stream;
+  return 0;
+}
+
+int ph_ctx_sync(ph_ctx* ctx) {
+  if (!ctx) return fail("null ctx");
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int ph_graph_begin(ph_ctx* ctx) {
+  if (!ctx) return fail("null ctx");
+  if (ctx->capturing) return fail("already capturing");
+  if (ctx->stream == nullptr) return fail("graph capture needs a non-default stream (ph_ctx_set_stream)");
+  PH_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  ctx->capturing = true;
+  return 0;
+}
+
+int ph_graph_end(ph_ctx* ctx, int* graph_id_out) {
+  if (!ctx || !graph_id_out) return fail("null ctx/graph_id_out");
+  if (!ctx->capturing) return fail("not capturing");
+  ctx->capturing = false;
+  hipGraph_t g = nullptr;
+  PH_HIP(hipStreamEndCapture(ctx->stream, &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return fail_hip("hipGraphInstantiate", e);
+  ctx->graphs.push_back(ge);
+  *graph_id_out = (int)ctx->graphs.size() - 1;
+  return 0;
+}
+
+int ph_graph_launch(ph_ctx* ctx, int graph_id) {
+  if (!ctx) return fail("null ctx");
+  if (graph_id < 0 || graph_id >= (int)ctx->graphs.size()) return fail("bad graph id");
+  PH_HIP(hipGraphLaunch(ctx->graphs[graph_id], ctx->stream));
+  return 0;
+}
+
+int ph_timer_start(ph_ctx* ctx) {
+  if (!ctx) return fail("null ctx");
+  PH_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  return 0;
+}
+int ph_timer_stop(ph_ctx* ctx, float* ms_out) {
+  if (!ctx || !ms_out) return fail("null ctx/ms_out");
+  PH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  PH_HIP(hipEventSynchronize(ctx->ev1));
+  PH_HIP(hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+  return 0;
+}
+
+int ph_layout_of(const ph_spec* spec, ph_layout* out) { return layout_of(spec, out); }
+
+// ---- K1 ----
+int ph_buffer_add(ph_ctx* ctx, const ph_spec* spec, const ph_rollout* rb, int pos, const float* obs,
+                  const float* actions, const float* episode_start, const float* values, const float* log_probs) {
+  if (!ctx) return fail("null ctx");
+  ph_layout lay;
+  if (layout_of(spec, &lay) || check_rb(rb)) return 1;
+  if (pos < 0 || pos >= rb->T) return fail("ph_buffer_add: pos out of range (buffer full?)");
+  if (!obs || !actions || !episode_start || !values || !log_probs) return fail("ph_buffer_add: null input");
+  const size_t E = rb->E, row = (size_t)pos * E;
+  PH_HIP(ph::launch_buffer_add(rb->observations + row * lay.D, rb->actions + row * lay.A, rb->rewards + row,
+                               rb->episode_starts + row, rb->values + row, rb->log_probs + row, obs, actions,
+                               episode_start, values, log_probs, rb->E, lay.D, lay.A, ctx->stream));
+  return 0;
+}
+
+int ph_buffer_add_reward(ph_ctx* ctx, const ph_rollout* rb, int pos, const float* reward,
+                         const unsigned char* env_mask) {
+  if (!ctx) return fail("null ctx");
+  if (check_rb(rb)) return 1;
+  if (pos < 0 || pos >= rb->T) return fail("ph_buffer_add_reward: pos out of range");
+  if (!reward) return fail("ph_buffer_add_reward: null reward");
+  PH_HIP(ph::launch_reward_add(rb->rewards + (size_t)pos * rb->E, reward, env_mask, rb->E, ctx->stream));
+  return 0;
+}
+
+int ph_buffer_reset(ph_ctx* ctx, const ph_spec* spec, const ph_rollout* rb) {
+  if (!ctx) return fail("null ctx");
+  ph_layout lay;
+  if (layout_of(spec, &lay) || check_rb(rb)) return 1;
+  const size_t n = (size_t)rb->T * rb->E;
+  PH_HIP(hipMemsetAsync(rb->observations, 0, n * lay.D * sizeof(float), ctx->stream));
+  PH_HIP(hipMemsetAsync(rb->actions, 0, n * lay.A * sizeof(float), ctx->stream));
+  float* arrs[] = {rb->rewards, rb->episode_starts, rb->values, rb->log_probs, rb->advantages, rb->returns};
+  for (float* a : arrs) PH_HIP(hipMemsetAsync(a, 0, n * sizeof(float), ctx->stream));
+  return 0;
+}
+
+// ---- K2 ----
+int ph_gae(ph_ctx* ctx, const ph_rollout* rb, const float* last_values, const float* dones, double gamma,
+           double gae_lambda, int mode) {
+  if (!ctx) return fail("null ctx");
+  if (check_rb(rb)) return 1;
+  if (!last_values || !dones) return fail("ph_gae: null last_values/dones");
+  if (mode < 0 || mode > 2) return fail("ph_gae: mode must be 0, 1 or 2");
+  if (mode == 2 && rb->T > 2048) return fail("ph_gae: scan mode supports T <= 2048 (use mode 0/1)");
+  PH_HIP(ph::launch_gae(rb->rewards, rb->values, rb->episode_starts, last_values, dones, rb->advantages, rb->returns,
+                        rb->T, rb->E, gamma, gae_lambda, mode, ctx->stream));
+  return 0;
+}
+
+// ---- K4 ----
+int ph_policy_forward(ph_ctx* ctx, const ph_spec* spec, const float* params, const float* obs, int n,
+                      const unsigned char* action_mask, const float* uniforms, const float* given_actions,
+                      unsigned long long seed, unsigned long long counter, int deterministic, int* actions_i32,
+                      float* actions_f32, float* values, float* log_probs, float* entropy, float* logits,
+                      const ph_rollout* rb, int pos, const float* episode_start_in, int gemm_mode) {
+  if (!ctx) return fail("null ctx");
+  if (!params || !obs) return fail("ph_policy_forward: null params/obs");
+  if (n <= 0) return fail("ph_policy_forward: n must be positive");
+  ph::FwdArgs a;
+  std::memset(&a, 0, sizeof(a));
+  if (resolve(ctx, spec, &a.nd)) return 1;
+  a.params = params;
+  a.obs = obs;
+  a.n = n;
+  a.mask = action_mask;
+  a.uniforms = uniforms;
+  a.given_actions = given_actions;
+  a.seed = seed;
+  a.counter = counter;
+  a.deterministic = deterministic;
+  a.act_i32 = actions_i32;
+  a.act_f32 = actions_f32;
+  a.values = values;
+  a.logp = log_probs;
+  a.entropy = entropy;
+  a.logits = logits;
+  if (rb) {
+    if (check_rb(rb)) return 1;
+    if (n != rb->E) return fail("ph_policy_forward: fused add needs n == rollout E");
+    if (pos < 0 || pos >= rb->T) return fail("ph_policy_forward: pos out of range (buffer full?)");
+    if (!episode_start_in) return fail("ph_policy_forward: fused add needs episode_start_in");
+    const size_t row = (size_t)pos * rb->E;
+    a.rb_obs = rb->observations + row * a.nd.D;
+    a.rb_act = rb->actions + row * a.nd.A;
+    a.rb_rew = rb->rewards + row;
+    a.rb_es = rb->episode_starts + row;
+    a.rb_val = rb->values + row;
+    a.rb_logp = rb->log_probs + row;
+    a.es_in = episode_start_in;
+  }
+  PH_HIP(ph::launch_policy_fwd(a, gemm_mode, ctx->stream));
+  return 0;
+}
+
+int ph_fix_illegal_actions(ph_ctx* ctx, int* actions, const unsigned char* action_mask, int n, int L) {
+  if (!ctx) return fail("null ctx");
+  if (!actions || !action_mask) return fail("ph_fix_illegal_actions: null argument");
+  if (n <= 0 || L <= 0) return fail("ph_fix_illegal_actions: bad sizes");
+  PH_HIP(ph::launch_fix_illegal(actions, action_mask, n, L, ctx->stream));
+  return 0;
+}
+
+// ---- K3 + K5 + K6 ----
+namespace {
+
+struct MbPlan {
+  int nb, ntiles, nwg;
+};
+
+MbPlan plan_minibatch(const ph_ctx* ctx, int nb) {
+  MbPlan p;
+  p.nb = nb;
+  p.ntiles = (nb + 63) / 64;
+  // 2 nets x nwg workgroups, two resident per CU: nwg = #CUs covers the chip; more tiles -> tiles walked per workgroup
+  p.nwg = p.ntiles < ctx->num_cu ? p.ntiles : ctx->num_cu;
+  return p;
+}
+
+void fill_grad_args(ph::GradArgs& g, const ph::NetDims& nd, const float* params, const ph_rollout* rb,
+                    const ph_ppo_hyper* hp, ph_ctx* ctx) {
+  g.nd = nd;
+  g.params = params;
+  g.rb_obs = rb->observations;
+  g.rb_act = rb->actions;
+  g.rb_val = rb->values;
+  g.rb_logp = rb->log_probs;
+  g.rb_adv = rb->advantages;
+  g.rb_ret = rb->returns;
+  g.T = rb->T;
+  g.E = rb->E;
+  g.clip = hp->clip_range;
+  g.clip_vf = hp->clip_range_vf;
+  g.ent_coef = hp->ent_coef;
+  g.vf_coef = hp->vf_coef;
+  g.norm_adv = hp->normalize_advantage;
+  g.slabs = ctx->slabs;
+  g.statpart = ctx->statpart;
+  g.stop_flag = ctx->stop_flag;
+}
+
+int ensure_train_ws(ph_ctx* ctx, int P, int nwg_max, int n_mb_total) {
+  if (ctx->capturing) {
+    if ((size_t)nwg_max * P > ctx->slabs_cap || (size_t)n_mb_total * 2 > ctx->advstats_cap)
+      return fail("workspace would grow inside graph capture: run the same call once outside capture first");
+    return 0;
+  }
+  if (ensure(ctx->slabs, ctx->slabs_cap, (size_t)nwg_max * P)) return 1;
+  if (ensure(ctx->statpart, ctx->statpart_cap, (size_t)2 * nwg_max * ph::NSTATP)) return 1;
+  if (ensure(ctx->grad, ctx->grad_cap, (size_t)P)) return 1;
+  if (ensure(ctx->blocksq, ctx->blocksq_cap, (size_t)(P + 255) / 256)) return 1;
+  if (ensure(ctx->advstats, ctx->advstats_cap, (size_t)n_mb_total * 2)) return 1;
+  return 0;
+}
+
+}  // namespace
+
+int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const ph_rollout* rb,
+                 const ph_ppo_hyper* hp, int n_epochs, int batch_size, const int* perms,
+                 unsigned long long perm_seed, float* stats, int gemm_mode) {
+  if (!ctx) return fail("null ctx");
+  if (!opt || !opt->params || !opt->adam_m || !opt->adam_v || !opt->step) return fail("ph_ppo_train: null optimizer state");
+  if (!hp) return fail("ph_ppo_train: null hyper-parameters");
+  if (check_rb(rb)) return 1;
+  if (n_epochs <= 0 || batch_size <= 0) return fail("ph_ppo_train: n_epochs and batch_size must be positive");
+  ph::NetDims nd;
+  if (resolve(ctx, spec, &nd)) return 1;
+  const int N = rb->T * rb->E;
+  const int n_mb = (N + batch_size - 1) / batch_size;
+  const int P = nd.lay.P;
+  const MbPlan big = plan_minibatch(ctx, batch_size < N ? batch_size : N);
+  if (ensure_train_ws(ctx, P, big.nwg, n_epochs * n_mb)) return 1;
+  hipStream_t s = ctx->stream;
+
+  PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
+  const uint32_t hb = ph::feistel_half_bits((uint32_t)N);
+  {
+    ph::AdvStatArgs aa;
+    aa.rb_adv = rb->advantages;
+    aa.T = rb->T;
+    aa.E = rb->E;
+    aa.perms = perms;
+    aa.perm_n = (uint32_t)N;
+    aa.perm_hb = hb;
+    aa.perm_seed = perm_seed;
+    aa.N = N;
+    aa.batch = batch_size;
+    aa.n_mb = n_mb;
+    aa.out = ctx->advstats;
+    PH_HIP(ph::launch_adv_stats(aa, n_epochs * n_mb, s));
+  }
+  for (int ep = 0; ep < n_epochs; ++ep) {
+    for (int k = 0; k < n_mb; ++k) {
+      const int start = k * batch_size;
+      const int nb = (N - start < batch_size) ? N - start : batch_size;
+      const MbPlan pl = plan_minibatch(ctx, nb);
+      const int mbi = ep * n_mb + k;
+      ph::GradArgs g;
+      std::memset(&g, 0, sizeof(g));
+      fill_grad_args(g, nd, opt->params, rb, hp, ctx);
+      g.idx = perms ? perms + (size_t)ep * N + start : nullptr;
+      g.perm_n = (uint32_t)N;
+      g.perm_hb = hb;
+      g.perm_key = ph::epoch_key(perm_seed, ep);
+      g.mb_start = start;
+      g.nb = nb;
+      g.advstats = ctx->advstats + 2 * (size_t)mbi;
+      g.ntiles = pl.ntiles;
+      PH_HIP(ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s));
+
+      ph::ReduceArgs r;
+      r.slabs = ctx->slabs;
+      r.nslab = pl.nwg;
+      r.P = P;
+      r.grad = ctx->grad;
+      r.blocksq = ctx->blocksq;
+      r.statpart = ctx->statpart;
+      r.stats_out = stats ? stats + (size_t)mbi * PH_NSTAT : nullptr;
+      r.nb = nb;
+      r.ent_coef = hp->ent_coef;
+      r.vf_coef = hp->vf_coef;
+      r.target_kl = hp->target_kl;
+      r.stop_flag = ctx->stop_flag;
+      r.step = opt->step;
+      r.scalars = ctx->scalars;
+      PH_HIP(ph::launch_ppo_reduce(r, s));
+
+      ph::AdamArgs ad;
+      ad.params = opt->params;
+      ad.m = opt->adam_m;
+      ad.v = opt->adam_v;
+      ad.grad = ctx->grad;
+      ad.blocksq = ctx->blocksq;
+      ad.nblk = (P + 255) / 256;
+      ad.P = P;
+      ad.step = opt->step;
+      ad.scalars = ctx->scalars;
+      ad.stop_flag = ctx->stop_flag;
+      ad.lr = hp->learning_rate;
+      ad.beta1 = hp->adam_beta1;
+      ad.beta2 = hp->adam_beta2;
+      ad.eps = hp->adam_eps;
+      ad.max_norm = hp->max_grad_norm;
+      ad.stats_out = r.stats_out;
+      PH_HIP(ph::launch_ppo_adam(ad, s));
+    }
+  }
+  return 0;
+}
+
+int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, const ph_rollout* rb,
+                          const ph_ppo_hyper* hp, const int* indices, int nb, float* grad_out, float* stats_out,
+                          int gemm_mode) {
+  if (!ctx) return fail("null ctx");
+  if (!params || !hp || !indices || !grad_out) return fail("ph_ppo_minibatch_grad: null argument");
+  if (check_rb(rb)) return 1;
+  if (nb <= 0) return fail("ph_ppo_minibatch_grad: nb must be positive");
+  ph::NetDims nd;
+  if (resolve(ctx, spec, &nd)) return 1;
+  const int P = nd.lay.P;
+  const MbPlan pl = plan_minibatch(ctx, nb);
+  if (ensure_train_ws(ctx, P, pl.nwg, 1)) return 1;
+  hipStream_t s = ctx->stream;
+  PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
+  ph::AdvStatArgs aa;
+  aa.rb_adv = rb->advantages;
+  aa.T = rb->T;
+  aa.E = rb->E;
+  aa.perms = indices;  // one "epoch" whose first nb entries are the minibatch
+  aa.perm_n = 0;
+  aa.perm_hb = 1;
+  aa.perm_seed = 0;
+  aa.N = nb;
+  aa.batch = nb;
+  aa.n_mb = 1;
+  aa.out = ctx->advstats;
+  PH_HIP(ph::launch_adv_stats(aa, 1, s));
+  ph::GradArgs g;
+  std::memset(&g, 0, sizeof(g));
+  fill_grad_args(g, nd, params, rb, hp, ctx);
+  g.idx = indices;
+  g.nb = nb;
+  g.advstats = ctx->advstats;
+  g.ntiles = pl.ntiles;
+  PH_HIP(ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s));
+  ph::ReduceArgs r;
+  r.slabs = ctx->slabs;
+  r.nslab = pl.nwg;
+  r.P = P;
+  r.grad = grad_out;
+  r.blocksq = ctx->blocksq;
+  r.statpart = ctx->statpart;
+  r.stats_out = stats_out;
+  r.nb = nb;
+  r.ent_coef = hp->ent_coef;
+  r.vf_coef = hp->vf_coef;
+  r.target_kl = -1.f;
+  r.stop_flag = ctx->stop_flag;
+  r.step = nullptr;
+  r.scalars = ctx->scalars;
+  PH_HIP(ph::launch_ppo_reduce(r, s));
+  return 0;
+}
+
+int ph_feistel_indices(int n, unsigned long long perm_seed, int epoch, int start, int count, int* out) {
+  if (!out) return fail("ph_feistel_indices: null out");
+  if (n <= 0 || start < 0 || count < 0 || (long long)start + count > n) return fail("ph_feistel_indices: bad range");
+  const uint32_t hb = ph::feistel_half_bits((uint32_t)n);
+  const uint64_t key = ph::epoch_key(perm_seed, epoch);
+  for (int i = 0; i < count; ++i) out[i] = (int)ph::feistel_perm((uint32_t)(start + i), (uint32_t)n, hb, key);
+  return 0;
+}
+
+}  // extern "C"

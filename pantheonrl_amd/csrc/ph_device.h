@@ -1,0 +1,179 @@
+// Device-side building blocks shared by the gfx950 kernels (policy forward, PPO gradient, GAE).
+// CDNA4 only: 64-lane wavefronts, v_mfma_f32_32x32x2_f32, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pantheon_hip.h"
+
+namespace ph {
+
+constexpr int HID = PH_HIDDEN;   // hidden width of both MLPs
+constexpr int LDH = HID + 1;     // LDS leading dimension of every 64-wide matrix: odd => the strided
+                                 // (transposed-operand) ds_read_b32 pattern below is bank-conflict free
+constexpr int NSTATP = 8;        // per-workgroup partial-stat record (sums, not means)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Row (inside a 32x32 C/D tile) held by accumulator register r of a lane in half h = lane>>5.
+// (cdna_hip_programming.md section 3: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).)
+__device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// One 32x32 output tile  acc += A[m0:m0+32, k0:k0+klen] * B[k0:k0+klen, n0:n0+32]  with both operands in
+// LDS.  A(m,k) = TA ? A[k*lda+m] : A[m*lda+k];  B(k,n) = TB ? B[n*ldb+k] : B[k*ldb+n].
+// MFMA path: v_mfma_f32_32x32x2_f32, lane l supplies A(m0+(l&31), k+(l>>5)) and B(k+(l>>5), n0+(l&31)).
+// The hardware result is bit-for-bit the k-ordered fmaf chain (guide section 3), which is what the VALU
+// path below computes with plain v_fma_f32 in the same accumulator layout -- a drop-in cross-check.
+template <bool TA, bool TB, bool VALU>
+__device__ __forceinline__ f32x16 tile_mma(const float* A, int lda, const float* B, int ldb, int m0, int n0,
+                                           int k0, int klen, f32x16 acc) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 31, h = lane >> 5;
+  if constexpr (!VALU) {
+    const float* ap = TA ? (A + (k0 + h) * lda + m0 + i) : (A + (m0 + i) * lda + k0 + h);
+    const float* bp = TB ? (B + (n0 + i) * ldb + k0 + h) : (B + (k0 + h) * ldb + n0 + i);
+    const int astep = TA ? 2 * lda : 2;
+    const int bstep = TB ? 2 : 2 * ldb;
+#pragma unroll 8
+    for (int s = 0; s < klen; s += 2) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(*ap, *bp, acc, 0, 0, 0);
+      ap += astep;
+      bp += bstep;
+    }
+  } else {
+    const int col = n0 + i;
+    for (int k = k0; k < k0 + klen; ++k) {  // per output element: the same k-ordered fmaf chain as the MFMA
+      const float b = TB ? B[col * ldb + k] : B[k * ldb + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + drow(r, h);
+        const float a = TA ? A[k * lda + row] : A[row * lda + k];
+        acc[r] = __builtin_fmaf(a, b, acc[r]);
+      }
+    }
+  }
+  return acc;
+}
+
+// ---- counter-based RNG: Philox4x32-10 --------------------------------------------------------------------
+__device__ __host__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+// uniform in [0,1) with 24 random bits for (seed, counter, row, component)
+__device__ __host__ inline float philox_uniform(uint64_t seed, uint64_t counter, uint32_t row, uint32_t comp) {
+  uint32_t c[4] = {row, comp, (uint32_t)counter, (uint32_t)(counter >> 32)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+}
+
+// ---- keyed pseudo-random permutation of [0,n): 4-round balanced Feistel + cycle walking ----------------------
+// Replaces np.random.permutation(T*E) (SB3 RolloutBuffer.get) when the caller passes no explicit index array:
+// no index buffer in HBM, no sort.  hb = half-width in bits, 2^(2*hb) >= n.
+__device__ __host__ inline uint32_t feistel_round_fn(uint32_t r, uint64_t key, uint32_t round) {
+  uint32_t x = r * 0x9E3779B1u + (uint32_t)key + round * 0x85EBCA6Bu;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  x ^= (uint32_t)(key >> 32);
+  x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+  return x;
+}
+__device__ __host__ inline uint32_t feistel_perm(uint32_t i, uint32_t n, uint32_t hb, uint64_t key) {
+  const uint32_t mask = (1u << hb) - 1u;
+  uint32_t x = i;
+  do {
+    uint32_t l = x >> hb, r = x & mask;
+#pragma unroll
+    for (uint32_t round = 0; round < 4; ++round) {
+      const uint32_t t = l ^ (feistel_round_fn(r, key, round) & mask);
+      l = r;
+      r = t;
+    }
+    x = (l << hb) | r;
+  } while (x >= n);
+  return x;
+}
+__host__ inline uint32_t feistel_half_bits(uint32_t n) {
+  uint32_t hb = 1;
+  while ((1ull << (2 * hb)) < (uint64_t)n) ++hb;
+  return hb;
+}
+
+// ---- spec resolved for kernels ---------------------------------------------------------------------------------
+struct NetDims {
+  int obs_kind;     // PH_SPACE_*
+  int D, F, A, L;   // stored obs len, features, stored action len, logits
+  int Lp;           // logits padded to a multiple of 32 (MFMA N tile)
+  int nchunk;       // ceil(F / 64) feature chunks of the first layer
+  const int* obs_off;  // device: prefix sums of obs nvec (D+1) for the one-hot path, else nullptr
+  const int* act_off;  // device: prefix sums of act nvec (A+1)
+  ph_layout lay;
+};
+
+// Fill dst[R][LDH] with features [c*64, c*64+64) of the R rows whose physical row index is rowphys[r]
+// (-1 = padding row -> zeros).  Box: straight copy (coalesced along the row).  Discrete family: one-hot.
+// Caller must __syncthreads() before (dst free) and after (dst ready).
+template <int R>
+__device__ __forceinline__ void load_x_chunk(float* dst, const int* rowphys, const float* obs, const NetDims& nd,
+                                             int c) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int base = c * HID;
+  if (nd.obs_kind == PH_SPACE_BOX) {
+    for (int e = tid; e < R * HID; e += nt) {
+      const int r = e >> 6, kk = e & 63;
+      const int ph_row = rowphys[r];
+      const int f = base + kk;
+      float v = 0.f;
+      if (ph_row >= 0 && f < nd.F) v = obs[(size_t)ph_row * nd.D + f];
+      dst[r * LDH + kk] = v;
+    }
+  } else {
+    for (int e = tid; e < R * HID; e += nt) dst[(e >> 6) * LDH + (e & 63)] = 0.f;
+    __syncthreads();
+    for (int e = tid; e < R * nd.D; e += nt) {
+      const int r = e / nd.D, comp = e - r * nd.D;
+      const int ph_row = rowphys[r];
+      if (ph_row < 0) continue;
+      const int lo = nd.obs_off[comp], n = nd.obs_off[comp + 1] - lo;
+      int v = (int)obs[(size_t)ph_row * nd.D + comp];
+      v = v < 0 ? 0 : (v >= n ? n - 1 : v);
+      const int f = lo + v - base;
+      if (f >= 0 && f < HID) dst[r * LDH + f] = 1.f;
+    }
+  }
+}
+
+// rows [c*64, c*64+64) of an input-major weight matrix W[F][64] -> dst[64][LDH]; rows >= F are zero.
+__device__ __forceinline__ void load_w_rows(float* dst, const float* W, int row0, int nrows_total) {
+  for (int e = threadIdx.x; e < HID * HID; e += blockDim.x) {
+    const int kk = e >> 6, j = e & 63;
+    const int k = row0 + kk;
+    dst[kk * LDH + j] = (k < nrows_total) ? W[(size_t)k * HID + j] : 0.f;
+  }
+}
+
+// act_W[64][L] -> dst[64][ldo] (columns >= L zero)
+__device__ __forceinline__ void load_w_out(float* dst, const float* W, int L, int Lp, int ldo) {
+  for (int e = threadIdx.x; e < HID * Lp; e += blockDim.x) {
+    const int j = e / Lp, a = e - j * Lp;
+    dst[j * ldo + a] = (a < L) ? W[j * L + a] : 0.f;
+  }
+}
+
+// per-row categorical maths on one row of logits held in LDS (z, length L), MultiDiscrete aware.
+// Matches torch.distributions.Categorical(logits=z): log_prob = z[a] - logsumexp(z); entropy = -sum p*logp.
+struct RowDist {
+  float logp;
+  float entropy;
+};
+
+}  // namespace ph

@@ -1,0 +1,225 @@
+// K1 + K2: rollout-buffer row writes and the GAE(lambda) return/advantage pass.
+// Reference: RolloutBuffer.add / rewards[pos-1] += r / compute_returns_and_advantage, called from
+// pantheonrl/common/agents.py:127-130,172-179,198 (SB3 1.7.0 semantics: SURVEY.md A.1, A.2).
+//
+// All arrays are time-major (T,E) float32, so every access below is coalesced along the env axis.
+// HBM-bound: 20 algorithmic bytes per transition (read r, V, episode_start; write A, R).
+#include "ph_launch.h"
+
+namespace ph {
+
+// ---- serial in T, one lane per env: bit-faithful to the numpy loop ---------------------------------------------
+//   delta = r[t] + gamma*V[t+1]*nnt - V[t];  A = delta + (gamma*lambda)*nnt*A;  numpy evaluates left to right in f32
+//   with one rounding per operation, so contraction to FMA must stay off here.
+__global__ __launch_bounds__(64) void gae_serial_kernel(const float* __restrict__ rew, const float* __restrict__ val,
+                                                        const float* __restrict__ es, const float* __restrict__ last_values,
+                                                        const float* __restrict__ dones, float* __restrict__ adv,
+                                                        float* __restrict__ ret, int T, int E, float g, float gl) {
+#pragma clang fp contract(off)
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float nv = last_values[e];
+  float nnt = 1.0f - dones[e];
+  float last = 0.f;
+  int t = T - 1;
+  // 8 independent row loads in flight per lane before the dependent chain consumes them
+  for (; t >= 7; t -= 8) {
+    float r[8], v[8], s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t o = (size_t)(t - u) * E + e;
+      r[u] = rew[o];
+      v[u] = val[o];
+      s[u] = es[o];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t o = (size_t)(t - u) * E + e;
+      const float delta = (r[u] + (g * nv) * nnt) - v[u];
+      last = delta + ((gl * nnt) * last);
+      adv[o] = last;
+      ret[o] = last + v[u];
+      nv = v[u];
+      nnt = 1.0f - s[u];
+    }
+  }
+  for (; t >= 0; --t) {
+    const size_t o = (size_t)t * E + e;
+    const float r = rew[o], v = val[o], s = es[o];
+    const float delta = (r + (g * nv) * nnt) - v;
+    last = delta + ((gl * nnt) * last);
+    adv[o] = last;
+    ret[o] = last + v;
+    nv = v;
+    nnt = 1.0f - s;
+  }
+}
+
+// ---- chunked wavefront suffix scan over T --------------------------------------------------------------------------
+// A_t = delta_t + c_t * A_{t+1} is a first-order linear recurrence: the map A_{t+1} -> A_t composes associatively,
+// (S1,P1) o (S2,P2) = (S1 + P1*S2, P1*P2).  A workgroup owns EB consecutive envs (one 64/128-byte segment per row)
+// and all T steps, cut into NCH = ceil(T/LC) chunks; lane (chunk, env) runs its LC steps serially keeping the local
+// advantages and running coefficient products in registers, the NCH chunk composites are suffix-scanned through LDS
+// (Hillis-Steele, log2 NCH rounds), and each lane then fixes up its LC outputs.  One HBM read + one write per element.
+template <int LC, int EB>
+__global__ __launch_bounds__(1024) void gae_scan_kernel(const float* __restrict__ rew, const float* __restrict__ val,
+                                                        const float* __restrict__ es,
+                                                        const float* __restrict__ last_values,
+                                                        const float* __restrict__ dones, float* __restrict__ adv,
+                                                        float* __restrict__ ret, int T, int E, int NCH, float g,
+                                                        float gl) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sS = sm;             // [NCH][EB]
+  float* sP = sm + NCH * EB;  // [NCH][EB]
+  const int el = threadIdx.x % EB, ch = threadIdx.x / EB;
+  const int e = blockIdx.x * EB + el;
+  const bool live = (e < E) && (ch < NCH);
+  const int t0 = ch * LC;
+  float a[LC], cp[LC], vv[LC];
+  float S = 0.f, P = 1.f;
+  if (live) {
+    const int tend = (t0 + LC < T) ? t0 + LC : T;  // exclusive
+    float nv, nnt;
+    if (tend == T) {
+      nv = last_values[e];
+      nnt = 1.0f - dones[e];
+    } else {
+      nv = val[(size_t)tend * E + e];
+      nnt = 1.0f - es[(size_t)tend * E + e];
+    }
+    float r[LC], s[LC];
+#pragma unroll
+    for (int k = 0; k < LC; ++k) {
+      const int t = t0 + k;
+      const size_t o = (size_t)(t < T ? t : T - 1) * E + e;
+      r[k] = rew[o];
+      vv[k] = val[o];
+      s[k] = es[o];
+    }
+    float A = 0.f, Pacc = 1.f;
+#pragma unroll
+    for (int k = LC - 1; k >= 0; --k) {
+      if (t0 + k < T) {
+        const float delta = r[k] + g * nv * nnt - vv[k];
+        const float c = gl * nnt;
+        A = delta + c * A;
+        Pacc = c * Pacc;
+        nv = vv[k];
+        nnt = 1.0f - s[k];
+      }
+      a[k] = A;
+      cp[k] = Pacc;
+    }
+    S = A;
+    P = Pacc;
+  }
+  if (ch < NCH) {
+    sS[ch * EB + el] = S;
+    sP[ch * EB + el] = P;
+  }
+  // suffix scan: after the loop (S,P) of chunk ch is the composite of chunks [ch, NCH)
+  for (int d = 1; d < NCH; d <<= 1) {
+    __syncthreads();
+    float S2 = 0.f, P2 = 1.f;
+    const bool has = (ch + d < NCH);
+    if (has) {
+      S2 = sS[(ch + d) * EB + el];
+      P2 = sP[(ch + d) * EB + el];
+    }
+    __syncthreads();
+    if (has) {
+      S = S + P * S2;
+      P = P * P2;
+      sS[ch * EB + el] = S;
+      sP[ch * EB + el] = P;
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const float Ain = (ch + 1 < NCH) ? sS[(ch + 1) * EB + el] : 0.f;  // true advantage at the first step of the next chunk
+#pragma unroll
+  for (int k = 0; k < LC; ++k) {
+    const int t = t0 + k;
+    if (t < T) {
+      const size_t o = (size_t)t * E + e;
+      const float A = a[k] + cp[k] * Ain;
+      adv[o] = A;
+      ret[o] = A + vv[k];
+    }
+  }
+}
+
+template <int LC, int EB>
+static hipError_t launch_scan(const float* rew, const float* val, const float* es, const float* lv, const float* dn,
+                              float* adv, float* ret, int T, int E, float g, float gl, hipStream_t s) {
+  const int NCH = (T + LC - 1) / LC;
+  dim3 grid((E + EB - 1) / EB), block(NCH * EB);
+  const size_t lds = sizeof(float) * 2 * NCH * EB;
+  hipLaunchKernelGGL((gae_scan_kernel<LC, EB>), grid, block, lds, s, rew, val, es, lv, dn, adv, ret, T, E, NCH, g, gl);
+  return hipGetLastError();
+}
+
+// mode: 1 serial, 2 scan, 0 auto.  Returns hipErrorInvalidValue for an impossible request.
+hipError_t launch_gae(const float* rew, const float* val, const float* es, const float* lv, const float* dn, float* adv,
+                      float* ret, int T, int E, double gamma, double lam, int mode, hipStream_t s) {
+  const float g = (float)gamma;
+  const float gl = (float)(gamma * lam);  // Python multiplies the two floats in double first
+  if (mode == 0) {
+    // the serial form needs >= ~64 lanes per CU to cover HBM latency; below that the scan's T-parallelism wins
+    mode = (E >= 32768 || T > 2048) ? 1 : 2;
+  }
+  if (mode == 1) {
+    hipLaunchKernelGGL(gae_serial_kernel, dim3((E + 63) / 64), dim3(64), 0, s, rew, val, es, lv, dn, adv, ret, T, E, g,
+                       gl);
+    return hipGetLastError();
+  }
+  if (T > 2048) return hipErrorInvalidValue;
+  // lanes per workgroup = ceil(T/LC) * EB <= 1024
+  if (T <= 128) return launch_scan<8, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);     // <=16 chunks x 32 envs
+  if (T <= 512) return launch_scan<16, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);    // <=32 x 32
+  if (T <= 1024) return launch_scan<32, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);   // <=32 x 32
+  return launch_scan<32, 16>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);                   // <=64 x 16
+}
+
+// ---- K1: RolloutBuffer.add / reward += / reset -----------------------------------------------------------------------
+__global__ void buffer_add_kernel(float* __restrict__ d_obs, float* __restrict__ d_act, float* __restrict__ d_rew,
+                                  float* __restrict__ d_es, float* __restrict__ d_val, float* __restrict__ d_lp,
+                                  const float* __restrict__ obs, const float* __restrict__ act,
+                                  const float* __restrict__ es, const float* __restrict__ val,
+                                  const float* __restrict__ lp, int E, int D, int A) {
+  const int stride = gridDim.x * blockDim.x;
+  const int g0 = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = g0; i < E * D; i += stride) d_obs[i] = obs[i];
+  for (int i = g0; i < E * A; i += stride) d_act[i] = act[i];
+  for (int i = g0; i < E; i += stride) {
+    d_rew[i] = 0.f;
+    d_es[i] = es[i];
+    d_val[i] = val[i];
+    d_lp[i] = lp[i];
+  }
+}
+hipError_t launch_buffer_add(float* d_obs, float* d_act, float* d_rew, float* d_es, float* d_val, float* d_lp,
+                             const float* obs, const float* act, const float* es, const float* val, const float* lp,
+                             int E, int D, int A, hipStream_t s) {
+  const int n = E * D;
+  int blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(buffer_add_kernel, dim3(blocks), dim3(256), 0, s, d_obs, d_act, d_rew, d_es, d_val, d_lp, obs, act,
+                     es, val, lp, E, D, A);
+  return hipGetLastError();
+}
+
+__global__ void reward_add_kernel(float* __restrict__ rew_row, const float* __restrict__ reward,
+                                  const unsigned char* __restrict__ env_mask, int E) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  if (env_mask && !env_mask[e]) return;
+  rew_row[e] += reward[e];
+}
+hipError_t launch_reward_add(float* rew_row, const float* reward, const unsigned char* env_mask, int E, hipStream_t s) {
+  hipLaunchKernelGGL(reward_add_kernel, dim3((E + 255) / 256), dim3(256), 0, s, rew_row, reward, env_mask, E);
+  return hipGetLastError();
+}
+
+}  // namespace ph

@@ -1,0 +1,120 @@
+// Launch-argument records and launcher prototypes shared between the kernel translation units and ph_abi.hip.
+#pragma once
+#include "ph_device.h"
+
+namespace ph {
+
+struct FwdArgs {
+  NetDims nd;
+  const float* params;
+  const float* obs;  // (n, D)
+  int n;
+  const unsigned char* mask;   // (n, L) or null
+  const float* uniforms;       // (n, A) or null
+  const float* given_actions;  // (n, A) or null
+  uint64_t seed, counter;
+  int deterministic;
+  int* act_i32;
+  float* act_f32;
+  float* values;
+  float* logp;
+  float* entropy;
+  float* logits;
+  // fused RolloutBuffer.add (pointers already offset to row `pos`), all null when not fused
+  float* rb_obs;
+  float* rb_act;
+  float* rb_rew;
+  float* rb_es;
+  float* rb_val;
+  float* rb_logp;
+  const float* es_in;
+};
+
+struct GradArgs {
+  NetDims nd;
+  const float* params;
+  // rollout buffer (time-major)
+  const float* rb_obs;
+  const float* rb_act;
+  const float* rb_val;
+  const float* rb_logp;
+  const float* rb_adv;
+  const float* rb_ret;
+  int T, E;
+  // minibatch rows: explicit env-major indices, or a Feistel permutation of [0, perm_n) starting at mb_start
+  const int* idx;
+  uint32_t perm_n, perm_hb;
+  uint64_t perm_key;
+  int mb_start;
+  int nb;                  // rows in this minibatch
+  const float* advstats;   // {mean, std} of this minibatch's advantages
+  float clip, clip_vf, ent_coef, vf_coef;
+  int norm_adv;
+  float* slabs;            // [gridDim.x][P]
+  float* statpart;         // [2*gridDim.x][NSTATP]
+  const int* stop_flag;    // device flag set by the KL early stop
+  int ntiles;
+};
+
+struct AdvStatArgs {
+  const float* rb_adv;
+  int T, E;
+  const int* perms;  // (n_epochs, N) or null
+  uint32_t perm_n, perm_hb;
+  uint64_t perm_seed;
+  int N, batch, n_mb;  // minibatch k of epoch ep covers [k*batch, min(N,(k+1)*batch))
+  float* out;          // [n_epochs*n_mb][2]
+};
+
+__device__ __host__ inline uint64_t epoch_key(uint64_t seed, int epoch) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(epoch + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+struct ReduceArgs {
+  const float* slabs;
+  int nslab, P;
+  float* grad;
+  float* blocksq;        // [gridDim.x]
+  const float* statpart; // [2*nslab][NSTATP]
+  float* stats_out;      // [PH_NSTAT] for this minibatch, or null
+  int nb;
+  float ent_coef, vf_coef, target_kl;
+  int* stop_flag;
+  int* step;             // optimizer step counter (incremented here when the step will be applied), may be null
+  float* scalars;        // [4]: kl, applied, stop-requested
+};
+
+struct AdamArgs {
+  float* params;
+  float* m;
+  float* v;
+  const float* grad;
+  const float* blocksq;
+  int nblk, P;
+  const int* step;        // already incremented for this step
+  const float* scalars;   // [1] = applied, [2] = stop requested
+  int* stop_flag;
+  float lr, beta1, beta2, eps, max_norm;
+  float* stats_out;       // [PH_NSTAT] or null: writes grad_norm at [6]
+};
+
+size_t fwd_lds_bytes(int R, int Lp);
+size_t grad_lds_bytes(int R, int Lp);
+hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s);
+hipError_t launch_fix_illegal(int* actions, const unsigned char* mask, int n, int L, hipStream_t s);
+hipError_t launch_gae(const float* rew, const float* val, const float* es, const float* lv, const float* dn, float* adv,
+                      float* ret, int T, int E, double gamma, double lam, int mode, hipStream_t s);
+hipError_t launch_buffer_add(float* d_obs, float* d_act, float* d_rew, float* d_es, float* d_val, float* d_lp,
+                             const float* obs, const float* act, const float* es, const float* val, const float* lp,
+                             int E, int D, int A, hipStream_t s);
+hipError_t launch_reward_add(float* rew_row, const float* reward, const unsigned char* env_mask, int E, hipStream_t s);
+hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
+hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);
+hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s);
+hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s);
+hipError_t launch_set_int(int* p, int v, hipStream_t s);
+
+}  // namespace ph

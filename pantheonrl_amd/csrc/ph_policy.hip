@@ -1,0 +1,220 @@
+// K4: ActorCriticPolicy.forward / evaluate_actions for the SB3 MlpPolicy (two separate 64-64 tanh MLPs),
+// fused with categorical sampling / log-prob / entropy, the optional action-mask logit offset and the
+// RolloutBuffer.add row write.   Reference call sites: pantheonrl/common/util.py:63-81,
+// pantheonrl/common/agents.py:162,172-179; structure pantheonrl/algos/modular/policies.py:273-290,364-383.
+//
+// Grid: (row tiles of R rows, 2).  blockIdx.y = 0 -> policy net workgroup (logits, sampling, log-prob),
+// 1 -> value net workgroup (values + the observation copy into the rollout buffer).  Each workgroup keeps the
+// 64x64 weight blocks in LDS and runs every layer as 32x32 v_mfma_f32_32x32x2_f32 tiles, one tile per wave.
+#include "ph_launch.h"
+
+namespace ph {
+
+
+template <int R, bool VALU>
+__global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const NetDims& nd = a.nd;
+  const int Lp = nd.Lp, LDO = Lp + 1;
+  float* bufA = smem;                    // [R][LDH]  X chunk, later H2
+  float* bufB = bufA + R * LDH;          // [R][LDH]  H1
+  float* regW = bufB + R * LDH;          // [64][LDH] W1 chunk; later Wo[64][LDO] + OUT[R][LDO]
+  const int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
+  float* w2s = regW + regW_sz;           // [64][LDH]
+  float* b1s = w2s + HID * LDH;          // [64]
+  float* b2s = b1s + HID;                // [64]
+  float* bos = b2s + HID;                // [Lp] (policy) / val_W[64] (value)
+  int* rowphys = (int*)(bos + 64);       // [R]
+  float* wos = regW;                     // Wo [64][LDO]
+  float* outs = regW + HID * LDO;        // OUT [R][LDO]
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int mt = wave >> 1, nt = wave & 1;
+  const int net = blockIdx.y;
+  const int row0 = blockIdx.x * R;
+  const ph_layout& lay = nd.lay;
+  const float* W1 = a.params + (net == 0 ? lay.pi_W1 : lay.vf_W1);
+  const float* B1 = a.params + (net == 0 ? lay.pi_b1 : lay.vf_b1);
+  const float* W2 = a.params + (net == 0 ? lay.pi_W2 : lay.vf_W2);
+  const float* B2 = a.params + (net == 0 ? lay.pi_b2 : lay.vf_b2);
+
+  if (tid < R) rowphys[tid] = (row0 + tid < a.n) ? row0 + tid : -1;
+  if (tid < HID) {
+    b1s[tid] = B1[tid];
+    b2s[tid] = B2[tid];
+    if (net == 0) {
+      if (tid < Lp) bos[tid] = (tid < nd.L) ? a.params[lay.act_b + tid] : 0.f;
+    } else {
+      bos[tid] = a.params[lay.val_W + tid];
+    }
+  }
+  load_w_rows(w2s, W2, 0, HID);
+  __syncthreads();
+
+  // ---- layer 1: Z1 = X * W1 (feature chunks of 64 accumulated in the MFMA accumulator) ----
+  f32x16 acc = {0};
+  for (int c = 0; c < nd.nchunk; ++c) {
+    load_x_chunk<R>(bufA, rowphys, a.obs, nd, c);
+    load_w_rows(regW, W1, c * HID, nd.F);
+    __syncthreads();
+    acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
+    bufB[row * LDH + col] = tanhf(acc[r] + b1s[col]);
+  }
+  if (net == 0) load_w_out(wos, a.params + lay.act_W, nd.L, Lp, LDO);  // regW (W1 chunk) is dead now
+  __syncthreads();
+
+  // ---- layer 2 ----
+  f32x16 acc2 = {0};
+  acc2 = tile_mma<false, false, VALU>(bufB, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc2);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
+    bufA[row * LDH + col] = tanhf(acc2[r] + b2s[col]);
+  }
+  __syncthreads();
+
+  if (net == 1) {
+    // ---- value head: v = H2 . val_W + val_b (VALU dot, one lane per row) ----
+    if (tid < R && rowphys[tid] >= 0) {
+      float v = 0.f;
+      for (int j = 0; j < HID; ++j) v = __builtin_fmaf(bufA[tid * LDH + j], bos[j], v);
+      v += a.params[lay.val_b];
+      const int g = row0 + tid;
+      if (a.values) a.values[g] = v;
+      if (a.rb_val) {
+        a.rb_val[g] = v;
+        a.rb_rew[g] = 0.f;
+        a.rb_es[g] = a.es_in[g];
+      }
+    }
+    if (a.rb_obs) {  // RolloutBuffer.add copies the observation (agents.py:172-173)
+      const int nrow = (a.n - row0 < R) ? a.n - row0 : R;
+      const size_t off = (size_t)row0 * nd.D;
+      for (int e = tid; e < nrow * nd.D; e += blockDim.x) a.rb_obs[off + e] = a.obs[off + e];
+    }
+    return;
+  }
+
+  // ---- policy head: logits = H2 * act_W + act_b  (tiles: R/32 x Lp/32) ----
+  {
+    const int ntn = Lp >> 5;
+    if (wave < (R >> 5) * ntn) {
+      const int hm = wave / ntn, hn = wave - hm * ntn;
+      f32x16 acc3 = {0};
+      acc3 = tile_mma<false, false, VALU>(bufA, LDH, wos, LDO, hm * 32, hn * 32, 0, HID, acc3);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = hm * 32 + drow(r, lh), col = hn * 32 + li;
+        outs[row * LDO + col] = acc3[r] + bos[col];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- distribution: one lane per row ----
+  if (tid < R && rowphys[tid] >= 0) {
+    const int g = row0 + tid;
+    float* z = outs + tid * LDO;
+    if (a.mask) {  // modular/policies.py:330-333 : logits - 30*(~mask)
+      for (int k = 0; k < nd.L; ++k) z[k] = z[k] - 30.0f * (1.0f - (float)(a.mask[(size_t)g * nd.L + k] != 0));
+    }
+    if (a.logits)
+      for (int k = 0; k < nd.L; ++k) a.logits[(size_t)g * nd.L + k] = z[k];
+    float logp = 0.f, ent = 0.f;
+    for (int c = 0; c < nd.A; ++c) {
+      const int lo = nd.act_off[c], nk = nd.act_off[c + 1] - lo;
+      float m = z[lo];
+      for (int k = 1; k < nk; ++k) m = fmaxf(m, z[lo + k]);
+      float se = 0.f;
+      for (int k = 0; k < nk; ++k) se += expf(z[lo + k] - m);
+      const float lse = m + logf(se);
+      int act;
+      if (a.given_actions) {
+        act = (int)a.given_actions[(size_t)g * nd.A + c];
+        act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
+      } else if (a.deterministic) {
+        act = 0;
+        float best = z[lo];
+        for (int k = 1; k < nk; ++k)
+          if (z[lo + k] > best) { best = z[lo + k]; act = k; }
+      } else {
+        const float u = a.uniforms ? a.uniforms[(size_t)g * nd.A + c]
+                                   : philox_uniform(a.seed, a.counter, (uint32_t)g, (uint32_t)c);
+        float cum = 0.f;
+        act = 0;
+        for (int k = 0; k < nk - 1; ++k) {  // inverse CDF: count prefix sums <= u
+          cum += expf(z[lo + k] - lse);
+          act += (u >= cum) ? 1 : 0;
+        }
+      }
+      float e = 0.f;
+      for (int k = 0; k < nk; ++k) {
+        const float lp = z[lo + k] - lse;
+        e -= expf(lp) * lp;
+      }
+      logp += z[lo + act] - lse;
+      ent += e;
+      if (a.act_i32) a.act_i32[(size_t)g * nd.A + c] = act;
+      if (a.act_f32) a.act_f32[(size_t)g * nd.A + c] = (float)act;
+      if (a.rb_act) a.rb_act[(size_t)g * nd.A + c] = (float)act;
+    }
+    if (a.logp) a.logp[g] = logp;
+    if (a.entropy) a.entropy[g] = ent;
+    if (a.rb_logp) a.rb_logp[g] = logp;
+  }
+}
+
+template __global__ void policy_fwd_kernel<32, false>(FwdArgs);
+template __global__ void policy_fwd_kernel<32, true>(FwdArgs);
+template __global__ void policy_fwd_kernel<64, false>(FwdArgs);
+
+size_t fwd_lds_bytes(int R, int Lp) {
+  const int LDO = Lp + 1;
+  const int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
+  return sizeof(float) * (size_t)(2 * R * LDH + regW_sz + HID * LDH + 3 * 64 + R);
+}
+
+hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s) {
+  const int n = a.n;
+  // R = 32 rows per workgroup keeps >= 2*n/32 workgroups in flight for the small-E rollout step
+  const int R = (gemm_mode == 0 && n >= 16384) ? 64 : 32;
+  dim3 grid((n + R - 1) / R, 2), block(R * 4);
+  const size_t lds = fwd_lds_bytes(R, a.nd.Lp);
+  if (gemm_mode != 0) {
+    hipLaunchKernelGGL((policy_fwd_kernel<32, true>), grid, block, lds, s, a);
+  } else if (R == 64) {
+    hipError_t e = hipFuncSetAttribute((const void*)policy_fwd_kernel<64, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((policy_fwd_kernel<64, false>), grid, block, lds, s, a);
+  } else {
+    hipLaunchKernelGGL((policy_fwd_kernel<32, false>), grid, block, lds, s, a);
+  }
+  return hipGetLastError();
+}
+
+// ---- env-side illegal action fix-up (pettingzoo.py:81-82): integer, bit-exact ----
+__global__ void fix_illegal_kernel(int* actions, const unsigned char* mask, int n, int L) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const unsigned char* m = mask + (size_t)g * L;
+  int act = actions[g];
+  if (act < 0 || act >= L || !m[act]) {
+    int first = 0;
+    for (int k = L - 1; k >= 0; --k)
+      if (m[k]) first = k;
+    actions[g] = first;
+  }
+}
+hipError_t launch_fix_illegal(int* actions, const unsigned char* mask, int n, int L, hipStream_t s) {
+  hipLaunchKernelGGL(fix_illegal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, actions, mask, n, L);
+  return hipGetLastError();
+}
+
+}  // namespace ph

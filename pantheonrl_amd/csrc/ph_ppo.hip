@@ -1,0 +1,557 @@
+// K3 + K5 + K6: one PPO minibatch step = {advantage statistics, gather + forward + loss + backward, slab
+// reduction + global-norm, clip + Adam}.   Reference: SB3 PPO.train() called from
+// pantheonrl/common/agents.py:155; arithmetic restated from SURVEY.md A.3 and the in-tree copy
+// pantheonrl/algos/adap/adap_learn.py:253-344.
+//
+// ppo_grad_kernel: grid (nWG, 2).  blockIdx.y selects the policy net (0) or the value net (1): the two SB3
+// MLPs share nothing but the input, so each workgroup keeps ONE net's 64x64 blocks in LDS (~69 KB -> two
+// workgroups per CU).  A workgroup walks row tiles of R=64 minibatch rows (gathered straight from the time-major
+// rollout buffer through the env-major index n = e*T + t); every layer, its transpose-products for the weight
+// gradients and the activation back-propagation run as 32x32 v_mfma_f32_32x32x2_f32 tiles on LDS operands, one
+// tile per wave.  Weight-gradient tiles accumulate in the workgroup's private slab in HBM/L2 (the MFMA accumulator
+// is initialised from the slab, so the add is free); a second kernel sums the slabs in a fixed order
+// (deterministic), a third applies clip_grad_norm_ + Adam.
+#include "ph_launch.h"
+
+namespace ph {
+
+
+__device__ __forceinline__ int env_major_to_phys(int n, int T, int E) {
+  const int e = n / T;
+  return (n - e * T) * E + e;
+}
+
+__device__ __forceinline__ int minibatch_row(const GradArgs& a, int gi) {
+  const int n = a.idx ? a.idx[gi] : (int)feistel_perm((uint32_t)(a.mb_start + gi), a.perm_n, a.perm_hb, a.perm_key);
+  return env_major_to_phys(n, a.T, a.E);
+}
+
+template <int R, bool VALU>
+__global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
+  if (*a.stop_flag) return;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const NetDims& nd = a.nd;
+  const ph_layout& lay = nd.lay;
+  const int Lp = nd.Lp, LDO = Lp + 1;
+  float* bufA = smem;                  // [R][LDH]  X chunk -> H2 -> dZ2 -> X chunk
+  float* bufB = bufA + R * LDH;        // [R][LDH]  H1 -> dZ1
+  float* regW = bufB + R * LDH;        // W1 chunk [64][LDH]  |  Wo [64][LDO] + OUT [R][LDO]
+  const int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
+  float* w2s = regW + regW_sz;         // [64][LDH]
+  float* b1s = w2s + HID * LDH;        // [64]
+  float* b2s = b1s + HID;              // [64]
+  float* bos = b2s + HID;              // act_b [Lp]  (policy)  |  val_W [64] (value)
+  float* radv = bos + 64;              // [R] normalised advantage (policy) | returns (value)
+  float* rold = radv + R;              // [R] old log-prob (policy) | old values (value)
+  float* rdv = rold + R;               // [R] dL/dv (value net)
+  float* red = rdv + R;                // [NSTATP * 4] cross-wave stat reduction
+  int* rowphys = (int*)(red + NSTATP * 4);  // [R]
+  float* wos = regW;
+  float* outs = regW + HID * LDO;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int mt = wave >> 1, nt = wave & 1;  // this wave's 32x32 tile of every [R x 64] / [64 x 64] product
+  const int net = blockIdx.y;
+  const int oW1 = net == 0 ? lay.pi_W1 : lay.vf_W1, oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1;
+  const int oW2 = net == 0 ? lay.pi_W2 : lay.vf_W2, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
+  float* slab = a.slabs + (size_t)blockIdx.x * lay.P;
+  const float inv_nb = 1.0f / (float)a.nb;
+
+  if (tid < HID) {
+    b1s[tid] = a.params[oB1 + tid];
+    b2s[tid] = a.params[oB2 + tid];
+    if (net == 0) {
+      if (tid < Lp) bos[tid] = (tid < nd.L) ? a.params[lay.act_b + tid] : 0.f;
+    } else {
+      bos[tid] = a.params[lay.val_W + tid];
+    }
+  }
+  load_w_rows(w2s, a.params + oW2, 0, HID);
+
+  float st[NSTATP];
+#pragma unroll
+  for (int k = 0; k < NSTATP; ++k) st[k] = 0.f;
+
+  bool first = true;
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, first = false) {
+    __syncthreads();  // previous tile fully consumed (also orders the prologue loads on the first pass)
+    // ---- S0: row metadata ----
+    if (tid < R) {
+      const int gi = tile * R + tid;
+      int phys = -1;
+      float adv = 0.f, old = 0.f;
+      if (gi < a.nb) {
+        phys = minibatch_row(a, gi);
+        if (net == 0) {
+          adv = a.rb_adv[phys];
+          if (a.norm_adv && a.nb > 1) adv = (adv - a.advstats[0]) / (a.advstats[1] + 1e-8f);
+          old = a.rb_logp[phys];
+        } else {
+          adv = a.rb_ret[phys];
+          old = a.rb_val[phys];
+        }
+      }
+      rowphys[tid] = phys;
+      radv[tid] = adv;
+      rold[tid] = old;
+    }
+    __syncthreads();
+
+    // ---- S1: Z1 = X W1 over feature chunks; H1 = tanh(Z1 + b1) -> bufB ----
+    f32x16 acc = {0};
+    for (int c = 0; c < nd.nchunk; ++c) {
+      load_x_chunk<R>(bufA, rowphys, a.rb_obs, nd, c);
+      load_w_rows(regW, a.params + oW1, c * HID, nd.F);
+      __syncthreads();
+      acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
+      bufB[row * LDH + col] = tanhf(acc[r] + b1s[col]);
+    }
+    if (net == 0) load_w_out(wos, a.params + lay.act_W, nd.L, Lp, LDO);
+    __syncthreads();
+
+    // ---- S2: H2 = tanh(H1 W2 + b2) -> bufA ----
+    {
+      f32x16 acc2 = {0};
+      acc2 = tile_mma<false, false, VALU>(bufB, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
+        bufA[row * LDH + col] = tanhf(acc2[r] + b2s[col]);
+      }
+    }
+    __syncthreads();
+
+    if (net == 0) {
+      // ---- S3: logits = H2 Wo + bo -> OUT ----
+      const int ntn = Lp >> 5;
+      if (wave < (R >> 5) * ntn) {
+        const int hm = wave / ntn, hn = wave - hm * ntn;
+        f32x16 acc3 = {0};
+        acc3 = tile_mma<false, false, VALU>(bufA, LDH, wos, LDO, hm * 32, hn * 32, 0, HID, acc3);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = hm * 32 + drow(r, lh), col = hn * 32 + li;
+          outs[row * LDO + col] = acc3[r] + bos[col];
+        }
+      }
+      __syncthreads();
+
+      // ---- S4: clipped-surrogate + entropy loss per row, dL/dlogits written over OUT ----
+      if (tid < R) {
+        float* z = outs + tid * LDO;
+        const int phys = rowphys[tid];
+        if (phys < 0) {
+          for (int k = 0; k < Lp; ++k) z[k] = 0.f;
+        } else {
+          float logp = 0.f, ent = 0.f;
+          // pass 1: log-prob and entropy (MultiDiscrete: sums over components)
+          for (int c = 0; c < nd.A; ++c) {
+            const int lo = nd.act_off[c], nk = nd.act_off[c + 1] - lo;
+            float m = z[lo];
+            for (int k = 1; k < nk; ++k) m = fmaxf(m, z[lo + k]);
+            float se = 0.f;
+            for (int k = 0; k < nk; ++k) se += expf(z[lo + k] - m);
+            const float lse = m + logf(se);
+            int act = (int)a.rb_act[(size_t)phys * nd.A + c];
+            act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
+            float e = 0.f;
+            for (int k = 0; k < nk; ++k) {
+              const float lp = z[lo + k] - lse;
+              e -= expf(lp) * lp;
+            }
+            logp += z[lo + act] - lse;
+            ent += e;
+          }
+          const float adv = radv[tid];
+          const float lr = logp - rold[tid];
+          const float ratio = expf(lr);
+          const float lo_c = 1.0f - a.clip, hi_c = 1.0f + a.clip;
+          const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
+          const float pl1 = adv * ratio, pl2 = adv * rc;
+          // torch.min backward: the smaller branch gets the gradient, ties split 1/2 + 1/2; clamp passes the
+          // gradient iff lo <= ratio <= hi.
+          const float inr = (ratio >= lo_c && ratio <= hi_c) ? 1.f : 0.f;
+          const float gate = (pl1 < pl2) ? 1.f : ((pl1 > pl2) ? inr : 0.5f + 0.5f * inr);
+          const float g_lp = -inv_nb * adv * ratio * gate;   // dL/dlogp
+          const float g_en = -a.ent_coef * inv_nb;            // dL/dH
+          st[0] += -fminf(pl1, pl2);
+          st[2] += -ent;
+          st[3] += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
+          st[4] += (ratio - 1.0f) - lr;
+          // pass 2: dL/dz
+          for (int c = 0; c < nd.A; ++c) {
+            const int lo = nd.act_off[c], nk = nd.act_off[c + 1] - lo;
+            float m = z[lo];
+            for (int k = 1; k < nk; ++k) m = fmaxf(m, z[lo + k]);
+            float se = 0.f;
+            for (int k = 0; k < nk; ++k) se += expf(z[lo + k] - m);
+            const float lse = m + logf(se);
+            int act = (int)a.rb_act[(size_t)phys * nd.A + c];
+            act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
+            float hc = 0.f;
+            for (int k = 0; k < nk; ++k) {
+              const float lp = z[lo + k] - lse;
+              hc -= expf(lp) * lp;
+            }
+            for (int k = 0; k < nk; ++k) {
+              const float lp = z[lo + k] - lse;
+              const float p = expf(lp);
+              const float dlogp = ((k == act) ? 1.f : 0.f) - p;
+              const float dent = -p * (lp + hc);
+              z[lo + k] = g_lp * dlogp + g_en * dent;
+            }
+          }
+          for (int k = nd.L; k < Lp; ++k) z[k] = 0.f;
+        }
+      }
+      __syncthreads();
+
+      // ---- S5a: dWo = H2^T dOut (tiles 2 x Lp/32), d bo = column sums of dOut ----
+      if (wave < 2 * ntn) {
+        const int hm = wave / ntn, hn = wave - hm * ntn;
+        f32x16 g = {0};
+        if (!first) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = hm * 32 + drow(r, lh), col = hn * 32 + li;
+            if (col < nd.L) g[r] = slab[lay.act_W + j * nd.L + col];
+          }
+        }
+        g = tile_mma<true, false, VALU>(bufA, LDH, outs, LDO, hm * 32, hn * 32, 0, R, g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = hm * 32 + drow(r, lh), col = hn * 32 + li;
+          if (col < nd.L) slab[lay.act_W + j * nd.L + col] = g[r];
+        }
+      }
+      if (tid >= R * 4 - 64 && tid - (R * 4 - 64) < nd.L) {  // last wave: bias gradient
+        const int k = tid - (R * 4 - 64);
+        float s = first ? 0.f : slab[lay.act_b + k];
+        for (int r = 0; r < R; ++r) s += outs[r * LDO + k];
+        slab[lay.act_b + k] = s;
+      }
+      __syncthreads();
+
+      // ---- S5b: dH2 = dOut Wo^T ; dZ2 = dH2 * (1 - H2^2) in place over H2 ----
+      {
+        f32x16 d = {0};
+        d = tile_mma<false, true, VALU>(outs, LDO, wos, LDO, mt * 32, nt * 32, 0, Lp, d);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
+          const float h = bufA[row * LDH + col];
+          bufA[row * LDH + col] = d[r] * (1.0f - h * h);
+        }
+      }
+      __syncthreads();
+    } else {
+      // ---- value net S3/S4: v = H2 . val_W + val_b ; value loss ; dv ----
+      if (tid < R) {
+        const int phys = rowphys[tid];
+        float dv = 0.f;
+        if (phys >= 0) {
+          float v = 0.f;
+          for (int j = 0; j < HID; ++j) v = __builtin_fmaf(bufA[tid * LDH + j], bos[j], v);
+          v += a.params[lay.val_b];
+          const float retn = radv[tid], oldv = rold[tid];
+          float vp = v, pass = 1.f;
+          if (a.clip_vf >= 0.f) {
+            const float dlt = v - oldv;
+            pass = (dlt >= -a.clip_vf && dlt <= a.clip_vf) ? 1.f : 0.f;
+            vp = oldv + fminf(fmaxf(dlt, -a.clip_vf), a.clip_vf);
+          }
+          const float err = vp - retn;
+          st[1] += err * err;
+          dv = a.vf_coef * 2.0f * err * inv_nb * pass;
+        }
+        rdv[tid] = dv;
+      }
+      __syncthreads();
+      // ---- S5a: d val_W[j] = sum_r H2[r][j] dv[r] ; d val_b = sum_r dv[r] ----
+      if (tid < HID) {
+        float s = first ? 0.f : slab[lay.val_W + tid];
+        for (int r = 0; r < R; ++r) s = __builtin_fmaf(bufA[r * LDH + tid], rdv[r], s);
+        slab[lay.val_W + tid] = s;
+      } else if (tid == HID) {
+        float s = first ? 0.f : slab[lay.val_b];
+        for (int r = 0; r < R; ++r) s += rdv[r];
+        slab[lay.val_b] = s;
+      }
+      __syncthreads();
+      // ---- S5b: dZ2[r][j] = dv[r] * val_W[j] * (1 - H2^2) in place ----
+      for (int e = tid; e < R * HID; e += blockDim.x) {
+        const int r = e >> 6, j = e & 63;
+        const float h = bufA[r * LDH + j];
+        bufA[r * LDH + j] = rdv[r] * bos[j] * (1.0f - h * h);
+      }
+      __syncthreads();
+    }
+
+    // ---- S6a: dW2 = H1^T dZ2 ; d b2 ; dH1 = dZ2 W2^T (kept in registers) ----
+    f32x16 dh1 = {0};
+    {
+      f32x16 g = {0};
+      if (!first) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = slab[oW2 + (mt * 32 + drow(r, lh)) * HID + nt * 32 + li];
+      }
+      g = tile_mma<true, false, VALU>(bufB, LDH, bufA, LDH, mt * 32, nt * 32, 0, R, g);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[oW2 + (mt * 32 + drow(r, lh)) * HID + nt * 32 + li] = g[r];
+      if (tid < HID) {
+        float s = first ? 0.f : slab[oB2 + tid];
+        for (int r = 0; r < R; ++r) s += bufA[r * LDH + tid];
+        slab[oB2 + tid] = s;
+      }
+      dh1 = tile_mma<false, true, VALU>(bufA, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1);
+    }
+    __syncthreads();
+    // ---- S6b: dZ1 = dH1 * (1 - H1^2) in place over H1 ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
+      const float h = bufB[row * LDH + col];
+      bufB[row * LDH + col] = dh1[r] * (1.0f - h * h);
+    }
+    __syncthreads();
+    // ---- S7: dW1 = X^T dZ1 per feature chunk ; d b1 ----
+    if (tid < HID) {
+      float s = first ? 0.f : slab[oB1 + tid];
+      for (int r = 0; r < R; ++r) s += bufB[r * LDH + tid];
+      slab[oB1 + tid] = s;
+    }
+    for (int c = 0; c < nd.nchunk; ++c) {
+      load_x_chunk<R>(bufA, rowphys, a.rb_obs, nd, c);
+      __syncthreads();
+      f32x16 g = {0};
+      if (!first) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = c * HID + mt * 32 + drow(r, lh);
+          if (k < nd.F) g[r] = slab[oW1 + (size_t)k * HID + nt * 32 + li];
+        }
+      }
+      g = tile_mma<true, false, VALU>(bufA, LDH, bufB, LDH, mt * 32, nt * 32, 0, R, g);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = c * HID + mt * 32 + drow(r, lh);
+        if (k < nd.F) slab[oW1 + (size_t)k * HID + nt * 32 + li] = g[r];
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- per-workgroup partial statistics (fixed reduction tree -> deterministic) ----
+#pragma unroll
+  for (int k = 0; k < NSTATP; ++k) {
+    float v = st[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    st[k] = v;
+  }
+  __syncthreads();
+  if (lane == 0 && wave < 4) {
+#pragma unroll
+    for (int k = 0; k < NSTATP; ++k) red[wave * NSTATP + k] = st[k];
+  }
+  __syncthreads();
+  if (tid < NSTATP) {
+    float v = 0.f;
+    for (int w = 0; w < (R * 4) / 64 && w < 4; ++w) v += red[w * NSTATP + tid];
+    a.statpart[((size_t)net * gridDim.x + blockIdx.x) * NSTATP + tid] = v;
+  }
+}
+
+template __global__ void ppo_grad_kernel<64, false>(GradArgs);
+template __global__ void ppo_grad_kernel<64, true>(GradArgs);
+
+size_t grad_lds_bytes(int R, int Lp) {
+  const int LDO = Lp + 1;
+  const int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
+  return sizeof(float) * (size_t)(2 * R * LDH + regW_sz + HID * LDH + 3 * 64 + 3 * R + NSTATP * 4 + R);
+}
+
+hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s) {
+  constexpr int R = 64;
+  const size_t lds = grad_lds_bytes(R, a.nd.Lp);
+  dim3 grid(nwg, 2), block(R * 4);
+  hipError_t e;
+  if (gemm_mode != 0) {
+    e = hipFuncSetAttribute((const void*)ppo_grad_kernel<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ppo_grad_kernel<R, true>), grid, block, lds, s, a);
+  } else {
+    e = hipFuncSetAttribute((const void*)ppo_grad_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ppo_grad_kernel<R, false>), grid, block, lds, s, a);
+  }
+  return hipGetLastError();
+}
+
+// ---- advantage statistics of every minibatch of a train() call: mean and unbiased std (torch .mean()/.std()) ----
+__global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
+  __shared__ double sh[1024 / 64];
+  __shared__ double bcast;
+  const int mb = blockIdx.x;
+  const int ep = mb / a.n_mb, k = mb - ep * a.n_mb;
+  const int start = k * a.batch;
+  const int nb = (a.N - start < a.batch) ? a.N - start : a.batch;
+  const uint64_t key = epoch_key(a.perm_seed, ep);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto value = [&](int i) -> double {
+    const int n = a.perms ? a.perms[(size_t)ep * a.N + start + i]
+                          : (int)feistel_perm((uint32_t)(start + i), a.perm_n, a.perm_hb, key);
+    return (double)a.rb_adv[env_major_to_phys(n, a.T, a.E)];
+  };
+  auto block_sum = [&](double v) -> double {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+      bcast = t;
+    }
+    __syncthreads();
+    return bcast;
+  };
+  double s = 0.0;
+  for (int i = tid; i < nb; i += blockDim.x) s += value(i);
+  const double mean = block_sum(s) / (double)nb;
+  double q = 0.0;
+  for (int i = tid; i < nb; i += blockDim.x) {
+    const double d = value(i) - mean;
+    q += d * d;
+  }
+  const double ss = block_sum(q);
+  if (tid == 0) {
+    a.out[2 * mb + 0] = (float)mean;
+    a.out[2 * mb + 1] = (nb > 1) ? (float)sqrt(ss / (double)(nb - 1)) : 0.f;
+  }
+}
+hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s) {
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(n_total), dim3(1024), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---- slab reduction: grad[p] = sum_g slab[g][p] (fixed order), per-block sum of squares, minibatch statistics ----
+__global__ __launch_bounds__(256) void ppo_reduce_kernel(ReduceArgs a) {
+  __shared__ float sh[4];
+  __shared__ float means[NSTATP];
+  const int tid = threadIdx.x;
+  if (*a.stop_flag != 0) {  // a previous minibatch of this train() call hit the KL early stop
+    if (blockIdx.x == 0 && tid < PH_NSTAT && a.stats_out) a.stats_out[tid] = 0.f;
+    if (blockIdx.x == 0 && tid == 0) {
+      a.scalars[1] = 0.f;
+      a.scalars[2] = 0.f;
+    }
+    return;
+  }
+  const int p = blockIdx.x * blockDim.x + tid;
+  float g = 0.f;
+  if (p < a.P) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < a.nslab; k += 4) {
+      s0 += a.slabs[(size_t)(k + 0) * a.P + p];
+      s1 += a.slabs[(size_t)(k + 1) * a.P + p];
+      s2 += a.slabs[(size_t)(k + 2) * a.P + p];
+      s3 += a.slabs[(size_t)(k + 3) * a.P + p];
+    }
+    for (; k < a.nslab; ++k) s0 += a.slabs[(size_t)k * a.P + p];
+    g = (s0 + s1) + (s2 + s3);
+    a.grad[p] = g;
+  }
+  float q = g * g;
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+  if ((tid & 63) == 0) sh[tid >> 6] = q;
+  __syncthreads();
+  if (tid == 0) a.blocksq[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+
+  if (blockIdx.x == 0) {  // minibatch statistics: means over the nb rows (block-uniform branch)
+    if (tid < NSTATP) {
+      float v = 0.f;
+      for (int w = 0; w < 2 * a.nslab; ++w) v += a.statpart[(size_t)w * NSTATP + tid];
+      means[tid] = v / (float)a.nb;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const float pl = means[0], vl = means[1], el = means[2], cf = means[3], kl = means[4];
+      const bool stop = (a.target_kl >= 0.f) && (kl > 1.5f * a.target_kl);
+      if (!stop && a.step) *a.step += 1;
+      a.scalars[0] = kl;
+      a.scalars[1] = stop ? 0.f : 1.f;
+      a.scalars[2] = stop ? 1.f : 0.f;  // ppo_adam_kernel raises stop_flag (next launch), never mid-kernel
+      if (a.stats_out) {
+        a.stats_out[0] = pl;
+        a.stats_out[1] = vl;
+        a.stats_out[2] = el;
+        a.stats_out[3] = cf;
+        a.stats_out[4] = kl;
+        a.stats_out[5] = pl + a.ent_coef * el + a.vf_coef * vl;
+        a.stats_out[6] = 0.f;
+        a.stats_out[7] = stop ? 0.f : 1.f;
+      }
+    }
+  }
+}
+hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(ppo_reduce_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---- clip_grad_norm_ + Adam (torch.optim.Adam single-tensor maths, eps = 1e-5) ----------------------------------------
+__global__ __launch_bounds__(256) void ppo_adam_kernel(AdamArgs a) {
+  __shared__ float sh[4];
+  __shared__ float coef_s, ss_s, bc2s_s;
+  const int tid = threadIdx.x;
+  if (a.scalars[1] == 0.f) {  // KL early stop (or already stopped): no optimizer step
+    if (blockIdx.x == 0 && tid == 0 && a.scalars[2] != 0.f) *a.stop_flag = 1;
+    return;
+  }
+  float q = 0.f;
+  for (int k = tid; k < a.nblk; k += blockDim.x) q += a.blocksq[k];
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+  if ((tid & 63) == 0) sh[tid >> 6] = q;
+  __syncthreads();
+  if (tid == 0) {
+    const float total = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3]));
+    const float cc = a.max_norm / (total + 1e-6f);  // torch.nn.utils.clip_grad_norm_
+    coef_s = cc < 1.0f ? cc : 1.0f;
+    const double t = (double)*a.step;
+    const double bc1 = 1.0 - pow((double)a.beta1, t);
+    const double bc2 = 1.0 - pow((double)a.beta2, t);
+    ss_s = (float)((double)a.lr / bc1);
+    bc2s_s = (float)sqrt(bc2);
+    if (blockIdx.x == 0 && a.stats_out) a.stats_out[6] = total;
+  }
+  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + tid;
+  if (p >= a.P) return;
+  const float g = a.grad[p] * coef_s;
+  const float m = a.m[p] + (g - a.m[p]) * (1.0f - a.beta1);          // exp_avg.lerp_(grad, 1-beta1)
+  const float v = a.v[p] * a.beta2 + (1.0f - a.beta2) * g * g;       // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+  const float denom = sqrtf(v) / bc2s_s + a.eps;
+  a.m[p] = m;
+  a.v[p] = v;
+  a.params[p] = a.params[p] - ss_s * (m / denom);                    // param.addcdiv_(exp_avg, denom, -step_size)
+}
+hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(ppo_adam_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+hipError_t launch_set_int(int* p, int v, hipStream_t s) {
+  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, p, v);
+  return hipGetLastError();
+}
+
+}  // namespace ph

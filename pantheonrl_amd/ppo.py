@@ -1,0 +1,563 @@
+"""The model surface PantheonRL's OnPolicyAgent / trainer.py expect from `stable_baselines3.PPO`, backed by the
+gfx950 engine (libpantheon_hip.so).
+
+Reference call sites this module answers (paths relative to the reference root):
+  * PPO(policy='MlpPolicy', env=, device=, seed=, verbose=, tensorboard_log=, **cfg)   trainer.py:108-126,196-203
+  * model.rollout_buffer.{add, reset, compute_returns_and_advantage, rewards, pos}      pantheonrl/common/agents.py:123-130,157,172-179,196-198
+  * model.policy.forward(obs_tensor) / .observation_space / .action_space / .device     pantheonrl/common/util.py:75-79, agents.py:170-171
+  * model.train(), model.n_steps, model.logger, model.set_logger, model.ep_info_buffer  agents.py:102-109,126,134-155
+  * model.learn(total_timesteps=, tb_log_name=), model.save(path), PPO.load(path)        trainer.py:140-149,410-432
+Semantics follow SB3 1.7.0 as restated in SURVEY.md Appendix A.
+
+torch is used for device memory, streams and host<->device copies only; all arithmetic of the hot path (buffer
+writes, GAE, forward, PPO update) runs in the hand-written HIP kernels.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import io
+import json
+import time
+import zipfile
+from collections import deque
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+import torch as th
+
+from . import _native as nat
+from . import spaces as sp
+from .logger import Logger, configure_logger
+
+HID = nat.PH_HIDDEN
+
+
+def _require_cuda(device) -> th.device:
+    dev = th.device("cuda" if device in (None, "auto") else device)
+    if dev.type != "cuda":
+        raise nat.NativeError(
+            f"device={device!r}: the PantheonRL MI355X engine runs on a gfx950 GPU only (no CPU fallback)")
+    if not th.cuda.is_available():
+        raise nat.NativeError("no HIP device visible to torch: the PantheonRL MI355X engine has no CPU fallback")
+    if dev.index is None:
+        dev = th.device("cuda", th.cuda.current_device())
+    return dev
+
+
+def _f32_dev(x, dev: th.device, shape: Tuple[int, ...]) -> th.Tensor:
+    """numpy / list / scalar / tensor -> contiguous float32 device tensor of `shape` (host data are copied)."""
+    if isinstance(x, th.Tensor):
+        t = x.detach()
+    else:
+        t = th.as_tensor(np.asarray(x))
+    return t.to(device=dev, dtype=th.float32).reshape(shape).contiguous()
+
+
+class RolloutBuffer:
+    """Device-resident SB3 RolloutBuffer.  Arrays are torch views of HBM, time-major (T, E, ...)."""
+
+    def __init__(self, buffer_size: int, observation_space, action_space, device, ctx: nat.Context,
+                 spec: nat.PhSpec, gae_lambda: float = 0.95, gamma: float = 0.99, n_envs: int = 1):
+        self.buffer_size, self.n_envs = int(buffer_size), int(n_envs)
+        self.observation_space, self.action_space = observation_space, action_space
+        self.obs_shape = sp.obs_stored_shape(observation_space)
+        self.action_dim = sp.action_dim(action_space)
+        self.device, self.ctx, self.spec = device, ctx, spec
+        self.gamma, self.gae_lambda = float(gamma), float(gae_lambda)
+        self.gae_mode = 0
+        T, E, D, A = self.buffer_size, self.n_envs, int(np.prod(self.obs_shape)), self.action_dim
+        z = lambda *s: th.zeros(*s, dtype=th.float32, device=device)  # noqa: E731
+        self.observations = z(T, E, D)
+        self.actions = z(T, E, A)
+        self.rewards, self.returns, self.episode_starts = z(T, E), z(T, E), z(T, E)
+        self.values, self.log_probs, self.advantages = z(T, E), z(T, E), z(T, E)
+        self._c = nat.PhRollout()
+        self._c.T, self._c.E = T, E
+        for name in ("observations", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages",
+                     "returns"):
+            setattr(self._c, name, getattr(self, name).data_ptr())
+        self.pos, self.full = 0, False
+
+    # -- SB3 surface --------------------------------------------------------------------------------------
+    def reset(self) -> None:
+        self._bind()
+        nat.check(self.ctx.lib.ph_buffer_reset(self.ctx.handle, C.byref(self.spec), C.byref(self._c)))
+        self.pos, self.full = 0, False
+
+    def add(self, obs, action, reward, episode_start, value, log_prob) -> None:
+        """RolloutBuffer.add <- agents.py:172-179.  Inputs (numpy or tensors, host or device) are copied."""
+        if self.pos >= self.buffer_size:
+            raise nat.NativeError("RolloutBuffer.add on a full buffer")
+        E, D, A, dev = self.n_envs, int(np.prod(self.obs_shape)), self.action_dim, self.device
+        o, a = _f32_dev(obs, dev, (E, D)), _f32_dev(action, dev, (E, A))
+        s, v, lp = _f32_dev(episode_start, dev, (E,)), _f32_dev(value, dev, (E,)), _f32_dev(log_prob, dev, (E,))
+        self._bind()
+        nat.check(self.ctx.lib.ph_buffer_add(self.ctx.handle, C.byref(self.spec), C.byref(self._c), self.pos,
+                                             o.data_ptr(), a.data_ptr(), s.data_ptr(), v.data_ptr(), lp.data_ptr()))
+        self.pos += 1
+        r = np.asarray(reward.detach().cpu() if isinstance(reward, th.Tensor) else reward, dtype=np.float32)
+        if np.any(r != 0):  # the row is written with reward 0 (agents.py:175); a non-zero reward is the ego path
+            self.add_reward(r)
+        self.full = self.pos == self.buffer_size
+
+    def add_reward(self, reward, env_mask=None, pos: Optional[int] = None) -> None:
+        """buf.rewards[pos-1][e] += reward[e] <- Agent.update, agents.py:198 (vectorised over envs)."""
+        row = self.pos - 1 if pos is None else pos
+        r = _f32_dev(np.broadcast_to(np.asarray(reward, np.float32), (self.n_envs,))
+                     if not isinstance(reward, th.Tensor) else reward, self.device, (self.n_envs,))
+        m = None
+        if env_mask is not None:
+            m = th.as_tensor(env_mask).to(device=self.device, dtype=th.uint8).contiguous()
+        self._bind()
+        nat.check(self.ctx.lib.ph_buffer_add_reward(self.ctx.handle, C.byref(self._c), row, r.data_ptr(), nat.ptr(m)))
+
+    def compute_returns_and_advantage(self, last_values, dones) -> None:
+        """GAE <- agents.py:127-130."""
+        E, dev = self.n_envs, self.device
+        lv = _f32_dev(last_values, dev, (E,))
+        dn = _f32_dev(np.broadcast_to(np.asarray(dones, np.float32), (E,)) if not isinstance(dones, th.Tensor)
+                      else dones, dev, (E,))
+        self._bind()
+        nat.check(self.ctx.lib.ph_gae(self.ctx.handle, C.byref(self._c), lv.data_ptr(), dn.data_ptr(), self.gamma,
+                                      self.gae_lambda, int(self.gae_mode)))
+
+    # -- helpers ---------------------------------------------------------------------------------------------
+    def _bind(self) -> None:
+        self.ctx.set_stream(th.cuda.current_stream(self.device).cuda_stream)
+
+    def c_struct(self) -> nat.PhRollout:
+        return self._c
+
+    def host(self) -> Dict[str, np.ndarray]:
+        """copy of every array on the host (tests, save/export)."""
+        return {k: getattr(self, k).detach().cpu().numpy() for k in (
+            "observations", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns")}
+
+
+# SB3 state_dict names of the MlpPolicy tensors, in the order of the flat parameter vector
+_SD = (("mlp_extractor.policy_net.0", "pi_W1", "pi_b1"), ("mlp_extractor.policy_net.2", "pi_W2", "pi_b2"),
+       ("mlp_extractor.value_net.0", "vf_W1", "vf_b1"), ("mlp_extractor.value_net.2", "vf_W2", "vf_b2"),
+       ("action_net", "act_W", "act_b"), ("value_net", "val_W", "val_b"))
+
+
+class ActorCriticPolicy:
+    """SB3 MlpPolicy (FlattenExtractor + MlpExtractor pi=[64,64], vf=[64,64], tanh) with parameters resident in HBM
+    as one flat input-major vector (layout in include/pantheon_hip.h)."""
+
+    def __init__(self, observation_space, action_space, lr: float = 3e-4, device="cuda",
+                 ortho_init: bool = True, seed: Optional[int] = None):
+        self.device = _require_cuda(device)
+        self.observation_space, self.action_space = observation_space, action_space
+        self.spec = sp.make_spec(observation_space, action_space)
+        self.layout = nat.layout_of(self.spec)
+        self.ctx = nat.Context(self.device.index)
+        self.gemm_mode = 0
+        lay = self.layout
+        self.params = th.zeros(lay.P, dtype=th.float32, device=self.device)
+        self.adam_m = th.zeros_like(self.params)
+        self.adam_v = th.zeros_like(self.params)
+        self.opt_step = th.zeros(1, dtype=th.int32, device=self.device)
+        self.lr = float(lr)
+        self._seed = int(seed) if seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
+        self._counter = 0
+        self._init_weights(ortho_init)
+
+    # -- parameters -------------------------------------------------------------------------------------------
+    def _shapes(self):
+        lay = self.layout
+        return {"pi_W1": (lay.F, HID), "pi_W2": (HID, HID), "vf_W1": (lay.F, HID), "vf_W2": (HID, HID),
+                "act_W": (HID, lay.L), "val_W": (HID, 1)}
+
+    def _init_weights(self, ortho_init: bool) -> None:
+        """orthogonal init with SB3's gains (modular/policies.py:229-241); host-side, once."""
+        gains = {"pi_W1": np.sqrt(2), "pi_W2": np.sqrt(2), "vf_W1": np.sqrt(2), "vf_W2": np.sqrt(2), "act_W": 0.01,
+                 "val_W": 1.0}
+        flat = th.zeros(self.layout.P, dtype=th.float32)
+        for name, (fin, fout) in self._shapes().items():
+            w = th.empty(fout, fin)  # torch Linear layout [out][in]
+            if ortho_init:
+                th.nn.init.orthogonal_(w, gain=gains[name])
+            else:
+                th.nn.init.kaiming_uniform_(w, a=np.sqrt(5))
+            off = getattr(self.layout, name)
+            flat[off:off + fin * fout] = w.t().contiguous().reshape(-1)
+        self.params.copy_(flat)
+
+    def state_dict(self) -> Dict[str, th.Tensor]:
+        """torch.nn.Linear-shaped CPU tensors under SB3's module names."""
+        flat, lay, shapes, out = self.params.detach().cpu(), self.layout, self._shapes(), {}
+        for mod, wname, bname in _SD:
+            fin, fout = shapes[wname]
+            woff, boff = getattr(lay, wname), getattr(lay, bname)
+            out[mod + ".weight"] = flat[woff:woff + fin * fout].reshape(fin, fout).t().contiguous()
+            out[mod + ".bias"] = flat[boff:boff + fout].clone()
+        return out
+
+    def load_state_dict(self, sd: Dict[str, th.Tensor]) -> None:
+        flat, lay, shapes = th.zeros(self.layout.P), self.layout, self._shapes()
+        for mod, wname, bname in _SD:
+            fin, fout = shapes[wname]
+            woff, boff = getattr(lay, wname), getattr(lay, bname)
+            flat[woff:woff + fin * fout] = th.as_tensor(sd[mod + ".weight"]).float().reshape(fout, fin).t().reshape(-1)
+            flat[boff:boff + fout] = th.as_tensor(sd[mod + ".bias"]).float().reshape(-1)
+        self.params.copy_(flat)
+
+    def get_flat_params(self) -> np.ndarray:
+        return self.params.detach().cpu().numpy().copy()
+
+    def set_flat_params(self, flat) -> None:
+        self.params.copy_(th.as_tensor(np.asarray(flat, np.float32)))
+
+    # -- forward family -----------------------------------------------------------------------------------------
+    def _obs(self, obs) -> th.Tensor:
+        D = self.layout.D
+        if isinstance(obs, th.Tensor):
+            t = obs.detach()
+        else:
+            t = th.as_tensor(np.asarray(obs))
+        return t.to(device=self.device, dtype=th.float32).reshape(-1, D).contiguous()
+
+    def _bind(self) -> None:
+        self.ctx.set_stream(th.cuda.current_stream(self.device).cuda_stream)
+
+    def _launch(self, obs_t, *, mask=None, uniforms=None, given=None, deterministic=False, want_logits=False,
+                want_entropy=False, rb: Optional[RolloutBuffer] = None, pos: int = 0, episode_start=None):
+        n, lay, dev = obs_t.shape[0], self.layout, self.device
+        acts = th.empty((n, lay.A), dtype=th.int32, device=dev)
+        values = th.empty((n, 1), dtype=th.float32, device=dev)
+        logp = th.empty((n,), dtype=th.float32, device=dev)
+        logits = th.empty((n, lay.L), dtype=th.float32, device=dev) if want_logits else None
+        ent = th.empty((n,), dtype=th.float32, device=dev) if want_entropy else None
+        m = None if mask is None else th.as_tensor(mask).to(device=dev, dtype=th.uint8).reshape(n, lay.L).contiguous()
+        u = None if uniforms is None else _f32_dev(uniforms, dev, (n, lay.A))
+        g = None if given is None else _f32_dev(given, dev, (n, lay.A))
+        es = None if episode_start is None else _f32_dev(episode_start, dev, (n,))
+        self._bind()
+        self._counter += 1
+        nat.check(self.ctx.lib.ph_policy_forward(
+            self.ctx.handle, C.byref(self.spec), self.params.data_ptr(), obs_t.data_ptr(), n, nat.ptr(m), nat.ptr(u),
+            nat.ptr(g), self._seed, self._counter, int(bool(deterministic)), acts.data_ptr(), None, values.data_ptr(),
+            logp.data_ptr(), nat.ptr(ent), nat.ptr(logits), C.byref(rb.c_struct()) if rb is not None else None,
+            int(pos), nat.ptr(es), int(self.gemm_mode)))
+        return acts, values, logp, ent, logits
+
+    def _shape_actions(self, acts: th.Tensor) -> th.Tensor:
+        # SB3: actions.reshape((-1,) + action_space.shape); Discrete has shape ()
+        return acts.long().reshape((-1,) + tuple(self.action_space.shape))
+
+    def forward(self, obs, deterministic: bool = False, action_mask=None, uniforms=None):
+        """-> (actions, values (n,1), log_prob (n,)) like ActorCriticPolicy.forward (util.py:79)."""
+        acts, values, logp, _, _ = self._launch(self._obs(obs), mask=action_mask, uniforms=uniforms,
+                                                deterministic=deterministic)
+        return self._shape_actions(acts), values, logp
+
+    __call__ = forward
+
+    def forward_and_store(self, obs, rb: RolloutBuffer, episode_start, deterministic: bool = False, action_mask=None,
+                          uniforms=None):
+        """forward fused with RolloutBuffer.add(reward = 0) at rb.pos (agents.py:162 + 172-179 in one launch)."""
+        if rb.pos >= rb.buffer_size:
+            raise nat.NativeError("RolloutBuffer.add on a full buffer")
+        acts, values, logp, _, _ = self._launch(self._obs(obs), mask=action_mask, uniforms=uniforms,
+                                                deterministic=deterministic, rb=rb, pos=rb.pos,
+                                                episode_start=episode_start)
+        rb.pos += 1
+        rb.full = rb.pos == rb.buffer_size
+        return self._shape_actions(acts), values, logp
+
+    def evaluate_actions(self, obs, actions, action_mask=None):
+        """-> (values (n,1), log_prob (n,), entropy (n,))  (modular/policies.py:364-383)."""
+        obs_t = self._obs(obs)
+        _, values, logp, ent, _ = self._launch(obs_t, mask=action_mask, given=actions, want_entropy=True)
+        return values, logp, ent
+
+    def predict_values(self, obs) -> th.Tensor:
+        return self._launch(self._obs(obs), deterministic=True)[1]
+
+    def get_logits(self, obs, action_mask=None) -> th.Tensor:
+        return self._launch(self._obs(obs), mask=action_mask, deterministic=True, want_logits=True)[4]
+
+    def predict(self, obs, deterministic: bool = False):
+        acts, _, _ = self.forward(obs, deterministic=deterministic)
+        return acts.cpu().numpy(), None
+
+    def reset_noise(self, n_envs: int = 1) -> None:  # gSDE hook (util.py:109-111); MlpPolicy default has none
+        return None
+
+    def set_training_mode(self, mode: bool) -> None:
+        return None
+
+
+class _SingleEnvVec:
+    """What SB3 wraps a lone env into: DummyVecEnv([Monitor(env)]) (trainer.py:119) -- batch of one, auto-reset on
+    done, episode return/length reported through info['episode']."""
+
+    num_envs = 1
+
+    def __init__(self, env):
+        self.env = env
+        self.observation_space, self.action_space = env.observation_space, env.action_space
+        self._ret, self._len = 0.0, 0
+
+    def reset(self):
+        self._ret, self._len = 0.0, 0
+        return np.asarray(self.env.reset())[None]
+
+    def step(self, actions):
+        obs, rew, done, info = self.env.step(actions[0])
+        self._ret += float(rew)
+        self._len += 1
+        info = dict(info)
+        if done:
+            info["episode"] = {"r": self._ret, "l": self._len}
+            info["terminal_observation"] = obs
+            self._ret, self._len = 0.0, 0
+            obs = self.env.reset()
+        return (np.asarray(obs)[None], np.asarray([rew], np.float32), np.asarray([done]), [info])
+
+
+class PPO:
+    """Drop-in for `stable_baselines3.PPO` on the surface PantheonRL uses (see module docstring)."""
+
+    def __init__(self, policy="MlpPolicy", env=None, learning_rate: float = 3e-4, n_steps: int = 2048,
+                 batch_size: int = 64, n_epochs: int = 10, gamma: float = 0.99, gae_lambda: float = 0.95,
+                 clip_range: float = 0.2, clip_range_vf: Optional[float] = None, normalize_advantage: bool = True,
+                 ent_coef: float = 0.0, vf_coef: float = 0.5, max_grad_norm: float = 0.5,
+                 target_kl: Optional[float] = None, tensorboard_log: Optional[str] = None, verbose: int = 0,
+                 seed: Optional[int] = None, device="cuda", n_envs: Optional[int] = None, use_sde: bool = False,
+                 sde_sample_freq: int = -1, _init_setup_model: bool = True):
+        if policy not in ("MlpPolicy", ActorCriticPolicy):
+            raise ValueError("the MI355X engine implements SB3's MlpPolicy")
+        if use_sde:
+            raise ValueError("gSDE is not on the categorical PPO path")
+        self.device = _require_cuda(device)
+        self.learning_rate, self.n_steps, self.batch_size, self.n_epochs = learning_rate, n_steps, batch_size, n_epochs
+        self.gamma, self.gae_lambda, self.clip_range, self.clip_range_vf = gamma, gae_lambda, clip_range, clip_range_vf
+        self.normalize_advantage, self.ent_coef, self.vf_coef = normalize_advantage, ent_coef, vf_coef
+        self.max_grad_norm, self.target_kl = max_grad_norm, target_kl
+        self.tensorboard_log, self.verbose, self.seed = tensorboard_log, verbose, seed
+        self.use_sde, self.sde_sample_freq = False, sde_sample_freq
+        self.num_timesteps, self._n_updates, self._custom_logger = 0, 0, False
+        self.ep_info_buffer: deque = deque(maxlen=100)
+        self._logger: Optional[Logger] = None
+        self.start_time = time.time()
+        self.env = None
+        self.n_envs = int(n_envs or 1)
+        self._last_obs, self._last_episode_starts = None, None
+        self.permutation_seed = 0 if seed is None else int(seed)
+        self.device_permutations = False  # True: Feistel permutations generated in-kernel (no host RNG, no H2D)
+        self.last_train_stats: Optional[np.ndarray] = None
+        if seed is not None:
+            self.set_random_seed(seed)
+        if env is not None:
+            self._attach_env(env, n_envs)
+        if _init_setup_model and env is not None:
+            self._setup_model()
+
+    # -- construction -------------------------------------------------------------------------------------------
+    def set_random_seed(self, seed: int) -> None:
+        """SB3 set_random_seed: random, numpy and torch (drives init and np.random.permutation)."""
+        import random
+        random.seed(seed)
+        np.random.seed(seed)
+        th.manual_seed(seed)
+
+    def _attach_env(self, env, n_envs: Optional[int] = None) -> None:
+        self.observation_space, self.action_space = env.observation_space, env.action_space
+        if hasattr(env, "num_envs"):
+            self.env = env
+        elif hasattr(env, "step") and hasattr(env, "reset") and not getattr(env, "_is_dummy_space_env", False):
+            self.env = _SingleEnvVec(env)
+        else:
+            self.env = env  # a DummyEnv that only carries spaces (partner models, trainer.py:95)
+        self.n_envs = int(n_envs or getattr(self.env, "num_envs", 1))
+
+    def _setup_model(self) -> None:
+        self.policy = ActorCriticPolicy(self.observation_space, self.action_space, lr=self.learning_rate,
+                                        device=self.device, seed=self.seed)
+        self.rollout_buffer = RolloutBuffer(self.n_steps, self.observation_space, self.action_space, self.device,
+                                            self.policy.ctx, self.policy.spec, gae_lambda=self.gae_lambda,
+                                            gamma=self.gamma, n_envs=self.n_envs)
+
+    def set_env(self, env) -> None:
+        self._attach_env(env)
+
+    # -- logger (agents.py:102-107) ---------------------------------------------------------------------------------
+    @property
+    def logger(self) -> Logger:
+        if self._logger is None:
+            self._logger = configure_logger(self.verbose, self.tensorboard_log, "PPO")
+        return self._logger
+
+    def set_logger(self, logger: Logger) -> None:
+        self._logger = logger
+        self._custom_logger = True
+
+    # -- PPO.train() (agents.py:155) -----------------------------------------------------------------------------------
+    def hyper(self) -> nat.PhPpoHyper:
+        h = nat.PhPpoHyper()
+        h.learning_rate, h.clip_range = float(self.learning_rate), float(self.clip_range)
+        h.clip_range_vf = -1.0 if self.clip_range_vf is None else float(self.clip_range_vf)
+        h.ent_coef, h.vf_coef, h.max_grad_norm = float(self.ent_coef), float(self.vf_coef), float(self.max_grad_norm)
+        h.target_kl = -1.0 if self.target_kl is None else float(self.target_kl)
+        h.normalize_advantage = int(bool(self.normalize_advantage))
+        h.adam_beta1, h.adam_beta2, h.adam_eps = 0.9, 0.999, 1e-5
+        return h
+
+    def train(self, perms: Optional[np.ndarray] = None, sync_stats: bool = True) -> None:
+        """One PPO update over the (full) rollout buffer.  `perms` (n_epochs, T*E) teacher-forces the index order;
+        default is np.random.permutation per epoch exactly like SB3's RolloutBuffer.get."""
+        rb, pol = self.rollout_buffer, self.policy
+        N = rb.buffer_size * rb.n_envs
+        n_mb = (N + self.batch_size - 1) // self.batch_size
+        perm_t = None
+        if perms is None and not self.device_permutations:
+            perms = np.stack([np.random.permutation(N) for _ in range(self.n_epochs)])
+        if perms is not None:
+            perm_t = th.as_tensor(np.ascontiguousarray(perms, dtype=np.int32)).to(self.device)
+            assert perm_t.shape == (self.n_epochs, N)
+        stats = th.zeros((self.n_epochs * n_mb, nat.PH_NSTAT), dtype=th.float32, device=self.device)
+        opt = nat.PhOptState()
+        opt.params, opt.adam_m, opt.adam_v = pol.params.data_ptr(), pol.adam_m.data_ptr(), pol.adam_v.data_ptr()
+        opt.step = pol.opt_step.data_ptr()
+        hp = self.hyper()
+        pol._bind()
+        self.permutation_seed += 1
+        nat.check(pol.ctx.lib.ph_ppo_train(pol.ctx.handle, C.byref(pol.spec), C.byref(opt), C.byref(rb.c_struct()),
+                                           C.byref(hp), int(self.n_epochs), int(self.batch_size), nat.ptr(perm_t),
+                                           int(self.permutation_seed), stats.data_ptr(), int(pol.gemm_mode)))
+        self._n_updates += self.n_epochs
+        self._stats_dev = stats
+        if sync_stats:
+            st = stats.cpu().numpy()
+            self.last_train_stats = st
+            applied = st[:, 7] > 0
+            used = st[applied] if applied.any() else st[:1]
+            lg = self.logger
+            lg.record("train/entropy_loss", float(used[:, 2].mean()))
+            lg.record("train/policy_gradient_loss", float(used[:, 0].mean()))
+            lg.record("train/value_loss", float(used[:, 1].mean()))
+            lg.record("train/approx_kl", float(used[:, 4].mean()))
+            lg.record("train/clip_fraction", float(used[:, 3].mean()))
+            lg.record("train/loss", float(used[-1, 5]))
+            lg.record("train/n_updates", self._n_updates, exclude="tensorboard")
+            lg.record("train/clip_range", self.clip_range)
+
+    # -- OnPolicyAlgorithm.learn() for the ego (trainer.py:413) -----------------------------------------
+    def collect_rollouts(self) -> bool:
+        env, rb, pol = self.env, self.rollout_buffer, self.policy
+        rb.reset()
+        dones = np.zeros(self.n_envs, dtype=bool)
+        new_obs = self._last_obs
+        for _ in range(self.n_steps):
+            actions, _, _ = pol.forward_and_store(self._last_obs, rb, self._last_episode_starts)
+            act_np = actions.cpu().numpy()
+            new_obs, rewards, dones, infos = env.step(act_np)
+            self.num_timesteps += self.n_envs
+            for info in infos:
+                ep = info.get("episode") if isinstance(info, dict) else None
+                if ep is not None:
+                    self.ep_info_buffer.append(ep)
+            rb.add_reward(np.asarray(rewards, np.float32))
+            self._last_obs = new_obs
+            self._last_episode_starts = np.asarray(dones, np.float32)
+        values = pol.predict_values(new_obs)  # ego bootstraps with V(o_T)
+        rb.compute_returns_and_advantage(last_values=values, dones=np.asarray(dones, np.float32))
+        return True
+
+    def learn(self, total_timesteps: int, log_interval: int = 1, tb_log_name: str = "PPO",
+              reset_num_timesteps: bool = True, callback=None, **_ignored) -> "PPO":
+        if self.env is None or not hasattr(self.env, "step"):
+            raise ValueError("learn() needs a steppable environment")
+        if not self._custom_logger:
+            self._logger = configure_logger(self.verbose, self.tensorboard_log, tb_log_name)
+        if reset_num_timesteps or self._last_obs is None:
+            if reset_num_timesteps:
+                self.num_timesteps = 0
+            self._last_obs = self.env.reset()
+            self._last_episode_starts = np.ones(self.n_envs, np.float32)
+        self.start_time = time.time()
+        iteration = 0
+        while self.num_timesteps < total_timesteps:
+            self.collect_rollouts()
+            iteration += 1
+            if log_interval is not None and iteration % log_interval == 0:
+                lg = self.logger
+                fps = int(self.num_timesteps / max(time.time() - self.start_time, 1e-9))
+                lg.record("time/iterations", iteration, exclude="tensorboard")
+                if len(self.ep_info_buffer) > 0:
+                    lg.record("rollout/ep_rew_mean", float(np.mean([e["r"] for e in self.ep_info_buffer])))
+                    lg.record("rollout/ep_len_mean", float(np.mean([e["l"] for e in self.ep_info_buffer])))
+                lg.record("time/fps", fps)
+                lg.record("time/total_timesteps", self.num_timesteps, exclude="tensorboard")
+                lg.dump(step=self.num_timesteps)
+            self.train()
+        return self
+
+    def predict(self, obs, deterministic: bool = False):
+        return self.policy.predict(obs, deterministic)
+
+    # -- save / load (trainer.py:419-432, 140-157).  Own container; see DESIGN.md for the SB3 mapping. --------------
+    _HP = ("learning_rate", "n_steps", "batch_size", "n_epochs", "gamma", "gae_lambda", "clip_range", "clip_range_vf",
+           "normalize_advantage", "ent_coef", "vf_coef", "max_grad_norm", "target_kl", "seed", "n_envs")
+
+    @staticmethod
+    def _space_to_json(space) -> Dict[str, Any]:
+        k = type(space).__name__
+        if k == "Box":
+            return {"type": k, "shape": list(space.shape), "low": np.asarray(space.low).tolist(),
+                    "high": np.asarray(space.high).tolist()}
+        if k == "MultiDiscrete":
+            return {"type": k, "nvec": [int(v) for v in space.nvec]}
+        return {"type": k, "n": int(space.n)}
+
+    @staticmethod
+    def _space_from_json(d: Dict[str, Any]):
+        if d["type"] == "Box":
+            return sp.Box(np.asarray(d["low"], np.float32), np.asarray(d["high"], np.float32), d["shape"])
+        if d["type"] == "MultiDiscrete":
+            return sp.MultiDiscrete(d["nvec"])
+        if d["type"] == "Discrete":
+            return sp.Discrete(d["n"])
+        return sp.MultiBinary(d["n"])
+
+    def save(self, path: str) -> None:
+        path = path if str(path).endswith(".zip") else str(path) + ".zip"
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        data = {k: getattr(self, k) for k in self._HP}
+        data.update(observation_space=self._space_to_json(self.observation_space),
+                    action_space=self._space_to_json(self.action_space), num_timesteps=self.num_timesteps,
+                    _n_updates=self._n_updates, format="pantheonrl_amd-1")
+        pol = self.policy
+        with zipfile.ZipFile(path, "w") as zf:
+            zf.writestr("data", json.dumps(data))
+            b = io.BytesIO()
+            th.save(pol.state_dict(), b)
+            zf.writestr("policy.pth", b.getvalue())
+            b = io.BytesIO()
+            th.save({"exp_avg": pol.adam_m.cpu(), "exp_avg_sq": pol.adam_v.cpu(), "step": int(pol.opt_step.item())}, b)
+            zf.writestr("policy.optimizer.pth", b.getvalue())
+
+    @classmethod
+    def load(cls, path: str, env=None, device="cuda", **kwargs) -> "PPO":
+        path = path if str(path).endswith(".zip") else str(path) + ".zip"
+        with zipfile.ZipFile(path) as zf:
+            data = json.loads(zf.read("data"))
+            sd = th.load(io.BytesIO(zf.read("policy.pth")), map_location="cpu")
+            opt = th.load(io.BytesIO(zf.read("policy.optimizer.pth")), map_location="cpu")
+        hp = {k: data[k] for k in cls._HP}
+        hp.update(kwargs)
+        model = cls(env=None, device=device, **hp)
+        model.observation_space = cls._space_from_json(data["observation_space"])
+        model.action_space = cls._space_from_json(data["action_space"])
+        model.n_envs = int(hp.get("n_envs") or 1)
+        if env is not None:
+            model._attach_env(env)
+        model._setup_model()
+        model.policy.load_state_dict(sd)
+        model.policy.adam_m.copy_(opt["exp_avg"])
+        model.policy.adam_v.copy_(opt["exp_avg_sq"])
+        model.policy.opt_step.fill_(int(opt["step"]))
+        model.num_timesteps, model._n_updates = data["num_timesteps"], data["_n_updates"]
+        return model
