@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: env-steps/sec (all agents), Overcooked-simple PPO self-play, on N MI355X.
+
+A "step" (--steps K) is ONE whole PPO iteration of every learning agent on this node: a rollout of n_steps=128
+environment steps over n_envs=1024 synthetic Overcooked-shaped environments (policy forward + rollout-buffer row write
++ late reward `+=` per step), the GAE pass, and PPO.train() with n_epochs=10 over minibatches of n_envs*n_steps/4
+rows (SURVEY.md 8d "throughput mode").  Inputs are synthetic, seeded, and already resident in HBM when the timed
+region starts.  value = agent-steps/s summed over all agents on all GPUs.
+
+Launch: `python bench.py` (N=1) or
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch as th
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+OBS_DIM, N_ACTIONS, HORIZON = 62, 6, 400   # Overcooked-simple shapes
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20, help="timed PPO iterations (K)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-envs", type=int, default=1024)
+    ap.add_argument("--n-steps", type=int, default=128)
+    ap.add_argument("--n-epochs", type=int, default=10)
+    ap.add_argument("--batch-size", type=int, default=0, help="0 = n_envs*n_steps/4")
+    ap.add_argument("--agents-per-gpu", type=int, default=2,
+                    help="self-play pair per GPU (ego PPO + partner PPO, trainer.py ... PPO PPO)")
+    ap.add_argument("--mode", choices=("auto", "graph", "eager"), default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build_agents(args, device):
+    from pantheonrl_amd import PPO, spaces as sp
+    from pantheonrl_amd.vec import SyntheticRollouts, VecOnPolicyAgent
+    obs_space, act_space = sp.Box(-np.inf, np.inf, (OBS_DIM,)), sp.Discrete(N_ACTIONS)
+    env = type("SpacesOnly", (), dict(observation_space=obs_space, action_space=act_space, _is_dummy_space_env=True))()
+    rank = int(os.environ.get("RANK", "0"))
+    agents, datas = [], []
+    for i in range(args.agents_per_gpu):
+        seed = 1000 * rank + i
+        model = PPO("MlpPolicy", env, n_steps=args.n_steps, n_envs=args.n_envs, batch_size=args.batch_size,
+                    n_epochs=args.n_epochs, seed=seed, device=device)
+        model.device_permutations = True
+        agents.append(VecOnPolicyAgent(model))
+        datas.append(SyntheticRollouts(obs_space, args.n_envs, args.n_steps, HORIZON, seed % 3, device))
+    return agents, datas
+
+
+def cpu_baseline(args):
+    """the oracle executed SB3-style (per-step add with host copies, Python-loop GAE, eager autograd) on the host
+    cores of this box: ONE iteration of ONE agent at the same sizes (a bounded sample of the workload)."""
+    from oracle.sb3_oracle import (MlpPolicyOracle, PPOHyper, RolloutBufferOracle, SpaceSpec, synthetic_iteration)
+    cores = os.cpu_count() or 1
+    th.set_num_threads(cores)
+    T, E = args.n_steps, args.n_envs
+    th.manual_seed(0)
+    pol = MlpPolicyOracle(SpaceSpec("box", dim=OBS_DIM), SpaceSpec("discrete", nvec=(N_ACTIONS,)))
+    buf = RolloutBufferOracle(T, E, OBS_DIM, 1)
+    rng = np.random.default_rng(0)
+    obs = rng.standard_normal((T, E, OBS_DIM), dtype=np.float32)
+    rew = rng.standard_normal((T, E), dtype=np.float32)
+    done = rng.random((T, E)) < 1.0 / HORIZON
+    hp = PPOHyper(batch_size=args.batch_size, n_epochs=args.n_epochs)
+    t0 = time.perf_counter()
+    synthetic_iteration(pol, buf, hp, obs, rew, done)
+    dt = time.perf_counter() - t0
+    return {"value": T * E / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 PPO iteration of 1 agent (n_envs={E}, n_steps={T}, batch={args.batch_size}, "
+                      f"n_epochs={args.n_epochs}) = {T * E} agent-steps in {dt:.2f}s, torch threads={cores}"}
+
+
+def roofline(args, agent):
+    """dominant kernel = ppo_grad_kernel (gather + forward + loss + backward of one minibatch); MFMA-bound.
+    achieved = algorithmic FLOPs per launch (6*M per row, M = forward MACs) / mean launch duration measured
+    with HIP events on the kernel's own stream."""
+    from pantheonrl_amd import _native as nat
+    model = agent.model
+    pol, rb = model.policy, model.rollout_buffer
+    lay = pol.layout
+    hp = model.hyper()
+    ms = C.c_float(0)
+    pol._bind()
+    nat.check(pol.ctx.lib.ph_bench_ppo_grad(pol.ctx.handle, C.byref(pol.spec), pol.params.data_ptr(),
+                                            C.byref(rb.c_struct()), C.byref(hp), int(model.batch_size), 20, 0,
+                                            C.byref(ms)))
+    macs = 2 * (lay.F * 64 + 64 * 64) + 64 * lay.L + 64
+    nb = min(model.batch_size, rb.buffer_size * rb.n_envs)
+    flops = 6.0 * macs * nb
+    achieved = flops / (ms.value * 1e-3) / 1e12
+    out = {"bound": "mfma", "kernel": "ppo_grad_kernel<64,false>", "achieved": achieved, "peak": 157.3,
+           "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None, "launch_ms": ms.value,
+           "flops_per_launch": flops}
+    # secondary, HBM-bound: the GAE pass at this size (20 algorithmic bytes per transition)
+    lv = th.zeros(rb.n_envs, device=pol.device)
+    gms = C.c_float(0)
+    nat.check(pol.ctx.lib.ph_bench_gae(pol.ctx.handle, C.byref(rb.c_struct()), lv.data_ptr(), lv.data_ptr(), 0.99, 0.95,
+                                       0, 20, C.byref(gms)))
+    gb = 20.0 * rb.buffer_size * rb.n_envs
+    out["gae"] = {"bound": "hbm", "achieved": gb / (gms.value * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                  "launch_ms": gms.value, "bytes_per_launch": gb}
+    return out
+
+
+def main():
+    args = parse()
+    if args.batch_size <= 0:
+        args.batch_size = args.n_envs * args.n_steps // 4
+    from pantheonrl_amd import dist as pdist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not th.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    th.cuda.set_device(local_rank)
+    device = th.device("cuda", local_rank)
+    distributed = pdist.init_from_env("nccl")
+    import torch.distributed as tdist
+
+    from pantheonrl_amd.vec import IterationGraph, run_iteration_eager
+    agents, datas = build_agents(args, device)
+    streams = [th.cuda.Stream(device=device) for _ in agents]
+    mode = args.mode
+    if mode == "auto":
+        mode = "eager" if distributed else "graph"
+    exchange = pdist.ActionExchange(len(agents), args.n_envs, device) if distributed else None
+
+    if mode == "graph":
+        graphs = [IterationGraph(a, d, s) for a, d, s in zip(agents, datas, streams)]
+
+        def iteration():
+            for g in graphs:
+                g.launch()
+    elif not distributed:
+        def iteration():
+            for a, d, s in zip(agents, datas, streams):
+                with th.cuda.stream(s):
+                    run_iteration_eager(a, d)
+    else:
+        # agent-per-GPU layout: every environment step all-gathers the actions of all seats (RCCL over xGMI); the
+        # (synthetic) transition consumes the joint action: a shared coordination bonus when a seat's action equals
+        # its round-robin partner's, like Overcooked's shared reward.
+        def iteration():
+            for a in agents:
+                a.bind_stream()
+            T = datas[0].T
+            for t in range(T):
+                acts = [a.get_action(d.obs[t]) for a, d in zip(agents, datas)]
+                joint = exchange.gather(acts)
+                for i, (a, d) in enumerate(zip(agents, datas)):
+                    partner = exchange.partner_of(exchange.seat(i), a.iteration)
+                    bonus = (joint[exchange.seat(i)] == joint[partner]).to(th.float32) * 0.01
+                    a.update(d.rewards[t] + bonus, d.dones[t])
+            for a in agents:
+                a.learn_from_buffer()
+
+    def barrier():
+        th.cuda.synchronize(device)
+        if distributed:
+            tdist.barrier()
+            th.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        iteration()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        iteration()
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tmax = th.tensor([dt], dtype=th.float64, device=device)
+        tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    steps_per_iter = args.n_envs * args.n_steps * len(agents) * world
+    value = steps_per_iter * args.steps / dt
+    result = {
+        "metric": "env-steps/sec (all agents) Overcooked-simple PPO self-play",
+        "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "OvercookedMultiEnv-v0 layout=simple, PPO self-play (two independent PPO learners per "
+                               "GPU), synthetic (n_envs, n_steps, obs_dim) rollouts",
+                   "n_envs": args.n_envs, "n_steps": args.n_steps, "obs_dim": OBS_DIM, "n_actions": N_ACTIONS,
+                   "batch_size": args.batch_size, "n_epochs": args.n_epochs, "agents_per_gpu": len(agents),
+                   "parallelism": f"agent-per-gpu x{world} ({'per-step RCCL action all-gather' if distributed else 'single process'})",
+                   "launch_mode": mode},
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            result["roofline"] = roofline(args, agents[0])
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(args)
+            result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+        print(json.dumps(result), flush=True)
+    if distributed:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,6 +108,11 @@ int ph_ctx_sync(ph_ctx *ctx);
 int ph_graph_begin(ph_ctx *ctx);
 int ph_graph_end(ph_ctx *ctx, int *graph_id_out /* host */);
 int ph_graph_launch(ph_ctx *ctx, int graph_id);
+/* Device-resident RNG epoch.  Philox counters and permutation seeds are launch arguments, so a captured graph would
+ * replay the same random numbers; when an epoch word (one device uint64, caller-owned) is attached, every random
+ * stream is additionally keyed by *epoch, and ph_rng_epoch_advance enqueues *epoch += 1 (capturable). */
+int ph_ctx_set_rng_epoch(ph_ctx *ctx, unsigned long long *epoch_dev /* device, or NULL to detach */);
+int ph_rng_epoch_advance(ph_ctx *ctx);
 /* HIP-event timing on the ctx stream (bench.py roofline: events must sit on the stream the kernels run on) */
 int ph_timer_start(ph_ctx *ctx);
 int ph_timer_stop(ph_ctx *ctx, float *ms_out /* host */); /* synchronises */
@@ -173,6 +178,16 @@ int ph_ppo_train(ph_ctx *ctx, const ph_spec *spec, const ph_opt_state *opt, cons
 int ph_ppo_minibatch_grad(ph_ctx *ctx, const ph_spec *spec, const float *params, const ph_rollout *rb,
                           const ph_ppo_hyper *hyper /* host */, const int *indices, int nb, float *grad_out,
                           float *stats_out, int gemm_mode);
+
+/* Measurement hook for bench.py's roofline: enqueue ONLY the ppo_grad kernel (the dominant kernel of PPO.train) `reps`
+ * times for the first minibatch (size min(batch_size, T*E), in-kernel permutation) between two HIP events on the ctx
+ * stream; *avg_ms_out = mean launch duration.  Optimizer state is not touched.  Synchronises. */
+int ph_bench_ppo_grad(ph_ctx *ctx, const ph_spec *spec, const float *params, const ph_rollout *rb,
+                      const ph_ppo_hyper *hyper /* host */, int batch_size, int reps, int gemm_mode,
+                      float *avg_ms_out /* host */);
+/* same for the GAE kernel (mode as in ph_gae); advantages/returns are overwritten with the same values each rep */
+int ph_bench_gae(ph_ctx *ctx, const ph_rollout *rb, const float *last_values, const float *dones, double gamma,
+                 double gae_lambda, int mode, int reps, float *avg_ms_out /* host */);
 
 /* Host-side evaluation of the keyed Feistel permutation ph_ppo_train uses when perms == NULL: writes
  * out[i] = perm_epoch(start + i) for i < count (env-major indices in [0, n)).  Pure CPU, needs no device;

@@ -67,6 +67,8 @@ SIGNATURES = {
     "ph_graph_begin": [_vp],
     "ph_graph_end": [_vp, C.POINTER(_i)],
     "ph_graph_launch": [_vp, _i],
+    "ph_ctx_set_rng_epoch": [_vp, _vp],
+    "ph_rng_epoch_advance": [_vp],
     "ph_timer_start": [_vp],
     "ph_timer_stop": [_vp, C.POINTER(C.c_float)],
     "ph_layout_of": [C.POINTER(PhSpec), C.POINTER(PhLayout)],
@@ -81,6 +83,9 @@ SIGNATURES = {
                      _vp, _ull, _vp, _i],
     "ph_ppo_minibatch_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _vp, _i, _vp,
                               _vp, _i],
+    "ph_bench_ppo_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i, _i,
+                          C.POINTER(C.c_float)],
+    "ph_bench_gae": [_vp, C.POINTER(PhRollout), _vp, _vp, _d, _d, _i, _i, C.POINTER(C.c_float)],
     "ph_feistel_indices": [_i, _ull, _i, _i, _i, C.POINTER(_i)],
 }
 

@@ -57,6 +57,7 @@ struct ph_ctx {
   bool capturing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cu = 256;
+  unsigned long long* rng_epoch = nullptr;  // caller-owned device word
 };
 
 namespace {
@@ -243,7 +244,7 @@ int ph_graph_begin(ph_ctx* ctx) {
   if (!ctx) return fail("null ctx");
   if (ctx->capturing) return fail("already capturing");
   if (ctx->stream == nullptr) return fail("graph capture needs a non-default stream (ph_ctx_set_stream)");
-  PH_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  PH_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
   ctx->capturing = true;
   return 0;
 }
@@ -267,6 +268,18 @@ int ph_graph_launch(ph_ctx* ctx, int graph_id) {
   if (!ctx) return fail("null ctx");
   if (graph_id < 0 || graph_id >= (int)ctx->graphs.size()) return fail("bad graph id");
   PH_HIP(hipGraphLaunch(ctx->graphs[graph_id], ctx->stream));
+  return 0;
+}
+
+int ph_ctx_set_rng_epoch(ph_ctx* ctx, unsigned long long* epoch_dev) {
+  if (!ctx) return fail("null ctx");
+  ctx->rng_epoch = epoch_dev;
+  return 0;
+}
+int ph_rng_epoch_advance(ph_ctx* ctx) {
+  if (!ctx) return fail("null ctx");
+  if (!ctx->rng_epoch) return fail("ph_rng_epoch_advance: no epoch word attached");
+  PH_HIP(ph::launch_epoch_advance(ctx->rng_epoch, ctx->stream));
   return 0;
 }
 
@@ -355,6 +368,7 @@ int ph_policy_forward(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   a.given_actions = given_actions;
   a.seed = seed;
   a.counter = counter;
+  a.epoch = ctx->rng_epoch;
   a.deterministic = deterministic;
   a.act_i32 = actions_i32;
   a.act_f32 = actions_f32;
@@ -470,6 +484,7 @@ int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, cons
     aa.perm_n = (uint32_t)N;
     aa.perm_hb = hb;
     aa.perm_seed = perm_seed;
+    aa.epoch = ctx->rng_epoch;
     aa.N = N;
     aa.batch = batch_size;
     aa.n_mb = n_mb;
@@ -488,7 +503,9 @@ int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, cons
       g.idx = perms ? perms + (size_t)ep * N + start : nullptr;
       g.perm_n = (uint32_t)N;
       g.perm_hb = hb;
-      g.perm_key = ph::epoch_key(perm_seed, ep);
+      g.perm_seed = perm_seed;
+      g.perm_epoch = ep;
+      g.epoch = ctx->rng_epoch;
       g.mb_start = start;
       g.nb = nb;
       g.advstats = ctx->advstats + 2 * (size_t)mbi;
@@ -557,6 +574,7 @@ int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params,
   aa.perm_n = 0;
   aa.perm_hb = 1;
   aa.perm_seed = 0;
+  aa.epoch = nullptr;
   aa.N = nb;
   aa.batch = nb;
   aa.n_mb = 1;
@@ -586,6 +604,75 @@ int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params,
   r.step = nullptr;
   r.scalars = ctx->scalars;
   PH_HIP(ph::launch_ppo_reduce(r, s));
+  return 0;
+}
+
+int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, const ph_rollout* rb,
+                      const ph_ppo_hyper* hp, int batch_size, int reps, int gemm_mode, float* avg_ms_out) {
+  if (!ctx || !params || !hp || !avg_ms_out) return fail("ph_bench_ppo_grad: null argument");
+  if (check_rb(rb)) return 1;
+  if (batch_size <= 0 || reps <= 0) return fail("ph_bench_ppo_grad: bad sizes");
+  ph::NetDims nd;
+  if (resolve(ctx, spec, &nd)) return 1;
+  const int N = rb->T * rb->E;
+  const int nb = batch_size < N ? batch_size : N;
+  const MbPlan pl = plan_minibatch(ctx, nb);
+  if (ensure_train_ws(ctx, nd.lay.P, pl.nwg, 1)) return 1;
+  hipStream_t s = ctx->stream;
+  PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
+  ph::AdvStatArgs aa;
+  aa.rb_adv = rb->advantages;
+  aa.T = rb->T;
+  aa.E = rb->E;
+  aa.perms = nullptr;
+  aa.perm_n = (uint32_t)N;
+  aa.perm_hb = ph::feistel_half_bits((uint32_t)N);
+  aa.perm_seed = 12345;
+  aa.epoch = nullptr;
+  aa.N = N;
+  aa.batch = nb;
+  aa.n_mb = 1;
+  aa.out = ctx->advstats;
+  PH_HIP(ph::launch_adv_stats(aa, 1, s));
+  ph::GradArgs g;
+  std::memset(&g, 0, sizeof(g));
+  fill_grad_args(g, nd, params, rb, hp, ctx);
+  g.perm_n = aa.perm_n;
+  g.perm_hb = aa.perm_hb;
+  g.perm_seed = aa.perm_seed;
+  g.nb = nb;
+  g.advstats = ctx->advstats;
+  g.ntiles = pl.ntiles;
+  PH_HIP(ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s));  // warm
+  PH_HIP(hipEventRecord(ctx->ev0, s));
+  for (int i = 0; i < reps; ++i) PH_HIP(ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s));
+  PH_HIP(hipEventRecord(ctx->ev1, s));
+  PH_HIP(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  PH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *avg_ms_out = ms / (float)reps;
+  return 0;
+}
+
+int ph_bench_gae(ph_ctx* ctx, const ph_rollout* rb, const float* last_values, const float* dones, double gamma,
+                 double gae_lambda, int mode, int reps, float* avg_ms_out) {
+  if (!ctx || !last_values || !dones || !avg_ms_out) return fail("ph_bench_gae: null argument");
+  if (check_rb(rb)) return 1;
+  if (reps <= 0 || mode < 0 || mode > 2) return fail("ph_bench_gae: bad arguments");
+  if (mode == 2 && rb->T > 2048) return fail("ph_bench_gae: scan mode supports T <= 2048");
+  hipStream_t s = ctx->stream;
+  auto once = [&]() {
+    return ph::launch_gae(rb->rewards, rb->values, rb->episode_starts, last_values, dones, rb->advantages, rb->returns,
+                          rb->T, rb->E, gamma, gae_lambda, mode, s);
+  };
+  PH_HIP(once());
+  PH_HIP(hipEventRecord(ctx->ev0, s));
+  for (int i = 0; i < reps; ++i) PH_HIP(once());
+  PH_HIP(hipEventRecord(ctx->ev1, s));
+  PH_HIP(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  PH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *avg_ms_out = ms / (float)reps;
   return 0;
 }
 

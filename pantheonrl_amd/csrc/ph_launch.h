@@ -13,6 +13,7 @@ struct FwdArgs {
   const float* uniforms;       // (n, A) or null
   const float* given_actions;  // (n, A) or null
   uint64_t seed, counter;
+  const unsigned long long* epoch;  // device RNG epoch word or null
   int deterministic;
   int* act_i32;
   float* act_f32;
@@ -44,7 +45,9 @@ struct GradArgs {
   // minibatch rows: explicit env-major indices, or a Feistel permutation of [0, perm_n) starting at mb_start
   const int* idx;
   uint32_t perm_n, perm_hb;
-  uint64_t perm_key;
+  uint64_t perm_seed;      // key = epoch_key(perm_seed + *epoch, perm_epoch)
+  int perm_epoch;
+  const unsigned long long* epoch;
   int mb_start;
   int nb;                  // rows in this minibatch
   const float* advstats;   // {mean, std} of this minibatch's advantages
@@ -62,6 +65,7 @@ struct AdvStatArgs {
   const int* perms;  // (n_epochs, N) or null
   uint32_t perm_n, perm_hb;
   uint64_t perm_seed;
+  const unsigned long long* epoch;
   int N, batch, n_mb;  // minibatch k of epoch ep covers [k*batch, min(N,(k+1)*batch))
   float* out;          // [n_epochs*n_mb][2]
 };
@@ -116,5 +120,6 @@ hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s);
 hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_set_int(int* p, int v, hipStream_t s);
+hipError_t launch_epoch_advance(unsigned long long* p, hipStream_t s);
 
 }  // namespace ph

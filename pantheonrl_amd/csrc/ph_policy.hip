@@ -121,6 +121,7 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
   if (tid < R && rowphys[tid] >= 0) {
     const int g = row0 + tid;
     float* z = outs + tid * LDO;
+    const uint64_t ctr = a.counter + (a.epoch ? (uint64_t)(*a.epoch) << 32 : 0ull);
     if (a.mask) {  // modular/policies.py:330-333 : logits - 30*(~mask)
       for (int k = 0; k < nd.L; ++k) z[k] = z[k] - 30.0f * (1.0f - (float)(a.mask[(size_t)g * nd.L + k] != 0));
     }
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
           if (z[lo + k] > best) { best = z[lo + k]; act = k; }
       } else {
         const float u = a.uniforms ? a.uniforms[(size_t)g * nd.A + c]
-                                   : philox_uniform(a.seed, a.counter, (uint32_t)g, (uint32_t)c);
+                                   : philox_uniform(a.seed, ctr, (uint32_t)g, (uint32_t)c);
         float cum = 0.f;
         act = 0;
         for (int k = 0; k < nk - 1; ++k) {  // inverse CDF: count prefix sums <= u
@@ -189,9 +190,13 @@ hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s) {
   if (gemm_mode != 0) {
     hipLaunchKernelGGL((policy_fwd_kernel<32, true>), grid, block, lds, s, a);
   } else if (R == 64) {
-    hipError_t e = hipFuncSetAttribute((const void*)policy_fwd_kernel<64, false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    static size_t allowed = 0;
+    if (lds > allowed) {
+      hipError_t e = hipFuncSetAttribute((const void*)policy_fwd_kernel<64, false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      allowed = lds;
+    }
     hipLaunchKernelGGL((policy_fwd_kernel<64, false>), grid, block, lds, s, a);
   } else {
     hipLaunchKernelGGL((policy_fwd_kernel<32, false>), grid, block, lds, s, a);

@@ -22,7 +22,13 @@ __device__ __forceinline__ int env_major_to_phys(int n, int T, int E) {
 }
 
 __device__ __forceinline__ int minibatch_row(const GradArgs& a, int gi) {
-  const int n = a.idx ? a.idx[gi] : (int)feistel_perm((uint32_t)(a.mb_start + gi), a.perm_n, a.perm_hb, a.perm_key);
+  int n;
+  if (a.idx) {
+    n = a.idx[gi];
+  } else {
+    const uint64_t key = epoch_key(a.perm_seed + (a.epoch ? *a.epoch : 0ull), a.perm_epoch);
+    n = (int)feistel_perm((uint32_t)(a.mb_start + gi), a.perm_n, a.perm_hb, key);
+  }
   return env_major_to_phys(n, a.T, a.E);
 }
 
@@ -381,16 +387,17 @@ hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_
   constexpr int R = 64;
   const size_t lds = grad_lds_bytes(R, a.nd.Lp);
   dim3 grid(nwg, 2), block(R * 4);
-  hipError_t e;
-  if (gemm_mode != 0) {
-    e = hipFuncSetAttribute((const void*)ppo_grad_kernel<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // > 64 KiB of dynamic LDS must be opted into once per kernel (not a stream operation; kept out of graph capture)
+  static size_t allowed[2] = {0, 0};
+  const int v = gemm_mode != 0 ? 1 : 0;
+  if (lds > allowed[v]) {
+    const void* fn = v ? (const void*)ppo_grad_kernel<R, true> : (const void*)ppo_grad_kernel<R, false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ppo_grad_kernel<R, true>), grid, block, lds, s, a);
-  } else {
-    e = hipFuncSetAttribute((const void*)ppo_grad_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ppo_grad_kernel<R, false>), grid, block, lds, s, a);
+    allowed[v] = lds;
   }
+  if (v) hipLaunchKernelGGL((ppo_grad_kernel<R, true>), grid, block, lds, s, a);
+  else hipLaunchKernelGGL((ppo_grad_kernel<R, false>), grid, block, lds, s, a);
   return hipGetLastError();
 }
 
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
   const int ep = mb / a.n_mb, k = mb - ep * a.n_mb;
   const int start = k * a.batch;
   const int nb = (a.N - start < a.batch) ? a.N - start : a.batch;
-  const uint64_t key = epoch_key(a.perm_seed, ep);
+  const uint64_t key = epoch_key(a.perm_seed + (a.epoch ? *a.epoch : 0ull), ep);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto value = [&](int i) -> double {
     const int n = a.perms ? a.perms[(size_t)ep * a.N + start + i]
@@ -548,6 +555,11 @@ hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+__global__ void epoch_advance_kernel(unsigned long long* p) { *p += 1ull; }
+hipError_t launch_epoch_advance(unsigned long long* p, hipStream_t s) {
+  hipLaunchKernelGGL(epoch_advance_kernel, dim3(1), dim3(1), 0, s, p);
+  return hipGetLastError();
+}
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
 hipError_t launch_set_int(int* p, int v, hipStream_t s) {
   hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, p, v);

@@ -1,0 +1,67 @@
+"""Agent-per-GPU exchange layer.
+
+In the reference every agent<->env hand-off is an in-process call inside MultiAgentEnv._get_actions /
+_update_players (pantheonrl/common/multiagentenv.py:149-170).  With one learner per GPU the same hand-off becomes:
+every rank contributes the actions of its local agents for the current SimultaneousEnv step, every rank receives the
+joint action.  Learners are independent (reference README.md:6): there is NO gradient or parameter exchange, hence no
+all-reduce anywhere -- only this KB-sized, latency-bound all-gather per environment step, issued on-stream through
+torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU for the world_size-2 tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch as th
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> bool:
+    """initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun); returns False for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return False
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if th.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend)
+    return True
+
+
+class ActionExchange:
+    """all-gather of per-step actions: local (A_local, E) int32 -> joint (world * A_local, E) int32.
+
+    Seats are numbered rank-major: global seat g = rank * A_local + local index.  `partner_of(g)` implements the
+    round-robin pairing the reference applies per episode (multiagentenv.py:118-125): at pairing round r, seat g plays
+    with seat (g + 1 + r mod (n_seats-1)) mod n_seats -- kept in Python, like the reference's partner selection.
+    """
+
+    def __init__(self, agents_local: int, n_envs: int, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.agents_local, self.n_envs = agents_local, n_envs
+        self.n_seats = self.world * agents_local
+        self.local = th.zeros((agents_local, n_envs), dtype=th.int32, device=device)
+        self.joint = th.zeros((self.n_seats, n_envs), dtype=th.int32, device=device)
+        self.bytes_per_step = self.joint.numel() * 4
+
+    def seat(self, local_index: int) -> int:
+        return self.rank * self.agents_local + local_index
+
+    def partner_of(self, seat: int, pairing_round: int = 0) -> int:
+        if self.n_seats < 2:
+            return seat
+        return (seat + 1 + pairing_round % (self.n_seats - 1)) % self.n_seats
+
+    def gather(self, local_actions: List[th.Tensor]) -> th.Tensor:
+        """local_actions[i]: (E,) or (E,1) int32 of local agent i -> joint (n_seats, E).  Enqueued on the current
+        stream; no host synchronisation."""
+        for i, a in enumerate(local_actions):
+            self.local[i].copy_(a.reshape(-1))
+        if self.world == 1:
+            self.joint.copy_(self.local)
+        else:
+            dist.all_gather_into_tensor(self.joint, self.local, group=self.group)
+        return self.joint

@@ -416,7 +416,9 @@ class PPO:
         if perms is not None:
             perm_t = th.as_tensor(np.ascontiguousarray(perms, dtype=np.int32)).to(self.device)
             assert perm_t.shape == (self.n_epochs, N)
-        stats = th.zeros((self.n_epochs * n_mb, nat.PH_NSTAT), dtype=th.float32, device=self.device)
+        stats = getattr(self, "_stats_dev", None)   # reused across calls: no allocation on the update path
+        if stats is None or stats.shape[0] != self.n_epochs * n_mb:
+            stats = th.zeros((self.n_epochs * n_mb, nat.PH_NSTAT), dtype=th.float32, device=self.device)
         opt = nat.PhOptState()
         opt.params, opt.adam_m, opt.adam_v = pol.params.data_ptr(), pol.adam_m.data_ptr(), pol.adam_v.data_ptr()
         opt.step = pol.opt_step.data_ptr()

@@ -1,0 +1,88 @@
+"""Shared test plumbing: matched (oracle, device) policy pairs and synthetic rollouts.  The oracle is the checker."""
+from __future__ import annotations
+
+import numpy as np
+import torch as th
+
+from oracle.sb3_oracle import MlpPolicyOracle, PPOHyper, RolloutBufferOracle, SpaceSpec
+
+# BASELINE.json configs: name -> (obs SpaceSpec, act SpaceSpec)
+CONFIGS = {
+    "rps": (SpaceSpec("discrete", nvec=(1,)), SpaceSpec("discrete", nvec=(3,))),
+    "liar": (SpaceSpec("multidiscrete", nvec=tuple([7] * 6 + [7, 12] * 12)), SpaceSpec("multidiscrete", nvec=(7, 12))),
+    "overcooked": (SpaceSpec("box", dim=62), SpaceSpec("discrete", nvec=(6,))),
+    "mpe8": (SpaceSpec("box", dim=48), SpaceSpec("discrete", nvec=(5,))),
+    "wide": (SpaceSpec("box", dim=130), SpaceSpec("multidiscrete", nvec=(3, 30, 7))),  # 3 feature chunks, Lp=64
+}
+
+
+def to_space(spec: SpaceSpec):
+    from pantheonrl_amd import spaces as sp
+    if spec.kind == "box":
+        return sp.Box(-np.inf, np.inf, (spec.dim,))
+    if spec.kind == "discrete":
+        return sp.Discrete(spec.nvec[0])
+    return sp.MultiDiscrete(list(spec.nvec))
+
+
+def sample_obs(spec: SpaceSpec, n: int, rng: np.random.Generator) -> np.ndarray:
+    if spec.kind == "box":
+        return rng.standard_normal((n, spec.dim)).astype(np.float32)
+    return np.stack([rng.integers(0, k, size=n) for k in spec.nvec], axis=1).astype(np.float32)
+
+
+def oracle_policy(name: str, seed: int = 0, perturb: float = 0.3) -> MlpPolicyOracle:
+    """seeded oracle policy; biases and the 0.01-gain action head are perturbed so logits are not ~uniform."""
+    th.manual_seed(seed)
+    obs_s, act_s = CONFIGS[name]
+    pol = MlpPolicyOracle(obs_s, act_s)
+    g = th.Generator().manual_seed(seed + 1)
+    with th.no_grad():
+        for p in pol.parameters():
+            if p.ndim == 1:
+                p.add_(perturb * th.randn(p.shape, generator=g))
+        pol.action_net.weight.add_(perturb * th.randn(pol.action_net.weight.shape, generator=g))
+    return pol
+
+
+def device_policy(name: str, oracle: MlpPolicyOracle):
+    from pantheonrl_amd.ppo import ActorCriticPolicy
+    obs_s, act_s = CONFIGS[name]
+    pol = ActorCriticPolicy(to_space(obs_s), to_space(act_s), device="cuda", seed=0)
+    pol.set_flat_params(oracle.flat_params())
+    return pol
+
+
+def filled_oracle_buffer(name: str, oracle: MlpPolicyOracle, T: int, E: int, seed: int = 0,
+                         p_done: float = 0.05) -> RolloutBufferOracle:
+    """a full rollout buffer produced by the oracle policy on synthetic inputs (SURVEY.md 8d generators)."""
+    rng = np.random.default_rng(seed)
+    obs_s, act_s = CONFIGS[name]
+    buf = RolloutBufferOracle(T, E, obs_s.stored_len, act_s.stored_len)
+    starts = np.ones(E, np.float32)
+    values = None
+    for _ in range(T):
+        obs = sample_obs(obs_s, E, rng)
+        with th.no_grad():
+            actions, values, logp = oracle.forward(th.as_tensor(obs))
+        buf.add(obs, actions.numpy(), rng.standard_normal(E).astype(np.float32), starts, values, logp)
+        starts = (rng.random(E) < p_done).astype(np.float32)
+    buf.compute_returns_and_advantage(values, starts)
+    return buf
+
+
+def upload_buffer(dev_buf, ob: RolloutBufferOracle) -> None:
+    """copy every array of an oracle buffer into a device RolloutBuffer (marks it full)."""
+    for k in ("observations", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns"):
+        getattr(dev_buf, k).copy_(th.as_tensor(getattr(ob, k)))
+    dev_buf.pos, dev_buf.full = dev_buf.buffer_size, True
+
+
+def make_device_buffer(name: str, pol, T: int, E: int):
+    from pantheonrl_amd.ppo import RolloutBuffer
+    obs_s, act_s = CONFIGS[name]
+    return RolloutBuffer(T, to_space(obs_s), to_space(act_s), pol.device, pol.ctx, pol.spec, n_envs=E)
+
+
+__all__ = ["CONFIGS", "PPOHyper", "to_space", "sample_obs", "oracle_policy", "device_policy",
+           "filled_oracle_buffer", "upload_buffer", "make_device_buffer"]
