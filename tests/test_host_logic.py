@@ -1,0 +1,245 @@
+"""not-gpu: the host-side mirror of pantheonrl.common -- Agent / OnPolicyAgent callbacks, MultiAgentEnv driving,
+partner selection, the two in-tree games -- exercised with scripted agents and an oracle-backed model."""
+import numpy as np
+import pytest
+import torch as th
+
+from pantheonrl_amd.common import (Agent, MultiAgentEnv, Observation, OnPolicyAgent, PlayerException,
+                                   SimultaneousEnv, StaticPolicyAgent, TurnBasedEnv)
+from pantheonrl_amd.common import util
+from pantheonrl_amd.envs import make
+from pantheonrl_amd.envs.liar import CALL, LiarDefaultAgent, LiarEnv
+from pantheonrl_amd.envs.rps import RPSEnv, RPSWeightedAgent, rps_payoff
+from pantheonrl_amd.spaces import Box, Discrete, MultiBinary, MultiDiscrete, SpaceException
+from tests.stub_model import OraclePPO
+
+
+class Scripted(Agent):
+    """records every callback; plays a fixed action"""
+
+    def __init__(self, action=0):
+        self.action, self.log = action, []
+
+    def get_action(self, obs, record=True):
+        self.log.append(("act", obs.obs.tolist() if hasattr(obs.obs, "tolist") else obs.obs))
+        return self.action
+
+    def update(self, reward, done):
+        self.log.append(("upd", reward, done))
+
+
+# ---- MultiAgentEnv --------------------------------------------------------------------------------------------------
+def test_simultaneous_env_drives_partner_callbacks_in_reference_order():
+    env = RPSEnv()
+    partner = Scripted(action=1)  # paper
+    env.add_partner_agent(partner)
+    obs = env.reset()
+    assert obs.tolist() == [0] and partner.log == []
+    obs, rew, done, info = env.step(2)  # scissors beats paper
+    assert (rew, done, info["_partnerid"]) == (1.0, True, [0])
+    # first move of the episode: get_action, then update(total_rews so far = 0, False), then update(reward, done)
+    assert partner.log == [("act", [0]), ("upd", 0, False), ("upd", -1, True)]
+    env.reset()
+    _, rew, _, _ = env.step(0)          # rock loses to paper
+    assert rew == -1.0
+    assert np.array_equal(rps_payoff(np.array([0, 1, 2, 0]), np.array([0, 0, 0, 2])), [0, 1, -1, 1])
+
+
+def test_round_robin_advances_on_every_reset_including_the_first():
+    env = RPSEnv()
+    partners = [Scripted(a) for a in (0, 1, 2)]
+    for p in partners:
+        env.add_partner_agent(p)
+    seen = []
+    for _ in range(7):
+        env.reset()
+        _, _, _, info = env.step(0)
+        seen.append(info["_partnerid"][0])
+    assert seen == [1, 2, 0, 1, 2, 0, 1]        # the first episode already uses partner 1
+    env.set_resample_policy("random")
+    np.random.seed(0)
+    ids = set()
+    for _ in range(30):
+        env.reset()
+        ids.add(env.partnerids[0])
+    assert ids == {0, 1, 2}
+    env.set_partnerid(2)
+    assert env.partnerids == [2]
+    with pytest.raises(AssertionError):
+        env.set_partnerid(3)
+
+
+def test_player_exceptions():
+    with pytest.raises(PlayerException):
+        RPSEnv().set_resample_policy("nope")
+
+    class Three(MultiAgentEnv):
+        def n_step(self, a):
+            return (0,), (Observation(np.zeros(1)),), (0, 0, 0), True, {}
+
+        def n_reset(self):
+            return (1,), (Observation(np.zeros(1)),)
+
+    with pytest.raises(PlayerException):
+        Three(n_players=3, resample_policy="robin")
+    with pytest.raises(PlayerException):
+        Three(n_players=3, partners=[[Scripted()]])            # wrong number of seats
+    with pytest.raises(PlayerException):
+        Three(n_players=3, partners=[[Scripted()], []])        # empty seat list
+    env = Three(n_players=3)
+    with pytest.raises(PlayerException):
+        env.add_partner_agent(Scripted(), player_num=0)        # the ego seat is not a partner seat
+    env.add_partner_agent(Scripted(), player_num=2)
+    assert len(env.partners[0]) == 0 and len(env.partners[1]) == 1   # D-7: seats do not alias
+    env.add_partner_agent(Scripted(), player_num=1)
+    with pytest.raises(PlayerException):                       # game ends before the ego ever moves
+        env.reset()
+
+
+def test_turn_based_env_and_first_move_reward_handover():
+    class Count(TurnBasedEnv):
+        """ego and partner alternate; every move pays (1, 10); game ends after 4 moves"""
+
+        def __init__(self):
+            super().__init__(probegostart=1.0)
+            self.observation_space, self.action_space = Discrete(8), Discrete(2)
+            self.moves = 0
+
+        def _move(self):
+            self.moves += 1
+            return np.array([self.moves]), (1, 10), self.moves >= 4, {}
+
+        def ego_step(self, action):
+            return self._move()
+
+        def alt_step(self, action):
+            return self._move()
+
+        def multi_reset(self, egofirst):
+            self.moves = 0
+            return np.array([0])
+
+    env = Count()
+    p = Scripted()
+    env.add_partner_agent(p)
+    assert env.reset().tolist() == [0]
+    obs, rew, done, _ = env.step(0)           # ego move (1) then partner move (2)
+    assert (obs.tolist(), rew, done) == ([2], 2.0, False)
+    # partner's first action is credited the 10 it accrued during the ego's move (multiagentenv.py:158-159)
+    assert p.log == [("act", [1]), ("upd", 10, False), ("upd", 10, False)]
+    obs, rew, done, _ = env.step(0)           # ego move (3), partner move (4) ends the game
+    assert (rew, done) == (2.0, True) and obs.tolist() == [2]   # D-8: previous ego obs on done
+    assert p.log[-3:] == [("upd", 10, False), ("act", [3]), ("upd", 10, True)]
+
+    env2 = Count()
+    env2.probegostart = 0.0                   # partner moves first inside reset()
+    p2 = Scripted()
+    env2.add_partner_agent(p2)
+    assert env2.reset().tolist() == [1]
+    assert p2.log == [("act", [0]), ("upd", 0, False), ("upd", 10, False)]
+    _, rew, _, _ = env2.step(0)
+    assert rew == 1 + 1 + 1                   # ego_moved False: total_rews so far (1 from reset) + this round's 2
+
+
+# ---- OnPolicyAgent ---------------------------------------------------------------------------------------------------
+def test_onpolicy_agent_buffer_contents_and_train_before_act():
+    env = RPSEnv()
+    model = OraclePPO(env, n_steps=4, batch_size=4, n_epochs=1)
+    agent = OnPolicyAgent(model)
+    assert agent._last_episode_starts == [True] and list(model.ep_info_buffer) == [{"r": 0, "l": 0}]
+    obs = Observation(np.array([0]))
+    script = [(1.0, True), (0.5, False), (-1.0, True), (2.0, True)]
+    for rew, done in script:
+        a = agent.get_action(obs)
+        assert a in (0, 1, 2)
+        agent.update(0, False)      # multiple updates per action add up, last done wins (agents.py:44-47)
+        agent.update(rew, done)
+    buf = model.rollout_buffer
+    assert buf.full and model.train_calls == 0                      # D-3: nothing trained yet
+    assert buf.rewards.ravel().tolist() == [1.0, 0.5, -1.0, 2.0]
+    assert buf.episode_starts.ravel().tolist() == [1, 1, 0, 1]     # [True] initially, then the previous done
+    last_value = float(agent.values.reshape(-1)[0])
+    agent.get_action(obs)                                            # 5th action: GAE + train + reset first
+    assert model.train_calls == 1 and agent.iteration == 1 and agent.n_steps == 1 and buf.pos == 1
+    t = model.trained_on[0]
+    # D-1: the bootstrap is V(o_{T-1}) with dones = last done (True) -> A_{T-1} = r - V
+    assert abs(t["advantages"].ravel()[-1] - (2.0 - t["values"].ravel()[-1])) < 1e-6
+    assert abs(t["values"].ravel()[-1] - last_value) < 1e-7
+    # episode bookkeeping: three finished episodes + the one in progress
+    eps = list(model.ep_info_buffer)
+    assert [e["r"] for e in eps[:3]] == [1.0, -0.5, 2.0] and [e["l"] for e in eps[:3]] == [1, 2, 1]
+    # record=False still advances n_steps but writes no row (D-4)
+    agent.get_action(obs, record=False)
+    assert agent.n_steps == 2 and buf.pos == 1
+
+
+def test_rps_ppo_vs_ppo_preset_object_graph():
+    """trainer.py preset-1 graph (env, altenv=getDummyEnv(1), partner OnPolicyAgent(PPO(altenv))) on the oracle model:
+    partner trains at the NEXT get_action after its buffer fills."""
+    env = make("RPS-v0")
+    altenv = env.getDummyEnv(1)
+    assert altenv is env
+    partner = OnPolicyAgent(OraclePPO(altenv, n_steps=64, batch_size=64, n_epochs=1), tb_log_name="alt")
+    env.add_partner_agent(partner)
+    env.reset()
+    for _ in range(200):
+        _, _, done, _ = env.step(np.random.randint(3))
+        assert done
+        env.reset()
+    assert partner.num_timesteps == 200 and partner.model.train_calls == 3   # after steps 64, 128, 192
+    assert len(partner.model.ep_info_buffer) == 100
+
+
+def test_static_policy_agent_and_util_helpers():
+    env = make("LiarsDice-v0")
+    model = OraclePPO(env, n_steps=8)
+    agent = StaticPolicyAgent(model.policy)
+    act = agent.get_action(Observation(np.zeros(30)))
+    assert act.shape == (2,) and 0 <= act[0] < 7 and 0 <= act[1] < 12
+    agent.update(1.0, True)
+    assert util.get_space_size(Box(-1, 1, (5,))) == 5 and util.get_space_size(Discrete(4)) == 1
+    assert util.get_space_size(MultiBinary(3)) == 3 and util.get_space_size(MultiDiscrete([2, 3])) == 2
+    assert util.calculate_space(Discrete(4), 3).nvec.tolist() == [4, 4, 4]
+    assert util.calculate_space(MultiDiscrete([2, 3]), 2).nvec.tolist() == [2, 3, 2, 3]
+    assert util.calculate_space(Box(-1, 1, (2,)), 2).shape == (4,) and util.calculate_space(MultiBinary(2), 3).n == 6
+    with pytest.raises(SpaceException):
+        util.get_space_size(object())
+    assert util.get_default_obs(env) == [0] * 30
+    clipped = util.clip_actions(np.array([[5.0]]), type("P", (), {"action_space": Box(-1, 1, (1,))})())
+    assert clipped.tolist() == [[1.0]]
+
+
+# ---- Liar's Dice integer rules ---------------------------------------------------------------------------------------------
+def test_liars_dice_rules():
+    np.random.seed(0)
+    env = LiarEnv(probegostart=1.0)
+    env.add_partner_agent(LiarDefaultAgent())
+    obs = env.reset()
+    assert obs.shape == (30,) and obs[:6].sum() == 6 and obs[6:].tolist() == [6, 0] * 12
+    # opening "call" is sanitised to [0, 0]; a non-raising bid is a call
+    assert env.sanitize_action(np.array([6, 3])) == [0, 0]
+    env.history = [2, 4]
+    assert env.sanitize_action(np.array([1, 4])) == CALL and env.sanitize_action(np.array([6, 9])) == CALL
+    assert env.sanitize_action(np.array([1, 5])) == [1, 5]
+    env.egohand, env.althand = [0, 0, 3, 0, 3, 0], [0, 0, 2, 0, 4, 0]
+    env.history = [2, 4]       # "five 3s" (count stored minus one): exactly 5 on the table -> not a bluff
+    assert env.eval_bluff() is False
+    env.history = [2, 5]
+    assert env.eval_bluff() is True
+    # ego calls a bluff -> ego wins
+    _, rews, done, _ = env.player_step(np.array(CALL), True)
+    assert (rews, done) == ((1, -1), True)
+    env.history = [2, 4]
+    _, rews, done, _ = env.player_step(np.array(CALL), True)
+    assert (rews, done) == ((-1, 1), True)
+    # a full game through the MultiAgentEnv driver terminates with a +-1 reward
+    for _ in range(20):
+        env.reset()
+        total, done, steps = 0, False, 0
+        while not done:
+            _, r, done, _ = env.step(env.action_space.sample())
+            total += r
+            steps += 1
+        assert total in (1, -1) and steps <= 13
+    w = RPSWeightedAgent(r=1, p=0, s=0)
+    assert all(w.get_action(None) == 0 for _ in range(5))

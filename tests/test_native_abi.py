@@ -1,0 +1,100 @@
+"""not-gpu: the C-ABI library loads, exports every symbol include/pantheon_hip.h declares, its host-only entry points
+work, and it fails loudly (no CPU fallback) when no device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch as th
+
+from pantheonrl_amd import _native as nat
+from pantheonrl_amd import spaces as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "pantheon_hip.h")).read()
+DECLARED = sorted(set(re.findall(r"^(?:int|const char \*)\s*(ph_[a-z_0-9]+)\s*\(", HEADER, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = nat.load()
+    assert len(DECLARED) >= 25
+    for name in DECLARED:
+        assert hasattr(lib, name), f"{name} declared in include/pantheon_hip.h but not exported"
+    assert set(DECLARED) == set(nat.SIGNATURES), set(DECLARED) ^ set(nat.SIGNATURES)
+    assert lib.ph_abi_version() == 1
+    assert int(re.search(r"#define PH_NSTAT (\d+)", HEADER).group(1)) == nat.PH_NSTAT
+    assert int(re.search(r"#define PH_MAX_COMP (\d+)", HEADER).group(1)) == nat.PH_MAX_COMP
+
+
+def test_struct_sizes_match_the_header_layout():
+    assert C.sizeof(nat.PhSpace) == 4 * (2 + nat.PH_MAX_COMP)
+    assert C.sizeof(nat.PhSpec) == 2 * C.sizeof(nat.PhSpace)
+    assert C.sizeof(nat.PhLayout) == 4 * 17
+    assert C.sizeof(nat.PhRollout) == 8 + 8 * 8
+    assert C.sizeof(nat.PhPpoHyper) == 4 * 11
+    assert C.sizeof(nat.PhOptState) == 8 * 4
+
+
+@pytest.mark.parametrize("obs,act,expect", [
+    (sp.Discrete(1), sp.Discrete(3), dict(D=1, F=1, A=1, L=3, P=8836)),                                  # RPS
+    (sp.MultiDiscrete([7] * 6 + [7, 12] * 12), sp.MultiDiscrete([7, 12]), dict(D=30, F=270, A=2, L=19, P=44308)),
+    (sp.Box(-np.inf, np.inf, (62,)), sp.Discrete(6), dict(D=62, F=62, A=1, L=6, P=16839)),               # Overcooked
+    (sp.Box(-np.inf, np.inf, (48,)), sp.Discrete(5), dict(D=48, F=48, A=1, L=5, P=14982)),               # MPE N=8
+])
+def test_layout_matches_survey_parameter_counts(obs, act, expect):
+    lay = nat.layout_of(sp.make_spec(obs, act))
+    for k, v in expect.items():
+        assert getattr(lay, k) == v, k
+    assert lay.pi_W1 == 0 and lay.pi_b1 == lay.F * 64 and lay.val_b == lay.P - 1
+    assert lay.act_W + 64 * lay.L == lay.act_b and lay.val_W == lay.act_b + lay.L
+
+
+def test_bad_specs_are_rejected_with_a_message():
+    with pytest.raises(sp.SpaceException):
+        sp.make_spec(sp.Box(-1, 1, (3,)), sp.Box(-1, 1, (2,)))
+    spec = sp.make_spec(sp.Box(-1, 1, (3,)), sp.Discrete(4))
+    spec.act.nvec[0] = 0
+    with pytest.raises(nat.NativeError, match="nvec"):
+        nat.layout_of(spec)
+    spec = sp.make_spec(sp.Box(-1, 1, (3,)), sp.MultiDiscrete([40, 40]))
+    with pytest.raises(nat.NativeError, match="logits"):
+        nat.layout_of(spec)
+
+
+def test_feistel_permutation_is_a_bijection_and_keyed():
+    for n in (1, 2, 3, 5, 64, 100, 1000, 2048, 4097):
+        p = nat.feistel_indices(n, 11, 0)
+        assert sorted(p.tolist()) == list(range(n))
+        if n >= 64:
+            assert (p != nat.feistel_indices(n, 11, 1)).mean() > 0.9      # a fresh permutation per epoch
+            assert (p != nat.feistel_indices(n, 12, 0)).mean() > 0.9      # and per seed
+            assert np.array_equal(p[10:20], nat.feistel_indices(n, 11, 0, start=10, count=10))
+    big = nat.feistel_indices(131072, 3, 2)
+    assert len(np.unique(big)) == 131072
+    # crude uniformity: each quarter of the output draws evenly from each quarter of the input range
+    q = (big.reshape(4, -1) // 32768)
+    for row in q:
+        counts = np.bincount(row, minlength=4)
+        assert (np.abs(counts - 8192) < 400).all()
+    with pytest.raises(nat.NativeError):
+        nat.feistel_indices(10, 0, 0, start=5, count=6)
+
+
+@pytest.mark.skipif(th.cuda.is_available(), reason="checks the no-device error path")
+def test_no_cpu_fallback():
+    lib = nat.load()
+    h = C.c_void_p()
+    assert lib.ph_ctx_create(0, C.byref(h)) != 0 and not h.value
+    assert b"no HIP device" in lib.ph_last_error() or b"fallback" in lib.ph_last_error()
+    n = C.c_int(-1)
+    lib.ph_device_count(C.byref(n))
+    assert n.value == 0
+    from pantheonrl_amd import PPO
+    env = type("E", (), dict(observation_space=sp.Discrete(1), action_space=sp.Discrete(3)))()
+    with pytest.raises(nat.NativeError, match="no CPU fallback"):
+        PPO("MlpPolicy", env)
+    with pytest.raises(nat.NativeError, match="no CPU fallback"):
+        PPO("MlpPolicy", env, device="cpu")
+    # null-handle calls report an error instead of crashing
+    assert lib.ph_ctx_sync(None) != 0 and lib.ph_gae(None, None, None, None, 0.99, 0.95, 0) != 0

@@ -1,0 +1,207 @@
+"""not-gpu: the oracle against the closed-form known answers, against the properties SB3's
+algorithm must have, and against the committed golden vectors (tests/golden, made by make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch as th
+
+from oracle import sb3_oracle as orc
+from tests import helpers as H
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_gae_appendix_c_known_answers():
+    r = np.array([1, 0, 2, -1], np.float32)[:, None]
+    v = np.array([.5, .4, .3, .2], np.float32)[:, None]
+    s = np.array([1, 0, 1, 0], np.float32)[:, None]
+    cases = {  # (last_values, dones) -> (advantages, returns)
+        (0.1, 0): ([0.5198, -0.4, 0.86250937, -1.1010001], [1.0198, 0.0, 1.1625094, -0.9010001]),   # C-A  SB3 ego
+        (0.2, 0): ([0.5198, -0.4, 0.955619, -1.002], [1.0198, 0.0, 1.255619, -0.802]),              # C-B  quirk D-1
+        (0.2, 1): ([0.5198, -0.4, 0.7693999, -1.2], [1.0198, 0.0, 1.0693998, -1.0]),                # C-C  terminal
+    }
+    for (lv, dn), (adv, ret) in cases.items():
+        a, R = orc.gae_reference(r, v, s, [lv], [dn])
+        np.testing.assert_allclose(a.ravel(), adv, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(R.ravel(), ret, rtol=0, atol=1e-6)
+    # C-D: gamma = lambda = 1, V = 0, r = 1 -> reward-to-go
+    a, R = orc.gae_reference(np.ones((5, 1), np.float32), np.zeros((5, 1), np.float32), np.zeros((5, 1), np.float32),
+                             [0], [0], 1.0, 1.0)
+    assert a.ravel().tolist() == [5, 4, 3, 2, 1] and np.array_equal(a, R)
+
+
+def test_gae_python_bool_dones_like_onpolicyagent():
+    """OnPolicyAgent passes dones=self._last_episode_starts[0], a Python bool (agents.py:129)."""
+    rng = np.random.default_rng(0)
+    r, v = rng.standard_normal((9, 1)).astype(np.float32), rng.standard_normal((9, 1)).astype(np.float32)
+    s = np.zeros((9, 1), np.float32)
+    for flag in (True, False):
+        buf = orc.RolloutBufferOracle(9, 1, 1, 1)
+        buf.rewards[:], buf.values[:], buf.episode_starts[:] = r, v, s
+        buf.compute_returns_and_advantage(th.tensor([[0.3]]), flag)
+        a_ref, _ = orc.gae_reference(r, v, s, [0.3], [float(flag)])
+        assert np.array_equal(buf.advantages, a_ref)
+
+
+def test_gae_closed_forms():
+    g, lam, T = 0.99, 0.95, 50
+    a, _ = orc.gae_reference(np.ones((T, 2), np.float32), np.zeros((T, 2), np.float32), np.zeros((T, 2), np.float32),
+                             [0, 0], [0, 0], g, lam)
+    k = np.arange(T, 0, -1)
+    np.testing.assert_allclose(a[:, 0], (1 - (g * lam) ** k) / (1 - g * lam), rtol=1e-5)
+    a64, _ = orc.gae_float64(np.ones((T, 2)), np.zeros((T, 2)), np.zeros((T, 2)), [0, 0], [0, 0], g, lam)
+    np.testing.assert_allclose(a, a64, rtol=1e-5)
+
+
+def test_rollout_buffer_semantics():
+    buf = orc.RolloutBufferOracle(3, 2, 4, 1)
+    obs = np.arange(8, dtype=np.float32).reshape(2, 4)
+    buf.add(obs, np.array([[1], [2]]), [0, 0], [1, 1], th.tensor([[.5], [.25]]), th.tensor([-1., -2.]))
+    obs[:] = -1  # add() copied its inputs
+    assert buf.observations[0, 1, 3] == 7 and buf.pos == 1 and not buf.full
+    buf.rewards[buf.pos - 1][0] += 2.5   # Agent.update (agents.py:198)
+    buf.rewards[buf.pos - 1][0] += 1.0
+    assert buf.rewards[0, 0] == 3.5 and buf.rewards[0, 1] == 0
+    for _ in range(2):
+        buf.add(obs, np.array([[0], [0]]), [0, 0], [0, 0], th.zeros(2, 1), th.zeros(2))
+    assert buf.full
+    flat = buf.flat()   # env-major: row e*T + t
+    assert flat["observations"].shape == (6, 4) and flat["observations"][3, 3] == 7  # e=1, t=0
+    seen = np.concatenate([mb["old_values"].numpy() for mb in buf.get(4, np.arange(6))])
+    assert seen.shape == (6,)
+    sizes = [len(mb["returns"]) for mb in buf.get(4, np.arange(6))]
+    assert sizes == [4, 2]   # last minibatch may be short
+    buf.reset()
+    assert buf.pos == 0 and not buf.full and buf.rewards.sum() == 0
+
+
+@pytest.mark.parametrize("name", list(H.CONFIGS))
+def test_policy_shapes_param_counts_and_roundtrip(name):
+    obs_s, act_s = H.CONFIGS[name]
+    pol = H.oracle_policy(name, seed=1)
+    F, L = obs_s.flat_len, act_s.flat_len
+    expected = 2 * (F * 64 + 64 + 64 * 64 + 64) + 64 * L + L + 65
+    assert sum(p.numel() for p in pol.parameters()) == expected == len(pol.flat_params())
+    if name == "overcooked":
+        assert expected == 16839
+    if name == "liar":
+        assert expected == 44308
+    other = H.oracle_policy(name, seed=2)
+    other.load_flat_params(pol.flat_params())
+    obs = th.as_tensor(H.sample_obs(obs_s, 5, np.random.default_rng(0)))
+    with th.no_grad():
+        assert th.equal(other.logits(obs), pol.logits(obs))
+        a, v, lp = pol.forward(obs, uniforms=th.rand(5, act_s.stored_len))
+        v2, lp2, ent = pol.evaluate_actions(obs, a)
+    assert a.shape == (5, act_s.stored_len) and v.shape == (5, 1) and lp.shape == (5,)
+    assert th.allclose(lp, lp2) and th.equal(v, v2) and (ent > 0).all()
+
+
+def test_orthogonal_init_gains():
+    th.manual_seed(0)
+    pol = orc.MlpPolicyOracle(*H.CONFIGS["overcooked"])
+    w = pol.policy_net[2].weight.detach()             # 64x64 orthogonal * sqrt(2)
+    assert th.allclose(w @ w.t(), 2 * th.eye(64), atol=1e-4)
+    wa = pol.action_net.weight.detach()               # 6x64, gain 0.01
+    assert th.allclose(wa @ wa.t(), 1e-4 * th.eye(6), atol=1e-7)
+    assert all(float(m.bias.detach().abs().max()) == 0 for m in pol.modules() if isinstance(m, th.nn.Linear))
+    assert pol.optimizer.defaults["eps"] == 1e-5 and pol.optimizer.defaults["betas"] == (0.9, 0.999)
+
+
+def test_ppo_first_minibatch_closed_forms():
+    """first minibatch of the first epoch: policy unchanged => ratio == 1, clip_fraction 0, approx_kl 0, policy loss
+    -mean(A_hat) == 0."""
+    name = "mpe8"
+    pol = H.oracle_policy(name, seed=3)
+    buf = H.filled_oracle_buffer(name, pol, 16, 4, seed=3)
+    hp = orc.PPOHyper(batch_size=32, n_epochs=1)
+    stats = orc.ppo_train(pol, buf, hp, [np.arange(64)])
+    assert stats[0]["clip_fraction"] == 0.0 and abs(stats[0]["approx_kl"]) < 1e-7
+    assert abs(stats[0]["policy_loss"]) < 1e-6
+    assert stats[0]["grad_norm"] > 0 and len(stats) == 2
+
+
+def test_ppo_matches_hand_written_gradient():
+    """the autograd oracle equals the closed-form gradient the kernels implement (min/clamp tie rule included)."""
+    name = "overcooked"
+    pol = H.oracle_policy(name, seed=4)
+    buf = H.filled_oracle_buffer(name, pol, 8, 4, seed=4)
+    hp = orc.PPOHyper(batch_size=32, ent_coef=0.02, clip_range=0.15)
+    # move the policy off the behaviour policy so some ratios leave the clip range
+    with th.no_grad():
+        pol.action_net.weight.add_(0.5 * th.randn(pol.action_net.weight.shape, generator=th.Generator().manual_seed(0)))
+    flat = buf.flat()
+    mb = {k: th.as_tensor(v) for k, v in flat.items()}
+    z = pol.logits(mb["observations"]).detach().requires_grad_(True)
+    dist = th.distributions.Categorical(logits=z)
+    acts = mb["actions"].long().flatten()
+    logp, ent = dist.log_prob(acts), dist.entropy()
+    adv = mb["advantages"]
+    adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+    ratio = th.exp(logp - mb["old_log_prob"])
+    loss = -th.min(adv * ratio, adv * th.clamp(ratio, 1 - hp.clip_range, 1 + hp.clip_range)).mean() \
+        - hp.ent_coef * ent.mean()
+    loss.backward()
+    with th.no_grad():
+        B = len(adv)
+        p = th.softmax(z, 1)
+        lo, hi = 1 - hp.clip_range, 1 + hp.clip_range
+        pl1, pl2 = adv * ratio, adv * th.clamp(ratio, lo, hi)
+        inr = ((ratio >= lo) & (ratio <= hi)).float()
+        gate = th.where(pl1 < pl2, th.ones_like(inr), th.where(pl1 > pl2, inr, 0.5 + 0.5 * inr))
+        g_lp = -(adv * ratio * gate) / B
+        onehot = th.nn.functional.one_hot(acts, z.shape[1]).float()
+        lpa = th.log_softmax(z, 1)
+        H_ = -(p * lpa).sum(1, keepdim=True)
+        dz = g_lp[:, None] * (onehot - p) + (-hp.ent_coef / B) * (-p * (lpa + H_))
+    assert ((ratio < lo) | (ratio > hi)).any(), "test must exercise clipped rows"
+    assert th.allclose(z.grad, dz, atol=1e-8, rtol=1e-5)
+
+
+def test_inverse_cdf_and_illegal_fixup():
+    probs = th.tensor([[0.2, 0.3, 0.5], [1.0, 0.0, 0.0]])
+    assert orc.inverse_cdf_sample(probs, th.tensor([0.1, 0.99])).tolist() == [0, 0]
+    assert orc.inverse_cdf_sample(probs, th.tensor([0.2, 0.0])).tolist() == [1, 0]
+    assert orc.inverse_cdf_sample(probs, th.tensor([0.75, 0.5])).tolist() == [2, 0]
+    acts = orc.fix_illegal_actions(np.array([0, 2, 1]), np.array([[0, 1, 1], [1, 0, 1], [0, 0, 1]]))
+    assert acts.tolist() == [1, 2, 2]   # first legal index (pettingzoo.py:81-82)
+
+
+# ---- golden vectors --------------------------------------------------------------------------------------------------
+def test_oracle_reproduces_golden_gae():
+    g = np.load(os.path.join(GOLD, "gae.npz"))
+    for i in range(int(g["n_cases"])):
+        a, ret = orc.gae_reference(g[f"c{i}_r"], g[f"c{i}_v"], g[f"c{i}_s"], g[f"c{i}_lv"], g[f"c{i}_dn"])
+        assert np.array_equal(a, g[f"c{i}_adv"]) and np.array_equal(ret, g[f"c{i}_ret"])
+
+
+def test_oracle_reproduces_golden_forward():
+    g = np.load(os.path.join(GOLD, "forward.npz"))
+    for name in ("rps", "liar", "overcooked", "mpe8"):
+        pol = orc.MlpPolicyOracle(*H.CONFIGS[name])
+        pol.load_flat_params(g[f"{name}_params"])
+        obs = th.as_tensor(g[f"{name}_obs"])
+        with th.no_grad():
+            z = pol.logits(obs).numpy()
+            a, v, lp = pol.forward(obs, uniforms=th.as_tensor(g[f"{name}_u"]))
+        np.testing.assert_allclose(z, g[f"{name}_logits"], atol=2e-6)
+        np.testing.assert_allclose(v.numpy().ravel(), g[f"{name}_values"], atol=2e-6)
+        assert np.array_equal(a.numpy(), g[f"{name}_actions"])
+        np.testing.assert_allclose(lp.numpy(), g[f"{name}_logp"], atol=2e-6)
+
+
+def test_oracle_reproduces_golden_ppo_step():
+    g = np.load(os.path.join(GOLD, "ppo_step.npz"))
+    pol = orc.MlpPolicyOracle(*H.CONFIGS["overcooked"])
+    pol.load_flat_params(g["params0"])
+    buf = orc.RolloutBufferOracle(16, 4, 62, 1)
+    for k in ("observations", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns"):
+        getattr(buf, k)[...] = g["rb_" + k]
+    buf.full = True
+    stats = orc.ppo_train(pol, buf, orc.PPOHyper(batch_size=24, n_epochs=2), g["perms"])
+    assert len(stats) == 6
+    got = np.array([[s[k] for k in ("policy_loss", "value_loss", "entropy_loss", "clip_fraction", "approx_kl", "loss",
+                                     "grad_norm")] for s in stats], np.float32)
+    np.testing.assert_allclose(got, g["stats"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(pol.flat_params(), g["params1"], atol=1e-6)
