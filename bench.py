@@ -27,6 +27,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 OBS_DIM, N_ACTIONS, HORIZON = 62, 6, 400   # Overcooked-simple shapes
+_T0 = time.perf_counter()
+
+
+def log(msg: str) -> None:
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:7.2f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores() -> int:
+    """host cores this process may actually use: affinity mask, capped by a cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:  # noqa: BLE001
+            pass
+    return max(1, n)
 
 
 def parse():
@@ -67,8 +92,9 @@ def cpu_baseline(args):
     """the oracle executed SB3-style (per-step add with host copies, Python-loop GAE, eager autograd) on the host
     cores of this box: ONE iteration of ONE agent at the same sizes (a bounded sample of the workload)."""
     from oracle.sb3_oracle import (MlpPolicyOracle, PPOHyper, RolloutBufferOracle, SpaceSpec, synthetic_iteration)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     th.set_num_threads(cores)
+    log(f"cpu_baseline: oracle on {cores} host threads (os.cpu_count()={os.cpu_count()})")
     T, E = args.n_steps, args.n_envs
     th.manual_seed(0)
     pol = MlpPolicyOracle(SpaceSpec("box", dim=OBS_DIM), SpaceSpec("discrete", nvec=(N_ACTIONS,)))
@@ -82,6 +108,7 @@ def cpu_baseline(args):
     synthetic_iteration(pol, buf, hp, obs, rew, done)
     dt = time.perf_counter() - t0
     return {"value": T * E / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+            "os_cpu_count": os.cpu_count(),
             "sample": f"1 PPO iteration of 1 agent (n_envs={E}, n_steps={T}, batch={args.batch_size}, "
                       f"n_epochs={args.n_epochs}) = {T * E} agent-steps in {dt:.2f}s, torch threads={cores}"}
 
@@ -134,7 +161,9 @@ def main():
     import torch.distributed as tdist
 
     from pantheonrl_amd.vec import IterationGraph, run_iteration_eager
+    log(f"building {args.agents_per_gpu} agents, n_envs={args.n_envs}, n_steps={args.n_steps}, batch={args.batch_size}")
     agents, datas = build_agents(args, device)
+    log("agents built")
     streams = [th.cuda.Stream(device=device) for _ in agents]
     mode = args.mode
     if mode == "auto":
@@ -176,14 +205,17 @@ def main():
             tdist.barrier()
             th.cuda.synchronize(device)
 
+    log(f"mode={mode}; warmup x{args.warmup}")
     for _ in range(args.warmup):
         iteration()
     barrier()
+    log(f"timing x{args.steps}")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         iteration()
     barrier()
     dt = time.perf_counter() - t0
+    log(f"timed region {dt:.3f}s")
     if distributed:
         tmax = th.tensor([dt], dtype=th.float64, device=device)
         tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
@@ -206,6 +238,7 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             result["roofline"] = roofline(args, agents[0])
+            log("roofline measured")
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(args)
             result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]

@@ -127,6 +127,7 @@ class IterationGraph:
         agent.model.device_permutations = True   # in-kernel Feistel permutations: nothing host-generated per replay
         with th.cuda.stream(stream):
             run_iteration_eager(agent, data)     # warm-up outside capture: sizes the workspace, caches the spec
+            run_iteration_eager(agent, data)
             stream.synchronize()
             agent.bind_stream()
             lib, h = pol.ctx.lib, pol.ctx.handle

@@ -324,8 +324,8 @@ def test_minibatch_gradient_options_and_valu_cross_check():
     _assert_grads(g, g_ref, lay)
     g1 = _grad_pair("overcooked", 16, 8, idx, hp, gemm_mode=1)[0]
     assert np.array_equal(g, g1), np.abs(g - g1).max()   # MFMA == fmaf chain, bitwise
-    g2, g2_ref, *_ = _grad_pair("liar", 16, 6, idx[:90], hp)
-    _assert_grads(g2, g2_ref, lay)
+    g2, g2_ref, _, _, lay2 = _grad_pair("liar", 16, 6, idx[idx < 96][:70], hp)
+    _assert_grads(g2, g2_ref, lay2)
 
 
 def _train_pair(name, T, E, hp: orc.PPOHyper, seed=21, device_perms=False):
