@@ -441,7 +441,7 @@ def test_rps_ppo_vs_ppo_plumbing():
     env.add_partner_agent(partner)
     ego.learn(total_timesteps=1000)
     assert ego.num_timesteps == 1024                      # 4 rollouts of 256
-    assert partner.num_timesteps == 1024 + 1              # one action per ego step + the post-done reset... see below
+    assert partner.num_timesteps == 1024                  # one partner action per ego step (simultaneous game)
     assert partner.iteration == 3                          # trains at the NEXT get_action after its buffer fills (D-3)
     assert int(ego.policy.opt_step.item()) == 4 * 10 * 4  # 4 updates x 10 epochs x 4 minibatches of 64
     assert len(ego.ep_info_buffer) == 100 and all(e["l"] == 1 for e in ego.ep_info_buffer)
