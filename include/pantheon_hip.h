@@ -149,12 +149,15 @@ int ph_gae(ph_ctx *ctx, const ph_rollout *rb, const float *last_values /* (E) */
  *  deterministic != 0           : argmax
  * Outputs (any may be NULL): actions_i32 (n,A), actions_f32 (n,A), values (n), log_probs (n), entropy (n), logits (n,L).
  * When rb != NULL the transition is also written at row `pos` of the rollout buffer (fused RolloutBuffer.add with
- * reward 0 and episode_start = episode_start_in) -- n must equal rb->E. */
+ * reward 0 and episode_start = episode_start_in) -- n must equal rb->E; if pending_reward (E) is also given, it is
+ * added to row pos-1's rewards in the same launch (the previous step's Agent.update, agents.py:198, folded in).
+ * params must be 16-byte aligned. */
 int ph_policy_forward(ph_ctx *ctx, const ph_spec *spec, const float *params, const float *obs, int n,
                       const unsigned char *action_mask, const float *uniforms, const float *given_actions,
                       unsigned long long seed, unsigned long long counter, int deterministic, int *actions_i32,
                       float *actions_f32, float *values, float *log_probs, float *entropy, float *logits,
-                      const ph_rollout *rb, int pos, const float *episode_start_in, int gemm_mode);
+                      const ph_rollout *rb, int pos, const float *episode_start_in, const float *pending_reward,
+                      int gemm_mode);
 
 /* env-side illegal-action fix-up: action not legal -> first legal index <- pettingzoo.py:81-82.  Integer, bit-exact. */
 int ph_fix_illegal_actions(ph_ctx *ctx, int *actions /* (n) in/out */, const unsigned char *action_mask /* (n,L) */,

@@ -77,7 +77,7 @@ SIGNATURES = {
     "ph_buffer_reset": [_vp, C.POINTER(PhSpec), C.POINTER(PhRollout)],
     "ph_gae": [_vp, C.POINTER(PhRollout), _vp, _vp, _d, _d, _i],
     "ph_policy_forward": [_vp, C.POINTER(PhSpec), _vp, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, _vp, _vp,
-                          _vp, C.POINTER(PhRollout), _i, _vp, _i],
+                          _vp, C.POINTER(PhRollout), _i, _vp, _vp, _i],
     "ph_fix_illegal_actions": [_vp, _vp, _vp, _i, _i],
     "ph_ppo_train": [_vp, C.POINTER(PhSpec), C.POINTER(PhOptState), C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i,
                      _vp, _ull, _vp, _i],

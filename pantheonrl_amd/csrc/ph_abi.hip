@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdint>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -44,6 +45,8 @@ struct ph_ctx {
   size_t slabs_cap = 0;
   float* statpart = nullptr;
   size_t statpart_cap = 0;
+  float* folded = nullptr;  // [FOLD_G][P] first-level slab sums
+  size_t folded_cap = 0;
   float* grad = nullptr;
   size_t grad_cap = 0;
   float* blocksq = nullptr;
@@ -219,7 +222,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (s.obs_off) (void)hipFree(s.obs_off);
     if (s.act_off) (void)hipFree(s.act_off);
   }
-  void* ptrs[] = {ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->scalars, ctx->stop_flag};
+  void* ptrs[] = {ctx->slabs, ctx->folded, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->scalars, ctx->stop_flag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -353,9 +356,11 @@ int ph_policy_forward(ph_ctx* ctx, const ph_spec* spec, const float* params, con
                       const unsigned char* action_mask, const float* uniforms, const float* given_actions,
                       unsigned long long seed, unsigned long long counter, int deterministic, int* actions_i32,
                       float* actions_f32, float* values, float* log_probs, float* entropy, float* logits,
-                      const ph_rollout* rb, int pos, const float* episode_start_in, int gemm_mode) {
+                      const ph_rollout* rb, int pos, const float* episode_start_in, const float* pending_reward,
+                      int gemm_mode) {
   if (!ctx) return fail("null ctx");
   if (!params || !obs) return fail("ph_policy_forward: null params/obs");
+  if ((uintptr_t)params % 16 != 0) return fail("ph_policy_forward: params must be 16-byte aligned");
   if (n <= 0) return fail("ph_policy_forward: n must be positive");
   ph::FwdArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -389,6 +394,13 @@ int ph_policy_forward(ph_ctx* ctx, const ph_spec* spec, const float* params, con
     a.rb_val = rb->values + row;
     a.rb_logp = rb->log_probs + row;
     a.es_in = episode_start_in;
+    if (pending_reward) {
+      if (pos < 1) return fail("ph_policy_forward: pending_reward needs pos >= 1");
+      a.prev_rew = rb->rewards + (row - rb->E);
+      a.pending_reward = pending_reward;
+    }
+  } else if (pending_reward) {
+    return fail("ph_policy_forward: pending_reward needs the fused rollout-buffer write");
   }
   PH_HIP(ph::launch_policy_fwd(a, gemm_mode, ctx->stream));
   return 0;
@@ -404,6 +416,9 @@ int ph_fix_illegal_actions(ph_ctx* ctx, int* actions, const unsigned char* actio
 
 // ---- K3 + K5 + K6 ----
 namespace {
+
+constexpr int FOLD_G = 16;   // first-level slab groups
+constexpr int FOLD_MIN = 32; // fold only when at least this many slabs
 
 struct MbPlan {
   int nb, ntiles, nwg;
@@ -448,6 +463,7 @@ int ensure_train_ws(ph_ctx* ctx, int P, int nwg_max, int n_mb_total) {
   }
   if (ensure(ctx->slabs, ctx->slabs_cap, (size_t)nwg_max * P)) return 1;
   if (ensure(ctx->statpart, ctx->statpart_cap, (size_t)2 * nwg_max * ph::NSTATP)) return 1;
+  if (ensure(ctx->folded, ctx->folded_cap, (size_t)FOLD_G * P)) return 1;
   if (ensure(ctx->grad, ctx->grad_cap, (size_t)P)) return 1;
   if (ensure(ctx->blocksq, ctx->blocksq_cap, (size_t)(P + 255) / 256)) return 1;
   if (ensure(ctx->advstats, ctx->advstats_cap, (size_t)n_mb_total * 2)) return 1;
@@ -461,6 +477,7 @@ int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, cons
                  unsigned long long perm_seed, float* stats, int gemm_mode) {
   if (!ctx) return fail("null ctx");
   if (!opt || !opt->params || !opt->adam_m || !opt->adam_v || !opt->step) return fail("ph_ppo_train: null optimizer state");
+  if ((uintptr_t)opt->params % 16 != 0) return fail("ph_ppo_train: params must be 16-byte aligned");
   if (!hp) return fail("ph_ppo_train: null hyper-parameters");
   if (check_rb(rb)) return 1;
   if (n_epochs <= 0 || batch_size <= 0) return fail("ph_ppo_train: n_epochs and batch_size must be positive");
@@ -515,6 +532,12 @@ int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, cons
       ph::ReduceArgs r;
       r.slabs = ctx->slabs;
       r.nslab = pl.nwg;
+      if (pl.nwg >= FOLD_MIN) {
+        PH_HIP(ph::launch_slab_fold(ctx->slabs, pl.nwg, P, ctx->folded, FOLD_G, ctx->stop_flag, s));
+        r.slabs = ctx->folded;
+        r.nslab = FOLD_G;
+      }
+      r.nstatpart = 2 * pl.nwg;
       r.P = P;
       r.grad = ctx->grad;
       r.blocksq = ctx->blocksq;
@@ -557,6 +580,7 @@ int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params,
                           int gemm_mode) {
   if (!ctx) return fail("null ctx");
   if (!params || !hp || !indices || !grad_out) return fail("ph_ppo_minibatch_grad: null argument");
+  if ((uintptr_t)params % 16 != 0) return fail("ph_ppo_minibatch_grad: params must be 16-byte aligned");
   if (check_rb(rb)) return 1;
   if (nb <= 0) return fail("ph_ppo_minibatch_grad: nb must be positive");
   ph::NetDims nd;
@@ -591,6 +615,12 @@ int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params,
   ph::ReduceArgs r;
   r.slabs = ctx->slabs;
   r.nslab = pl.nwg;
+  if (pl.nwg >= FOLD_MIN) {
+    PH_HIP(ph::launch_slab_fold(ctx->slabs, pl.nwg, P, ctx->folded, FOLD_G, ctx->stop_flag, s));
+    r.slabs = ctx->folded;
+    r.nslab = FOLD_G;
+  }
+  r.nstatpart = 2 * pl.nwg;
   r.P = P;
   r.grad = grad_out;
   r.blocksq = ctx->blocksq;

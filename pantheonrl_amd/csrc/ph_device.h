@@ -120,26 +120,31 @@ struct NetDims {
 };
 
 // Fill dst[R][LDH] with features [c*64, c*64+64) of the R rows whose physical row index is rowphys[r]
-// (-1 = padding row -> zeros).  Box: straight copy (coalesced along the row).  Discrete family: one-hot.
-// Caller must __syncthreads() before (dst free) and after (dst ready).
-template <int R>
+// (-1 = padding row -> zeros).  Box: straight copy, one 256-byte row segment per wave-instruction; every lane issues
+// all of its R*64/NT loads before the first LDS store, so a tile costs ONE memory latency, not R*64/NT of them.
+// Discrete family: one-hot.  Caller must __syncthreads() before (dst free) and after (dst ready).
+template <int R, int NT>
 __device__ __forceinline__ void load_x_chunk(float* dst, const int* rowphys, const float* obs, const NetDims& nd,
                                              int c) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x;
   const int base = c * HID;
   if (nd.obs_kind == PH_SPACE_BOX) {
-    for (int e = tid; e < R * HID; e += nt) {
-      const int r = e >> 6, kk = e & 63;
+    constexpr int ITERS = R * HID / NT;
+    float v[ITERS];
+    const int kk = tid & 63, f = base + kk;
+    const bool fok = f < nd.F;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int r = (tid + NT * i) >> 6;
       const int ph_row = rowphys[r];
-      const int f = base + kk;
-      float v = 0.f;
-      if (ph_row >= 0 && f < nd.F) v = obs[(size_t)ph_row * nd.D + f];
-      dst[r * LDH + kk] = v;
+      v[i] = (ph_row >= 0 && fok) ? obs[(size_t)ph_row * nd.D + f] : 0.f;
     }
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) dst[((tid + NT * i) >> 6) * LDH + kk] = v[i];
   } else {
-    for (int e = tid; e < R * HID; e += nt) dst[(e >> 6) * LDH + (e & 63)] = 0.f;
+    for (int e = tid; e < R * HID; e += NT) dst[(e >> 6) * LDH + (e & 63)] = 0.f;
     __syncthreads();
-    for (int e = tid; e < R * nd.D; e += nt) {
+    for (int e = tid; e < R * nd.D; e += NT) {
       const int r = e / nd.D, comp = e - r * nd.D;
       const int ph_row = rowphys[r];
       if (ph_row < 0) continue;
@@ -152,12 +157,27 @@ __device__ __forceinline__ void load_x_chunk(float* dst, const int* rowphys, con
   }
 }
 
-// rows [c*64, c*64+64) of an input-major weight matrix W[F][64] -> dst[64][LDH]; rows >= F are zero.
+// rows [row0, row0+64) of an input-major weight matrix W[nrows_total][64] -> dst[64][LDH]; rows >= nrows_total are
+// zero.  16-byte global loads (W rows are 256-byte aligned relative to the 16-byte aligned parameter vector), all
+// issued before the LDS stores.
+template <int NT>
 __device__ __forceinline__ void load_w_rows(float* dst, const float* W, int row0, int nrows_total) {
-  for (int e = threadIdx.x; e < HID * HID; e += blockDim.x) {
-    const int kk = e >> 6, j = e & 63;
+  constexpr int ITERS = HID * HID / 4 / NT;
+  float4 v[ITERS];
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int q = tid + NT * i;          // float4 index inside the 64x64 block
+    const int kk = q >> 4;
     const int k = row0 + kk;
-    dst[kk * LDH + j] = (k < nrows_total) ? W[(size_t)k * HID + j] : 0.f;
+    v[i] = (k < nrows_total) ? *reinterpret_cast<const float4*>(W + (size_t)k * HID + ((q & 15) << 2))
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int q = tid + NT * i;
+    float* d = dst + (q >> 4) * LDH + ((q & 15) << 2);
+    d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
   }
 }
 

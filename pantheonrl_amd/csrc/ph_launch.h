@@ -29,6 +29,8 @@ struct FwdArgs {
   float* rb_val;
   float* rb_logp;
   const float* es_in;
+  float* prev_rew;              // rewards row pos-1, or null
+  const float* pending_reward;  // (E) added to prev_rew (Agent.update folded into the next step's launch)
 };
 
 struct GradArgs {
@@ -82,7 +84,8 @@ struct ReduceArgs {
   int nslab, P;
   float* grad;
   float* blocksq;        // [gridDim.x]
-  const float* statpart; // [2*nslab][NSTATP]
+  const float* statpart; // [nstatpart][NSTATP] per-workgroup partial sums of the grad kernel
+  int nstatpart;
   float* stats_out;      // [PH_NSTAT] for this minibatch, or null
   int nb;
   float ent_coef, vf_coef, target_kl;
@@ -118,6 +121,8 @@ hipError_t launch_reward_add(float* rew_row, const float* reward, const unsigned
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s);
+hipError_t launch_slab_fold(const float* slabs, int nslab, int P, float* folded, int G, const int* stop_flag,
+                            hipStream_t s);
 hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_set_int(int* p, int v, hipStream_t s);
 hipError_t launch_epoch_advance(unsigned long long* p, hipStream_t s);

@@ -49,14 +49,14 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
       bos[tid] = a.params[lay.val_W + tid];
     }
   }
-  load_w_rows(w2s, W2, 0, HID);
+  load_w_rows<R * 4>(w2s, W2, 0, HID);
   __syncthreads();
 
   // ---- layer 1: Z1 = X * W1 (feature chunks of 64 accumulated in the MFMA accumulator) ----
   f32x16 acc = {0};
   for (int c = 0; c < nd.nchunk; ++c) {
-    load_x_chunk<R>(bufA, rowphys, a.obs, nd, c);
-    load_w_rows(regW, W1, c * HID, nd.F);
+    load_x_chunk<R, R * 4>(bufA, rowphys, a.obs, nd, c);
+    load_w_rows<R * 4>(regW, W1, c * HID, nd.F);
     __syncthreads();
     acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc);
     __syncthreads();
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
         a.rb_val[g] = v;
         a.rb_rew[g] = 0.f;
         a.rb_es[g] = a.es_in[g];
+        if (a.pending_reward) a.prev_rew[g] += a.pending_reward[g];
       }
     }
     if (a.rb_obs) {  // RolloutBuffer.add copies the observation (agents.py:172-173)

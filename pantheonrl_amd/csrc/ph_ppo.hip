@@ -73,7 +73,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       bos[tid] = a.params[lay.val_W + tid];
     }
   }
-  load_w_rows(w2s, a.params + oW2, 0, HID);
+  load_w_rows<R * 4>(w2s, a.params + oW2, 0, HID);
 
   float st[NSTATP];
 #pragma unroll
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     // ---- S1: Z1 = X W1 over feature chunks; H1 = tanh(Z1 + b1) -> bufB ----
     f32x16 acc = {0};
     for (int c = 0; c < nd.nchunk; ++c) {
-      load_x_chunk<R>(bufA, rowphys, a.rb_obs, nd, c);
-      load_w_rows(regW, a.params + oW1, c * HID, nd.F);
+      load_x_chunk<R, R * 4>(bufA, rowphys, a.rb_obs, nd, c);
+      load_w_rows<R * 4>(regW, a.params + oW1, c * HID, nd.F);
       __syncthreads();
       acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc);
       __syncthreads();
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       slab[oB1 + tid] = s;
     }
     for (int c = 0; c < nd.nchunk; ++c) {
-      load_x_chunk<R>(bufA, rowphys, a.rb_obs, nd, c);
+      load_x_chunk<R, R * 4>(bufA, rowphys, a.rb_obs, nd, c);
       __syncthreads();
       f32x16 g = {0};
       if (!first) {
@@ -403,8 +403,7 @@ hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_
 
 // ---- advantage statistics of every minibatch of a train() call: mean and unbiased std (torch .mean()/.std()) ----
 __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
-  __shared__ double sh[1024 / 64];
-  __shared__ double bcast;
+  __shared__ double sh[2][1024 / 64];
   const int mb = blockIdx.x;
   const int ep = mb / a.n_mb, k = mb - ep * a.n_mb;
   const int start = k * a.batch;
@@ -412,35 +411,38 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
   const uint64_t key = epoch_key(a.perm_seed + (a.epoch ? *a.epoch : 0ull), ep);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto value = [&](int i) -> double {
+    if (i >= nb) return 0.0;
     const int n = a.perms ? a.perms[(size_t)ep * a.N + start + i]
                           : (int)feistel_perm((uint32_t)(start + i), a.perm_n, a.perm_hb, key);
     return (double)a.rb_adv[env_major_to_phys(n, a.T, a.E)];
   };
-  auto block_sum = [&](double v) -> double {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    __syncthreads();
-    if (lane == 0) sh[wave] = v;
-    __syncthreads();
-    if (tid == 0) {
-      double t = 0.0;
-      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
-      bcast = t;
-    }
-    __syncthreads();
-    return bcast;
-  };
-  double s = 0.0;
-  for (int i = tid; i < nb; i += blockDim.x) s += value(i);
-  const double mean = block_sum(s) / (double)nb;
-  double q = 0.0;
-  for (int i = tid; i < nb; i += blockDim.x) {
-    const double d = value(i) - mean;
-    q += d * d;
+  // one pass: sum and sum of squares in fp64 (exact products of f32 values), 4 independent gathers per round
+  double s = 0.0, q = 0.0;
+  for (int i = tid; i < nb; i += 4 * 1024) {
+    const double v0 = value(i), v1 = value(i + 1024), v2 = value(i + 2048), v3 = value(i + 3072);
+    s += (v0 + v1) + (v2 + v3);
+    q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
   }
-  const double ss = block_sum(q);
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    q += __shfl_down(q, off, 64);
+  }
+  if (lane == 0) {
+    sh[0][wave] = s;
+    sh[1][wave] = q;
+  }
+  __syncthreads();
   if (tid == 0) {
+    double ts = 0.0, tq = 0.0;
+    for (int w = 0; w < 1024 / 64; ++w) {
+      ts += sh[0][w];
+      tq += sh[1][w];
+    }
+    const double mean = ts / (double)nb;
+    double var = (nb > 1) ? (tq - (double)nb * mean * mean) / (double)(nb - 1) : 0.0;
+    if (var < 0.0) var = 0.0;
     a.out[2 * mb + 0] = (float)mean;
-    a.out[2 * mb + 1] = (nb > 1) ? (float)sqrt(ss / (double)(nb - 1)) : 0.f;
+    a.out[2 * mb + 1] = (float)sqrt(var);
   }
 }
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s) {
@@ -449,8 +451,33 @@ hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s) {
 }
 
 // ---- slab reduction: grad[p] = sum_g slab[g][p] (fixed order), per-block sum of squares, minibatch statistics ----
+// pass A (only when there are many slabs): grid (ceil(P/256), G); block (bx, g) sums its contiguous group of slabs
+// into partial slab g -- 8 independent loads in flight per lane, so 256 slabs cost a few memory latencies, not 64.
+__global__ __launch_bounds__(256) void ppo_slab_fold_kernel(const float* __restrict__ slabs, int nslab, int P,
+                                                            float* __restrict__ folded, int G,
+                                                            const int* __restrict__ stop_flag) {
+  if (*stop_flag != 0) return;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int g = blockIdx.y;
+  const int per = (nslab + G - 1) / G;
+  const int k0 = g * per, k1 = (k0 + per < nslab) ? k0 + per : nslab;
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  int k = k0;
+  for (; k + 7 < k1; k += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += slabs[(size_t)(k + u) * P + p];
+  }
+  for (; k < k1; ++k) acc[0] += slabs[(size_t)k * P + p];
+  folded[(size_t)g * P + p] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+}
+
+// pass B: grad[p] = sum_g slab[g][p] (fixed order), per-block sum of squares, minibatch statistics, KL decision
 __global__ __launch_bounds__(256) void ppo_reduce_kernel(ReduceArgs a) {
   __shared__ float sh[4];
+  __shared__ float part[32][NSTATP];
   __shared__ float means[NSTATP];
   const int tid = threadIdx.x;
   if (*a.stop_flag != 0) {  // a previous minibatch of this train() call hit the KL early stop
@@ -483,9 +510,16 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(ReduceArgs a) {
   if (tid == 0) a.blocksq[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 
   if (blockIdx.x == 0) {  // minibatch statistics: means over the nb rows (block-uniform branch)
+    {  // 32 lanes per statistic, strided over the workgroup partials, then a fixed-order fold
+      const int kst = tid & (NSTATP - 1), j = tid >> 3;
+      float v = 0.f;
+      for (int w = j; w < a.nstatpart; w += 32) v += a.statpart[(size_t)w * NSTATP + kst];
+      part[j][kst] = v;
+    }
+    __syncthreads();
     if (tid < NSTATP) {
       float v = 0.f;
-      for (int w = 0; w < 2 * a.nslab; ++w) v += a.statpart[(size_t)w * NSTATP + tid];
+      for (int j = 0; j < 32; ++j) v += part[j][tid];
       means[tid] = v / (float)a.nb;
     }
     __syncthreads();
@@ -508,6 +542,12 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(ReduceArgs a) {
       }
     }
   }
+}
+hipError_t launch_slab_fold(const float* slabs, int nslab, int P, float* folded, int G, const int* stop_flag,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(ppo_slab_fold_kernel, dim3((P + 255) / 256, G), dim3(256), 0, s, slabs, nslab, P, folded, G,
+                     stop_flag);
+  return hipGetLastError();
 }
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(ppo_reduce_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);

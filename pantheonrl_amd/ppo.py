@@ -238,7 +238,7 @@ class ActorCriticPolicy:
             self.ctx.handle, C.byref(self.spec), self.params.data_ptr(), obs_t.data_ptr(), n, nat.ptr(m), nat.ptr(u),
             nat.ptr(g), self._seed, self._counter, int(bool(deterministic)), acts.data_ptr(), None, values.data_ptr(),
             logp.data_ptr(), nat.ptr(ent), nat.ptr(logits), C.byref(rb.c_struct()) if rb is not None else None,
-            int(pos), nat.ptr(es), int(self.gemm_mode)))
+            int(pos), nat.ptr(es), None, int(self.gemm_mode)))
         return acts, values, logp, ent, logits
 
     def _shape_actions(self, acts: th.Tensor) -> th.Tensor:

@@ -42,6 +42,7 @@ class VecOnPolicyAgent:
         self._lib, self._h = pol.ctx.lib, pol.ctx.handle
         self._spec, self._rb = C.byref(pol.spec), C.byref(rb.c_struct())
         self.sync_stats = False
+        self._pending = None   # reward tensor of the previous update(), folded into the next step's launch
 
     # -- callbacks --------------------------------------------------------------------------------------------------
     def get_action(self, obs: th.Tensor, record: bool = True, action_mask: Optional[th.Tensor] = None,
@@ -51,12 +52,15 @@ class VecOnPolicyAgent:
         if record and self.n_steps >= model.n_steps:
             self.learn_from_buffer()
         es = self._last_episode_starts if episode_start is None else episode_start
+        pending = self._pending if (record and rb.pos >= 1) else None
         pol._counter += 1
         nat.check(self._lib.ph_policy_forward(
             self._h, self._spec, pol.params.data_ptr(), obs.data_ptr(), self.E, nat.ptr(action_mask), None, None,
             pol._seed, pol._counter, 0, self.actions.data_ptr(), None, self.values.data_ptr(),
             self.log_probs.data_ptr(), None, None, self._rb if record else None, rb.pos if record else 0,
-            es.data_ptr() if record else None, int(pol.gemm_mode)))
+            es.data_ptr() if record else None, nat.ptr(pending), int(pol.gemm_mode)))
+        if pending is not None:
+            self._pending = None
         if record:
             rb.pos += 1
             rb.full = rb.pos == rb.buffer_size
@@ -65,14 +69,27 @@ class VecOnPolicyAgent:
         return self.actions
 
     def update(self, reward: th.Tensor, done: th.Tensor, env_mask: Optional[th.Tensor] = None) -> None:
-        rb = self.model.rollout_buffer
-        nat.check(self._lib.ph_buffer_add_reward(self._h, self._rb, rb.pos - 1, reward.data_ptr(), nat.ptr(env_mask)))
+        if self._pending is not None or env_mask is not None:
+            self.flush_rewards()              # a second update for the same action: rewards add up (agents.py:44-47)
+        if env_mask is None:
+            self._pending = reward            # applied by the next get_action's launch (or flush_rewards)
+        else:
+            rb = self.model.rollout_buffer
+            nat.check(self._lib.ph_buffer_add_reward(self._h, self._rb, rb.pos - 1, reward.data_ptr(),
+                                                     nat.ptr(env_mask)))
         self._last_episode_starts = done
+
+    def flush_rewards(self) -> None:
+        if self._pending is not None:
+            rb = self.model.rollout_buffer
+            nat.check(self._lib.ph_buffer_add_reward(self._h, self._rb, rb.pos - 1, self._pending.data_ptr(), None))
+            self._pending = None
 
     def learn_from_buffer(self) -> None:
         """GAE with the cached V(o_{T-1}) (quirk D-1), PPO update, buffer reset (agents.py:126-158)."""
         model = self.model
         rb = model.rollout_buffer
+        self.flush_rewards()
         nat.check(self._lib.ph_gae(self._h, self._rb, self.values.data_ptr(), self._last_episode_starts.data_ptr(),
                                    rb.gamma, rb.gae_lambda, int(rb.gae_mode)))
         model.train(sync_stats=self.sync_stats)

@@ -445,3 +445,86 @@ def test_rps_ppo_vs_ppo_plumbing():
     assert partner.iteration == 3                          # trains at the NEXT get_action after its buffer fills (D-3)
     assert int(ego.policy.opt_step.item()) == 4 * 10 * 4  # 4 updates x 10 epochs x 4 minibatches of 64
     assert len(ego.ep_info_buffer) == 100 and all(e["l"] == 1 for e in ego.ep_info_buffer)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# vectorised agent (n_envs = E) and the captured iteration graph
+# ----------------------------------------------------------------------------------------------------------------
+def _vec_setup(T=12, E=96, seed=0, n_epochs=2):
+    from pantheonrl_amd import PPO
+    from pantheonrl_amd.vec import SyntheticRollouts, VecOnPolicyAgent
+    name = "overcooked"
+    orac = H.oracle_policy(name, seed=seed)
+    obs_s, act_s = H.CONFIGS[name]
+    env = type("E", (), dict(observation_space=H.to_space(obs_s), action_space=H.to_space(act_s),
+                             _is_dummy_space_env=True))()
+    model = PPO("MlpPolicy", env, n_steps=T, n_envs=E, batch_size=T * E // 4, n_epochs=n_epochs, seed=seed)
+    model.policy.set_flat_params(orac.flat_params())
+    agent = VecOnPolicyAgent(model)
+    data = SyntheticRollouts(H.to_space(obs_s), E, T, horizon=5, seed=seed, device=model.device)
+    return orac, model, agent, data
+
+
+def test_vec_agent_rollout_buffer_contents():
+    """T x (get_action, update) on device tensors leaves exactly the buffer the reference's callbacks would: obs copied,
+    rewards = the late additive rewards (folded into the next step's launch), episode_starts = previous dones (first
+    row True), values / log-probs = the policy's at the stored actions, GAE with V(o_{T-1}) (quirk D-1)."""
+    orac, model, agent, data = _vec_setup()
+    rb = model.rollout_buffer
+    agent.bind_stream()
+    for t in range(data.T):
+        acts = agent.get_action(data.obs[t])
+        assert acts.shape == (data.E, 1) and int(acts.min()) >= 0 and int(acts.max()) < 6
+        agent.update(data.rewards[t] * 0.5, data.dones[t] * 0)       # two updates for one action: rewards add up,
+        agent.update(data.rewards[t] * 0.5, data.dones[t])           # the last done wins (agents.py:44-47)
+    agent.flush_rewards()
+    got = rb.host()
+    obs, rew, dones = data.obs.cpu().numpy(), data.rewards.cpu().numpy(), data.dones.cpu().numpy()
+    assert np.array_equal(got["observations"], obs)
+    np.testing.assert_allclose(got["rewards"], rew, atol=1e-7)
+    assert np.array_equal(got["episode_starts"], np.vstack([np.ones((1, data.E), np.float32), dones[:-1]]))
+    with th.no_grad():
+        v_ref, lp_ref, _ = orac.evaluate_actions(th.as_tensor(obs.reshape(-1, 62)),
+                                                 th.as_tensor(got["actions"].reshape(-1, 1)))
+    np.testing.assert_allclose(got["values"].ravel(), v_ref.numpy().ravel(), atol=2e-5)
+    np.testing.assert_allclose(got["log_probs"].ravel(), lp_ref.numpy(), atol=2e-5)
+    # sampled actions follow the policy distribution (chi-square-ish sanity on the pooled histogram)
+    with th.no_grad():
+        p = th.softmax(orac.logits(th.as_tensor(obs.reshape(-1, 62))), 1).mean(0).numpy()
+    hist = np.bincount(got["actions"].astype(int).ravel(), minlength=6) / got["actions"].size
+    assert np.abs(hist - p).max() < 0.05
+    # learn_from_buffer: GAE bootstraps with the cached V(o_{T-1}) and the last dones
+    values_last = agent.values.clone()
+    rb.gae_mode = 1
+    agent.sync_stats = True
+    agent.learn_from_buffer()
+    a_ref, _ = orc.gae_reference(got["rewards"], got["values"], got["episode_starts"], values_last.cpu().numpy(),
+                                 dones[-1])
+    assert np.array_equal(rb.advantages.cpu().numpy(), a_ref)
+    assert agent.iteration == 1 and rb.pos == 0 and agent.n_steps == 0
+    assert model.last_train_stats.shape == (8, 8) and (model.last_train_stats[:, 7] == 1).all()
+
+
+def test_iteration_graph_replays_with_fresh_randomness_and_is_deterministic():
+    from pantheonrl_amd.vec import IterationGraph
+    _, model_g, agent_g, data = _vec_setup(seed=3)
+    stream = th.cuda.Stream()
+    graph = IterationGraph(agent_g, data, stream)        # 2 eager warm-up iterations + capture
+    with th.cuda.stream(stream):
+        graph.launch()
+        stream.synchronize()
+        acts1 = model_g.rollout_buffer.actions.clone()
+        p1 = model_g.policy.get_flat_params()
+        graph.launch()
+        stream.synchronize()
+        acts2 = model_g.rollout_buffer.actions.clone()
+        p2 = model_g.policy.get_flat_params()
+    assert int(graph.epoch_word.item()) == 2
+    assert not th.equal(acts1, acts2), "each replay must draw new actions (device RNG epoch)"
+    assert np.isfinite(p2).all() and not np.array_equal(p1, p2)
+    # a second, independently built and captured agent reproduces the parameters bit for bit
+    _, model_h, agent_h, data_h = _vec_setup(seed=3)
+    graph_h = IterationGraph(agent_h, data_h, th.cuda.Stream())
+    graph_h.launch(); graph_h.launch()
+    th.cuda.synchronize()
+    assert np.array_equal(model_h.policy.get_flat_params(), p2)   # run-to-run deterministic
