@@ -113,6 +113,9 @@ int ph_graph_launch(ph_ctx *ctx, int graph_id);
  * stream is additionally keyed by *epoch, and ph_rng_epoch_advance enqueues *epoch += 1 (capturable). */
 int ph_ctx_set_rng_epoch(ph_ctx *ctx, unsigned long long *epoch_dev /* device, or NULL to detach */);
 int ph_rng_epoch_advance(ph_ctx *ctx);
+/* Debug: while a buffer is attached, workgroup (bx,by) of policy_fwd / ppo_grad writes the shader clock at up to 16
+ * phase boundaries to stamps[((by*gridDim.x)+bx)*16 + phase] (caller sizes it: 16 * workgroups int64).  NULL detaches. */
+int ph_debug_set_profile_buffer(ph_ctx *ctx, long long *stamps_dev);
 /* HIP-event timing on the ctx stream (bench.py roofline: events must sit on the stream the kernels run on) */
 int ph_timer_start(ph_ctx *ctx);
 int ph_timer_stop(ph_ctx *ctx, float *ms_out /* host */); /* synchronises */

@@ -69,6 +69,7 @@ SIGNATURES = {
     "ph_graph_launch": [_vp, _i],
     "ph_ctx_set_rng_epoch": [_vp, _vp],
     "ph_rng_epoch_advance": [_vp],
+    "ph_debug_set_profile_buffer": [_vp, _vp],
     "ph_timer_start": [_vp],
     "ph_timer_stop": [_vp, C.POINTER(C.c_float)],
     "ph_layout_of": [C.POINTER(PhSpec), C.POINTER(PhLayout)],

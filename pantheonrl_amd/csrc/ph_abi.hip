@@ -61,6 +61,7 @@ struct ph_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cu = 256;
   unsigned long long* rng_epoch = nullptr;  // caller-owned device word
+  long long* prof = nullptr;                // caller-owned debug stamp buffer
 };
 
 namespace {
@@ -286,6 +287,12 @@ int ph_rng_epoch_advance(ph_ctx* ctx) {
   return 0;
 }
 
+int ph_debug_set_profile_buffer(ph_ctx* ctx, long long* stamps_dev) {
+  if (!ctx) return fail("null ctx");
+  ctx->prof = stamps_dev;
+  return 0;
+}
+
 int ph_timer_start(ph_ctx* ctx) {
   if (!ctx) return fail("null ctx");
   PH_HIP(hipEventRecord(ctx->ev0, ctx->stream));
@@ -374,6 +381,7 @@ int ph_policy_forward(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   a.seed = seed;
   a.counter = counter;
   a.epoch = ctx->rng_epoch;
+  a.prof = ctx->prof;
   a.deterministic = deterministic;
   a.act_i32 = actions_i32;
   a.act_f32 = actions_f32;
@@ -453,6 +461,7 @@ void fill_grad_args(ph::GradArgs& g, const ph::NetDims& nd, const float* params,
   g.slabs = ctx->slabs;
   g.statpart = ctx->statpart;
   g.stop_flag = ctx->stop_flag;
+  g.prof = ctx->prof;
 }
 
 int ensure_train_ws(ph_ctx* ctx, int P, int nwg_max, int n_mb_total) {

@@ -108,6 +108,13 @@ __host__ inline uint32_t feistel_half_bits(uint32_t n) {
   return hb;
 }
 
+// debug phase stamp: lane 0 of the workgroup records the shader clock (no-op when prof == nullptr)
+#define PH_STAMP(prof, slot)                                                                               \
+  do {                                                                                                     \
+    if ((prof) != nullptr && threadIdx.x == 0)                                                             \
+      (prof)[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] = (long long)clock64();          \
+  } while (0)
+
 // ---- spec resolved for kernels ---------------------------------------------------------------------------------
 struct NetDims {
   int obs_kind;     // PH_SPACE_*

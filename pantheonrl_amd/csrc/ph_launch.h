@@ -29,6 +29,7 @@ struct FwdArgs {
   float* rb_val;
   float* rb_logp;
   const float* es_in;
+  long long* prof;              // debug: per-workgroup phase timestamps (clock64), or null
   float* prev_rew;              // rewards row pos-1, or null
   const float* pending_reward;  // (E) added to prev_rew (Agent.update folded into the next step's launch)
 };
@@ -58,6 +59,7 @@ struct GradArgs {
   float* slabs;            // [gridDim.x][P]
   float* statpart;         // [2*gridDim.x][NSTATP]
   const int* stop_flag;    // device flag set by the KL early stop
+  long long* prof;         // debug: per-workgroup phase timestamps (clock64), or null
   int ntiles;
 };
 

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
   const float* W2 = a.params + (net == 0 ? lay.pi_W2 : lay.vf_W2);
   const float* B2 = a.params + (net == 0 ? lay.pi_b2 : lay.vf_b2);
 
+  PH_STAMP(a.prof, 0);
   if (tid < R) rowphys[tid] = (row0 + tid < a.n) ? row0 + tid : -1;
   if (tid < HID) {
     b1s[tid] = B1[tid];
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
   }
   load_w_rows<R * 4>(w2s, W2, 0, HID);
   __syncthreads();
+  PH_STAMP(a.prof, 1);
 
   // ---- layer 1: Z1 = X * W1 (feature chunks of 64 accumulated in the MFMA accumulator) ----
   f32x16 acc = {0};
@@ -58,9 +60,11 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
     load_x_chunk<R, R * 4>(bufA, rowphys, a.obs, nd, c);
     load_w_rows<R * 4>(regW, W1, c * HID, nd.F);
     __syncthreads();
+    PH_STAMP(a.prof, 2);
     acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc);
     __syncthreads();
   }
+  PH_STAMP(a.prof, 3);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
@@ -68,6 +72,7 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
   }
   if (net == 0) load_w_out(wos, a.params + lay.act_W, nd.L, Lp, LDO);  // regW (W1 chunk) is dead now
   __syncthreads();
+  PH_STAMP(a.prof, 4);
 
   // ---- layer 2 ----
   f32x16 acc2 = {0};
@@ -78,6 +83,7 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
     bufA[row * LDH + col] = tanhf(acc2[r] + b2s[col]);
   }
   __syncthreads();
+  PH_STAMP(a.prof, 5);
 
   if (net == 1) {
     // ---- value head: v = H2 . val_W + val_b (VALU dot, one lane per row) ----
@@ -99,6 +105,7 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
       const size_t off = (size_t)row0 * nd.D;
       for (int e = tid; e < nrow * nd.D; e += blockDim.x) a.rb_obs[off + e] = a.obs[off + e];
     }
+    PH_STAMP(a.prof, 7);
     return;
   }
 
@@ -117,6 +124,7 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
     }
   }
   __syncthreads();
+  PH_STAMP(a.prof, 6);
 
   // ---- distribution: one lane per row ----
   if (tid < R && rowphys[tid] >= 0) {
@@ -170,6 +178,7 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
     if (a.entropy) a.entropy[g] = ent;
     if (a.rb_logp) a.rb_logp[g] = logp;
   }
+  PH_STAMP(a.prof, 7);
 }
 
 template __global__ void policy_fwd_kernel<32, false>(FwdArgs);

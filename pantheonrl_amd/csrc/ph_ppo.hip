@@ -35,6 +35,7 @@ __device__ __forceinline__ int minibatch_row(const GradArgs& a, int gi) {
 template <int R, bool VALU>
 __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   if (*a.stop_flag) return;
+  PH_STAMP(a.prof, 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const NetDims& nd = a.nd;
   const ph_layout& lay = nd.lay;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       rold[tid] = old;
     }
     __syncthreads();
+    if (first) PH_STAMP(a.prof, 1);
 
     // ---- S1: Z1 = X W1 over feature chunks; H1 = tanh(Z1 + b1) -> bufB ----
     f32x16 acc = {0};
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       load_x_chunk<R, R * 4>(bufA, rowphys, a.rb_obs, nd, c);
       load_w_rows<R * 4>(regW, a.params + oW1, c * HID, nd.F);
       __syncthreads();
+      if (first) PH_STAMP(a.prof, 2);
       acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc);
       __syncthreads();
     }
@@ -118,8 +121,10 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
       bufB[row * LDH + col] = tanhf(acc[r] + b1s[col]);
     }
+    if (first) PH_STAMP(a.prof, 3);
     if (net == 0) load_w_out(wos, a.params + lay.act_W, nd.L, Lp, LDO);
     __syncthreads();
+    if (first) PH_STAMP(a.prof, 4);
 
     // ---- S2: H2 = tanh(H1 W2 + b2) -> bufA ----
     {
@@ -132,6 +137,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       }
     }
     __syncthreads();
+    if (first) PH_STAMP(a.prof, 5);
 
     if (net == 0) {
       // ---- S3: logits = H2 Wo + bo -> OUT ----
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
         }
       }
       __syncthreads();
+      if (first) PH_STAMP(a.prof, 6);
 
       // ---- S4: clipped-surrogate + entropy loss per row, dL/dlogits written over OUT ----
       if (tid < R) {
@@ -217,6 +224,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
         }
       }
       __syncthreads();
+      if (first) PH_STAMP(a.prof, 7);
 
       // ---- S5a: dWo = H2^T dOut (tiles 2 x Lp/32), d bo = column sums of dOut ----
       if (wave < 2 * ntn) {
@@ -243,6 +251,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
         slab[lay.act_b + k] = s;
       }
       __syncthreads();
+      if (first) PH_STAMP(a.prof, 8);
 
       // ---- S5b: dH2 = dOut Wo^T ; dZ2 = dH2 * (1 - H2^2) in place over H2 ----
       {
@@ -299,6 +308,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       __syncthreads();
     }
 
+    if (first) PH_STAMP(a.prof, 9);
     // ---- S6a: dW2 = H1^T dZ2 ; d b2 ; dH1 = dZ2 W2^T (kept in registers) ----
     f32x16 dh1 = {0};
     {
@@ -318,6 +328,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       dh1 = tile_mma<false, true, VALU>(bufA, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1);
     }
     __syncthreads();
+    if (first) PH_STAMP(a.prof, 10);
     // ---- S6b: dZ1 = dH1 * (1 - H1^2) in place over H1 ----
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -326,6 +337,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       bufB[row * LDH + col] = dh1[r] * (1.0f - h * h);
     }
     __syncthreads();
+    if (first) PH_STAMP(a.prof, 11);
     // ---- S7: dW1 = X^T dZ1 per feature chunk ; d b1 ----
     if (tid < HID) {
       float s = first ? 0.f : slab[oB1 + tid];
@@ -353,6 +365,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     }
   }
 
+  PH_STAMP(a.prof, 12);
   // ---- per-workgroup partial statistics (fixed reduction tree -> deterministic) ----
 #pragma unroll
   for (int k = 0; k < NSTATP; ++k) {
@@ -372,6 +385,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     for (int w = 0; w < (R * 4) / 64 && w < 4; ++w) v += red[w * NSTATP + tid];
     a.statpart[((size_t)net * gridDim.x + blockIdx.x) * NSTATP + tid] = v;
   }
+  PH_STAMP(a.prof, 13);
 }
 
 template __global__ void ppo_grad_kernel<64, false>(GradArgs);

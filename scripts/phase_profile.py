@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Per-phase shader-clock breakdown of policy_fwd_kernel and ppo_grad_kernel at the bench sizes (debug stamps)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch as th
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pantheonrl_amd import PPO, _native as nat, spaces as sp  # noqa: E402
+from pantheonrl_amd.vec import SyntheticRollouts, VecOnPolicyAgent, run_iteration_eager  # noqa: E402
+
+E, T = int(os.environ.get("E", 1024)), int(os.environ.get("T", 128))
+obs_space, act_space = sp.Box(-np.inf, np.inf, (62,)), sp.Discrete(6)
+env = type("S", (), dict(observation_space=obs_space, action_space=act_space, _is_dummy_space_env=True))()
+model = PPO("MlpPolicy", env, n_steps=T, n_envs=E, batch_size=E * T // 4, n_epochs=2, seed=0)
+model.device_permutations = True
+agent = VecOnPolicyAgent(model)
+data = SyntheticRollouts(obs_space, E, T, 400, 0, model.device)
+run_iteration_eager(agent, data)
+th.cuda.synchronize()
+pol, rb = model.policy, model.rollout_buffer
+lib, h = pol.ctx.lib, pol.ctx.handle
+stamps = th.zeros(16 * 1024, dtype=th.int64, device="cuda")
+
+
+def report(name, nblk_x, nblk_y, labels):
+    st = stamps.cpu().numpy().reshape(-1, 16)[: nblk_x * nblk_y]
+    for by in range(nblk_y):
+        blk = st[by * nblk_x:(by + 1) * nblk_x]
+        blk = blk[blk[:, 0] > 0]
+        if len(blk) == 0:
+            continue
+        d = np.diff(blk[:, :len(labels) + 1].astype(np.float64), axis=1)
+        print(f"{name} net={by}: {len(blk)} workgroups, total {np.median(blk[:, len(labels)] - blk[:, 0]):.0f} cycles (median)")
+        for lab, col in zip(labels, d.T):
+            print(f"    {lab:<34} median {np.median(col):>9.0f}   max {col.max():>9.0f}")
+
+
+nat.check(lib.ph_debug_set_profile_buffer(h, stamps.data_ptr()))
+# forward
+agent.bind_stream()
+for rep in range(2):
+    stamps.zero_()
+    rb.pos = 0
+    agent.n_steps = 0
+    agent.get_action(data.obs[0])
+    th.cuda.synchronize()
+report("policy_fwd", (E + 31) // 32, 2, ["params+W2 load", "X+W1 load", "L1 mma", "H1 tanh + Wo load", "L2 mma+tanh",
+                                        "head mma", "sampling / value+obs copy"])
+# grad
+hp = model.hyper()
+ms = C.c_float(0)
+stamps.zero_()
+rb.pos = T
+nat.check(lib.ph_bench_ppo_grad(h, C.byref(pol.spec), pol.params.data_ptr(), C.byref(rb.c_struct()), C.byref(hp),
+                                int(model.batch_size), 1, 0, C.byref(ms)))
+th.cuda.synchronize()
+nwg = min((model.batch_size + 63) // 64, 256)
+print(f"ppo_grad launch {ms.value * 1e3:.1f} us, {nwg} workgroups per net")
+report("ppo_grad", nwg, 2, ["prologue+S0 meta", "S1 X+W1 load", "S1 mma", "Wo load+H1 tanh", "S2 mma+tanh", "S3 head/value",
+                            "S4 loss", "S5a dWo", "S5b dH2/dZ2", "S6a dW2+dH1", "S6b dZ1", "S7 dW1 (+rest of tiles)",
+                            "stats"])
+nat.check(lib.ph_debug_set_profile_buffer(h, None))
