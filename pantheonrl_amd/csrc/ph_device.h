@@ -19,9 +19,33 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // (cdna_hip_programming.md section 3: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).)
 __device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// ---- float32 transcendental helpers ----------------------------------------------------------------------------------
+// ocml's tanhf/expf/logf are correctly rounded but cost ~300 cycles per wave-instruction-equivalent here (exec-masked
+// range branches); the epilogues of every layer are tanh, so they dominated the kernels.  These versions are
+// branch-free and stay within ~3 ulp (abs. error <= 2e-7 on tanh, rel. error <= |x|*1.2e-7 on exp), far inside the
+// 2e-5 parity tolerance of the logits.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float ax = __builtin_fabsf(x);
+  // |x| < 0.3: odd Taylor polynomial to x^9 (next term < 1.6e-8 at 0.3)
+  const float x2 = x * x;
+  float p = 62.0f / 2835.0f;
+  p = __builtin_fmaf(p, x2, -17.0f / 315.0f);
+  p = __builtin_fmaf(p, x2, 2.0f / 15.0f);
+  p = __builtin_fmaf(p, x2, -1.0f / 3.0f);
+  p = __builtin_fmaf(p * x2, x, x);
+  // otherwise 1 - 2/(exp(2|x|)+1); exp2 saturates to +inf for large |x| -> exactly 1
+  const float e = __builtin_amdgcn_exp2f(ax * (2.0f * 1.44269504088896340736f));
+  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  return ax < 0.3f ? p : __builtin_copysignf(t, x);
+}
+
 // One 32x32 output tile  acc += A[m0:m0+32, k0:k0+klen] * B[k0:k0+klen, n0:n0+32]  with both operands in
 // LDS.  A(m,k) = TA ? A[k*lda+m] : A[m*lda+k];  B(k,n) = TB ? B[n*ldb+k] : B[k*ldb+n].
 // MFMA path: v_mfma_f32_32x32x2_f32, lane l supplies A(m0+(l&31), k+(l>>5)) and B(k+(l>>5), n0+(l&31)).
+// klen must be a multiple of 8: operands are fetched four MFMAs ahead (8 k-values per group) so the LDS latency of
+// group g+1 hides under the 256 cycles the matrix pipe spends on group g.
 // The hardware result is bit-for-bit the k-ordered fmaf chain (guide section 3), which is what the VALU
 // path below computes with plain v_fma_f32 in the same accumulator layout -- a drop-in cross-check.
 template <bool TA, bool TB, bool VALU>
@@ -34,11 +58,31 @@ __device__ __forceinline__ f32x16 tile_mma(const float* A, int lda, const float*
     const float* bp = TB ? (B + (n0 + i) * ldb + k0 + h) : (B + (k0 + h) * ldb + n0 + i);
     const int astep = TA ? 2 * lda : 2;
     const int bstep = TB ? 2 : 2 * ldb;
-#pragma unroll 8
-    for (int s = 0; s < klen; s += 2) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(*ap, *bp, acc, 0, 0, 0);
-      ap += astep;
-      bp += bstep;
+    float a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a0[u] = ap[u * astep];
+      b0[u] = bp[u * bstep];
+    }
+    for (int s = 0; s < klen; s += 8) {
+      ap += 4 * astep;
+      bp += 4 * bstep;
+      if (s + 8 < klen) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a1[u] = ap[u * astep];
+          b1[u] = bp[u * bstep];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ds_reads ahead of this group's MFMAs
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0[u] = a1[u];
+        b0[u] = b1[u];
+      }
     }
   } else {
     const int col = n0 + i;
@@ -126,29 +170,36 @@ struct NetDims {
   ph_layout lay;
 };
 
-// Fill dst[R][LDH] with features [c*64, c*64+64) of the R rows whose physical row index is rowphys[r]
-// (-1 = padding row -> zeros).  Box: straight copy, one 256-byte row segment per wave-instruction; every lane issues
-// all of its R*64/NT loads before the first LDS store, so a tile costs ONE memory latency, not R*64/NT of them.
-// Discrete family: one-hot.  Caller must __syncthreads() before (dst free) and after (dst ready).
+// ---- global -> LDS staging, split into issue (all global loads of a lane, no waits) and commit (LDS stores) ------------
+// A workgroup issues every staging load of a phase back to back and commits afterwards, so a phase costs ONE memory
+// latency; loads issued before an MFMA phase and committed after it cost none.
+
+// X tile: features [c*64, c*64+64) of the R rows whose physical row index is rowphys[r] (-1 = padding -> zeros).
+// Box: straight copy, one 256-byte row segment per wave-instruction.  Discrete family: one-hot (built at commit).
 template <int R, int NT>
-__device__ __forceinline__ void load_x_chunk(float* dst, const int* rowphys, const float* obs, const NetDims& nd,
-                                             int c) {
-  const int tid = threadIdx.x;
-  const int base = c * HID;
-  if (nd.obs_kind == PH_SPACE_BOX) {
-    constexpr int ITERS = R * HID / NT;
-    float v[ITERS];
-    const int kk = tid & 63, f = base + kk;
+struct XStage {
+  static constexpr int ITERS = R * HID / NT;
+  float v[ITERS];
+  __device__ __forceinline__ void issue(const int* rowphys, const float* obs, const NetDims& nd, int c) {
+    if (nd.obs_kind != PH_SPACE_BOX) return;
+    const int tid = threadIdx.x, kk = tid & 63, f = c * HID + kk;
     const bool fok = f < nd.F;
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
-      const int r = (tid + NT * i) >> 6;
-      const int ph_row = rowphys[r];
+      const int ph_row = rowphys[(tid + NT * i) >> 6];
       v[i] = (ph_row >= 0 && fok) ? obs[(size_t)ph_row * nd.D + f] : 0.f;
     }
+  }
+  // caller: dst must be free (barrier before), and a barrier must follow before dst is read
+  __device__ __forceinline__ void commit(float* dst, const int* rowphys, const float* obs, const NetDims& nd, int c) {
+    const int tid = threadIdx.x;
+    if (nd.obs_kind == PH_SPACE_BOX) {
+      const int kk = tid & 63;
 #pragma unroll
-    for (int i = 0; i < ITERS; ++i) dst[((tid + NT * i) >> 6) * LDH + kk] = v[i];
-  } else {
+      for (int i = 0; i < ITERS; ++i) dst[((tid + NT * i) >> 6) * LDH + kk] = v[i];
+      return;
+    }
+    const int base = c * HID;
     for (int e = tid; e < R * HID; e += NT) dst[(e >> 6) * LDH + (e & 63)] = 0.f;
     __syncthreads();
     for (int e = tid; e < R * nd.D; e += NT) {
@@ -156,45 +207,59 @@ __device__ __forceinline__ void load_x_chunk(float* dst, const int* rowphys, con
       const int ph_row = rowphys[r];
       if (ph_row < 0) continue;
       const int lo = nd.obs_off[comp], n = nd.obs_off[comp + 1] - lo;
-      int v = (int)obs[(size_t)ph_row * nd.D + comp];
-      v = v < 0 ? 0 : (v >= n ? n - 1 : v);
-      const int f = lo + v - base;
+      int x = (int)obs[(size_t)ph_row * nd.D + comp];
+      x = x < 0 ? 0 : (x >= n ? n - 1 : x);
+      const int f = lo + x - base;
       if (f >= 0 && f < HID) dst[r * LDH + f] = 1.f;
     }
   }
-}
+};
 
 // rows [row0, row0+64) of an input-major weight matrix W[nrows_total][64] -> dst[64][LDH]; rows >= nrows_total are
-// zero.  16-byte global loads (W rows are 256-byte aligned relative to the 16-byte aligned parameter vector), all
-// issued before the LDS stores.
+// zero.  16-byte global loads (W rows are 256-byte aligned relative to the 16-byte aligned parameter vector).
 template <int NT>
-__device__ __forceinline__ void load_w_rows(float* dst, const float* W, int row0, int nrows_total) {
-  constexpr int ITERS = HID * HID / 4 / NT;
+struct WStage {
+  static constexpr int ITERS = HID * HID / 4 / NT;
   float4 v[ITERS];
-  const int tid = threadIdx.x;
+  __device__ __forceinline__ void issue(const float* W, int row0, int nrows_total) {
+    const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < ITERS; ++i) {
-    const int q = tid + NT * i;          // float4 index inside the 64x64 block
-    const int kk = q >> 4;
-    const int k = row0 + kk;
-    v[i] = (k < nrows_total) ? *reinterpret_cast<const float4*>(W + (size_t)k * HID + ((q & 15) << 2))
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < ITERS; ++i) {
+      const int q = tid + NT * i;  // float4 index inside the 64x64 block
+      const int k = row0 + (q >> 4);
+      v[i] = (k < nrows_total) ? *reinterpret_cast<const float4*>(W + (size_t)k * HID + ((q & 15) << 2))
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
+  __device__ __forceinline__ void commit(float* dst) {
+    const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < ITERS; ++i) {
-    const int q = tid + NT * i;
-    float* d = dst + (q >> 4) * LDH + ((q & 15) << 2);
-    d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+    for (int i = 0; i < ITERS; ++i) {
+      const int q = tid + NT * i;
+      float* d = dst + (q >> 4) * LDH + ((q & 15) << 2);
+      d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+    }
   }
-}
+};
 
-// act_W[64][L] -> dst[64][ldo] (columns >= L zero)
-__device__ __forceinline__ void load_w_out(float* dst, const float* W, int L, int Lp, int ldo) {
-  for (int e = threadIdx.x; e < HID * Lp; e += blockDim.x) {
-    const int j = e / Lp, a = e - j * Lp;
-    dst[j * ldo + a] = (a < L) ? W[j * L + a] : 0.f;
+// act_W[64][L] -> dst[64][ldo] (columns >= L zero): lane tid owns hidden row j = tid % 64 and a column slice.
+template <int NT, int LPMAX = PH_MAX_LOGITS>
+struct WoStage {
+  static constexpr int PARTS = NT / 64;       // column slices
+  static constexpr int MAXC = LPMAX / PARTS;  // columns per lane, upper bound
+  float v[MAXC];
+  __device__ __forceinline__ void issue(const float* W, int L, int Lp) {
+    const int j = threadIdx.x & 63, c0 = (threadIdx.x >> 6) * (Lp / PARTS), per = Lp / PARTS;
+#pragma unroll
+    for (int u = 0; u < MAXC; ++u) v[u] = (u < per && c0 + u < L) ? W[j * L + c0 + u] : 0.f;
   }
-}
+  __device__ __forceinline__ void commit(float* dst, int Lp, int ldo) {
+    const int j = threadIdx.x & 63, c0 = (threadIdx.x >> 6) * (Lp / PARTS), per = Lp / PARTS;
+#pragma unroll
+    for (int u = 0; u < MAXC; ++u)
+      if (u < per) dst[j * ldo + c0 + u] = v[u];
+  }
+};
 
 // per-row categorical maths on one row of logits held in LDS (z, length L), MultiDiscrete aware.
 // Matches torch.distributions.Categorical(logits=z): log_prob = z[a] - logsumexp(z); entropy = -sum p*logp.

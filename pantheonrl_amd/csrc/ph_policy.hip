@@ -11,22 +11,22 @@
 namespace ph {
 
 
-template <int R, bool VALU>
+template <int R, int LP, bool VALU>
 __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = R * 4;
   const NetDims& nd = a.nd;
-  const int Lp = nd.Lp, LDO = Lp + 1;
+  constexpr int Lp = LP, LDO = LP + 1;   // compile-time so LDS offsets fold into the ds_read immediates
   float* bufA = smem;                    // [R][LDH]  X chunk, later H2
   float* bufB = bufA + R * LDH;          // [R][LDH]  H1
-  float* regW = bufB + R * LDH;          // [64][LDH] W1 chunk; later Wo[64][LDO] + OUT[R][LDO]
-  const int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
-  float* w2s = regW + regW_sz;           // [64][LDH]
-  float* b1s = w2s + HID * LDH;          // [64]
+  float* w1s = bufB + R * LDH;           // [64][LDH] W1 chunk
+  float* w2s = w1s + HID * LDH;          // [64][LDH]
+  float* wos = w2s + HID * LDH;          // Wo [64][LDO]
+  float* outs = wos + HID * LDO;         // OUT [R][LDO]
+  float* b1s = outs + R * LDO;           // [64]
   float* b2s = b1s + HID;                // [64]
   float* bos = b2s + HID;                // [Lp] (policy) / val_W[64] (value)
   int* rowphys = (int*)(bos + 64);       // [R]
-  float* wos = regW;                     // Wo [64][LDO]
-  float* outs = regW + HID * LDO;        // OUT [R][LDO]
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -40,37 +40,54 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
   const float* B2 = a.params + (net == 0 ? lay.pi_b2 : lay.vf_b2);
 
   PH_STAMP(a.prof, 0);
+  // ---- every staging load of the kernel is issued here, back to back: one memory latency in total ----
   if (tid < R) rowphys[tid] = (row0 + tid < a.n) ? row0 + tid : -1;
+  WStage<NT> w2r, w1r;
+  WoStage<NT> wor;
+  XStage<R, NT> xr;
+  w2r.issue(W2, 0, HID);
+  w1r.issue(W1, 0, nd.F);
+  if (net == 0) wor.issue(a.params + lay.act_W, nd.L, Lp);
+  float bias1 = 0.f, bias2 = 0.f, bias3 = 0.f;
   if (tid < HID) {
-    b1s[tid] = B1[tid];
-    b2s[tid] = B2[tid];
-    if (net == 0) {
-      if (tid < Lp) bos[tid] = (tid < nd.L) ? a.params[lay.act_b + tid] : 0.f;
-    } else {
-      bos[tid] = a.params[lay.val_W + tid];
-    }
+    bias1 = B1[tid];
+    bias2 = B2[tid];
+    bias3 = (net == 0) ? ((tid < nd.L) ? a.params[lay.act_b + tid] : 0.f) : a.params[lay.val_W + tid];
   }
-  load_w_rows<R * 4>(w2s, W2, 0, HID);
+  __syncthreads();  // rowphys visible
+  xr.issue(rowphys, a.obs, nd, 0);
+  w2r.commit(w2s);
+  w1r.commit(w1s);
+  if (net == 0) wor.commit(wos, Lp, LDO);
+  if (tid < HID) {
+    b1s[tid] = bias1;
+    b2s[tid] = bias2;
+    bos[tid] = bias3;
+  }
+  xr.commit(bufA, rowphys, a.obs, nd, 0);
   __syncthreads();
   PH_STAMP(a.prof, 1);
 
   // ---- layer 1: Z1 = X * W1 (feature chunks of 64 accumulated in the MFMA accumulator) ----
   f32x16 acc = {0};
   for (int c = 0; c < nd.nchunk; ++c) {
-    load_x_chunk<R, R * 4>(bufA, rowphys, a.obs, nd, c);
-    load_w_rows<R * 4>(regW, W1, c * HID, nd.F);
-    __syncthreads();
+    if (c > 0) {
+      __syncthreads();  // previous chunk consumed
+      w1r.issue(W1, c * HID, nd.F);
+      xr.issue(rowphys, a.obs, nd, c);
+      w1r.commit(w1s);
+      xr.commit(bufA, rowphys, a.obs, nd, c);
+      __syncthreads();
+    }
     PH_STAMP(a.prof, 2);
-    acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc);
-    __syncthreads();
+    acc = tile_mma<false, false, VALU>(bufA, LDH, w1s, LDH, mt * 32, nt * 32, 0, HID, acc);
   }
   PH_STAMP(a.prof, 3);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
-    bufB[row * LDH + col] = tanhf(acc[r] + b1s[col]);
+    bufB[row * LDH + col] = fast_tanh(acc[r] + b1s[col]);
   }
-  if (net == 0) load_w_out(wos, a.params + lay.act_W, nd.L, Lp, LDO);  // regW (W1 chunk) is dead now
   __syncthreads();
   PH_STAMP(a.prof, 4);
 
@@ -80,7 +97,7 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
-    bufA[row * LDH + col] = tanhf(acc2[r] + b2s[col]);
+    bufA[row * LDH + col] = fast_tanh(acc2[r] + b2s[col]);
   }
   __syncthreads();
   PH_STAMP(a.prof, 5);
@@ -142,8 +159,8 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
       float m = z[lo];
       for (int k = 1; k < nk; ++k) m = fmaxf(m, z[lo + k]);
       float se = 0.f;
-      for (int k = 0; k < nk; ++k) se += expf(z[lo + k] - m);
-      const float lse = m + logf(se);
+      for (int k = 0; k < nk; ++k) se += fast_exp(z[lo + k] - m);
+      const float lse = m + fast_log(se);
       int act;
       if (a.given_actions) {
         act = (int)a.given_actions[(size_t)g * nd.A + c];
@@ -159,14 +176,14 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
         float cum = 0.f;
         act = 0;
         for (int k = 0; k < nk - 1; ++k) {  // inverse CDF: count prefix sums <= u
-          cum += expf(z[lo + k] - lse);
+          cum += fast_exp(z[lo + k] - lse);
           act += (u >= cum) ? 1 : 0;
         }
       }
       float e = 0.f;
       for (int k = 0; k < nk; ++k) {
         const float lp = z[lo + k] - lse;
-        e -= expf(lp) * lp;
+        e -= fast_exp(lp) * lp;
       }
       logp += z[lo + act] - lse;
       ent += e;
@@ -181,37 +198,35 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
   PH_STAMP(a.prof, 7);
 }
 
-template __global__ void policy_fwd_kernel<32, false>(FwdArgs);
-template __global__ void policy_fwd_kernel<32, true>(FwdArgs);
-template __global__ void policy_fwd_kernel<64, false>(FwdArgs);
 
 size_t fwd_lds_bytes(int R, int Lp) {
   const int LDO = Lp + 1;
-  const int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
-  return sizeof(float) * (size_t)(2 * R * LDH + regW_sz + HID * LDH + 3 * 64 + R);
+  return sizeof(float) * (size_t)(2 * R * LDH + 2 * HID * LDH + (HID + R) * LDO + 3 * 64 + R);
+}
+
+template <int R, int LP, bool VALU>
+static hipError_t launch_fwd_variant(const FwdArgs& a, hipStream_t s) {
+  dim3 grid((a.n + R - 1) / R, 2), block(R * 4);
+  const size_t lds = fwd_lds_bytes(R, LP);
+  static size_t allowed = 64 * 1024;  // dynamic LDS above 64 KiB is opt-in, once per kernel
+  if (lds > allowed) {
+    hipError_t e = hipFuncSetAttribute((const void*)policy_fwd_kernel<R, LP, VALU>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    allowed = lds;
+  }
+  hipLaunchKernelGGL((policy_fwd_kernel<R, LP, VALU>), grid, block, lds, s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s) {
-  const int n = a.n;
   // R = 32 rows per workgroup keeps >= 2*n/32 workgroups in flight for the small-E rollout step
-  const int R = (gemm_mode == 0 && n >= 16384) ? 64 : 32;
-  dim3 grid((n + R - 1) / R, 2), block(R * 4);
-  const size_t lds = fwd_lds_bytes(R, a.nd.Lp);
-  if (gemm_mode != 0) {
-    hipLaunchKernelGGL((policy_fwd_kernel<32, true>), grid, block, lds, s, a);
-  } else if (R == 64) {
-    static size_t allowed = 0;
-    if (lds > allowed) {
-      hipError_t e = hipFuncSetAttribute((const void*)policy_fwd_kernel<64, false>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      allowed = lds;
-    }
-    hipLaunchKernelGGL((policy_fwd_kernel<64, false>), grid, block, lds, s, a);
-  } else {
-    hipLaunchKernelGGL((policy_fwd_kernel<32, false>), grid, block, lds, s, a);
-  }
-  return hipGetLastError();
+  const bool big = (gemm_mode == 0 && a.n >= 16384);
+  const bool lp64 = a.nd.Lp == 64;
+  if (a.nd.Lp != 32 && a.nd.Lp != 64) return hipErrorInvalidValue;
+  if (gemm_mode != 0) return lp64 ? launch_fwd_variant<32, 64, true>(a, s) : launch_fwd_variant<32, 32, true>(a, s);
+  if (big) return lp64 ? launch_fwd_variant<64, 64, false>(a, s) : launch_fwd_variant<64, 32, false>(a, s);
+  return lp64 ? launch_fwd_variant<32, 64, false>(a, s) : launch_fwd_variant<32, 32, false>(a, s);
 }
 
 // ---- env-side illegal action fix-up (pettingzoo.py:81-82): integer, bit-exact ----

@@ -32,18 +32,19 @@ __device__ __forceinline__ int minibatch_row(const GradArgs& a, int gi) {
   return env_major_to_phys(n, a.T, a.E);
 }
 
-template <int R, bool VALU>
+template <int R, int LP, bool VALU>
 __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   if (*a.stop_flag) return;
   PH_STAMP(a.prof, 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = R * 4;
   const NetDims& nd = a.nd;
   const ph_layout& lay = nd.lay;
-  const int Lp = nd.Lp, LDO = Lp + 1;
+  constexpr int Lp = LP, LDO = LP + 1;  // logits padded to the MFMA tile width: compile-time so LDS offsets fold
   float* bufA = smem;                  // [R][LDH]  X chunk -> H2 -> dZ2 -> X chunk
   float* bufB = bufA + R * LDH;        // [R][LDH]  H1 -> dZ1
   float* regW = bufB + R * LDH;        // W1 chunk [64][LDH]  |  Wo [64][LDO] + OUT [R][LDO]
-  const int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
+  constexpr int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
   float* w2s = regW + regW_sz;         // [64][LDH]
   float* b1s = w2s + HID * LDH;        // [64]
   float* b2s = b1s + HID;              // [64]
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   float* outs = regW + HID * LDO;
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = tid >> 6, lane = tid & 63;
   const int mt = wave >> 1, nt = wave & 1;  // this wave's 32x32 tile of every [R x 64] / [64 x 64] product
   const int net = blockIdx.y;
   const int oW1 = net == 0 ? lay.pi_W1 : lay.vf_W1, oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1;
@@ -65,25 +66,23 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   float* slab = a.slabs + (size_t)blockIdx.x * lay.P;
   const float inv_nb = 1.0f / (float)a.nb;
 
+  // prologue: W2 and the bias vectors are issued now and committed after the first tile's row metadata, so their
+  // latency overlaps the index gathers of S0
+  WStage<NT> w2r;
+  w2r.issue(a.params + oW2, 0, HID);
+  float bias1 = 0.f, bias2 = 0.f, bias3 = 0.f;
   if (tid < HID) {
-    b1s[tid] = a.params[oB1 + tid];
-    b2s[tid] = a.params[oB2 + tid];
-    if (net == 0) {
-      if (tid < Lp) bos[tid] = (tid < nd.L) ? a.params[lay.act_b + tid] : 0.f;
-    } else {
-      bos[tid] = a.params[lay.val_W + tid];
-    }
+    bias1 = a.params[oB1 + tid];
+    bias2 = a.params[oB2 + tid];
+    bias3 = (net == 0) ? ((tid < nd.L) ? a.params[lay.act_b + tid] : 0.f) : a.params[lay.val_W + tid];
   }
-  load_w_rows<R * 4>(w2s, a.params + oW2, 0, HID);
 
   float st[NSTATP];
 #pragma unroll
   for (int k = 0; k < NSTATP; ++k) st[k] = 0.f;
 
-  bool first = true;
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, first = false) {
-    __syncthreads();  // previous tile fully consumed (also orders the prologue loads on the first pass)
-    // ---- S0: row metadata ----
+  // S0: row metadata of one tile (gather indices -> physical rows, per-row scalars)
+  auto stage_rows = [&](int tile) {
     if (tid < R) {
       const int gi = tile * R + tid;
       int phys = -1;
@@ -103,27 +102,48 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       radv[tid] = adv;
       rold[tid] = old;
     }
-    __syncthreads();
+  };
+  stage_rows(blockIdx.x);  // overlaps the W2 / bias loads issued above
+  w2r.commit(w2s);
+  if (tid < HID) {
+    b1s[tid] = bias1;
+    b2s[tid] = bias2;
+    bos[tid] = bias3;
+  }
+
+  bool first = true;
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, first = false) {
+    __syncthreads();  // row metadata (and, first time, W2 / biases) visible
     if (first) PH_STAMP(a.prof, 1);
+    // lane coordinates re-materialised per tile: keeps the (many) per-register slab / LDS addresses derived from them
+    // from being hoisted out of the tile loop and pinned in VGPRs for the whole kernel (that spilled to scratch)
+    int li = lane & 31, lh = lane >> 5;
+    asm volatile("" : "+v"(li), "+v"(lh));
 
     // ---- S1: Z1 = X W1 over feature chunks; H1 = tanh(Z1 + b1) -> bufB ----
     f32x16 acc = {0};
+    XStage<R, NT> xr;
+    WStage<NT> w1r;
+    WoStage<NT> wor;
     for (int c = 0; c < nd.nchunk; ++c) {
-      load_x_chunk<R, R * 4>(bufA, rowphys, a.rb_obs, nd, c);
-      load_w_rows<R * 4>(regW, a.params + oW1, c * HID, nd.F);
+      if (c > 0) __syncthreads();  // previous chunk consumed
+      xr.issue(rowphys, a.rb_obs, nd, c);
+      w1r.issue(a.params + oW1, c * HID, nd.F);
+      xr.commit(bufA, rowphys, a.rb_obs, nd, c);
+      w1r.commit(regW);
       __syncthreads();
       if (first) PH_STAMP(a.prof, 2);
+      if (net == 0 && c == nd.nchunk - 1) wor.issue(a.params + lay.act_W, nd.L, Lp);  // lands during the MFMAs
       acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc);
-      __syncthreads();
     }
+    if (first) PH_STAMP(a.prof, 3);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
-      bufB[row * LDH + col] = tanhf(acc[r] + b1s[col]);
+      bufB[row * LDH + col] = fast_tanh(acc[r] + b1s[col]);
     }
-    if (first) PH_STAMP(a.prof, 3);
-    if (net == 0) load_w_out(wos, a.params + lay.act_W, nd.L, Lp, LDO);
-    __syncthreads();
+    __syncthreads();  // every wave is done with the W1 chunk in regW and H1 is complete
+    if (net == 0) wor.commit(wos, Lp, LDO);
     if (first) PH_STAMP(a.prof, 4);
 
     // ---- S2: H2 = tanh(H1 W2 + b2) -> bufA ----
@@ -133,7 +153,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
-        bufA[row * LDH + col] = tanhf(acc2[r] + b2s[col]);
+        bufA[row * LDH + col] = fast_tanh(acc2[r] + b2s[col]);
       }
     }
     __syncthreads();
@@ -169,21 +189,21 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
             float m = z[lo];
             for (int k = 1; k < nk; ++k) m = fmaxf(m, z[lo + k]);
             float se = 0.f;
-            for (int k = 0; k < nk; ++k) se += expf(z[lo + k] - m);
-            const float lse = m + logf(se);
+            for (int k = 0; k < nk; ++k) se += fast_exp(z[lo + k] - m);
+            const float lse = m + fast_log(se);
             int act = (int)a.rb_act[(size_t)phys * nd.A + c];
             act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
             float e = 0.f;
             for (int k = 0; k < nk; ++k) {
               const float lp = z[lo + k] - lse;
-              e -= expf(lp) * lp;
+              e -= fast_exp(lp) * lp;
             }
             logp += z[lo + act] - lse;
             ent += e;
           }
           const float adv = radv[tid];
           const float lr = logp - rold[tid];
-          const float ratio = expf(lr);
+          const float ratio = fast_exp(lr);
           const float lo_c = 1.0f - a.clip, hi_c = 1.0f + a.clip;
           const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
           const float pl1 = adv * ratio, pl2 = adv * rc;
@@ -203,18 +223,18 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
             float m = z[lo];
             for (int k = 1; k < nk; ++k) m = fmaxf(m, z[lo + k]);
             float se = 0.f;
-            for (int k = 0; k < nk; ++k) se += expf(z[lo + k] - m);
-            const float lse = m + logf(se);
+            for (int k = 0; k < nk; ++k) se += fast_exp(z[lo + k] - m);
+            const float lse = m + fast_log(se);
             int act = (int)a.rb_act[(size_t)phys * nd.A + c];
             act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
             float hc = 0.f;
             for (int k = 0; k < nk; ++k) {
               const float lp = z[lo + k] - lse;
-              hc -= expf(lp) * lp;
+              hc -= fast_exp(lp) * lp;
             }
             for (int k = 0; k < nk; ++k) {
               const float lp = z[lo + k] - lse;
-              const float p = expf(lp);
+              const float p = fast_exp(lp);
               const float dlogp = ((k == act) ? 1.f : 0.f) - p;
               const float dent = -p * (lp + hc);
               z[lo + k] = g_lp * dlogp + g_en * dent;
@@ -244,8 +264,8 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
           if (col < nd.L) slab[lay.act_W + j * nd.L + col] = g[r];
         }
       }
-      if (tid >= R * 4 - 64 && tid - (R * 4 - 64) < nd.L) {  // last wave: bias gradient
-        const int k = tid - (R * 4 - 64);
+      if (tid >= NT - 64 && tid - (NT - 64) < nd.L) {  // last wave: bias gradient
+        const int k = tid - (NT - 64);
         float s = first ? 0.f : slab[lay.act_b + k];
         for (int r = 0; r < R; ++r) s += outs[r * LDO + k];
         slab[lay.act_b + k] = s;
@@ -300,17 +320,18 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       }
       __syncthreads();
       // ---- S5b: dZ2[r][j] = dv[r] * val_W[j] * (1 - H2^2) in place ----
-      for (int e = tid; e < R * HID; e += blockDim.x) {
+      for (int e = tid; e < R * HID; e += NT) {
         const int r = e >> 6, j = e & 63;
         const float h = bufA[r * LDH + j];
         bufA[r * LDH + j] = rdv[r] * bos[j] * (1.0f - h * h);
       }
       __syncthreads();
     }
-
     if (first) PH_STAMP(a.prof, 9);
-    // ---- S6a: dW2 = H1^T dZ2 ; d b2 ; dH1 = dZ2 W2^T (kept in registers) ----
+
+    // ---- S6a: dW2 = H1^T dZ2 ; d b2 ; dH1 = dZ2 W2^T (kept in registers); X chunk 0 re-issued for S7 ----
     f32x16 dh1 = {0};
+    xr.issue(rowphys, a.rb_obs, nd, 0);
     {
       f32x16 g = {0};
       if (!first) {
@@ -327,15 +348,16 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       }
       dh1 = tile_mma<false, true, VALU>(bufA, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1);
     }
-    __syncthreads();
+    __syncthreads();  // dZ2 (bufA) and H1 (bufB) fully consumed
     if (first) PH_STAMP(a.prof, 10);
-    // ---- S6b: dZ1 = dH1 * (1 - H1^2) in place over H1 ----
+    // ---- S6b: dZ1 = dH1 * (1 - H1^2) in place over H1; X chunk 0 lands in bufA ----
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
       const float h = bufB[row * LDH + col];
       bufB[row * LDH + col] = dh1[r] * (1.0f - h * h);
     }
+    xr.commit(bufA, rowphys, a.rb_obs, nd, 0);
     __syncthreads();
     if (first) PH_STAMP(a.prof, 11);
     // ---- S7: dW1 = X^T dZ1 per feature chunk ; d b1 ----
@@ -345,8 +367,12 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       slab[oB1 + tid] = s;
     }
     for (int c = 0; c < nd.nchunk; ++c) {
-      load_x_chunk<R, R * 4>(bufA, rowphys, a.rb_obs, nd, c);
-      __syncthreads();
+      if (c > 0) {
+        __syncthreads();  // previous chunk consumed
+        xr.issue(rowphys, a.rb_obs, nd, c);
+        xr.commit(bufA, rowphys, a.rb_obs, nd, c);
+        __syncthreads();
+      }
       f32x16 g = {0};
       if (!first) {
 #pragma unroll
@@ -361,7 +387,10 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
         const int k = c * HID + mt * 32 + drow(r, lh);
         if (k < nd.F) slab[oW1 + (size_t)k * HID + nt * 32 + li] = g[r];
       }
-      __syncthreads();
+    }
+    if (tile + (int)gridDim.x < a.ntiles) {
+      __syncthreads();  // this tile's row metadata fully consumed
+      stage_rows(tile + gridDim.x);
     }
   }
 
@@ -382,14 +411,16 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   __syncthreads();
   if (tid < NSTATP) {
     float v = 0.f;
-    for (int w = 0; w < (R * 4) / 64 && w < 4; ++w) v += red[w * NSTATP + tid];
+    for (int w = 0; w < NT / 64 && w < 4; ++w) v += red[w * NSTATP + tid];
     a.statpart[((size_t)net * gridDim.x + blockIdx.x) * NSTATP + tid] = v;
   }
   PH_STAMP(a.prof, 13);
 }
 
-template __global__ void ppo_grad_kernel<64, false>(GradArgs);
-template __global__ void ppo_grad_kernel<64, true>(GradArgs);
+template __global__ void ppo_grad_kernel<64, 32, false>(GradArgs);
+template __global__ void ppo_grad_kernel<64, 64, false>(GradArgs);
+template __global__ void ppo_grad_kernel<64, 32, true>(GradArgs);
+template __global__ void ppo_grad_kernel<64, 64, true>(GradArgs);
 
 size_t grad_lds_bytes(int R, int Lp) {
   const int LDO = Lp + 1;
@@ -402,16 +433,22 @@ hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_
   const size_t lds = grad_lds_bytes(R, a.nd.Lp);
   dim3 grid(nwg, 2), block(R * 4);
   // > 64 KiB of dynamic LDS must be opted into once per kernel (not a stream operation; kept out of graph capture)
-  static size_t allowed[2] = {0, 0};
-  const int v = gemm_mode != 0 ? 1 : 0;
+  const int v = (gemm_mode != 0 ? 2 : 0) + (a.nd.Lp == 64 ? 1 : 0);
+  const void* fns[4] = {(const void*)ppo_grad_kernel<R, 32, false>, (const void*)ppo_grad_kernel<R, 64, false>,
+                        (const void*)ppo_grad_kernel<R, 32, true>, (const void*)ppo_grad_kernel<R, 64, true>};
+  static size_t allowed[4] = {0, 0, 0, 0};
+  if (a.nd.Lp != 32 && a.nd.Lp != 64) return hipErrorInvalidValue;
   if (lds > allowed[v]) {
-    const void* fn = v ? (const void*)ppo_grad_kernel<R, true> : (const void*)ppo_grad_kernel<R, false>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     allowed[v] = lds;
   }
-  if (v) hipLaunchKernelGGL((ppo_grad_kernel<R, true>), grid, block, lds, s, a);
-  else hipLaunchKernelGGL((ppo_grad_kernel<R, false>), grid, block, lds, s, a);
+  switch (v) {
+    case 0: hipLaunchKernelGGL((ppo_grad_kernel<R, 32, false>), grid, block, lds, s, a); break;
+    case 1: hipLaunchKernelGGL((ppo_grad_kernel<R, 64, false>), grid, block, lds, s, a); break;
+    case 2: hipLaunchKernelGGL((ppo_grad_kernel<R, 32, true>), grid, block, lds, s, a); break;
+    default: hipLaunchKernelGGL((ppo_grad_kernel<R, 64, true>), grid, block, lds, s, a); break;
+  }
   return hipGetLastError();
 }
 
