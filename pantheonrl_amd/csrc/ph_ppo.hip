@@ -181,6 +181,58 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
         const int phys = rowphys[tid];
         if (phys < 0) {
           for (int k = 0; k < Lp; ++k) z[k] = 0.f;
+        } else if (nd.A == 1 && nd.L <= 8) {
+          // fast path (Discrete action space, <= 8 logits: every BASELINE config but Liar's Dice): the row lives in
+          // registers, one LDS read and one LDS write per logit, one exp per logit
+          const int nk = nd.L;
+          float zr[8], pr[8];
+          float m = -3.0e38f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            zr[k] = (k < nk) ? z[k] : -3.0e38f;
+            m = fmaxf(m, zr[k]);
+          }
+          float se = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            pr[k] = (k < nk) ? fast_exp(zr[k] - m) : 0.f;
+            se += pr[k];
+          }
+          const float lse = m + fast_log(se), inv = __builtin_amdgcn_rcpf(se);
+          int act = (int)a.rb_act[phys];
+          act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
+          float ent = 0.f, zact = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            pr[k] *= inv;
+            const float lp = zr[k] - lse;
+            ent -= (k < nk) ? pr[k] * lp : 0.f;
+            zact = (k == act) ? zr[k] : zact;
+          }
+          const float logp = zact - lse;
+          const float adv = radv[tid];
+          const float lr = logp - rold[tid];
+          const float ratio = fast_exp(lr);
+          const float lo_c = 1.0f - a.clip, hi_c = 1.0f + a.clip;
+          const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
+          const float pl1 = adv * ratio, pl2 = adv * rc;
+          const float inr = (ratio >= lo_c && ratio <= hi_c) ? 1.f : 0.f;
+          const float gate = (pl1 < pl2) ? 1.f : ((pl1 > pl2) ? inr : 0.5f + 0.5f * inr);
+          const float g_lp = -inv_nb * adv * ratio * gate;
+          const float g_en = -a.ent_coef * inv_nb;
+          st[0] += -fminf(pl1, pl2);
+          st[2] += -ent;
+          st[3] += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
+          st[4] += (ratio - 1.0f) - lr;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (k < nk) {
+              const float dlogp = ((k == act) ? 1.f : 0.f) - pr[k];
+              const float dent = -pr[k] * ((zr[k] - lse) + ent);
+              z[k] = g_lp * dlogp + g_en * dent;
+            }
+          }
+          for (int k = nk; k < Lp; ++k) z[k] = 0.f;
         } else {
           float logp = 0.f, ent = 0.f;
           // pass 1: log-prob and entropy (MultiDiscrete: sums over components)
@@ -329,9 +381,11 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     }
     if (first) PH_STAMP(a.prof, 9);
 
-    // ---- S6a: dW2 = H1^T dZ2 ; d b2 ; dH1 = dZ2 W2^T (kept in registers); X chunk 0 re-issued for S7 ----
+    // ---- S6a: dW2 = H1^T dZ2 ; d b2 ; dH1 = dZ2 W2^T (kept in registers) ----
+    // S7 needs X chunk 0 again: with one feature chunk the staged registers of S1 are still live (no second
+    // gather); otherwise it is re-issued here and lands during the MFMAs.
     f32x16 dh1 = {0};
-    xr.issue(rowphys, a.rb_obs, nd, 0);
+    if (nd.nchunk > 1) xr.issue(rowphys, a.rb_obs, nd, 0);
     {
       f32x16 g = {0};
       if (!first) {
