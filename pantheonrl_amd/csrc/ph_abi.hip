@@ -45,8 +45,6 @@ struct ph_ctx {
   size_t slabs_cap = 0;
   float* statpart = nullptr;
   size_t statpart_cap = 0;
-  float* folded = nullptr;  // [FOLD_G][P] first-level slab sums
-  size_t folded_cap = 0;
   float* grad = nullptr;
   size_t grad_cap = 0;
   float* blocksq = nullptr;
@@ -223,7 +221,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (s.obs_off) (void)hipFree(s.obs_off);
     if (s.act_off) (void)hipFree(s.act_off);
   }
-  void* ptrs[] = {ctx->slabs, ctx->folded, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->scalars, ctx->stop_flag};
+  void* ptrs[] = {ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->scalars, ctx->stop_flag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -425,9 +423,6 @@ int ph_fix_illegal_actions(ph_ctx* ctx, int* actions, const unsigned char* actio
 // ---- K3 + K5 + K6 ----
 namespace {
 
-constexpr int FOLD_G = 16;   // first-level slab groups
-constexpr int FOLD_MIN = 32; // fold only when at least this many slabs
-
 struct MbPlan {
   int nb, ntiles, nwg;
 };
@@ -472,9 +467,8 @@ int ensure_train_ws(ph_ctx* ctx, int P, int nwg_max, int n_mb_total) {
   }
   if (ensure(ctx->slabs, ctx->slabs_cap, (size_t)nwg_max * P)) return 1;
   if (ensure(ctx->statpart, ctx->statpart_cap, (size_t)2 * nwg_max * ph::NSTATP)) return 1;
-  if (ensure(ctx->folded, ctx->folded_cap, (size_t)FOLD_G * P)) return 1;
   if (ensure(ctx->grad, ctx->grad_cap, (size_t)P)) return 1;
-  if (ensure(ctx->blocksq, ctx->blocksq_cap, (size_t)(P + 255) / 256)) return 1;
+  if (ensure(ctx->blocksq, ctx->blocksq_cap, (size_t)ph::reduce_blocks(P))) return 1;
   if (ensure(ctx->advstats, ctx->advstats_cap, (size_t)n_mb_total * 2)) return 1;
   return 0;
 }
@@ -541,11 +535,6 @@ int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, cons
       ph::ReduceArgs r;
       r.slabs = ctx->slabs;
       r.nslab = pl.nwg;
-      if (pl.nwg >= FOLD_MIN) {
-        PH_HIP(ph::launch_slab_fold(ctx->slabs, pl.nwg, P, ctx->folded, FOLD_G, ctx->stop_flag, s));
-        r.slabs = ctx->folded;
-        r.nslab = FOLD_G;
-      }
       r.nstatpart = 2 * pl.nwg;
       r.P = P;
       r.grad = ctx->grad;
@@ -567,7 +556,7 @@ int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, cons
       ad.v = opt->adam_v;
       ad.grad = ctx->grad;
       ad.blocksq = ctx->blocksq;
-      ad.nblk = (P + 255) / 256;
+      ad.nblk = ph::reduce_blocks(P);
       ad.P = P;
       ad.step = opt->step;
       ad.scalars = ctx->scalars;
@@ -624,11 +613,6 @@ int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params,
   ph::ReduceArgs r;
   r.slabs = ctx->slabs;
   r.nslab = pl.nwg;
-  if (pl.nwg >= FOLD_MIN) {
-    PH_HIP(ph::launch_slab_fold(ctx->slabs, pl.nwg, P, ctx->folded, FOLD_G, ctx->stop_flag, s));
-    r.slabs = ctx->folded;
-    r.nslab = FOLD_G;
-  }
   r.nstatpart = 2 * pl.nwg;
   r.P = P;
   r.grad = grad_out;

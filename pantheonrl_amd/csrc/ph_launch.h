@@ -123,8 +123,7 @@ hipError_t launch_reward_add(float* rew_row, const float* reward, const unsigned
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s);
-hipError_t launch_slab_fold(const float* slabs, int nslab, int P, float* folded, int G, const int* stop_flag,
-                            hipStream_t s);
+int reduce_blocks(int P);
 hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_set_int(int* p, int v, hipStream_t s);
 hipError_t launch_epoch_advance(unsigned long long* p, hipStream_t s);

@@ -54,9 +54,12 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
     bias2 = B2[tid];
     bias3 = (net == 0) ? ((tid < nd.L) ? a.params[lay.act_b + tid] : 0.f) : a.params[lay.val_W + tid];
   }
+  PH_STAMP(a.prof, 8);
   __syncthreads();  // rowphys visible
+  PH_STAMP(a.prof, 9);
   xr.issue(rowphys, a.obs, nd, 0);
   w2r.commit(w2s);
+  PH_STAMP(a.prof, 10);
   w1r.commit(w1s);
   if (net == 0) wor.commit(wos, Lp, LDO);
   if (tid < HID) {
@@ -64,6 +67,7 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
     b2s[tid] = bias2;
     bos[tid] = bias3;
   }
+  PH_STAMP(a.prof, 11);
   xr.commit(bufA, rowphys, a.obs, nd, 0);
   __syncthreads();
   PH_STAMP(a.prof, 1);

@@ -32,6 +32,14 @@ __device__ __forceinline__ int minibatch_row(const GradArgs& a, int gi) {
   return env_major_to_phys(n, a.T, a.E);
 }
 
+// slab[i] (+)= v : the first tile of a workgroup stores, later tiles add with a no-return float atomic (the slab is
+// private to the workgroup and a sum of two terms is order-independent, so the result stays deterministic) -- no
+// load latency, no accumulator registers pinned across the tile.
+__device__ __forceinline__ void slab_acc(float* p, float v, bool first) {
+  if (first) *p = v;
+  else (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int R, int LP, bool VALU>
 __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   if (*a.stop_flag) return;
@@ -302,25 +310,18 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       if (wave < 2 * ntn) {
         const int hm = wave / ntn, hn = wave - hm * ntn;
         f32x16 g = {0};
-        if (!first) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int j = hm * 32 + drow(r, lh), col = hn * 32 + li;
-            if (col < nd.L) g[r] = slab[lay.act_W + j * nd.L + col];
-          }
-        }
         g = tile_mma<true, false, VALU>(bufA, LDH, outs, LDO, hm * 32, hn * 32, 0, R, g);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = hm * 32 + drow(r, lh), col = hn * 32 + li;
-          if (col < nd.L) slab[lay.act_W + j * nd.L + col] = g[r];
+          if (col < nd.L) slab_acc(slab + lay.act_W + j * nd.L + col, g[r], first);
         }
       }
       if (tid >= NT - 64 && tid - (NT - 64) < nd.L) {  // last wave: bias gradient
         const int k = tid - (NT - 64);
-        float s = first ? 0.f : slab[lay.act_b + k];
+        float s = 0.f;
         for (int r = 0; r < R; ++r) s += outs[r * LDO + k];
-        slab[lay.act_b + k] = s;
+        slab_acc(slab + lay.act_b + k, s, first);
       }
       __syncthreads();
       if (first) PH_STAMP(a.prof, 8);
@@ -362,13 +363,13 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       __syncthreads();
       // ---- S5a: d val_W[j] = sum_r H2[r][j] dv[r] ; d val_b = sum_r dv[r] ----
       if (tid < HID) {
-        float s = first ? 0.f : slab[lay.val_W + tid];
+        float s = 0.f;
         for (int r = 0; r < R; ++r) s = __builtin_fmaf(bufA[r * LDH + tid], rdv[r], s);
-        slab[lay.val_W + tid] = s;
+        slab_acc(slab + lay.val_W + tid, s, first);
       } else if (tid == HID) {
-        float s = first ? 0.f : slab[lay.val_b];
+        float s = 0.f;
         for (int r = 0; r < R; ++r) s += rdv[r];
-        slab[lay.val_b] = s;
+        slab_acc(slab + lay.val_b, s, first);
       }
       __syncthreads();
       // ---- S5b: dZ2[r][j] = dv[r] * val_W[j] * (1 - H2^2) in place ----
@@ -388,17 +389,13 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     if (nd.nchunk > 1) xr.issue(rowphys, a.rb_obs, nd, 0);
     {
       f32x16 g = {0};
-      if (!first) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g[r] = slab[oW2 + (mt * 32 + drow(r, lh)) * HID + nt * 32 + li];
-      }
       g = tile_mma<true, false, VALU>(bufB, LDH, bufA, LDH, mt * 32, nt * 32, 0, R, g);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) slab[oW2 + (mt * 32 + drow(r, lh)) * HID + nt * 32 + li] = g[r];
+      for (int r = 0; r < 16; ++r) slab_acc(slab + oW2 + (mt * 32 + drow(r, lh)) * HID + nt * 32 + li, g[r], first);
       if (tid < HID) {
-        float s = first ? 0.f : slab[oB2 + tid];
+        float s = 0.f;
         for (int r = 0; r < R; ++r) s += bufA[r * LDH + tid];
-        slab[oB2 + tid] = s;
+        slab_acc(slab + oB2 + tid, s, first);
       }
       dh1 = tile_mma<false, true, VALU>(bufA, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1);
     }
@@ -416,9 +413,9 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     if (first) PH_STAMP(a.prof, 11);
     // ---- S7: dW1 = X^T dZ1 per feature chunk ; d b1 ----
     if (tid < HID) {
-      float s = first ? 0.f : slab[oB1 + tid];
+      float s = 0.f;
       for (int r = 0; r < R; ++r) s += bufB[r * LDH + tid];
-      slab[oB1 + tid] = s;
+      slab_acc(slab + oB1 + tid, s, first);
     }
     for (int c = 0; c < nd.nchunk; ++c) {
       if (c > 0) {
@@ -428,18 +425,11 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
         __syncthreads();
       }
       f32x16 g = {0};
-      if (!first) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int k = c * HID + mt * 32 + drow(r, lh);
-          if (k < nd.F) g[r] = slab[oW1 + (size_t)k * HID + nt * 32 + li];
-        }
-      }
       g = tile_mma<true, false, VALU>(bufA, LDH, bufB, LDH, mt * 32, nt * 32, 0, R, g);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int k = c * HID + mt * 32 + drow(r, lh);
-        if (k < nd.F) slab[oW1 + (size_t)k * HID + nt * 32 + li] = g[r];
+        if (k < nd.F) slab_acc(slab + oW1 + (size_t)k * HID + nt * 32 + li, g[r], first);
       }
     }
     if (tile + (int)gridDim.x < a.ntiles) {
@@ -556,32 +546,13 @@ hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s) {
 }
 
 // ---- slab reduction: grad[p] = sum_g slab[g][p] (fixed order), per-block sum of squares, minibatch statistics ----
-// pass A (only when there are many slabs): grid (ceil(P/256), G); block (bx, g) sums its contiguous group of slabs
-// into partial slab g -- 8 independent loads in flight per lane, so 256 slabs cost a few memory latencies, not 64.
-__global__ __launch_bounds__(256) void ppo_slab_fold_kernel(const float* __restrict__ slabs, int nslab, int P,
-                                                            float* __restrict__ folded, int G,
-                                                            const int* __restrict__ stop_flag) {
-  if (*stop_flag != 0) return;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  const int g = blockIdx.y;
-  const int per = (nslab + G - 1) / G;
-  const int k0 = g * per, k1 = (k0 + per < nslab) ? k0 + per : nslab;
-  float acc[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-  int k = k0;
-  for (; k + 7 < k1; k += 8) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] += slabs[(size_t)(k + u) * P + p];
-  }
-  for (; k < k1; ++k) acc[0] += slabs[(size_t)k * P + p];
-  folded[(size_t)g * P + p] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-}
-
-// pass B: grad[p] = sum_g slab[g][p] (fixed order), per-block sum of squares, minibatch statistics, KL decision
-__global__ __launch_bounds__(256) void ppo_reduce_kernel(ReduceArgs a) {
-  __shared__ float sh[4];
+// grad[p] = sum_g slab[g][p] in a fixed order, per-block sum of squares, minibatch statistics, KL decision.
+// Block = 64 parameters x 16 slab groups (1024 lanes): every lane sums its group's slabs with 8 loads in flight, the 16
+// group sums are folded through LDS in a fixed order -- the whole slab set (17 MB at 256 slabs) costs two or three
+// memory latencies, and the result is bit-reproducible run to run.
+constexpr int RED_PARAMS = 64, RED_GROUPS = 16;
+__global__ __launch_bounds__(1024) void ppo_reduce_kernel(ReduceArgs a) {
+  __shared__ float gsum[RED_GROUPS][RED_PARAMS];
   __shared__ float part[32][NSTATP];
   __shared__ float means[NSTATP];
   const int tid = threadIdx.x;
@@ -593,29 +564,38 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(ReduceArgs a) {
     }
     return;
   }
-  const int p = blockIdx.x * blockDim.x + tid;
-  float g = 0.f;
-  if (p < a.P) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 3 < a.nslab; k += 4) {
-      s0 += a.slabs[(size_t)(k + 0) * a.P + p];
-      s1 += a.slabs[(size_t)(k + 1) * a.P + p];
-      s2 += a.slabs[(size_t)(k + 2) * a.P + p];
-      s3 += a.slabs[(size_t)(k + 3) * a.P + p];
+  const int pl = tid & (RED_PARAMS - 1), grp = tid >> 6;
+  const int p = blockIdx.x * RED_PARAMS + pl;
+  {
+    const int per = (a.nslab + RED_GROUPS - 1) / RED_GROUPS;
+    const int k0 = grp * per, k1 = (k0 + per < a.nslab) ? k0 + per : a.nslab;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    if (p < a.P) {
+      int k = k0;
+      for (; k + 7 < k1; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += a.slabs[(size_t)(k + u) * a.P + p];
+      }
+      for (; k < k1; ++k) acc[0] += a.slabs[(size_t)k * a.P + p];
     }
-    for (; k < a.nslab; ++k) s0 += a.slabs[(size_t)k * a.P + p];
-    g = (s0 + s1) + (s2 + s3);
-    a.grad[p] = g;
+    gsum[grp][pl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
-  float q = g * g;
-  for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
-  if ((tid & 63) == 0) sh[tid >> 6] = q;
   __syncthreads();
-  if (tid == 0) a.blocksq[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  if (tid < RED_PARAMS) {  // wave 0: fold the 16 group sums, square, wave-reduce
+    float g = 0.f;
+#pragma unroll
+    for (int j = 0; j < RED_GROUPS; ++j) g += gsum[j][tid];
+    if (p < a.P) a.grad[p] = g;
+    else g = 0.f;
+    float q = g * g;
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+    if (tid == 0) a.blocksq[blockIdx.x] = q;
+  }
 
   if (blockIdx.x == 0) {  // minibatch statistics: means over the nb rows (block-uniform branch)
-    {  // 32 lanes per statistic, strided over the workgroup partials, then a fixed-order fold
+    if (tid < 256) {  // 32 lanes per statistic, strided over the workgroup partials, then a fixed-order fold
       const int kst = tid & (NSTATP - 1), j = tid >> 3;
       float v = 0.f;
       for (int w = j; w < a.nstatpart; w += 32) v += a.statpart[(size_t)w * NSTATP + kst];
@@ -629,33 +609,28 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(ReduceArgs a) {
     }
     __syncthreads();
     if (tid == 0) {
-      const float pl = means[0], vl = means[1], el = means[2], cf = means[3], kl = means[4];
+      const float pl_ = means[0], vl = means[1], el = means[2], cf = means[3], kl = means[4];
       const bool stop = (a.target_kl >= 0.f) && (kl > 1.5f * a.target_kl);
       if (!stop && a.step) *a.step += 1;
       a.scalars[0] = kl;
       a.scalars[1] = stop ? 0.f : 1.f;
       a.scalars[2] = stop ? 1.f : 0.f;  // ppo_adam_kernel raises stop_flag (next launch), never mid-kernel
       if (a.stats_out) {
-        a.stats_out[0] = pl;
+        a.stats_out[0] = pl_;
         a.stats_out[1] = vl;
         a.stats_out[2] = el;
         a.stats_out[3] = cf;
         a.stats_out[4] = kl;
-        a.stats_out[5] = pl + a.ent_coef * el + a.vf_coef * vl;
+        a.stats_out[5] = pl_ + a.ent_coef * el + a.vf_coef * vl;
         a.stats_out[6] = 0.f;
         a.stats_out[7] = stop ? 0.f : 1.f;
       }
     }
   }
 }
-hipError_t launch_slab_fold(const float* slabs, int nslab, int P, float* folded, int G, const int* stop_flag,
-                            hipStream_t s) {
-  hipLaunchKernelGGL(ppo_slab_fold_kernel, dim3((P + 255) / 256, G), dim3(256), 0, s, slabs, nslab, P, folded, G,
-                     stop_flag);
-  return hipGetLastError();
-}
+int reduce_blocks(int P) { return (P + RED_PARAMS - 1) / RED_PARAMS; }
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(ppo_reduce_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(ppo_reduce_kernel, dim3(reduce_blocks(a.P)), dim3(RED_PARAMS * RED_GROUPS), 0, s, a);
   return hipGetLastError();
 }
 

@@ -47,8 +47,12 @@ for rep in range(2):
     agent.n_steps = 0
     agent.get_action(data.obs[0])
     th.cuda.synchronize()
-report("policy_fwd", (E + 31) // 32, 2, ["params+W2 load", "X+W1 load", "L1 mma", "H1 tanh + Wo load", "L2 mma+tanh",
+report("policy_fwd", (E + 31) // 32, 2, ["all staging loads+commit", "(chunk loop entry)", "L1 mma", "H1 tanh", "L2 mma+tanh",
                                         "head mma", "sampling / value+obs copy"])
+st = stamps.cpu().numpy().reshape(-1, 16)[:(E + 31) // 32]
+for lab, a0, a1 in (("issue W2/W1/Wo/bias", 0, 8), ("barrier(rowphys)", 8, 9), ("X issue + W2 commit", 9, 10),
+                    ("W1/Wo/bias commit", 10, 11), ("X commit + barrier", 11, 1)):
+    print(f"    fwd prologue  {lab:<24} median {np.median(st[:, a1] - st[:, a0]):>8.0f}")
 # grad
 hp = model.hyper()
 ms = C.c_float(0)
