@@ -32,14 +32,9 @@ __device__ __forceinline__ int minibatch_row(const GradArgs& a, int gi) {
   return env_major_to_phys(n, a.T, a.E);
 }
 
-// slab[i] (+)= v : the first tile of a workgroup stores, later tiles add with a no-return float atomic (the slab is
-// private to the workgroup and a sum of two terms is order-independent, so the result stays deterministic) -- no
-// load latency, no accumulator registers pinned across the tile.
-__device__ __forceinline__ void slab_acc(float* p, float v, bool first) {
-  if (first) *p = v;
-  else (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
+// Weight-gradient tiles accumulate across the tiles of a workgroup in its private slab: the MFMA accumulator is
+// initialised from the slab (the loads hide under the operand prefetch of the tile product), then stored back.
+// (No-return L2 float atomics instead of the reload measured 8 % slower on the whole kernel.)
 template <int R, int LP, bool VALU>
 __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   if (*a.stop_flag) return;
@@ -310,18 +305,25 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       if (wave < 2 * ntn) {
         const int hm = wave / ntn, hn = wave - hm * ntn;
         f32x16 g = {0};
+        if (!first) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = hm * 32 + drow(r, lh), col = hn * 32 + li;
+            if (col < nd.L) g[r] = slab[lay.act_W + j * nd.L + col];
+          }
+        }
         g = tile_mma<true, false, VALU>(bufA, LDH, outs, LDO, hm * 32, hn * 32, 0, R, g);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = hm * 32 + drow(r, lh), col = hn * 32 + li;
-          if (col < nd.L) slab_acc(slab + lay.act_W + j * nd.L + col, g[r], first);
+          if (col < nd.L) slab[lay.act_W + j * nd.L + col] = g[r];
         }
       }
       if (tid >= NT - 64 && tid - (NT - 64) < nd.L) {  // last wave: bias gradient
         const int k = tid - (NT - 64);
-        float s = 0.f;
+        float s = first ? 0.f : slab[lay.act_b + k];
         for (int r = 0; r < R; ++r) s += outs[r * LDO + k];
-        slab_acc(slab + lay.act_b + k, s, first);
+        slab[lay.act_b + k] = s;
       }
       __syncthreads();
       if (first) PH_STAMP(a.prof, 8);
@@ -363,13 +365,13 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       __syncthreads();
       // ---- S5a: d val_W[j] = sum_r H2[r][j] dv[r] ; d val_b = sum_r dv[r] ----
       if (tid < HID) {
-        float s = 0.f;
+        float s = first ? 0.f : slab[lay.val_W + tid];
         for (int r = 0; r < R; ++r) s = __builtin_fmaf(bufA[r * LDH + tid], rdv[r], s);
-        slab_acc(slab + lay.val_W + tid, s, first);
+        slab[lay.val_W + tid] = s;
       } else if (tid == HID) {
-        float s = 0.f;
+        float s = first ? 0.f : slab[lay.val_b];
         for (int r = 0; r < R; ++r) s += rdv[r];
-        slab_acc(slab + lay.val_b, s, first);
+        slab[lay.val_b] = s;
       }
       __syncthreads();
       // ---- S5b: dZ2[r][j] = dv[r] * val_W[j] * (1 - H2^2) in place ----
@@ -389,13 +391,17 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     if (nd.nchunk > 1) xr.issue(rowphys, a.rb_obs, nd, 0);
     {
       f32x16 g = {0};
+      if (!first) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = slab[oW2 + (mt * 32 + drow(r, lh)) * HID + nt * 32 + li];
+      }
       g = tile_mma<true, false, VALU>(bufB, LDH, bufA, LDH, mt * 32, nt * 32, 0, R, g);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) slab_acc(slab + oW2 + (mt * 32 + drow(r, lh)) * HID + nt * 32 + li, g[r], first);
+      for (int r = 0; r < 16; ++r) slab[oW2 + (mt * 32 + drow(r, lh)) * HID + nt * 32 + li] = g[r];
       if (tid < HID) {
-        float s = 0.f;
+        float s = first ? 0.f : slab[oB2 + tid];
         for (int r = 0; r < R; ++r) s += bufA[r * LDH + tid];
-        slab_acc(slab + oB2 + tid, s, first);
+        slab[oB2 + tid] = s;
       }
       dh1 = tile_mma<false, true, VALU>(bufA, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1);
     }
@@ -413,9 +419,9 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     if (first) PH_STAMP(a.prof, 11);
     // ---- S7: dW1 = X^T dZ1 per feature chunk ; d b1 ----
     if (tid < HID) {
-      float s = 0.f;
+      float s = first ? 0.f : slab[oB1 + tid];
       for (int r = 0; r < R; ++r) s += bufB[r * LDH + tid];
-      slab_acc(slab + oB1 + tid, s, first);
+      slab[oB1 + tid] = s;
     }
     for (int c = 0; c < nd.nchunk; ++c) {
       if (c > 0) {
@@ -425,11 +431,18 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
         __syncthreads();
       }
       f32x16 g = {0};
+      if (!first) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = c * HID + mt * 32 + drow(r, lh);
+          if (k < nd.F) g[r] = slab[oW1 + (size_t)k * HID + nt * 32 + li];
+        }
+      }
       g = tile_mma<true, false, VALU>(bufA, LDH, bufB, LDH, mt * 32, nt * 32, 0, R, g);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int k = c * HID + mt * 32 + drow(r, lh);
-        if (k < nd.F) slab_acc(slab + oW1 + (size_t)k * HID + nt * 32 + li, g[r], first);
+        if (k < nd.F) slab[oW1 + (size_t)k * HID + nt * 32 + li] = g[r];
       }
     }
     if (tile + (int)gridDim.x < a.ntiles) {
