@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--agents-per-gpu", type=int, default=2,
                     help="self-play pair per GPU (ego PPO + partner PPO, trainer.py ... PPO PPO)")
     ap.add_argument("--mode", choices=("auto", "graph", "eager"), default="auto")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
+                    "exercise the N>1 code path with several ranks on ONE GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -134,7 +136,8 @@ def roofline(args, agent):
     out = {"bound": "mfma", "kernel": "ppo_grad_kernel<64,false>", "achieved": achieved, "peak": 157.3,
            "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None, "launch_ms": ms.value,
            "flops_per_launch": flops}
-    # secondary, HBM-bound: the GAE pass at this size (20 algorithmic bytes per transition)
+    # secondary, HBM-bound: the GAE pass (20 algorithmic bytes per transition) at the bench size (launch-latency bound:
+    # 2.6 MB) and at a saturating size (E=16384, T=2048: 671 MB), serial (bit-exact) and scan kernels
     lv = th.zeros(rb.n_envs, device=pol.device)
     gms = C.c_float(0)
     nat.check(pol.ctx.lib.ph_bench_gae(pol.ctx.handle, C.byref(rb.c_struct()), lv.data_ptr(), lv.data_ptr(), 0.99, 0.95,
@@ -142,6 +145,39 @@ def roofline(args, agent):
     gb = 20.0 * rb.buffer_size * rb.n_envs
     out["gae"] = {"bound": "hbm", "achieved": gb / (gms.value * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                   "launch_ms": gms.value, "bytes_per_launch": gb}
+    try:
+        Tb, Eb = 2048, 16384
+        big = nat.PhRollout()
+        big.T, big.E = Tb, Eb
+        keep = []
+        gen = th.Generator(device=pol.device).manual_seed(0)
+        for name in ("observations", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages",
+                     "returns"):
+            if name in ("observations", "actions", "log_probs"):
+                t = th.zeros(1, device=pol.device)
+            elif name == "episode_starts":
+                t = (th.rand((Tb, Eb), device=pol.device, generator=gen) < 0.0025).float()
+            else:
+                t = th.randn((Tb, Eb), device=pol.device, generator=gen)
+            keep.append(t)
+            setattr(big, name, t.data_ptr())
+        lvb = th.zeros(Eb, device=pol.device)
+        sat = {}
+        for mode, label in ((1, "serial"), (2, "scan")):
+            nat.check(pol.ctx.lib.ph_bench_gae(pol.ctx.handle, C.byref(big), lvb.data_ptr(), lvb.data_ptr(), 0.99, 0.95,
+                                               mode, 5, C.byref(gms)))
+            sat[label] = {"GB/s": 20.0 * Tb * Eb / (gms.value * 1e-3) / 1e9, "launch_ms": gms.value}
+        out["gae_saturating"] = {"n_envs": Eb, "n_steps": Tb, "bytes_per_launch": 20.0 * Tb * Eb, "peak": 8000.0, **sat}
+        del keep
+    except Exception as exc:  # noqa: BLE001 -- measurement extra, never fatal
+        out["gae_saturating"] = {"error": str(exc)}
+    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc, separate runs), if recorded
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_ppo_grad.json")))
+        out["traffic"] = rec["hbm_bytes_per_launch"]
+        out["traffic_source"] = rec["source"]
+    except Exception:  # noqa: BLE001
+        pass
     return out
 
 
@@ -155,9 +191,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not th.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    if args.backend != "nccl":
+        local_rank = local_rank % th.cuda.device_count()   # several ranks per GPU: functional test only
     th.cuda.set_device(local_rank)
     device = th.device("cuda", local_rank)
-    distributed = pdist.init_from_env("nccl")
+    distributed = pdist.init_from_env(args.backend)
     import torch.distributed as tdist
 
     from pantheonrl_amd.vec import IterationGraph, run_iteration_eager

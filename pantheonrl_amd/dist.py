@@ -62,6 +62,11 @@ class ActionExchange:
             self.local[i].copy_(a.reshape(-1))
         if self.world == 1:
             self.joint.copy_(self.local)
+        elif self.local.is_cuda and dist.get_backend(self.group) == "gloo":
+            # test-only route (two ranks sharing one GPU cannot form an RCCL communicator): stage through the host
+            host = th.empty(self.joint.shape, dtype=self.joint.dtype)
+            dist.all_gather_into_tensor(host, self.local.cpu(), group=self.group)
+            self.joint.copy_(host)
         else:
             dist.all_gather_into_tensor(self.joint, self.local, group=self.group)
         return self.joint
