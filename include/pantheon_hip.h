@@ -140,7 +140,7 @@ int ph_buffer_reset(ph_ctx *ctx, const ph_spec *spec, const ph_rollout *rb);
  * gamma / gae_lambda are doubles because the reference multiplies them as Python floats before the
  * float32 array arithmetic (gamma*gae_lambda is rounded to f32 once).
  * mode 0 = auto, 1 = serial-in-T / one lane per env (summation order and rounding identical to the numpy
- * loop: bit-exact), 2 = chunked wavefront suffix scan over T (fp32 tolerance). */
+ * loop: bit-exact), 2 = chunked wavefront suffix scan over T, any T (fp32 tolerance). */
 int ph_gae(ph_ctx *ctx, const ph_rollout *rb, const float *last_values /* (E) */, const float *dones /* (E) */,
            double gamma, double gae_lambda, int mode);
 

@@ -350,7 +350,6 @@ int ph_gae(ph_ctx* ctx, const ph_rollout* rb, const float* last_values, const fl
   if (check_rb(rb)) return 1;
   if (!last_values || !dones) return fail("ph_gae: null last_values/dones");
   if (mode < 0 || mode > 2) return fail("ph_gae: mode must be 0, 1 or 2");
-  if (mode == 2 && rb->T > 2048) return fail("ph_gae: scan mode supports T <= 2048 (use mode 0/1)");
   PH_HIP(ph::launch_gae(rb->rewards, rb->values, rb->episode_starts, last_values, dones, rb->advantages, rb->returns,
                         rb->T, rb->E, gamma, gae_lambda, mode, ctx->stream));
   return 0;
@@ -682,7 +681,6 @@ int ph_bench_gae(ph_ctx* ctx, const ph_rollout* rb, const float* last_values, co
   if (!ctx || !last_values || !dones || !avg_ms_out) return fail("ph_bench_gae: null argument");
   if (check_rb(rb)) return 1;
   if (reps <= 0 || mode < 0 || mode > 2) return fail("ph_bench_gae: bad arguments");
-  if (mode == 2 && rb->T > 2048) return fail("ph_bench_gae: scan mode supports T <= 2048");
   hipStream_t s = ctx->stream;
   auto once = [&]() {
     return ph::launch_gae(rb->rewards, rb->values, rb->episode_starts, last_values, dones, rb->advantages, rb->returns,

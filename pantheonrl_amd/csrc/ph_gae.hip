@@ -57,10 +57,12 @@ __global__ __launch_bounds__(64) void gae_serial_kernel(const float* __restrict_
 
 // ---- chunked wavefront suffix scan over T --------------------------------------------------------------------------
 // A_t = delta_t + c_t * A_{t+1} is a first-order linear recurrence: the map A_{t+1} -> A_t composes associatively,
-// (S1,P1) o (S2,P2) = (S1 + P1*S2, P1*P2).  A workgroup owns EB consecutive envs (one 64/128-byte segment per row)
-// and all T steps, cut into NCH = ceil(T/LC) chunks; lane (chunk, env) runs its LC steps serially keeping the local
-// advantages and running coefficient products in registers, the NCH chunk composites are suffix-scanned through LDS
-// (Hillis-Steele, log2 NCH rounds), and each lane then fixes up its LC outputs.  One HBM read + one write per element.
+// (S1,P1) o (S2,P2) = (S1 + P1*S2, P1*P2).  A workgroup owns EB = 32 consecutive envs (one full 128-byte line per
+// row: 16-env / 64-byte segments measured 2x FETCH_SIZE) and walks T from the end in super-chunks of NCH*LC steps;
+// inside a super-chunk lane (chunk, env) runs its LC steps serially keeping the local advantages and running
+// coefficient products in registers, the NCH chunk composites are suffix-scanned through LDS (Hillis-Steele,
+// log2 NCH rounds), each lane fixes up its LC outputs with the carried-in advantage, and the advantage at the first
+// step of the super-chunk is carried to the next one.  One HBM read + one write per element, any T.
 template <int LC, int EB>
 __global__ __launch_bounds__(1024) void gae_scan_kernel(const float* __restrict__ rew, const float* __restrict__ val,
                                                         const float* __restrict__ es,
@@ -69,82 +71,95 @@ __global__ __launch_bounds__(1024) void gae_scan_kernel(const float* __restrict_
                                                         float* __restrict__ ret, int T, int E, int NCH, float g,
                                                         float gl) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* sS = sm;             // [NCH][EB]
-  float* sP = sm + NCH * EB;  // [NCH][EB]
+  float* sS = sm;                 // [NCH][EB]
+  float* sP = sm + NCH * EB;      // [NCH][EB]
+  float* carry = sP + NCH * EB;   // [EB] advantage at the first step of the super-chunk processed before this one
   const int el = threadIdx.x % EB, ch = threadIdx.x / EB;
   const int e = blockIdx.x * EB + el;
-  const bool live = (e < E) && (ch < NCH);
-  const int t0 = ch * LC;
-  float a[LC], cp[LC], vv[LC];
-  float S = 0.f, P = 1.f;
-  if (live) {
-    const int tend = (t0 + LC < T) ? t0 + LC : T;  // exclusive
-    float nv, nnt;
-    if (tend == T) {
-      nv = last_values[e];
-      nnt = 1.0f - dones[e];
-    } else {
-      nv = val[(size_t)tend * E + e];
-      nnt = 1.0f - es[(size_t)tend * E + e];
-    }
-    float r[LC], s[LC];
-#pragma unroll
-    for (int k = 0; k < LC; ++k) {
-      const int t = t0 + k;
-      const size_t o = (size_t)(t < T ? t : T - 1) * E + e;
-      r[k] = rew[o];
-      vv[k] = val[o];
-      s[k] = es[o];
-    }
-    float A = 0.f, Pacc = 1.f;
-#pragma unroll
-    for (int k = LC - 1; k >= 0; --k) {
-      if (t0 + k < T) {
-        const float delta = r[k] + g * nv * nnt - vv[k];
-        const float c = gl * nnt;
-        A = delta + c * A;
-        Pacc = c * Pacc;
-        nv = vv[k];
-        nnt = 1.0f - s[k];
+  const bool env_ok = e < E;
+  const int span = NCH * LC;
+  if (ch == 0) carry[el] = 0.f;
+  // super-chunks cover [base, base+span) with base = T - span, T - 2*span, ... (the first one may start below 0)
+  for (int top = T; top > 0; top -= span) {
+    const int base = top - span;
+    const int t0 = base + ch * LC;              // first step of this lane's chunk (may be negative: masked)
+    const int tend = t0 + LC;                   // exclusive; tend <= top <= T
+    const bool live = env_ok && tend > 0;
+    float a[LC], cp[LC], vv[LC];
+    float S = 0.f, P = 1.f;
+    if (live) {
+      float nv, nnt;
+      if (tend == T) {
+        nv = last_values[e];
+        nnt = 1.0f - dones[e];
+      } else {
+        nv = val[(size_t)tend * E + e];
+        nnt = 1.0f - es[(size_t)tend * E + e];
       }
-      a[k] = A;
-      cp[k] = Pacc;
+      float r[LC], s[LC];
+#pragma unroll
+      for (int k = 0; k < LC; ++k) {
+        const int t = t0 + k;
+        const size_t o = (size_t)(t >= 0 ? t : 0) * E + e;
+        r[k] = rew[o];
+        vv[k] = val[o];
+        s[k] = es[o];
+      }
+      float A = 0.f, Pacc = 1.f;
+#pragma unroll
+      for (int k = LC - 1; k >= 0; --k) {
+        if (t0 + k >= 0) {
+          const float delta = r[k] + g * nv * nnt - vv[k];
+          const float c = gl * nnt;
+          A = delta + c * A;
+          Pacc = c * Pacc;
+          nv = vv[k];
+          nnt = 1.0f - s[k];
+        }
+        a[k] = A;
+        cp[k] = Pacc;
+      }
+      S = A;
+      P = Pacc;
     }
-    S = A;
-    P = Pacc;
-  }
-  if (ch < NCH) {
+    __syncthreads();  // carry of the previous super-chunk visible / LDS of the previous round consumed
     sS[ch * EB + el] = S;
     sP[ch * EB + el] = P;
-  }
-  // suffix scan: after the loop (S,P) of chunk ch is the composite of chunks [ch, NCH)
-  for (int d = 1; d < NCH; d <<= 1) {
-    __syncthreads();
-    float S2 = 0.f, P2 = 1.f;
-    const bool has = (ch + d < NCH);
-    if (has) {
-      S2 = sS[(ch + d) * EB + el];
-      P2 = sP[(ch + d) * EB + el];
+    // suffix scan: afterwards (S,P) of chunk ch is the composite of chunks [ch, NCH) of this super-chunk
+    for (int d = 1; d < NCH; d <<= 1) {
+      __syncthreads();
+      float S2 = 0.f, P2 = 1.f;
+      const bool has = (ch + d < NCH);
+      if (has) {
+        S2 = sS[(ch + d) * EB + el];
+        P2 = sP[(ch + d) * EB + el];
+      }
+      __syncthreads();
+      if (has) {
+        S = S + P * S2;
+        P = P * P2;
+        sS[ch * EB + el] = S;
+        sP[ch * EB + el] = P;
+      }
     }
     __syncthreads();
-    if (has) {
-      S = S + P * S2;
-      P = P * P2;
-      sS[ch * EB + el] = S;
-      sP[ch * EB + el] = P;
-    }
-  }
-  __syncthreads();
-  if (!live) return;
-  const float Ain = (ch + 1 < NCH) ? sS[(ch + 1) * EB + el] : 0.f;  // true advantage at the first step of the next chunk
+    const float cin = carry[el];
+    // true advantage entering this lane's chunk from above: composite of the later chunks applied to the carry
+    const float Ain = (ch + 1 < NCH) ? sS[(ch + 1) * EB + el] + sP[(ch + 1) * EB + el] * cin : cin;
+    const float Afirst = sS[el] + sP[el] * cin;  // advantage at the first (valid) step of the super-chunk
+    __syncthreads();
+    if (ch == 0) carry[el] = Afirst;
+    if (live) {
 #pragma unroll
-  for (int k = 0; k < LC; ++k) {
-    const int t = t0 + k;
-    if (t < T) {
-      const size_t o = (size_t)t * E + e;
-      const float A = a[k] + cp[k] * Ain;
-      adv[o] = A;
-      ret[o] = A + vv[k];
+      for (int k = 0; k < LC; ++k) {
+        const int t = t0 + k;
+        if (t >= 0) {
+          const size_t o = (size_t)t * E + e;
+          const float A = a[k] + cp[k] * Ain;
+          adv[o] = A;
+          ret[o] = A + vv[k];
+        }
+      }
     }
   }
 }
@@ -152,33 +167,30 @@ __global__ __launch_bounds__(1024) void gae_scan_kernel(const float* __restrict_
 template <int LC, int EB>
 static hipError_t launch_scan(const float* rew, const float* val, const float* es, const float* lv, const float* dn,
                               float* adv, float* ret, int T, int E, float g, float gl, hipStream_t s) {
-  const int NCH = (T + LC - 1) / LC;
+  int NCH = (T + LC - 1) / LC;
+  const int maxch = 1024 / EB;
+  if (NCH > maxch) NCH = maxch;
   dim3 grid((E + EB - 1) / EB), block(NCH * EB);
-  const size_t lds = sizeof(float) * 2 * NCH * EB;
+  const size_t lds = sizeof(float) * (2 * NCH * EB + EB);
   hipLaunchKernelGGL((gae_scan_kernel<LC, EB>), grid, block, lds, s, rew, val, es, lv, dn, adv, ret, T, E, NCH, g, gl);
   return hipGetLastError();
 }
 
-// mode: 1 serial, 2 scan, 0 auto.  Returns hipErrorInvalidValue for an impossible request.
+// mode: 1 serial, 2 scan, 0 auto.
 hipError_t launch_gae(const float* rew, const float* val, const float* es, const float* lv, const float* dn, float* adv,
                       float* ret, int T, int E, double gamma, double lam, int mode, hipStream_t s) {
   const float g = (float)gamma;
   const float gl = (float)(gamma * lam);  // Python multiplies the two floats in double first
-  if (mode == 0) {
-    // the serial form needs >= ~64 lanes per CU to cover HBM latency; below that the scan's T-parallelism wins
-    mode = (E >= 32768 || T > 2048) ? 1 : 2;
-  }
+  if (mode == 0) mode = 2;  // the scan exposes T-parallelism as well as E-parallelism: faster at every measured shape
   if (mode == 1) {
     hipLaunchKernelGGL(gae_serial_kernel, dim3((E + 63) / 64), dim3(64), 0, s, rew, val, es, lv, dn, adv, ret, T, E, g,
                        gl);
     return hipGetLastError();
   }
-  if (T > 2048) return hipErrorInvalidValue;
-  // lanes per workgroup = ceil(T/LC) * EB <= 1024
-  if (T <= 128) return launch_scan<8, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);     // <=16 chunks x 32 envs
-  if (T <= 512) return launch_scan<16, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);    // <=32 x 32
-  if (T <= 1024) return launch_scan<32, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);   // <=32 x 32
-  return launch_scan<32, 16>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);                   // <=64 x 16
+  // lanes per workgroup = min(ceil(T/LC), 1024/32) * 32
+  if (T <= 256) return launch_scan<8, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
+  if (T <= 512) return launch_scan<16, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
+  return launch_scan<32, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
 }
 
 // ---- K1: RolloutBuffer.add / reward += / reset -----------------------------------------------------------------------

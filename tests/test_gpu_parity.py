@@ -69,8 +69,8 @@ def test_gae_serial_is_bit_exact(T, E):
     assert np.array_equal(ret, ret_ref)
 
 
-@pytest.mark.parametrize("T,E", [(1, 1), (4, 1), (7, 3), (8, 64), (37, 5), (128, 1024), (129, 40), (512, 16),
-                                 (1000, 31), (2048, 1), (2048, 70)])
+@pytest.mark.parametrize("T,E", [(1, 1), (4, 1), (7, 3), (8, 64), (37, 5), (128, 1024), (129, 40), (257, 33), (512, 16),
+                                 (1000, 31), (1025, 2), (2048, 1), (2048, 70), (3000, 7), (4097, 33)])
 def test_gae_scan_within_fp32_tolerance(T, E):
     r, v, s, lv, dn = _gae_inputs(T, E, seed=T * 1000 + E + 1)
     a_ref, ret_ref = orc.gae_reference(r, v, s, lv, dn)
