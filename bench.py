@@ -205,7 +205,9 @@ def main():
     streams = [th.cuda.Stream(device=device) for _ in agents]
     mode = args.mode
     if mode == "auto":
-        mode = "eager" if distributed else "graph"
+        mode = "stepgraph" if distributed else "graph"
+    if distributed:
+        mode = "stepgraph"
     exchange = pdist.ActionExchange(len(agents), args.n_envs, device) if distributed else None
 
     if mode == "graph":
@@ -220,22 +222,18 @@ def main():
                 with th.cuda.stream(s):
                     run_iteration_eager(a, d)
     else:
-        # agent-per-GPU layout: every environment step all-gathers the actions of all seats (RCCL over xGMI); the
-        # (synthetic) transition consumes the joint action: a shared coordination bonus when a seat's action equals
-        # its round-robin partner's, like Overcooked's shared reward.
+        # agent-per-GPU layout: every environment step all-gathers the actions of all seats (RCCL over xGMI) between
+        # the policy forwards and the reward updates; the (synthetic) transition consumes the joint action: a shared
+        # coordination bonus when a seat's action equals its round-robin partner's (Overcooked's reward is shared).
+        # Local work is pre-captured per step (vec.StepGraphs): 2 graph launches + 1 collective per step.
+        from pantheonrl_amd.vec import StepGraphs
+        th.cuda.set_stream(streams[0])
+        steps = StepGraphs(agents, datas, exchange, streams[0])
+        it_counter = [0]
+
         def iteration():
-            for a in agents:
-                a.bind_stream()
-            T = datas[0].T
-            for t in range(T):
-                acts = [a.get_action(d.obs[t]) for a, d in zip(agents, datas)]
-                joint = exchange.gather(acts)
-                for i, (a, d) in enumerate(zip(agents, datas)):
-                    partner = exchange.partner_of(exchange.seat(i), a.iteration)
-                    bonus = (joint[exchange.seat(i)] == joint[partner]).to(th.float32) * 0.01
-                    a.update(d.rewards[t] + bonus, d.dones[t])
-            for a in agents:
-                a.learn_from_buffer()
+            steps.run_iteration(it_counter[0])
+            it_counter[0] += 1
 
     def barrier():
         th.cuda.synchronize(device)

@@ -132,6 +132,13 @@ int ph_buffer_add(ph_ctx *ctx, const ph_spec *spec, const ph_rollout *rb, int po
 /* buf.rewards[pos][e] += reward[e] for e with env_mask[e] != 0 (NULL = all) <- Agent.update, agents.py:198 */
 int ph_buffer_add_reward(ph_ctx *ctx, const ph_rollout *rb, int pos, const float *reward /* (E) */,
                          const unsigned char *env_mask /* (E) or NULL */);
+/* Agent-per-GPU SimultaneousEnv step (multiagentenv.py:149-170 with the actions all-gathered over RCCL): seat `seat`
+ * receives rewards[pos][e] += base_reward[e] + bonus * (joint[seat][e] == joint[*partner_seat][e]) -- the shared
+ * coordination term of the synthetic transition, consuming the JOINT action.  joint_actions is (n_seats, E) int32;
+ * partner_seat is a DEVICE int so the round-robin pairing (kept in Python) can change between graph replays. */
+int ph_buffer_add_reward_joint(ph_ctx *ctx, const ph_rollout *rb, int pos, const float *base_reward /* (E) */,
+                               const int *joint_actions, int n_seats, int seat, const int *partner_seat /* device */,
+                               float bonus);
 /* RolloutBuffer.reset() <- agents.py:157 : zero-fills every array */
 int ph_buffer_reset(ph_ctx *ctx, const ph_spec *spec, const ph_rollout *rb);
 

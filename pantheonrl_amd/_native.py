@@ -75,6 +75,7 @@ SIGNATURES = {
     "ph_layout_of": [C.POINTER(PhSpec), C.POINTER(PhLayout)],
     "ph_buffer_add": [_vp, C.POINTER(PhSpec), C.POINTER(PhRollout), _i, _vp, _vp, _vp, _vp, _vp],
     "ph_buffer_add_reward": [_vp, C.POINTER(PhRollout), _i, _vp, _vp],
+    "ph_buffer_add_reward_joint": [_vp, C.POINTER(PhRollout), _i, _vp, _vp, _i, _i, _vp, C.c_float],
     "ph_buffer_reset": [_vp, C.POINTER(PhSpec), C.POINTER(PhRollout)],
     "ph_gae": [_vp, C.POINTER(PhRollout), _vp, _vp, _d, _d, _i],
     "ph_policy_forward": [_vp, C.POINTER(PhSpec), _vp, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, _vp, _vp,

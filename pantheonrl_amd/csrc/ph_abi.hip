@@ -331,6 +331,18 @@ int ph_buffer_add_reward(ph_ctx* ctx, const ph_rollout* rb, int pos, const float
   return 0;
 }
 
+int ph_buffer_add_reward_joint(ph_ctx* ctx, const ph_rollout* rb, int pos, const float* base_reward,
+                               const int* joint_actions, int n_seats, int seat, const int* partner_seat, float bonus) {
+  if (!ctx) return fail("null ctx");
+  if (check_rb(rb)) return 1;
+  if (pos < 0 || pos >= rb->T) return fail("ph_buffer_add_reward_joint: pos out of range");
+  if (!base_reward || !joint_actions || !partner_seat) return fail("ph_buffer_add_reward_joint: null argument");
+  if (n_seats <= 0 || seat < 0 || seat >= n_seats) return fail("ph_buffer_add_reward_joint: bad seat");
+  PH_HIP(ph::launch_reward_add_joint(rb->rewards + (size_t)pos * rb->E, base_reward, joint_actions, rb->E, n_seats, seat,
+                                     partner_seat, bonus, ctx->stream));
+  return 0;
+}
+
 int ph_buffer_reset(ph_ctx* ctx, const ph_spec* spec, const ph_rollout* rb) {
   if (!ctx) return fail("null ctx");
   ph_layout lay;

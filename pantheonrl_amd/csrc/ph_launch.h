@@ -120,6 +120,8 @@ hipError_t launch_buffer_add(float* d_obs, float* d_act, float* d_rew, float* d_
                              const float* obs, const float* act, const float* es, const float* val, const float* lp,
                              int E, int D, int A, hipStream_t s);
 hipError_t launch_reward_add(float* rew_row, const float* reward, const unsigned char* env_mask, int E, hipStream_t s);
+hipError_t launch_reward_add_joint(float* rew_row, const float* base, const int* joint, int E, int n_seats, int seat,
+                                   const int* partner_seat, float bonus, hipStream_t s);
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s);

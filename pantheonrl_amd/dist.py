@@ -60,6 +60,10 @@ class ActionExchange:
         stream; no host synchronisation."""
         for i, a in enumerate(local_actions):
             self.local[i].copy_(a.reshape(-1))
+        return self.gather_inplace()
+
+    def gather_inplace(self) -> th.Tensor:
+        """all-gather of `self.local` (already filled in place, e.g. by the policy-forward kernels) -> `self.joint`."""
         if self.world == 1:
             self.joint.copy_(self.local)
         elif self.local.is_cuda and dist.get_backend(self.group) == "gloo":

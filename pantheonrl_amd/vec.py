@@ -36,7 +36,7 @@ class VecOnPolicyAgent:
         self.num_timesteps = 0
         self.iteration = 0
         # preallocated outputs: no allocation on the per-step path (and stable pointers for graph capture)
-        self.actions = th.zeros((E, lay.A), dtype=th.int32, device=dev)
+        self.actions = th.zeros((E, lay.A), dtype=th.int32, device=dev)   # may be re-pointed at an exchange buffer row
         self.values = th.zeros((E,), dtype=th.float32, device=dev)
         self.log_probs = th.zeros((E,), dtype=th.float32, device=dev)
         self._lib, self._h = pol.ctx.lib, pol.ctx.handle
@@ -77,6 +77,17 @@ class VecOnPolicyAgent:
             rb = self.model.rollout_buffer
             nat.check(self._lib.ph_buffer_add_reward(self._h, self._rb, rb.pos - 1, reward.data_ptr(),
                                                      nat.ptr(env_mask)))
+        self._last_episode_starts = done
+
+    def update_joint(self, base_reward: th.Tensor, done: th.Tensor, joint: th.Tensor, seat: int,
+                     partner_seat: th.Tensor, bonus: float = 0.01) -> None:
+        """update() of the agent-per-GPU simultaneous step: reward = base + bonus * [own action == partner's], computed
+        from the all-gathered JOINT action (n_seats, E) in one launch.  `partner_seat` is a device int32 scalar."""
+        self.flush_rewards()
+        rb = self.model.rollout_buffer
+        nat.check(self._lib.ph_buffer_add_reward_joint(self._h, self._rb, rb.pos - 1, base_reward.data_ptr(),
+                                                       joint.data_ptr(), int(joint.shape[0]), int(seat),
+                                                       partner_seat.data_ptr(), float(bonus)))
         self._last_episode_starts = done
 
     def flush_rewards(self) -> None:
@@ -162,3 +173,91 @@ class IterationGraph:
         nat.check(pol.ctx.lib.ph_graph_launch(pol.ctx.handle, self.graph_id))
         self.agent.iteration += 1
         self.agent.num_timesteps += self.data.T * self.data.E
+
+
+class StepGraphs:
+    """Agent-per-GPU rollout with a collective between the two halves of every environment step.
+
+    For every step t two small hipGraphs are captured once: `act[t]` = the policy forward + row write of every local
+    agent, `upd[t]` = every local agent's joint-action reward update.  An iteration then costs, per step, two graph
+    launches plus ONE torch.distributed all-gather issued by the caller between them; GAE + PPO update of all local
+    agents are a third graph.  Host overhead per step drops from ~10 calls to 3, which is what keeps the N>1 path
+    GPU-bound (the collective itself is a KB-sized, latency-bound message)."""
+
+    def __init__(self, agents, datas, exchange, stream: th.cuda.Stream, bonus: float = 0.01):
+        self.agents, self.datas, self.exchange, self.stream, self.bonus = agents, datas, exchange, stream, bonus
+        dev = agents[0].model.policy.device
+        self.partner = [th.zeros(1, dtype=th.int32, device=dev) for _ in agents]
+        self.T = datas[0].T
+        lead = agents[0].model.policy
+        self._lib, self._h = lead.ctx.lib, lead.ctx.handle
+        self.epoch_word = th.zeros(1, dtype=th.int64, device=dev)
+        for i, a in enumerate(agents):
+            a.actions = exchange.local[i].view(a.E, 1)       # forward writes straight into the exchange buffer
+            a.model.device_permutations = True
+            nat.check(a.model.policy.ctx.lib.ph_ctx_set_rng_epoch(a.model.policy.ctx.handle, self.epoch_word.data_ptr()))
+        with th.cuda.stream(stream):
+            self._eager_iteration(gather=False)              # warm-up: sizes workspaces, caches specs
+            stream.synchronize()
+            self.act, self.upd = [], []
+            for t in range(self.T):
+                self.act.append(self._capture(lambda t=t: self._act(t)))
+                self.upd.append(self._capture(lambda t=t: self._upd(t)))
+            self.learn = self._capture(self._learn)
+            for a in agents:                                  # captures do not execute: restore the Python-side counters
+                a.model.rollout_buffer.pos, a.n_steps = 0, 0
+
+    def _bind(self):
+        for a in self.agents:
+            a.bind_stream()
+
+    def _act(self, t):
+        for a, d in zip(self.agents, self.datas):
+            a.get_action(d.obs[t])
+
+    def _upd(self, t):
+        ex = self.exchange
+        for i, (a, d) in enumerate(zip(self.agents, self.datas)):
+            a.update_joint(d.rewards[t], d.dones[t], ex.joint, ex.seat(i), self.partner[i], self.bonus)
+
+    def _learn(self):
+        for a in self.agents:
+            a.learn_from_buffer()
+        nat.check(self._lib.ph_rng_epoch_advance(self._h))
+
+    def _eager_iteration(self, gather: bool):
+        self._bind()
+        for t in range(self.T):
+            self._act(t)
+            if gather:
+                self.exchange.gather_inplace()
+            self._upd(t)
+        self._learn()
+
+    def _capture(self, fn) -> int:
+        self._bind()
+        nat.check(self._lib.ph_graph_begin(self._h))
+        try:
+            fn()
+        finally:
+            gid = C.c_int(-1)
+            nat.check(self._lib.ph_graph_end(self._h, C.byref(gid)))
+        return gid.value
+
+    def set_pairing(self, pairing_round: int) -> None:
+        ex = self.exchange
+        for i, p in enumerate(self.partner):
+            p.fill_(ex.partner_of(ex.seat(i), pairing_round))
+
+    def run_iteration(self, pairing_round: int) -> None:
+        """must be called with `self.stream` current"""
+        self.set_pairing(pairing_round)
+        lib, h, ex = self._lib, self._h, self.exchange
+        for t in range(self.T):
+            nat.check(lib.ph_graph_launch(h, self.act[t]))
+            ex.gather_inplace()
+            nat.check(lib.ph_graph_launch(h, self.upd[t]))
+        nat.check(lib.ph_graph_launch(h, self.learn))
+        for a in self.agents:
+            a.iteration += 1
+            a.num_timesteps += self.T * a.E
