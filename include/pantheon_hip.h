@@ -173,6 +173,18 @@ int ph_policy_forward(ph_ctx *ctx, const ph_spec *spec, const float *params, con
 int ph_fix_illegal_actions(ph_ctx *ctx, int *actions /* (n) in/out */, const unsigned char *action_mask /* (n,L) */,
                            int n, int L);
 
+/* ---- vectorised integer game rules ------------------------------------------------------ */
+/* RPSEnv.multi_step <- pantheonrl/envs/rpsgym/rps.py:41-45 for n environments: rewards (ego, partner) as f32 */
+int ph_rps_step(ph_ctx *ctx, const int *ego_actions, const int *alt_actions, float *ego_reward, float *alt_reward, int n);
+/* LiarEnv.player_step <- pantheonrl/envs/liargym/liar.py:58-83 (sanitize_action, eval_bluff, getObs) for every env with
+ * active[e] != 0 (NULL = all).  hands (n,12) int32 = ego histogram then partner histogram; history (n,24) int32 moves
+ * newest first, nmoves (n) int32 -- both updated in place; actions (n,2) int32 raw (side, count-1) of the mover,
+ * is_ego (n) u8 = who moves.  Outputs: obs_next (n,30) f32 observation of the OTHER player, rewards (n,2) f32
+ * (ego, partner), done (n) u8. */
+int ph_liar_step(ph_ctx *ctx, const int *hands, int *history, int *nmoves, const int *actions,
+                 const unsigned char *is_ego, const unsigned char *active, float *obs_next, float *rewards,
+                 unsigned char *done, int n);
+
 /* ---- K3+K5+K6: PPO.train() ------------------------------------------------------------------------------------ */
 /* PPO.train() <- agents.py:155 (SB3 semantics SURVEY.md A.3; in-tree witness adap_learn.py:229-371).
  * For each epoch, for each consecutive slice of `batch_size` indices (last may be short): gather by index,

@@ -431,6 +431,26 @@ int ph_fix_illegal_actions(ph_ctx* ctx, int* actions, const unsigned char* actio
   return 0;
 }
 
+// ---- vectorised game rules ----
+int ph_rps_step(ph_ctx* ctx, const int* ego_actions, const int* alt_actions, float* ego_reward, float* alt_reward, int n) {
+  if (!ctx) return fail("null ctx");
+  if (!ego_actions || !alt_actions || !ego_reward || !alt_reward) return fail("ph_rps_step: null argument");
+  if (n <= 0) return fail("ph_rps_step: n must be positive");
+  PH_HIP(ph::launch_rps_step(ego_actions, alt_actions, ego_reward, alt_reward, n, ctx->stream));
+  return 0;
+}
+
+int ph_liar_step(ph_ctx* ctx, const int* hands, int* history, int* nmoves, const int* actions,
+                 const unsigned char* is_ego, const unsigned char* active, float* obs_next, float* rewards,
+                 unsigned char* done, int n) {
+  if (!ctx) return fail("null ctx");
+  if (!hands || !history || !nmoves || !actions || !is_ego || !obs_next || !rewards || !done)
+    return fail("ph_liar_step: null argument");
+  if (n <= 0) return fail("ph_liar_step: n must be positive");
+  PH_HIP(ph::launch_liar_step(hands, history, nmoves, actions, is_ego, active, obs_next, rewards, done, n, ctx->stream));
+  return 0;
+}
+
 // ---- K3 + K5 + K6 ----
 namespace {
 

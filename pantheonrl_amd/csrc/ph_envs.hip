@@ -1,0 +1,91 @@
+// Vectorised integer rules of the two games whose rules live entirely in the reference tree:
+// rock-paper-scissors (pantheonrl/envs/rpsgym/rps.py:41-45) and Liar's Dice (pantheonrl/envs/liargym/liar.py:53-83).
+// One lane per environment; everything is integer arithmetic and must be bit-exact with the Python games.
+#include "ph_launch.h"
+
+namespace ph {
+
+// ego payoff: (ego - alt + 3) % 3 mapped {0: 0, 1: +1, 2: -1}; zero-sum
+__global__ void rps_step_kernel(const int* __restrict__ ego_act, const int* __restrict__ alt_act,
+                                float* __restrict__ ego_rew, float* __restrict__ alt_rew, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  int o = (ego_act[e] - alt_act[e] + 3) % 3;
+  o = (o == 2) ? -1 : o;
+  ego_rew[e] = (float)o;
+  alt_rew[e] = (float)(-o);
+}
+hipError_t launch_rps_step(const int* ego_act, const int* alt_act, float* ego_rew, float* alt_rew, int n, hipStream_t s) {
+  hipLaunchKernelGGL(rps_step_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ego_act, alt_act, ego_rew, alt_rew, n);
+  return hipGetLastError();
+}
+
+constexpr int LD_SIDES = 6, LD_DICE = 6, LD_MAXMOVES = 12;
+
+// One move of Liar's Dice in every environment with active[e] != 0.
+//   hands   (n, 12) int32 : ego histogram (6) then partner histogram (6)
+//   history (n, 24) int32 : moves newest first (side, count-1); nmoves (n) int32
+//   actions (n, 2)  int32 : raw (side, count-1) proposed by whoever moves; is_ego (n) u8 says who that is
+// Outputs: obs_next (n, 30) f32 = observation of the OTHER player (liar.py:53-56), rew (n, 2) f32 (ego, partner),
+//          done (n) u8.  History / nmoves are updated in place.
+__global__ void liar_step_kernel(const int* __restrict__ hands, int* __restrict__ history, int* __restrict__ nmoves,
+                                 const int* __restrict__ actions, const unsigned char* __restrict__ is_ego,
+                                 const unsigned char* __restrict__ active, float* __restrict__ obs_next,
+                                 float* __restrict__ rew, unsigned char* __restrict__ done, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  if (active && !active[e]) return;
+  const int* hand = hands + (size_t)e * 12;
+  int* hist = history + (size_t)e * 24;
+  int nm = nmoves[e];
+  int a0 = actions[2 * e], a1 = actions[2 * e + 1];
+  const bool ego = is_ego[e] != 0;
+  // sanitize_action (liar.py:58-67)
+  bool call = false;
+  if (nm > 0) {
+    if (a1 <= hist[1] || a0 == LD_SIDES) call = true;
+  } else if (a0 == LD_SIDES) {
+    a0 = 0;
+    a1 = 0;
+  }
+  if (!call && a0 == LD_SIDES && a1 == 2 * LD_DICE - 1) call = true;  // the literal "bluff!" move
+  float r_ego = 0.f, r_alt = 0.f;
+  unsigned char d = 0;
+  if (call) {
+    bool bluff = false;  // eval_bluff (liar.py:69-75)
+    if (nm > 0) {
+      const int side = hist[0];
+      bluff = hist[1] > hand[side] + hand[6 + side] - 1;
+    }
+    const bool ego_wins = (bluff == ego);
+    r_ego = ego_wins ? 1.f : -1.f;
+    r_alt = -r_ego;
+    d = 1;
+  } else if (nm < LD_MAXMOVES) {
+    for (int k = 2 * nm - 1; k >= 0; --k) hist[k + 2] = hist[k];
+    hist[0] = a0;
+    hist[1] = a1;
+    nm += 1;
+    nmoves[e] = nm;
+  }
+  // getObs(not isego): the other player's hand + history padded with the null move [6, 0]
+  float* o = obs_next + (size_t)e * 30;
+  const int* oh = hand + (ego ? 6 : 0);
+  for (int k = 0; k < 6; ++k) o[k] = (float)oh[k];
+  for (int m = 0; m < LD_MAXMOVES; ++m) {
+    o[6 + 2 * m] = (float)(m < nm ? hist[2 * m] : LD_SIDES);
+    o[7 + 2 * m] = (float)(m < nm ? hist[2 * m + 1] : 0);
+  }
+  rew[2 * e] = r_ego;
+  rew[2 * e + 1] = r_alt;
+  done[e] = d;
+}
+hipError_t launch_liar_step(const int* hands, int* history, int* nmoves, const int* actions, const unsigned char* is_ego,
+                            const unsigned char* active, float* obs_next, float* rew, unsigned char* done, int n,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(liar_step_kernel, dim3((n + 255) / 256), dim3(256), 0, s, hands, history, nmoves, actions, is_ego,
+                     active, obs_next, rew, done, n);
+  return hipGetLastError();
+}
+
+}  // namespace ph

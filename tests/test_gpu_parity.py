@@ -528,3 +528,78 @@ def test_iteration_graph_replays_with_fresh_randomness_and_is_deterministic():
     graph_h.launch(); graph_h.launch()
     th.cuda.synchronize()
     assert np.array_equal(model_h.policy.get_flat_params(), p2)   # run-to-run deterministic
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# vectorised integer game rules: bit-exact against the Python games
+# ----------------------------------------------------------------------------------------------------------------
+def test_vec_rps_and_liars_dice_rules_are_bit_exact():
+    from pantheonrl_amd import _native as nat
+    from pantheonrl_amd.envs.liar import LiarEnv
+    from pantheonrl_amd.envs.rps import rps_payoff
+    from pantheonrl_amd.envs.vec import VecLiarsDice, VecRPS
+    ctx = nat.Context(0)
+    rng = np.random.default_rng(0)
+    E = 1000
+    env = VecRPS(E, ctx, th.device("cuda", 0))
+    a0, a1 = rng.integers(0, 3, E).astype(np.int32), rng.integers(0, 3, E).astype(np.int32)
+    r0, r1, d = env.step(_dev(a0), _dev(a1))
+    assert np.array_equal(r0.cpu().numpy(), rps_payoff(a0, a1).astype(np.float32))
+    assert np.array_equal(r1.cpu().numpy(), -rps_payoff(a0, a1).astype(np.float32)) and bool((d == 1).all())
+
+    # Liar's Dice: E Python tables and the device tables are fed the same dice and the same (mostly illegal) raw moves
+    E = 256
+    tables = [LiarEnv() for _ in range(E)]
+    hands = np.zeros((E, 12), np.int32)
+    for e, t in enumerate(tables):
+        t.multi_reset(True)
+        hands[e, :6], hands[e, 6:] = t.egohand, t.althand
+    vec = VecLiarsDice(E, ctx, th.device("cuda", 0))
+    vec.reset(hands)
+    alive = np.ones(E, bool)
+    ego_turn = rng.random(E) < 0.5
+    finished = 0
+    for step in range(14):
+        acts = np.stack([rng.integers(0, 7, E), rng.integers(0, 12, E)], 1).astype(np.int32)
+        if step < 3:
+            acts[:, 1] = np.minimum(acts[:, 1], 3 * step + 2)   # keep some games going for a few raises
+        obs, rew, done = vec.player_step(_dev(acts), _dev(ego_turn.astype(np.uint8)), _dev(alive.astype(np.uint8)))
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        for e in np.nonzero(alive)[0]:
+            o_ref, r_ref, d_ref, _ = tables[e].player_step(acts[e], bool(ego_turn[e]))
+            assert np.array_equal(obs[e], np.asarray(o_ref, np.float32)), (step, e)
+            assert tuple(rew[e]) == tuple(float(x) for x in r_ref) and bool(done[e]) == d_ref
+            if d_ref:
+                alive[e] = False
+                finished += 1
+        ego_turn = ~ego_turn
+    assert finished == E   # every table reached a call within 12 raises + 1
+
+
+def test_vec_rps_selfplay_on_device():
+    """trainer.py RPS-v0 PPO PPO with n_envs = 256, entirely on the device."""
+    from pantheonrl_amd import PPO
+    from pantheonrl_amd.envs.rps import rps_payoff
+    from pantheonrl_amd.envs.vec import VecRPS, selfplay_iteration
+    from pantheonrl_amd.vec import VecOnPolicyAgent
+    E, T = 256, 16
+    spaces = type("S", (), dict(observation_space=VecRPS.observation_space, action_space=VecRPS.action_space,
+                                _is_dummy_space_env=True))()
+    agents = []
+    for seed in (0, 1):
+        m = PPO("MlpPolicy", spaces, n_steps=T, n_envs=E, batch_size=E * T // 4, n_epochs=2, seed=seed)
+        m.device_permutations = True
+        agents.append(VecOnPolicyAgent(m))
+    ego, alt = agents
+    env = VecRPS(E, ego.model.policy.ctx, ego.model.device)
+    p0 = ego.model.policy.get_flat_params()
+    selfplay_iteration(env, ego, alt, T)
+    th.cuda.synchronize()
+    be, ba = ego.model.rollout_buffer.host(), alt.model.rollout_buffer.host()
+    pay = rps_payoff(be["actions"][..., 0].astype(int), ba["actions"][..., 0].astype(int)).astype(np.float32)
+    assert np.array_equal(be["rewards"], pay) and np.array_equal(ba["rewards"], -pay)      # zero-sum, integer exact
+    assert (be["episode_starts"] == 1).all() and (be["observations"] == 0).all()
+    assert ego.iteration == 1 and alt.iteration == 1
+    assert not np.array_equal(ego.model.policy.get_flat_params(), p0)
+    # one-step episodes with V bootstrapped by a terminal: A_t = r_t - V_t exactly (GAE with every step an episode end)
+    np.testing.assert_allclose(be["advantages"][:-1], (be["rewards"] - be["values"])[:-1], atol=1e-6)
