@@ -473,6 +473,8 @@ class PPO:
             raise ValueError("learn() needs a steppable environment")
         if not self._custom_logger:
             self._logger = configure_logger(self.verbose, self.tensorboard_log, tb_log_name)
+        if not reset_num_timesteps:
+            total_timesteps += self.num_timesteps   # SB3 _setup_learn: continue for `total_timesteps` MORE steps
         if reset_num_timesteps or self._last_obs is None:
             if reset_num_timesteps:
                 self.num_timesteps = 0

@@ -603,3 +603,46 @@ def test_vec_rps_selfplay_on_device():
     assert not np.array_equal(ego.model.policy.get_flat_params(), p0)
     # one-step episodes with V bootstrapped by a terminal: A_t = r_t - V_t exactly (GAE with every step an episode end)
     np.testing.assert_allclose(be["advantages"][:-1], (be["rewards"] - be["values"])[:-1], atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# checkpoint + FIXED / LOAD partners (trainer.py:140-162, 419-432; agents.py:54-79)
+# ----------------------------------------------------------------------------------------------------------------
+def test_save_load_and_static_policy_agent(tmp_path):
+    from pantheonrl_amd import OnPolicyAgent, PPO, StaticPolicyAgent
+    from pantheonrl_amd.common import Observation
+    from pantheonrl_amd.envs import make
+    env = make("LiarsDice-v0")
+    model = PPO("MlpPolicy", env, n_steps=32, batch_size=16, n_epochs=2, seed=3)
+    partner = OnPolicyAgent(PPO("MlpPolicy", env.getDummyEnv(1), n_steps=32, batch_size=16, n_epochs=2, seed=4))
+    env.add_partner_agent(partner)
+    np.random.seed(0)
+    model.learn(total_timesteps=64)
+    path = str(tmp_path / "models" / "liar-ego")
+    model.save(path)                                            # trainer.py:420
+    partner.model.save(str(tmp_path / "models" / "liar-alt"))    # trainer.py:424
+    loaded = PPO.load(path)                                      # trainer.py:149 (gen_load)
+    obs = H.sample_obs(H.CONFIGS["liar"][0], 50, np.random.default_rng(0))
+    assert th.equal(loaded.policy.get_logits(obs), model.policy.get_logits(obs))
+    assert np.array_equal(loaded.policy.adam_m.cpu().numpy(), model.policy.adam_m.cpu().numpy())
+    assert int(loaded.policy.opt_step.item()) == int(model.policy.opt_step.item()) > 0
+    assert loaded.num_timesteps == model.num_timesteps and loaded.n_steps == 32
+    sd = model.policy.state_dict()                               # SB3 module names / nn.Linear shapes
+    assert sd["mlp_extractor.policy_net.0.weight"].shape == (64, 270) and sd["action_net.weight"].shape == (19, 64)
+    assert sd["value_net.weight"].shape == (1, 64) and len(sd) == 12
+    # FIXED partner: a frozen policy in a seat (gen_fixed, trainer.py:160-162)
+    fixed = StaticPolicyAgent(PPO.load(str(tmp_path / "models" / "liar-alt")).policy)
+    env2 = make("LiarsDice-v0")
+    env2.add_partner_agent(fixed)
+    env2.reset()
+    done, steps = False, 0
+    while not done and steps < 20:
+        _, r, done, _ = env2.step(env2.action_space.sample())
+        steps += 1
+    assert done and r in (1, -1)
+    act = fixed.get_action(Observation(np.zeros(30)))
+    assert act.shape == (2,)
+    # LOAD ego: continue training a loaded model on a fresh env (trainer.py:116-124)
+    loaded.set_env(env2)
+    loaded.learn(total_timesteps=32, reset_num_timesteps=False)
+    assert loaded.num_timesteps == model.num_timesteps + 32
