@@ -185,6 +185,12 @@ int ph_liar_step(ph_ctx *ctx, const int *hands, int *history, int *nmoves, const
                  const unsigned char *is_ego, const unsigned char *active, float *obs_next, float *rewards,
                  unsigned char *done, int n);
 
+/* Frame stack as a device ring buffer <- HistoryQueue.add / reset, wrappers.py:37-71, applied to
+ * n environments: stack (n, numframes*D) f32 holds the last numframes observations NEWEST FIRST; for envs with
+ * reset_mask[e] != 0 the history is first refilled with default_obs (D, NULL = zeros), then obs (n, D) is pushed. */
+int ph_framestack_push(ph_ctx *ctx, float *stack, const float *obs, const unsigned char *reset_mask,
+                       const float *default_obs, int n, int D, int numframes);
+
 /* ---- K3+K5+K6: PPO.train() ------------------------------------------------------------------------------------ */
 /* PPO.train() <- agents.py:155 (SB3 semantics SURVEY.md A.3; in-tree witness adap_learn.py:229-371).
  * For each epoch, for each consecutive slice of `batch_size` indices (last may be short): gather by index,

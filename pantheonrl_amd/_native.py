@@ -83,6 +83,7 @@ SIGNATURES = {
     "ph_fix_illegal_actions": [_vp, _vp, _vp, _i, _i],
     "ph_rps_step": [_vp, _vp, _vp, _vp, _vp, _i],
     "ph_liar_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
+    "ph_framestack_push": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "ph_ppo_train": [_vp, C.POINTER(PhSpec), C.POINTER(PhOptState), C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i,
                      _vp, _ull, _vp, _i],
     "ph_ppo_minibatch_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _vp, _i, _vp,

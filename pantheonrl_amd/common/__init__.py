@@ -4,3 +4,4 @@ from .observation import Observation, extract_obs, extract_partial_obs  # noqa: 
 from .agents import Agent, OnPolicyAgent, StaticPolicyAgent  # noqa: F401
 from .multiagentenv import (DummyEnv, MultiAgentEnv, PlayerException, SimultaneousEnv,  # noqa: F401
                             TurnBasedEnv)
+from .wrappers import HistoryQueue, SimultaneousFrameStack, TurnBasedFrameStack, frame_wrap  # noqa: F401,E402

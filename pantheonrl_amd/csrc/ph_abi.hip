@@ -451,6 +451,15 @@ int ph_liar_step(ph_ctx* ctx, const int* hands, int* history, int* nmoves, const
   return 0;
 }
 
+int ph_framestack_push(ph_ctx* ctx, float* stack, const float* obs, const unsigned char* reset_mask,
+                       const float* default_obs, int n, int D, int numframes) {
+  if (!ctx) return fail("null ctx");
+  if (!stack || !obs) return fail("ph_framestack_push: null argument");
+  if (n <= 0 || D <= 0 || numframes <= 0) return fail("ph_framestack_push: bad sizes");
+  PH_HIP(ph::launch_framestack_push(stack, obs, reset_mask, default_obs, n, D, numframes, ctx->stream));
+  return 0;
+}
+
 // ---- K3 + K5 + K6 ----
 namespace {
 

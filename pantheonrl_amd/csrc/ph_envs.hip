@@ -88,4 +88,25 @@ hipError_t launch_liar_step(const int* hands, int* history, int* nmoves, const i
   return hipGetLastError();
 }
 
+// HistoryQueue for n envs: one lane per (env, feature) walks its column of frames from the oldest to the newest
+__global__ void framestack_push_kernel(float* __restrict__ stack, const float* __restrict__ obs,
+                                       const unsigned char* __restrict__ reset_mask,
+                                       const float* __restrict__ default_obs, int n, int D, int nf) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)n * D) return;
+  const int e = (int)(g / D), d = (int)(g - (size_t)e * D);
+  float* col = stack + (size_t)e * nf * D + d;
+  const bool reset = reset_mask && reset_mask[e];
+  const float fill = default_obs ? default_obs[d] : 0.f;
+  for (int f = nf - 1; f >= 1; --f) col[(size_t)f * D] = reset ? fill : col[(size_t)(f - 1) * D];
+  col[0] = obs[g];
+}
+hipError_t launch_framestack_push(float* stack, const float* obs, const unsigned char* reset_mask,
+                                  const float* default_obs, int n, int D, int nf, hipStream_t s) {
+  const size_t total = (size_t)n * D;
+  hipLaunchKernelGGL(framestack_push_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, stack, obs,
+                     reset_mask, default_obs, n, D, nf);
+  return hipGetLastError();
+}
+
 }  // namespace ph

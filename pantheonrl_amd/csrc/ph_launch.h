@@ -122,6 +122,8 @@ hipError_t launch_buffer_add(float* d_obs, float* d_act, float* d_rew, float* d_
 hipError_t launch_reward_add(float* rew_row, const float* reward, const unsigned char* env_mask, int E, hipStream_t s);
 hipError_t launch_reward_add_joint(float* rew_row, const float* base, const int* joint, int E, int n_seats, int seat,
                                    const int* partner_seat, float bonus, hipStream_t s);
+hipError_t launch_framestack_push(float* stack, const float* obs, const unsigned char* reset_mask,
+                                  const float* default_obs, int n, int D, int nf, hipStream_t s);
 hipError_t launch_rps_step(const int* ego_act, const int* alt_act, float* ego_rew, float* alt_rew, int n, hipStream_t s);
 hipError_t launch_liar_step(const int* hands, int* history, int* nmoves, const int* actions, const unsigned char* is_ego,
                             const unsigned char* active, float* obs_next, float* rew, unsigned char* done, int n,

@@ -49,7 +49,8 @@ def _f32_dev(x, dev: th.device, shape: Tuple[int, ...]) -> th.Tensor:
     if isinstance(x, th.Tensor):
         t = x.detach()
     else:
-        t = th.as_tensor(np.asarray(x))
+        arr = np.asarray(x)
+        t = th.as_tensor(arr if arr.flags.writeable else arr.copy())
     return t.to(device=dev, dtype=th.float32).reshape(shape).contiguous()
 
 

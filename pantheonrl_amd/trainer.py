@@ -1,0 +1,186 @@
+"""The object graph of the reference's training CLI (trainer.py:92-137,182-256,394-432) on the MI355X engine.
+
+    python -m pantheonrl_amd.trainer RPS-v0 PPO PPO --preset 1 --seed 0 -t 10000        (BASELINE config 1)
+
+Same positional arguments and flags as the reference for the part of the surface that sits on the PPO path:
+env in {RPS-v0, LiarsDice-v0}; ego in {PPO, LOAD}; each partner in {PPO, FIXED, DEFAULT}; JSON configs splatted into
+the constructors; `--framestack`, `--preset 1`, `--ego-save/--alt-save`, `--tensorboard-log/-name`, `--seed`,
+`--device`, `--total-timesteps`.  ADAP / ModularAlgorithm / BC agents, `--record` and `--share-latent` belong to
+components outside the PPO rollout+update path and raise EnvException.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+from typing import List, Tuple
+
+from . import envs as _envs
+from .common import OnPolicyAgent, StaticPolicyAgent
+from .common.wrappers import frame_wrap
+from .envs.liar import LiarDefaultAgent, LiarEnv
+from .envs.rps import RPSEnv, RPSWeightedAgent
+from .ppo import PPO
+
+EGO_LIST = ["PPO", "LOAD"]
+PARTNER_LIST = ["PPO", "DEFAULT", "FIXED"]
+OUT_OF_SCOPE = {"ADAP", "ADAP_MULT", "ModularAlgorithm", "BC"}
+
+
+class EnvException(Exception):
+    """Raise when parameters do not align with the environment (reference trainer.py:37)."""
+
+
+def input_check(args) -> None:
+    """reject combinations the engine cannot honour, with the reference's error class (trainer.py:41-63)"""
+    if args.env not in _envs.REGISTRY:
+        raise EnvException(f"unknown or out-of-scope environment {args.env!r}; available: {sorted(_envs.REGISTRY)}")
+    for name in [args.ego] + list(args.alt):
+        if name in OUT_OF_SCOPE:
+            raise EnvException(f"{name} agents are outside the PPO rollout+update path this engine implements")
+    if args.ego not in EGO_LIST:
+        raise EnvException(f"ego must be one of {EGO_LIST}")
+    for name in args.alt:
+        if name not in PARTNER_LIST:
+            raise EnvException(f"partners must be among {PARTNER_LIST}")
+    if len(args.alt_config) != len(args.alt):
+        raise EnvException("number of partners is different from number of --alt-config")
+    if args.record is not None or args.share_latent:
+        raise EnvException("--record / --share-latent belong to the recorder / ADAP components (out of scope)")
+    if args.framestack > 1 and args.env_config.get("framestack_incompatible", False):
+        raise EnvException("this environment cannot be frame-stacked")
+
+
+def generate_env(args) -> Tuple[object, object]:
+    """env + the partner-side dummy env, optionally frame-stacked (trainer.py:92-104)"""
+    env = _envs.make(args.env, **args.env_config)
+    altenv = env.getDummyEnv(1)
+    if args.framestack > 1:
+        env = frame_wrap(env, args.framestack)
+        altenv = env.getDummyEnv(1)   # the wrapped env carries the stacked observation space for both seats
+    return env, altenv
+
+
+def gen_load(config: dict, policy_type: str, location: str):
+    if policy_type != "PPO":
+        raise EnvException("Not a valid FIXED/LOAD policy")
+    return PPO.load(location, device=config.get("device", "cuda"))
+
+
+def generate_ego(env, args):
+    """the ego learner (trainer.py:107-137)"""
+    kwargs = dict(args.ego_config)
+    kwargs.update(env=env, device=args.device, tensorboard_log=args.tensorboard_log)
+    if args.seed is not None:
+        kwargs["seed"] = args.seed
+    if args.ego == "LOAD":
+        model = gen_load(kwargs, kwargs["type"], kwargs["location"])
+        model.set_env(env)
+        return model
+    return PPO(policy="MlpPolicy", **kwargs)
+
+
+def gen_partner(kind: str, config: dict, altenv, ego, args, index: int):
+    """one partner agent (trainer.py:182-213)"""
+    config = dict(config)
+    if kind == "FIXED":
+        return StaticPolicyAgent(gen_load(config, config["type"], config["location"]).policy)
+    if kind == "DEFAULT":
+        base = getattr(altenv, "env", altenv)
+        if isinstance(base, RPSEnv):
+            return RPSWeightedAgent(**config)
+        if config:
+            raise EnvException("No config possible for this default agent")
+        if isinstance(base, LiarEnv):
+            return LiarDefaultAgent()
+        raise EnvException("No default policy available")
+    agentarg = {}
+    if args.tensorboard_log is not None:
+        agentarg = {"tensorboard_log": args.tensorboard_log,
+                    "tb_log_name": f"{args.tensorboard_name}_alt_{index}"}
+    config.update(env=altenv, device=args.device, verbose=args.verbose_partner)
+    if args.seed is not None:
+        config["seed"] = args.seed
+    return OnPolicyAgent(PPO(policy="MlpPolicy", **config), **agentarg)
+
+
+def generate_partners(altenv, env, ego, args) -> List:
+    partners = []
+    for i, kind in enumerate(args.alt):
+        agent = gen_partner(kind, args.alt_config[i], altenv, ego, args, i)
+        print(f"Partner {i}: {agent}")
+        env.add_partner_agent(agent)
+        partners.append(agent)
+    return partners
+
+
+def preset(args, preset_id: int):
+    """default log / save names (trainer.py:231-256)"""
+    if preset_id != 1:
+        raise Exception("Invalid preset id")
+    env_name = args.env
+    if "layout_name" in args.env_config:
+        env_name = f"{args.env}-{args.env_config['layout_name']}"
+    seed = 0 if args.seed is None else args.seed
+    args.tensorboard_log = args.tensorboard_log or "logs"
+    args.tensorboard_name = args.tensorboard_name or f"{env_name}-{args.ego}{args.alt[0]}-{seed}"
+    args.ego_save = args.ego_save or f"models/{env_name}-{args.ego}-ego-{seed}"
+    args.alt_save = args.alt_save or f"models/{env_name}-{args.alt[0]}-alt-{seed}"
+    return args
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Train an ego agent with partner agents in a multi-agent environment "
+                                            "on the MI355X PPO engine (flags as in PantheonRL's trainer.py)")
+    p.add_argument("env", help="environment id")
+    p.add_argument("ego", help="algorithm of the ego agent")
+    p.add_argument("alt", nargs="+", help="algorithm(s) of the partner agent(s)")
+    p.add_argument("--total-timesteps", "-t", type=int, default=500000)
+    p.add_argument("--device", "-d", default="cuda")
+    p.add_argument("--seed", "-s", type=int)
+    p.add_argument("--ego-config", type=json.loads, default={})
+    p.add_argument("--alt-config", type=json.loads, action="append")
+    p.add_argument("--env-config", type=json.loads, default={})
+    p.add_argument("--framestack", "-f", type=int, default=1)
+    p.add_argument("--record", "-r")
+    p.add_argument("--ego-save")
+    p.add_argument("--alt-save")
+    p.add_argument("--share-latent", action="store_true")
+    p.add_argument("--tensorboard-log")
+    p.add_argument("--tensorboard-name")
+    p.add_argument("--verbose-partner", action="store_true")
+    p.add_argument("--preset", type=int)
+    return p
+
+
+def run(argv=None):
+    """parse, build the graph, learn, save -- returns (ego, partners, env) for callers and tests"""
+    args = build_parser().parse_args(argv)
+    if args.alt_config is None:
+        args.alt_config = [{} for _ in args.alt]
+    input_check(args)
+    if args.preset:
+        args = preset(args, args.preset)
+    print(f"Arguments: {args}")
+    env, altenv = generate_env(args)
+    print(f"Environment: {env}; Partner env: {altenv}")
+    ego = generate_ego(env, args)
+    print(f"Ego: {ego}")
+    partners = generate_partners(altenv, env, ego, args)
+    learn_config = {"total_timesteps": args.total_timesteps}
+    if args.tensorboard_log:
+        learn_config["tb_log_name"] = args.tensorboard_name
+    ego.learn(**learn_config)
+    if args.ego_save:
+        ego.save(args.ego_save)
+    if args.alt_save:
+        multiple = len(partners) > 1
+        for i, partner in enumerate(partners):
+            model = getattr(partner, "model", None)
+            if model is None:           # DEFAULT / FIXED partners have nothing to save (trainer.py:423-432)
+                continue
+            model.save(f"{args.alt_save}/{i}" if multiple else args.alt_save)
+    return ego, partners, env
+
+
+if __name__ == "__main__":
+    run()

@@ -112,6 +112,25 @@ class VecOnPolicyAgent:
         self.model.policy._bind()
 
 
+class VecFrameStack:
+    """HistoryQueue (wrappers.py:37-71) for E environments as a ring buffer in HBM: `push(obs, reset_mask)` returns the
+    (E, numframes*D) newest-first stacked observation that feeds the policy forward."""
+
+    def __init__(self, n_envs: int, obs_dim: int, numframes: int, ctx: nat.Context, device, default_obs=None):
+        self.E, self.D, self.nf, self.ctx, self.device = n_envs, obs_dim, numframes, ctx, device
+        self.default = None if default_obs is None else th.as_tensor(
+            np.asarray(default_obs, np.float32)).to(device).contiguous()
+        self.stack = th.zeros((n_envs, numframes * obs_dim), dtype=th.float32, device=device)
+        if self.default is not None:
+            self.stack.copy_(self.default.repeat(numframes).expand(n_envs, -1))
+
+    def push(self, obs: th.Tensor, reset_mask: Optional[th.Tensor] = None) -> th.Tensor:
+        self.ctx.set_stream(th.cuda.current_stream(self.device).cuda_stream)
+        nat.check(self.ctx.lib.ph_framestack_push(self.ctx.handle, self.stack.data_ptr(), obs.data_ptr(),
+                                                  nat.ptr(reset_mask), nat.ptr(self.default), self.E, self.D, self.nf))
+        return self.stack
+
+
 class SyntheticRollouts:
     """Seeded synthetic rollout inputs resident in HBM: obs ~ N(0,1) for Box / uniform categories for
     the discrete family, rewards ~ N(0,1), dones ~ Bernoulli(1/horizon)."""

@@ -646,3 +646,37 @@ def test_save_load_and_static_policy_agent(tmp_path):
     loaded.set_env(env2)
     loaded.learn(total_timesteps=32, reset_num_timesteps=False)
     assert loaded.num_timesteps == model.num_timesteps + 32
+
+
+def test_vec_frame_stack_matches_history_queue():
+    from pantheonrl_amd import _native as nat
+    from pantheonrl_amd.common.wrappers import HistoryQueue
+    from pantheonrl_amd.vec import VecFrameStack
+    E, D, nf = 37, 5, 4
+    rng = np.random.default_rng(0)
+    default = rng.standard_normal(D).astype(np.float32)
+    ctx = nat.Context(0)
+    vec = VecFrameStack(E, D, nf, ctx, th.device("cuda", 0), default_obs=default)
+    queues = [HistoryQueue(default, nf) for _ in range(E)]
+    for step in range(9):
+        obs = rng.standard_normal((E, D)).astype(np.float32)
+        reset = rng.random(E) < (1.0 if step == 0 else 0.2)
+        got = vec.push(_dev(obs), _dev(reset.astype(np.uint8))).cpu().numpy()
+        for e, q in enumerate(queues):
+            if reset[e]:
+                q.reset()
+            assert np.array_equal(got[e], q.add(obs[e]).astype(np.float32)), (step, e)
+
+
+def test_trainer_preset_object_graph_end_to_end(tmp_path, monkeypatch):
+    """`trainer.py RPS-v0 PPO PPO --preset 1` (BASELINE config 1) through the mirrored CLI, at a reduced step count."""
+    import os
+    from pantheonrl_amd import trainer
+    monkeypatch.chdir(tmp_path)
+    ego, partners, env = trainer.run(["RPS-v0", "PPO", "PPO", "--preset", "1", "--seed", "0", "-t", "600",
+                                      "--ego-config", '{"n_steps": 256}', "--alt-config", '{"n_steps": 256}',
+                                      "--framestack", "2"])
+    assert ego.num_timesteps == 768 and partners[0].iteration == 2
+    assert env.observation_space.nvec.tolist() == [1, 1]
+    assert os.path.exists("models/RPS-v0-PPO-ego-0.zip") and os.path.exists("models/RPS-v0-PPO-alt-0.zip")
+    assert os.path.isdir("logs") and any(n.startswith("RPS-v0-PPOPPO-0") for n in os.listdir("logs"))
