@@ -211,6 +211,9 @@ class StepGraphs:
         lead = agents[0].model.policy
         self._lib, self._h = lead.ctx.lib, lead.ctx.handle
         self.epoch_word = th.zeros(1, dtype=th.int64, device=dev)
+        self._side = [th.cuda.Stream(device=dev) for _ in agents[1:]]
+        self._fork = th.cuda.Event()
+        self._join = [th.cuda.Event() for _ in agents[1:]]
         for i, a in enumerate(agents):
             a.actions = exchange.local[i].view(a.E, 1)       # forward writes straight into the exchange buffer
             a.model.device_permutations = True
@@ -231,8 +234,24 @@ class StepGraphs:
             a.bind_stream()
 
     def _act(self, t):
-        for a, d in zip(self.agents, self.datas):
-            a.get_action(d.obs[t])
+        """policy forwards of all local agents; agents 1.. run on side streams forked from / joined to the main
+        stream, so inside the captured graph the (latency-bound, 64-workgroup) forwards execute concurrently"""
+        main = th.cuda.current_stream()
+        self._fork.record(main)
+        for i, (a, d) in enumerate(zip(self.agents, self.datas)):
+            if i == 0:
+                a.bind_stream()
+                a.get_action(d.obs[t])
+                continue
+            side = self._side[i - 1]
+            side.wait_event(self._fork)
+            with th.cuda.stream(side):
+                a.bind_stream()
+                a.get_action(d.obs[t])
+                self._join[i - 1].record(side)
+        for ev in self._join[:len(self.agents) - 1]:
+            main.wait_event(ev)
+        self._bind()
 
     def _upd(self, t):
         ex = self.exchange
