@@ -65,7 +65,9 @@ def parse():
     ap.add_argument("--batch-size", type=int, default=0, help="0 = n_envs*n_steps/4")
     ap.add_argument("--agents-per-gpu", type=int, default=2,
                     help="self-play pair per GPU (ego PPO + partner PPO, trainer.py ... PPO PPO)")
-    ap.add_argument("--mode", choices=("auto", "graph", "eager"), default="auto")
+    ap.add_argument("--mode", choices=("auto", "graph", "eager", "fusedstep"), default="auto",
+                    help="graph: one hipGraph per agent-iteration (N=1 default); fusedstep: per-step graphs with the "
+                         "action exchange between them (the N>1 path; at N=1 the exchange is a local copy)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "exercise the N>1 code path with several ranks on ONE GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -205,10 +207,10 @@ def main():
     streams = [th.cuda.Stream(device=device) for _ in agents]
     mode = args.mode
     if mode == "auto":
-        mode = "stepgraph" if distributed else "graph"
+        mode = "fusedstep" if distributed else "graph"
     if distributed:
-        mode = "stepgraph"
-    exchange = pdist.ActionExchange(len(agents), args.n_envs, device) if distributed else None
+        mode = "fusedstep"
+    exchange = pdist.ActionExchange(len(agents), args.n_envs, device) if (distributed or mode == "fusedstep") else None
 
     if mode == "graph":
         graphs = [IterationGraph(a, d, s) for a, d, s in zip(agents, datas, streams)]
@@ -216,7 +218,7 @@ def main():
         def iteration():
             for g in graphs:
                 g.launch()
-    elif not distributed:
+    elif mode == "eager":
         def iteration():
             for a, d, s in zip(agents, datas, streams):
                 with th.cuda.stream(s):
@@ -225,10 +227,11 @@ def main():
         # agent-per-GPU layout: every environment step all-gathers the actions of all seats (RCCL over xGMI) between
         # the policy forwards and the reward updates; the (synthetic) transition consumes the joint action: a shared
         # coordination bonus when a seat's action equals its round-robin partner's (Overcooked's reward is shared).
-        # Local work is pre-captured per step (vec.StepGraphs): 2 graph launches + 1 collective per step.
-        from pantheonrl_amd.vec import StepGraphs
+        # One fused launch (all local agents' forwards + the previous step's joint-action reward) and one collective per
+        # step (vec.FusedSelfPlayRollout); per-step hipGraphs measured 2x slower than direct launches here.
+        from pantheonrl_amd.vec import FusedSelfPlayRollout
         th.cuda.set_stream(streams[0])
-        steps = StepGraphs(agents, datas, exchange, streams[0])
+        steps = FusedSelfPlayRollout(agents, datas, exchange, streams[0])
         it_counter = [0]
 
         def iteration():

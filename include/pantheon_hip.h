@@ -169,6 +169,34 @@ int ph_policy_forward(ph_ctx *ctx, const ph_spec *spec, const float *params, con
                       const ph_rollout *rb, int pos, const float *episode_start_in, const float *pending_reward,
                       int gemm_mode);
 
+/* One environment step of SEVERAL local agents in one launch (agent-per-GPU self-play hosts two learners per GPU).
+ * Each record is one agent's ph_policy_forward call with the fused rollout-buffer write; optionally the PREVIOUS step's
+ * late reward (Agent.update, agents.py:198) is applied to row pos-1 in the same launch:
+ *   rewards[pos-1][e] += pending_reward[e] + (joint_actions ? bonus * [joint[seat][e] == joint[*partner_seat][e]] : 0)
+ * where joint_actions (n_seats, n) int32 is the all-gathered action matrix of that previous step.
+ * All records must have the same n and the same padded logit count; n_calls <= 4. */
+typedef struct ph_step_call {
+  const ph_spec *spec;               /* host */
+  const float *params;
+  const float *obs;                  /* (n, D) */
+  int n;
+  const unsigned char *action_mask;  /* (n, L) or NULL */
+  unsigned long long seed, counter;
+  int deterministic;
+  int *actions_i32;                  /* (n, A) */
+  float *values;                     /* (n) */
+  float *log_probs;                  /* (n) */
+  const ph_rollout *rb;              /* host; required */
+  int pos;
+  const float *episode_start_in;     /* (n) */
+  const float *pending_reward;       /* (n) or NULL */
+  const int *joint_actions;          /* (n_seats, n) or NULL */
+  int n_seats, seat;
+  const int *partner_seat;           /* device int; required when joint_actions != NULL */
+  float bonus;
+} ph_step_call;
+int ph_policy_step_multi(ph_ctx *ctx, int n_calls, const ph_step_call *calls /* host */);
+
 /* env-side illegal-action fix-up: action not legal -> first legal index <- pettingzoo.py:81-82.  Integer, bit-exact. */
 int ph_fix_illegal_actions(ph_ctx *ctx, int *actions /* (n) in/out */, const unsigned char *action_mask /* (n,L) */,
                            int n, int L);

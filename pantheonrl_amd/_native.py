@@ -50,6 +50,15 @@ class PhPpoHyper(C.Structure):
                 ("adam_beta2", C.c_float), ("adam_eps", C.c_float)]
 
 
+class PhStepCall(C.Structure):
+    _fields_ = [("spec", C.POINTER(PhSpec)), ("params", C.c_void_p), ("obs", C.c_void_p), ("n", C.c_int),
+                ("action_mask", C.c_void_p), ("seed", C.c_ulonglong), ("counter", C.c_ulonglong),
+                ("deterministic", C.c_int), ("actions_i32", C.c_void_p), ("values", C.c_void_p),
+                ("log_probs", C.c_void_p), ("rb", C.POINTER(PhRollout)), ("pos", C.c_int),
+                ("episode_start_in", C.c_void_p), ("pending_reward", C.c_void_p), ("joint_actions", C.c_void_p),
+                ("n_seats", C.c_int), ("seat", C.c_int), ("partner_seat", C.c_void_p), ("bonus", C.c_float)]
+
+
 class PhOptState(C.Structure):
     _fields_ = [("params", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("step", C.c_void_p)]
 
@@ -80,6 +89,7 @@ SIGNATURES = {
     "ph_gae": [_vp, C.POINTER(PhRollout), _vp, _vp, _d, _d, _i],
     "ph_policy_forward": [_vp, C.POINTER(PhSpec), _vp, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, _vp, _vp,
                           _vp, C.POINTER(PhRollout), _i, _vp, _vp, _i],
+    "ph_policy_step_multi": [_vp, _i, C.POINTER(PhStepCall)],
     "ph_fix_illegal_actions": [_vp, _vp, _vp, _i, _i],
     "ph_rps_step": [_vp, _vp, _vp, _vp, _vp, _i],
     "ph_liar_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],

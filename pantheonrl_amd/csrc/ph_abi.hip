@@ -423,6 +423,61 @@ int ph_policy_forward(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   return 0;
 }
 
+int ph_policy_step_multi(ph_ctx* ctx, int n_calls, const ph_step_call* calls) {
+  if (!ctx) return fail("null ctx");
+  if (!calls) return fail("ph_policy_step_multi: null calls");
+  if (n_calls <= 0 || n_calls > ph::MAX_LOCAL_AGENTS) return fail("ph_policy_step_multi: 1..4 calls per launch");
+  ph::FwdMulti m;
+  std::memset(&m, 0, sizeof(m));
+  for (int i = 0; i < n_calls; ++i) {
+    const ph_step_call& c = calls[i];
+    ph::FwdArgs& a = m.a[i];
+    if (!c.params || !c.obs || !c.rb || !c.episode_start_in) return fail("ph_policy_step_multi: null argument");
+    if ((uintptr_t)c.params % 16 != 0) return fail("ph_policy_step_multi: params must be 16-byte aligned");
+    if (resolve(ctx, c.spec, &a.nd)) return 1;
+    if (check_rb(c.rb)) return 1;
+    if (c.n != c.rb->E) return fail("ph_policy_step_multi: n must equal the rollout E");
+    if (c.pos < 0 || c.pos >= c.rb->T) return fail("ph_policy_step_multi: pos out of range (buffer full?)");
+    if (i > 0 && (c.n != calls[0].n || a.nd.Lp != m.a[0].nd.Lp))
+      return fail("ph_policy_step_multi: all calls must share n and the padded logit count");
+    a.params = c.params;
+    a.obs = c.obs;
+    a.n = c.n;
+    a.mask = c.action_mask;
+    a.seed = c.seed;
+    a.counter = c.counter;
+    a.epoch = ctx->rng_epoch;
+    a.deterministic = c.deterministic;
+    a.act_i32 = c.actions_i32;
+    a.values = c.values;
+    a.logp = c.log_probs;
+    const size_t row = (size_t)c.pos * c.rb->E;
+    a.rb_obs = c.rb->observations + row * a.nd.D;
+    a.rb_act = c.rb->actions + row * a.nd.A;
+    a.rb_rew = c.rb->rewards + row;
+    a.rb_es = c.rb->episode_starts + row;
+    a.rb_val = c.rb->values + row;
+    a.rb_logp = c.rb->log_probs + row;
+    a.es_in = c.episode_start_in;
+    if (c.pending_reward) {
+      if (c.pos < 1) return fail("ph_policy_step_multi: pending_reward needs pos >= 1");
+      a.prev_rew = c.rb->rewards + (row - c.rb->E);
+      a.pending_reward = c.pending_reward;
+      if (c.joint_actions) {
+        if (!c.partner_seat || c.n_seats <= 0 || c.seat < 0 || c.seat >= c.n_seats)
+          return fail("ph_policy_step_multi: bad joint-action description");
+        a.joint = c.joint_actions;
+        a.n_seats = c.n_seats;
+        a.seat = c.seat;
+        a.partner_seat = c.partner_seat;
+        a.bonus = c.bonus;
+      }
+    }
+  }
+  PH_HIP(ph::launch_policy_fwd_multi(m, n_calls, ctx->stream));
+  return 0;
+}
+
 int ph_fix_illegal_actions(ph_ctx* ctx, int* actions, const unsigned char* action_mask, int n, int L) {
   if (!ctx) return fail("null ctx");
   if (!actions || !action_mask) return fail("ph_fix_illegal_actions: null argument");

@@ -32,6 +32,15 @@ struct FwdArgs {
   long long* prof;              // debug: per-workgroup phase timestamps (clock64), or null
   float* prev_rew;              // rewards row pos-1, or null
   const float* pending_reward;  // (E) added to prev_rew (Agent.update folded into the next step's launch)
+  const int* joint;             // (n_seats, n) all-gathered actions of the previous step, or null
+  int n_seats, seat;
+  const int* partner_seat;      // device int
+  float bonus;
+};
+
+constexpr int MAX_LOCAL_AGENTS = 4;
+struct FwdMulti {
+  FwdArgs a[MAX_LOCAL_AGENTS];
 };
 
 struct GradArgs {
@@ -113,6 +122,7 @@ struct AdamArgs {
 size_t fwd_lds_bytes(int R, int Lp);
 size_t grad_lds_bytes(int R, int Lp);
 hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s);
+hipError_t launch_policy_fwd_multi(const FwdMulti& m, int n_agents, hipStream_t s);
 hipError_t launch_fix_illegal(int* actions, const unsigned char* mask, int n, int L, hipStream_t s);
 hipError_t launch_gae(const float* rew, const float* val, const float* es, const float* lv, const float* dn, float* adv,
                       float* ret, int T, int E, double gamma, double lam, int mode, hipStream_t s);

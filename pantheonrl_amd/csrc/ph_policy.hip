@@ -12,7 +12,7 @@ namespace ph {
 
 
 template <int R, int LP, bool VALU>
-__global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
+__device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = R * 4;
   const NetDims& nd = a.nd;
@@ -118,7 +118,15 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
         a.rb_val[g] = v;
         a.rb_rew[g] = 0.f;
         a.rb_es[g] = a.es_in[g];
-        if (a.pending_reward) a.prev_rew[g] += a.pending_reward[g];
+        if (a.pending_reward) {
+          float add = a.pending_reward[g];
+          if (a.joint) {  // shared coordination term of the synthetic SimultaneousEnv transition (joint action)
+            int p = *a.partner_seat;
+            p = p < 0 ? 0 : (p >= a.n_seats ? a.n_seats - 1 : p);
+            add += (a.joint[(size_t)a.seat * a.n + g] == a.joint[(size_t)p * a.n + g]) ? a.bonus : 0.f;
+          }
+          a.prev_rew[g] += add;
+        }
       }
     }
     if (a.rb_obs) {  // RolloutBuffer.add copies the observation (agents.py:172-173)
@@ -202,6 +210,19 @@ __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
   PH_STAMP(a.prof, 7);
 }
 
+template <int R, int LP, bool VALU>
+__global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
+  policy_fwd_body<R, LP, VALU>(a);
+}
+
+// the same step for several local agents in ONE launch: blockIdx.z selects the agent's argument record (agent-per-GPU
+// self-play hosts two learners per GPU; their forwards are independent, 64-workgroup, latency-bound launches)
+template <int R, int LP>
+__global__ __launch_bounds__(R * 4) void policy_fwd_multi_kernel(FwdMulti m) {
+  policy_fwd_body<R, LP, false>(m.a[blockIdx.z]);
+}
+
+
 
 size_t fwd_lds_bytes(int R, int Lp) {
   const int LDO = Lp + 1;
@@ -221,6 +242,29 @@ static hipError_t launch_fwd_variant(const FwdArgs& a, hipStream_t s) {
   }
   hipLaunchKernelGGL((policy_fwd_kernel<R, LP, VALU>), grid, block, lds, s, a);
   return hipGetLastError();
+}
+
+template <int R, int LP>
+static hipError_t launch_fwd_multi_variant(const FwdMulti& m, int n_agents, hipStream_t s) {
+  dim3 grid((m.a[0].n + R - 1) / R, 2, n_agents), block(R * 4);
+  const size_t lds = fwd_lds_bytes(R, LP);
+  static size_t allowed = 64 * 1024;
+  if (lds > allowed) {
+    hipError_t e = hipFuncSetAttribute((const void*)policy_fwd_multi_kernel<R, LP>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    allowed = lds;
+  }
+  hipLaunchKernelGGL((policy_fwd_multi_kernel<R, LP>), grid, block, lds, s, m);
+  return hipGetLastError();
+}
+
+// all records must share n and the padded logit count (checked by the ABI layer)
+hipError_t launch_policy_fwd_multi(const FwdMulti& m, int n_agents, hipStream_t s) {
+  const bool big = m.a[0].n >= 16384;
+  const bool lp64 = m.a[0].nd.Lp == 64;
+  if (big) return lp64 ? launch_fwd_multi_variant<64, 64>(m, n_agents, s) : launch_fwd_multi_variant<64, 32>(m, n_agents, s);
+  return lp64 ? launch_fwd_multi_variant<32, 64>(m, n_agents, s) : launch_fwd_multi_variant<32, 32>(m, n_agents, s);
 }
 
 hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s) {

@@ -194,93 +194,48 @@ class IterationGraph:
         self.agent.num_timesteps += self.data.T * self.data.E
 
 
-class StepGraphs:
-    """Agent-per-GPU rollout with a collective between the two halves of every environment step.
+class FusedSelfPlayRollout:
+    """Agent-per-GPU rollout of the local agents with ONE kernel launch and ONE collective per environment step.
 
-    For every step t two small hipGraphs are captured once: `act[t]` = the policy forward + row write of every local
-    agent, `upd[t]` = every local agent's joint-action reward update.  An iteration then costs, per step, two graph
-    launches plus ONE torch.distributed all-gather issued by the caller between them; GAE + PPO update of all local
-    agents are a third graph.  Host overhead per step drops from ~10 calls to 3, which is what keeps the N>1 path
-    GPU-bound (the collective itself is a KB-sized, latency-bound message)."""
+    Step t: `ph_policy_step_multi` runs the policy forward + rollout-buffer row write of every local agent (and applies
+    step t-1's reward, including the shared coordination term computed from the joint action gathered at t-1), the
+    actions land directly in the exchange buffer, then the caller-visible all-gather makes the joint action of step t
+    available everywhere (multiagentenv.py:149-170 with the in-process hand-off replaced by RCCL).  The per-step launch
+    records are prebuilt (pointers into the HBM-resident synthetic inputs), so the host does two calls per step; GAE +
+    PPO update of the local agents then run concurrently on separate streams."""
 
     def __init__(self, agents, datas, exchange, stream: th.cuda.Stream, bonus: float = 0.01):
         self.agents, self.datas, self.exchange, self.stream, self.bonus = agents, datas, exchange, stream, bonus
         dev = agents[0].model.policy.device
-        self.partner = [th.zeros(1, dtype=th.int32, device=dev) for _ in agents]
+        n = len(agents)
         self.T = datas[0].T
         lead = agents[0].model.policy
         self._lib, self._h = lead.ctx.lib, lead.ctx.handle
+        self.partner = [th.zeros(1, dtype=th.int32, device=dev) for _ in agents]
         self.epoch_word = th.zeros(1, dtype=th.int64, device=dev)
         self._side = [th.cuda.Stream(device=dev) for _ in agents[1:]]
         self._fork = th.cuda.Event()
         self._join = [th.cuda.Event() for _ in agents[1:]]
+        self.first_start = th.ones(agents[0].E, dtype=th.float32, device=dev)
         for i, a in enumerate(agents):
             a.actions = exchange.local[i].view(a.E, 1)       # forward writes straight into the exchange buffer
             a.model.device_permutations = True
             nat.check(a.model.policy.ctx.lib.ph_ctx_set_rng_epoch(a.model.policy.ctx.handle, self.epoch_word.data_ptr()))
-        with th.cuda.stream(stream):
-            self._eager_iteration(gather=False)              # warm-up: sizes workspaces, caches specs
-            stream.synchronize()
-            self.act, self.upd = [], []
-            for t in range(self.T):
-                self.act.append(self._capture(lambda t=t: self._act(t)))
-                self.upd.append(self._capture(lambda t=t: self._upd(t)))
-            self.learn = self._capture(self._learn)
-            for a in agents:                                  # captures do not execute: restore the Python-side counters
-                a.model.rollout_buffer.pos, a.n_steps = 0, 0
-
-    def _bind(self):
-        for a in self.agents:
-            a.bind_stream()
-
-    def _act(self, t):
-        """policy forwards of all local agents; agents 1.. run on side streams forked from / joined to the main
-        stream, so inside the captured graph the (latency-bound, 64-workgroup) forwards execute concurrently"""
-        main = th.cuda.current_stream()
-        self._fork.record(main)
-        for i, (a, d) in enumerate(zip(self.agents, self.datas)):
-            if i == 0:
-                a.bind_stream()
-                a.get_action(d.obs[t])
-                continue
-            side = self._side[i - 1]
-            side.wait_event(self._fork)
-            with th.cuda.stream(side):
-                a.bind_stream()
-                a.get_action(d.obs[t])
-                self._join[i - 1].record(side)
-        for ev in self._join[:len(self.agents) - 1]:
-            main.wait_event(ev)
-        self._bind()
-
-    def _upd(self, t):
-        ex = self.exchange
-        for i, (a, d) in enumerate(zip(self.agents, self.datas)):
-            a.update_joint(d.rewards[t], d.dones[t], ex.joint, ex.seat(i), self.partner[i], self.bonus)
-
-    def _learn(self):
-        for a in self.agents:
-            a.learn_from_buffer()
-        nat.check(self._lib.ph_rng_epoch_advance(self._h))
-
-    def _eager_iteration(self, gather: bool):
-        self._bind()
+        # prebuilt launch records, one array per step
+        self.calls = []
         for t in range(self.T):
-            self._act(t)
-            if gather:
-                self.exchange.gather_inplace()
-            self._upd(t)
-        self._learn()
-
-    def _capture(self, fn) -> int:
-        self._bind()
-        nat.check(self._lib.ph_graph_begin(self._h))
-        try:
-            fn()
-        finally:
-            gid = C.c_int(-1)
-            nat.check(self._lib.ph_graph_end(self._h, C.byref(gid)))
-        return gid.value
+            arr = (nat.PhStepCall * n)()
+            for i, (a, d) in enumerate(zip(agents, datas)):
+                pol, rb, c = a.model.policy, a.model.rollout_buffer, arr[i]
+                c.spec, c.params, c.obs, c.n = C.pointer(pol.spec), pol.params.data_ptr(), d.obs[t].data_ptr(), a.E
+                c.action_mask, c.seed, c.counter, c.deterministic = None, pol._seed, t + 1, 0
+                c.actions_i32, c.values, c.log_probs = a.actions.data_ptr(), a.values.data_ptr(), a.log_probs.data_ptr()
+                c.rb, c.pos = C.pointer(rb.c_struct()), t
+                c.episode_start_in = (self.first_start if t == 0 else d.dones[t - 1]).data_ptr()
+                if t > 0:
+                    c.pending_reward, c.joint_actions = d.rewards[t - 1].data_ptr(), exchange.joint.data_ptr()
+                    c.n_seats, c.seat, c.partner_seat, c.bonus = exchange.n_seats, exchange.seat(i), self.partner[i].data_ptr(), bonus
+            self.calls.append(arr)
 
     def set_pairing(self, pairing_round: int) -> None:
         ex = self.exchange
@@ -290,12 +245,34 @@ class StepGraphs:
     def run_iteration(self, pairing_round: int) -> None:
         """must be called with `self.stream` current"""
         self.set_pairing(pairing_round)
-        lib, h, ex = self._lib, self._h, self.exchange
-        for t in range(self.T):
-            nat.check(lib.ph_graph_launch(h, self.act[t]))
+        agents, lib, h, ex, T = self.agents, self._lib, self._h, self.exchange, self.T
+        agents[0].bind_stream()
+        for t in range(T):
+            nat.check(lib.ph_policy_step_multi(h, len(agents), self.calls[t]))
             ex.gather_inplace()
-            nat.check(lib.ph_graph_launch(h, self.upd[t]))
-        nat.check(lib.ph_graph_launch(h, self.learn))
-        for a in self.agents:
-            a.iteration += 1
-            a.num_timesteps += self.T * a.E
+        # the last step's reward (no further forward to carry it)
+        for i, (a, d) in enumerate(zip(agents, self.datas)):
+            a.bind_stream()
+            a.model.rollout_buffer.pos = T
+            a._last_episode_starts = d.dones[T - 1]
+            a.update_joint(d.rewards[T - 1], d.dones[T - 1], ex.joint, ex.seat(i), self.partner[i], self.bonus)
+        # GAE + PPO update: local learners are independent -> concurrent on forked streams
+        main = th.cuda.current_stream()
+        self._fork.record(main)
+        for i, a in enumerate(agents):
+            if i == 0:
+                a.bind_stream()
+                a.learn_from_buffer()
+                continue
+            side = self._side[i - 1]
+            side.wait_event(self._fork)
+            with th.cuda.stream(side):
+                a.bind_stream()
+                a.learn_from_buffer()
+                self._join[i - 1].record(side)
+        for ev in self._join:
+            main.wait_event(ev)
+        agents[0].bind_stream()
+        nat.check(lib.ph_rng_epoch_advance(h))
+        for a in agents:
+            a.num_timesteps += T * a.E

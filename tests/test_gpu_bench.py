@@ -44,5 +44,5 @@ def test_bench_two_ranks_agent_per_rank_path():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     d = _json_line(r.stdout)
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["launch_mode"] == "stepgraph"
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["launch_mode"] == "fusedstep"
     assert "all-gather" in d["config"]["parallelism"]

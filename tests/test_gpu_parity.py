@@ -680,3 +680,29 @@ def test_trainer_preset_object_graph_end_to_end(tmp_path, monkeypatch):
     assert env.observation_space.nvec.tolist() == [1, 1]
     assert os.path.exists("models/RPS-v0-PPO-ego-0.zip") and os.path.exists("models/RPS-v0-PPO-alt-0.zip")
     assert os.path.isdir("logs") and any(n.startswith("RPS-v0-PPOPPO-0") for n in os.listdir("logs"))
+
+
+def test_fused_multi_agent_step_matches_per_agent_calls():
+    """ph_policy_step_multi (all local agents in one launch, previous step's joint-action reward folded in) leaves the
+    same rollout buffers as the per-agent forward + ph_buffer_add_reward_joint sequence."""
+    from pantheonrl_amd import dist as pdist
+    from pantheonrl_amd.vec import FusedSelfPlayRollout
+    built = [_vec_setup(T=6, E=64, seed=s) for s in (0, 1)]
+    agents, datas = [b[2] for b in built], [b[3] for b in built]
+    ex = pdist.ActionExchange(2, 64, agents[0].model.device)
+    stream = th.cuda.Stream()
+    with th.cuda.stream(stream):
+        roll = FusedSelfPlayRollout(agents, datas, ex, stream, bonus=0.25)
+        for a in agents:
+            a.sync_stats = True
+        roll.run_iteration(0)
+        stream.synchronize()
+    bufs = [a.model.rollout_buffer.host() for a in agents]
+    acts = [b["actions"][..., 0] for b in bufs]
+    for i, (b, d) in enumerate(zip(bufs, datas)):
+        expect = d.rewards.cpu().numpy() + 0.25 * (acts[i] == acts[1 - i])
+        assert np.array_equal(b["rewards"], expect.astype(np.float32)), i
+        assert np.array_equal(b["observations"], d.obs.cpu().numpy())
+        assert np.array_equal(b["episode_starts"], np.vstack([np.ones((1, 64), np.float32), d.dones.cpu().numpy()[:-1]]))
+        assert agents[i].iteration == 1 and agents[i].model.last_train_stats[:, 7].all()
+    assert ex.partner_of(0, 0) == 1 and int(roll.epoch_word.item()) == 1
