@@ -66,8 +66,9 @@ def parse():
     ap.add_argument("--agents-per-gpu", type=int, default=2,
                     help="self-play pair per GPU (ego PPO + partner PPO, trainer.py ... PPO PPO)")
     ap.add_argument("--mode", choices=("auto", "graph", "eager", "fusedstep"), default="auto",
-                    help="graph: one hipGraph per agent-iteration (N=1 default); fusedstep: per-step graphs with the "
-                         "action exchange between them (the N>1 path; at N=1 the exchange is a local copy)")
+                    help="graph: one hipGraph per agent-iteration (N=1 default); fusedstep: one fused launch of all local "
+                         "agents + one action exchange per env step (the N>1 path; at N=1 the exchange is a local copy); "
+                         "eager: per-agent launches")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "exercise the N>1 code path with several ranks on ONE GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
