@@ -50,8 +50,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // path below computes with plain v_fma_f32 in the same accumulator layout -- a drop-in cross-check.
 template <bool TA, bool TB, bool VALU>
 __device__ __forceinline__ f32x16 tile_mma(const float* A, int lda, const float* B, int ldb, int m0, int n0,
-                                           int k0, int klen, f32x16 acc) {
-  const int lane = threadIdx.x & 63;
+                                           int k0, int klen, f32x16 acc, int lane = -1) {
+  if (lane < 0) lane = threadIdx.x & 63;
   const int i = lane & 31, h = lane >> 5;
   if constexpr (!VALU) {
     const float* ap = TA ? (A + (k0 + h) * lda + m0 + i) : (A + (m0 + i) * lda + k0 + h);
@@ -180,9 +180,10 @@ template <int R, int NT>
 struct XStage {
   static constexpr int ITERS = R * HID / NT;
   float v[ITERS];
-  __device__ __forceinline__ void issue(const int* rowphys, const float* obs, const NetDims& nd, int c) {
+  __device__ __forceinline__ void issue(const int* rowphys, const float* obs, const NetDims& nd, int c, int tid = -1) {
     if (nd.obs_kind != PH_SPACE_BOX) return;
-    const int tid = threadIdx.x, kk = tid & 63, f = c * HID + kk;
+    if (tid < 0) tid = threadIdx.x;
+    const int kk = tid & 63, f = c * HID + kk;
     const bool fok = f < nd.F;
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
@@ -191,8 +192,8 @@ struct XStage {
     }
   }
   // caller: dst must be free (barrier before), and a barrier must follow before dst is read
-  __device__ __forceinline__ void commit(float* dst, const int* rowphys, const float* obs, const NetDims& nd, int c) {
-    const int tid = threadIdx.x;
+  __device__ __forceinline__ void commit(float* dst, const int* rowphys, const float* obs, const NetDims& nd, int c, int tid = -1) {
+    if (tid < 0) tid = threadIdx.x;
     if (nd.obs_kind == PH_SPACE_BOX) {
       const int kk = tid & 63;
 #pragma unroll
@@ -221,8 +222,8 @@ template <int NT>
 struct WStage {
   static constexpr int ITERS = HID * HID / 4 / NT;
   float4 v[ITERS];
-  __device__ __forceinline__ void issue(const float* W, int row0, int nrows_total) {
-    const int tid = threadIdx.x;
+  __device__ __forceinline__ void issue(const float* W, int row0, int nrows_total, int tid = -1) {
+    if (tid < 0) tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
       const int q = tid + NT * i;  // float4 index inside the 64x64 block
@@ -231,8 +232,8 @@ struct WStage {
                                : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  __device__ __forceinline__ void commit(float* dst) {
-    const int tid = threadIdx.x;
+  __device__ __forceinline__ void commit(float* dst, int tid = -1) {
+    if (tid < 0) tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
       const int q = tid + NT * i;
@@ -248,13 +249,15 @@ struct WoStage {
   static constexpr int PARTS = NT / 64;       // column slices
   static constexpr int MAXC = LPMAX / PARTS;  // columns per lane, upper bound
   float v[MAXC];
-  __device__ __forceinline__ void issue(const float* W, int L, int Lp) {
-    const int j = threadIdx.x & 63, c0 = (threadIdx.x >> 6) * (Lp / PARTS), per = Lp / PARTS;
+  __device__ __forceinline__ void issue(const float* W, int L, int Lp, int tid = -1) {
+    if (tid < 0) tid = threadIdx.x;
+    const int j = tid & 63, c0 = (tid >> 6) * (Lp / PARTS), per = Lp / PARTS;
 #pragma unroll
     for (int u = 0; u < MAXC; ++u) v[u] = (u < per && c0 + u < L) ? W[j * L + c0 + u] : 0.f;
   }
-  __device__ __forceinline__ void commit(float* dst, int Lp, int ldo) {
-    const int j = threadIdx.x & 63, c0 = (threadIdx.x >> 6) * (Lp / PARTS), per = Lp / PARTS;
+  __device__ __forceinline__ void commit(float* dst, int Lp, int ldo, int tid = -1) {
+    if (tid < 0) tid = threadIdx.x;
+    const int j = tid & 63, c0 = (tid >> 6) * (Lp / PARTS), per = Lp / PARTS;
 #pragma unroll
     for (int u = 0; u < MAXC; ++u)
       if (u < per) dst[j * ldo + c0 + u] = v[u];

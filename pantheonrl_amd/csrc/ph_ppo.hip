@@ -62,7 +62,6 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int mt = wave >> 1, nt = wave & 1;  // this wave's 32x32 tile of every [R x 64] / [64 x 64] product
   const int net = blockIdx.y;
   const int oW1 = net == 0 ? lay.pi_W1 : lay.vf_W1, oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1;
   const int oW2 = net == 0 ? lay.pi_W2 : lay.vf_W2, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
@@ -118,10 +117,14 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, first = false) {
     __syncthreads();  // row metadata (and, first time, W2 / biases) visible
     if (first) PH_STAMP(a.prof, 1);
-    // lane coordinates re-materialised per tile: keeps the (many) per-register slab / LDS addresses derived from them
-    // from being hoisted out of the tile loop and pinned in VGPRs for the whole kernel (that spilled to scratch)
-    int li = lane & 31, lh = lane >> 5;
-    asm volatile("" : "+v"(li), "+v"(lh));
+    // every thread-id-derived coordinate is re-materialised per tile from an opaque copy of threadIdx.x: otherwise the
+    // compiler hoists ~160 loop-invariant per-register LDS / slab addresses out of the tile loop and pins them in
+    // VGPRs for the whole kernel (217 VGPRs, spills at 3 waves/SIMD); with this the kernel needs 170
+    int tidv = threadIdx.x;
+    asm volatile("" : "+v"(tidv));
+    const int tid = tidv, lane = tid & 63, wave = tid >> 6;
+    const int mt = wave >> 1, nt = wave & 1;  // this wave's 32x32 tile of every [R x 64] / [64 x 64] product
+    const int li = lane & 31, lh = lane >> 5;
 
     // ---- S1: Z1 = X W1 over feature chunks; H1 = tanh(Z1 + b1) -> bufB ----
     f32x16 acc = {0};
@@ -130,14 +133,14 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     WoStage<NT> wor;
     for (int c = 0; c < nd.nchunk; ++c) {
       if (c > 0) __syncthreads();  // previous chunk consumed
-      xr.issue(rowphys, a.rb_obs, nd, c);
-      w1r.issue(a.params + oW1, c * HID, nd.F);
-      xr.commit(bufA, rowphys, a.rb_obs, nd, c);
-      w1r.commit(regW);
+      xr.issue(rowphys, a.rb_obs, nd, c, tid);
+      w1r.issue(a.params + oW1, c * HID, nd.F, tid);
+      xr.commit(bufA, rowphys, a.rb_obs, nd, c, tid);
+      w1r.commit(regW, tid);
       __syncthreads();
       if (first) PH_STAMP(a.prof, 2);
-      if (net == 0 && c == nd.nchunk - 1) wor.issue(a.params + lay.act_W, nd.L, Lp);  // lands during the MFMAs
-      acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc);
+      if (net == 0 && c == nd.nchunk - 1) wor.issue(a.params + lay.act_W, nd.L, Lp, tid);  // lands during the MFMAs
+      acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
     }
     if (first) PH_STAMP(a.prof, 3);
 #pragma unroll
@@ -146,13 +149,13 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       bufB[row * LDH + col] = fast_tanh(acc[r] + b1s[col]);
     }
     __syncthreads();  // every wave is done with the W1 chunk in regW and H1 is complete
-    if (net == 0) wor.commit(wos, Lp, LDO);
+    if (net == 0) wor.commit(wos, Lp, LDO, tid);
     if (first) PH_STAMP(a.prof, 4);
 
     // ---- S2: H2 = tanh(H1 W2 + b2) -> bufA ----
     {
       f32x16 acc2 = {0};
-      acc2 = tile_mma<false, false, VALU>(bufB, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc2);
+      acc2 = tile_mma<false, false, VALU>(bufB, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc2, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       if (wave < (R >> 5) * ntn) {
         const int hm = wave / ntn, hn = wave - hm * ntn;
         f32x16 acc3 = {0};
-        acc3 = tile_mma<false, false, VALU>(bufA, LDH, wos, LDO, hm * 32, hn * 32, 0, HID, acc3);
+        acc3 = tile_mma<false, false, VALU>(bufA, LDH, wos, LDO, hm * 32, hn * 32, 0, HID, acc3, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = hm * 32 + drow(r, lh), col = hn * 32 + li;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
             if (col < nd.L) g[r] = slab[lay.act_W + j * nd.L + col];
           }
         }
-        g = tile_mma<true, false, VALU>(bufA, LDH, outs, LDO, hm * 32, hn * 32, 0, R, g);
+        g = tile_mma<true, false, VALU>(bufA, LDH, outs, LDO, hm * 32, hn * 32, 0, R, g, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = hm * 32 + drow(r, lh), col = hn * 32 + li;
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       // ---- S5b: dH2 = dOut Wo^T ; dZ2 = dH2 * (1 - H2^2) in place over H2 ----
       {
         f32x16 d = {0};
-        d = tile_mma<false, true, VALU>(outs, LDO, wos, LDO, mt * 32, nt * 32, 0, Lp, d);
+        d = tile_mma<false, true, VALU>(outs, LDO, wos, LDO, mt * 32, nt * 32, 0, Lp, d, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
@@ -388,14 +391,14 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     // S7 needs X chunk 0 again: with one feature chunk the staged registers of S1 are still live (no second
     // gather); otherwise it is re-issued here and lands during the MFMAs.
     f32x16 dh1 = {0};
-    if (nd.nchunk > 1) xr.issue(rowphys, a.rb_obs, nd, 0);
+    if (nd.nchunk > 1) xr.issue(rowphys, a.rb_obs, nd, 0, tid);
     {
       f32x16 g = {0};
       if (!first) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] = slab[oW2 + (mt * 32 + drow(r, lh)) * HID + nt * 32 + li];
       }
-      g = tile_mma<true, false, VALU>(bufB, LDH, bufA, LDH, mt * 32, nt * 32, 0, R, g);
+      g = tile_mma<true, false, VALU>(bufB, LDH, bufA, LDH, mt * 32, nt * 32, 0, R, g, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) slab[oW2 + (mt * 32 + drow(r, lh)) * HID + nt * 32 + li] = g[r];
       if (tid < HID) {
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
         for (int r = 0; r < R; ++r) s += bufA[r * LDH + tid];
         slab[oB2 + tid] = s;
       }
-      dh1 = tile_mma<false, true, VALU>(bufA, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1);
+      dh1 = tile_mma<false, true, VALU>(bufA, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1, lane);
     }
     __syncthreads();  // dZ2 (bufA) and H1 (bufB) fully consumed
     if (first) PH_STAMP(a.prof, 10);
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       const float h = bufB[row * LDH + col];
       bufB[row * LDH + col] = dh1[r] * (1.0f - h * h);
     }
-    xr.commit(bufA, rowphys, a.rb_obs, nd, 0);
+    xr.commit(bufA, rowphys, a.rb_obs, nd, 0, tid);
     __syncthreads();
     if (first) PH_STAMP(a.prof, 11);
     // ---- S7: dW1 = X^T dZ1 per feature chunk ; d b1 ----
@@ -426,8 +429,8 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     for (int c = 0; c < nd.nchunk; ++c) {
       if (c > 0) {
         __syncthreads();  // previous chunk consumed
-        xr.issue(rowphys, a.rb_obs, nd, c);
-        xr.commit(bufA, rowphys, a.rb_obs, nd, c);
+        xr.issue(rowphys, a.rb_obs, nd, c, tid);
+        xr.commit(bufA, rowphys, a.rb_obs, nd, c, tid);
         __syncthreads();
       }
       f32x16 g = {0};
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
           if (k < nd.F) g[r] = slab[oW1 + (size_t)k * HID + nt * 32 + li];
         }
       }
-      g = tile_mma<true, false, VALU>(bufA, LDH, bufB, LDH, mt * 32, nt * 32, 0, R, g);
+      g = tile_mma<true, false, VALU>(bufA, LDH, bufB, LDH, mt * 32, nt * 32, 0, R, g, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int k = c * HID + mt * 32 + drow(r, lh);
