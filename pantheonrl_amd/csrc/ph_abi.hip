@@ -51,6 +51,7 @@ struct ph_ctx {
   size_t blocksq_cap = 0;
   float* advstats = nullptr;
   size_t advstats_cap = 0;
+  float* w2t = nullptr;      // [2][64][64] (W2G gradient-kernel variant)
   float* scalars = nullptr;  // [4]
   int* stop_flag = nullptr;  // [1]
   std::vector<SpecCache> specs;
@@ -198,7 +199,8 @@ int ph_ctx_create(int device, ph_ctx** out) {
   ph_ctx* c = new ph_ctx();
   c->device = device;
   c->num_cu = prop.multiProcessorCount;
-  if (hipMalloc((void**)&c->scalars, 4 * sizeof(float)) != hipSuccess ||
+  if (hipMalloc((void**)&c->w2t, 2 * 64 * 64 * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&c->scalars, 4 * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&c->stop_flag, sizeof(int)) != hipSuccess) {
     delete c;
     return fail("hipMalloc(ctx scalars) failed");
@@ -221,7 +223,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (s.obs_off) (void)hipFree(s.obs_off);
     if (s.act_off) (void)hipFree(s.act_off);
   }
-  void* ptrs[] = {ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->scalars, ctx->stop_flag};
+  void* ptrs[] = {ctx->w2t, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->scalars, ctx->stop_flag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -552,6 +554,7 @@ void fill_grad_args(ph::GradArgs& g, const ph::NetDims& nd, const float* params,
   g.statpart = ctx->statpart;
   g.stop_flag = ctx->stop_flag;
   g.prof = ctx->prof;
+  g.w2t = ctx->w2t;
 }
 
 int ensure_train_ws(ph_ctx* ctx, int P, int nwg_max, int n_mb_total) {
@@ -589,6 +592,8 @@ int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, cons
   hipStream_t s = ctx->stream;
 
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
+  const bool w2g = ph::grad_variant() == 1;
+  if (w2g) PH_HIP(ph::launch_transpose_w2(opt->params, nd.lay.pi_W2, nd.lay.vf_W2, ctx->w2t, s));
   const uint32_t hb = ph::feistel_half_bits((uint32_t)N);
   {
     ph::AdvStatArgs aa;
@@ -662,6 +667,9 @@ int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, cons
       ad.eps = hp->adam_eps;
       ad.max_norm = hp->max_grad_norm;
       ad.stats_out = r.stats_out;
+      ad.w2t = w2g ? ctx->w2t : nullptr;
+      ad.pi_W2 = nd.lay.pi_W2;
+      ad.vf_W2 = nd.lay.vf_W2;
       PH_HIP(ph::launch_ppo_adam(ad, s));
     }
   }
@@ -704,6 +712,7 @@ int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params,
   g.nb = nb;
   g.advstats = ctx->advstats;
   g.ntiles = pl.ntiles;
+  if (ph::grad_variant() == 1) PH_HIP(ph::launch_transpose_w2(params, nd.lay.pi_W2, nd.lay.vf_W2, ctx->w2t, s));
   PH_HIP(ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s));
   ph::ReduceArgs r;
   r.slabs = ctx->slabs;
@@ -761,6 +770,7 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   g.nb = nb;
   g.advstats = ctx->advstats;
   g.ntiles = pl.ntiles;
+  if (ph::grad_variant() == 1) PH_HIP(ph::launch_transpose_w2(params, nd.lay.pi_W2, nd.lay.vf_W2, ctx->w2t, s));
   PH_HIP(ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s));  // warm
   PH_HIP(hipEventRecord(ctx->ev0, s));
   for (int i = 0; i < reps; ++i) PH_HIP(ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s));

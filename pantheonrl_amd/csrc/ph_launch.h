@@ -69,6 +69,7 @@ struct GradArgs {
   float* statpart;         // [2*gridDim.x][NSTATP]
   const int* stop_flag;    // device flag set by the KL early stop
   long long* prof;         // debug: per-workgroup phase timestamps (clock64), or null
+  const float* w2t;        // [2][64][64] transposed W2 copies (W2G variant), or null
   int ntiles;
 };
 
@@ -117,10 +118,14 @@ struct AdamArgs {
   int* stop_flag;
   float lr, beta1, beta2, eps, max_norm;
   float* stats_out;       // [PH_NSTAT] or null: writes grad_norm at [6]
+  float* w2t;             // transposed W2 copies to refresh, or null
+  int pi_W2, vf_W2;
 };
 
 size_t fwd_lds_bytes(int R, int Lp);
-size_t grad_lds_bytes(int R, int Lp);
+size_t grad_lds_bytes(int R, int Lp, bool w2g);
+int grad_variant();
+hipError_t launch_transpose_w2(const float* params, int pi_W2, int vf_W2, float* w2t, hipStream_t s);
 hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s);
 hipError_t launch_policy_fwd_multi(const FwdMulti& m, int n_agents, hipStream_t s);
 hipError_t launch_fix_illegal(int* actions, const unsigned char* mask, int n, int L, hipStream_t s);

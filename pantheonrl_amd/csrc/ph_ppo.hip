@@ -35,8 +35,8 @@ __device__ __forceinline__ int minibatch_row(const GradArgs& a, int gi) {
 // Weight-gradient tiles accumulate across the tiles of a workgroup in its private slab: the MFMA accumulator is
 // initialised from the slab (the loads hide under the operand prefetch of the tile product), then stored back.
 // (No-return L2 float atomics instead of the reload measured 8 % slower on the whole kernel.)
-template <int R, int LP, bool VALU>
-__global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
+template <int R, int LP, bool VALU, bool W2G>
+__global__ __launch_bounds__(R * 4, W2G ? 3 : 2) void ppo_grad_kernel(GradArgs a) {
   if (*a.stop_flag) return;
   PH_STAMP(a.prof, 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -48,8 +48,8 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   float* bufB = bufA + R * LDH;        // [R][LDH]  H1 -> dZ1
   float* regW = bufB + R * LDH;        // W1 chunk [64][LDH]  |  Wo [64][LDO] + OUT [R][LDO]
   constexpr int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
-  float* w2s = regW + regW_sz;         // [64][LDH]
-  float* b1s = w2s + HID * LDH;        // [64]
+  float* w2s = regW + regW_sz;         // [64][LDH]  (absent when W2G: W2 / W2^T are read from global as MFMA operands)
+  float* b1s = w2s + (W2G ? 0 : HID * LDH);  // [64]
   float* b2s = b1s + HID;              // [64]
   float* bos = b2s + HID;              // act_b [Lp]  (policy)  |  val_W [64] (value)
   float* radv = bos + 64;              // [R] normalised advantage (policy) | returns (value)
@@ -71,7 +71,9 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   // prologue: W2 and the bias vectors are issued now and committed after the first tile's row metadata, so their
   // latency overlaps the index gathers of S0
   WStage<NT> w2r;
-  w2r.issue(a.params + oW2, 0, HID);
+  if constexpr (!W2G) w2r.issue(a.params + oW2, 0, HID);
+  const float* w2g = a.params + oW2;                       // W2 [k][j]
+  const float* w2tg = a.w2t + (size_t)net * HID * HID;     // W2^T [j][k]
   float bias1 = 0.f, bias2 = 0.f, bias3 = 0.f;
   if (tid < HID) {
     bias1 = a.params[oB1 + tid];
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     }
   };
   stage_rows(blockIdx.x);  // overlaps the W2 / bias loads issued above
-  w2r.commit(w2s);
+  if constexpr (!W2G) w2r.commit(w2s);
   if (tid < HID) {
     b1s[tid] = bias1;
     b2s[tid] = bias2;
@@ -155,7 +157,8 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     // ---- S2: H2 = tanh(H1 W2 + b2) -> bufA ----
     {
       f32x16 acc2 = {0};
-      acc2 = tile_mma<false, false, VALU>(bufB, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc2, lane);
+      if constexpr (W2G) acc2 = tile_mma<false, false, VALU>(bufB, LDH, w2g, HID, mt * 32, nt * 32, 0, HID, acc2, lane);
+      else acc2 = tile_mma<false, false, VALU>(bufB, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc2, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
@@ -406,7 +409,8 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
         for (int r = 0; r < R; ++r) s += bufA[r * LDH + tid];
         slab[oB2 + tid] = s;
       }
-      dh1 = tile_mma<false, true, VALU>(bufA, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1, lane);
+      if constexpr (W2G) dh1 = tile_mma<false, false, VALU>(bufA, LDH, w2tg, HID, mt * 32, nt * 32, 0, HID, dh1, lane);
+      else dh1 = tile_mma<false, true, VALU>(bufA, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1, lane);
     }
     __syncthreads();  // dZ2 (bufA) and H1 (bufB) fully consumed
     if (first) PH_STAMP(a.prof, 10);
@@ -477,38 +481,57 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   PH_STAMP(a.prof, 13);
 }
 
-template __global__ void ppo_grad_kernel<64, 32, false>(GradArgs);
-template __global__ void ppo_grad_kernel<64, 64, false>(GradArgs);
-template __global__ void ppo_grad_kernel<64, 32, true>(GradArgs);
-template __global__ void ppo_grad_kernel<64, 64, true>(GradArgs);
 
-size_t grad_lds_bytes(int R, int Lp) {
+size_t grad_lds_bytes(int R, int Lp, bool w2g) {
   const int LDO = Lp + 1;
   const int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
-  return sizeof(float) * (size_t)(2 * R * LDH + regW_sz + HID * LDH + 3 * 64 + 3 * R + NSTATP * 4 + R);
+  return sizeof(float) * (size_t)(2 * R * LDH + regW_sz + (w2g ? 0 : HID * LDH) + 3 * 64 + 3 * R + NSTATP * 4 + R);
+}
+
+template <int LP, bool VALU, bool W2G>
+static hipError_t launch_grad_variant(const GradArgs& a, int nwg, hipStream_t s) {
+  constexpr int R = 64;
+  const size_t lds = grad_lds_bytes(R, LP, W2G);
+  dim3 grid(nwg, 2), block(R * 4);
+  static size_t allowed = 0;  // > 64 KiB of dynamic LDS is opt-in, once per kernel (kept out of graph capture)
+  if (lds > allowed) {
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<R, LP, VALU, W2G>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    allowed = lds;
+  }
+  hipLaunchKernelGGL((ppo_grad_kernel<R, LP, VALU, W2G>), grid, block, lds, s, a);
+  return hipGetLastError();
+}
+
+// variant 0: W2 staged in LDS, 2 workgroups / CU.  variant 1 ("W2G"): W2 and W2^T read from global as MFMA operands,
+// 52 KB LDS and <= 168 VGPRs -> 3 workgroups / CU.
+int grad_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PH_GRAD_W2G");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v;
 }
 
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s) {
-  constexpr int R = 64;
-  const size_t lds = grad_lds_bytes(R, a.nd.Lp);
-  dim3 grid(nwg, 2), block(R * 4);
-  // > 64 KiB of dynamic LDS must be opted into once per kernel (not a stream operation; kept out of graph capture)
-  const int v = (gemm_mode != 0 ? 2 : 0) + (a.nd.Lp == 64 ? 1 : 0);
-  const void* fns[4] = {(const void*)ppo_grad_kernel<R, 32, false>, (const void*)ppo_grad_kernel<R, 64, false>,
-                        (const void*)ppo_grad_kernel<R, 32, true>, (const void*)ppo_grad_kernel<R, 64, true>};
-  static size_t allowed[4] = {0, 0, 0, 0};
   if (a.nd.Lp != 32 && a.nd.Lp != 64) return hipErrorInvalidValue;
-  if (lds > allowed[v]) {
-    hipError_t e = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    allowed[v] = lds;
-  }
-  switch (v) {
-    case 0: hipLaunchKernelGGL((ppo_grad_kernel<R, 32, false>), grid, block, lds, s, a); break;
-    case 1: hipLaunchKernelGGL((ppo_grad_kernel<R, 64, false>), grid, block, lds, s, a); break;
-    case 2: hipLaunchKernelGGL((ppo_grad_kernel<R, 32, true>), grid, block, lds, s, a); break;
-    default: hipLaunchKernelGGL((ppo_grad_kernel<R, 64, true>), grid, block, lds, s, a); break;
-  }
+  const bool lp64 = a.nd.Lp == 64;
+  if (gemm_mode != 0) return lp64 ? launch_grad_variant<64, true, false>(a, nwg, s) : launch_grad_variant<32, true, false>(a, nwg, s);
+  if (grad_variant() == 1) return lp64 ? launch_grad_variant<64, false, true>(a, nwg, s) : launch_grad_variant<32, false, true>(a, nwg, s);
+  return lp64 ? launch_grad_variant<64, false, false>(a, nwg, s) : launch_grad_variant<32, false, false>(a, nwg, s);
+}
+
+// W2^T copies ([net][j][k]) for the W2G variant: refreshed by ppo_adam_kernel after every step, built here once
+__global__ void transpose_w2_kernel(const float* __restrict__ params, int pi_W2, int vf_W2, float* __restrict__ w2t) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // 2 * 4096
+  if (e >= 2 * HID * HID) return;
+  const int net = e / (HID * HID), r = e - net * HID * HID, k = r / HID, j = r - k * HID;
+  w2t[(size_t)net * HID * HID + j * HID + k] = params[(net == 0 ? pi_W2 : vf_W2) + r];
+}
+hipError_t launch_transpose_w2(const float* params, int pi_W2, int vf_W2, float* w2t, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_w2_kernel, dim3((2 * HID * HID + 255) / 256), dim3(256), 0, s, params, pi_W2, vf_W2, w2t);
   return hipGetLastError();
 }
 
@@ -684,7 +707,13 @@ __global__ __launch_bounds__(256) void ppo_adam_kernel(AdamArgs a) {
   const float denom = sqrtf(v) / bc2s_s + a.eps;
   a.m[p] = m;
   a.v[p] = v;
-  a.params[p] = a.params[p] - ss_s * (m / denom);                    // param.addcdiv_(exp_avg, denom, -step_size)
+  const float pn = a.params[p] - ss_s * (m / denom);                   // param.addcdiv_(exp_avg, denom, -step_size)
+  a.params[p] = pn;
+  if (a.w2t) {  // keep the transposed W2 copies of the W2G gradient kernel current
+    int r = p - a.pi_W2, net = 0;
+    if (r < 0 || r >= HID * HID) { r = p - a.vf_W2; net = 1; }
+    if (r >= 0 && r < HID * HID) a.w2t[(size_t)net * HID * HID + (r % HID) * HID + r / HID] = pn;
+  }
 }
 hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(ppo_adam_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
