@@ -39,6 +39,30 @@ class DummyEnv:
         self.action_space = action_space
 
 
+class _Seats:
+    """Book-keeping of the non-ego seats: who may sit there, who currently does, who already acted this episode."""
+
+    def __init__(self, n_seats: int, ego_ind: int, candidates: Optional[List[List[Agent]]]):
+        self.ego_ind = ego_ind
+        self.candidates: List[List[Agent]] = candidates if candidates else [[] for _ in range(n_seats)]
+        self.current: List[int] = [0] * n_seats
+        self.acted: List[bool] = [False] * n_seats
+
+    def index_of(self, player_num: int) -> int:
+        if player_num == self.ego_ind:
+            raise PlayerException("Ego agent is not set by the environment")
+        return player_num - (player_num > self.ego_ind)
+
+    def player_of(self, seat: int) -> int:
+        return seat + (seat >= self.ego_ind)
+
+    def agent(self, seat: int) -> Agent:
+        return self.candidates[seat][self.current[seat]]
+
+    def new_episode(self) -> None:
+        self.acted = [False] * len(self.acted)
+
+
 class MultiAgentEnv(ABC):
     """Base of all multi-agent games (multiagentenv.py:25-284).
 
@@ -52,23 +76,37 @@ class MultiAgentEnv(ABC):
     def __init__(self, ego_ind: int = 0, n_players: int = 2, resample_policy: str = "default",
                  partners: Optional[List[List[Agent]]] = None,
                  ego_extractor: Callable[[Observation], Any] = extract_obs):
-        self.ego_ind, self.n_players = ego_ind, n_players
-        n_seats = n_players - 1
         if partners is not None:
-            if len(partners) != n_seats:
+            if len(partners) != n_players - 1:
                 raise PlayerException("The number of partners needs to equal the number of non-ego players")
-            if any((not isinstance(seat, list)) or len(seat) == 0 for seat in partners):
+            if not all(isinstance(seat, list) and len(seat) > 0 for seat in partners):
                 raise PlayerException("Sublist for each partner must be nonempty list")
-        self.partners: List[List[Agent]] = partners if partners else [[] for _ in range(n_seats)]
-        self.partnerids: List[int] = [0] * n_seats
+        self.ego_ind, self.n_players = ego_ind, n_players
+        self._seats = _Seats(n_players - 1, ego_ind, partners)
         self._players: Tuple[int, ...] = ()
         self._obs: Tuple[Optional[Observation], ...] = ()
         self._old_ego_obs: Optional[Observation] = None
-        self.should_update = [False] * n_seats
         self.total_rews = [0] * n_players
         self.ego_moved = False
-        self.set_resample_policy(resample_policy)
         self.ego_extractor = ego_extractor
+        self.set_resample_policy(resample_policy)
+
+    # the reference exposes these three as plain attributes; keep them readable / assignable under the same names
+    @property
+    def partners(self) -> List[List[Agent]]:
+        return self._seats.candidates
+
+    @property
+    def partnerids(self) -> List[int]:
+        return self._seats.current
+
+    @partnerids.setter
+    def partnerids(self, ids: List[int]) -> None:
+        self._seats.current = list(ids)
+
+    @property
+    def should_update(self) -> List[bool]:
+        return self._seats.acted
 
     # -- partner management (multiagentenv.py:72-147) ---------------------------------------------------------------
     def getDummyEnv(self, player_num: int):
@@ -79,9 +117,7 @@ class MultiAgentEnv(ABC):
         self.ego_extractor = ego_extractor
 
     def _get_partner_num(self, player_num: int) -> int:
-        if player_num == self.ego_ind:
-            raise PlayerException("Ego agent is not set by the environment")
-        return player_num - 1 if player_num > self.ego_ind else player_num
+        return self._seats.index_of(player_num)
 
     def add_partner_agent(self, agent: Agent, player_num: int = 1) -> None:
         """Register `agent` as a candidate for seat `player_num`; one candidate is drawn per episode."""
@@ -90,89 +126,94 @@ class MultiAgentEnv(ABC):
     def set_partnerid(self, agent_id: int, player_num: int = 1) -> None:
         seat = self._get_partner_num(player_num)
         assert 0 <= agent_id < len(self.partners[seat])
-        self.partnerids[seat] = agent_id
+        self._seats.current[seat] = agent_id
 
     def resample_random(self) -> None:
-        self.partnerids = [np.random.randint(len(seat)) for seat in self.partners]
+        self.partnerids = [np.random.randint(len(options)) for options in self.partners]
 
     def resample_round_robin(self) -> None:
-        """next candidate of the single partner seat (2-player games only)."""
+        """advance the single partner seat to its next candidate (2-player games only)"""
         self.partnerids = [(self.partnerids[0] + 1) % len(self.partners[0])]
 
     def set_resample_policy(self, resample_policy: str) -> None:
-        if resample_policy == "default":
-            resample_policy = "robin" if self.n_players == 2 else "random"
-        if resample_policy == "robin":
-            if self.n_players != 2:
-                raise PlayerException("Cannot do round robin resampling for >2 players")
-            self.resample_partner = self.resample_round_robin
-        elif resample_policy == "random":
-            self.resample_partner = self.resample_random
-        else:
+        choice = resample_policy
+        if choice == "default":
+            choice = "robin" if self.n_players == 2 else "random"
+        if choice == "robin" and self.n_players != 2:
+            raise PlayerException("Cannot do round robin resampling for >2 players")
+        table = {"robin": self.resample_round_robin, "random": self.resample_random}
+        if choice not in table:
             raise PlayerException(f"Invalid resampling policy: {resample_policy}")
+        self.resample_partner = table[choice]
 
     # -- driving the partners (multiagentenv.py:149-170) ----------------------------------------------------------------
-    def _active(self, seat: int) -> Agent:
-        return self.partners[seat][self.partnerids[seat]]
-
     def _get_actions(self, players, obs, ego_act=None):
-        chosen = []
+        """actions of everybody due to move: the ego's is given, partners are asked (and, on their first move of the
+        episode, handed the reward they accrued before moving -- never a terminal one)"""
+        seats = self._seats
+        actions = []
         for player, ob in zip(players, obs):
             if player == self.ego_ind:
-                chosen.append(ego_act)
+                actions.append(ego_act)
                 continue
-            seat = self._get_partner_num(player)
-            agent = self._active(seat)
-            chosen.append(agent.get_action(ob))
-            if not self.should_update[seat]:  # first move of the episode: rewards accrued so far, not terminal
+            seat = seats.index_of(player)
+            agent = seats.agent(seat)
+            actions.append(agent.get_action(ob))
+            if not seats.acted[seat]:
                 agent.update(self.total_rews[player], False)
-            self.should_update[seat] = True
-        return np.array(chosen)
+                seats.acted[seat] = True
+        return np.array(actions)
 
     def _update_players(self, rews, done) -> None:
-        for seat in range(self.n_players - 1):
-            player = seat if seat < self.ego_ind else seat + 1
-            if self.should_update[seat]:
-                self._active(seat).update(rews[player], done)
-        for player in range(self.n_players):
-            self.total_rews[player] += rews[player]
+        """credit this transition to every partner that has acted, then to the running totals"""
+        seats = self._seats
+        for seat, acted in enumerate(seats.acted):
+            if acted:
+                seats.agent(seat).update(rews[seats.player_of(seat)], done)
+        self.total_rews = [total + r for total, r in zip(self.total_rews, rews)]
+
+    def _advance(self, ego_act=None):
+        """one n_step with everybody due to move"""
+        acts = self._get_actions(self._players, self._obs, ego_act)
+        self._players, self._obs, rews, done, info = self.n_step(acts)
+        return rews, done, info
+
+    def _ego_view(self):
+        ego_obs = self._obs[self._players.index(self.ego_ind)]
+        self._old_ego_obs = ego_obs
+        return self.ego_extractor(ego_obs)
 
     # -- gym.Env surface (multiagentenv.py:172-243) --------------------------------------------------------------------
     def step(self, action: np.ndarray):
-        """One ego timestep -> (ego observation, ego reward, done, info)."""
+        """One ego timestep -> (ego observation, ego reward, done, info): the ego's move, then every partner move until
+        the ego is due again or the game ends (in which case the previous ego observation is returned)."""
         ego_rew = 0.0
         while True:
-            acts = self._get_actions(self._players, self._obs, action)
-            self._players, self._obs, rews, done, info = self.n_step(acts)
+            rews, done, info = self._advance(action)
             info["_partnerid"] = self.partnerids
             self._update_players(rews, done)
+            # the first time the ego is credited in an episode it also collects what accrued before it moved
             ego_rew += rews[self.ego_ind] if self.ego_moved else self.total_rews[self.ego_ind]
             self.ego_moved = True
             if done:
                 return self.ego_extractor(self._old_ego_obs), ego_rew, done, info
             if self.ego_ind in self._players:
-                break
-        ego_obs = self._obs[self._players.index(self.ego_ind)]
-        self._old_ego_obs = ego_obs
-        return self.ego_extractor(ego_obs), ego_rew, done, info
+                return self._ego_view(), ego_rew, done, info
 
     def reset(self):
         """New episode: resample partners, play partners forward until the ego is due, return its first obs."""
         self.resample_partner()
         self._players, self._obs = self.n_reset()
-        self.should_update = [False] * (self.n_players - 1)
+        self._seats.new_episode()
         self.total_rews = [0] * self.n_players
         self.ego_moved = False
         while self.ego_ind not in self._players:
-            acts = self._get_actions(self._players, self._obs)
-            self._players, self._obs, rews, done, _ = self.n_step(acts)
+            rews, done, _ = self._advance()
             if done:
                 raise PlayerException("Game ended before ego moved")
             self._update_players(rews, done)
-        ego_obs = self._obs[self._players.index(self.ego_ind)]
-        assert ego_obs is not None
-        self._old_ego_obs = ego_obs
-        return self.ego_extractor(ego_obs)
+        assert self._obs[self._players.index(self.ego_ind)] is not None
+        return self._ego_view()
 
     # -- what a concrete game implements (multiagentenv.py:245-284) -------------------------------------------------------
     @abstractmethod

@@ -1,4 +1,9 @@
-"""Policy call shim and space helpers (reference pantheonrl/common/util.py:14-111)."""
+"""Policy call shim and space helpers (behaviour of reference pantheonrl/common/util.py:14-111).
+
+The space helpers are table-driven on the space kind (Box / Discrete / MultiBinary / MultiDiscrete, matched by class
+name so `gym.spaces` objects work as well as `pantheonrl_amd.spaces`); anything else raises SpaceException like the
+reference.
+"""
 from __future__ import annotations
 
 from typing import Tuple
@@ -6,84 +11,70 @@ from typing import Tuple
 import numpy as np
 import torch as th
 
-from ..spaces import Box, Discrete, MultiBinary, MultiDiscrete, SpaceException  # noqa: F401
+from ..spaces import Box, Discrete, MultiBinary, MultiDiscrete, SpaceException, obs_stored_shape  # noqa: F401
+
+# kind -> (stored scalars per sample, space after stacking k frames, default observation)
+_SPACE_RULES = {
+    "Box": (lambda s: len(s.low),
+            lambda s, k: Box(np.tile(s.low, k), np.tile(s.high, k), dtype=s.dtype),
+            lambda s: s.low),
+    "Discrete": (lambda s: 1,
+                 lambda s, k: MultiDiscrete([s.n] * k),
+                 lambda s: [0]),
+    "MultiBinary": (lambda s: s.n,
+                    lambda s, k: MultiBinary(s.n * k),
+                    lambda s: [0] * s.n),
+    "MultiDiscrete": (lambda s: len(s.nvec),
+                      lambda s, k: MultiDiscrete(list(s.nvec) * k),
+                      lambda s: [0] * len(s.nvec)),
+}
 
 
-def _kind(space) -> str:
-    return type(space).__name__
+def _rules(space):
+    try:
+        return _SPACE_RULES[type(space).__name__]
+    except KeyError:
+        raise SpaceException from None
 
 
 def get_space_size(space) -> int:
-    """number of stored scalars of one sample (util.py:18-29)."""
-    k = _kind(space)
-    if k == "Box":
-        return len(space.low)
-    if k == "Discrete":
-        return 1
-    if k == "MultiBinary":
-        return space.n
-    if k == "MultiDiscrete":
-        return len(space.nvec)
-    raise SpaceException
+    """number of stored scalars of one sample of `space`"""
+    return _rules(space)[0](space)
 
 
 def calculate_space(space, numframes: int):
-    """the observation space after stacking `numframes` frames (util.py:32-45)."""
-    k = _kind(space)
-    if k == "Box":
-        return Box(np.tile(space.low, numframes), np.tile(space.high, numframes), dtype=space.dtype)
-    if k == "Discrete":
-        return MultiDiscrete([space.n] * numframes)
-    if k == "MultiBinary":
-        return MultiBinary(space.n * numframes)
-    if k == "MultiDiscrete":
-        return MultiDiscrete(list(space.nvec) * numframes)
-    raise SpaceException
+    """the observation space seen through a frame stack of `numframes` frames"""
+    return _rules(space)[1](space, numframes)
 
 
 def get_default_obs(env):
-    """the filler observation used before an episode has enough history (util.py:48-60)."""
-    space = env.observation_space
-    k = _kind(space)
-    if k == "Box":
-        return space.low
-    if k == "Discrete":
-        return [0]
-    if k == "MultiBinary":
-        return [0] * space.n
-    if k == "MultiDiscrete":
-        return [0] * len(space.nvec)
-    raise SpaceException
+    """the filler observation a frame stack uses for slots the episode has not reached"""
+    return _rules(env.observation_space)[2](env.observation_space)
 
 
 def action_from_policy(obs: np.ndarray, policy, action_mask=None) -> Tuple[np.ndarray, th.Tensor, th.Tensor]:
-    """(actions as numpy, values tensor, log_probs tensor) from one policy forward (util.py:63-81).
+    """one policy forward -> (actions as a host array, values tensor, log-prob tensor) (util.py:63-81).
 
-    The reshape to (-1,)+obs_shape and the host copy of the actions are kept; the forward itself is one fused
-    launch on the GPU."""
-    obs = np.asarray(obs).reshape((-1,) + tuple(_obs_shape(policy.observation_space)))
+    As in the reference the observation is first reshaped to a batch of the policy's observation shape and the actions
+    come back as numpy; the forward in between is a single fused launch on the GPU."""
+    space = policy.observation_space
+    shape = tuple(getattr(space, "shape", ()) or obs_stored_shape(space))
+    batch = np.asarray(obs).reshape((-1,) + shape)
+    kwargs = {}
     if action_mask is not None:
-        actions, values, log_probs = policy.forward(obs, action_mask=np.asarray(action_mask).reshape(obs.shape[0], -1))
-    else:
-        actions, values, log_probs = policy.forward(obs)
+        kwargs["action_mask"] = np.asarray(action_mask).reshape(batch.shape[0], -1)
+    actions, values, log_probs = policy.forward(batch, **kwargs)
     return actions.cpu().numpy(), values, log_probs
 
 
-def _obs_shape(space):
-    from ..spaces import obs_stored_shape
-    shape = getattr(space, "shape", None)
-    return shape if shape else obs_stored_shape(space)
-
-
 def clip_actions(actions: np.ndarray, policy) -> np.ndarray:
-    """clip to a Box action space, identity otherwise (util.py:84-99)."""
+    """continuous actions are clipped to their Box; discrete ones pass through (util.py:84-99)"""
     space = policy.action_space
-    if _kind(space) == "Box":
-        actions = np.clip(actions, space.low, space.high)
-    return actions
+    return np.clip(actions, space.low, space.high) if type(space).__name__ == "Box" else actions
 
 
 def resample_noise(model, n_steps: int) -> None:
-    """gSDE noise tick (util.py:102-111); the MlpPolicy default never uses it."""
-    if getattr(model, "use_sde", False) and model.sde_sample_freq > 0 and n_steps % model.sde_sample_freq == 0:
+    """gSDE exploration-noise tick (util.py:102-111); a no-op for the MlpPolicy defaults this engine implements"""
+    freq = getattr(model, "sde_sample_freq", -1)
+    if getattr(model, "use_sde", False) and freq > 0 and n_steps % freq == 0:
         model.policy.reset_noise(model.env.num_envs)

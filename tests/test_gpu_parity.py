@@ -783,3 +783,40 @@ def test_abi_misuse_is_reported_not_fatal():
     assert pol.forward(np.zeros((8, 48), np.float32))[0].shape == (8,)
     with pytest.raises(nat.NativeError):
         buf.add_reward(np.zeros(8), pos=99)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# committed golden vectors (tests/golden/*.npz, made by make_golden.py from the oracle): a file-based expectation
+# ----------------------------------------------------------------------------------------------------------------
+def test_device_reproduces_committed_golden_vectors():
+    import os
+    from pantheonrl_amd.ppo import PPO
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(gold, "gae.npz"))
+    for i in range(int(g["n_cases"])):
+        a, ret = _run_gae(g[f"c{i}_r"], g[f"c{i}_v"], g[f"c{i}_s"], g[f"c{i}_lv"], g[f"c{i}_dn"], mode=1)
+        assert np.array_equal(a, g[f"c{i}_adv"]) and np.array_equal(ret, g[f"c{i}_ret"])
+    f = np.load(os.path.join(gold, "forward.npz"))
+    for name in ("rps", "liar", "overcooked", "mpe8"):
+        obs_s, act_s = H.CONFIGS[name]
+        from pantheonrl_amd.ppo import ActorCriticPolicy
+        pol = ActorCriticPolicy(H.to_space(obs_s), H.to_space(act_s), seed=0)
+        pol.set_flat_params(f[f"{name}_params"])
+        np.testing.assert_allclose(pol.get_logits(f[f"{name}_obs"]).cpu().numpy(), f[f"{name}_logits"], atol=2e-5)
+        v, lp, ent = pol.evaluate_actions(f[f"{name}_obs"], f[f"{name}_actions"])
+        np.testing.assert_allclose(v.cpu().numpy().ravel(), f[f"{name}_values"], atol=2e-5)
+        np.testing.assert_allclose(lp.cpu().numpy(), f[f"{name}_logp"], atol=2e-5)
+        np.testing.assert_allclose(ent.cpu().numpy(), f[f"{name}_entropy"], atol=2e-5)
+    s = np.load(os.path.join(gold, "ppo_step.npz"))
+    obs_s, act_s = H.CONFIGS["overcooked"]
+    env = type("E", (), dict(observation_space=H.to_space(obs_s), action_space=H.to_space(act_s),
+                             _is_dummy_space_env=True))()
+    model = PPO("MlpPolicy", env, n_steps=16, n_envs=4, batch_size=24, n_epochs=2, seed=0)
+    model.policy.set_flat_params(s["params0"])
+    rb = model.rollout_buffer
+    for k in ("observations", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns"):
+        getattr(rb, k).copy_(th.as_tensor(s["rb_" + k]).reshape(getattr(rb, k).shape))
+    rb.pos, rb.full = 16, True
+    model.train(perms=s["perms"])
+    np.testing.assert_allclose(model.last_train_stats[:, :7], s["stats"], atol=2e-4, rtol=2e-3)
+    assert np.abs(model.policy.get_flat_params() - s["params1"]).max() <= 1.5e-5
