@@ -22,23 +22,29 @@ __device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2
 // ---- float32 transcendental helpers ----------------------------------------------------------------------------------
 // ocml's tanhf/expf/logf are correctly rounded but cost ~300 cycles per wave-instruction-equivalent here (exec-masked
 // range branches); the epilogues of every layer are tanh, so they dominated the kernels.  These versions are
-// branch-free and stay within ~3 ulp (abs. error <= 2e-7 on tanh, rel. error <= |x|*1.2e-7 on exp), far inside the
-// 2e-5 parity tolerance of the logits.
+// branch-free and stay within a few ulp (rel. error <= |x|*1.2e-7 on exp), far inside the 2e-5 parity tolerance of
+// the logits.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
 __device__ __forceinline__ float fast_tanh(float x) {
-  const float ax = __builtin_fabsf(x);
-  // |x| < 0.3: odd Taylor polynomial to x^9 (next term < 1.6e-8 at 0.3)
-  const float x2 = x * x;
-  float p = 62.0f / 2835.0f;
-  p = __builtin_fmaf(p, x2, -17.0f / 315.0f);
-  p = __builtin_fmaf(p, x2, 2.0f / 15.0f);
-  p = __builtin_fmaf(p, x2, -1.0f / 3.0f);
-  p = __builtin_fmaf(p * x2, x, x);
-  // otherwise 1 - 2/(exp(2|x|)+1); exp2 saturates to +inf for large |x| -> exactly 1
-  const float e = __builtin_amdgcn_exp2f(ax * (2.0f * 1.44269504088896340736f));
-  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-  return ax < 0.3f ? p : __builtin_copysignf(t, x);
+  // odd/even rational minimax approximation x*P(x^2)/Q(x^2) on the clamped argument (|x| <= 7.905: beyond it tanh
+  // rounds to +-1 in float32): 11 FMAs and ONE quarter-rate op (rcp), no exp, ~2 ulp over the whole range including
+  // tiny |x| (the exp-based form 1 - 2/(e^{2x}+1) loses relative accuracy there and needs two quarter-rate ops)
+  const float c = fminf(fmaxf(x, -7.90531110763549805f), 7.90531110763549805f);
+  const float x2 = c * c;
+  float p = -2.76076847742355e-16f;
+  p = __builtin_fmaf(p, x2, 2.00018790482477e-13f);
+  p = __builtin_fmaf(p, x2, -8.60467152213735e-11f);
+  p = __builtin_fmaf(p, x2, 5.12229709037114e-08f);
+  p = __builtin_fmaf(p, x2, 1.48572235717979e-05f);
+  p = __builtin_fmaf(p, x2, 6.37261928875436e-04f);
+  p = __builtin_fmaf(p, x2, 4.89352455891786e-03f);
+  p *= c;
+  float q = 1.19825839466702e-06f;
+  q = __builtin_fmaf(q, x2, 1.18534705686654e-04f);
+  q = __builtin_fmaf(q, x2, 2.26843463243900e-03f);
+  q = __builtin_fmaf(q, x2, 4.89352518554385e-03f);
+  return p * __builtin_amdgcn_rcpf(q);
 }
 
 // One 32x32 output tile  acc += A[m0:m0+32, k0:k0+klen] * B[k0:k0+klen, n0:n0+32]  with both operands in

@@ -166,6 +166,53 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
     if (a.logits)
       for (int k = 0; k < nd.L; ++k) a.logits[(size_t)g * nd.L + k] = z[k];
     float logp = 0.f, ent = 0.f;
+    if (nd.A == 1 && nd.L <= 8) {
+      // fast path (Discrete action space, <= 8 logits): the row lives in registers, one exp per logit
+      const int nk = nd.L;
+      float zr[8], pr[8];
+      float m = -3.0e38f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        zr[k] = (k < nk) ? z[k] : -3.0e38f;
+        m = fmaxf(m, zr[k]);
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        pr[k] = (k < nk) ? fast_exp(zr[k] - m) : 0.f;
+        se += pr[k];
+      }
+      const float lse = m + fast_log(se), inv = __builtin_amdgcn_rcpf(se);
+      int act = 0;
+      if (a.given_actions) {
+        act = (int)a.given_actions[g];
+        act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
+      } else if (a.deterministic) {
+        float best = zr[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+          if (k < nk && zr[k] > best) { best = zr[k]; act = k; }
+      } else {
+        const float u = a.uniforms ? a.uniforms[g] : philox_uniform(a.seed, ctr, (uint32_t)g, 0u);
+        float cum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {  // inverse CDF: count prefix sums <= u
+          cum += pr[k] * inv;
+          act += (k < nk - 1 && u >= cum) ? 1 : 0;
+        }
+      }
+      float zact = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float lp = zr[k] - lse;
+        ent -= (k < nk) ? pr[k] * inv * lp : 0.f;
+        zact = (k == act) ? zr[k] : zact;
+      }
+      logp = zact - lse;
+      if (a.act_i32) a.act_i32[g] = act;
+      if (a.act_f32) a.act_f32[g] = (float)act;
+      if (a.rb_act) a.rb_act[g] = (float)act;
+    } else
     for (int c = 0; c < nd.A; ++c) {
       const int lo = nd.act_off[c], nk = nd.act_off[c + 1] - lo;
       float m = z[lo];
