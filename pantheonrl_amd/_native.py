@@ -18,7 +18,7 @@ PH_SPACE_DISCRETE = 1
 STAT_NAMES = ("policy_loss", "value_loss", "entropy_loss", "clip_fraction", "approx_kl", "loss", "grad_norm", "applied")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpantheon_hip.so")
+LIB_PATH = os.environ.get("PANTHEON_HIP_LIB") or os.path.join(_HERE, "csrc", "libpantheon_hip.so")
 
 
 class NativeError(RuntimeError):
@@ -112,7 +112,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if build_if_missing:
+    if build_if_missing and not os.environ.get("PANTHEON_HIP_LIB"):
         try:
             from .csrc import build as _build
             if _build.needs_build():

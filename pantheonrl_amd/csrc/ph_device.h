@@ -26,6 +26,23 @@ __device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2
 // the logits.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+#ifndef PH_TANH_RATIONAL
+// polynomial for |x| < 0.3 (next Taylor term < 1.6e-8), 1 - 2/(e^{2x}+1) otherwise; abs. error <= 2e-7.  A/B on the same
+// box against the rational form below (11-FMA Horner chain + one rcp): 59.0 vs 62.0 us per ppo_grad launch, 6.69 vs
+// 7.04 ms per bench iteration -- the short dependency chains of this form win although it has more instructions.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float ax = __builtin_fabsf(x);
+  const float x2 = x * x;
+  float p = 62.0f / 2835.0f;
+  p = __builtin_fmaf(p, x2, -17.0f / 315.0f);
+  p = __builtin_fmaf(p, x2, 2.0f / 15.0f);
+  p = __builtin_fmaf(p, x2, -1.0f / 3.0f);
+  p = __builtin_fmaf(p * x2, x, x);
+  const float e = __builtin_amdgcn_exp2f(ax * (2.0f * 1.44269504088896340736f));
+  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  return ax < 0.3f ? p : __builtin_copysignf(t, x);
+}
+#else
 __device__ __forceinline__ float fast_tanh(float x) {
   // odd/even rational minimax approximation x*P(x^2)/Q(x^2) on the clamped argument (|x| <= 7.905: beyond it tanh
   // rounds to +-1 in float32): 11 FMAs and ONE quarter-rate op (rcp), no exp, ~2 ulp over the whole range including
@@ -46,6 +63,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
   q = __builtin_fmaf(q, x2, 4.89352518554385e-03f);
   return p * __builtin_amdgcn_rcpf(q);
 }
+#endif
 
 // One 32x32 output tile  acc += A[m0:m0+32, k0:k0+klen] * B[k0:k0+klen, n0:n0+32]  with both operands in
 // LDS.  A(m,k) = TA ? A[k*lda+m] : A[m*lda+k];  B(k,n) = TB ? B[n*ldb+k] : B[k*ldb+n].
