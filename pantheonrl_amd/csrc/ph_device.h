@@ -26,7 +26,12 @@ __device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2
 // the logits.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
-#ifndef PH_TANH_RATIONAL
+#if defined(PH_TANH_EXPONLY)
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * (2.0f * 1.44269504088896340736f));
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+#elif !defined(PH_TANH_RATIONAL)
 // polynomial for |x| < 0.3 (next Taylor term < 1.6e-8), 1 - 2/(e^{2x}+1) otherwise; abs. error <= 2e-7.  A/B on the same
 // box against the rational form below (11-FMA Horner chain + one rcp): 59.0 vs 62.0 us per ppo_grad launch, 6.69 vs
 // 7.04 ms per bench iteration -- the short dependency chains of this form win although it has more instructions.
@@ -286,13 +291,6 @@ struct WoStage {
     for (int u = 0; u < MAXC; ++u)
       if (u < per) dst[j * ldo + c0 + u] = v[u];
   }
-};
-
-// per-row categorical maths on one row of logits held in LDS (z, length L), MultiDiscrete aware.
-// Matches torch.distributions.Categorical(logits=z): log_prob = z[a] - logsumexp(z); entropy = -sum p*logp.
-struct RowDist {
-  float logp;
-  float entropy;
 };
 
 }  // namespace ph
