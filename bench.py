@@ -26,7 +26,16 @@ import torch as th
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-OBS_DIM, N_ACTIONS, HORIZON = 62, 6, 400   # Overcooked-simple shapes
+# synthetic shape sets of the other BASELINE configs; the default and the headline is "overcooked"
+WORKLOADS = {
+    "overcooked": dict(obs=("box", 62), act=[6], horizon=400, n_envs=1024,
+                       name="OvercookedMultiEnv-v0 layout=simple, PPO self-play"),
+    "liar": dict(obs=("multidiscrete", [7] * 6 + [7, 12] * 12), act=[7, 12], horizon=6, n_envs=256,
+                 name="LiarsDice-v0 PPO-vs-PPO (synthetic transitions of the game's shapes)"),
+    "mpe8": dict(obs=("box", 48), act=[5], horizon=25, n_envs=1024,
+                 name="PettingZoo MPE simple_spread_v3 N=8 shapes, PPO learners"),
+    "rps": dict(obs=("multidiscrete", [1]), act=[3], horizon=1, n_envs=1024, name="RPS-v0 PPO-vs-PPO shapes"),
+}
 _T0 = time.perf_counter()
 
 
@@ -59,7 +68,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20, help="timed PPO iterations (K)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n-envs", type=int, default=1024)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="overcooked")
+    ap.add_argument("--n-envs", type=int, default=0, help="0 = the workload's BASELINE value (1024 for overcooked)")
     ap.add_argument("--n-steps", type=int, default=128)
     ap.add_argument("--n-epochs", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=0, help="0 = n_envs*n_steps/4")
@@ -79,7 +89,10 @@ def parse():
 def build_agents(args, device):
     from pantheonrl_amd import PPO, spaces as sp
     from pantheonrl_amd.vec import SyntheticRollouts, VecOnPolicyAgent
-    obs_space, act_space = sp.Box(-np.inf, np.inf, (OBS_DIM,)), sp.Discrete(N_ACTIONS)
+    wl = WORKLOADS[args.workload]
+    obs_space = sp.Box(-np.inf, np.inf, (wl["obs"][1],)) if wl["obs"][0] == "box" else (
+        sp.Discrete(wl["obs"][1][0]) if len(wl["obs"][1]) == 1 else sp.MultiDiscrete(wl["obs"][1]))
+    act_space = sp.Discrete(wl["act"][0]) if len(wl["act"]) == 1 else sp.MultiDiscrete(wl["act"])
     env = type("SpacesOnly", (), dict(observation_space=obs_space, action_space=act_space, _is_dummy_space_env=True))()
     rank = int(os.environ.get("RANK", "0"))
     agents, datas = [], []
@@ -89,7 +102,7 @@ def build_agents(args, device):
                     n_epochs=args.n_epochs, seed=seed, device=device)
         model.device_permutations = True
         agents.append(VecOnPolicyAgent(model))
-        datas.append(SyntheticRollouts(obs_space, args.n_envs, args.n_steps, HORIZON, seed % 3, device))
+        datas.append(SyntheticRollouts(obs_space, args.n_envs, args.n_steps, wl["horizon"], seed % 3, device))
     return agents, datas
 
 
@@ -102,12 +115,19 @@ def cpu_baseline(args):
     log(f"cpu_baseline: oracle on {cores} host threads (os.cpu_count()={os.cpu_count()})")
     T, E = args.n_steps, args.n_envs
     th.manual_seed(0)
-    pol = MlpPolicyOracle(SpaceSpec("box", dim=OBS_DIM), SpaceSpec("discrete", nvec=(N_ACTIONS,)))
-    buf = RolloutBufferOracle(T, E, OBS_DIM, 1)
+    wl = WORKLOADS[args.workload]
+    obs_spec = SpaceSpec("box", dim=wl["obs"][1]) if wl["obs"][0] == "box" else SpaceSpec(
+        "multidiscrete", nvec=tuple(wl["obs"][1]))
+    act_spec = SpaceSpec("discrete" if len(wl["act"]) == 1 else "multidiscrete", nvec=tuple(wl["act"]))
+    pol = MlpPolicyOracle(obs_spec, act_spec)
+    buf = RolloutBufferOracle(T, E, obs_spec.stored_len, act_spec.stored_len)
     rng = np.random.default_rng(0)
-    obs = rng.standard_normal((T, E, OBS_DIM), dtype=np.float32)
+    if obs_spec.kind == "box":
+        obs = rng.standard_normal((T, E, obs_spec.dim), dtype=np.float32)
+    else:
+        obs = (rng.random((T, E, len(obs_spec.nvec))) * np.asarray(obs_spec.nvec)).astype(np.int64).astype(np.float32)
     rew = rng.standard_normal((T, E), dtype=np.float32)
-    done = rng.random((T, E)) < 1.0 / HORIZON
+    done = rng.random((T, E)) < 1.0 / wl["horizon"]
     hp = PPOHyper(batch_size=args.batch_size, n_epochs=args.n_epochs)
     t0 = time.perf_counter()
     synthetic_iteration(pol, buf, hp, obs, rew, done)
@@ -186,6 +206,8 @@ def roofline(args, agent):
 
 def main():
     args = parse()
+    if args.n_envs <= 0:
+        args.n_envs = WORKLOADS[args.workload]["n_envs"]
     if args.batch_size <= 0:
         args.batch_size = args.n_envs * args.n_steps // 4
     from pantheonrl_amd import dist as pdist
@@ -264,13 +286,15 @@ def main():
     steps_per_iter = args.n_envs * args.n_steps * len(agents) * world
     value = steps_per_iter * args.steps / dt
     result = {
-        "metric": "env-steps/sec (all agents) Overcooked-simple PPO self-play",
+        "metric": "env-steps/sec (all agents) Overcooked-simple PPO self-play" if args.workload == "overcooked"
+                  else f"env-steps/sec (all agents) {args.workload} shapes",
         "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "OvercookedMultiEnv-v0 layout=simple, PPO self-play (two independent PPO learners per "
-                               "GPU), synthetic (n_envs, n_steps, obs_dim) rollouts",
-                   "n_envs": args.n_envs, "n_steps": args.n_steps, "obs_dim": OBS_DIM, "n_actions": N_ACTIONS,
+        "config": {"workload": WORKLOADS[args.workload]["name"] + " (two independent PPO learners per GPU), synthetic "
+                               "(n_envs, n_steps, obs_dim) rollouts",
+                   "n_envs": args.n_envs, "n_steps": args.n_steps, "obs_dim": agents[0].model.policy.layout.D,
+                   "features": agents[0].model.policy.layout.F, "n_logits": agents[0].model.policy.layout.L,
                    "batch_size": args.batch_size, "n_epochs": args.n_epochs, "agents_per_gpu": len(agents),
                    "parallelism": f"agent-per-gpu x{world} ({'per-step RCCL action all-gather' if distributed else 'single process'})",
                    "launch_mode": mode},
