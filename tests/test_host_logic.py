@@ -304,3 +304,53 @@ def test_trainer_cli_surface_and_presets():
     with pytest.raises(trainer.EnvException):
         trainer.gen_partner("DEFAULT", {"r": 1}, altenv, None, a, 0)
     assert isinstance(trainer.gen_partner("DEFAULT", {"r": 1, "p": 0, "s": 0}, RPSEnv(), None, a, 0), RPSWeightedAgent)
+
+
+def test_three_player_aec_style_game_like_the_pettingzoo_adapter():
+    """n_players = 3, one player acts per n_step (the shape of PettingZooAECWrapper.n_step, pettingzoo.py:54-103, and of
+    BASELINE config 5): ego is seat 0, partners in seats 1 and 2 are resampled at random per episode."""
+    class Ring(MultiAgentEnv):
+        """players act 0,1,2,0,1,2,...; each action pays its mover `action` and everybody else 0; 2 full rounds"""
+
+        def __init__(self):
+            super().__init__(ego_ind=0, n_players=3)
+            self.observation_space, self.action_space = Discrete(10), Discrete(5)
+            self.t = 0
+
+        def n_reset(self):
+            self.t = 0
+            return (0,), (Observation(np.array([0])),)
+
+        def n_step(self, actions):
+            mover = self.t % 3
+            rews = [0.0, 0.0, 0.0]
+            rews[mover] = float(actions[0])
+            self.t += 1
+            done = self.t >= 6
+            return ((self.t % 3,), (Observation(np.array([self.t])),), tuple(rews), done, {})
+
+    env = Ring()
+    assert env.resample_partner == env.resample_random        # "default" policy for > 2 players (multiagentenv.py:134-139)
+    a1, a2, b2 = Scripted(1), Scripted(2), Scripted(4)
+    env.add_partner_agent(a1, player_num=1)
+    env.add_partner_agent(a2, player_num=2)
+    env.add_partner_agent(b2, player_num=2)
+    np.random.seed(3)
+    seen = set()
+    for _ in range(12):
+        obs = env.reset()
+        assert obs.tolist() == [0]
+        seat2 = env.partners[1][env.partnerids[1]]
+        seen.add(env.partnerids[1])
+        a1.log.clear(); seat2.log.clear()
+        obs, rew, done, info = env.step(3)          # ego acts (t=0), then seats 1 and 2 (t=1,2)
+        assert (obs.tolist(), rew, done) == ([3], 3.0, False) and info["_partnerid"] == env.partnerids
+        # seat 1: acts on obs [1]; hand-over update(0, False); its own move's reward; then seat 2's move (reward 0)
+        assert a1.log == [("act", [1]), ("upd", 0.0, False), ("upd", 1.0, False), ("upd", 0.0, False)]
+        assert seat2.log == [("act", [2]), ("upd", 0.0, False), ("upd", float(seat2.action), False)]
+        obs, rew, done, _ = env.step(2)             # second round ends the game at t=6
+        assert done and rew == 2.0 and obs.tolist() == [3]      # D-8: previous ego observation on done
+        assert a1.log[-1] == ("upd", 0.0, True) and seat2.log[-1] == ("upd", float(seat2.action), True)
+    assert seen == {0, 1}
+    with pytest.raises(PlayerException):
+        env.set_resample_policy("robin")
