@@ -185,64 +185,63 @@ __global__ __launch_bounds__(R * 4, W2G ? 3 : 2) void ppo_grad_kernel(GradArgs a
       if (first) PH_STAMP(a.prof, 6);
 
       // ---- S4: clipped-surrogate + entropy loss per row, dL/dlogits written over OUT ----
-      if (nd.A == 1 && nd.L <= 8) {
-        // fast path (Discrete action space, <= 8 logits: every BASELINE config but Liar's Dice): FOUR lanes per row
-        // (all 4 waves busy instead of one), two logits per lane, row reductions by xor-shuffles inside the lane quad
-        const int r = tid >> 2, part = tid & 3, nk = nd.L;
-        float* z = outs + r * LDO;
-        const int phys = rowphys[r];
-        const int k0 = 2 * part, k1 = k0 + 1;
-        const float z0 = (k0 < nk) ? z[k0] : -3.0e38f, z1 = (k1 < nk) ? z[k1] : -3.0e38f;
-        float m = fmaxf(z0, z1);
-        m = fmaxf(m, __shfl_xor(m, 1, 64));
-        m = fmaxf(m, __shfl_xor(m, 2, 64));
-        float p0 = (k0 < nk) ? fast_exp(z0 - m) : 0.f, p1 = (k1 < nk) ? fast_exp(z1 - m) : 0.f;
-        float se = p0 + p1;
-        se += __shfl_xor(se, 1, 64);
-        se += __shfl_xor(se, 2, 64);
-        const float lse = m + fast_log(se), inv = __builtin_amdgcn_rcpf(se);
-        p0 *= inv;
-        p1 *= inv;
-        int act = (phys >= 0) ? (int)a.rb_act[phys] : 0;
-        act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
-        const float lp0 = z0 - lse, lp1 = z1 - lse;
-        float ent = -((k0 < nk ? p0 * lp0 : 0.f) + (k1 < nk ? p1 * lp1 : 0.f));
-        float zact = (k0 == act ? z0 : 0.f) + (k1 == act ? z1 : 0.f);
-        ent += __shfl_xor(ent, 1, 64);
-        ent += __shfl_xor(ent, 2, 64);
-        zact += __shfl_xor(zact, 1, 64);
-        zact += __shfl_xor(zact, 2, 64);
-        if (phys < 0) {
-          for (int k = part; k < Lp; k += 4) z[k] = 0.f;
-        } else {
-          const float logp = zact - lse;
-          const float adv = radv[r];
-          const float lr = logp - rold[r];
-          const float ratio = fast_exp(lr);
-          const float lo_c = 1.0f - a.clip, hi_c = 1.0f + a.clip;
-          const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
-          const float pl1 = adv * ratio, pl2 = adv * rc;
-          // torch.min backward: the smaller branch gets the gradient, ties split 1/2 + 1/2; clamp passes the
-          // gradient iff lo <= ratio <= hi.
-          const float inr = (ratio >= lo_c && ratio <= hi_c) ? 1.f : 0.f;
-          const float gate = (pl1 < pl2) ? 1.f : ((pl1 > pl2) ? inr : 0.5f + 0.5f * inr);
-          const float g_lp = -inv_nb * adv * ratio * gate;   // dL/dlogp
-          const float g_en = -a.ent_coef * inv_nb;            // dL/dH
-          if (part == 0) {
-            st[0] += -fminf(pl1, pl2);
-            st[2] += -ent;
-            st[3] += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
-            st[4] += (ratio - 1.0f) - lr;
-          }
-          if (k0 < nk) z[k0] = g_lp * ((k0 == act ? 1.f : 0.f) - p0) + g_en * (-p0 * (lp0 + ent));
-          if (k1 < nk) z[k1] = g_lp * ((k1 == act ? 1.f : 0.f) - p1) + g_en * (-p1 * (lp1 + ent));
-          for (int k = nk + part; k < Lp; k += 4) z[k] = 0.f;
-        }
-      } else if (tid < R) {
+      if (tid < R) {
         float* z = outs + tid * LDO;
         const int phys = rowphys[tid];
         if (phys < 0) {
           for (int k = 0; k < Lp; ++k) z[k] = 0.f;
+        } else if (nd.A == 1 && nd.L <= 8) {
+          // fast path (Discrete action space, <= 8 logits: every BASELINE config but Liar's Dice): the row lives in
+          // registers, one LDS read and one LDS write per logit, one exp per logit
+          const int nk = nd.L;
+          float zr[8], pr[8];
+          float m = -3.0e38f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            zr[k] = (k < nk) ? z[k] : -3.0e38f;
+            m = fmaxf(m, zr[k]);
+          }
+          float se = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            pr[k] = (k < nk) ? fast_exp(zr[k] - m) : 0.f;
+            se += pr[k];
+          }
+          const float lse = m + fast_log(se), inv = __builtin_amdgcn_rcpf(se);
+          int act = (int)a.rb_act[phys];
+          act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
+          float ent = 0.f, zact = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            pr[k] *= inv;
+            const float lp = zr[k] - lse;
+            ent -= (k < nk) ? pr[k] * lp : 0.f;
+            zact = (k == act) ? zr[k] : zact;
+          }
+          const float logp = zact - lse;
+          const float adv = radv[tid];
+          const float lr = logp - rold[tid];
+          const float ratio = fast_exp(lr);
+          const float lo_c = 1.0f - a.clip, hi_c = 1.0f + a.clip;
+          const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
+          const float pl1 = adv * ratio, pl2 = adv * rc;
+          const float inr = (ratio >= lo_c && ratio <= hi_c) ? 1.f : 0.f;
+          const float gate = (pl1 < pl2) ? 1.f : ((pl1 > pl2) ? inr : 0.5f + 0.5f * inr);
+          const float g_lp = -inv_nb * adv * ratio * gate;
+          const float g_en = -a.ent_coef * inv_nb;
+          st[0] += -fminf(pl1, pl2);
+          st[2] += -ent;
+          st[3] += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
+          st[4] += (ratio - 1.0f) - lr;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (k < nk) {
+              const float dlogp = ((k == act) ? 1.f : 0.f) - pr[k];
+              const float dent = -pr[k] * ((zr[k] - lse) + ent);
+              z[k] = g_lp * dlogp + g_en * dent;
+            }
+          }
+          for (int k = nk; k < Lp; ++k) z[k] = 0.f;
         } else {
           float logp = 0.f, ent = 0.f;
           // pass 1: log-prob and entropy (MultiDiscrete: sums over components)
