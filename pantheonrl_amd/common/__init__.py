@@ -5,3 +5,5 @@ from .agents import Agent, OnPolicyAgent, StaticPolicyAgent  # noqa: F401
 from .multiagentenv import (DummyEnv, MultiAgentEnv, PlayerException, SimultaneousEnv,  # noqa: F401
                             TurnBasedEnv)
 from .wrappers import HistoryQueue, SimultaneousFrameStack, TurnBasedFrameStack, frame_wrap  # noqa: F401,E402
+from .wrappers import SimultaneousRecorder, TurnBasedRecorder, recorder_wrap  # noqa: F401,E402
+from .trajsaver import SimultaneousTransitions, TransitionsMinimal, TurnBasedTransitions  # noqa: F401,E402

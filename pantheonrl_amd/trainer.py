@@ -5,8 +5,8 @@
 Same positional arguments and flags as the reference for the part of the surface that sits on the PPO path:
 env in {RPS-v0, LiarsDice-v0}; ego in {PPO, LOAD}; each partner in {PPO, FIXED, DEFAULT}; JSON configs splatted into
 the constructors; `--framestack`, `--preset 1`, `--ego-save/--alt-save`, `--tensorboard-log/-name`, `--seed`,
-`--device`, `--total-timesteps`.  ADAP / ModularAlgorithm / BC agents, `--record` and `--share-latent` belong to
-components outside the PPO rollout+update path and raise EnvException.
+`--device`, `--total-timesteps`.  `--record FILE` writes the episode transitions in the reference's `.npy` format.  ADAP / ModularAlgorithm / BC agents
+and `--share-latent` belong to components outside the PPO rollout+update path and raise EnvException.
 """
 from __future__ import annotations
 
@@ -16,7 +16,7 @@ from typing import List, Tuple
 
 from . import envs as _envs
 from .common import OnPolicyAgent, StaticPolicyAgent
-from .common.wrappers import frame_wrap
+from .common.wrappers import frame_wrap, recorder_wrap
 from .envs.liar import LiarDefaultAgent, LiarEnv
 from .envs.rps import RPSEnv, RPSWeightedAgent
 from .ppo import PPO
@@ -44,8 +44,8 @@ def input_check(args) -> None:
             raise EnvException(f"partners must be among {PARTNER_LIST}")
     if len(args.alt_config) != len(args.alt):
         raise EnvException("number of partners is different from number of --alt-config")
-    if args.record is not None or args.share_latent:
-        raise EnvException("--record / --share-latent belong to the recorder / ADAP components (out of scope)")
+    if args.share_latent:
+        raise EnvException("--share-latent belongs to the ADAP component (out of scope)")
     if args.framestack > 1 and args.env_config.get("framestack_incompatible", False):
         raise EnvException("this environment cannot be frame-stacked")
 
@@ -57,6 +57,8 @@ def generate_env(args) -> Tuple[object, object]:
     if args.framestack > 1:
         env = frame_wrap(env, args.framestack)
         altenv = env.getDummyEnv(1)   # the wrapped env carries the stacked observation space for both seats
+    if args.record is not None:
+        env = recorder_wrap(env)      # trainer.py:101-102
     return env, altenv
 
 
@@ -85,7 +87,9 @@ def gen_partner(kind: str, config: dict, altenv, ego, args, index: int):
     if kind == "FIXED":
         return StaticPolicyAgent(gen_load(config, config["type"], config["location"]).policy)
     if kind == "DEFAULT":
-        base = getattr(altenv, "env", altenv)
+        base = altenv
+        while hasattr(base, "env"):      # unwrap frame-stack / recorder wrappers down to the game itself
+            base = base.env
         if isinstance(base, RPSEnv):
             return RPSWeightedAgent(**config)
         if config:
@@ -170,6 +174,8 @@ def run(argv=None):
     if args.tensorboard_log:
         learn_config["tb_log_name"] = args.tensorboard_name
     ego.learn(**learn_config)
+    if args.record is not None:
+        env.get_transitions().write_transition(args.record)   # trainer.py:415-417
     if args.ego_save:
         ego.save(args.ego_save)
     if args.alt_save:
