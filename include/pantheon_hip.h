@@ -197,6 +197,22 @@ typedef struct ph_step_call {
 } ph_step_call;
 int ph_policy_step_multi(ph_ctx *ctx, int n_calls, const ph_step_call *calls /* host */);
 
+/* Ragged rollout buffers for vectorised TURN-BASED games ("per-env pos"): a partner does not act in
+ * every env at every step, so each env e has its own write row pos_env[e] (device int32, caller-owned).
+ *  ph_policy_forward_ragged: forward for all n = rb->E envs; the transition of env e is recorded at row pos_env[e] iff
+ *      record_mask[e] != 0 and pos_env[e] < rb->T; `values` (n) is only updated for recorded envs (it caches V of the
+ *      last recorded action, the bootstrap OnPolicyAgent hands to GAE -- agents.py:127-130,183).
+ *  ph_buffer_add_reward_ragged: rewards[pos_env[e]-1][e] += reward[e] for env_mask[e] != 0 with pos_env[e] >= 1.
+ *  ph_ragged_advance: pos_env[e] += 1 for record_mask[e] != 0 while pos_env[e] < rb->T (call after the forward). */
+int ph_policy_forward_ragged(ph_ctx *ctx, const ph_spec *spec, const float *params, const float *obs,
+                             const unsigned char *action_mask, unsigned long long seed, unsigned long long counter,
+                             int deterministic, int *actions_i32, float *values, float *log_probs,
+                             const ph_rollout *rb, const int *pos_env, const unsigned char *record_mask,
+                             const float *episode_start_in);
+int ph_buffer_add_reward_ragged(ph_ctx *ctx, const ph_rollout *rb, const int *pos_env, const float *reward,
+                                const unsigned char *env_mask);
+int ph_ragged_advance(ph_ctx *ctx, const ph_rollout *rb, int *pos_env, const unsigned char *record_mask);
+
 /* env-side illegal-action fix-up: action not legal -> first legal index <- pettingzoo.py:81-82.  Integer, bit-exact. */
 int ph_fix_illegal_actions(ph_ctx *ctx, int *actions /* (n) in/out */, const unsigned char *action_mask /* (n,L) */,
                            int n, int L);
@@ -212,6 +228,16 @@ int ph_rps_step(ph_ctx *ctx, const int *ego_actions, const int *alt_actions, flo
 int ph_liar_step(ph_ctx *ctx, const int *hands, int *history, int *nmoves, const int *actions,
                  const unsigned char *is_ego, const unsigned char *active, float *obs_next, float *rewards,
                  unsigned char *done, int n);
+
+/* LiarEnv.multi_reset <- liar.py:96-102 for every env with reset_mask[e] != 0 (NULL = all): dice from Philox4x32-10
+ * keyed (seed, counter, env, die), empty history; ego_first (n) u8 <- first mover ~ Bernoulli(probegostart)
+ * (TurnBasedEnv.n_reset, multiagentenv.py:323-326). */
+int ph_liar_reset(ph_ctx *ctx, int *hands, int *history, int *nmoves, const unsigned char *reset_mask,
+                  unsigned char *ego_first, unsigned long long seed, unsigned long long counter, float probegostart,
+                  int n);
+/* LiarEnv.getObs(isego) <- liar.py:53-56: observation (n,30) f32 of the player is_ego[e] selects, active envs only */
+int ph_liar_obs(ph_ctx *ctx, const int *hands, const int *history, const int *nmoves, const unsigned char *is_ego,
+                const unsigned char *active, float *obs_out, int n);
 
 /* Frame stack as a device ring buffer <- HistoryQueue.add / reset, wrappers.py:37-71, applied to
  * n environments: stack (n, numframes*D) f32 holds the last numframes observations NEWEST FIRST; for envs with

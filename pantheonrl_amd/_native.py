@@ -90,9 +90,15 @@ SIGNATURES = {
     "ph_policy_forward": [_vp, C.POINTER(PhSpec), _vp, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, _vp, _vp,
                           _vp, C.POINTER(PhRollout), _i, _vp, _vp, _i],
     "ph_policy_step_multi": [_vp, _i, C.POINTER(PhStepCall)],
+    "ph_policy_forward_ragged": [_vp, C.POINTER(PhSpec), _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, C.POINTER(PhRollout),
+                                 _vp, _vp, _vp],
+    "ph_buffer_add_reward_ragged": [_vp, C.POINTER(PhRollout), _vp, _vp, _vp],
+    "ph_ragged_advance": [_vp, C.POINTER(PhRollout), _vp, _vp],
     "ph_fix_illegal_actions": [_vp, _vp, _vp, _i, _i],
     "ph_rps_step": [_vp, _vp, _vp, _vp, _vp, _i],
     "ph_liar_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
+    "ph_liar_reset": [_vp, _vp, _vp, _vp, _vp, _vp, _ull, _ull, C.c_float, _i],
+    "ph_liar_obs": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "ph_framestack_push": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "ph_ppo_train": [_vp, C.POINTER(PhSpec), C.POINTER(PhOptState), C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i,
                      _vp, _ull, _vp, _i],

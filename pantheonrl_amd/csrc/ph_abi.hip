@@ -480,6 +480,61 @@ int ph_policy_step_multi(ph_ctx* ctx, int n_calls, const ph_step_call* calls) {
   return 0;
 }
 
+int ph_policy_forward_ragged(ph_ctx* ctx, const ph_spec* spec, const float* params, const float* obs,
+                             const unsigned char* action_mask, unsigned long long seed, unsigned long long counter,
+                             int deterministic, int* actions_i32, float* values, float* log_probs, const ph_rollout* rb,
+                             const int* pos_env, const unsigned char* record_mask, const float* episode_start_in) {
+  if (!ctx) return fail("null ctx");
+  if (!params || !obs || !pos_env || !record_mask || !episode_start_in)
+    return fail("ph_policy_forward_ragged: null argument");
+  if ((uintptr_t)params % 16 != 0) return fail("ph_policy_forward_ragged: params must be 16-byte aligned");
+  if (check_rb(rb)) return 1;
+  ph::FwdArgs a;
+  std::memset(&a, 0, sizeof(a));
+  if (resolve(ctx, spec, &a.nd)) return 1;
+  a.params = params;
+  a.obs = obs;
+  a.n = rb->E;
+  a.mask = action_mask;
+  a.seed = seed;
+  a.counter = counter;
+  a.epoch = ctx->rng_epoch;
+  a.prof = ctx->prof;
+  a.deterministic = deterministic;
+  a.act_i32 = actions_i32;
+  a.values = values;
+  a.logp = log_probs;
+  a.rb_obs = rb->observations;  // array bases: rows are selected per env
+  a.rb_act = rb->actions;
+  a.rb_rew = rb->rewards;
+  a.rb_es = rb->episode_starts;
+  a.rb_val = rb->values;
+  a.rb_logp = rb->log_probs;
+  a.es_in = episode_start_in;
+  a.pos_env = pos_env;
+  a.rec_mask = record_mask;
+  a.rb_T = rb->T;
+  PH_HIP(ph::launch_policy_fwd(a, 0, ctx->stream));
+  return 0;
+}
+
+int ph_buffer_add_reward_ragged(ph_ctx* ctx, const ph_rollout* rb, const int* pos_env, const float* reward,
+                                const unsigned char* env_mask) {
+  if (!ctx) return fail("null ctx");
+  if (check_rb(rb)) return 1;
+  if (!pos_env || !reward) return fail("ph_buffer_add_reward_ragged: null argument");
+  PH_HIP(ph::launch_reward_add_ragged(rb->rewards, pos_env, reward, env_mask, rb->T, rb->E, ctx->stream));
+  return 0;
+}
+
+int ph_ragged_advance(ph_ctx* ctx, const ph_rollout* rb, int* pos_env, const unsigned char* record_mask) {
+  if (!ctx) return fail("null ctx");
+  if (check_rb(rb)) return 1;
+  if (!pos_env || !record_mask) return fail("ph_ragged_advance: null argument");
+  PH_HIP(ph::launch_ragged_advance(pos_env, record_mask, rb->T, rb->E, ctx->stream));
+  return 0;
+}
+
 int ph_fix_illegal_actions(ph_ctx* ctx, int* actions, const unsigned char* action_mask, int n, int L) {
   if (!ctx) return fail("null ctx");
   if (!actions || !action_mask) return fail("ph_fix_illegal_actions: null argument");
@@ -505,6 +560,25 @@ int ph_liar_step(ph_ctx* ctx, const int* hands, int* history, int* nmoves, const
     return fail("ph_liar_step: null argument");
   if (n <= 0) return fail("ph_liar_step: n must be positive");
   PH_HIP(ph::launch_liar_step(hands, history, nmoves, actions, is_ego, active, obs_next, rewards, done, n, ctx->stream));
+  return 0;
+}
+
+int ph_liar_reset(ph_ctx* ctx, int* hands, int* history, int* nmoves, const unsigned char* reset_mask,
+                  unsigned char* ego_first, unsigned long long seed, unsigned long long counter, float probegostart,
+                  int n) {
+  if (!ctx) return fail("null ctx");
+  if (!hands || !history || !nmoves || !ego_first) return fail("ph_liar_reset: null argument");
+  if (n <= 0) return fail("ph_liar_reset: n must be positive");
+  PH_HIP(ph::launch_liar_reset(hands, history, nmoves, reset_mask, ego_first, seed, counter, probegostart, n, ctx->stream));
+  return 0;
+}
+
+int ph_liar_obs(ph_ctx* ctx, const int* hands, const int* history, const int* nmoves, const unsigned char* is_ego,
+                const unsigned char* active, float* obs_out, int n) {
+  if (!ctx) return fail("null ctx");
+  if (!hands || !history || !nmoves || !is_ego || !obs_out) return fail("ph_liar_obs: null argument");
+  if (n <= 0) return fail("ph_liar_obs: n must be positive");
+  PH_HIP(ph::launch_liar_obs(hands, history, nmoves, is_ego, active, obs_out, n, ctx->stream));
   return 0;
 }
 

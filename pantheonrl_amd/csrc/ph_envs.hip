@@ -88,6 +88,58 @@ hipError_t launch_liar_step(const int* hands, int* history, int* nmoves, const i
   return hipGetLastError();
 }
 
+// LiarEnv.getObs(isego) without a move: the observation of the requested player in every active env
+__global__ void liar_obs_kernel(const int* __restrict__ hands, const int* __restrict__ history,
+                                const int* __restrict__ nmoves, const unsigned char* __restrict__ is_ego,
+                                const unsigned char* __restrict__ active, float* __restrict__ obs_out, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  if (active && !active[e]) return;
+  const int* hand = hands + (size_t)e * 12 + (is_ego[e] ? 0 : 6);
+  const int* hist = history + (size_t)e * 24;
+  const int nm = nmoves[e];
+  float* o = obs_out + (size_t)e * 30;
+  for (int k = 0; k < 6; ++k) o[k] = (float)hand[k];
+  for (int m = 0; m < LD_MAXMOVES; ++m) {
+    o[6 + 2 * m] = (float)(m < nm ? hist[2 * m] : LD_SIDES);
+    o[7 + 2 * m] = (float)(m < nm ? hist[2 * m + 1] : 0);
+  }
+}
+hipError_t launch_liar_obs(const int* hands, const int* history, const int* nmoves, const unsigned char* is_ego,
+                           const unsigned char* active, float* obs_out, int n, hipStream_t s) {
+  hipLaunchKernelGGL(liar_obs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, hands, history, nmoves, is_ego, active,
+                     obs_out, n);
+  return hipGetLastError();
+}
+
+// LiarEnv.multi_reset for every env with reset_mask[e] != 0: N_DICE dice per player from Philox4x32-10 (one draw per
+// die, like the reference's randint per die), empty history, first mover ~ Bernoulli(probegostart)
+__global__ void liar_reset_kernel(int* __restrict__ hands, int* __restrict__ history, int* __restrict__ nmoves,
+                                  const unsigned char* __restrict__ reset_mask, unsigned char* __restrict__ ego_first,
+                                  uint64_t seed, uint64_t counter, float probegostart, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  if (reset_mask && !reset_mask[e]) return;
+  int* hand = hands + (size_t)e * 12;
+  for (int k = 0; k < 12; ++k) hand[k] = 0;
+  for (int die = 0; die < 2 * LD_DICE; ++die) {
+    const float u = philox_uniform(seed, counter, (uint32_t)e, (uint32_t)die);
+    int side = (int)(u * LD_SIDES);
+    side = side >= LD_SIDES ? LD_SIDES - 1 : side;
+    hand[(die < LD_DICE ? 0 : 6) + side] += 1;
+  }
+  for (int k = 0; k < 24; ++k) history[(size_t)e * 24 + k] = 0;
+  nmoves[e] = 0;
+  ego_first[e] = philox_uniform(seed, counter, (uint32_t)e, 100u) < probegostart ? 1 : 0;
+}
+hipError_t launch_liar_reset(int* hands, int* history, int* nmoves, const unsigned char* reset_mask,
+                             unsigned char* ego_first, unsigned long long seed, unsigned long long counter,
+                             float probegostart, int n, hipStream_t s) {
+  hipLaunchKernelGGL(liar_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, s, hands, history, nmoves, reset_mask,
+                     ego_first, seed, counter, probegostart, n);
+  return hipGetLastError();
+}
+
 // HistoryQueue for n envs: one lane per (env, feature) walks its column of frames from the oldest to the newest
 __global__ void framestack_push_kernel(float* __restrict__ stack, const float* __restrict__ obs,
                                        const unsigned char* __restrict__ reset_mask,

@@ -234,6 +234,32 @@ hipError_t launch_reward_add(float* rew_row, const float* reward, const unsigned
   return hipGetLastError();
 }
 
+// ragged (per-env write position) forms of Agent.update and of the position advance after a recorded action
+__global__ void reward_add_ragged_kernel(float* __restrict__ rewards, const int* __restrict__ pos_env,
+                                         const float* __restrict__ reward, const unsigned char* __restrict__ mask, int T,
+                                         int E) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  if (mask && !mask[e]) return;
+  const int p = pos_env[e];
+  if (p < 1 || p > T) return;   // nothing recorded yet in this column
+  rewards[(size_t)(p - 1) * E + e] += reward[e];
+}
+hipError_t launch_reward_add_ragged(float* rewards, const int* pos_env, const float* reward, const unsigned char* mask,
+                                    int T, int E, hipStream_t s) {
+  hipLaunchKernelGGL(reward_add_ragged_kernel, dim3((E + 255) / 256), dim3(256), 0, s, rewards, pos_env, reward, mask, T, E);
+  return hipGetLastError();
+}
+__global__ void ragged_advance_kernel(int* __restrict__ pos_env, const unsigned char* __restrict__ mask, int T, int E) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  if (mask[e] && pos_env[e] < T) pos_env[e] += 1;
+}
+hipError_t launch_ragged_advance(int* pos_env, const unsigned char* mask, int T, int E, hipStream_t s) {
+  hipLaunchKernelGGL(ragged_advance_kernel, dim3((E + 255) / 256), dim3(256), 0, s, pos_env, mask, T, E);
+  return hipGetLastError();
+}
+
 __global__ void reward_add_joint_kernel(float* __restrict__ rew_row, const float* __restrict__ base,
                                         const int* __restrict__ joint, int E, int n_seats, int seat,
                                         const int* __restrict__ partner_seat, float bonus) {

@@ -32,6 +32,9 @@ struct FwdArgs {
   long long* prof;              // debug: per-workgroup phase timestamps (clock64), or null
   float* prev_rew;              // rewards row pos-1, or null
   const float* pending_reward;  // (E) added to prev_rew (Agent.update folded into the next step's launch)
+  const int* pos_env;           // ragged mode: per-env write row (device), rb_* are array bases; null = rectangular
+  const unsigned char* rec_mask;  // ragged mode: which envs record this action
+  int rb_T;
   const int* joint;             // (n_seats, n) all-gathered actions of the previous step, or null
   int n_seats, seat;
   const int* partner_seat;      // device int
@@ -134,6 +137,14 @@ hipError_t launch_gae(const float* rew, const float* val, const float* es, const
 hipError_t launch_buffer_add(float* d_obs, float* d_act, float* d_rew, float* d_es, float* d_val, float* d_lp,
                              const float* obs, const float* act, const float* es, const float* val, const float* lp,
                              int E, int D, int A, hipStream_t s);
+hipError_t launch_reward_add_ragged(float* rewards, const int* pos_env, const float* reward, const unsigned char* mask,
+                                    int T, int E, hipStream_t s);
+hipError_t launch_ragged_advance(int* pos_env, const unsigned char* mask, int T, int E, hipStream_t s);
+hipError_t launch_liar_obs(const int* hands, const int* history, const int* nmoves, const unsigned char* is_ego,
+                           const unsigned char* active, float* obs_out, int n, hipStream_t s);
+hipError_t launch_liar_reset(int* hands, int* history, int* nmoves, const unsigned char* reset_mask,
+                             unsigned char* ego_first, unsigned long long seed, unsigned long long counter,
+                             float probegostart, int n, hipStream_t s);
 hipError_t launch_reward_add(float* rew_row, const float* reward, const unsigned char* env_mask, int E, hipStream_t s);
 hipError_t launch_reward_add_joint(float* rew_row, const float* base, const int* joint, int E, int n_seats, int seat,
                                    const int* partner_seat, float bonus, hipStream_t s);

@@ -11,6 +11,16 @@
 namespace ph {
 
 
+// Row of the rollout buffer that env g's transition goes to, or -1 when it is not recorded.  Rectangular mode: the
+// caller pre-offset the rb_* pointers to row `pos`, so the index is g.  Ragged mode (turn-based games: every env has
+// its own write position, SURVEY.md 8e "per-env pos"): rb_* are the array bases and the row is pos_env[g].
+__device__ __forceinline__ long long rb_row(const FwdArgs& a, int g) {
+  if (!a.pos_env) return g;
+  const int p = a.pos_env[g];
+  if (!a.rec_mask[g] || p >= a.rb_T) return -1;
+  return (long long)p * a.n + g;
+}
+
 template <int R, int LP, bool VALU>
 __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -113,11 +123,12 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
       for (int j = 0; j < HID; ++j) v = __builtin_fmaf(bufA[tid * LDH + j], bos[j], v);
       v += a.params[lay.val_b];
       const int g = row0 + tid;
-      if (a.values) a.values[g] = v;
-      if (a.rb_val) {
-        a.rb_val[g] = v;
-        a.rb_rew[g] = 0.f;
-        a.rb_es[g] = a.es_in[g];
+      const long long ridx = a.rb_val ? rb_row(a, g) : -1;
+      if (a.values && (!a.pos_env || ridx >= 0)) a.values[g] = v;  // ragged: V of the last RECORDED action is cached
+      if (ridx >= 0) {
+        a.rb_val[ridx] = v;
+        a.rb_rew[ridx] = 0.f;
+        a.rb_es[ridx] = a.es_in[g];
         if (a.pending_reward) {
           float add = a.pending_reward[g];
           if (a.joint) {  // shared coordination term of the synthetic SimultaneousEnv transition (joint action)
@@ -131,8 +142,16 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
     }
     if (a.rb_obs) {  // RolloutBuffer.add copies the observation (agents.py:172-173)
       const int nrow = (a.n - row0 < R) ? a.n - row0 : R;
-      const size_t off = (size_t)row0 * nd.D;
-      for (int e = tid; e < nrow * nd.D; e += blockDim.x) a.rb_obs[off + e] = a.obs[off + e];
+      if (!a.pos_env) {
+        const size_t off = (size_t)row0 * nd.D;
+        for (int e = tid; e < nrow * nd.D; e += blockDim.x) a.rb_obs[off + e] = a.obs[off + e];
+      } else {
+        for (int e = tid; e < nrow * nd.D; e += blockDim.x) {
+          const int r = e / nd.D, d = e - r * nd.D;
+          const long long ridx = rb_row(a, row0 + r);
+          if (ridx >= 0) a.rb_obs[(size_t)ridx * nd.D + d] = a.obs[(size_t)(row0 + r) * nd.D + d];
+        }
+      }
     }
     PH_STAMP(a.prof, 7);
     return;
@@ -211,7 +230,10 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
       logp = zact - lse;
       if (a.act_i32) a.act_i32[g] = act;
       if (a.act_f32) a.act_f32[g] = (float)act;
-      if (a.rb_act) a.rb_act[g] = (float)act;
+      if (a.rb_act) {
+        const long long ridx = rb_row(a, g);
+        if (ridx >= 0) a.rb_act[ridx] = (float)act;
+      }
     } else
     for (int c = 0; c < nd.A; ++c) {
       const int lo = nd.act_off[c], nk = nd.act_off[c + 1] - lo;
@@ -248,11 +270,17 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
       ent += e;
       if (a.act_i32) a.act_i32[(size_t)g * nd.A + c] = act;
       if (a.act_f32) a.act_f32[(size_t)g * nd.A + c] = (float)act;
-      if (a.rb_act) a.rb_act[(size_t)g * nd.A + c] = (float)act;
+      if (a.rb_act) {
+        const long long ridx = rb_row(a, g);
+        if (ridx >= 0) a.rb_act[(size_t)ridx * nd.A + c] = (float)act;
+      }
     }
     if (a.logp) a.logp[g] = logp;
     if (a.entropy) a.entropy[g] = ent;
-    if (a.rb_logp) a.rb_logp[g] = logp;
+    if (a.rb_logp) {
+      const long long ridx = rb_row(a, g);
+      if (ridx >= 0) a.rb_logp[ridx] = logp;
+    }
   }
   PH_STAMP(a.prof, 7);
 }

@@ -11,6 +11,8 @@ of the reference's step loop (multiagentenv.py:149-170) applied to E-long device
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 import torch as th
 
@@ -81,3 +83,177 @@ class VecLiarsDice:
                                             nat.ptr(active), self.obs_next.data_ptr(), self.rewards.data_ptr(),
                                             self.done.data_ptr(), self.E))
         return self.obs_next, self.rewards, self.done
+
+
+class RaggedVecOnPolicyAgent:
+    """OnPolicyAgent for the PARTNER seat of a vectorised turn-based game.
+
+    In a turn-based game the partner does not act in every environment at every vectorised step (a game may end on the
+    ego's move, a new game may start with either player), so its rollout buffer cannot advance one row per step.  Each
+    environment e owns column e of the (T, E) buffer and its own write row `pos[e]`; the learner trains
+    when every column is full, which is the E-environment reading of "train before acting once the buffer is full"
+    (agents.py:126).  Per environment the callbacks keep the reference's semantics:
+      * a recorded action opens its row for late additive rewards until the agent is asked to act again (agents.py:198),
+      * `episode_start` of a row = an episode ended since the previous recorded row (agents.py:176,197),
+      * GAE bootstraps with V of the last recorded observation and dones = "the game ended before the next action"
+        (agents.py:127-130, quirk D-1).
+    """
+
+    def __init__(self, model):
+        self.model = model
+        pol, rb = model.policy, model.rollout_buffer
+        E, lay, dev = rb.n_envs, pol.layout, pol.device
+        self.E, self.T = E, rb.buffer_size
+        u8 = lambda v: th.full((E,), v, dtype=th.uint8, device=dev)  # noqa: E731
+        self.pos = th.zeros(E, dtype=th.int32, device=dev)
+        self.actions = th.zeros((E, lay.A), dtype=th.int32, device=dev)
+        self.values = th.zeros(E, dtype=th.float32, device=dev)
+        self.log_probs = th.zeros(E, dtype=th.float32, device=dev)
+        self.boundary, self.term, self.open = u8(1), u8(0), u8(0)
+        self.iteration = 0
+        self.num_timesteps = 0
+        self._lib, self._h = pol.ctx.lib, pol.ctx.handle
+        self._spec, self._rb = C.byref(pol.spec), C.byref(rb.c_struct())
+
+    def get_action(self, obs: th.Tensor, rec_mask: th.Tensor) -> th.Tensor:
+        """forward in every env; record the transition where rec_mask is set and the column still has room"""
+        pol = self.model.policy
+        pol._bind()
+        room = self.pos < self.T
+        can = (rec_mask.bool() & room).to(th.uint8)
+        blocked = rec_mask.bool() & ~room
+        es = self.boundary.to(th.float32)
+        pol._counter += 1
+        nat.check(self._lib.ph_policy_forward_ragged(
+            self._h, self._spec, pol.params.data_ptr(), obs.data_ptr(), None, pol._seed, pol._counter, 0,
+            self.actions.data_ptr(), self.values.data_ptr(), self.log_probs.data_ptr(), self._rb, self.pos.data_ptr(),
+            can.data_ptr(), es.data_ptr()))
+        nat.check(self._lib.ph_ragged_advance(self._h, self._rb, self.pos.data_ptr(), can.data_ptr()))
+        canb = can.bool()
+        self.boundary = th.where(canb, th.zeros_like(self.boundary), self.boundary)
+        self.term = th.where(canb, th.zeros_like(self.term), self.term)
+        self.open = th.where(canb, th.ones_like(self.open), th.where(blocked, th.zeros_like(self.open), self.open))
+        self.num_timesteps += int(self.E)
+        return self.actions
+
+    def update(self, reward: th.Tensor, done: th.Tensor, mask: th.Tensor) -> None:
+        """credit `reward` to the last recorded action of the envs in `mask` (whose rows are still open); remember the
+        episode boundaries"""
+        self.model.policy._bind()
+        m = (mask.bool() & self.open.bool())
+        m8 = m.to(th.uint8)
+        nat.check(self._lib.ph_buffer_add_reward_ragged(self._h, self._rb, self.pos.data_ptr(), reward.data_ptr(),
+                                                        m8.data_ptr()))
+        d = done.bool()
+        self.boundary = (self.boundary.bool() | d).to(th.uint8)
+        self.term = (self.term.bool() | (m & d)).to(th.uint8)
+
+    def full(self) -> bool:
+        return bool((self.pos >= self.T).all().item())
+
+    def learn_from_buffer(self) -> None:
+        model, rb = self.model, self.model.rollout_buffer
+        model.policy._bind()
+        dones = self.term.to(th.float32)
+        nat.check(self._lib.ph_gae(self._h, self._rb, self.values.data_ptr(), dones.data_ptr(), rb.gamma, rb.gae_lambda,
+                                   int(rb.gae_mode)))
+        rb.pos, rb.full = rb.buffer_size, True
+        model.train(sync_stats=False)
+        rb.pos, rb.full = 0, False
+        self.pos.zero_()
+        self.open.zero_()
+        self.term.zero_()
+        self.iteration += 1
+
+
+class VecLiarSelfPlay:
+    """`trainer.py LiarsDice-v0 PPO PPO` (BASELINE config 2) with n_envs tables resident on the device.
+
+    One vectorised step is one `MultiAgentEnv.step` of every table from the ego's point of view (multiagentenv.py:
+    172-215): the ego moves, the partner replies in the tables that are still running, finished tables are re-dealt and --
+    where the partner opens the new game -- the partner moves once more, so every table is back at the ego's turn.
+    The ego is a rectangular VecOnPolicyAgent (one row per table per step); the partner is ragged."""
+
+    def __init__(self, n_envs: int, ego: VecOnPolicyAgent, alt: RaggedVecOnPolicyAgent, seed: int = 0,
+                 probegostart: float = 0.5):
+        self.E, self.ego, self.alt = n_envs, ego, alt
+        pol = ego.model.policy
+        self.dev = pol.device
+        self.env = VecLiarsDice(n_envs, pol.ctx, self.dev)
+        self.seed, self.counter, self.probegostart = int(seed), 0, float(probegostart)
+        E, dev = n_envs, self.dev
+        self.ego_first = th.zeros(E, dtype=th.uint8, device=dev)
+        self.obs_ego = th.zeros((E, 30), dtype=th.float32, device=dev)
+        self.obs_alt = th.zeros((E, 30), dtype=th.float32, device=dev)
+        self.alt_acted = th.zeros(E, dtype=th.uint8, device=dev)   # should_update of the partner seat, per table
+        self.ones8 = th.ones(E, dtype=th.uint8, device=dev)
+        self.zeros8 = th.zeros(E, dtype=th.uint8, device=dev)
+        self.episodes = 0
+        self._deal(self.ones8)
+
+    # -- helpers -----------------------------------------------------------------------------------------------------
+    def _bind(self):
+        self.env.ctx.set_stream(th.cuda.current_stream(self.dev).cuda_stream)
+
+    def _deal(self, reset_mask: th.Tensor) -> None:
+        """re-deal the tables in reset_mask; where the partner opens, it moves once (that move cannot end the game)"""
+        env, lib, h = self.env, self.env.ctx.lib, self.env.ctx.handle
+        self._bind()
+        self.counter += 1
+        nat.check(lib.ph_liar_reset(h, env.hands.data_ptr(), env.history.data_ptr(), env.nmoves.data_ptr(),
+                                    reset_mask.data_ptr(), self.ego_first.data_ptr(), self.seed, self.counter,
+                                    self.probegostart, self.E))
+        rm = reset_mask.bool()
+        self.alt_acted = th.where(rm, self.zeros8, self.alt_acted)
+        alt_opens = (rm & ~self.ego_first.bool()).to(th.uint8)
+        # partner's opening observation and move
+        nat.check(lib.ph_liar_obs(h, env.hands.data_ptr(), env.history.data_ptr(), env.nmoves.data_ptr(),
+                                  self.zeros8.data_ptr(), alt_opens.data_ptr(), self.obs_alt.data_ptr(), self.E))
+        if bool(alt_opens.any().item()):
+            a_alt = self.alt.get_action(self.obs_alt, alt_opens)
+            self.alt_acted = (self.alt_acted.bool() | alt_opens.bool()).to(th.uint8)
+            env.player_step(a_alt, self.zeros8, alt_opens)          # obs_next = ego's observation in those tables
+            self.obs_ego = th.where(alt_opens.bool()[:, None], env.obs_next, self.obs_ego)
+        ego_opens = (rm & self.ego_first.bool()).to(th.uint8)
+        tmp = th.zeros_like(self.obs_ego)
+        nat.check(lib.ph_liar_obs(h, env.hands.data_ptr(), env.history.data_ptr(), env.nmoves.data_ptr(),
+                                  self.ones8.data_ptr(), ego_opens.data_ptr(), tmp.data_ptr(), self.E))
+        self.obs_ego = th.where(ego_opens.bool()[:, None], tmp, self.obs_ego)
+
+    # -- one vectorised MultiAgentEnv.step ---------------------------------------------------------------------------------
+    def step(self):
+        env, ego, alt = self.env, self.ego, self.alt
+        self._bind()
+        a_ego = ego.get_action(self.obs_ego)                                   # every table is at the ego's turn
+        obs_alt, rew1, done1 = env.player_step(a_ego, self.ones8, None)
+        rew1, done1 = rew1.clone(), done1.clone()
+        running = (~done1.bool()).to(th.uint8)
+        # partners that already acted this game are credited this transition (multiagentenv.py:163-170)
+        alt.update(rew1[:, 1].contiguous(), done1, self.alt_acted)
+        self.obs_alt = th.where(running.bool()[:, None], obs_alt, self.obs_alt)
+        # partner replies where the game goes on
+        a_alt = alt.get_action(self.obs_alt, running)
+        self.alt_acted = (self.alt_acted.bool() | running.bool()).to(th.uint8)
+        obs_ego, rew2, done2 = env.player_step(a_alt, self.zeros8, running)
+        rew2 = th.where(running.bool()[:, None], rew2, th.zeros_like(rew2))
+        done2 = (done2.bool() & running.bool())
+        alt.update(rew2[:, 1].contiguous(), done2.to(th.uint8), running)
+        done = done1.bool() | done2
+        # the ego collects both transitions of the step; the last done wins (agents.py:44-47)
+        ego.update((rew1[:, 0] + rew2[:, 0]).contiguous(), done.to(th.float32))
+        ego.flush_rewards()
+        self.obs_ego = th.where((running.bool() & ~done2)[:, None], obs_ego, self.obs_ego)
+        done8 = done.to(th.uint8)
+        n_done = int(done8.sum().item())
+        if n_done:
+            self.episodes += n_done
+            self._deal(done8)
+        return done8
+
+    def rollout_and_learn(self, n_steps: int) -> None:
+        """n_steps vectorised steps, the ego's update, and the partner's whenever all its columns are full"""
+        for _ in range(n_steps):
+            self.step()
+        self.ego.learn_from_buffer()
+        if self.alt.full():
+            self.alt.learn_from_buffer()

@@ -153,7 +153,60 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--tensorboard-name")
     p.add_argument("--verbose-partner", action="store_true")
     p.add_argument("--preset", type=int)
+    p.add_argument("--n-envs", type=int, default=1,
+                   help="(extension) >1: E copies of the game resident on the device, PPO-vs-PPO self-play without the "
+                        "host in the step loop")
     return p
+
+
+def run_vectorised(args):
+    """`<env> PPO PPO --n-envs E`: the reference's object graph with every table on the device.
+    total_timesteps counts ego transitions over all tables, as SB3 does for a VecEnv."""
+    import torch as th
+
+    from .envs.vec import RaggedVecOnPolicyAgent, VecLiarsDice, VecLiarSelfPlay, VecRPS, selfplay_iteration
+    from .vec import VecOnPolicyAgent
+    if args.ego != "PPO" or list(args.alt) != ["PPO"]:
+        raise EnvException("--n-envs supports the PPO-vs-PPO self-play pairing")
+    if args.framestack > 1 or args.record is not None:
+        raise EnvException("--n-envs cannot be combined with --framestack / --record")
+    game = {"RPS-v0": VecRPS, "LiarsDice-v0": VecLiarsDice}.get(args.env)
+    if game is None:
+        raise EnvException(f"no device-resident form of {args.env}")
+    E = int(args.n_envs)
+    spaces = type("Spaces", (), dict(observation_space=game.observation_space, action_space=game.action_space,
+                                     _is_dummy_space_env=True))()
+    models = []
+    for offset, config in enumerate((dict(args.ego_config), dict(args.alt_config[0]))):
+        config.setdefault("n_steps", 128)
+        config.setdefault("batch_size", max(64, E * config["n_steps"] // 4))
+        config.update(env=spaces, device=args.device, n_envs=E)
+        if args.seed is not None:
+            config["seed"] = args.seed + offset
+        model = PPO(policy="MlpPolicy", **config)
+        model.device_permutations = True
+        models.append(model)
+    ego = VecOnPolicyAgent(models[0])
+    n_steps = models[0].n_steps
+    iterations = max(1, -(-args.total_timesteps // (E * n_steps)))
+    if args.env == "RPS-v0":
+        alt = VecOnPolicyAgent(models[1])
+        env = VecRPS(E, models[0].policy.ctx, models[0].device)
+        for _ in range(iterations):
+            selfplay_iteration(env, ego, alt, n_steps)
+    else:
+        alt = RaggedVecOnPolicyAgent(models[1])
+        env = VecLiarSelfPlay(E, ego, alt, seed=args.seed or 0, **args.env_config)
+        for _ in range(iterations):
+            env.rollout_and_learn(n_steps)
+    th.cuda.synchronize()
+    print(f"vectorised self-play: {iterations} iterations x {E} envs x {n_steps} steps; "
+          f"ego updates {ego.iteration}, partner updates {alt.iteration}")
+    if args.ego_save:
+        models[0].save(args.ego_save)
+    if args.alt_save:
+        models[1].save(args.alt_save)
+    return models[0], [alt], env
 
 
 def run(argv=None):
@@ -165,6 +218,8 @@ def run(argv=None):
     if args.preset:
         args = preset(args, args.preset)
     print(f"Arguments: {args}")
+    if args.n_envs > 1:
+        return run_vectorised(args)
     env, altenv = generate_env(args)
     print(f"Environment: {env}; Partner env: {altenv}")
     ego = generate_ego(env, args)

@@ -820,3 +820,161 @@ def test_device_reproduces_committed_golden_vectors():
     model.train(perms=s["perms"])
     np.testing.assert_allclose(model.last_train_stats[:, :7], s["stats"], atol=2e-4, rtol=2e-3)
     assert np.abs(model.policy.get_flat_params() - s["params1"]).max() <= 1.5e-5
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# vectorised turn-based self-play (BASELINE config 2: LiarsDice-v0 PPO PPO) with a ragged partner buffer
+# ----------------------------------------------------------------------------------------------------------------
+def _liar_selfplay(E, T_ego, T_alt, seed=0):
+    from pantheonrl_amd import PPO
+    from pantheonrl_amd.envs.vec import RaggedVecOnPolicyAgent, VecLiarsDice, VecLiarSelfPlay
+    from pantheonrl_amd.vec import VecOnPolicyAgent
+    spaces = type("S", (), dict(observation_space=VecLiarsDice.observation_space,
+                                action_space=VecLiarsDice.action_space, _is_dummy_space_env=True))()
+    me = PPO("MlpPolicy", spaces, n_steps=T_ego, n_envs=E, batch_size=E * T_ego // 2, n_epochs=2, seed=seed)
+    ma = PPO("MlpPolicy", spaces, n_steps=T_alt, n_envs=E, batch_size=E * T_alt // 2, n_epochs=2, seed=seed + 1)
+    me.device_permutations = ma.device_permutations = True
+    ego, alt = VecOnPolicyAgent(me), RaggedVecOnPolicyAgent(ma)
+    calls = []
+    inner = alt.get_action
+
+    def logged(obs, rec_mask):
+        acts = inner(obs, rec_mask)
+        calls.append((acts.cpu().numpy().copy(), rec_mask.cpu().numpy().astype(bool)))
+        return acts
+    alt.get_action = logged
+    return VecLiarSelfPlay(E, ego, alt, seed=seed + 7), ego, alt, calls
+
+
+def test_vec_liars_dice_selfplay_matches_the_python_step_loop():
+    """Every table of the device self-play is replayed through the Python MultiAgentEnv step loop (same dice, same first
+    mover, same sampled moves): the ego's and the partner's recorded transitions must be identical, row by row."""
+    from collections import deque
+    from pantheonrl_amd.common import Agent, Observation
+    from pantheonrl_amd.envs.liar import LiarEnv
+
+    class Shadow(LiarEnv):
+        def __init__(self):
+            super().__init__()
+            self.deals = deque()
+
+        def n_reset(self):
+            ego_first, hands = self.deals.popleft()
+            self.ego_next = bool(ego_first)
+            self.history, self.egohand, self.althand = [], [int(x) for x in hands[:6]], [int(x) for x in hands[6:]]
+            return (0 if self.ego_next else 1,), (Observation(self.getObs(self.ego_next)),)
+
+    class Replay(Agent):
+        """partner that plays the moves the device sampled and keeps OnPolicyAgent's book (agents.py:172-198)"""
+        def __init__(self):
+            self.moves, self.rows, self.last_done = deque(), [], True
+
+        def get_action(self, obs, record=True):
+            act = self.moves.popleft()
+            self.rows.append(dict(obs=np.asarray(obs.obs, np.float32), act=act, rew=0.0, start=float(self.last_done)))
+            return act
+
+        def update(self, reward, done):
+            self.rows[-1]["rew"] += float(reward)
+            self.last_done = bool(done)
+
+    E, T, steps = 24, 20, 20
+    sp, ego, alt, calls = _liar_selfplay(E, T, 64)
+    shadows, partners = [Shadow() for _ in range(E)], [Replay() for _ in range(E)]
+    for s, p in zip(shadows, partners):
+        s.add_partner_agent(p)
+
+    def feed(reset_mask):
+        hands, first = sp.env.hands.cpu().numpy(), sp.ego_first.cpu().numpy()
+        for acts, mask in calls:
+            for e in np.nonzero(mask)[0]:
+                partners[e].moves.append(acts[e].copy())
+        calls.clear()
+        for e in np.nonzero(reset_mask)[0]:
+            shadows[e].deals.append((first[e], hands[e].copy()))
+
+    feed(np.ones(E, bool))
+    cur = [s.reset() for s in shadows]
+    ego_rows = []
+    n_games = 0
+    for t in range(steps):
+        before = sp.obs_ego.cpu().numpy().copy()
+        done = sp.step().cpu().numpy().astype(bool)
+        a_ego = ego.actions.cpu().numpy().copy()
+        feed(done)
+        after = sp.obs_ego.cpu().numpy()
+        for e in range(E):
+            assert np.array_equal(before[e], np.asarray(cur[e], np.float32)), (t, e)
+            o, r, d, _ = shadows[e].step(a_ego[e])
+            assert bool(d) == bool(done[e]), (t, e)
+            ego_rows.append((t, e, float(r), bool(d)))
+            if d:
+                n_games += 1
+                o = shadows[e].reset()
+            cur[e] = o
+            assert np.array_equal(after[e], np.asarray(o, np.float32)), (t, e)
+            assert not partners[e].moves            # the Python loop consumed exactly the moves the device made
+    assert n_games == sp.episodes and n_games > E   # several games per table
+    th.cuda.synchronize()
+    be, ba = ego.model.rollout_buffer.host(), alt.model.rollout_buffer.host()
+    for t, e, r, d in ego_rows:
+        assert be["rewards"][t, e] == r
+        if t + 1 < T:
+            assert be["episode_starts"][t + 1, e] == float(d)
+    pos = alt.pos.cpu().numpy()
+    term, opened = alt.term.cpu().numpy(), alt.open.cpu().numpy()
+    assert pos.min() >= 1 and len(set(pos.tolist())) > 1           # the columns really are ragged
+    for e in range(E):
+        rows = partners[e].rows
+        assert pos[e] == len(rows)
+        for k, row in enumerate(rows):
+            assert np.array_equal(ba["observations"][k, e], row["obs"]), (e, k)
+            assert np.array_equal(ba["actions"][k, e], row["act"].astype(np.float32))
+            assert ba["rewards"][k, e] == row["rew"] and ba["episode_starts"][k, e] == row["start"], (e, k)
+            assert np.isfinite(ba["values"][k, e]) and ba["log_probs"][k, e] < 0
+        assert opened[e] == 1 and bool(term[e]) == partners[e].last_done
+
+
+def test_vec_liars_dice_partner_trains_when_every_column_is_full():
+    E, T_ego, T_alt = 64, 8, 4
+    sp, ego, alt, _ = _liar_selfplay(E, T_ego, T_alt, seed=3)
+    alt.model.rollout_buffer.gae_mode = 1                              # serial-in-T: bit-exact with the numpy loop
+    p_ego, p_alt = ego.model.policy.get_flat_params(), alt.model.policy.get_flat_params()
+    while not alt.full():
+        sp.step()
+        if ego.n_steps >= T_ego:
+            ego.learn_from_buffer()
+    assert int(alt.pos.max().item()) == T_alt                         # a full column stops recording
+    buf = alt.model.rollout_buffer.host()
+    last_values, dones = alt.values.cpu().numpy().copy(), alt.term.cpu().numpy().astype(np.float32)
+    alt.learn_from_buffer()
+    th.cuda.synchronize()
+    adv = alt.model.rollout_buffer.host()["advantages"]
+    rb = alt.model.rollout_buffer
+    adv_ref, _ = orc.gae_reference(buf["rewards"], buf["values"], buf["episode_starts"], last_values, dones,
+                                   rb.gamma, rb.gae_lambda)
+    assert np.array_equal(adv, adv_ref)                                # serial GAE is bit-exact
+    assert set(np.unique(buf["rewards"]).tolist()) <= {-1.0, 0.0, 1.0} and np.abs(buf["rewards"]).sum() > 0
+    assert alt.iteration == 1 and int(alt.pos.max().item()) == 0
+    for _ in range(2 * T_ego):                                         # keeps running after both learners updated
+        sp.step()
+        if ego.n_steps >= T_ego:
+            ego.learn_from_buffer()
+    assert int(alt.pos.min().item()) >= 1 and ego.iteration >= 1
+    q_ego, q_alt = ego.model.policy.get_flat_params(), alt.model.policy.get_flat_params()
+    assert np.isfinite(q_ego).all() and np.isfinite(q_alt).all()
+    assert not np.array_equal(p_ego, q_ego) and not np.array_equal(p_alt, q_alt)
+
+
+@pytest.mark.parametrize("game", ["RPS-v0", "LiarsDice-v0"])
+def test_trainer_n_envs_runs_device_selfplay(game, tmp_path):
+    from pantheonrl_amd import PPO
+    from pantheonrl_amd.trainer import run
+    ego, partners, _ = run([game, "PPO", "PPO", "--n-envs", "32", "-t", "2048", "--seed", "1",
+                            "--ego-config", '{"n_steps": 16, "n_epochs": 2}',
+                            "--alt-config", '{"n_steps": 8, "n_epochs": 2}' if game != "RPS-v0" else
+                            '{"n_steps": 16, "n_epochs": 2}',
+                            "--ego-save", str(tmp_path / "ego"), "--alt-save", str(tmp_path / "alt")])
+    assert partners[0].iteration >= 1
+    again = PPO.load(str(tmp_path / "ego"))
+    assert np.array_equal(again.policy.get_flat_params(), ego.policy.get_flat_params())
