@@ -76,6 +76,30 @@ struct GradArgs {
   int ntiles;
 };
 
+__device__ __host__ inline uint64_t epoch_key(uint64_t seed, int epoch) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(epoch + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// env-major flat index n = e*T + t (SB3 swap_and_flatten) -> row of the time-major buffer
+__device__ __forceinline__ int env_major_to_phys(int n, int T, int E) {
+  const int e = n / T;
+  return (n - e * T) * E + e;
+}
+// physical buffer row of minibatch element gi: explicit index array, or the keyed Feistel permutation of this epoch
+__device__ __forceinline__ int minibatch_row(const GradArgs& a, int gi) {
+  int n;
+  if (a.idx) {
+    n = a.idx[gi];
+  } else {
+    const uint64_t key = epoch_key(a.perm_seed + (a.epoch ? *a.epoch : 0ull), a.perm_epoch);
+    n = (int)feistel_perm((uint32_t)(a.mb_start + gi), a.perm_n, a.perm_hb, key);
+  }
+  return env_major_to_phys(n, a.T, a.E);
+}
+
 struct AdvStatArgs {
   const float* rb_adv;
   int T, E;
@@ -86,13 +110,6 @@ struct AdvStatArgs {
   int N, batch, n_mb;  // minibatch k of epoch ep covers [k*batch, min(N,(k+1)*batch))
   float* out;          // [n_epochs*n_mb][2]
 };
-
-__device__ __host__ inline uint64_t epoch_key(uint64_t seed, int epoch) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(epoch + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
 
 struct ReduceArgs {
   const float* slabs;
@@ -155,6 +172,9 @@ hipError_t launch_liar_step(const int* hands, int* history, int* nmoves, const i
                             const unsigned char* active, float* obs_next, float* rew, unsigned char* done, int n,
                             hipStream_t s);
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
+// single-chunk / small-Discrete-head variant (ph_ppo_fast.hip); eligible() says whether the spec fits it
+bool grad_fast_eligible(const NetDims& nd);
+hipError_t launch_ppo_grad_fast(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s);
 int reduce_blocks(int P);

@@ -16,22 +16,6 @@
 namespace ph {
 
 
-__device__ __forceinline__ int env_major_to_phys(int n, int T, int E) {
-  const int e = n / T;
-  return (n - e * T) * E + e;
-}
-
-__device__ __forceinline__ int minibatch_row(const GradArgs& a, int gi) {
-  int n;
-  if (a.idx) {
-    n = a.idx[gi];
-  } else {
-    const uint64_t key = epoch_key(a.perm_seed + (a.epoch ? *a.epoch : 0ull), a.perm_epoch);
-    n = (int)feistel_perm((uint32_t)(a.mb_start + gi), a.perm_n, a.perm_hb, key);
-  }
-  return env_major_to_phys(n, a.T, a.E);
-}
-
 // Weight-gradient tiles accumulate across the tiles of a workgroup in its private slab: the MFMA accumulator is
 // initialised from the slab (the loads hide under the operand prefetch of the tile product), then stored back.
 // (No-return L2 float atomics instead of the reload measured 8 % slower on the whole kernel.)
@@ -516,6 +500,7 @@ int grad_variant() {
 }
 
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s) {
+  if (grad_fast_eligible(a.nd)) return launch_ppo_grad_fast(a, nwg, gemm_mode, s);
   if (a.nd.Lp != 32 && a.nd.Lp != 64) return hipErrorInvalidValue;
   const bool lp64 = a.nd.Lp == 64;
   if (gemm_mode != 0) return lp64 ? launch_grad_variant<64, true, false>(a, nwg, s) : launch_grad_variant<32, true, false>(a, nwg, s);

@@ -1,0 +1,543 @@
+// ppo_grad_fast_kernel: the PPO minibatch gradient (SB3 PPO.train() inner loop, pantheonrl/common/agents.py:155; arithmetic
+// from SURVEY.md A.3 and the in-tree copy pantheonrl/algos/adap/adap_learn.py:253-344) for the shape class every
+// BASELINE config but Liar's Dice falls in: one feature chunk (F <= 64) and a Discrete action head with <= 8 logits.
+//
+// Same decomposition as ppo_grad_kernel (grid (nWG, 2 nets), 64-row tiles, every 64x64 product as 32x32
+// v_mfma_f32_32x32x2_f32 tiles on LDS operands, one per wave) with three structural differences:
+//   * the head (logits / value, loss, dL/dlogits, dH2, dZ2) is ONE register-resident VALU phase -- four lanes per row,
+//     each owning 16 hidden units, quad-DPP reductions -- instead of four barrier-separated phases around 32-wide padded
+//     MFMA tiles of a 6-wide head;
+//   * weight- and bias-gradient accumulators live in registers across the row tiles of a workgroup and are stored to
+//     the workgroup's slab once (no slab read-modify-write per tile, no store drain at barriers);
+//   * barriers wait for LDS only (s_waitcnt lgkmcnt(0); s_barrier), so global loads issued in one phase -- the next
+//     tile's gathered rows, its per-row scalars, the W1 refill -- stay in flight across phases and are consumed later.
+// LDS: bufA/bufB/bufC/W2 (4 x [64][65] f32) + head weights + per-row scalars = 72.9 KB -> two workgroups per CU.
+#include "ph_launch.h"
+
+namespace ph {
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the four lanes of a quad; every lane of the quad ends with the bitwise-identical result
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp_quad<0xB1>(v);  // quad_perm [1,0,3,2]
+  v += dpp_quad<0x4E>(v);  // quad_perm [2,3,0,1]
+  return v;
+}
+
+// hidden units owned by lane q of a row quad, m = 0..15: base(q) + constant(m), so the LDS offsets fold into the
+// instructions, and the H2 / dZ2 accesses of a wave (8 rows x 4 quads per 32 lanes) fall on distinct banks.
+__device__ __forceinline__ int head_unit(int q, int m) { return 8 * q + (m & 7) + 32 * (m >> 3); }
+// act_W row j sits at hw[8*(j + (j>>3))]: the one-row skew per 8 rows puts the four rows a wave reads at a time (j = 8q + c)
+// on different banks while keeping 16-byte alignment
+__device__ __forceinline__ int head_row(int j) { return 8 * (j + (j >> 3)); }
+constexpr int HW_FLOATS = 8 * (HID + HID / 8);
+
+// Calls f(m, w0, w1) for the 16 head-weight rows of lane q, four rows per group, the next group's ds_read_b128s issued
+// before the current group's arithmetic (the scheduler otherwise emits read-wait-use per row: 16 LDS round trips).
+template <class F>
+__device__ __forceinline__ void for_head_rows(const float* hw, int q, F&& f) {
+  constexpr int G = 2;  // rows per group
+  float4 wa[2][G], wb[2][G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    const float4* w = reinterpret_cast<const float4*>(hw + head_row(head_unit(q, i)));
+    wa[0][i] = w[0];
+    wb[0][i] = w[1];
+  }
+#pragma unroll
+  for (int g = 0; g < 16 / G; ++g) {
+    if (g + 1 < 16 / G) {
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const float4* w = reinterpret_cast<const float4*>(hw + head_row(head_unit(q, G * (g + 1) + i)));
+        wa[(g + 1) & 1][i] = w[0];
+        wb[(g + 1) & 1][i] = w[1];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < G; ++i) f(G * g + i, wa[g & 1][i], wb[g & 1][i]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// sum of 16 LDS values p[i*stride], all reads issued before the adds (fixed tree order)
+__device__ __forceinline__ float lds_sum16(const float* p, int stride) {
+  float t[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t[i] = p[i * stride];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int w = 8; w > 0; w >>= 1) {
+#pragma unroll
+    for (int i = 0; i < w; ++i) t[i] += t[i + w];
+  }
+  return t[0];
+}
+
+struct RowMeta {
+  int phys;
+  float adv, old, act;
+};
+
+// Box observation tile in registers: lane = feature, register i = row wave + 4*i.  The row bases come from the lanes
+// that computed them through v_readlane (scalar), so the gather is 16 back-to-back 256-byte row loads per wave.
+struct XRegs {
+  float v[16];
+  // raw loads only: masking happens at commit, so nothing here waits for the data
+  __device__ __forceinline__ void issue(int physv, const float* obs, const NetDims& nd, int lane) {
+    const int f = lane < nd.F ? lane : 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = __builtin_amdgcn_readlane(physv, i);
+      v[i] = obs[(size_t)(p < 0 ? 0 : p) * nd.D + f];
+    }
+  }
+  __device__ __forceinline__ void commit(float* dst, int physv, const NetDims& nd, int wave, int lane) const {
+    const bool fok = lane < nd.F;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = __builtin_amdgcn_readlane(physv, i);
+      dst[(wave + 4 * i) * LDH + lane] = (p >= 0 && fok) ? v[i] : 0.f;
+    }
+  }
+};
+
+template <bool VALU>
+__global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
+  if (*a.stop_flag) return;
+  PH_STAMP(a.prof, 0);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int R = 64, NT = 256;
+  const NetDims& nd = a.nd;
+  const ph_layout& lay = nd.lay;
+  float* bufA = smem;               // [R][LDH]   X -> H2 -> X
+  float* bufB = bufA + R * LDH;     // [R][LDH]   H1 -> dZ1
+  float* bufC = bufB + R * LDH;     // [64][LDH]  W1 -> dZ2 -> W1
+  float* w2s = bufC + HID * LDH;    // [64][LDH]
+  float* hw = w2s + HID * LDH;      // policy: act_W as [64][8] (columns >= L zero) | value: val_W [64]
+  float* dzs = hw + HW_FLOATS;       // policy: dL/dlogits [R][8] | value: dL/dv [R]
+  float* b1s = dzs + R * 8;         // [64]
+  float* b2s = b1s + HID;           // [64]
+  float* hbs = b2s + HID;           // act_b [8] | val_b
+  float* radv = hbs + 16;           // [R] normalised advantage | returns
+  float* rold = radv + R;           // [R] old log-prob | old values
+  float* ract = rold + R;           // [R] action index
+  int* rowphys = (int*)(ract + R);  // [R] physical buffer row, -1 = padding
+
+  const int net = blockIdx.y;
+  const bool box = nd.obs_kind == PH_SPACE_BOX;
+  const int oW1 = net == 0 ? lay.pi_W1 : lay.vf_W1, oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1;
+  const int oW2 = net == 0 ? lay.pi_W2 : lay.vf_W2, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
+  float* slab = a.slabs + (size_t)blockIdx.x * lay.P;
+  const float inv_nb = 1.0f / (float)a.nb;
+  const int nk = nd.L;
+
+  // loop invariants that live in memory are read once here (inside the tile loop each would be a fresh dependent load
+  // -- the asm barriers are memory clobbers -- and its wait would also drain the prefetches in flight)
+  const uint64_t perm_key = a.idx ? 0ull : epoch_key(a.perm_seed + (a.epoch ? *a.epoch : 0ull), a.perm_epoch);
+  const bool norm = net == 0 && a.norm_adv && a.nb > 1;
+  const float adv_mean = norm ? a.advstats[0] : 0.f;
+  const float adv_den = norm ? a.advstats[1] + 1e-8f : 1.f;
+
+  // per-row gathers of one tile: lane i < 16 of wave w serves row w + 4*i
+  auto fetch_rows = [&](int tile, int wave, int lane) -> RowMeta {
+    RowMeta m;
+    m.phys = -1;
+    m.adv = m.old = m.act = 0.f;
+    const int gi = tile * R + wave + 4 * lane;
+    if (lane < 16 && gi < a.nb) {
+      const int n = a.idx ? a.idx[gi] : (int)feistel_perm((uint32_t)(a.mb_start + gi), a.perm_n, a.perm_hb, perm_key);
+      m.phys = env_major_to_phys(n, a.T, a.E);
+      if (net == 0) {
+        m.adv = a.rb_adv[m.phys];   // normalised when it is committed to LDS (no wait on the gather here)
+        m.old = a.rb_logp[m.phys];
+        m.act = a.rb_act[m.phys];
+      } else {
+        m.adv = a.rb_ret[m.phys];
+        m.old = a.rb_val[m.phys];
+      }
+    }
+    return m;
+  };
+
+  // ---- prologue: every global load of the first tile is in flight before the first wait ----
+  WStage<NT> w2r, w1r;
+  XRegs xt;
+  XStage<R, NT> xs;  // one-hot observation path (gathers at commit)
+  RowMeta meta;
+  {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    meta = fetch_rows(blockIdx.x, wave, lane);
+    if (box) xt.issue(meta.phys, a.rb_obs, nd, lane);
+    w1r.issue(a.params + oW1, 0, nd.F);
+    w2r.issue(a.params + oW2, 0, HID);
+    float bias1 = 0.f, bias2 = 0.f, hv0 = 0.f, hv1 = 0.f, hb = 0.f;
+    if (tid < HID) {
+      bias1 = a.params[oB1 + tid];
+      bias2 = a.params[oB2 + tid];
+    }
+    if (net == 0) {
+      const int j0 = tid >> 3, k = tid & 7;  // elements tid and tid + 256 of the [64][8] block
+      if (k < nk) {
+        hv0 = a.params[lay.act_W + j0 * nk + k];
+        hv1 = a.params[lay.act_W + (j0 + 32) * nk + k];
+      }
+      // padded logits get a -3e38 "bias": they drop out of softmax, entropy and every gradient with no special cases
+      if (tid < 8) hb = (tid < nk) ? a.params[lay.act_b + tid] : -3.0e38f;
+    } else {
+      if (tid < HID) hv0 = a.params[lay.val_W + tid];
+      if (tid == 0) hb = a.params[lay.val_b];
+    }
+    w1r.commit(bufC);
+    w2r.commit(w2s);
+    if (tid < HID) {
+      b1s[tid] = bias1;
+      b2s[tid] = bias2;
+    }
+    if (net == 0) {
+      hw[head_row(tid >> 3) + (tid & 7)] = hv0;
+      hw[head_row((tid >> 3) + 32) + (tid & 7)] = hv1;
+      if (tid < 8) hbs[tid] = hb;
+    } else {
+      if (tid < HID) hw[tid] = hv0;
+      if (tid == 0) hbs[0] = hb;
+    }
+  }
+
+  f32x16 gW1 = {0}, gW2 = {0};
+  float gh0 = 0.f, gh1 = 0.f;   // policy: d act_W[j][2w], [j][2w+1] | value: d val_W[j] partial of this wave (gh0)
+  float gb1 = 0.f, gb2 = 0.f;   // bias-gradient partials of this wave's 16 rows (lane = hidden unit)
+  float ghb = 0.f;              // policy: d act_b[lane] partial (lane < 8) | value: d val_b partial
+  float st[NSTATP];
+#pragma unroll
+  for (int k = 0; k < NSTATP; ++k) st[k] = 0.f;
+
+  bool first = true;
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, first = false) {
+    // thread coordinates are re-derived per tile from an opaque copy of threadIdx.x (stops the compiler from pinning
+    // hundreds of loop-invariant LDS addresses in VGPRs across the tile loop)
+    int tidv = threadIdx.x;
+    asm volatile("" : "+v"(tidv));
+    const int tid = tidv, lane = tid & 63, wave = tid >> 6;
+    const int mt = wave >> 1, nt = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const bool has_next = tile + (int)gridDim.x < a.ntiles;
+
+    // ---- T0: this tile's rows (gathered during the previous tile / the prologue) land in LDS ----
+    if (lane < 16) {
+      const int row = wave + 4 * lane;
+      rowphys[row] = meta.phys;
+      radv[row] = (norm && meta.phys >= 0) ? (meta.adv - adv_mean) / adv_den : meta.adv;
+      rold[row] = meta.old;
+      ract[row] = meta.act;
+    }
+    if (box) xt.commit(bufA, meta.phys, nd, wave, lane);
+    lds_barrier();
+    if (!box) {
+      xs.commit(bufA, rowphys, a.rb_obs, nd, 0, tid);
+      lds_barrier();
+    }
+    if (first) PH_STAMP(a.prof, 1);
+
+    // ---- S1: H1 = tanh(X W1 + b1) -> bufB ----
+    {
+      f32x16 acc = {0};
+      acc = tile_mma<false, false, VALU>(bufA, LDH, bufC, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
+        bufB[row * LDH + col] = fast_tanh(acc[r] + b1s[col]);
+      }
+    }
+    lds_barrier();
+    if (first) PH_STAMP(a.prof, 2);
+
+    // ---- S2: H2 = tanh(H1 W2 + b2) -> bufA ----
+    {
+      f32x16 acc = {0};
+      acc = tile_mma<false, false, VALU>(bufB, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
+        bufA[row * LDH + col] = fast_tanh(acc[r] + b2s[col]);
+      }
+    }
+    lds_barrier();
+    if (first) PH_STAMP(a.prof, 3);
+
+    // ---- SH: head forward, loss, dL/dhead, dZ2 = dH2 * (1 - H2^2) -> bufC; four lanes per row ----
+    {
+      const int r = tid >> 2, q = tid & 3;
+      const bool valid = rowphys[r] >= 0;
+      float h[16];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) h[m] = bufA[r * LDH + head_unit(q, m)];
+      if (net == 0) {
+        float z[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = 0.f;
+        for_head_rows(hw, q, [&](int m, const float4& w0, const float4& w1) {
+          z[0] = __builtin_fmaf(h[m], w0.x, z[0]);
+          z[1] = __builtin_fmaf(h[m], w0.y, z[1]);
+          z[2] = __builtin_fmaf(h[m], w0.z, z[2]);
+          z[3] = __builtin_fmaf(h[m], w0.w, z[3]);
+          z[4] = __builtin_fmaf(h[m], w1.x, z[4]);
+          z[5] = __builtin_fmaf(h[m], w1.y, z[5]);
+          z[6] = __builtin_fmaf(h[m], w1.z, z[6]);
+          z[7] = __builtin_fmaf(h[m], w1.w, z[7]);
+        });
+        float pr[8];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          z[k] = quad_sum(z[k]) + hbs[k];
+          mx = fmaxf(mx, z[k]);
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          pr[k] = fast_exp(z[k] - mx);
+          se += pr[k];
+        }
+        const float lse = mx + fast_log(se), inv = __builtin_amdgcn_rcpf(se);
+        int act = (int)ract[r];
+        act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
+        float ent = 0.f, zact = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          pr[k] *= inv;
+          ent -= pr[k] * (z[k] - lse);
+          zact = (k == act) ? z[k] : zact;
+        }
+        const float logp = zact - lse;
+        const float adv = radv[r];
+        const float lr = logp - rold[r];
+        const float ratio = fast_exp(lr);
+        const float lo_c = 1.0f - a.clip, hi_c = 1.0f + a.clip;
+        const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
+        const float pl1 = adv * ratio, pl2 = adv * rc;
+        // torch.min backward: the smaller branch gets the gradient, ties split 1/2 + 1/2; clamp passes it iff lo <= ratio <= hi
+        const float inr = (ratio >= lo_c && ratio <= hi_c) ? 1.f : 0.f;
+        const float gate = (pl1 < pl2) ? 1.f : ((pl1 > pl2) ? inr : 0.5f + 0.5f * inr);
+        const float live = valid ? 1.f : 0.f;
+        const float g_lp = -inv_nb * adv * ratio * gate * live;
+        const float g_en = -a.ent_coef * inv_nb * live;
+        if (valid && q == 0) {
+          st[0] += -fminf(pl1, pl2);
+          st[2] += -ent;
+          st[3] += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
+          st[4] += (ratio - 1.0f) - lr;
+        }
+        float dz[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float dlogp = ((k == act) ? 1.f : 0.f) - pr[k];
+          const float dent = -pr[k] * ((z[k] - lse) + ent);
+          dz[k] = g_lp * dlogp + g_en * dent;
+        }
+        if (q == 0) {
+          float4* o = reinterpret_cast<float4*>(dzs + r * 8);
+          o[0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+          o[1] = make_float4(dz[4], dz[5], dz[6], dz[7]);
+        }
+        for_head_rows(hw, q, [&](int m, const float4& w0, const float4& w1) {
+          float d = dz[0] * w0.x;
+          d = __builtin_fmaf(dz[1], w0.y, d);
+          d = __builtin_fmaf(dz[2], w0.z, d);
+          d = __builtin_fmaf(dz[3], w0.w, d);
+          d = __builtin_fmaf(dz[4], w1.x, d);
+          d = __builtin_fmaf(dz[5], w1.y, d);
+          d = __builtin_fmaf(dz[6], w1.z, d);
+          d = __builtin_fmaf(dz[7], w1.w, d);
+          bufC[r * LDH + head_unit(q, m)] = d * (1.0f - h[m] * h[m]);
+        });
+      } else {
+        float wv[16];
+        float v = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          wv[m] = hw[head_unit(q, m)];
+          v = __builtin_fmaf(h[m], wv[m], v);
+        }
+        v = quad_sum(v) + hbs[0];
+        const float retn = radv[r], oldv = rold[r];
+        float vp = v, pass = 1.f;
+        if (a.clip_vf >= 0.f) {
+          const float dlt = v - oldv;
+          pass = (dlt >= -a.clip_vf && dlt <= a.clip_vf) ? 1.f : 0.f;
+          vp = oldv + fminf(fmaxf(dlt, -a.clip_vf), a.clip_vf);
+        }
+        const float err = vp - retn;
+        const float dv = valid ? a.vf_coef * 2.0f * err * inv_nb * pass : 0.f;
+        if (valid && q == 0) st[1] += err * err;
+        if (q == 0) dzs[r] = dv;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) bufC[r * LDH + head_unit(q, m)] = dv * wv[m] * (1.0f - h[m] * h[m]);
+      }
+    }
+    lds_barrier();
+    if (first) PH_STAMP(a.prof, 4);
+
+    // ---- S6a: dW2 += H1^T dZ2 ; dH1 = dZ2 W2^T ; d b2, d head weights, d head bias (VALU, beside the MFMAs) ----
+    RowMeta meta_next = meta;
+    if (has_next) {
+      // (order matters: the index phi inside fetch_rows ends in a vmcnt(0) wait, which must find nothing in flight)
+      meta_next = fetch_rows(tile + gridDim.x, wave, lane);   // next tile's row scalars, committed at its T0
+      if (first) PH_STAMP(a.prof, 8);
+      w1r.issue(a.params + oW1, 0, nd.F, tid);                // refill of bufC, committed in S6b
+    }
+    if (first) PH_STAMP(a.prof, 9);
+    f32x16 dh1 = {0};
+    {
+      gb2 += lds_sum16(bufC + wave * 16 * LDH + lane, LDH);
+      if (net == 0) {
+        const float* hp = bufA + lane;
+        const float* dp = dzs + 2 * wave;
+#pragma unroll 1
+        for (int r0 = 0; r0 < R; r0 += 8, hp += 8 * LDH, dp += 8 * 8) {  // a real loop: 8 rows of reads, then their FMAs
+          float hv[8];
+          float2 d[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            hv[i] = hp[i * LDH];
+            d[i] = *reinterpret_cast<const float2*>(dp + i * 8);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            gh0 = __builtin_fmaf(hv[i], d[i].x, gh0);
+            gh1 = __builtin_fmaf(hv[i], d[i].y, gh1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (lane < 8) ghb += lds_sum16(dzs + wave * 16 * 8 + lane, 8);
+      } else {
+        float hv[16], dv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          hv[i] = bufA[(wave * 16 + i) * LDH + lane];
+          dv[i] = dzs[wave * 16 + i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          gh0 = __builtin_fmaf(hv[i], dv[i], gh0);
+          ghb += dv[i];
+        }
+      }
+      if (first) PH_STAMP(a.prof, 10);
+      gW2 = tile_mma<true, false, VALU>(bufB, LDH, bufC, LDH, mt * 32, nt * 32, 0, R, gW2, lane);
+      if (first) PH_STAMP(a.prof, 11);
+      dh1 = tile_mma<false, true, VALU>(bufC, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1, lane);
+    }
+    lds_barrier();
+    if (first) PH_STAMP(a.prof, 5);
+
+    // ---- S6b: dZ1 = dH1 * (1 - H1^2) in place; X back into bufA; W1 back into bufC ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
+      const float hv = bufB[row * LDH + col];
+      bufB[row * LDH + col] = dh1[r] * (1.0f - hv * hv);
+    }
+    if (box) xt.commit(bufA, meta.phys, nd, wave, lane);
+    else xs.commit(bufA, rowphys, a.rb_obs, nd, 0, tid);
+    if (has_next) w1r.commit(bufC, tid);
+    lds_barrier();
+    if (first) PH_STAMP(a.prof, 6);
+
+    // ---- S7: dW1 += X^T dZ1 ; d b1.  The next tile's rows are gathered underneath. ----
+    meta = meta_next;
+    if (has_next && box) xt.issue(meta.phys, a.rb_obs, nd, lane);
+    gb1 += lds_sum16(bufB + wave * 16 * LDH + lane, LDH);
+    gW1 = tile_mma<true, false, VALU>(bufA, LDH, bufB, LDH, mt * 32, nt * 32, 0, R, gW1, lane);
+    lds_barrier();  // bufA / bufB / row scalars are free for the next tile
+    if (first) PH_STAMP(a.prof, 7);
+  }
+  PH_STAMP(a.prof, 12);
+
+  // ---- epilogue: accumulators -> slab (once), cross-wave sums in a fixed order ----
+  {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mt = wave >> 1, nt = wave & 1, li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = mt * 32 + drow(r, lh), col = nt * 32 + li;
+      slab[oW2 + k * HID + col] = gW2[r];
+      if (k < nd.F) slab[oW1 + (size_t)k * HID + col] = gW1[r];
+    }
+    if (net == 0) {
+      if (2 * wave < nk) slab[lay.act_W + lane * nk + 2 * wave] = gh0;
+      if (2 * wave + 1 < nk) slab[lay.act_W + lane * nk + 2 * wave + 1] = gh1;
+    }
+#pragma unroll
+    for (int k = 0; k < NSTATP; ++k) {
+      float v = st[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      st[k] = v;
+    }
+    float* part = bufA;  // [5][4 waves][64]
+    part[(0 * 4 + wave) * 64 + lane] = gb1;
+    part[(1 * 4 + wave) * 64 + lane] = gb2;
+    part[(2 * 4 + wave) * 64 + lane] = gh0;   // value net: d val_W partials
+    part[(3 * 4 + wave) * 64 + lane] = ghb;
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < NSTATP; ++k) part[(4 * 4 + wave) * 64 + k] = st[k];
+    }
+    lds_barrier();
+    auto wsum = [&](int which, int idx) {
+      return ((part[(which * 4 + 0) * 64 + idx] + part[(which * 4 + 1) * 64 + idx]) + part[(which * 4 + 2) * 64 + idx]) +
+             part[(which * 4 + 3) * 64 + idx];
+    };
+    if (tid < HID) {
+      slab[oB1 + tid] = wsum(0, tid);
+      slab[oB2 + tid] = wsum(1, tid);
+      if (net == 1) slab[lay.val_W + tid] = wsum(2, tid);
+    }
+    if (net == 0 && tid < nk) slab[lay.act_b + tid] = wsum(3, tid);
+    if (net == 1 && tid == 0) slab[lay.val_b] = wsum(3, 0);
+    if (tid < NSTATP) a.statpart[((size_t)net * gridDim.x + blockIdx.x) * NSTATP + tid] = wsum(4, tid);
+  }
+  PH_STAMP(a.prof, 13);
+}
+
+static size_t grad_fast_lds_bytes() {
+  return sizeof(float) * (size_t)(4 * 64 * LDH + HW_FLOATS + 64 * 8 + 2 * HID + 16 + 3 * 64 + 64);
+}
+
+bool grad_fast_eligible(const NetDims& nd) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("PH_GRAD_FAST");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  return enabled && nd.nchunk == 1 && nd.A == 1 && nd.L <= 8;
+}
+
+template <bool VALU>
+static hipError_t launch_fast_variant(const GradArgs& a, int nwg, hipStream_t s) {
+  const size_t lds = grad_fast_lds_bytes();
+  static bool allowed = false;  // > 64 KiB of dynamic LDS is opt-in, once per kernel (kept out of graph capture)
+  if (!allowed) {
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_fast_kernel<VALU>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    allowed = true;
+  }
+  hipLaunchKernelGGL((ppo_grad_fast_kernel<VALU>), dim3(nwg, 2), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_ppo_grad_fast(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s) {
+  return gemm_mode != 0 ? launch_fast_variant<true>(a, nwg, s) : launch_fast_variant<false>(a, nwg, s);
+}
+
+}  // namespace ph

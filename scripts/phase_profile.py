@@ -25,8 +25,10 @@ lib, h = pol.ctx.lib, pol.ctx.handle
 stamps = th.zeros(16 * 1024, dtype=th.int64, device="cuda")
 
 
-def report(name, nblk_x, nblk_y, labels):
+def report(name, nblk_x, nblk_y, labels, slots=None):
     st = stamps.cpu().numpy().reshape(-1, 16)[: nblk_x * nblk_y]
+    if slots is not None:
+        st = st[:, slots]
     for by in range(nblk_y):
         blk = st[by * nblk_x:(by + 1) * nblk_x]
         blk = blk[blk[:, 0] > 0]
@@ -63,7 +65,12 @@ nat.check(lib.ph_bench_ppo_grad(h, C.byref(pol.spec), pol.params.data_ptr(), C.b
 th.cuda.synchronize()
 nwg = min((model.batch_size + 63) // 64, 256)
 print(f"ppo_grad launch {ms.value * 1e3:.1f} us, {nwg} workgroups per net")
-report("ppo_grad", nwg, 2, ["prologue+S0 meta", "S1 X+W1 load", "S1 mma", "Wo load+H1 tanh", "S2 mma+tanh", "S3 head/value",
-                            "S4 loss", "S5a dWo", "S5b dH2/dZ2", "S6a dW2+dH1", "S6b dZ1", "S7 dW1 (+rest of tiles)",
-                            "stats"])
+if os.environ.get("PH_GRAD_FAST", "1") != "0":
+    report("ppo_grad_fast", nwg, 2, ["prologue + T0 (rows, X, W1, W2)", "S1 mma+tanh", "S2 mma+tanh", "SH head (VALU)",
+                                     "S6a fetch_rows", "S6a W1 issue", "S6a side work", "S6a dW2 mma", "S6a dH1 mma", "S6b dZ1, X, W1", "S7 dW1", "remaining tiles",
+                                     "epilogue"], slots=[0, 1, 2, 3, 4, 8, 9, 10, 11, 5, 6, 7, 12, 13])
+else:
+    report("ppo_grad", nwg, 2, ["prologue+S0 meta", "S1 X+W1 load", "S1 mma", "Wo load+H1 tanh", "S2 mma+tanh",
+                                "S3 head/value", "S4 loss", "S5a dWo", "S5b dH2/dZ2", "S6a dW2+dH1", "S6b dZ1",
+                                "S7 dW1 (+rest of tiles)", "stats"])
 nat.check(lib.ph_debug_set_profile_buffer(h, None))
