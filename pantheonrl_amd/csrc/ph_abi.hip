@@ -51,6 +51,8 @@ struct ph_ctx {
   size_t blocksq_cap = 0;
   float* advstats = nullptr;
   size_t advstats_cap = 0;
+  int* perm_idx = nullptr;   // (n_epochs, N) minibatch order of the current train() call, written by adv_stats
+  size_t perm_idx_cap = 0;
   float* w2t = nullptr;      // [2][64][64] (W2G gradient-kernel variant)
   float* scalars = nullptr;  // [4]
   int* stop_flag = nullptr;  // [1]
@@ -223,7 +225,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (s.obs_off) (void)hipFree(s.obs_off);
     if (s.act_off) (void)hipFree(s.act_off);
   }
-  void* ptrs[] = {ctx->w2t, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->scalars, ctx->stop_flag};
+  void* ptrs[] = {ctx->w2t, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->scalars, ctx->stop_flag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -631,9 +633,9 @@ void fill_grad_args(ph::GradArgs& g, const ph::NetDims& nd, const float* params,
   g.w2t = ctx->w2t;
 }
 
-int ensure_train_ws(ph_ctx* ctx, int P, int nwg_max, int n_mb_total) {
+int ensure_train_ws(ph_ctx* ctx, int P, int nwg_max, int n_mb_total, size_t n_idx = 0) {
   if (ctx->capturing) {
-    if ((size_t)nwg_max * P > ctx->slabs_cap || (size_t)n_mb_total * 2 > ctx->advstats_cap)
+    if ((size_t)nwg_max * P > ctx->slabs_cap || (size_t)n_mb_total * 2 > ctx->advstats_cap || n_idx > ctx->perm_idx_cap)
       return fail("workspace would grow inside graph capture: run the same call once outside capture first");
     return 0;
   }
@@ -642,6 +644,7 @@ int ensure_train_ws(ph_ctx* ctx, int P, int nwg_max, int n_mb_total) {
   if (ensure(ctx->grad, ctx->grad_cap, (size_t)P)) return 1;
   if (ensure(ctx->blocksq, ctx->blocksq_cap, (size_t)ph::reduce_blocks(P))) return 1;
   if (ensure(ctx->advstats, ctx->advstats_cap, (size_t)n_mb_total * 2)) return 1;
+  if (n_idx && ensure(ctx->perm_idx, ctx->perm_idx_cap, n_idx)) return 1;
   return 0;
 }
 
@@ -662,7 +665,7 @@ int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, cons
   const int n_mb = (N + batch_size - 1) / batch_size;
   const int P = nd.lay.P;
   const MbPlan big = plan_minibatch(ctx, batch_size < N ? batch_size : N);
-  if (ensure_train_ws(ctx, P, big.nwg, n_epochs * n_mb)) return 1;
+  if (ensure_train_ws(ctx, P, big.nwg, n_epochs * n_mb, perms ? 0 : (size_t)n_epochs * N)) return 1;
   hipStream_t s = ctx->stream;
 
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
@@ -683,6 +686,7 @@ int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, cons
     aa.batch = batch_size;
     aa.n_mb = n_mb;
     aa.out = ctx->advstats;
+    aa.idx_out = perms ? nullptr : ctx->perm_idx;
     PH_HIP(ph::launch_adv_stats(aa, n_epochs * n_mb, s));
   }
   for (int ep = 0; ep < n_epochs; ++ep) {
@@ -694,7 +698,7 @@ int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, cons
       ph::GradArgs g;
       std::memset(&g, 0, sizeof(g));
       fill_grad_args(g, nd, opt->params, rb, hp, ctx);
-      g.idx = perms ? perms + (size_t)ep * N + start : nullptr;
+      g.idx = (perms ? perms : ctx->perm_idx) + (size_t)ep * N + start;
       g.perm_n = (uint32_t)N;
       g.perm_hb = hb;
       g.perm_seed = perm_seed;
@@ -778,6 +782,7 @@ int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params,
   aa.batch = nb;
   aa.n_mb = 1;
   aa.out = ctx->advstats;
+  aa.idx_out = nullptr;
   PH_HIP(ph::launch_adv_stats(aa, 1, s));
   ph::GradArgs g;
   std::memset(&g, 0, sizeof(g));
@@ -818,7 +823,7 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   const int N = rb->T * rb->E;
   const int nb = batch_size < N ? batch_size : N;
   const MbPlan pl = plan_minibatch(ctx, nb);
-  if (ensure_train_ws(ctx, nd.lay.P, pl.nwg, 1)) return 1;
+  if (ensure_train_ws(ctx, nd.lay.P, pl.nwg, 1, (size_t)N)) return 1;
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
   ph::AdvStatArgs aa;
@@ -834,10 +839,12 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   aa.batch = nb;
   aa.n_mb = 1;
   aa.out = ctx->advstats;
+  aa.idx_out = ctx->perm_idx;   // as in ph_ppo_train: the grad launches read the materialised order
   PH_HIP(ph::launch_adv_stats(aa, 1, s));
   ph::GradArgs g;
   std::memset(&g, 0, sizeof(g));
   fill_grad_args(g, nd, params, rb, hp, ctx);
+  g.idx = ctx->perm_idx;
   g.perm_n = aa.perm_n;
   g.perm_hb = aa.perm_hb;
   g.perm_seed = aa.perm_seed;

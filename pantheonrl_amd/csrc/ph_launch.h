@@ -109,6 +109,7 @@ struct AdvStatArgs {
   const unsigned long long* epoch;
   int N, batch, n_mb;  // minibatch k of epoch ep covers [k*batch, min(N,(k+1)*batch))
   float* out;          // [n_epochs*n_mb][2]
+  int* idx_out;        // (n_epochs, N) or null: the env-major index of every element, materialised for the grad launches
 };
 
 struct ReduceArgs {

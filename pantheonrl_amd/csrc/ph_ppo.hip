@@ -531,8 +531,13 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto value = [&](int i) -> double {
     if (i >= nb) return 0.0;
-    const int n = a.perms ? a.perms[(size_t)ep * a.N + start + i]
-                          : (int)feistel_perm((uint32_t)(start + i), a.perm_n, a.perm_hb, key);
+    int n;
+    if (a.perms) {
+      n = a.perms[(size_t)ep * a.N + start + i];
+    } else {
+      n = (int)feistel_perm((uint32_t)(start + i), a.perm_n, a.perm_hb, key);
+      if (a.idx_out) a.idx_out[(size_t)ep * a.N + start + i] = n;   // each element is visited exactly once
+    }
     return (double)a.rb_adv[env_major_to_phys(n, a.T, a.E)];
   };
   // one pass: sum and sum of squares in fp64 (exact products of f32 values), 4 independent gathers per round

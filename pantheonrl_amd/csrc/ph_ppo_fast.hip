@@ -145,14 +145,18 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
   const float adv_mean = norm ? a.advstats[0] : 0.f;
   const float adv_den = norm ? a.advstats[1] + 1e-8f : 1.f;
 
-  // per-row gathers of one tile: lane i < 16 of wave w serves row w + 4*i
-  auto fetch_rows = [&](int tile, int wave, int lane) -> RowMeta {
+  // per-row gathers of one tile, lane i < 16 of wave w serving row w + 4*i, in two steps so that the index load of the
+  // materialised minibatch order (ph_ppo_train) can be issued phases before the gathers that depend on it
+  auto row_index = [&](int tile, int wave, int lane) -> int {
+    const int gi = tile * R + wave + 4 * lane;
+    if (lane >= 16 || gi >= a.nb) return -1;
+    return a.idx ? a.idx[gi] : (int)feistel_perm((uint32_t)(a.mb_start + gi), a.perm_n, a.perm_hb, perm_key);
+  };
+  auto row_scalars = [&](int n) -> RowMeta {
     RowMeta m;
     m.phys = -1;
     m.adv = m.old = m.act = 0.f;
-    const int gi = tile * R + wave + 4 * lane;
-    if (lane < 16 && gi < a.nb) {
-      const int n = a.idx ? a.idx[gi] : (int)feistel_perm((uint32_t)(a.mb_start + gi), a.perm_n, a.perm_hb, perm_key);
+    if (n >= 0) {
       m.phys = env_major_to_phys(n, a.T, a.E);
       if (net == 0) {
         m.adv = a.rb_adv[m.phys];   // normalised when it is committed to LDS (no wait on the gather here)
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
   RowMeta meta;
   {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    meta = fetch_rows(blockIdx.x, wave, lane);
+    meta = row_scalars(row_index(blockIdx.x, wave, lane));
     if (box) xt.issue(meta.phys, a.rb_obs, nd, lane);
     w1r.issue(a.params + oW1, 0, nd.F);
     w2r.issue(a.params + oW2, 0, HID);
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
     if (first) PH_STAMP(a.prof, 2);
 
     // ---- S2: H2 = tanh(H1 W2 + b2) -> bufA ----
+    const int n_next = has_next ? row_index(tile + gridDim.x, wave, lane) : -1;   // consumed in S6a
     {
       f32x16 acc = {0};
       acc = tile_mma<false, false, VALU>(bufB, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
@@ -387,8 +392,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
     // ---- S6a: dW2 += H1^T dZ2 ; dH1 = dZ2 W2^T ; d b2, d head weights, d head bias (VALU, beside the MFMAs) ----
     RowMeta meta_next = meta;
     if (has_next) {
-      // (order matters: the index phi inside fetch_rows ends in a vmcnt(0) wait, which must find nothing in flight)
-      meta_next = fetch_rows(tile + gridDim.x, wave, lane);   // next tile's row scalars, committed at its T0
+      meta_next = row_scalars(n_next);                        // next tile's row scalars, committed at its T0
       if (first) PH_STAMP(a.prof, 8);
       w1r.issue(a.params + oW1, 0, nd.F, tid);                // refill of bufC, committed in S6b
     }
