@@ -600,12 +600,10 @@ struct MbPlan {
   int nb, ntiles, nwg;
 };
 
-MbPlan plan_minibatch(const ph_ctx* ctx, int nb) {
+MbPlan plan_minibatch(const ph_ctx* ctx, const ph::NetDims& nd, int nb) {
   MbPlan p;
   p.nb = nb;
-  p.ntiles = (nb + 63) / 64;
-  // 2 nets x nwg workgroups, two resident per CU: nwg = #CUs covers the chip; more tiles -> tiles walked per workgroup
-  p.nwg = p.ntiles < ctx->num_cu ? p.ntiles : ctx->num_cu;
+  ph::grad_plan(nd, nb, ctx->num_cu, &p.ntiles, &p.nwg);
   return p;
 }
 
@@ -664,7 +662,7 @@ int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, cons
   const int N = rb->T * rb->E;
   const int n_mb = (N + batch_size - 1) / batch_size;
   const int P = nd.lay.P;
-  const MbPlan big = plan_minibatch(ctx, batch_size < N ? batch_size : N);
+  const MbPlan big = plan_minibatch(ctx, nd, batch_size < N ? batch_size : N);
   if (ensure_train_ws(ctx, P, big.nwg, n_epochs * n_mb, perms ? 0 : (size_t)n_epochs * N)) return 1;
   hipStream_t s = ctx->stream;
 
@@ -693,7 +691,7 @@ int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, cons
     for (int k = 0; k < n_mb; ++k) {
       const int start = k * batch_size;
       const int nb = (N - start < batch_size) ? N - start : batch_size;
-      const MbPlan pl = plan_minibatch(ctx, nb);
+      const MbPlan pl = plan_minibatch(ctx, nd, nb);
       const int mbi = ep * n_mb + k;
       ph::GradArgs g;
       std::memset(&g, 0, sizeof(g));
@@ -765,7 +763,7 @@ int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params,
   ph::NetDims nd;
   if (resolve(ctx, spec, &nd)) return 1;
   const int P = nd.lay.P;
-  const MbPlan pl = plan_minibatch(ctx, nb);
+  const MbPlan pl = plan_minibatch(ctx, nd, nb);
   if (ensure_train_ws(ctx, P, pl.nwg, 1)) return 1;
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
@@ -822,7 +820,7 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   if (resolve(ctx, spec, &nd)) return 1;
   const int N = rb->T * rb->E;
   const int nb = batch_size < N ? batch_size : N;
-  const MbPlan pl = plan_minibatch(ctx, nb);
+  const MbPlan pl = plan_minibatch(ctx, nd, nb);
   if (ensure_train_ws(ctx, nd.lay.P, pl.nwg, 1, (size_t)N)) return 1;
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));

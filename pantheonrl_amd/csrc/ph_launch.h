@@ -175,6 +175,12 @@ hipError_t launch_liar_step(const int* hands, int* history, int* nmoves, const i
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
 // single-chunk / small-Discrete-head variant (ph_ppo_fast.hip); eligible() says whether the spec fits it
 bool grad_fast_eligible(const NetDims& nd);
+// row-parallel variant (ph_ppo_rp.hip): Box observations, single chunk, small Discrete head; rows walked in 16-row blocks
+bool grad_rp_eligible(const NetDims& nd);
+void grad_rp_plan(int nb, int num_cu, int* ntiles16, int* nwg);
+hipError_t launch_ppo_grad_rp(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
+// tiles (GradArgs.ntiles) and workgroups per net that launch_ppo_grad will use for a minibatch of nb rows
+void grad_plan(const NetDims& nd, int nb, int num_cu, int* ntiles, int* nwg);
 hipError_t launch_ppo_grad_fast(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s);

@@ -499,7 +499,18 @@ int grad_variant() {
   return v;
 }
 
+void grad_plan(const NetDims& nd, int nb, int num_cu, int* ntiles, int* nwg) {
+  if (grad_rp_eligible(nd)) {
+    grad_rp_plan(nb, num_cu, ntiles, nwg);
+    return;
+  }
+  // 64-row tiles; 2 nets x nwg workgroups, two resident per CU: nwg = #CUs covers the chip, more tiles are walked
+  *ntiles = (nb + 63) / 64;
+  *nwg = *ntiles < num_cu ? *ntiles : num_cu;
+}
+
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s) {
+  if (grad_rp_eligible(a.nd)) return launch_ppo_grad_rp(a, nwg, gemm_mode, s);
   if (grad_fast_eligible(a.nd)) return launch_ppo_grad_fast(a, nwg, gemm_mode, s);
   if (a.nd.Lp != 32 && a.nd.Lp != 64) return hipErrorInvalidValue;
   const bool lp64 = a.nd.Lp == 64;
