@@ -128,6 +128,26 @@ __device__ __forceinline__ f32x16 tile_mma(const float* A, int lda, const float*
   return acc;
 }
 
+// ---- 16x16x4 f32 MFMA tile step ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// D[4g+r][c] += sum_k A[c'][k] B[k][c]: lane (c = lane&15, g = lane>>4) supplies a = A[c][g], b = B[g][c].
+// VALU restatement (gemm_mode 1): the same lanes' operands fetched with ds_bpermute, k-ordered fmaf chain.
+template <bool VALU>
+__device__ __forceinline__ f32x4 mma16(float a, float b, f32x4 acc, int lane) {
+  if constexpr (!VALU) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+  } else {
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float bk = __shfl(b, c + 16 * k, 64);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(__shfl(a, 4 * g + r + 16 * k, 64), bk, acc[r]);
+    }
+    return acc;
+  }
+}
+
 // ---- counter-based RNG: Philox4x32-10 --------------------------------------------------------------------
 __device__ __host__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll

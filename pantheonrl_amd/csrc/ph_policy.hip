@@ -21,6 +21,110 @@ __device__ __forceinline__ long long rb_row(const FwdArgs& a, int g) {
   return (long long)p * a.n + g;
 }
 
+// value-net tail of one row: cache V, write the rollout-buffer row scalars, fold the previous step's late reward in
+__device__ __forceinline__ void value_row_tail(const FwdArgs& a, int g, float v) {
+  const long long ridx = a.rb_val ? rb_row(a, g) : -1;
+  if (a.values && (!a.pos_env || ridx >= 0)) a.values[g] = v;  // ragged: V of the last RECORDED action is cached
+  if (ridx >= 0) {
+    a.rb_val[ridx] = v;
+    a.rb_rew[ridx] = 0.f;
+    a.rb_es[ridx] = a.es_in[g];
+    if (a.pending_reward) {
+      float add = a.pending_reward[g];
+      if (a.joint) {  // shared coordination term of the synthetic SimultaneousEnv transition (joint action)
+        int p = *a.partner_seat;
+        p = p < 0 ? 0 : (p >= a.n_seats ? a.n_seats - 1 : p);
+        add += (a.joint[(size_t)a.seat * a.n + g] == a.joint[(size_t)p * a.n + g]) ? a.bonus : 0.f;
+      }
+      a.prev_rew[g] += add;
+    }
+  }
+}
+
+// RolloutBuffer.add copies the observation (agents.py:172-173): rows [row0, row0 + nrow) by the whole workgroup
+__device__ __forceinline__ void copy_obs_rows(const FwdArgs& a, int row0, int nrow, int D) {
+  if (!a.rb_obs) return;
+  const int tid = threadIdx.x;
+  if (!a.pos_env) {
+    const size_t off = (size_t)row0 * D;
+    for (int e = tid; e < nrow * D; e += blockDim.x) a.rb_obs[off + e] = a.obs[off + e];
+  } else {
+    for (int e = tid; e < nrow * D; e += blockDim.x) {
+      const int r = e / D, d = e - r * D;
+      const long long ridx = rb_row(a, row0 + r);
+      if (ridx >= 0) a.rb_obs[(size_t)ridx * D + d] = a.obs[(size_t)(row0 + r) * D + d];
+    }
+  }
+}
+
+// Discrete action space with <= 8 logits, one lane per row, the row's logits in registers (z[k >= L] ignored): optional
+// mask offset, logits output, sampling / argmax / given action, log-prob, entropy and the rollout-buffer writes
+__device__ __forceinline__ void discrete8_row_tail(const FwdArgs& a, const NetDims& nd, int g, float (&zr)[8]) {
+  const int nk = nd.L;
+  const uint64_t ctr = a.counter + (a.epoch ? (uint64_t)(*a.epoch) << 32 : 0ull);
+  if (a.mask) {  // modular/policies.py:330-333 : logits - 30*(~mask)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < nk) zr[k] = zr[k] - 30.0f * (1.0f - (float)(a.mask[(size_t)g * nk + k] != 0));
+  }
+  if (a.logits) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < nk) a.logits[(size_t)g * nk + k] = zr[k];
+  }
+  float pr[8];
+  float m = -3.0e38f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    zr[k] = (k < nk) ? zr[k] : -3.0e38f;
+    m = fmaxf(m, zr[k]);
+  }
+  float se = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    pr[k] = (k < nk) ? fast_exp(zr[k] - m) : 0.f;
+    se += pr[k];
+  }
+  const float lse = m + fast_log(se), inv = __builtin_amdgcn_rcpf(se);
+  int act = 0;
+  if (a.given_actions) {
+    act = (int)a.given_actions[g];
+    act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
+  } else if (a.deterministic) {
+    float best = zr[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+      if (k < nk && zr[k] > best) { best = zr[k]; act = k; }
+  } else {
+    const float u = a.uniforms ? a.uniforms[g] : philox_uniform(a.seed, ctr, (uint32_t)g, 0u);
+    float cum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {  // inverse CDF: count prefix sums <= u
+      cum += pr[k] * inv;
+      act += (k < nk - 1 && u >= cum) ? 1 : 0;
+    }
+  }
+  float zact = 0.f, ent = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float lp = zr[k] - lse;
+    ent -= (k < nk) ? pr[k] * inv * lp : 0.f;
+    zact = (k == act) ? zr[k] : zact;
+  }
+  const float logp = zact - lse;
+  if (a.act_i32) a.act_i32[g] = act;
+  if (a.act_f32) a.act_f32[g] = (float)act;
+  if (a.logp) a.logp[g] = logp;
+  if (a.entropy) a.entropy[g] = ent;
+  if (a.rb_act || a.rb_logp) {
+    const long long ridx = rb_row(a, g);
+    if (ridx >= 0) {
+      if (a.rb_act) a.rb_act[ridx] = (float)act;
+      if (a.rb_logp) a.rb_logp[ridx] = logp;
+    }
+  }
+}
+
 template <int R, int LP, bool VALU>
 __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -121,38 +225,9 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
     if (tid < R && rowphys[tid] >= 0) {
       float v = 0.f;
       for (int j = 0; j < HID; ++j) v = __builtin_fmaf(bufA[tid * LDH + j], bos[j], v);
-      v += a.params[lay.val_b];
-      const int g = row0 + tid;
-      const long long ridx = a.rb_val ? rb_row(a, g) : -1;
-      if (a.values && (!a.pos_env || ridx >= 0)) a.values[g] = v;  // ragged: V of the last RECORDED action is cached
-      if (ridx >= 0) {
-        a.rb_val[ridx] = v;
-        a.rb_rew[ridx] = 0.f;
-        a.rb_es[ridx] = a.es_in[g];
-        if (a.pending_reward) {
-          float add = a.pending_reward[g];
-          if (a.joint) {  // shared coordination term of the synthetic SimultaneousEnv transition (joint action)
-            int p = *a.partner_seat;
-            p = p < 0 ? 0 : (p >= a.n_seats ? a.n_seats - 1 : p);
-            add += (a.joint[(size_t)a.seat * a.n + g] == a.joint[(size_t)p * a.n + g]) ? a.bonus : 0.f;
-          }
-          a.prev_rew[g] += add;
-        }
-      }
+      value_row_tail(a, row0 + tid, v + a.params[lay.val_b]);
     }
-    if (a.rb_obs) {  // RolloutBuffer.add copies the observation (agents.py:172-173)
-      const int nrow = (a.n - row0 < R) ? a.n - row0 : R;
-      if (!a.pos_env) {
-        const size_t off = (size_t)row0 * nd.D;
-        for (int e = tid; e < nrow * nd.D; e += blockDim.x) a.rb_obs[off + e] = a.obs[off + e];
-      } else {
-        for (int e = tid; e < nrow * nd.D; e += blockDim.x) {
-          const int r = e / nd.D, d = e - r * nd.D;
-          const long long ridx = rb_row(a, row0 + r);
-          if (ridx >= 0) a.rb_obs[(size_t)ridx * nd.D + d] = a.obs[(size_t)(row0 + r) * nd.D + d];
-        }
-      }
-    }
+    copy_obs_rows(a, row0, (a.n - row0 < R) ? a.n - row0 : R, nd.D);
     PH_STAMP(a.prof, 7);
     return;
   }
@@ -179,61 +254,21 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
     const int g = row0 + tid;
     float* z = outs + tid * LDO;
     const uint64_t ctr = a.counter + (a.epoch ? (uint64_t)(*a.epoch) << 32 : 0ull);
-    if (a.mask) {  // modular/policies.py:330-333 : logits - 30*(~mask)
+    const bool small = nd.A == 1 && nd.L <= 8;
+    if (a.mask && !small) {  // modular/policies.py:330-333 : logits - 30*(~mask)
       for (int k = 0; k < nd.L; ++k) z[k] = z[k] - 30.0f * (1.0f - (float)(a.mask[(size_t)g * nd.L + k] != 0));
     }
-    if (a.logits)
+    if (a.logits && !small)
       for (int k = 0; k < nd.L; ++k) a.logits[(size_t)g * nd.L + k] = z[k];
     float logp = 0.f, ent = 0.f;
-    if (nd.A == 1 && nd.L <= 8) {
+    if (small) {
       // fast path (Discrete action space, <= 8 logits): the row lives in registers, one exp per logit
-      const int nk = nd.L;
-      float zr[8], pr[8];
-      float m = -3.0e38f;
+      float zr[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        zr[k] = (k < nk) ? z[k] : -3.0e38f;
-        m = fmaxf(m, zr[k]);
-      }
-      float se = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        pr[k] = (k < nk) ? fast_exp(zr[k] - m) : 0.f;
-        se += pr[k];
-      }
-      const float lse = m + fast_log(se), inv = __builtin_amdgcn_rcpf(se);
-      int act = 0;
-      if (a.given_actions) {
-        act = (int)a.given_actions[g];
-        act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
-      } else if (a.deterministic) {
-        float best = zr[0];
-#pragma unroll
-        for (int k = 1; k < 8; ++k)
-          if (k < nk && zr[k] > best) { best = zr[k]; act = k; }
-      } else {
-        const float u = a.uniforms ? a.uniforms[g] : philox_uniform(a.seed, ctr, (uint32_t)g, 0u);
-        float cum = 0.f;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {  // inverse CDF: count prefix sums <= u
-          cum += pr[k] * inv;
-          act += (k < nk - 1 && u >= cum) ? 1 : 0;
-        }
-      }
-      float zact = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float lp = zr[k] - lse;
-        ent -= (k < nk) ? pr[k] * inv * lp : 0.f;
-        zact = (k == act) ? zr[k] : zact;
-      }
-      logp = zact - lse;
-      if (a.act_i32) a.act_i32[g] = act;
-      if (a.act_f32) a.act_f32[g] = (float)act;
-      if (a.rb_act) {
-        const long long ridx = rb_row(a, g);
-        if (ridx >= 0) a.rb_act[ridx] = (float)act;
-      }
+      for (int k = 0; k < 8; ++k) zr[k] = (k < nd.L) ? z[k] : 0.f;
+      discrete8_row_tail(a, nd, g, zr);
+      PH_STAMP(a.prof, 7);
+      return;
     } else
     for (int c = 0; c < nd.A; ++c) {
       const int lo = nd.act_off[c], nk = nd.act_off[c + 1] - lo;
@@ -283,6 +318,200 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
     }
   }
   PH_STAMP(a.prof, 7);
+}
+
+
+// ---- 16-row variant for the rollout step (single feature chunk, Discrete head with <= 8 logits) -------------------------
+// The step forward of E = 1024 environments is a latency chain, not a throughput problem: 32-row workgroups leave 3/4 of the
+// CUs idle and every layer costs a 32-MFMA dependent chain per wave.  Here a workgroup owns 16 rows and each of its four
+// waves one 16-column output tile of a layer: 16 v_mfma_f32_16x16x4_f32 in two interleaved accumulator chains per
+// layer, twice the workgroups, and the head runs as a register-resident VALU phase (four lanes per row) in one wave.
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_sum_f(float v) {
+  v += dpp_quad_f<0xB1>(v);  // quad_perm [1,0,3,2]
+  v += dpp_quad_f<0x4E>(v);  // quad_perm [2,3,0,1]
+  return v;
+}
+
+template <bool VALU>
+__device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int R = 16, NT = 256;
+  const NetDims& nd = a.nd;
+  float* xs = smem;                 // [16][LDH]  X, later H2
+  float* hs = xs + R * LDH;         // [16][LDH]  H1
+  float* w1s = hs + R * LDH;        // [64][LDH]
+  float* w2s = w1s + HID * LDH;     // [64][LDH]
+  float* hw = w2s + HID * LDH;      // policy: act_W [64][8] | value: val_W [64]
+  float* b1s = hw + HID * 8;        // [64]
+  float* b2s = b1s + HID;           // [64]
+  float* hbs = b2s + HID;           // act_b [8] | val_b
+  int* rowphys = (int*)(hbs + 8);   // [16]
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int net = blockIdx.y;
+  const int row0 = blockIdx.x * R;
+  const ph_layout& lay = nd.lay;
+  const float* W1 = a.params + (net == 0 ? lay.pi_W1 : lay.vf_W1);
+  const float* B1 = a.params + (net == 0 ? lay.pi_b1 : lay.vf_b1);
+  const float* W2 = a.params + (net == 0 ? lay.pi_W2 : lay.vf_W2);
+  const float* B2 = a.params + (net == 0 ? lay.pi_b2 : lay.vf_b2);
+  const int nk = nd.L;
+
+  PH_STAMP(a.prof, 0);
+  // every global load of the kernel is issued here; row indices are trivial (row0 + r), so X needs no metadata pass
+  if (tid < R) rowphys[tid] = (row0 + tid < a.n) ? row0 + tid : -1;
+  WStage<NT> w1r, w2r;
+  w1r.issue(W1, 0, nd.F);
+  w2r.issue(W2, 0, HID);
+  float bias1 = 0.f, bias2 = 0.f, hv0 = 0.f, hv1 = 0.f, hb = 0.f;
+  if (tid < HID) {
+    bias1 = B1[tid];
+    bias2 = B2[tid];
+  }
+  if (net == 0) {
+    const int j0 = tid >> 3, k = tid & 7;  // elements tid and tid + 256 of the [64][8] block
+    if (k < nk) {
+      hv0 = a.params[lay.act_W + j0 * nk + k];
+      hv1 = a.params[lay.act_W + (j0 + 32) * nk + k];
+    }
+    if (tid < 8 && tid < nk) hb = a.params[lay.act_b + tid];
+  } else {
+    if (tid < HID) hv0 = a.params[lay.val_W + tid];
+    if (tid == 0) hb = a.params[lay.val_b];
+  }
+  XStage<R, NT> xr;
+  lds_only_barrier();  // rowphys visible
+  xr.issue(rowphys, a.obs, nd, 0);
+  w1r.commit(w1s);
+  w2r.commit(w2s);
+  if (tid < HID) {
+    b1s[tid] = bias1;
+    b2s[tid] = bias2;
+  }
+  if (net == 0) {
+    hw[tid] = hv0;
+    hw[tid + 256] = hv1;
+    if (tid < 8) hbs[tid] = hb;
+  } else {
+    if (tid < HID) hw[tid] = hv0;
+    if (tid == 0) hbs[0] = hb;
+  }
+  xr.commit(xs, rowphys, a.obs, nd, 0);
+  lds_only_barrier();
+  PH_STAMP(a.prof, 1);
+
+  // one 16x16 output tile per wave: D[row 4g+r][col 16*wave + c] = sum_k A[row][k] W[k][col]; two accumulator chains
+  auto layer = [&](const float* A, const float* W) -> f32x4 {
+    f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = A + c * LDH + g;
+    const float* bp = W + g * LDH + 16 * wave + c;
+    float av[16], bv[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      av[s] = ap[4 * s];
+      bv[s] = bp[4 * s * LDH];
+    }
+#pragma unroll
+    for (int s = 0; s < 16; s += 2) {
+      e = mma16<VALU>(av[s], bv[s], e, lane);
+      o = mma16<VALU>(av[s + 1], bv[s + 1], o, lane);
+    }
+    return e + o;
+  };
+  {
+    const f32x4 z1 = layer(xs, w1s);
+    const float b = b1s[16 * wave + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hs[(4 * g + r) * LDH + 16 * wave + c] = fast_tanh(z1[r] + b);
+  }
+  lds_only_barrier();
+  PH_STAMP(a.prof, 3);
+  {
+    const f32x4 z2 = layer(hs, w2s);
+    const float b = b2s[16 * wave + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xs[(4 * g + r) * LDH + 16 * wave + c] = fast_tanh(z2[r] + b);   // X is dead: H2 over it
+  }
+  lds_only_barrier();
+  PH_STAMP(a.prof, 5);
+
+  // ---- head: wave 0, four lanes per row (16 hidden units each), quad-DPP reduction; the other waves copy observations ----
+  if (wave == 0) {
+    const int r = lane >> 2, q = lane & 3;
+    const int grow = row0 + r;
+    float h[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) h[m] = xs[r * LDH + 8 * q + (m & 7) + 32 * (m >> 3)];
+    if (net == 0) {
+      float z[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) z[k] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const float4* w = reinterpret_cast<const float4*>(hw + (8 * q + (m & 7) + 32 * (m >> 3)) * 8);
+        const float4 w0 = w[0], w1 = w[1];
+        z[0] = __builtin_fmaf(h[m], w0.x, z[0]);
+        z[1] = __builtin_fmaf(h[m], w0.y, z[1]);
+        z[2] = __builtin_fmaf(h[m], w0.z, z[2]);
+        z[3] = __builtin_fmaf(h[m], w0.w, z[3]);
+        z[4] = __builtin_fmaf(h[m], w1.x, z[4]);
+        z[5] = __builtin_fmaf(h[m], w1.y, z[5]);
+        z[6] = __builtin_fmaf(h[m], w1.z, z[6]);
+        z[7] = __builtin_fmaf(h[m], w1.w, z[7]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) z[k] = quad_sum_f(z[k]) + ((k < nk) ? hbs[k] : 0.f);
+      if (q == 0 && grow < a.n) discrete8_row_tail(a, nd, grow, z);
+    } else {
+      float v = 0.f;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) v = __builtin_fmaf(h[m], hw[8 * q + (m & 7) + 32 * (m >> 3)], v);
+      v = quad_sum_f(v) + hbs[0];
+      if (q == 0 && grow < a.n) value_row_tail(a, grow, v);
+    }
+  }
+  if (net == 1) copy_obs_rows(a, row0, (a.n - row0 < R) ? a.n - row0 : R, nd.D);
+  PH_STAMP(a.prof, 7);
+}
+
+template <bool VALU>
+__global__ __launch_bounds__(256) void policy_fwd16_kernel(FwdArgs a) {
+  policy_fwd16_body<VALU>(a);
+}
+__global__ __launch_bounds__(256) void policy_fwd16_multi_kernel(FwdMulti m) {
+  policy_fwd16_body<false>(m.a[blockIdx.z]);
+}
+
+static size_t fwd16_lds_bytes() { return sizeof(float) * (size_t)(2 * 16 * LDH + 2 * HID * LDH + HID * 8 + 2 * HID + 8 + 16); }
+
+bool fwd16_eligible(const NetDims& nd, int n) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("PH_FWD16");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  return enabled && nd.nchunk == 1 && nd.A == 1 && nd.L <= 8 && n < 16384;
+}
+
+template <bool VALU>
+static hipError_t launch_fwd16_variant(const FwdArgs& a, hipStream_t s) {
+  static bool allowed = false;  // dynamic LDS above 64 KiB is opt-in, once per kernel
+  const size_t lds = fwd16_lds_bytes();
+  if (!allowed && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)policy_fwd16_kernel<VALU>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    allowed = true;
+  }
+  hipLaunchKernelGGL((policy_fwd16_kernel<VALU>), dim3((a.n + 15) / 16, 2), dim3(256), lds, s, a);
+  return hipGetLastError();
 }
 
 template <int R, int LP, bool VALU>
@@ -336,6 +565,10 @@ static hipError_t launch_fwd_multi_variant(const FwdMulti& m, int n_agents, hipS
 
 // all records must share n and the padded logit count (checked by the ABI layer)
 hipError_t launch_policy_fwd_multi(const FwdMulti& m, int n_agents, hipStream_t s) {
+  if (fwd16_eligible(m.a[0].nd, m.a[0].n)) {
+    hipLaunchKernelGGL(policy_fwd16_multi_kernel, dim3((m.a[0].n + 15) / 16, 2, n_agents), dim3(256), fwd16_lds_bytes(), s, m);
+    return hipGetLastError();
+  }
   const bool big = m.a[0].n >= 16384;
   const bool lp64 = m.a[0].nd.Lp == 64;
   if (big) return lp64 ? launch_fwd_multi_variant<64, 64>(m, n_agents, s) : launch_fwd_multi_variant<64, 32>(m, n_agents, s);
@@ -347,6 +580,7 @@ hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s) {
   const bool big = (gemm_mode == 0 && a.n >= 16384);
   const bool lp64 = a.nd.Lp == 64;
   if (a.nd.Lp != 32 && a.nd.Lp != 64) return hipErrorInvalidValue;
+  if (fwd16_eligible(a.nd, a.n)) return gemm_mode != 0 ? launch_fwd16_variant<true>(a, s) : launch_fwd16_variant<false>(a, s);
   if (gemm_mode != 0) return lp64 ? launch_fwd_variant<32, 64, true>(a, s) : launch_fwd_variant<32, 32, true>(a, s);
   if (big) return lp64 ? launch_fwd_variant<64, 64, false>(a, s) : launch_fwd_variant<64, 32, false>(a, s);
   return lp64 ? launch_fwd_variant<32, 64, false>(a, s) : launch_fwd_variant<32, 32, false>(a, s);

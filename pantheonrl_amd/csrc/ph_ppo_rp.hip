@@ -22,28 +22,8 @@
 
 namespace ph {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 __device__ __forceinline__ int swz(int row) { return ((2 * row) & 62) ^ (16 * ((row ^ (row >> 2)) & 1)); }
 __device__ __forceinline__ int sidx(int row, int col) { return row * 64 + (col ^ swz(row)); }
-
-// D[4g+r][c] += sum_k A[c'][k] B[k][c]: lane (c = lane&15, g = lane>>4) supplies a = A[c][g], b = B[g][c].
-// VALU restatement (gemm_mode 1): the same lanes' operands fetched with ds_bpermute, k-ordered fmaf chain.
-template <bool VALU>
-__device__ __forceinline__ f32x4 mma16(float a, float b, f32x4 acc, int lane) {
-  if constexpr (!VALU) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-  } else {
-    const int c = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float bk = __shfl(b, c + 16 * k, 64);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(__shfl(a, 4 * g + r + 16 * k, 64), bk, acc[r]);
-    }
-    return acc;
-  }
-}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_row(float v) {
@@ -617,8 +597,8 @@ __global__ __launch_bounds__(RP_NT, 1) void ppo_grad_rp_kernel(GradArgs a) {
 bool grad_rp_eligible(const NetDims& nd) {
   static int enabled = -1;
   if (enabled < 0) {
-    const char* e = getenv("PH_GRAD_RP");
-    enabled = (e && e[0] == '0') ? 0 : 1;
+    const char* e = getenv("PH_GRAD_RP");   // opt-in: measured 44.5 us vs 42.2 us for ppo_grad_fast_kernel at the bench shape
+    enabled = (e && e[0] == '1') ? 1 : 0;
   }
   return enabled && nd.obs_kind == PH_SPACE_BOX && nd.nchunk == 1 && nd.A == 1 && nd.L <= 8;
 }

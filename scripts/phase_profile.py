@@ -49,8 +49,12 @@ for rep in range(2):
     agent.n_steps = 0
     agent.get_action(data.obs[0])
     th.cuda.synchronize()
-report("policy_fwd", (E + 31) // 32, 2, ["all staging loads+commit", "(chunk loop entry)", "L1 mma", "H1 tanh", "L2 mma+tanh",
-                                        "head mma", "sampling / value+obs copy"])
+if os.environ.get("PH_FWD16", "1") != "0":
+    report("policy_fwd16", (E + 15) // 16, 2, ["staging (W1, W2, X, head) + barriers", "L1 mma+tanh", "L2 mma+tanh",
+                                              "head + tail"], slots=[0, 1, 3, 5, 7])
+else:
+    report("policy_fwd", (E + 31) // 32, 2, ["all staging loads+commit", "(chunk loop entry)", "L1 mma", "H1 tanh",
+                                            "L2 mma+tanh", "head mma", "sampling / value+obs copy"])
 st = stamps.cpu().numpy().reshape(-1, 16)[:(E + 31) // 32]
 for lab, a0, a1 in (("issue W2/W1/Wo/bias", 0, 8), ("barrier(rowphys)", 8, 9), ("X issue + W2 commit", 9, 10),
                     ("W1/Wo/bias commit", 10, 11), ("X commit + barrier", 11, 1)):
@@ -65,7 +69,7 @@ nat.check(lib.ph_bench_ppo_grad(h, C.byref(pol.spec), pol.params.data_ptr(), C.b
 th.cuda.synchronize()
 nwg = min((model.batch_size + 63) // 64, 256)
 print(f"ppo_grad launch {ms.value * 1e3:.1f} us, {nwg} workgroups per net")
-if os.environ.get("PH_GRAD_RP", "1") != "0":
+if os.environ.get("PH_GRAD_RP", "0") == "1":
     report("ppo_grad_rp", min((model.batch_size + 127) // 128, 128), 2,
            ["prologue + T0", "P1 S1 mma+tanh", "P1 S2 mma+tanh", "P1 head + B1", "P2 dW2 (all rows)", "P2 dH1, dZ1, B2, B3",
             "P3 dW1 + B4", "remaining steps", "epilogue"], slots=[0, 1, 2, 3, 4, 5, 6, 7, 12, 13])
