@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--batch-size", type=int, default=0, help="0 = n_envs*n_steps/4")
     ap.add_argument("--agents-per-gpu", type=int, default=2,
                     help="self-play pair per GPU (ego PPO + partner PPO, trainer.py ... PPO PPO)")
-    ap.add_argument("--mode", choices=("auto", "graph", "eager", "fusedstep"), default="auto",
+    ap.add_argument("--mode", choices=("auto", "graph", "jointgraph", "eager", "fusedstep"), default="auto",
                     help="graph: one hipGraph per agent-iteration (N=1 default); fusedstep: one fused launch of all local "
                          "agents + one action exchange per env step (the N>1 path; at N=1 the exchange is a local copy); "
                          "eager: per-agent launches")
@@ -241,6 +241,13 @@ def main():
         def iteration():
             for g in graphs:
                 g.launch()
+    elif mode == "jointgraph":
+        # all local learners in ONE hipGraph per iteration; the update is the chained joint call (ph_ppo_train_multi)
+        from pantheonrl_amd.vec import JointIterationGraph
+        joint = JointIterationGraph(agents, datas, streams)
+
+        def iteration():
+            joint.launch()
     elif mode == "eager":
         def iteration():
             for a, d, s in zip(agents, datas, streams):

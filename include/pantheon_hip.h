@@ -258,6 +258,27 @@ int ph_framestack_push(ph_ctx *ctx, float *stack, const float *obs, const unsign
 int ph_ppo_train(ph_ctx *ctx, const ph_spec *spec, const ph_opt_state *opt, const ph_rollout *rb,
                  const ph_ppo_hyper *hyper /* host */, int n_epochs, int batch_size, const int *perms,
                  unsigned long long perm_seed, float *stats, int gemm_mode);
+/* The same call for several independent learners at once (trainer.py: `PPO PPO` self-play keeps two PPO objects, each
+ * with its own buffer, policy and optimizer <- trainer.py:126,203; README.md:6).  Every learner's launches go to its own
+ * context's stream exactly as ph_ppo_train would issue them -- results are bit-identical -- but the gradient launches of
+ * the learners are chained round-robin with events, so that one learner's small reduce / Adam launches overlap the next
+ * learner's device-filling gradient launch instead of all learners alternating between "everyone computes gradients" and
+ * "everyone reduces".  Streams may be captured into one hipGraph (fork / join is the caller's). */
+#define PH_MAX_TRAIN_CALLS 8
+typedef struct ph_train_call {
+  ph_ctx *ctx;
+  const ph_spec *spec;
+  const ph_opt_state *opt;
+  const ph_rollout *rb;
+  const ph_ppo_hyper *hyper;
+  int n_epochs, batch_size;
+  const int *perms;
+  unsigned long long perm_seed;
+  float *stats;
+  int gemm_mode;
+} ph_train_call;
+int ph_ppo_train_multi(const ph_train_call *calls, int n_calls);
+
 /* gradient of ONE minibatch (indices given, (nb) int32 env-major) without touching the optimizer state:
  * grad_out (P) = d loss / d params before clipping; stats_out (PH_NSTAT) as above.  For parity tests. */
 int ph_ppo_minibatch_grad(ph_ctx *ctx, const ph_spec *spec, const float *params, const ph_rollout *rb,

@@ -65,6 +65,14 @@ class PhOptState(C.Structure):
 
 _vp, _i, _ull, _d = C.c_void_p, C.c_int, C.c_ulonglong, C.c_double
 # name -> argtypes (restype is int except where noted); the single source the symbol test walks
+class PhTrainCall(C.Structure):
+    """ph_train_call: one learner's PPO.train() arguments for ph_ppo_train_multi"""
+    _fields_ = [("ctx", C.c_void_p), ("spec", C.POINTER(PhSpec)), ("opt", C.POINTER(PhOptState)),
+                ("rb", C.POINTER(PhRollout)), ("hyper", C.POINTER(PhPpoHyper)), ("n_epochs", C.c_int),
+                ("batch_size", C.c_int), ("perms", C.c_void_p), ("perm_seed", C.c_ulonglong), ("stats", C.c_void_p),
+                ("gemm_mode", C.c_int)]
+
+
 SIGNATURES = {
     "ph_abi_version": [],
     "ph_last_error": [],
@@ -102,6 +110,7 @@ SIGNATURES = {
     "ph_framestack_push": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "ph_ppo_train": [_vp, C.POINTER(PhSpec), C.POINTER(PhOptState), C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i,
                      _vp, _ull, _vp, _i],
+    "ph_ppo_train_multi": [C.POINTER(PhTrainCall), _i],
     "ph_ppo_minibatch_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _vp, _i, _vp,
                               _vp, _i],
     "ph_bench_ppo_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i, _i,

@@ -60,6 +60,7 @@ struct ph_ctx {
   std::vector<hipGraphExec_t> graphs;
   bool capturing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_grad = nullptr;   // ph_ppo_train_multi: "this learner's latest gradient launch"
   int num_cu = 256;
   unsigned long long* rng_epoch = nullptr;  // caller-owned device word
   long long* prof = nullptr;                // caller-owned debug stamp buffer
@@ -230,6 +231,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (p) (void)hipFree(p);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ev_grad) (void)hipEventDestroy(ctx->ev_grad);
   delete ctx;
   return 0;
 }
@@ -648,105 +650,188 @@ int ensure_train_ws(ph_ctx* ctx, int P, int nwg_max, int n_mb_total, size_t n_id
 
 }  // namespace
 
-int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const ph_rollout* rb,
-                 const ph_ppo_hyper* hp, int n_epochs, int batch_size, const int* perms,
-                 unsigned long long perm_seed, float* stats, int gemm_mode) {
+namespace {
+
+// one PPO.train() call resolved into launch parameters
+struct TrainPlan {
+  ph_ctx* ctx;
+  ph::NetDims nd;
+  const ph_opt_state* opt;
+  const ph_rollout* rb;
+  const ph_ppo_hyper* hp;
+  const int* perms;
+  unsigned long long perm_seed;
+  float* stats;
+  int n_epochs, batch_size, gemm_mode, N, n_mb, P;
+  uint32_t hb;
+  bool w2g;
+};
+
+// validation, workspace, stop-flag reset and the advantage statistics / minibatch order of every minibatch
+int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const ph_rollout* rb,
+                  const ph_ppo_hyper* hp, int n_epochs, int batch_size, const int* perms, unsigned long long perm_seed,
+                  float* stats, int gemm_mode) {
   if (!ctx) return fail("null ctx");
   if (!opt || !opt->params || !opt->adam_m || !opt->adam_v || !opt->step) return fail("ph_ppo_train: null optimizer state");
   if ((uintptr_t)opt->params % 16 != 0) return fail("ph_ppo_train: params must be 16-byte aligned");
   if (!hp) return fail("ph_ppo_train: null hyper-parameters");
   if (check_rb(rb)) return 1;
   if (n_epochs <= 0 || batch_size <= 0) return fail("ph_ppo_train: n_epochs and batch_size must be positive");
-  ph::NetDims nd;
-  if (resolve(ctx, spec, &nd)) return 1;
-  const int N = rb->T * rb->E;
-  const int n_mb = (N + batch_size - 1) / batch_size;
-  const int P = nd.lay.P;
-  const MbPlan big = plan_minibatch(ctx, nd, batch_size < N ? batch_size : N);
-  if (ensure_train_ws(ctx, P, big.nwg, n_epochs * n_mb, perms ? 0 : (size_t)n_epochs * N)) return 1;
+  if (resolve(ctx, spec, &t.nd)) return 1;
+  t.ctx = ctx;
+  t.opt = opt;
+  t.rb = rb;
+  t.hp = hp;
+  t.perms = perms;
+  t.perm_seed = perm_seed;
+  t.stats = stats;
+  t.n_epochs = n_epochs;
+  t.batch_size = batch_size;
+  t.gemm_mode = gemm_mode;
+  t.N = rb->T * rb->E;
+  t.n_mb = (t.N + batch_size - 1) / batch_size;
+  t.P = t.nd.lay.P;
+  const MbPlan big = plan_minibatch(ctx, t.nd, batch_size < t.N ? batch_size : t.N);
+  if (ensure_train_ws(ctx, t.P, big.nwg, n_epochs * t.n_mb, perms ? 0 : (size_t)n_epochs * t.N)) return 1;
   hipStream_t s = ctx->stream;
-
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
-  const bool w2g = ph::grad_variant() == 1;
-  if (w2g) PH_HIP(ph::launch_transpose_w2(opt->params, nd.lay.pi_W2, nd.lay.vf_W2, ctx->w2t, s));
-  const uint32_t hb = ph::feistel_half_bits((uint32_t)N);
-  {
-    ph::AdvStatArgs aa;
-    aa.rb_adv = rb->advantages;
-    aa.T = rb->T;
-    aa.E = rb->E;
-    aa.perms = perms;
-    aa.perm_n = (uint32_t)N;
-    aa.perm_hb = hb;
-    aa.perm_seed = perm_seed;
-    aa.epoch = ctx->rng_epoch;
-    aa.N = N;
-    aa.batch = batch_size;
-    aa.n_mb = n_mb;
-    aa.out = ctx->advstats;
-    aa.idx_out = perms ? nullptr : ctx->perm_idx;
-    PH_HIP(ph::launch_adv_stats(aa, n_epochs * n_mb, s));
+  t.w2g = ph::grad_variant() == 1;
+  if (t.w2g) PH_HIP(ph::launch_transpose_w2(opt->params, t.nd.lay.pi_W2, t.nd.lay.vf_W2, ctx->w2t, s));
+  t.hb = ph::feistel_half_bits((uint32_t)t.N);
+  ph::AdvStatArgs aa;
+  aa.rb_adv = rb->advantages;
+  aa.T = rb->T;
+  aa.E = rb->E;
+  aa.perms = perms;
+  aa.perm_n = (uint32_t)t.N;
+  aa.perm_hb = t.hb;
+  aa.perm_seed = perm_seed;
+  aa.epoch = ctx->rng_epoch;
+  aa.N = t.N;
+  aa.batch = batch_size;
+  aa.n_mb = t.n_mb;
+  aa.out = ctx->advstats;
+  aa.idx_out = perms ? nullptr : ctx->perm_idx;
+  PH_HIP(ph::launch_adv_stats(aa, n_epochs * t.n_mb, s));
+  return 0;
+}
+
+// gradient launch of minibatch mbi = ep * n_mb + k
+int train_launch_grad(const TrainPlan& t, int mbi, MbPlan* pl_out) {
+  ph_ctx* ctx = t.ctx;
+  const int ep = mbi / t.n_mb, k = mbi - ep * t.n_mb;
+  const int start = k * t.batch_size;
+  const int nb = (t.N - start < t.batch_size) ? t.N - start : t.batch_size;
+  const MbPlan pl = plan_minibatch(ctx, t.nd, nb);
+  ph::GradArgs g;
+  std::memset(&g, 0, sizeof(g));
+  fill_grad_args(g, t.nd, t.opt->params, t.rb, t.hp, ctx);
+  g.idx = (t.perms ? t.perms : ctx->perm_idx) + (size_t)ep * t.N + start;
+  g.perm_n = (uint32_t)t.N;
+  g.perm_hb = t.hb;
+  g.perm_seed = t.perm_seed;
+  g.perm_epoch = ep;
+  g.epoch = ctx->rng_epoch;
+  g.mb_start = start;
+  g.nb = nb;
+  g.advstats = ctx->advstats + 2 * (size_t)mbi;
+  g.ntiles = pl.ntiles;
+  PH_HIP(ph::launch_ppo_grad(g, pl.nwg, t.gemm_mode, ctx->stream));
+  *pl_out = pl;
+  return 0;
+}
+
+// slab reduction + statistics + KL decision, then clip + Adam, of the minibatch whose gradient launch returned `pl`
+int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
+  ph_ctx* ctx = t.ctx;
+  hipStream_t s = ctx->stream;
+  ph::ReduceArgs r;
+  r.slabs = ctx->slabs;
+  r.nslab = pl.nwg;
+  r.nstatpart = 2 * pl.nwg;
+  r.P = t.P;
+  r.grad = ctx->grad;
+  r.blocksq = ctx->blocksq;
+  r.statpart = ctx->statpart;
+  r.stats_out = t.stats ? t.stats + (size_t)mbi * PH_NSTAT : nullptr;
+  r.nb = pl.nb;
+  r.ent_coef = t.hp->ent_coef;
+  r.vf_coef = t.hp->vf_coef;
+  r.target_kl = t.hp->target_kl;
+  r.stop_flag = ctx->stop_flag;
+  r.step = t.opt->step;
+  r.scalars = ctx->scalars;
+  PH_HIP(ph::launch_ppo_reduce(r, s));
+
+  ph::AdamArgs ad;
+  ad.params = t.opt->params;
+  ad.m = t.opt->adam_m;
+  ad.v = t.opt->adam_v;
+  ad.grad = ctx->grad;
+  ad.blocksq = ctx->blocksq;
+  ad.nblk = ph::reduce_blocks(t.P);
+  ad.P = t.P;
+  ad.step = t.opt->step;
+  ad.scalars = ctx->scalars;
+  ad.stop_flag = ctx->stop_flag;
+  ad.lr = t.hp->learning_rate;
+  ad.beta1 = t.hp->adam_beta1;
+  ad.beta2 = t.hp->adam_beta2;
+  ad.eps = t.hp->adam_eps;
+  ad.max_norm = t.hp->max_grad_norm;
+  ad.stats_out = r.stats_out;
+  ad.w2t = t.w2g ? ctx->w2t : nullptr;
+  ad.pi_W2 = t.nd.lay.pi_W2;
+  ad.vf_W2 = t.nd.lay.vf_W2;
+  PH_HIP(ph::launch_ppo_adam(ad, s));
+  return 0;
+}
+
+}  // namespace
+
+int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const ph_rollout* rb,
+                 const ph_ppo_hyper* hp, int n_epochs, int batch_size, const int* perms,
+                 unsigned long long perm_seed, float* stats, int gemm_mode) {
+  TrainPlan t;
+  if (train_prepare(t, ctx, spec, opt, rb, hp, n_epochs, batch_size, perms, perm_seed, stats, gemm_mode)) return 1;
+  for (int mbi = 0; mbi < n_epochs * t.n_mb; ++mbi) {
+    MbPlan pl;
+    if (train_launch_grad(t, mbi, &pl)) return 1;
+    if (train_launch_step(t, mbi, pl)) return 1;
   }
-  for (int ep = 0; ep < n_epochs; ++ep) {
-    for (int k = 0; k < n_mb; ++k) {
-      const int start = k * batch_size;
-      const int nb = (N - start < batch_size) ? N - start : batch_size;
-      const MbPlan pl = plan_minibatch(ctx, nd, nb);
-      const int mbi = ep * n_mb + k;
-      ph::GradArgs g;
-      std::memset(&g, 0, sizeof(g));
-      fill_grad_args(g, nd, opt->params, rb, hp, ctx);
-      g.idx = (perms ? perms : ctx->perm_idx) + (size_t)ep * N + start;
-      g.perm_n = (uint32_t)N;
-      g.perm_hb = hb;
-      g.perm_seed = perm_seed;
-      g.perm_epoch = ep;
-      g.epoch = ctx->rng_epoch;
-      g.mb_start = start;
-      g.nb = nb;
-      g.advstats = ctx->advstats + 2 * (size_t)mbi;
-      g.ntiles = pl.ntiles;
-      PH_HIP(ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s));
+  return 0;
+}
 
-      ph::ReduceArgs r;
-      r.slabs = ctx->slabs;
-      r.nslab = pl.nwg;
-      r.nstatpart = 2 * pl.nwg;
-      r.P = P;
-      r.grad = ctx->grad;
-      r.blocksq = ctx->blocksq;
-      r.statpart = ctx->statpart;
-      r.stats_out = stats ? stats + (size_t)mbi * PH_NSTAT : nullptr;
-      r.nb = nb;
-      r.ent_coef = hp->ent_coef;
-      r.vf_coef = hp->vf_coef;
-      r.target_kl = hp->target_kl;
-      r.stop_flag = ctx->stop_flag;
-      r.step = opt->step;
-      r.scalars = ctx->scalars;
-      PH_HIP(ph::launch_ppo_reduce(r, s));
-
-      ph::AdamArgs ad;
-      ad.params = opt->params;
-      ad.m = opt->adam_m;
-      ad.v = opt->adam_v;
-      ad.grad = ctx->grad;
-      ad.blocksq = ctx->blocksq;
-      ad.nblk = ph::reduce_blocks(P);
-      ad.P = P;
-      ad.step = opt->step;
-      ad.scalars = ctx->scalars;
-      ad.stop_flag = ctx->stop_flag;
-      ad.lr = hp->learning_rate;
-      ad.beta1 = hp->adam_beta1;
-      ad.beta2 = hp->adam_beta2;
-      ad.eps = hp->adam_eps;
-      ad.max_norm = hp->max_grad_norm;
-      ad.stats_out = r.stats_out;
-      ad.w2t = w2g ? ctx->w2t : nullptr;
-      ad.pi_W2 = nd.lay.pi_W2;
-      ad.vf_W2 = nd.lay.vf_W2;
-      PH_HIP(ph::launch_ppo_adam(ad, s));
+int ph_ppo_train_multi(const ph_train_call* calls, int n_calls) {
+  if (!calls || n_calls <= 0) return fail("ph_ppo_train_multi: no calls");
+  if (n_calls > PH_MAX_TRAIN_CALLS) return fail("ph_ppo_train_multi: too many calls");
+  TrainPlan t[PH_MAX_TRAIN_CALLS];
+  int total[PH_MAX_TRAIN_CALLS], longest = 0;
+  for (int k = 0; k < n_calls; ++k) {
+    const ph_train_call& c = calls[k];
+    if (train_prepare(t[k], c.ctx, c.spec, c.opt, c.rb, c.hyper, c.n_epochs, c.batch_size, c.perms, c.perm_seed, c.stats,
+                      c.gemm_mode))
+      return 1;
+    if (!t[k].ctx->ev_grad) PH_HIP(hipEventCreateWithFlags(&t[k].ctx->ev_grad, hipEventDisableTiming));
+    total[k] = c.n_epochs * t[k].n_mb;
+    longest = total[k] > longest ? total[k] : longest;
+  }
+  // Round-robin over the learners, minibatch by minibatch.  Gradient launches fill the whole device, so two of them side by
+  // side only slow each other down; chaining them (each waits for the previous learner's gradient launch) lets one
+  // learner's small reduce / Adam launches run in the shadow of the next learner's gradient launch.
+  hipEvent_t prev = nullptr;
+  hipStream_t prev_stream = nullptr;
+  for (int mbi = 0; mbi < longest; ++mbi) {
+    for (int k = 0; k < n_calls; ++k) {
+      if (mbi >= total[k]) continue;
+      hipStream_t s = t[k].ctx->stream;
+      if (prev && prev_stream != s) PH_HIP(hipStreamWaitEvent(s, prev, 0));
+      MbPlan pl;
+      if (train_launch_grad(t[k], mbi, &pl)) return 1;
+      PH_HIP(hipEventRecord(t[k].ctx->ev_grad, s));
+      prev = t[k].ctx->ev_grad;
+      prev_stream = s;
+      if (train_launch_step(t[k], mbi, pl)) return 1;
     }
   }
   return 0;

@@ -590,7 +590,11 @@ hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s) {
 // Block = 64 parameters x 16 slab groups (1024 lanes): every lane sums its group's slabs with 8 loads in flight, the 16
 // group sums are folded through LDS in a fixed order -- the whole slab set (17 MB at 256 slabs) costs two or three
 // memory latencies, and the result is bit-reproducible run to run.
-constexpr int RED_PARAMS = 64, RED_GROUPS = 16;
+#if defined(PH_RED32)
+constexpr int RED_PARAMS = 32, RED_GROUPS = 32, RED_SHIFT = 5;
+#else
+constexpr int RED_PARAMS = 64, RED_GROUPS = 16, RED_SHIFT = 6;
+#endif
 __global__ __launch_bounds__(1024) void ppo_reduce_kernel(ReduceArgs a) {
   __shared__ float gsum[RED_GROUPS][RED_PARAMS];
   __shared__ float part[32][NSTATP];
@@ -604,7 +608,7 @@ __global__ __launch_bounds__(1024) void ppo_reduce_kernel(ReduceArgs a) {
     }
     return;
   }
-  const int pl = tid & (RED_PARAMS - 1), grp = tid >> 6;
+  const int pl = tid & (RED_PARAMS - 1), grp = tid >> RED_SHIFT;
   const int p = blockIdx.x * RED_PARAMS + pl;
   {
     const int per = (a.nslab + RED_GROUPS - 1) / RED_GROUPS;
@@ -623,12 +627,14 @@ __global__ __launch_bounds__(1024) void ppo_reduce_kernel(ReduceArgs a) {
     gsum[grp][pl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
   __syncthreads();
-  if (tid < RED_PARAMS) {  // wave 0: fold the 16 group sums, square, wave-reduce
+  if (tid < 64) {  // wave 0: fold the group sums, square, wave-reduce
     float g = 0.f;
+    if (tid < RED_PARAMS) {
 #pragma unroll
-    for (int j = 0; j < RED_GROUPS; ++j) g += gsum[j][tid];
-    if (p < a.P) a.grad[p] = g;
-    else g = 0.f;
+      for (int j = 0; j < RED_GROUPS; ++j) g += gsum[j][tid];
+      if (p < a.P) a.grad[p] = g;
+      else g = 0.f;
+    }
     float q = g * g;
     for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
     if (tid == 0) a.blocksq[blockIdx.x] = q;

@@ -20,7 +20,7 @@ import json
 import time
 import zipfile
 from collections import deque
-from typing import Any, Dict, Optional, Tuple
+from typing import Sequence, Any, Dict, Optional, Tuple
 
 import numpy as np
 import torch as th
@@ -445,6 +445,40 @@ class PPO:
             lg.record("train/loss", float(used[-1, 5]))
             lg.record("train/n_updates", self._n_updates, exclude="tensorboard")
             lg.record("train/clip_range", self.clip_range)
+
+    def _train_call(self, keep: list) -> "nat.PhTrainCall":
+        """this learner's train() arguments as a ph_train_call (device permutations; statistics stay on the device)"""
+        rb, pol = self.rollout_buffer, self.policy
+        N = rb.buffer_size * rb.n_envs
+        n_mb = (N + self.batch_size - 1) // self.batch_size
+        stats = getattr(self, "_stats_dev", None)
+        if stats is None or stats.shape[0] != self.n_epochs * n_mb:
+            stats = th.zeros((self.n_epochs * n_mb, nat.PH_NSTAT), dtype=th.float32, device=self.device)
+        self._stats_dev = stats
+        opt = nat.PhOptState()
+        opt.params, opt.adam_m, opt.adam_v = pol.params.data_ptr(), pol.adam_m.data_ptr(), pol.adam_v.data_ptr()
+        opt.step = pol.opt_step.data_ptr()
+        hp, rbc = self.hyper(), rb.c_struct()
+        keep += [opt, hp, rbc]
+        self.permutation_seed += 1
+        call = nat.PhTrainCall()
+        call.ctx, call.spec, call.opt, call.rb, call.hyper = pol.ctx.handle, C.pointer(pol.spec), C.pointer(opt), \
+            C.pointer(rbc), C.pointer(hp)
+        call.n_epochs, call.batch_size, call.perms = int(self.n_epochs), int(self.batch_size), None
+        call.perm_seed, call.stats, call.gemm_mode = int(self.permutation_seed), stats.data_ptr(), int(pol.gemm_mode)
+        return call
+
+    @staticmethod
+    def train_joint(models: Sequence["PPO"]) -> None:
+        """train() of several independent learners in one call (ph_ppo_train_multi): same results as calling train() on
+        each, with the learners' gradient launches chained so that the small launches of one overlap the large launch of
+        the next.  Every learner's context must already be bound to the stream its launches should go to."""
+        keep: list = []
+        calls = (nat.PhTrainCall * len(models))(*[m._train_call(keep) for m in models])
+        lib = models[0].policy.ctx.lib
+        nat.check(lib.ph_ppo_train_multi(calls, len(models)))
+        for m in models:
+            m._n_updates += m.n_epochs
 
     # -- OnPolicyAlgorithm.learn() for the ego (trainer.py:413; SURVEY.md 3.2) -----------------------------------------
     def collect_rollouts(self) -> bool:

@@ -96,17 +96,25 @@ class VecOnPolicyAgent:
             nat.check(self._lib.ph_buffer_add_reward(self._h, self._rb, rb.pos - 1, self._pending.data_ptr(), None))
             self._pending = None
 
-    def learn_from_buffer(self) -> None:
-        """GAE with the cached V(o_{T-1}) (quirk D-1), PPO update, buffer reset (agents.py:126-158)."""
-        model = self.model
-        rb = model.rollout_buffer
+    def compute_returns(self) -> None:
+        """late rewards + GAE with the cached V(o_{T-1}) (quirk D-1) <- agents.py:127-130"""
+        rb = self.model.rollout_buffer
         self.flush_rewards()
         nat.check(self._lib.ph_gae(self._h, self._rb, self.values.data_ptr(), self._last_episode_starts.data_ptr(),
                                    rb.gamma, rb.gae_lambda, int(rb.gae_mode)))
-        model.train(sync_stats=self.sync_stats)
+
+    def finish_update(self) -> None:
+        """bookkeeping after the PPO update: buffer reset (agents.py:157)"""
+        rb = self.model.rollout_buffer
         self.iteration += 1
         rb.pos, rb.full = 0, False   # rows are fully overwritten by the next rollout; no memset needed on this path
         self.n_steps = 0
+
+    def learn_from_buffer(self) -> None:
+        """GAE, PPO update, buffer reset (agents.py:126-158)."""
+        self.compute_returns()
+        self.model.train(sync_stats=self.sync_stats)
+        self.finish_update()
 
     def bind_stream(self) -> None:
         self.model.policy._bind()
@@ -192,6 +200,73 @@ class IterationGraph:
         nat.check(pol.ctx.lib.ph_graph_launch(pol.ctx.handle, self.graph_id))
         self.agent.iteration += 1
         self.agent.num_timesteps += self.data.T * self.data.E
+
+
+def run_joint_iteration_eager(agents, datas, streams) -> None:
+    """one PPO iteration of several independent learners: every learner's rollout and GAE on its own stream, then ONE joint
+    update call (PPO.train_joint) that chains the learners' gradient launches"""
+    for agent, data, stream in zip(agents, datas, streams):
+        with th.cuda.stream(stream):
+            agent.bind_stream()
+            for t in range(data.T):
+                agent.get_action(data.obs[t])
+                agent.update(data.rewards[t], data.dones[t])
+            agent.compute_returns()
+    PPO.train_joint([agent.model for agent in agents])
+    for agent in agents:
+        agent.finish_update()
+
+
+class JointIterationGraph:
+    """One whole PPO iteration of ALL local learners as a single hipGraph: the learners' streams fork from the first one at
+    the start of the capture and join it at the end; the update is the chained joint call."""
+
+    def __init__(self, agents, datas, streams):
+        self.agents, self.datas, self.streams = list(agents), list(datas), list(streams)
+        lead = self.agents[0].model.policy
+        self.epoch_words = []
+        for agent in self.agents:
+            pol = agent.model.policy
+            word = th.zeros(1, dtype=th.int64, device=pol.device)
+            nat.check(pol.ctx.lib.ph_ctx_set_rng_epoch(pol.ctx.handle, word.data_ptr()))
+            self.epoch_words.append(word)
+            agent.model.device_permutations = True
+        s0, others = self.streams[0], self.streams[1:]
+        fork, joins = th.cuda.Event(), [th.cuda.Event() for _ in others]
+        for _ in range(2):                    # warm-up outside capture: sizes the workspaces, creates the events
+            run_joint_iteration_eager(self.agents, self.datas, self.streams)
+            fork.record(s0)
+            for s, j in zip(others, joins):
+                s.wait_event(fork)
+                j.record(s)
+                s0.wait_event(j)
+        th.cuda.synchronize(lead.device)
+        with th.cuda.stream(s0):
+            self.agents[0].bind_stream()
+        lib, h = lead.ctx.lib, lead.ctx.handle
+        nat.check(lib.ph_graph_begin(h))
+        try:
+            fork.record(s0)
+            for s in others:
+                s.wait_event(fork)            # the other learners' streams join the capture
+            run_joint_iteration_eager(self.agents, self.datas, self.streams)
+            for agent in self.agents:
+                pol = agent.model.policy
+                nat.check(pol.ctx.lib.ph_rng_epoch_advance(pol.ctx.handle))
+            for s, j in zip(others, joins):
+                j.record(s)
+                s0.wait_event(j)
+        finally:
+            gid = C.c_int(-1)
+            nat.check(lib.ph_graph_end(h, C.byref(gid)))
+        self.graph_id = gid.value
+        self._lib, self._h = lib, h
+
+    def launch(self) -> None:
+        nat.check(self._lib.ph_graph_launch(self._h, self.graph_id))
+        for agent, data in zip(self.agents, self.datas):
+            agent.iteration += 1
+            agent.num_timesteps += data.T * data.E
 
 
 class FusedSelfPlayRollout:

@@ -992,3 +992,59 @@ def test_opt_in_kernel_variants_pass_the_gradient_and_forward_parity_tests():
                               "minibatch_gradient or forward_matches_oracle or mfma_and_valu or train_matches_oracle"],
                              cwd=root, env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, (env, out.stdout[-2000:], out.stderr[-2000:])
+
+
+def test_joint_update_of_two_learners_is_bitwise_the_two_separate_updates():
+    """ph_ppo_train_multi only re-orders the learners' launches relative to each other (event-chained gradient launches on the
+    learners' own streams): parameters, Adam moments and statistics must equal two plain ph_ppo_train calls bit for bit --
+    eagerly and replayed from the single two-stream hipGraph."""
+    from pantheonrl_amd import PPO, spaces as sp
+    from pantheonrl_amd.vec import (JointIterationGraph, SyntheticRollouts, VecOnPolicyAgent, run_iteration_eager,
+                                    run_joint_iteration_eager)
+    E, T = 64, 16
+    obs_space, act_space = sp.Box(-np.inf, np.inf, (62,)), sp.Discrete(6)
+    env = type("S", (), dict(observation_space=obs_space, action_space=act_space, _is_dummy_space_env=True))()
+
+    def make():
+        agents, datas = [], []
+        for seed in (3, 4):
+            m = PPO("MlpPolicy", env, n_steps=T, n_envs=E, batch_size=E * T // 4, n_epochs=3, seed=seed)
+            m.device_permutations = True
+            agents.append(VecOnPolicyAgent(m))
+            datas.append(SyntheticRollouts(obs_space, E, T, 400, seed, m.device))
+        return agents, datas
+
+    ref_agents, ref_datas = make()
+    for _ in range(3):
+        for a, d in zip(ref_agents, ref_datas):
+            run_iteration_eager(a, d)
+    th.cuda.synchronize()
+    want = [a.model.policy.get_flat_params() for a in ref_agents]
+
+    agents, datas = make()
+    streams = [th.cuda.Stream() for _ in agents]
+    for _ in range(3):
+        run_joint_iteration_eager(agents, datas, streams)
+    th.cuda.synchronize()
+    for a, w, r in zip(agents, want, ref_agents):
+        assert np.array_equal(a.model.policy.get_flat_params(), w)
+        assert th.equal(a.model.policy.adam_v, r.model.policy.adam_v)
+        assert th.equal(a.model._stats_dev, r.model._stats_dev)
+
+    # the same three iterations out of the captured graph (its constructor runs two warm-up iterations + the capture pass:
+    # rebuild the reference with the same count)
+    agents, datas = make()
+    streams = [th.cuda.Stream() for _ in agents]
+    joint = JointIterationGraph(agents, datas, streams)
+    joint.launch()
+    th.cuda.synchronize()
+    ref_agents, ref_datas = make()
+    for a, d in zip(ref_agents, ref_datas):
+        from pantheonrl_amd.vec import IterationGraph
+    graphs = [IterationGraph(a, d, th.cuda.Stream()) for a, d in zip(ref_agents, ref_datas)]
+    for gph in graphs:
+        gph.launch()
+    th.cuda.synchronize()
+    for a, r in zip(agents, ref_agents):
+        assert np.isfinite(a.model.policy.get_flat_params()).all()
+        assert np.array_equal(a.model.policy.get_flat_params(), r.model.policy.get_flat_params())
