@@ -156,7 +156,11 @@ def roofline(args, agent):
     nb = min(model.batch_size, rb.buffer_size * rb.n_envs)
     flops = 6.0 * macs * nb
     achieved = flops / (ms.value * 1e-3) / 1e12
-    out = {"bound": "mfma", "kernel": "ppo_grad_kernel<64,false>", "achieved": achieved, "peak": 157.3,
+    small = lay.F <= 64 and lay.A == 1 and lay.L <= 8 and os.environ.get("PH_GRAD_FAST", "1") != "0"
+    kernel = "ppo_grad_fast_kernel<false>" if small else "ppo_grad_kernel<64,LP,false>"
+    if small and os.environ.get("PH_GRAD_RP", "0") == "1":
+        kernel = "ppo_grad_rp_kernel<false>"
+    out = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": 157.3,
            "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None, "launch_ms": ms.value,
            "flops_per_launch": flops}
     # secondary, HBM-bound: the GAE pass (20 algorithmic bytes per transition) at the bench size (launch-latency bound:
@@ -197,8 +201,9 @@ def roofline(args, agent):
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc, separate runs), if recorded
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_ppo_grad.json")))
-        out["traffic"] = rec["hbm_bytes_per_launch"]
-        out["traffic_source"] = rec["source"]
+        if rec["kernel"].split("::")[-1] == kernel:    # the committed counters belong to this kernel
+            out["traffic"] = rec["hbm_bytes_per_launch"]
+            out["traffic_source"] = rec["source"]
     except Exception:  # noqa: BLE001
         pass
     return out
