@@ -210,6 +210,9 @@ def roofline(args, agent):
 
 
 def main():
+    # RCCL prints a version banner to stdout at communicator creation: keep fd 1 clean for the one JSON line
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     args = parse()
     if args.n_envs <= 0:
         args.n_envs = WORKLOADS[args.workload]["n_envs"]
@@ -239,6 +242,10 @@ def main():
     if distributed:
         mode = "fusedstep"
     exchange = pdist.ActionExchange(len(agents), args.n_envs, device) if (distributed or mode == "fusedstep") else None
+    native_exchange = False
+    if exchange is not None and os.environ.get("PANTHEON_NATIVE_EXCHANGE", "1") != "0":
+        native_exchange = exchange.attach_native(agents[0].model.policy.ctx)   # engine-side RCCL all-gather per step
+        log(f"exchange: {'engine-side RCCL (ph_selfplay_rollout)' if native_exchange else 'torch.distributed'}")
 
     if mode == "graph":
         graphs = [IterationGraph(a, d, s) for a, d, s in zip(agents, datas, streams)]
@@ -309,6 +316,7 @@ def main():
                    "features": agents[0].model.policy.layout.F, "n_logits": agents[0].model.policy.layout.L,
                    "batch_size": args.batch_size, "n_epochs": args.n_epochs, "agents_per_gpu": len(agents),
                    "parallelism": f"agent-per-gpu x{world} ({'per-step RCCL action all-gather' if distributed else 'single process'})",
+                   "exchange": ("engine-side ncclAllGather" if native_exchange else "torch.distributed") if exchange is not None else None,
                    "launch_mode": mode},
     }
     if rank == 0:
@@ -318,7 +326,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(args)
             result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if distributed:
         tdist.barrier()
         tdist.destroy_process_group()

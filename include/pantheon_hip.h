@@ -197,6 +197,25 @@ typedef struct ph_step_call {
 } ph_step_call;
 int ph_policy_step_multi(ph_ctx *ctx, int n_calls, const ph_step_call *calls /* host */);
 
+/* ---- agent-per-GPU action exchange over RCCL ------------------------------------------------------
+ * What MultiAgentEnv._get_actions does in-process (multiagentenv.py:149-170) across ranks: every rank contributes the actions
+ * of its local agents for the current step, every rank receives the joint action.  librccl.so is loaded on first use
+ * (dlopen) -- a build or a node without it still loads this library and gets an error from these calls only.
+ *  ph_comm_unique_id: ncclGetUniqueId on the calling rank (rank 0); the 128 bytes travel to the other ranks through the
+ *      caller's rendezvous (torch.distributed's store).
+ *  ph_comm_init:      ncclCommInitRank for this context (one process per GPU).
+ *  ph_all_gather_i32: joint[r*count .. (r+1)*count) <- rank r's local[0..count), on the context's stream, no host sync.
+ *      Without a communicator (single process) it degenerates to a device copy.
+ *  ph_selfplay_rollout: T environment steps back to back -- step t = ph_policy_step_multi(calls + t*n_calls) followed by
+ *      the all-gather of the step's actions -- in ONE host call: the per-step host work is two native enqueues. */
+#define PH_COMM_ID_BYTES 128
+int ph_comm_unique_id(unsigned char *id_out /* host, PH_COMM_ID_BYTES */);
+int ph_comm_init(ph_ctx *ctx, const unsigned char *id /* host */, int world, int rank);
+int ph_comm_destroy(ph_ctx *ctx);
+int ph_all_gather_i32(ph_ctx *ctx, const int *local /* (count) */, int *joint /* (world*count) */, int count);
+int ph_selfplay_rollout(ph_ctx *ctx, int n_calls, const ph_step_call *calls /* host, [T][n_calls] */, int T,
+                        const int *local, int *joint, int count);
+
 /* Ragged rollout buffers for vectorised TURN-BASED games ("per-env pos"): a partner does not act in
  * every env at every step, so each env e has its own write row pos_env[e] (device int32, caller-owned).
  *  ph_policy_forward_ragged: forward for all n = rb->E envs; the transition of env e is recorded at row pos_env[e] iff

@@ -111,6 +111,11 @@ SIGNATURES = {
     "ph_ppo_train": [_vp, C.POINTER(PhSpec), C.POINTER(PhOptState), C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i,
                      _vp, _ull, _vp, _i],
     "ph_ppo_train_multi": [C.POINTER(PhTrainCall), _i],
+    "ph_comm_unique_id": [_vp],
+    "ph_comm_init": [_vp, _vp, _i, _i],
+    "ph_comm_destroy": [_vp],
+    "ph_all_gather_i32": [_vp, _vp, _vp, _i],
+    "ph_selfplay_rollout": [_vp, _i, C.POINTER(PhStepCall), _i, _vp, _vp, _i],
     "ph_ppo_minibatch_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _vp, _i, _vp,
                               _vp, _i],
     "ph_bench_ppo_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i, _i,

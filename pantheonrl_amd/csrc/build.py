@@ -33,7 +33,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-I", os.path.join(ROOT, "include"), "-I", HERE, "-Wall", "-Wno-unused-function",
-           "-o", LIB] + [os.path.join(HERE, s) for s in SOURCES]
+           "-o", LIB] + [os.path.join(HERE, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print("[pantheonrl_amd] " + " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

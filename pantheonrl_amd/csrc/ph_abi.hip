@@ -1,6 +1,8 @@
 // C ABI of libpantheon_hip.so (see include/pantheon_hip.h for the contract and the reference call sites).
 // Host side only: argument checking, workspace management, kernel launches on the context stream.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdio>
@@ -60,6 +62,8 @@ struct ph_ctx {
   std::vector<hipGraphExec_t> graphs;
   bool capturing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  void* comm = nullptr;           // ncclComm_t of the agent-per-GPU exchange (ph_comm_init), or null
+  int comm_world = 1, comm_rank = 0;
   hipEvent_t ev_grad = nullptr;   // ph_ppo_train_multi: "this learner's latest gradient launch"
   int num_cu = 256;
   unsigned long long* rng_epoch = nullptr;  // caller-owned device word
@@ -232,6 +236,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev_grad) (void)hipEventDestroy(ctx->ev_grad);
+  (void)ph_comm_destroy(ctx);
   delete ctx;
   return 0;
 }
@@ -481,6 +486,106 @@ int ph_policy_step_multi(ph_ctx* ctx, int n_calls, const ph_step_call* calls) {
     }
   }
   PH_HIP(ph::launch_policy_fwd_multi(m, n_calls, ctx->stream));
+  return 0;
+}
+
+// ---- RCCL exchange (librccl.so resolved at first use) ------------------------------------------------------------------
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, ncclUniqueId, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (api.lib) {
+      api.GetUniqueId = (int (*)(void*))dlsym(api.lib, "ncclGetUniqueId");
+      api.CommInitRank = (int (*)(void**, int, ncclUniqueId, int))dlsym(api.lib, "ncclCommInitRank");
+      api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllGather");
+      api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
+      api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+      if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) api.lib = nullptr;
+    }
+  }
+  return api.lib ? &api : nullptr;
+}
+int fail_rccl(const char* what, int rc) {
+  RcclApi* r = rccl_api();
+  std::string msg = std::string(what) + ": " + ((r && r->GetErrorString) ? r->GetErrorString(rc) : "RCCL error");
+  return fail(msg.c_str());
+}
+}  // namespace
+
+int ph_comm_unique_id(unsigned char* id_out) {
+  if (!id_out) return fail("ph_comm_unique_id: null output");
+  RcclApi* r = rccl_api();
+  if (!r) return fail("ph_comm_unique_id: librccl.so could not be loaded");
+  ncclUniqueId id;
+  const int rc = r->GetUniqueId(&id);
+  if (rc != 0) return fail_rccl("ncclGetUniqueId", rc);
+  std::memcpy(id_out, id.internal, PH_COMM_ID_BYTES);
+  return 0;
+}
+
+int ph_comm_init(ph_ctx* ctx, const unsigned char* id, int world, int rank) {
+  if (!ctx || !id) return fail("ph_comm_init: null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail("ph_comm_init: bad world / rank");
+  if (ctx->comm) return fail("ph_comm_init: this context already has a communicator");
+  RcclApi* r = rccl_api();
+  if (!r) return fail("ph_comm_init: librccl.so could not be loaded");
+  PH_HIP(hipSetDevice(ctx->device));
+  ncclUniqueId uid;
+  std::memcpy(uid.internal, id, PH_COMM_ID_BYTES);
+  void* comm = nullptr;
+  const int rc = r->CommInitRank(&comm, world, uid, rank);
+  if (rc != 0) return fail_rccl("ncclCommInitRank", rc);
+  ctx->comm = comm;
+  ctx->comm_world = world;
+  ctx->comm_rank = rank;
+  return 0;
+}
+
+int ph_comm_destroy(ph_ctx* ctx) {
+  if (!ctx) return fail("null ctx");
+  if (ctx->comm) {
+    RcclApi* r = rccl_api();
+    if (r) (void)r->CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_world = 1;
+    ctx->comm_rank = 0;
+  }
+  return 0;
+}
+
+int ph_all_gather_i32(ph_ctx* ctx, const int* local, int* joint, int count) {
+  if (!ctx || !local || !joint || count <= 0) return fail("ph_all_gather_i32: bad argument");
+  if (!ctx->comm) {  // single process: the joint action is the local one
+    PH_HIP(hipMemcpyAsync(joint, local, (size_t)count * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+  }
+  RcclApi* r = rccl_api();
+  const int rc = r->AllGather(local, joint, (size_t)count, (int)ncclInt32, ctx->comm, ctx->stream);
+  if (rc != 0) return fail_rccl("ncclAllGather", rc);
+  return 0;
+}
+
+int ph_selfplay_rollout(ph_ctx* ctx, int n_calls, const ph_step_call* calls, int T, const int* local, int* joint,
+                        int count) {
+  if (!ctx || !calls || T <= 0) return fail("ph_selfplay_rollout: bad argument");
+  for (int t = 0; t < T; ++t) {
+    if (ph_policy_step_multi(ctx, n_calls, calls + (size_t)t * n_calls)) return 1;
+    if (ph_all_gather_i32(ctx, local, joint, count)) return 1;
+  }
   return 0;
 }
 

@@ -279,8 +279,9 @@ class FusedSelfPlayRollout:
     records are prebuilt (pointers into the HBM-resident synthetic inputs), so the host does two calls per step; GAE +
     PPO update of the local agents then run concurrently on separate streams."""
 
-    def __init__(self, agents, datas, exchange, stream: th.cuda.Stream, bonus: float = 0.01):
+    def __init__(self, agents, datas, exchange, stream: th.cuda.Stream, bonus: float = 0.01, update_graphs: bool = True):
         self.agents, self.datas, self.exchange, self.stream, self.bonus = agents, datas, exchange, stream, bonus
+        self.update_graphs, self._update_gid, self._iterations_run = update_graphs, None, 0
         dev = agents[0].model.policy.device
         n = len(agents)
         self.T = datas[0].T
@@ -296,10 +297,11 @@ class FusedSelfPlayRollout:
             a.actions = exchange.local[i].view(a.E, 1)       # forward writes straight into the exchange buffer
             a.model.device_permutations = True
             nat.check(a.model.policy.ctx.lib.ph_ctx_set_rng_epoch(a.model.policy.ctx.handle, self.epoch_word.data_ptr()))
-        # prebuilt launch records, one array per step
+        # prebuilt launch records: one contiguous [T][n] array (ph_selfplay_rollout walks it), `calls[t]` = step t's slice
+        self._all_calls = (nat.PhStepCall * (n * self.T))()
         self.calls = []
         for t in range(self.T):
-            arr = (nat.PhStepCall * n)()
+            arr = (nat.PhStepCall * n).from_buffer(self._all_calls, t * n * C.sizeof(nat.PhStepCall))
             for i, (a, d) in enumerate(zip(agents, datas)):
                 pol, rb, c = a.model.policy, a.model.rollout_buffer, arr[i]
                 c.spec, c.params, c.obs, c.n = C.pointer(pol.spec), pol.params.data_ptr(), d.obs[t].data_ptr(), a.E
@@ -322,29 +324,54 @@ class FusedSelfPlayRollout:
         self.set_pairing(pairing_round)
         agents, lib, h, ex, T = self.agents, self._lib, self._h, self.exchange, self.T
         agents[0].bind_stream()
-        for t in range(T):
-            nat.check(lib.ph_policy_step_multi(h, len(agents), self.calls[t]))
-            ex.gather_inplace()
+        if ex.native_ctx is not None and ex.native_ctx.handle.value == h.value:
+            # engine-side exchange: the T x (fused launch, RCCL all-gather) chain is enqueued by one native call
+            nat.check(lib.ph_selfplay_rollout(h, len(agents), self._all_calls, T, ex.local.data_ptr(),
+                                              ex.joint.data_ptr(), ex.local.numel()))
+        else:
+            for t in range(T):
+                nat.check(lib.ph_policy_step_multi(h, len(agents), self.calls[t]))
+                ex.gather_inplace()
         # the last step's reward (no further forward to carry it)
         for i, (a, d) in enumerate(zip(agents, self.datas)):
             a.bind_stream()
             a.model.rollout_buffer.pos = T
             a._last_episode_starts = d.dones[T - 1]
             a.update_joint(d.rewards[T - 1], d.dones[T - 1], ex.joint, ex.seat(i), self.partner[i], self.bonus)
-        # GAE + PPO update: local learners are independent -> concurrent on forked streams
+        # GAE + PPO update: local learners are independent -> concurrent on forked streams; each learner's 1 + 1 + 3*40
+        # launches are replayed from a hipGraph captured on its stream at the second iteration (no collective inside)
         main = th.cuda.current_stream()
         self._fork.record(main)
+        self._iterations_run += 1
+        capture_now = (self.update_graphs and self._update_gid is None and self._iterations_run == 2
+                       and not any(a.sync_stats for a in agents))   # a stats read-back cannot be captured
+        gids = []
         for i, a in enumerate(agents):
-            if i == 0:
+            stream = main if i == 0 else self._side[i - 1]
+            if i > 0:
+                stream.wait_event(self._fork)
+            with th.cuda.stream(stream):
                 a.bind_stream()
-                a.learn_from_buffer()
-                continue
-            side = self._side[i - 1]
-            side.wait_event(self._fork)
-            with th.cuda.stream(side):
-                a.bind_stream()
-                a.learn_from_buffer()
-                self._join[i - 1].record(side)
+                alib, ah = a.model.policy.ctx.lib, a.model.policy.ctx.handle
+                if self._update_gid is not None:
+                    nat.check(alib.ph_graph_launch(ah, self._update_gid[i]))
+                    a.finish_update()
+                elif capture_now:
+                    stream.synchronize()
+                    nat.check(alib.ph_graph_begin(ah))
+                    try:
+                        a.learn_from_buffer()
+                    finally:
+                        gid = C.c_int(-1)
+                        nat.check(alib.ph_graph_end(ah, C.byref(gid)))
+                    gids.append(gid.value)
+                    nat.check(alib.ph_graph_launch(ah, gid.value))
+                else:
+                    a.learn_from_buffer()
+                if i > 0:
+                    self._join[i - 1].record(stream)
+        if capture_now:
+            self._update_gid = gids
         for ev in self._join:
             main.wait_event(ev)
         agents[0].bind_stream()

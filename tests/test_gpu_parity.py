@@ -1048,3 +1048,43 @@ def test_joint_update_of_two_learners_is_bitwise_the_two_separate_updates():
     for a, r in zip(agents, ref_agents):
         assert np.isfinite(a.model.policy.get_flat_params()).all()
         assert np.array_equal(a.model.policy.get_flat_params(), r.model.policy.get_flat_params())
+
+
+def test_engine_side_exchange_single_rank_and_native_rollout_loop():
+    """ph_all_gather_i32 / ph_selfplay_rollout: without a communicator the gather is a device copy; with a one-rank RCCL
+    communicator (PANTHEON_FORCE_RCCL=1: dlopen of librccl, ncclCommInitRank, ncclAllGather on the engine's stream) the result
+    is the same; the native T-step loop leaves the same buffers and parameters as the per-step Python loop."""
+    import os
+    from pantheonrl_amd import PPO, spaces as sp
+    from pantheonrl_amd import dist as pdist
+    from pantheonrl_amd.vec import FusedSelfPlayRollout, SyntheticRollouts, VecOnPolicyAgent
+    E, T = 64, 8
+    obs_space, act_space = sp.Box(-np.inf, np.inf, (62,)), sp.Discrete(6)
+    env = type("S", (), dict(observation_space=obs_space, action_space=act_space, _is_dummy_space_env=True))()
+
+    def run(native, force_rccl):
+        os.environ["PANTHEON_FORCE_RCCL"] = "1" if force_rccl else "0"
+        agents, datas = [], []
+        for seed in (5, 6):
+            m = PPO("MlpPolicy", env, n_steps=T, n_envs=E, batch_size=E * T // 2, n_epochs=2, seed=seed)
+            agents.append(VecOnPolicyAgent(m))
+            datas.append(SyntheticRollouts(obs_space, E, T, 400, seed, m.device))
+        ex = pdist.ActionExchange(len(agents), E, agents[0].model.device)
+        if native:
+            assert ex.attach_native(agents[0].model.policy.ctx)
+        stream = th.cuda.Stream()
+        with th.cuda.stream(stream):
+            steps = FusedSelfPlayRollout(agents, datas, ex, stream)
+            for it in range(2):
+                steps.run_iteration(it)
+        th.cuda.synchronize()
+        out = [a.model.policy.get_flat_params() for a in agents] + [ex.joint.cpu().numpy().copy()]
+        del steps, ex, agents
+        return out
+
+    base = run(False, False)
+    for native, force in ((True, False), (True, True)):
+        got = run(native, force)
+        for x, y in zip(base, got):
+            assert np.array_equal(x, y), (native, force)
+    os.environ["PANTHEON_FORCE_RCCL"] = "0"
