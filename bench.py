@@ -242,10 +242,9 @@ def main():
     if distributed:
         mode = "fusedstep"
     exchange = pdist.ActionExchange(len(agents), args.n_envs, device) if (distributed or mode == "fusedstep") else None
-    native_exchange = False
-    if exchange is not None and os.environ.get("PANTHEON_NATIVE_EXCHANGE", "1") != "0":
-        native_exchange = exchange.attach_native(agents[0].model.policy.ctx)   # engine-side RCCL all-gather per step
-        log(f"exchange: {'engine-side RCCL (ph_selfplay_rollout)' if native_exchange else 'torch.distributed'}")
+    if exchange is not None:
+        # per-step all-gather route: auto = time engine-side RCCL against direct peer-to-peer stores on this node, keep the faster
+        exchange.requested_route = os.environ.get("PANTHEON_EXCHANGE", "auto")
 
     if mode == "graph":
         graphs = [IterationGraph(a, d, s) for a, d, s in zip(agents, datas, streams)]
@@ -316,7 +315,8 @@ def main():
                    "features": agents[0].model.policy.layout.F, "n_logits": agents[0].model.policy.layout.L,
                    "batch_size": args.batch_size, "n_epochs": args.n_epochs, "agents_per_gpu": len(agents),
                    "parallelism": f"agent-per-gpu x{world} ({'per-step RCCL action all-gather' if distributed else 'single process'})",
-                   "exchange": ("engine-side ncclAllGather" if native_exchange else "torch.distributed") if exchange is not None else None,
+                   "exchange": ({"route": exchange.route, **exchange.route_log, "p2p_timeouts": exchange.p2p_timeouts()}
+                                if exchange is not None and hasattr(exchange, "route") else None),
                    "launch_mode": mode},
     }
     if rank == 0:

@@ -216,6 +216,47 @@ int ph_all_gather_i32(ph_ctx *ctx, const int *local /* (count) */, int *joint /*
 int ph_selfplay_rollout(ph_ctx *ctx, int n_calls, const ph_step_call *calls /* host, [T][n_calls] */, int T,
                         const int *local, int *joint, int count);
 
+/* ---- the same exchange as direct peer-to-peer stores over xGMI -------------------------------------------------------
+ * The per-step message is KB-sized, so the collective's cost is its latency.  Here every rank owns a fine-grained
+ * (uncached, cross-device coherent) receive area that all ranks map through HIP IPC; after the step's forward launch a
+ * one-workgroup kernel stores the local actions straight into every peer's receive area (slot = step parity), fences at
+ * system scope and publishes a monotonic step stamp in the peer's flag array; the consumer is a one-wave kernel that waits
+ * for all stamps (bounded: a timeout raises the error word instead of hanging the device).
+ *  ph_p2p_alloc / ph_p2p_open / ph_p2p_close / ph_p2p_free: the shareable buffer and its 64-byte IPC handle.
+ *  ph_p2p: the exchange as seen from one rank -- peers' receive areas and flag arrays as mapped here (own ones included).
+ *  ph_p2p_push(t): joint[t&1][peer][rank*count ..] <- local[0..count) for every peer; flags[peer][rank] <- stamp(t).
+ *  ph_p2p_wait(t): until flags_local[src] >= stamp(t) for every src.   stamp(t) = (*epoch) * T + t + 1.
+ *  ph_selfplay_rollout_p2p: T x { ph_policy_step_multi, push, wait } in one host call.  When every call fits the 16-row
+ *      step kernel the exchange is folded INTO the step launch with the stamp in-band: a policy workgroup stores each row's
+ *      action as ONE 8-byte word (stamp << 32 | action) into every rank's `ll` area (slot = t mod 3; 8-byte stores are
+ *      single-copy atomic, so no fence, flag or arrival counter is needed), and the value workgroups of the next step poll
+ *      exactly the two words they consume (own seat, partner seat) until the stamp matches.  After the last step the
+ *      words of step T-1 are unpacked into this rank's plain receive slot for ordinary consumers. */
+#define PH_MAX_RANKS 16
+#define PH_IPC_HANDLE_BYTES 64
+typedef struct ph_p2p {
+  int world, rank, count, T;
+  int *joint[2][PH_MAX_RANKS];                 /* [parity][peer] -> that peer's (world*count) int32 receive slot */
+  unsigned long long *flags[PH_MAX_RANKS];     /* [peer] -> that peer's (world) stamp array */
+  unsigned long long *ll[3][PH_MAX_RANKS];     /* [t mod 3][peer] -> that peer's (world*count) stamp-in-band words */
+  const unsigned long long *epoch;             /* device word advanced once per iteration (ph_rng_epoch_advance) */
+  unsigned long long *error;                   /* local device word: number of timed-out waits */
+  unsigned long long timeout_cycles;           /* bound of one wait in wall_clock64() ticks (100 MHz) */
+} ph_p2p;
+int ph_p2p_alloc(ph_ctx *ctx, size_t bytes, void **ptr_out, unsigned char *handle_out /* host, 64 */);
+int ph_p2p_open(ph_ctx *ctx, const unsigned char *handle /* host, 64 */, void **ptr_out);
+int ph_p2p_close(ph_ctx *ctx, void *ptr);
+int ph_p2p_free(ph_ctx *ctx, void *ptr);
+int ph_p2p_push(ph_ctx *ctx, const ph_p2p *x, const int *local, int t);
+int ph_p2p_wait(ph_ctx *ctx, const ph_p2p *x, int t);
+/* stamp-in-band variant as separate launches (what the fused step launch does per row; used by the route self-test):
+ * ll_push stores (stamp(t) << 32 | local[i]) into every rank's word area, ll_unpack waits for step t's words of every rank
+ * and writes their low halves to this rank's plain receive slot of parity t & 1 */
+int ph_p2p_ll_push(ph_ctx *ctx, const ph_p2p *x, const int *local, int t);
+int ph_p2p_ll_unpack(ph_ctx *ctx, const ph_p2p *x, int t);
+int ph_selfplay_rollout_p2p(ph_ctx *ctx, int n_calls, const ph_step_call *calls /* host, [T][n_calls] */, int T,
+                            const int *local, const ph_p2p *x);
+
 /* Ragged rollout buffers for vectorised TURN-BASED games ("per-env pos"): a partner does not act in
  * every env at every step, so each env e has its own write row pos_env[e] (device int32, caller-owned).
  *  ph_policy_forward_ragged: forward for all n = rb->E envs; the transition of env e is recorded at row pos_env[e] iff

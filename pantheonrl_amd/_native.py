@@ -73,6 +73,16 @@ class PhTrainCall(C.Structure):
                 ("gemm_mode", C.c_int)]
 
 
+PH_MAX_RANKS = 16
+
+
+class PhP2P(C.Structure):
+    """ph_p2p: the peer-to-peer exchange as seen from one rank"""
+    _fields_ = [("world", C.c_int), ("rank", C.c_int), ("count", C.c_int), ("T", C.c_int),
+                ("joint", (C.c_void_p * PH_MAX_RANKS) * 2), ("flags", C.c_void_p * PH_MAX_RANKS), ("ll", (C.c_void_p * PH_MAX_RANKS) * 3),
+                ("epoch", C.c_void_p), ("error", C.c_void_p), ("timeout_cycles", C.c_ulonglong)]
+
+
 SIGNATURES = {
     "ph_abi_version": [],
     "ph_last_error": [],
@@ -116,6 +126,15 @@ SIGNATURES = {
     "ph_comm_destroy": [_vp],
     "ph_all_gather_i32": [_vp, _vp, _vp, _i],
     "ph_selfplay_rollout": [_vp, _i, C.POINTER(PhStepCall), _i, _vp, _vp, _i],
+    "ph_p2p_alloc": [_vp, C.c_size_t, C.POINTER(C.c_void_p), _vp],
+    "ph_p2p_open": [_vp, _vp, C.POINTER(C.c_void_p)],
+    "ph_p2p_close": [_vp, _vp],
+    "ph_p2p_free": [_vp, _vp],
+    "ph_p2p_push": [_vp, C.POINTER(PhP2P), _vp, _i],
+    "ph_p2p_wait": [_vp, C.POINTER(PhP2P), _i],
+    "ph_p2p_ll_push": [_vp, C.POINTER(PhP2P), _vp, _i],
+    "ph_p2p_ll_unpack": [_vp, C.POINTER(PhP2P), _i],
+    "ph_selfplay_rollout_p2p": [_vp, _i, C.POINTER(PhStepCall), _i, _vp, C.POINTER(PhP2P)],
     "ph_ppo_minibatch_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _vp, _i, _vp,
                               _vp, _i],
     "ph_bench_ppo_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i, _i,

@@ -62,6 +62,9 @@ struct ph_ctx {
   std::vector<hipGraphExec_t> graphs;
   bool capturing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  ph_p2p* p2p_dev = nullptr;      // device copy of the peer-to-peer descriptor used by the fused step launches
+  ph_p2p p2p_host;                // what p2p_dev currently holds
+  bool p2p_valid = false;
   void* comm = nullptr;           // ncclComm_t of the agent-per-GPU exchange (ph_comm_init), or null
   int comm_world = 1, comm_rank = 0;
   hipEvent_t ev_grad = nullptr;   // ph_ppo_train_multi: "this learner's latest gradient launch"
@@ -230,7 +233,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (s.obs_off) (void)hipFree(s.obs_off);
     if (s.act_off) (void)hipFree(s.act_off);
   }
-  void* ptrs[] = {ctx->w2t, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->scalars, ctx->stop_flag};
+  void* ptrs[] = {ctx->p2p_dev, ctx->w2t, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->scalars, ctx->stop_flag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -434,7 +437,14 @@ int ph_policy_forward(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   return 0;
 }
 
+namespace {
+int step_multi_impl(ph_ctx* ctx, int n_calls, const ph_step_call* calls, const ph_p2p* x, int t);
+}
 int ph_policy_step_multi(ph_ctx* ctx, int n_calls, const ph_step_call* calls) {
+  return step_multi_impl(ctx, n_calls, calls, nullptr, 0);
+}
+namespace {
+int step_multi_impl(ph_ctx* ctx, int n_calls, const ph_step_call* calls, const ph_p2p* x, int t) {
   if (!ctx) return fail("null ctx");
   if (!calls) return fail("ph_policy_step_multi: null calls");
   if (n_calls <= 0 || n_calls > ph::MAX_LOCAL_AGENTS) return fail("ph_policy_step_multi: 1..4 calls per launch");
@@ -485,9 +495,34 @@ int ph_policy_step_multi(ph_ctx* ctx, int n_calls, const ph_step_call* calls) {
       }
     }
   }
+  if (x) {  // exchange fused into the launch (16-row kernel only; the caller checked eligibility)
+    if (!ph::fwd16_eligible(m.a[0].nd, m.a[0].n)) return fail("fused peer-to-peer step needs the 16-row forward kernel");
+    if (x->count != n_calls * m.a[0].n) return fail("ph_p2p.count must be local agents x n");
+    if (!ctx->p2p_dev) PH_HIP(hipMalloc((void**)&ctx->p2p_dev, sizeof(ph_p2p)));
+    if (!ctx->p2p_valid || std::memcmp(&ctx->p2p_host, x, sizeof(ph_p2p)) != 0) {
+      if (ctx->capturing) return fail("the peer-to-peer descriptor changed inside graph capture");
+      ctx->p2p_host = *x;
+      PH_HIP(hipMemcpyAsync(ctx->p2p_dev, &ctx->p2p_host, sizeof(ph_p2p), hipMemcpyHostToDevice, ctx->stream));
+      PH_HIP(hipStreamSynchronize(ctx->stream));
+      ctx->p2p_valid = true;
+    }
+    m.px.x = ctx->p2p_dev;
+    m.px.t = t;
+    m.px.a_local = n_calls;
+    for (int i = 0; i < n_calls; ++i) {
+      if (!m.a[i].joint) continue;   // consumers of the previous step's joint action read the stamp-in-band words
+      m.a[i].joint_ll = x->ll[(t + 2) % 3][x->rank];
+      m.a[i].ll_epoch = x->epoch;
+      m.a[i].ll_T = x->T;
+      m.a[i].ll_t = t - 1;
+      m.a[i].ll_timeout = x->timeout_cycles;
+      m.a[i].ll_error = x->error;
+    }
+  }
   PH_HIP(ph::launch_policy_fwd_multi(m, n_calls, ctx->stream));
   return 0;
 }
+}  // namespace
 
 // ---- RCCL exchange (librccl.so resolved at first use) ------------------------------------------------------------------
 namespace {
@@ -585,6 +620,106 @@ int ph_selfplay_rollout(ph_ctx* ctx, int n_calls, const ph_step_call* calls, int
   for (int t = 0; t < T; ++t) {
     if (ph_policy_step_multi(ctx, n_calls, calls + (size_t)t * n_calls)) return 1;
     if (ph_all_gather_i32(ctx, local, joint, count)) return 1;
+  }
+  return 0;
+}
+
+// ---- peer-to-peer exchange buffers ---------------------------------------------------------------------------------------
+int ph_p2p_alloc(ph_ctx* ctx, size_t bytes, void** ptr_out, unsigned char* handle_out) {
+  if (!ctx || !ptr_out || !handle_out || bytes == 0) return fail("ph_p2p_alloc: bad argument");
+  PH_HIP(hipSetDevice(ctx->device));
+  void* p = nullptr;
+  PH_HIP(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+  hipError_t e = hipMemset(p, 0, bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  hipIpcMemHandle_t hd;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&hd, p);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return fail_hip("ph_p2p_alloc", e);
+  }
+  static_assert(sizeof(hd) == PH_IPC_HANDLE_BYTES, "IPC handle size");
+  std::memcpy(handle_out, &hd, PH_IPC_HANDLE_BYTES);
+  *ptr_out = p;
+  return 0;
+}
+int ph_p2p_open(ph_ctx* ctx, const unsigned char* handle, void** ptr_out) {
+  if (!ctx || !handle || !ptr_out) return fail("ph_p2p_open: bad argument");
+  PH_HIP(hipSetDevice(ctx->device));
+  hipIpcMemHandle_t hd;
+  std::memcpy(&hd, handle, PH_IPC_HANDLE_BYTES);
+  void* p = nullptr;
+  PH_HIP(hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess));
+  *ptr_out = p;
+  return 0;
+}
+int ph_p2p_close(ph_ctx* ctx, void* ptr) {
+  if (!ctx) return fail("null ctx");
+  if (ptr) PH_HIP(hipIpcCloseMemHandle(ptr));
+  return 0;
+}
+int ph_p2p_free(ph_ctx* ctx, void* ptr) {
+  if (!ctx) return fail("null ctx");
+  if (ptr) PH_HIP(hipFree(ptr));
+  return 0;
+}
+namespace {
+int check_p2p(const ph_p2p* x) {
+  if (!x) return fail("null ph_p2p");
+  if (x->world < 1 || x->world > PH_MAX_RANKS || x->rank < 0 || x->rank >= x->world || x->count <= 0 || x->T <= 0)
+    return fail("ph_p2p: bad world / rank / count / T");
+  if (!x->epoch || !x->error) return fail("ph_p2p: epoch and error words are required");
+  for (int p = 0; p < x->world; ++p)
+    if (!x->joint[0][p] || !x->joint[1][p] || !x->flags[p] || !x->ll[0][p] || !x->ll[1][p] || !x->ll[2][p])
+      return fail("ph_p2p: unmapped peer");
+  return 0;
+}
+}  // namespace
+int ph_p2p_push(ph_ctx* ctx, const ph_p2p* x, const int* local, int t) {
+  if (!ctx || !local) return fail("ph_p2p_push: null argument");
+  if (check_p2p(x)) return 1;
+  PH_HIP(ph::launch_p2p_push(*x, local, t, ctx->stream));
+  return 0;
+}
+int ph_p2p_wait(ph_ctx* ctx, const ph_p2p* x, int t) {
+  if (!ctx) return fail("null ctx");
+  if (check_p2p(x)) return 1;
+  PH_HIP(ph::launch_p2p_wait(*x, t, ctx->stream));
+  return 0;
+}
+int ph_p2p_ll_push(ph_ctx* ctx, const ph_p2p* x, const int* local, int t) {
+  if (!ctx || !local) return fail("ph_p2p_ll_push: null argument");
+  if (check_p2p(x)) return 1;
+  PH_HIP(ph::launch_p2p_ll_push(*x, local, t, ctx->stream));
+  return 0;
+}
+int ph_p2p_ll_unpack(ph_ctx* ctx, const ph_p2p* x, int t) {
+  if (!ctx) return fail("null ctx");
+  if (check_p2p(x)) return 1;
+  PH_HIP(ph::launch_p2p_ll_unpack(*x, t, ctx->stream));
+  return 0;
+}
+int ph_selfplay_rollout_p2p(ph_ctx* ctx, int n_calls, const ph_step_call* calls, int T, const int* local,
+                            const ph_p2p* x) {
+  if (!ctx || !calls || !local || T <= 0) return fail("ph_selfplay_rollout_p2p: bad argument");
+  if (check_p2p(x)) return 1;
+  bool fused = x->count == n_calls * calls[0].n && getenv("PH_P2P_UNFUSED") == nullptr;
+  for (int i = 0; i < n_calls && fused; ++i) {
+    ph::NetDims nd;
+    if (resolve(ctx, calls[i].spec, &nd)) return 1;
+    fused = ph::fwd16_eligible(nd, calls[i].n);
+  }
+  if (fused) {
+    // push and wait live inside the step launch; the stamp of the last step is awaited once, for whoever reads it next
+    for (int t = 0; t < T; ++t)
+      if (step_multi_impl(ctx, n_calls, calls + (size_t)t * n_calls, x, t)) return 1;
+    PH_HIP(ph::launch_p2p_ll_unpack(*x, T - 1, ctx->stream));
+    return 0;
+  }
+  for (int t = 0; t < T; ++t) {
+    if (ph_policy_step_multi(ctx, n_calls, calls + (size_t)t * n_calls)) return 1;
+    PH_HIP(ph::launch_p2p_push(*x, local, t, ctx->stream));
+    PH_HIP(ph::launch_p2p_wait(*x, t, ctx->stream));
   }
   return 0;
 }

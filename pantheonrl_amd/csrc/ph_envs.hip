@@ -140,6 +140,89 @@ hipError_t launch_liar_reset(int* hands, int* history, int* nmoves, const unsign
   return hipGetLastError();
 }
 
+// ---- peer-to-peer action exchange over xGMI (include/pantheon_hip.h: ph_p2p) --------------------------------------------
+// push: one workgroup.  Every peer's receive slot gets this rank's `count` actions with plain (uncached, fine-grained
+// memory) stores; after a workgroup barrier one lane fences at system scope and publishes the step stamp to every peer --
+// the data stores of all lanes are ordered before the stamp store by barrier + release fence.
+__global__ __launch_bounds__(1024) void p2p_push_kernel(ph_p2p x, const int* __restrict__ local, int t) {
+  const int par = t & 1;
+  const size_t off = (size_t)x.rank * x.count;
+  for (int i = threadIdx.x; i < x.count; i += blockDim.x) {
+    const int v = local[i];
+    for (int p = 0; p < x.world; ++p) __builtin_nontemporal_store(v, x.joint[par][p] + off + i);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x < x.world) {
+    const unsigned long long stamp = (*x.epoch) * (unsigned long long)x.T + (unsigned long long)t + 1ull;
+    __threadfence_system();
+    __hip_atomic_store(x.flags[threadIdx.x] + x.rank, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+hipError_t launch_p2p_push(const ph_p2p& x, const int* local, int t, hipStream_t s) {
+  hipLaunchKernelGGL(p2p_push_kernel, dim3(1), dim3(1024), 0, s, x, local, t);
+  return hipGetLastError();
+}
+
+// wait: one wave, lane = source rank; polls this rank's own stamp array until every source has published step t (or
+// the bound expires: then the error word is bumped and the kernel returns -- a lost peer must not hang the device)
+__global__ __launch_bounds__(64) void p2p_wait_kernel(ph_p2p x, int t) {
+  const int src = threadIdx.x;
+  if (src >= x.world) return;
+  const unsigned long long want = (*x.epoch) * (unsigned long long)x.T + (unsigned long long)t + 1ull;
+  const unsigned long long* flag = x.flags[x.rank] + src;
+  const long long t0 = wall_clock64();
+  bool ok = false;
+  while (true) {
+    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) { ok = true; break; }
+    if ((unsigned long long)(wall_clock64() - t0) > x.timeout_cycles) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (!ok) atomicAdd(x.error, 1ull);
+  __threadfence_system();
+}
+hipError_t launch_p2p_wait(const ph_p2p& x, int t, hipStream_t s) {
+  hipLaunchKernelGGL(p2p_wait_kernel, dim3(1), dim3(64), 0, s, x, t);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void p2p_ll_push_kernel(ph_p2p x, const int* __restrict__ local, int t) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= x.count) return;
+  const unsigned long long w = ((unsigned long long)p2p_stamp32(*x.epoch, x.T, t) << 32) | (unsigned long long)(unsigned)local[i];
+  for (int p = 0; p < x.world; ++p)
+    __hip_atomic_store(x.ll[t % 3][p] + (size_t)x.rank * x.count + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_p2p_ll_push(const ph_p2p& x, const int* local, int t, hipStream_t s) {
+  hipLaunchKernelGGL(p2p_ll_push_kernel, dim3((x.count + 255) / 256), dim3(256), 0, s, x, local, t);
+  return hipGetLastError();
+}
+
+// words of step t (stamp-in-band area) -> this rank's plain int32 receive slot of parity t & 1, for ordinary consumers
+__global__ __launch_bounds__(256) void p2p_ll_unpack_kernel(ph_p2p x, int t) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= x.world * x.count) return;
+  const unsigned want = p2p_stamp32(*x.epoch, x.T, t);
+  const unsigned long long* word = x.ll[t % 3][x.rank] + i;
+  const long long t0 = wall_clock64();
+  unsigned long long v;
+  while (true) {
+    v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned)(v >> 32) == want) break;
+    if ((unsigned long long)(wall_clock64() - t0) > x.timeout_cycles) {
+      atomicAdd(x.error, 1ull);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  x.joint[t & 1][x.rank][i] = (int)(unsigned)v;
+}
+hipError_t launch_p2p_ll_unpack(const ph_p2p& x, int t, hipStream_t s) {
+  const int n = x.world * x.count;
+  hipLaunchKernelGGL(p2p_ll_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, t);
+  return hipGetLastError();
+}
+
 // HistoryQueue for n envs: one lane per (env, feature) walks its column of frames from the oldest to the newest
 __global__ void framestack_push_kernel(float* __restrict__ stack, const float* __restrict__ obs,
                                        const unsigned char* __restrict__ reset_mask,

@@ -4,6 +4,11 @@
 
 namespace ph {
 
+// stamp of step t of the iteration whose epoch word reads `epoch` (peer-to-peer exchange; 32 bits travel in-band)
+__host__ __device__ inline unsigned p2p_stamp32(unsigned long long epoch, int T, int t) {
+  return (unsigned)(epoch * (unsigned long long)T + (unsigned long long)t + 1ull);
+}
+
 struct FwdArgs {
   NetDims nd;
   const float* params;
@@ -36,15 +41,30 @@ struct FwdArgs {
   const unsigned char* rec_mask;  // ragged mode: which envs record this action
   int rb_T;
   const int* joint;             // (n_seats, n) all-gathered actions of the previous step, or null
+  const unsigned long long* joint_ll;  // the same as stamp-in-band words (fused peer-to-peer step), or null
+  const unsigned long long* ll_epoch;  // stamp of those words = p2p_stamp32(*ll_epoch, ll_T, ll_t)
+  int ll_T, ll_t;
+  unsigned long long ll_timeout;       // bound of one poll in wall_clock64 ticks
+  unsigned long long* ll_error;        // timed-out polls
   int n_seats, seat;
   const int* partner_seat;      // device int
   float bonus;
 };
 
 constexpr int MAX_LOCAL_AGENTS = 4;
+// peer-to-peer exchange fused into the step launch (policy_fwd16_multi_kernel): the policy workgroups store every row's sampled
+// action, stamp in-band, straight into every rank's receive area; consumers poll the words they need.  x.world == 0: off.
+struct P2PStep {
+  const ph_p2p* x;   // DEVICE copy of the descriptor (a by-value copy inside the kernel arguments, indexed dynamically,
+                     // makes the compiler spill the whole argument block to scratch), or null
+  int t;             // step index of this launch
+  int a_local;       // local agents per rank (seat = rank * a_local + blockIdx.z)
+};
 struct FwdMulti {
   FwdArgs a[MAX_LOCAL_AGENTS];
+  P2PStep px;
 };
+bool fwd16_eligible(const NetDims& nd, int n);
 
 struct GradArgs {
   NetDims nd;
@@ -173,6 +193,11 @@ hipError_t launch_liar_step(const int* hands, int* history, int* nmoves, const i
                             const unsigned char* active, float* obs_next, float* rew, unsigned char* done, int n,
                             hipStream_t s);
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
+// peer-to-peer action exchange (ph_envs.hip)
+hipError_t launch_p2p_push(const ph_p2p& x, const int* local, int t, hipStream_t s);
+hipError_t launch_p2p_wait(const ph_p2p& x, int t, hipStream_t s);
+hipError_t launch_p2p_ll_unpack(const ph_p2p& x, int t, hipStream_t s);
+hipError_t launch_p2p_ll_push(const ph_p2p& x, const int* local, int t, hipStream_t s);
 // single-chunk / small-Discrete-head variant (ph_ppo_fast.hip); eligible() says whether the spec fits it
 bool grad_fast_eligible(const NetDims& nd);
 // row-parallel variant (ph_ppo_rp.hip): Box observations, single chunk, small Discrete head; rows walked in 16-row blocks

@@ -21,6 +21,21 @@ __device__ __forceinline__ long long rb_row(const FwdArgs& a, int g) {
   return (long long)p * a.n + g;
 }
 
+// one stamp-in-band word of the fused peer-to-peer exchange: spin (bounded) until it carries the expected step's stamp
+__device__ __forceinline__ int ll_read(const FwdArgs& a, const unsigned long long* word) {
+  const unsigned want = p2p_stamp32(*a.ll_epoch, a.ll_T, a.ll_t);
+  const long long t0 = wall_clock64();
+  while (true) {
+    const unsigned long long v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned)(v >> 32) == want) return (int)(unsigned)v;
+    if ((unsigned long long)(wall_clock64() - t0) > a.ll_timeout) {
+      atomicAdd(a.ll_error, 1ull);
+      return (int)(unsigned)v;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
 // value-net tail of one row: cache V, write the rollout-buffer row scalars, fold the previous step's late reward in
 __device__ __forceinline__ void value_row_tail(const FwdArgs& a, int g, float v) {
   const long long ridx = a.rb_val ? rb_row(a, g) : -1;
@@ -34,7 +49,13 @@ __device__ __forceinline__ void value_row_tail(const FwdArgs& a, int g, float v)
       if (a.joint) {  // shared coordination term of the synthetic SimultaneousEnv transition (joint action)
         int p = *a.partner_seat;
         p = p < 0 ? 0 : (p >= a.n_seats ? a.n_seats - 1 : p);
-        add += (a.joint[(size_t)a.seat * a.n + g] == a.joint[(size_t)p * a.n + g]) ? a.bonus : 0.f;
+        if (a.joint_ll) {
+          const int mine = ll_read(a, a.joint_ll + (size_t)a.seat * a.n + g);
+          const int theirs = ll_read(a, a.joint_ll + (size_t)p * a.n + g);
+          add += (mine == theirs) ? a.bonus : 0.f;
+        } else {
+          add += (a.joint[(size_t)a.seat * a.n + g] == a.joint[(size_t)p * a.n + g]) ? a.bonus : 0.f;
+        }
       }
       a.prev_rew[g] += add;
     }
@@ -59,7 +80,7 @@ __device__ __forceinline__ void copy_obs_rows(const FwdArgs& a, int row0, int nr
 
 // Discrete action space with <= 8 logits, one lane per row, the row's logits in registers (z[k >= L] ignored): optional
 // mask offset, logits output, sampling / argmax / given action, log-prob, entropy and the rollout-buffer writes
-__device__ __forceinline__ void discrete8_row_tail(const FwdArgs& a, const NetDims& nd, int g, float (&zr)[8]) {
+__device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDims& nd, int g, float (&zr)[8]) {
   const int nk = nd.L;
   const uint64_t ctr = a.counter + (a.epoch ? (uint64_t)(*a.epoch) << 32 : 0ull);
   if (a.mask) {  // modular/policies.py:330-333 : logits - 30*(~mask)
@@ -123,6 +144,7 @@ __device__ __forceinline__ void discrete8_row_tail(const FwdArgs& a, const NetDi
       if (a.rb_logp) a.rb_logp[ridx] = logp;
     }
   }
+  return act;
 }
 
 template <int R, int LP, bool VALU>
@@ -339,7 +361,8 @@ __device__ __forceinline__ float quad_sum_f(float v) {
 }
 
 template <bool VALU>
-__device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a) {
+__device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a, const ph_p2p* px = nullptr, int px_t = 0, int px_a_local = 0,
+                                                  int agent = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16, NT = 256;
   const NetDims& nd = a.nd;
@@ -468,7 +491,16 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a) {
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) z[k] = quad_sum_f(z[k]) + ((k < nk) ? hbs[k] : 0.f);
-      if (q == 0 && grow < a.n) discrete8_row_tail(a, nd, grow, z);
+      if (q == 0 && grow < a.n) {
+        const int act = discrete8_row_tail(a, nd, grow, z);
+        if (px) {  // push: (stamp << 32 | action) as one 8-byte store into every rank's receive area, slot t mod 3
+          const size_t off = (size_t)(px->rank * px_a_local + agent) * a.n + grow;
+          const unsigned long long w =
+              ((unsigned long long)p2p_stamp32(*px->epoch, px->T, px_t) << 32) | (unsigned long long)(unsigned)act;
+          for (int p = 0; p < px->world; ++p)
+            __hip_atomic_store(px->ll[px_t % 3][p] + off, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
     } else {
       float v = 0.f;
 #pragma unroll
@@ -486,7 +518,7 @@ __global__ __launch_bounds__(256) void policy_fwd16_kernel(FwdArgs a) {
   policy_fwd16_body<VALU>(a);
 }
 __global__ __launch_bounds__(256) void policy_fwd16_multi_kernel(FwdMulti m) {
-  policy_fwd16_body<false>(m.a[blockIdx.z]);
+  policy_fwd16_body<false>(m.a[blockIdx.z], m.px.x, m.px.t, m.px.a_local, blockIdx.z);
 }
 
 static size_t fwd16_lds_bytes() { return sizeof(float) * (size_t)(2 * 16 * LDH + 2 * HID * LDH + HID * 8 + 2 * HID + 8 + 16); }

@@ -49,6 +49,152 @@ class ActionExchange:
         self.joint = th.zeros((self.n_seats, n_envs), dtype=th.int32, device=device)
         self.bytes_per_step = self.joint.numel() * 4
         self.native_ctx = None      # engine context holding the RCCL communicator (attach_native)
+        self.p2p = None             # _native.PhP2P once the peer-to-peer route is attached (attach_p2p)
+        self._p2p_slots = None      # [parity] -> (n_seats, n_envs) int32 tensor view of this rank's receive area
+        self._p2p_keep = []
+
+    # -- peer-to-peer route ---------------------------------------------------------------------------------------------
+    def attach_p2p(self, ctx, epoch_word: th.Tensor, n_steps: int, timeout_s: float = 2.0) -> bool:
+        """Map every rank's fine-grained receive area through HIP IPC (handles travel through the process group's store)
+        and build the ph_p2p descriptor.  `epoch_word` is the device word the engine advances once per iteration
+        (ph_rng_epoch_advance); stamps are epoch * n_steps + t + 1.  Returns False if anything fails."""
+        import ctypes as C
+
+        from . import _native as nat
+        if not self.local.is_cuda or self.world > nat.PH_MAX_RANKS:
+            return False
+        try:
+            count = self.local.numel()
+            slot = self.world * count * 4
+            ll_slot = self.world * count * 8       # stamp-in-band words of the fused route: 3 slots
+            ll_base = 2 * slot + self.world * 8 + 64
+            nbytes = ll_base + 3 * ll_slot
+            base, handle = C.c_void_p(), (C.c_ubyte * 64)()
+            nat.check(ctx.lib.ph_p2p_alloc(ctx.handle, nbytes, C.byref(base), handle))
+            bases = [None] * self.world
+            bases[self.rank] = base.value
+            if self.world > 1:
+                store = dist.distributed_c10d._get_default_store()
+                store.set(f"pantheonrl_amd/p2p/{self.rank}", bytes(handle))
+                for p in range(self.world):
+                    if p == self.rank:
+                        continue
+                    peer = (C.c_ubyte * 64).from_buffer_copy(store.get(f"pantheonrl_amd/p2p/{p}"))
+                    mapped = C.c_void_p()
+                    nat.check(ctx.lib.ph_p2p_open(ctx.handle, peer, C.byref(mapped)))
+                    bases[p] = mapped.value
+            x = nat.PhP2P()
+            x.world, x.rank, x.count, x.T = self.world, self.rank, count, int(n_steps)
+            for p in range(self.world):
+                x.joint[0][p], x.joint[1][p] = bases[p], bases[p] + slot
+                x.flags[p] = bases[p] + 2 * slot
+                for k in range(3):
+                    x.ll[k][p] = bases[p] + ll_base + k * ll_slot
+            x.epoch = epoch_word.data_ptr()
+            x.error = base.value + 2 * slot + self.world * 8
+            x.timeout_cycles = int(timeout_s * 1e8)
+            own = base.value
+
+            class _View:   # zero-copy torch view of a raw device range
+                def __init__(self, ptr, shape):
+                    self.__cuda_array_interface__ = {"shape": shape, "typestr": "<i4", "data": (ptr, False), "version": 2}
+            self._p2p_slots = [th.as_tensor(_View(own + par * slot, (self.n_seats, self.n_envs)), device=self.local.device)
+                               for par in (0, 1)]
+            self._p2p_error = th.as_tensor(_View(x.error, (2,)), device=self.local.device)   # u64 as two i32
+            self._p2p_keep = [epoch_word, bases]
+            self.p2p, self.native_ctx = x, ctx
+            return True
+        except Exception as exc:  # noqa: BLE001
+            import sys
+            print(f"[pantheonrl_amd.dist] peer-to-peer exchange unavailable ({exc})", file=sys.stderr)
+            self.p2p = None
+            return False
+
+    # -- route selection -----------------------------------------------------------------------------------------------------
+    def setup(self, ctx, epoch_word: th.Tensor, n_steps: int, route: Optional[str] = None) -> str:
+        """Pick how the per-step all-gather is carried: "torch" (torch.distributed call per step), "rccl" (engine-side
+        ncclAllGather), "p2p" (direct stores into IPC-mapped peer memory) or "auto": with more than one rank, time the
+        engine-side RCCL route against the peer-to-peer route on this very node (after checking that the peer-to-peer
+        route delivers the right bytes) and keep the faster one; every rank takes the same decision.  Idempotent."""
+        import time
+        if getattr(self, "route", None) in ("torch", "rccl", "p2p"):
+            return self.route
+        route = route or getattr(self, "requested_route", None) or ("p2p" if getattr(self, "want_p2p", False) else "torch")
+        log = {}
+        if self.local.is_cuda:
+            ctx.set_stream(th.cuda.current_stream(self.local.device).cuda_stream)
+        if route == "auto":
+            route = "rccl" if self.world == 1 else "measure"
+        if route in ("rccl", "measure") and self.native_ctx is None:
+            if not self.attach_native(ctx):
+                route = "torch"
+        if route == "measure":
+            def timed(step_fn, k=32):
+                th.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                for t in range(k):
+                    step_fn(t)
+                th.cuda.synchronize()
+                return (time.perf_counter() - t0) / k
+            log["rccl_us"] = 1e6 * timed(lambda t: self.gather_inplace())
+            ok = self.attach_p2p(ctx, epoch_word, max(int(n_steps), 32))
+            if ok:
+                self.local.copy_(th.arange(self.local.numel(), dtype=th.int32, device=self.local.device)
+                                 .view_as(self.local) + 100003 * (self.rank + 1))
+                want = th.cat([th.arange(self.local.numel(), dtype=th.int32, device=self.local.device)
+                               .view_as(self.local) + 100003 * (r + 1) for r in range(self.world)])
+                got = self.p2p_step(0).clone()
+                th.cuda.synchronize()
+                ok = bool(th.equal(got, want)) and self.p2p_timeouts() == 0
+                dist.barrier()
+                got = self.p2p_step(1, in_band=True).clone()       # the protocol of the fused step launch
+                th.cuda.synchronize()
+                ok = ok and bool(th.equal(got, want)) and self.p2p_timeouts() == 0
+                dist.barrier()
+            if ok:
+                log["p2p_us"] = 1e6 * timed(lambda t: self.p2p_step(2 + t, in_band=True), k=30)
+                ok = self.p2p_timeouts() == 0
+            verdict = th.tensor([1.0 if ok else 0.0, -log.get("p2p_us", 1e9), -log["rccl_us"]], device=self.local.device)
+            dist.all_reduce(verdict, op=dist.ReduceOp.MIN)       # all ok, slowest rank's times
+            # (the timed form is two extra launches per step; in the rollout the exchange is folded into the step launch)
+            use_p2p = verdict[0].item() > 0.5 and -verdict[1].item() < 2.0 * -verdict[2].item()
+            log.update(p2p_ok=bool(verdict[0].item() > 0.5), chosen="p2p" if use_p2p else "rccl")
+            epoch_word += 1          # stamps of the measurement must not satisfy the first real iteration's waits
+            th.cuda.synchronize()
+            dist.barrier()
+            if use_p2p:
+                self.p2p.T = int(n_steps)
+                route = "p2p"
+            else:
+                self.p2p, route = None, "rccl"
+        elif route == "p2p":
+            if not self.attach_p2p(ctx, epoch_word, n_steps):
+                route = "rccl" if self.attach_native(ctx) else "torch"
+        self.route, self.route_log = route, log
+        return route
+
+    def joint_slot(self, parity: int) -> th.Tensor:
+        """the (n_seats, n_envs) joint-action buffer holding steps of this parity (one buffer unless peer-to-peer)"""
+        return self._p2p_slots[parity & 1] if self.p2p is not None else self.joint
+
+    def p2p_timeouts(self) -> int:
+        return int(self._p2p_error[0].item()) if self.p2p is not None else 0
+
+    def p2p_step(self, t: int, in_band: bool = False) -> th.Tensor:
+        """one exchange of step t outside the fused rollout loop (tests, self-test): push + wait with stamp flags, or -- the
+        protocol of the fused step launch -- stamp-in-band words + unpack"""
+        import ctypes as C
+
+        from . import _native as nat
+        ctx = self.native_ctx
+        if in_band:
+            nat.check(ctx.lib.ph_p2p_ll_push(ctx.handle, C.byref(self.p2p), self.local.data_ptr(), int(t)))
+            nat.check(ctx.lib.ph_p2p_ll_unpack(ctx.handle, C.byref(self.p2p), int(t)))
+        else:
+            nat.check(ctx.lib.ph_p2p_push(ctx.handle, C.byref(self.p2p), self.local.data_ptr(), int(t)))
+            nat.check(ctx.lib.ph_p2p_wait(ctx.handle, C.byref(self.p2p), int(t)))
+        return self.joint_slot(t)
 
     def attach_native(self, ctx) -> bool:
         """Create the engine-side RCCL communicator on `ctx` (a _native.Context): rank 0 draws the unique id, the store of

@@ -293,6 +293,8 @@ class FusedSelfPlayRollout:
         self._fork = th.cuda.Event()
         self._join = [th.cuda.Event() for _ in agents[1:]]
         self.first_start = th.ones(agents[0].E, dtype=th.float32, device=dev)
+        if getattr(exchange, "want_p2p", False) or getattr(exchange, "requested_route", None):
+            exchange.setup(lead.ctx, self.epoch_word, self.T)
         for i, a in enumerate(agents):
             a.actions = exchange.local[i].view(a.E, 1)       # forward writes straight into the exchange buffer
             a.model.device_permutations = True
@@ -310,7 +312,7 @@ class FusedSelfPlayRollout:
                 c.rb, c.pos = C.pointer(rb.c_struct()), t
                 c.episode_start_in = (self.first_start if t == 0 else d.dones[t - 1]).data_ptr()
                 if t > 0:
-                    c.pending_reward, c.joint_actions = d.rewards[t - 1].data_ptr(), exchange.joint.data_ptr()
+                    c.pending_reward, c.joint_actions = d.rewards[t - 1].data_ptr(), exchange.joint_slot(t - 1).data_ptr()
                     c.n_seats, c.seat, c.partner_seat, c.bonus = exchange.n_seats, exchange.seat(i), self.partner[i].data_ptr(), bonus
             self.calls.append(arr)
 
@@ -324,7 +326,10 @@ class FusedSelfPlayRollout:
         self.set_pairing(pairing_round)
         agents, lib, h, ex, T = self.agents, self._lib, self._h, self.exchange, self.T
         agents[0].bind_stream()
-        if ex.native_ctx is not None and ex.native_ctx.handle.value == h.value:
+        if ex.p2p is not None:
+            # peer-to-peer stores over xGMI: T x (fused launch, push, wait) enqueued by one native call
+            nat.check(lib.ph_selfplay_rollout_p2p(h, len(agents), self._all_calls, T, ex.local.data_ptr(), C.byref(ex.p2p)))
+        elif ex.native_ctx is not None and ex.native_ctx.handle.value == h.value:
             # engine-side exchange: the T x (fused launch, RCCL all-gather) chain is enqueued by one native call
             nat.check(lib.ph_selfplay_rollout(h, len(agents), self._all_calls, T, ex.local.data_ptr(),
                                               ex.joint.data_ptr(), ex.local.numel()))
@@ -337,7 +342,7 @@ class FusedSelfPlayRollout:
             a.bind_stream()
             a.model.rollout_buffer.pos = T
             a._last_episode_starts = d.dones[T - 1]
-            a.update_joint(d.rewards[T - 1], d.dones[T - 1], ex.joint, ex.seat(i), self.partner[i], self.bonus)
+            a.update_joint(d.rewards[T - 1], d.dones[T - 1], ex.joint_slot(T - 1), ex.seat(i), self.partner[i], self.bonus)
         # GAE + PPO update: local learners are independent -> concurrent on forked streams; each learner's 1 + 1 + 3*40
         # launches are replayed from a hipGraph captured on its stream at the second iteration (no collective inside)
         main = th.cuda.current_stream()

@@ -1088,3 +1088,48 @@ def test_engine_side_exchange_single_rank_and_native_rollout_loop():
         for x, y in zip(base, got):
             assert np.array_equal(x, y), (native, force)
     os.environ["PANTHEON_FORCE_RCCL"] = "0"
+
+
+def test_peer_to_peer_exchange_single_rank_matches_the_copy_route():
+    """ph_selfplay_rollout_p2p with one rank (receive area mapped onto itself): same buffers and parameters as the device-copy
+    route, no timeouts, stamps advance with the iteration word."""
+    from pantheonrl_amd import PPO, spaces as sp
+    from pantheonrl_amd import dist as pdist
+    from pantheonrl_amd.vec import FusedSelfPlayRollout, SyntheticRollouts, VecOnPolicyAgent
+    E, T = 64, 8
+    obs_space, act_space = sp.Box(-np.inf, np.inf, (62,)), sp.Discrete(6)
+    env = type("S", (), dict(observation_space=obs_space, action_space=act_space, _is_dummy_space_env=True))()
+
+    def run(p2p):
+        agents, datas = [], []
+        for seed in (5, 6):
+            m = PPO("MlpPolicy", env, n_steps=T, n_envs=E, batch_size=E * T // 2, n_epochs=2, seed=seed)
+            agents.append(VecOnPolicyAgent(m))
+            datas.append(SyntheticRollouts(obs_space, E, T, 400, seed, m.device))
+        ex = pdist.ActionExchange(len(agents), E, agents[0].model.device)
+        ex.want_p2p = p2p
+        stream = th.cuda.Stream()
+        with th.cuda.stream(stream):
+            steps = FusedSelfPlayRollout(agents, datas, ex, stream)
+            assert (ex.p2p is not None) == p2p
+            for it in range(3):
+                steps.run_iteration(it)
+        th.cuda.synchronize()
+        assert ex.p2p_timeouts() == 0
+        return ([a.model.policy.get_flat_params() for a in agents] +
+                [a.model.rollout_buffer.host()["rewards"] for a in agents] + [ex.joint_slot(T - 1).cpu().numpy().copy()])
+
+    for x, y in zip(run(False), run(True)):
+        assert np.array_equal(x, y)
+
+
+def test_peer_to_peer_exchange_between_two_processes():
+    """two ranks (sharing this GPU) map each other's receive areas through HIP IPC and exchange 3 x 8 steps"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "tests", "scripts", "p2p_two_rank.py")]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.count("P2P_OK") == 2, (out.stdout[-1500:], out.stderr[-3000:])
