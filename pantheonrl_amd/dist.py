@@ -126,7 +126,7 @@ class ActionExchange:
         if route == "auto":
             route = "rccl" if self.world == 1 else "measure"
         if route in ("rccl", "measure") and self.native_ctx is None:
-            if not self.attach_native(ctx):
+            if not self.attach_native(ctx) and route == "rccl":
                 route = "torch"
         if route == "measure":
             def timed(step_fn, k=32):
@@ -137,37 +137,47 @@ class ActionExchange:
                     step_fn(t)
                 th.cuda.synchronize()
                 return (time.perf_counter() - t0) / k
+            vdev = self.local.device if dist.get_backend(self.group) == "nccl" else "cpu"
+            baseline = "rccl" if self.native_ctx is not None else "torch"
+
+            def everyone(flag: bool) -> bool:      # the same decision on every rank, whatever happened locally
+                v = th.tensor([1.0 if flag else 0.0], device=vdev)
+                dist.all_reduce(v, op=dist.ReduceOp.MIN)
+                return bool(v.item() > 0.5)
             log["rccl_us"] = 1e6 * timed(lambda t: self.gather_inplace())
-            ok = self.attach_p2p(ctx, epoch_word, max(int(n_steps), 32))
+            T_test = max(int(n_steps), 32)
+            ok = everyone(self.attach_p2p(ctx, epoch_word, T_test))
             if ok:
-                self.local.copy_(th.arange(self.local.numel(), dtype=th.int32, device=self.local.device)
-                                 .view_as(self.local) + 100003 * (self.rank + 1))
-                want = th.cat([th.arange(self.local.numel(), dtype=th.int32, device=self.local.device)
-                               .view_as(self.local) + 100003 * (r + 1) for r in range(self.world)])
-                got = self.p2p_step(0).clone()
-                th.cuda.synchronize()
-                ok = bool(th.equal(got, want)) and self.p2p_timeouts() == 0
-                dist.barrier()
-                got = self.p2p_step(1, in_band=True).clone()       # the protocol of the fused step launch
-                th.cuda.synchronize()
-                ok = ok and bool(th.equal(got, want)) and self.p2p_timeouts() == 0
-                dist.barrier()
+                pattern = th.arange(self.local.numel(), dtype=th.int32, device=self.local.device).view_as(self.local)
+                want = th.cat([pattern + 100003 * (r + 1) for r in range(self.world)])
+                self.local.copy_(pattern + 100003 * (self.rank + 1))
+                good = True
+                for step, in_band in ((0, False), (1, True)):   # stamp flags, then the fused launch's stamp-in-band words
+                    try:
+                        got = self.p2p_step(step, in_band=in_band).clone()
+                        th.cuda.synchronize()
+                        good = good and bool(th.equal(got, want)) and self.p2p_timeouts() == 0
+                    except Exception:  # noqa: BLE001
+                        good = False
+                    dist.barrier()
+                ok = everyone(good)
             if ok:
                 log["p2p_us"] = 1e6 * timed(lambda t: self.p2p_step(2 + t, in_band=True), k=30)
-                ok = self.p2p_timeouts() == 0
-            verdict = th.tensor([1.0 if ok else 0.0, -log.get("p2p_us", 1e9), -log["rccl_us"]], device=self.local.device)
-            dist.all_reduce(verdict, op=dist.ReduceOp.MIN)       # all ok, slowest rank's times
+                ok = everyone(self.p2p_timeouts() == 0)
+            times = th.tensor([log.get("p2p_us", 1e9), log["rccl_us"]], device=vdev)
+            dist.all_reduce(times, op=dist.ReduceOp.MAX)          # the slowest rank's view
             # (the timed form is two extra launches per step; in the rollout the exchange is folded into the step launch)
-            use_p2p = verdict[0].item() > 0.5 and -verdict[1].item() < 2.0 * -verdict[2].item()
-            log.update(p2p_ok=bool(verdict[0].item() > 0.5), chosen="p2p" if use_p2p else "rccl")
+            use_p2p = ok and times[0].item() < 2.0 * times[1].item()
+            log.update(p2p_ok=ok, chosen="p2p" if use_p2p else baseline)
             epoch_word += 1          # stamps of the measurement must not satisfy the first real iteration's waits
             th.cuda.synchronize()
             dist.barrier()
             if use_p2p:
-                self.p2p.T = int(n_steps)
-                route = "p2p"
+                route = "p2p"        # (the descriptor keeps T_test >= n_steps: stamps stay unique and monotonic)
             else:
-                self.p2p, route = None, "rccl"
+                self.p2p, route = None, baseline
+                if baseline == "torch":
+                    self.native_ctx = None
         elif route == "p2p":
             if not self.attach_p2p(ctx, epoch_word, n_steps):
                 route = "rccl" if self.attach_native(ctx) else "torch"
