@@ -53,6 +53,8 @@ struct ph_ctx {
   size_t blocksq_cap = 0;
   float* advstats = nullptr;
   size_t advstats_cap = 0;
+  double* advpart = nullptr;     // per-segment partial sums of the advantage statistics
+  size_t advpart_cap = 0;
   int* perm_idx = nullptr;   // (n_epochs, N) minibatch order of the current train() call, written by adv_stats
   size_t perm_idx_cap = 0;
   float* w2t = nullptr;      // [2][64][64] (W2G gradient-kernel variant)
@@ -233,7 +235,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (s.obs_off) (void)hipFree(s.obs_off);
     if (s.act_off) (void)hipFree(s.act_off);
   }
-  void* ptrs[] = {ctx->p2p_dev, ctx->w2t, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->scalars, ctx->stop_flag};
+  void* ptrs[] = {ctx->advpart, ctx->p2p_dev, ctx->w2t, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->scalars, ctx->stop_flag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -884,6 +886,7 @@ int ensure_train_ws(ph_ctx* ctx, int P, int nwg_max, int n_mb_total, size_t n_id
   if (ensure(ctx->grad, ctx->grad_cap, (size_t)P)) return 1;
   if (ensure(ctx->blocksq, ctx->blocksq_cap, (size_t)ph::reduce_blocks(P))) return 1;
   if (ensure(ctx->advstats, ctx->advstats_cap, (size_t)n_mb_total * 2)) return 1;
+  if (ensure(ctx->advpart, ctx->advpart_cap, (size_t)n_mb_total * 2 * ph::ADV_SPLIT)) return 1;
   if (n_idx && ensure(ctx->perm_idx, ctx->perm_idx_cap, n_idx)) return 1;
   return 0;
 }
@@ -951,6 +954,7 @@ int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_s
   aa.batch = batch_size;
   aa.n_mb = t.n_mb;
   aa.out = ctx->advstats;
+  aa.partial = ctx->advpart;
   aa.idx_out = perms ? nullptr : ctx->perm_idx;
   PH_HIP(ph::launch_adv_stats(aa, n_epochs * t.n_mb, s));
   return 0;
@@ -1105,6 +1109,7 @@ int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params,
   aa.batch = nb;
   aa.n_mb = 1;
   aa.out = ctx->advstats;
+  aa.partial = ctx->advpart;
   aa.idx_out = nullptr;
   PH_HIP(ph::launch_adv_stats(aa, 1, s));
   ph::GradArgs g;
@@ -1162,6 +1167,7 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   aa.batch = nb;
   aa.n_mb = 1;
   aa.out = ctx->advstats;
+  aa.partial = ctx->advpart;
   aa.idx_out = ctx->perm_idx;   // as in ph_ppo_train: the grad launches read the materialised order
   PH_HIP(ph::launch_adv_stats(aa, 1, s));
   ph::GradArgs g;

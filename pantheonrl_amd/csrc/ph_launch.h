@@ -120,6 +120,7 @@ __device__ __forceinline__ int minibatch_row(const GradArgs& a, int gi) {
   return env_major_to_phys(n, a.T, a.E);
 }
 
+constexpr int ADV_SPLIT = 8;   // workgroups per minibatch in the advantage-statistics pass
 struct AdvStatArgs {
   const float* rb_adv;
   int T, E;
@@ -129,6 +130,7 @@ struct AdvStatArgs {
   const unsigned long long* epoch;
   int N, batch, n_mb;  // minibatch k of epoch ep covers [k*batch, min(N,(k+1)*batch))
   float* out;          // [n_epochs*n_mb][2]
+  double* partial;     // [n_epochs*n_mb][ADV_SPLIT][2] per-segment (sum, sum of squares)
   int* idx_out;        // (n_epochs, N) or null: the env-major index of every element, materialised for the grad launches
 };
 

@@ -534,14 +534,16 @@ hipError_t launch_transpose_w2(const float* params, int pi_W2, int vf_W2, float*
 // ---- advantage statistics of every minibatch of a train() call: mean and unbiased std (torch .mean()/.std()) ----
 __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
   __shared__ double sh[2][1024 / 64];
-  const int mb = blockIdx.x;
+  const int mb = blockIdx.x / ADV_SPLIT, seg = blockIdx.x - mb * ADV_SPLIT;   // ADV_SPLIT workgroups share a minibatch
   const int ep = mb / a.n_mb, k = mb - ep * a.n_mb;
   const int start = k * a.batch;
   const int nb = (a.N - start < a.batch) ? a.N - start : a.batch;
   const uint64_t key = epoch_key(a.perm_seed + (a.epoch ? *a.epoch : 0ull), ep);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = (nb + ADV_SPLIT - 1) / ADV_SPLIT;
+  const int lo = seg * chunk, hi = (lo + chunk < nb) ? lo + chunk : nb;
   auto value = [&](int i) -> double {
-    if (i >= nb) return 0.0;
+    if (i >= hi) return 0.0;
     int n;
     if (a.perms) {
       n = a.perms[(size_t)ep * a.N + start + i];
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
   };
   // one pass: sum and sum of squares in fp64 (exact products of f32 values), 4 independent gathers per round
   double s = 0.0, q = 0.0;
-  for (int i = tid; i < nb; i += 4 * 1024) {
+  for (int i = lo + tid; i < hi; i += 4 * 1024) {
     const double v0 = value(i), v1 = value(i + 1024), v2 = value(i + 2048), v3 = value(i + 3072);
     s += (v0 + v1) + (v2 + v3);
     q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
@@ -573,15 +575,31 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
       ts += sh[0][w];
       tq += sh[1][w];
     }
-    const double mean = ts / (double)nb;
-    double var = (nb > 1) ? (tq - (double)nb * mean * mean) / (double)(nb - 1) : 0.0;
-    if (var < 0.0) var = 0.0;
-    a.out[2 * mb + 0] = (float)mean;
-    a.out[2 * mb + 1] = (float)sqrt(var);
+    a.partial[((size_t)mb * ADV_SPLIT + seg) * 2 + 0] = ts;
+    a.partial[((size_t)mb * ADV_SPLIT + seg) * 2 + 1] = tq;
   }
 }
+// mean and unbiased std of every minibatch from the segment partials, folded in a fixed order
+__global__ void adv_finalize_kernel(AdvStatArgs a, int n_total) {
+  const int mb = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mb >= n_total) return;
+  const int k = mb % a.n_mb;
+  const int start = k * a.batch;
+  const int nb = (a.N - start < a.batch) ? a.N - start : a.batch;
+  double ts = 0.0, tq = 0.0;
+  for (int seg = 0; seg < ADV_SPLIT; ++seg) {
+    ts += a.partial[((size_t)mb * ADV_SPLIT + seg) * 2 + 0];
+    tq += a.partial[((size_t)mb * ADV_SPLIT + seg) * 2 + 1];
+  }
+  const double mean = ts / (double)nb;
+  double var = (nb > 1) ? (tq - (double)nb * mean * mean) / (double)(nb - 1) : 0.0;
+  if (var < 0.0) var = 0.0;
+  a.out[2 * mb + 0] = (float)mean;
+  a.out[2 * mb + 1] = (float)sqrt(var);
+}
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s) {
-  hipLaunchKernelGGL(adv_stats_kernel, dim3(n_total), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(n_total * ADV_SPLIT), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(adv_finalize_kernel, dim3((n_total + 63) / 64), dim3(64), 0, s, a, n_total);
   return hipGetLastError();
 }
 
