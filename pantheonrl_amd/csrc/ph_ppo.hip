@@ -605,15 +605,19 @@ hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s) {
 
 // ---- slab reduction: grad[p] = sum_g slab[g][p] (fixed order), per-block sum of squares, minibatch statistics ----
 // grad[p] = sum_g slab[g][p] in a fixed order, per-block sum of squares, minibatch statistics, KL decision.
-// Block = 64 parameters x 16 slab groups (1024 lanes): every lane sums its group's slabs with 8 loads in flight, the 16
-// group sums are folded through LDS in a fixed order -- the whole slab set (17 MB at 256 slabs) costs two or three
-// memory latencies, and the result is bit-reproducible run to run.
-#if defined(PH_RED32)
-constexpr int RED_PARAMS = 32, RED_GROUPS = 32, RED_SHIFT = 5;
-#else
+// Every lane sums its group's slabs with 8 loads in flight, the group sums are folded through LDS in a fixed order; the
+// result is bit-reproducible run to run.
+// Block = 64 parameters x 4 slab groups = 256 lanes.  The block is deliberately SMALL: one wave per SIMD at 42 VGPRs fits
+// into the registers two resident gradient workgroups leave free (2 x 224 of 512 per lane), so the reduce blocks of one
+// learner run beside the other learner's gradient launch instead of waiting for a whole CU to drain.  With 1024-lane
+// blocks (64 x 16: faster in isolation, 9.5 us vs ~14 us) they could not, and the two learners' updates serialised:
+// 4.74 -> 4.10 ms per bench iteration on the same box.  (-DPH_RED_WIDE restores the wide block.)
+#if defined(PH_RED_WIDE)
 constexpr int RED_PARAMS = 64, RED_GROUPS = 16, RED_SHIFT = 6;
+#else
+constexpr int RED_PARAMS = 64, RED_GROUPS = 4, RED_SHIFT = 6;
 #endif
-__global__ __launch_bounds__(1024) void ppo_reduce_kernel(ReduceArgs a) {
+__global__ __launch_bounds__(RED_PARAMS * RED_GROUPS) void ppo_reduce_kernel(ReduceArgs a) {
   __shared__ float gsum[RED_GROUPS][RED_PARAMS];
   __shared__ float part[32][NSTATP];
   __shared__ float means[NSTATP];
