@@ -148,6 +148,12 @@ __device__ __forceinline__ f32x4 mma16(float a, float b, f32x4 acc, int lane) {
   }
 }
 
+// ---- XOR-swizzled [rows][64] LDS matrices for the 16x16x4 fragments ----------------------------------------------------
+// element (row, col) sits at row*64 + (col ^ swz(row)): conflict-free for "16 rows x 2 columns" (A operands), "2 rows x 16
+// columns" (B / transposed-A operands) and the C/D shape "rows 4g+r x 16 columns" (see ph_ppo_rp.hip)
+__device__ __forceinline__ int swz(int row) { return ((2 * row) & 62) ^ (16 * ((row ^ (row >> 2)) & 1)); }
+__device__ __forceinline__ int sidx(int row, int col) { return row * 64 + (col ^ swz(row)); }
+
 // ---- counter-based RNG: Philox4x32-10 --------------------------------------------------------------------
 __device__ __host__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll

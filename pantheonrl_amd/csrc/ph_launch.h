@@ -202,6 +202,9 @@ hipError_t launch_p2p_ll_unpack(const ph_p2p& x, int t, hipStream_t s);
 hipError_t launch_p2p_ll_push(const ph_p2p& x, const int* local, int t, hipStream_t s);
 // single-chunk / small-Discrete-head variant (ph_ppo_fast.hip); eligible() says whether the spec fits it
 bool grad_fast_eligible(const NetDims& nd);
+// eight-wave phased variant (ph_ppo_w8.hip): same tiling as the fast kernel (64-row tiles, <= #CU workgroups per net)
+bool grad_w8_eligible(const NetDims& nd);
+hipError_t launch_ppo_grad_w8(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
 // row-parallel variant (ph_ppo_rp.hip): Box observations, single chunk, small Discrete head; rows walked in 16-row blocks
 bool grad_rp_eligible(const NetDims& nd);
 void grad_rp_plan(int nb, int num_cu, int* ntiles16, int* nwg);

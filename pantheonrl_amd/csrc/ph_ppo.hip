@@ -511,6 +511,7 @@ void grad_plan(const NetDims& nd, int nb, int num_cu, int* ntiles, int* nwg) {
 
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s) {
   if (grad_rp_eligible(a.nd)) return launch_ppo_grad_rp(a, nwg, gemm_mode, s);
+  if (grad_w8_eligible(a.nd)) return launch_ppo_grad_w8(a, nwg, gemm_mode, s);
   if (grad_fast_eligible(a.nd)) return launch_ppo_grad_fast(a, nwg, gemm_mode, s);
   if (a.nd.Lp != 32 && a.nd.Lp != 64) return hipErrorInvalidValue;
   const bool lp64 = a.nd.Lp == 64;

@@ -22,9 +22,6 @@
 
 namespace ph {
 
-__device__ __forceinline__ int swz(int row) { return ((2 * row) & 62) ^ (16 * ((row ^ (row >> 2)) & 1)); }
-__device__ __forceinline__ int sidx(int row, int col) { return row * 64 + (col ^ swz(row)); }
-
 template <int CTRL>
 __device__ __forceinline__ float dpp_row(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
