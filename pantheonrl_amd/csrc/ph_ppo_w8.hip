@@ -205,8 +205,11 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
     const int bq = g * 64 + (c ^ (2 * g) ^ (16 * (g & 1)));
     const int aqm = (16 * tm + c) * 64 + (g ^ swz(16 * tm + c));
 #define W8_KS(s) ((((8 * (s)) & 62) ^ (16 * ((s) & 1))))
-#define W8_B(buf, s, t) (buf)[((bq ^ (16 * (t))) ^ W8_KS(s)) + 256 * (s)]
-#define W8_A(buf, s) (buf)[aqm ^ (4 * (s))]
+#define W8_B(buf, s, t) (buf)[((bqp ^ (16 * (t))) ^ W8_KS(s)) + 256 * (s)]
+#define W8_A(buf, s) (buf)[aqp ^ (4 * (s))]
+    // every phase works on its own opaque copies of the two bases: otherwise the operand addresses of all phases are
+    // computed once per tile and stay live across it (tens of VGPRs)
+#define W8_PHASE_BASES() int bqp = bq, aqp = aqm; asm volatile("" : "+v"(bqp), "+v"(aqp))
 
     // ---- T0: this tile's rows land in LDS ----
     if (lane < 8) {
@@ -231,7 +234,10 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
     // ---- S1: H1 = tanh(X W1 + b1) -> bufB ----
     f32x4 acc[2];
     acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_1x2<VALU>(acc, [&](int s) { return W8_A(bufA, s); }, [&](int s, int j) { return W8_B(bufC, s, tn0 + j); }, lane);
+    {
+      W8_PHASE_BASES();
+      mma_1x2<VALU>(acc, [&](int s) { return W8_A(bufA, s); }, [&](int s, int j) { return W8_B(bufC, s, tn0 + j); }, lane);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = 16 * (tn0 + j) + c;
@@ -242,26 +248,31 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
     w8_barrier();
     if (first) PH_STAMP(a.prof, 2);
 
-    // ---- S2: H2 = tanh(H1 W2 + b2) -> bufA ----
+    // ---- S2: H2 = tanh(H1 W2 + b2) -> bufC (W1 is dead after layer 1; X stays in bufA for the whole tile) ----
     acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_1x2<VALU>(acc, [&](int s) { return W8_A(bufB, s); }, [&](int s, int j) { return W8_B(w2s, s, tn0 + j); }, lane);
+    {
+      W8_PHASE_BASES();
+      mma_1x2<VALU>(acc, [&](int s) { return W8_A(bufB, s); }, [&](int s, int j) { return W8_B(w2s, s, tn0 + j); }, lane);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = 16 * (tn0 + j) + c;
       const float b = b2s[col];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bufA[sidx(16 * tm + 4 * g + r, col)] = fast_tanh(acc[j][r] + b);
+      for (int r = 0; r < 4; ++r) bufC[sidx(16 * tm + 4 * g + r, col)] = fast_tanh(acc[j][r] + b);
     }
     w8_barrier();
     if (first) PH_STAMP(a.prof, 3);
 
-    // ---- SH: head forward, loss, dL/dhead, dZ2 = dH2 * (1 - H2^2) -> bufC; eight lanes per row, units q + 8m ----
+    // ---- SH: head forward, loss, dL/dhead; dZ2 = dH2 * (1 - H2^2) stays in registers until the head-weight gradient has
+    //      read H2 (it replaces H2 in bufC two barriers later); eight lanes per row, units q + 8m ----
+    float dz2[8];
     {
       const int r = tid >> 3, q = tid & 7;
       const bool valid = rowphys[r] >= 0;
       float h[8];
 #pragma unroll
-      for (int m = 0; m < 8; ++m) h[m] = bufA[sidx(r, q + 8 * m)];
+      for (int m = 0; m < 8; ++m) h[m] = bufC[sidx(r, q + 8 * m)];
       if constexpr (net == 0) {
         float z[8];
 #pragma unroll
@@ -347,7 +358,7 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
           d = __builtin_fmaf(dz[5], w1.y, d);
           d = __builtin_fmaf(dz[6], w1.z, d);
           d = __builtin_fmaf(dz[7], w1.w, d);
-          bufC[sidx(r, q + 8 * m)] = d * (1.0f - h[m] * h[m]);
+          dz2[m] = d * (1.0f - h[m] * h[m]);
         }
       } else {
         float wv[8];
@@ -370,31 +381,15 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
         if (valid && q == 0) st1 += err * err;
         if (q == 0) dzs[r] = dv;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) bufC[sidx(r, q + 8 * m)] = dv * wv[m] * (1.0f - h[m] * h[m]);
+        for (int m = 0; m < 8; ++m) dz2[m] = dv * wv[m] * (1.0f - h[m] * h[m]);
       }
     }
     w8_barrier();
     if (first) PH_STAMP(a.prof, 4);
 
-    // ---- S6a: dW2 += H1^T dZ2 ; dH1 = dZ2 W2^T ; d b2, d head weights, d head bias (VALU, beside the MFMAs) ----
-    W8Meta meta_next;
-    meta_next.phys = -1;
-    meta_next.adv = meta_next.old = meta_next.act = 0.f;
-    if (has_next) meta_next = row_scalars(n_next);          // next tile's row scalars, committed at its T0
-    float xb[8];                                            // this tile's rows again (L2 hits), for dW1: committed in S6b
+    // ---- SD: head-weight gradients from H2 (bufC) and dL/dhead (dzs) ----
     {
-      const int f = lane < nd.F ? lane : 0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int p = rowphys[wave + 8 * i];
-        xb[i] = a.rb_obs[(size_t)(p < 0 ? 0 : p) * nd.D + f];
-      }
-    }
-    {
-      const int col = tid & 63, part = tid >> 6;            // part == wave: rows 8*wave .. 8*wave + 7
-      float t2[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) t2[i] = bufC[sidx(8 * part + i, col)];
+      const int col = tid & 63, part = tid >> 6;            // part == wave
       if constexpr (net == 0) {
         // d act_W[col][k = wave] over all 64 rows, 8 rows of operands in flight
 #pragma unroll 1
@@ -402,7 +397,7 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
           float hv[8], dv[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            hv[i] = bufA[sidx(r0 + i, col)];
+            hv[i] = bufC[sidx(r0 + i, col)];
             dv[i] = dzs[(r0 + i) * 8 + part];
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -418,16 +413,36 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float dv = dzs[8 * part + i];
-          gh = __builtin_fmaf(bufA[sidx(8 * part + i, col)], dv, gh);
+          gh = __builtin_fmaf(bufC[sidx(8 * part + i, col)], dv, gh);
           ghb += dv;
         }
       }
+    }
+    w8_barrier();
+    // ---- SW: dZ2 replaces H2 ----
+    {
+      const int r = tid >> 3, q = tid & 7;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) bufC[sidx(r, q + 8 * m)] = dz2[m];
+    }
+    w8_barrier();
+
+    // ---- S6a: d b2 ; dW2 += H1^T dZ2 ; dH1 = dZ2 W2^T ----
+    {
+      const int col = tid & 63, part = tid >> 6;
+      float t2[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t2[i] = bufC[sidx(8 * part + i, col)];
       gb2 += ((t2[0] + t2[1]) + (t2[2] + t2[3])) + ((t2[4] + t2[5]) + (t2[6] + t2[7]));
     }
-    mma_1x2<VALU>(G2, [&](int s) { return W8_B(bufB, s, tm); }, [&](int s, int j) { return W8_B(bufC, s, tn0 + j); }, lane);
+    {
+      W8_PHASE_BASES();
+      mma_1x2<VALU>(G2, [&](int s) { return W8_B(bufB, s, tm); }, [&](int s, int j) { return W8_B(bufC, s, tn0 + j); }, lane);
+    }
     if (first) PH_STAMP(a.prof, 5);
     acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
+      W8_PHASE_BASES();
       int wq[2];   // B[k = j][n = k'] = W2[k'][j]: row 16t + c of W2s, column 4s + g -- an A-type access
 #pragma unroll
       for (int j = 0; j < 2; ++j) wq[j] = (16 * (tn0 + j) + c) * 64 + (g ^ swz(16 * (tn0 + j) + c));
@@ -436,7 +451,7 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
     w8_barrier();
     if (first) PH_STAMP(a.prof, 6);
 
-    // ---- S6b: dZ1 = dH1 * (1 - H1^2) in place; X back into bufA; W1 back into bufC ----
+    // ---- S6b: dZ1 = dH1 * (1 - H1^2) in place ----
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -446,18 +461,13 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
         bufB[o] = acc[j][r] * (1.0f - hv * hv);
       }
     }
-    {
-      const bool fok = lane < nd.F;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) bufA[sidx(wave + 8 * i, lane)] = (rowphys[wave + 8 * i] >= 0 && fok) ? xb[i] : 0.f;
-    }
     w8_barrier();
     if (first) PH_STAMP(a.prof, 7);
 
     // ---- S7: dW1 += X^T dZ1 ; d b1.  The next tile's rows are gathered underneath. ----
-    meta = meta_next;
     float4 w1r[2];
     if (has_next) {
+      meta = row_scalars(n_next);               // next tile's row scalars and rows, committed at its T0
       load_w(a.params + oW1, nd.F, w1r, tid);   // refill of bufC (dZ2 is consumed): lands under the dW1 MFMAs
       load_x(meta.phys, xr, lane);
     }
@@ -468,7 +478,10 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
       for (int i = 0; i < 8; ++i) t1[i] = bufB[sidx(8 * part + i, col)];
       gb1 += ((t1[0] + t1[1]) + (t1[2] + t1[3])) + ((t1[4] + t1[5]) + (t1[6] + t1[7]));
     }
-    mma_1x2<VALU>(G1, [&](int s) { return W8_B(bufA, s, tm); }, [&](int s, int j) { return W8_B(bufB, s, tn0 + j); }, lane);
+    {
+      W8_PHASE_BASES();
+      mma_1x2<VALU>(G1, [&](int s) { return W8_B(bufA, s, tm); }, [&](int s, int j) { return W8_B(bufB, s, tn0 + j); }, lane);
+    }
     if (has_next) store_w(bufC, w1r, tid);
     w8_barrier();  // bufA / bufB / row scalars are free for the next tile
     if (first) PH_STAMP(a.prof, 8);
@@ -479,14 +492,22 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4, tm = wave >> 1, tn0 = 2 * (wave & 1);
+    // weight-gradient tiles -> LDS (row-major [64][64] over the dead bufB / bufC), then row-contiguous copies to the slab:
+    // coalesced stores and no per-element 64-bit address arithmetic in registers
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int k = 16 * tm + 4 * g + r, col = 16 * (tn0 + j) + c;
-        slab[oW2 + k * HID + col] = G2[j][r];
-        if (k < nd.F) slab[oW1 + (size_t)k * HID + col] = G1[j][r];
+        const int e = (16 * tm + 4 * g + r) * 64 + 16 * (tn0 + j) + c;
+        bufB[e] = G2[j][r];
+        bufC[e] = G1[j][r];
       }
+    }
+    w8_barrier();
+#pragma unroll 1
+    for (int e = tid; e < 64 * 64; e += W8_NT) {
+      slab[oW2 + e] = bufB[e];
+      if ((e >> 6) < nd.F) slab[oW1 + e] = bufC[e];
     }
     if (net == 0 && wave < nk) slab[lay.act_W + lane * nk + wave] = gh;   // d act_W[j = lane][k = wave], summed over all rows
     float st[NSTATP] = {st0, st1, st2, st3, st4, 0.f, 0.f, 0.f};
@@ -514,7 +535,7 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
     w8_barrier();
     auto wsum = [&](int which, int idx) {
       float v = part[(which * 8 + 0) * 64 + idx];
-#pragma unroll
+#pragma unroll 1
       for (int w = 1; w < 8; ++w) v += part[(which * 8 + w) * 64 + idx];
       return v;
     };
