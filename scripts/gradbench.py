@@ -1,0 +1,22 @@
+"""ph_bench_ppo_grad timing at the bench size (overcooked): prints us per launch.  Same-box A/B of kernel variants:
+PANTHEON_HIP_LIB=<other build> or PH_GRAD_RP / PH_GRAD_W8 / PH_GRAD_FAST switches."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch as th
+from pantheonrl_amd import PPO, _native as nat, spaces as sp
+from pantheonrl_amd.vec import SyntheticRollouts, VecOnPolicyAgent, run_iteration_eager
+E, T = 1024, 128
+obs_space, act_space = sp.Box(-np.inf, np.inf, (62,)), sp.Discrete(6)
+env = type("S", (), dict(observation_space=obs_space, action_space=act_space, _is_dummy_space_env=True))()
+model = PPO("MlpPolicy", env, n_steps=T, n_envs=E, batch_size=E * T // 4, n_epochs=1, seed=0)
+model.device_permutations = True
+agent = VecOnPolicyAgent(model)
+data = SyntheticRollouts(obs_space, E, T, 400, 0, model.device)
+run_iteration_eager(agent, data)
+th.cuda.synchronize()
+pol, rb = model.policy, model.rollout_buffer
+hp = model.hyper(); ms = C.c_float(0); rb.pos = T
+for rep in range(3):
+    nat.check(pol.ctx.lib.ph_bench_ppo_grad(pol.ctx.handle, C.byref(pol.spec), pol.params.data_ptr(), C.byref(rb.c_struct()),
+                                            C.byref(hp), int(model.batch_size), 200, 0, C.byref(ms)))
+print(os.environ.get("PANTHEON_HIP_LIB", "default").split("/")[-1], os.environ.get("PH_GRAD_RP", ""), "us/launch %.2f" % (ms.value * 1e3))
