@@ -299,6 +299,46 @@ int ph_liar_reset(ph_ctx *ctx, int *hands, int *history, int *nmoves, const unsi
 int ph_liar_obs(ph_ctx *ctx, const int *hands, const int *history, const int *nmoves, const unsigned char *is_ego,
                 const unsigned char *active, float *obs_out, int n);
 
+/* One vectorised MultiAgentEnv.step of n Liar's Dice tables with a PPO ego and a PPO partner, entirely on the device
+ * (multiagentenv.py:149-215 + TurnBasedEnv.n_step/n_reset :307-327 + LiarEnv, liar.py:53-102), as ONE host call that
+ * enqueues ~15 launches and keeps every mask on the device: ego forward (recorded at row ego_pos of its rectangular
+ * buffer) -> player_step -> partner credited / flagged (Agent.update) -> partner forward where the game goes on (ragged
+ * rows) -> player_step -> both credited, ego observation, episode flags -> finished tables re-dealt -> where the partner
+ * opens the new game it moves once -> every table is back at the ego's turn.  With deal_only != 0 only the re-deal half
+ * runs, for the tables flagged in `done` (the initial deal).  RNG counters: ego forward `counter`, partner forwards
+ * 2*counter and 2*counter+1, dice `counter`.  All pointers are device pointers owned by the caller. */
+typedef struct ph_liar_selfplay {
+  int n;
+  const ph_spec *spec;                       /* LiarsDice spaces (both seats) */
+  int *hands, *history, *nmoves;             /* (n,12) (n,24) (n) game state */
+  unsigned char *ego_first;                  /* (n) */
+  unsigned long long dice_seed;
+  float probegostart;
+  /* ego: rectangular rollout buffer */
+  const float *ego_params;
+  const ph_rollout *ego_rb;
+  int *ego_actions;                          /* (n,2) */
+  float *ego_values, *ego_log_probs;         /* (n) */
+  float *ego_episode_start;                  /* (n) in: flags of the previous step; out: this step's done */
+  unsigned long long ego_seed;
+  /* partner: ragged rollout buffer */
+  const float *alt_params;
+  const ph_rollout *alt_rb;
+  int *alt_actions;                          /* (n,2) */
+  float *alt_values, *alt_log_probs;         /* (n) */
+  int *alt_pos;                              /* (n) per-table write row */
+  unsigned char *alt_boundary, *alt_term, *alt_open, *alt_acted;   /* (n) OnPolicyAgent book-keeping per table */
+  unsigned long long alt_seed;
+  /* observations of whoever moves next */
+  float *obs_ego, *obs_alt;                  /* (n,30) */
+  unsigned long long *episodes;              /* finished games */
+  /* scratch */
+  float *obs_next, *rew1, *rew2, *es_alt;    /* (n,30) (n,2) (n,2) (n) */
+  unsigned char *done1, *done2, *running, *can, *alt_opens, *ego_opens, *done;   /* (n) */
+  const unsigned char *zeros8, *ones8;       /* (n) constants */
+} ph_liar_selfplay;
+int ph_liar_selfplay_step(ph_ctx *ctx, const ph_liar_selfplay *s, int ego_pos, unsigned long long counter, int deal_only);
+
 /* Frame stack as a device ring buffer <- HistoryQueue.add / reset, wrappers.py:37-71, applied to
  * n environments: stack (n, numframes*D) f32 holds the last numframes observations NEWEST FIRST; for envs with
  * reset_mask[e] != 0 the history is first refilled with default_obs (D, NULL = zeros), then obs (n, D) is pushed. */

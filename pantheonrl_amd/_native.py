@@ -83,6 +83,25 @@ class PhP2P(C.Structure):
                 ("epoch", C.c_void_p), ("error", C.c_void_p), ("timeout_cycles", C.c_ulonglong)]
 
 
+class PhLiarSelfPlay(C.Structure):
+    """ph_liar_selfplay: every device pointer of the vectorised Liar's Dice self-play step"""
+    _fields_ = [("n", C.c_int), ("spec", C.POINTER(PhSpec)),
+                ("hands", C.c_void_p), ("history", C.c_void_p), ("nmoves", C.c_void_p), ("ego_first", C.c_void_p),
+                ("dice_seed", C.c_ulonglong), ("probegostart", C.c_float),
+                ("ego_params", C.c_void_p), ("ego_rb", C.POINTER(PhRollout)), ("ego_actions", C.c_void_p),
+                ("ego_values", C.c_void_p), ("ego_log_probs", C.c_void_p), ("ego_episode_start", C.c_void_p),
+                ("ego_seed", C.c_ulonglong),
+                ("alt_params", C.c_void_p), ("alt_rb", C.POINTER(PhRollout)), ("alt_actions", C.c_void_p),
+                ("alt_values", C.c_void_p), ("alt_log_probs", C.c_void_p), ("alt_pos", C.c_void_p),
+                ("alt_boundary", C.c_void_p), ("alt_term", C.c_void_p), ("alt_open", C.c_void_p), ("alt_acted", C.c_void_p),
+                ("alt_seed", C.c_ulonglong),
+                ("obs_ego", C.c_void_p), ("obs_alt", C.c_void_p), ("episodes", C.c_void_p),
+                ("obs_next", C.c_void_p), ("rew1", C.c_void_p), ("rew2", C.c_void_p), ("es_alt", C.c_void_p),
+                ("done1", C.c_void_p), ("done2", C.c_void_p), ("running", C.c_void_p), ("can", C.c_void_p),
+                ("alt_opens", C.c_void_p), ("ego_opens", C.c_void_p), ("done", C.c_void_p),
+                ("zeros8", C.c_void_p), ("ones8", C.c_void_p)]
+
+
 SIGNATURES = {
     "ph_abi_version": [],
     "ph_last_error": [],
@@ -117,6 +136,7 @@ SIGNATURES = {
     "ph_liar_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "ph_liar_reset": [_vp, _vp, _vp, _vp, _vp, _vp, _ull, _ull, C.c_float, _i],
     "ph_liar_obs": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
+    "ph_liar_selfplay_step": [_vp, C.POINTER(PhLiarSelfPlay), _i, _ull, _i],
     "ph_framestack_push": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "ph_ppo_train": [_vp, C.POINTER(PhSpec), C.POINTER(PhOptState), C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i,
                      _vp, _ull, _vp, _i],

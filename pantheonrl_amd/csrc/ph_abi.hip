@@ -828,6 +828,48 @@ int ph_liar_obs(ph_ctx* ctx, const int* hands, const int* history, const int* nm
   return 0;
 }
 
+int ph_liar_selfplay_step(ph_ctx* ctx, const ph_liar_selfplay* sp, int ego_pos, unsigned long long counter, int deal_only) {
+  if (!ctx || !sp) return fail("ph_liar_selfplay_step: null argument");
+  const ph_liar_selfplay& s = *sp;
+  if (s.n <= 0 || !s.spec || !s.ego_rb || !s.alt_rb) return fail("ph_liar_selfplay_step: incomplete description");
+  if (check_rb(s.ego_rb) || check_rb(s.alt_rb)) return 1;
+  if (s.ego_rb->E != s.n || s.alt_rb->E != s.n) return fail("ph_liar_selfplay_step: buffers must have E = n");
+  hipStream_t st = ctx->stream;
+  if (!deal_only) {
+    if (ego_pos < 0 || ego_pos >= s.ego_rb->T) return fail("ph_liar_selfplay_step: ego_pos out of range (buffer full?)");
+    // ego moves in every table
+    if (ph_policy_forward(ctx, s.spec, s.ego_params, s.obs_ego, s.n, nullptr, nullptr, nullptr, s.ego_seed, counter, 0,
+                          s.ego_actions, nullptr, s.ego_values, s.ego_log_probs, nullptr, nullptr, s.ego_rb, ego_pos,
+                          s.ego_episode_start, nullptr, 0))
+      return 1;
+    PH_HIP(ph::launch_liar_step(s.hands, s.history, s.nmoves, s.ego_actions, s.ones8, nullptr, s.obs_next, s.rew1, s.done1,
+                                s.n, st));
+    PH_HIP(ph::launch_liar_sp_after_ego(s, st));
+    // partner replies where the game goes on (obs_next = its observation there)
+    if (ph_policy_forward_ragged(ctx, s.spec, s.alt_params, s.obs_next, nullptr, s.alt_seed, 2 * counter, 0, s.alt_actions,
+                                 s.alt_values, s.alt_log_probs, s.alt_rb, s.alt_pos, s.can, s.es_alt))
+      return 1;
+    PH_HIP(ph::launch_liar_sp_commit(s, s.running, st));
+    PH_HIP(ph::launch_liar_step(s.hands, s.history, s.nmoves, s.alt_actions, s.zeros8, s.running, s.obs_next, s.rew2,
+                                s.done2, s.n, st));
+    PH_HIP(ph::launch_liar_sp_after_alt(s, s.ego_rb->rewards + (size_t)ego_pos * s.n, st));
+  }
+  // finished tables (flagged in s.done) are re-dealt; where the partner opens the new game it moves once
+  PH_HIP(ph::launch_liar_reset(s.hands, s.history, s.nmoves, s.done, s.ego_first, s.dice_seed, counter, s.probegostart, s.n,
+                               st));
+  PH_HIP(ph::launch_liar_sp_openers(s, st));
+  PH_HIP(ph::launch_liar_obs(s.hands, s.history, s.nmoves, s.zeros8, s.alt_opens, s.obs_alt, s.n, st));
+  if (ph_policy_forward_ragged(ctx, s.spec, s.alt_params, s.obs_alt, nullptr, s.alt_seed, 2 * counter + 1, 0, s.alt_actions,
+                               s.alt_values, s.alt_log_probs, s.alt_rb, s.alt_pos, s.can, s.es_alt))
+    return 1;
+  PH_HIP(ph::launch_liar_sp_commit(s, s.alt_opens, st));
+  PH_HIP(ph::launch_liar_step(s.hands, s.history, s.nmoves, s.alt_actions, s.zeros8, s.alt_opens, s.obs_next, s.rew2,
+                              s.done2, s.n, st));
+  PH_HIP(ph::launch_liar_sp_opened(s, st));
+  PH_HIP(ph::launch_liar_obs(s.hands, s.history, s.nmoves, s.ones8, s.ego_opens, s.obs_ego, s.n, st));
+  return 0;
+}
+
 int ph_framestack_push(ph_ctx* ctx, float* stack, const float* obs, const unsigned char* reset_mask,
                        const float* default_obs, int n, int D, int numframes) {
   if (!ctx) return fail("null ctx");

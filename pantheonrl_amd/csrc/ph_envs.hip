@@ -140,6 +140,105 @@ hipError_t launch_liar_reset(int* hands, int* history, int* nmoves, const unsign
   return hipGetLastError();
 }
 
+// ---- vectorised Liar's Dice self-play: the step loop's book-keeping, one lane per table ------------------------------------
+// (MultiAgentEnv._update_players / _get_actions, multiagentenv.py:149-170, and OnPolicyAgent.update, agents.py:186-203,
+// applied to n tables; the partner's rollout rows are ragged: table e writes row alt_pos[e])
+__device__ __forceinline__ void liar_sp_credit(const ph_liar_selfplay& s, float* alt_rewards, int alt_T, int e, float r, bool done,
+                                               bool credited) {
+  const bool m = credited && s.alt_open[e];
+  if (m) {
+    const int p = s.alt_pos[e];
+    if (p >= 1 && p <= alt_T) alt_rewards[(size_t)(p - 1) * s.n + e] += r;
+  }
+  if (done) s.alt_boundary[e] = 1;
+  if (m && done) s.alt_term[e] = 1;
+}
+// what the partner's next forward records: a row where it is asked to move and its column still has room
+__device__ __forceinline__ void liar_sp_prepare(const ph_liar_selfplay& s, int alt_T, int e, bool requested) {
+  s.can[e] = (requested && s.alt_pos[e] < alt_T) ? 1 : 0;
+  s.es_alt[e] = s.alt_boundary[e] ? 1.f : 0.f;
+}
+// after the ego's move: credit the partner where it already acted this game, find the tables that go on
+__global__ void liar_sp_after_ego_kernel(ph_liar_selfplay s, float* alt_rewards, int alt_T) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= s.n) return;
+  const bool d1 = s.done1[e] != 0;
+  liar_sp_credit(s, alt_rewards, alt_T, e, s.rew1[2 * e + 1], d1, s.alt_acted[e] != 0);
+  s.running[e] = d1 ? 0 : 1;
+  liar_sp_prepare(s, alt_T, e, !d1);
+}
+// after a partner forward: advance the recorded columns, open / close the reward window, mark the partner as having acted
+__global__ void liar_sp_commit_kernel(ph_liar_selfplay s, const unsigned char* __restrict__ requested) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= s.n) return;
+  if (!requested[e]) return;
+  if (s.can[e]) {
+    s.alt_pos[e] += 1;
+    s.alt_boundary[e] = 0;
+    s.alt_term[e] = 0;
+    s.alt_open[e] = 1;
+  } else {
+    s.alt_open[e] = 0;     // the column is full: a later reward belongs to a row that was not recorded
+  }
+  s.alt_acted[e] = 1;
+}
+// after the partner's reply: credit both, the ego's reward row / episode flags / next observation, finished games
+__global__ void liar_sp_after_alt_kernel(ph_liar_selfplay s, float* alt_rewards, int alt_T, float* __restrict__ ego_rew_row) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= s.n) return;
+  const bool run = s.running[e] != 0;
+  const bool d2 = run && s.done2[e] != 0;
+  liar_sp_credit(s, alt_rewards, alt_T, e, s.rew2[2 * e + 1], d2, run);
+  const bool done = s.done1[e] != 0 || d2;
+  ego_rew_row[e] += s.rew1[2 * e] + (run ? s.rew2[2 * e] : 0.f);    // both transitions of the step (agents.py:44-47)
+  s.ego_episode_start[e] = done ? 1.f : 0.f;
+  if (run && !d2) {
+    for (int k = 0; k < 30; ++k) s.obs_ego[(size_t)e * 30 + k] = s.obs_next[(size_t)e * 30 + k];
+  }
+  s.done[e] = done ? 1 : 0;
+  if (done) {
+    s.alt_acted[e] = 0;
+    atomicAdd(s.episodes, 1ull);
+  }
+}
+// after the re-deal: who opens the new games; the partner's opening forward is prepared like any other
+__global__ void liar_sp_openers_kernel(ph_liar_selfplay s, int alt_T) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= s.n) return;
+  const bool fresh = s.done[e] != 0, ego_first = s.ego_first[e] != 0;
+  s.alt_opens[e] = (fresh && !ego_first) ? 1 : 0;
+  s.ego_opens[e] = (fresh && ego_first) ? 1 : 0;
+  if (fresh) s.alt_acted[e] = 0;
+  liar_sp_prepare(s, alt_T, e, fresh && !ego_first);
+}
+// after the partner's opening move: the ego's observation of those tables
+__global__ void liar_sp_opened_kernel(ph_liar_selfplay s) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= s.n || !s.alt_opens[e]) return;
+  for (int k = 0; k < 30; ++k) s.obs_ego[(size_t)e * 30 + k] = s.obs_next[(size_t)e * 30 + k];
+}
+#define PH_SP_GRID(s) dim3(((s).n + 255) / 256), dim3(256)
+hipError_t launch_liar_sp_after_ego(const ph_liar_selfplay& s, hipStream_t st) {
+  hipLaunchKernelGGL(liar_sp_after_ego_kernel, PH_SP_GRID(s), 0, st, s, s.alt_rb->rewards, s.alt_rb->T);
+  return hipGetLastError();
+}
+hipError_t launch_liar_sp_commit(const ph_liar_selfplay& s, const unsigned char* requested, hipStream_t st) {
+  hipLaunchKernelGGL(liar_sp_commit_kernel, PH_SP_GRID(s), 0, st, s, requested);
+  return hipGetLastError();
+}
+hipError_t launch_liar_sp_after_alt(const ph_liar_selfplay& s, float* ego_rew_row, hipStream_t st) {
+  hipLaunchKernelGGL(liar_sp_after_alt_kernel, PH_SP_GRID(s), 0, st, s, s.alt_rb->rewards, s.alt_rb->T, ego_rew_row);
+  return hipGetLastError();
+}
+hipError_t launch_liar_sp_openers(const ph_liar_selfplay& s, hipStream_t st) {
+  hipLaunchKernelGGL(liar_sp_openers_kernel, PH_SP_GRID(s), 0, st, s, s.alt_rb->T);
+  return hipGetLastError();
+}
+hipError_t launch_liar_sp_opened(const ph_liar_selfplay& s, hipStream_t st) {
+  hipLaunchKernelGGL(liar_sp_opened_kernel, PH_SP_GRID(s), 0, st, s);
+  return hipGetLastError();
+}
+
 // ---- peer-to-peer action exchange over xGMI (include/pantheon_hip.h: ph_p2p) --------------------------------------------
 // push: one workgroup.  Every peer's receive slot gets this rank's `count` actions with plain (uncached, fine-grained
 // memory) stores; after a workgroup barrier one lane fences at system scope and publishes the step stamp to every peer --

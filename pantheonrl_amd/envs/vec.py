@@ -172,68 +172,133 @@ class VecLiarSelfPlay:
     One vectorised step is one `MultiAgentEnv.step` of every table from the ego's point of view (multiagentenv.py:
     172-215): the ego moves, the partner replies in the tables that are still running, finished tables are re-dealt and --
     where the partner opens the new game -- the partner moves once more, so every table is back at the ego's turn.
-    The ego is a rectangular VecOnPolicyAgent (one row per table per step); the partner is ragged."""
+    The ego is a rectangular VecOnPolicyAgent (one row per table per step); the partner is ragged.
+
+    native=True (default): the whole step is ONE engine call (`ph_liar_selfplay_step`: ~15 launches, every mask stays on the
+    device, no host synchronisation).  native=False walks the same step with the per-call entry points and torch masks -- the
+    readable statement of the protocol, and the bit-exact cross-check of the native step (both use the same RNG counters:
+    step c -> ego forward c, partner forwards 2c and 2c+1, dice c)."""
 
     def __init__(self, n_envs: int, ego: VecOnPolicyAgent, alt: RaggedVecOnPolicyAgent, seed: int = 0,
-                 probegostart: float = 0.5):
-        self.E, self.ego, self.alt = n_envs, ego, alt
+                 probegostart: float = 0.5, native: bool = True):
+        self.E, self.ego, self.alt, self.native = n_envs, ego, alt, bool(native)
         pol = ego.model.policy
         self.dev = pol.device
         self.env = VecLiarsDice(n_envs, pol.ctx, self.dev)
         self.seed, self.counter, self.probegostart = int(seed), 0, float(probegostart)
         E, dev = n_envs, self.dev
-        self.ego_first = th.zeros(E, dtype=th.uint8, device=dev)
+        u8 = lambda v=0: th.full((E,), v, dtype=th.uint8, device=dev)  # noqa: E731
+        self.ego_first = u8()
         self.obs_ego = th.zeros((E, 30), dtype=th.float32, device=dev)
         self.obs_alt = th.zeros((E, 30), dtype=th.float32, device=dev)
-        self.alt_acted = th.zeros(E, dtype=th.uint8, device=dev)   # should_update of the partner seat, per table
-        self.ones8 = th.ones(E, dtype=th.uint8, device=dev)
-        self.zeros8 = th.zeros(E, dtype=th.uint8, device=dev)
-        self.episodes = 0
-        self._deal(self.ones8)
+        self.alt_acted = u8()                                      # should_update of the partner seat, per table
+        self.ones8, self.zeros8 = u8(1), u8(0)
+        self._episodes_dev = th.zeros(1, dtype=th.int64, device=dev)
+        self.steps_done = 0
+        if self.native:
+            self._build_native()
+            self._done.fill_(1)
+            self._native_call(0, deal_only=True)
+        else:
+            self._deal(self.ones8, 0)
+
+    @property
+    def episodes(self) -> int:
+        return int(self._episodes_dev.item())
 
     # -- helpers -----------------------------------------------------------------------------------------------------
     def _bind(self):
-        self.env.ctx.set_stream(th.cuda.current_stream(self.dev).cuda_stream)
+        stream = th.cuda.current_stream(self.dev).cuda_stream
+        self.env.ctx.set_stream(stream)
+        for agent in (self.ego, self.alt):
+            agent.model.policy.ctx.set_stream(stream)
 
-    def _deal(self, reset_mask: th.Tensor) -> None:
-        """re-deal the tables in reset_mask; where the partner opens, it moves once (that move cannot end the game)"""
+    def _build_native(self) -> None:
+        E, dev, env, ego, alt = self.E, self.dev, self.env, self.ego, self.alt
+        f32 = lambda *shape: th.zeros(shape, dtype=th.float32, device=dev)  # noqa: E731
+        u8 = lambda: th.zeros(E, dtype=th.uint8, device=dev)               # noqa: E731
+        self._obs_next, self._rew1, self._rew2, self._es_alt = f32(E, 30), f32(E, 2), f32(E, 2), f32(E)
+        self._done1, self._done2, self._running, self._can = u8(), u8(), u8(), u8()
+        self._alt_opens, self._ego_opens, self._done = u8(), u8(), u8()
+        ego._last_episode_starts = ego._last_episode_starts.clone()    # updated in place by the step from here on
+        s = nat.PhLiarSelfPlay()
+        s.n, s.spec = E, C.pointer(ego.model.policy.spec)
+        s.hands, s.history, s.nmoves = env.hands.data_ptr(), env.history.data_ptr(), env.nmoves.data_ptr()
+        s.ego_first, s.dice_seed, s.probegostart = self.ego_first.data_ptr(), self.seed, self.probegostart
+        pe, pa = ego.model.policy, alt.model.policy
+        self._ego_rbc, self._alt_rbc = ego.model.rollout_buffer.c_struct(), alt.model.rollout_buffer.c_struct()
+        s.ego_params, s.ego_rb, s.ego_actions = pe.params.data_ptr(), C.pointer(self._ego_rbc), ego.actions.data_ptr()
+        s.ego_values, s.ego_log_probs = ego.values.data_ptr(), ego.log_probs.data_ptr()
+        s.ego_episode_start, s.ego_seed = ego._last_episode_starts.data_ptr(), pe._seed
+        s.alt_params, s.alt_rb, s.alt_actions = pa.params.data_ptr(), C.pointer(self._alt_rbc), alt.actions.data_ptr()
+        s.alt_values, s.alt_log_probs, s.alt_pos = alt.values.data_ptr(), alt.log_probs.data_ptr(), alt.pos.data_ptr()
+        s.alt_boundary, s.alt_term, s.alt_open = alt.boundary.data_ptr(), alt.term.data_ptr(), alt.open.data_ptr()
+        s.alt_acted, s.alt_seed = self.alt_acted.data_ptr(), pa._seed
+        s.obs_ego, s.obs_alt, s.episodes = self.obs_ego.data_ptr(), self.obs_alt.data_ptr(), self._episodes_dev.data_ptr()
+        s.obs_next, s.rew1, s.rew2, s.es_alt = (t.data_ptr() for t in (self._obs_next, self._rew1, self._rew2, self._es_alt))
+        s.done1, s.done2, s.running, s.can = (t.data_ptr() for t in (self._done1, self._done2, self._running, self._can))
+        s.alt_opens, s.ego_opens, s.done = self._alt_opens.data_ptr(), self._ego_opens.data_ptr(), self._done.data_ptr()
+        s.zeros8, s.ones8 = self.zeros8.data_ptr(), self.ones8.data_ptr()
+        self._desc = s
+
+    def _native_call(self, counter: int, deal_only: bool = False) -> None:
+        self._bind()
+        ctx, rb = self.env.ctx, self.ego.model.rollout_buffer
+        nat.check(ctx.lib.ph_liar_selfplay_step(ctx.handle, C.byref(self._desc), int(rb.pos), int(counter), int(deal_only)))
+
+    def _deal(self, reset_mask: th.Tensor, c: int) -> None:
+        """(reference path) re-deal the tables in reset_mask; where the partner opens, it moves once"""
         env, lib, h = self.env, self.env.ctx.lib, self.env.ctx.handle
         self._bind()
-        self.counter += 1
         nat.check(lib.ph_liar_reset(h, env.hands.data_ptr(), env.history.data_ptr(), env.nmoves.data_ptr(),
-                                    reset_mask.data_ptr(), self.ego_first.data_ptr(), self.seed, self.counter,
+                                    reset_mask.data_ptr(), self.ego_first.data_ptr(), self.seed, int(c),
                                     self.probegostart, self.E))
         rm = reset_mask.bool()
-        self.alt_acted = th.where(rm, self.zeros8, self.alt_acted)
+        self.alt_acted.copy_(th.where(rm, self.zeros8, self.alt_acted))
         alt_opens = (rm & ~self.ego_first.bool()).to(th.uint8)
         # partner's opening observation and move
         nat.check(lib.ph_liar_obs(h, env.hands.data_ptr(), env.history.data_ptr(), env.nmoves.data_ptr(),
                                   self.zeros8.data_ptr(), alt_opens.data_ptr(), self.obs_alt.data_ptr(), self.E))
-        if bool(alt_opens.any().item()):
-            a_alt = self.alt.get_action(self.obs_alt, alt_opens)
-            self.alt_acted = (self.alt_acted.bool() | alt_opens.bool()).to(th.uint8)
-            env.player_step(a_alt, self.zeros8, alt_opens)          # obs_next = ego's observation in those tables
-            self.obs_ego = th.where(alt_opens.bool()[:, None], env.obs_next, self.obs_ego)
+        self.alt.model.policy._counter = 2 * c                      # the forward below draws with counter 2c + 1
+        a_alt = self.alt.get_action(self.obs_alt, alt_opens)
+        self.alt_acted.copy_((self.alt_acted.bool() | alt_opens.bool()).to(th.uint8))
+        env.player_step(a_alt, self.zeros8, alt_opens)              # obs_next = ego's observation in those tables
+        self.obs_ego.copy_(th.where(alt_opens.bool()[:, None], env.obs_next, self.obs_ego))
         ego_opens = (rm & self.ego_first.bool()).to(th.uint8)
-        tmp = th.zeros_like(self.obs_ego)
         nat.check(lib.ph_liar_obs(h, env.hands.data_ptr(), env.history.data_ptr(), env.nmoves.data_ptr(),
-                                  self.ones8.data_ptr(), ego_opens.data_ptr(), tmp.data_ptr(), self.E))
-        self.obs_ego = th.where(ego_opens.bool()[:, None], tmp, self.obs_ego)
+                                  self.ones8.data_ptr(), ego_opens.data_ptr(), self.obs_ego.data_ptr(), self.E))
 
     # -- one vectorised MultiAgentEnv.step ---------------------------------------------------------------------------------
     def step(self):
-        env, ego, alt = self.env, self.ego, self.alt
+        """-> (E,) uint8 device tensor: tables whose game ended in this step"""
+        ego, alt = self.ego, self.alt
+        self.steps_done += 1
+        c = self.steps_done
+        if self.native:
+            model, rb = ego.model, ego.model.rollout_buffer
+            if ego.n_steps >= model.n_steps:
+                ego.learn_from_buffer()
+            self._native_call(c)
+            rb.pos += 1
+            rb.full = rb.pos == rb.buffer_size
+            ego.n_steps += 1
+            ego.num_timesteps += self.E
+            alt.num_timesteps += self.E
+            return self._done
+        env = self.env
         self._bind()
+        ego.model.policy._counter = c - 1
         a_ego = ego.get_action(self.obs_ego)                                   # every table is at the ego's turn
         obs_alt, rew1, done1 = env.player_step(a_ego, self.ones8, None)
         rew1, done1 = rew1.clone(), done1.clone()
         running = (~done1.bool()).to(th.uint8)
         # partners that already acted this game are credited this transition (multiagentenv.py:163-170)
         alt.update(rew1[:, 1].contiguous(), done1, self.alt_acted)
-        self.obs_alt = th.where(running.bool()[:, None], obs_alt, self.obs_alt)
+        self.obs_alt.copy_(th.where(running.bool()[:, None], obs_alt, self.obs_alt))
         # partner replies where the game goes on
+        alt.model.policy._counter = 2 * c - 1
         a_alt = alt.get_action(self.obs_alt, running)
-        self.alt_acted = (self.alt_acted.bool() | running.bool()).to(th.uint8)
+        self.alt_acted.copy_((self.alt_acted.bool() | running.bool()).to(th.uint8))
         obs_ego, rew2, done2 = env.player_step(a_alt, self.zeros8, running)
         rew2 = th.where(running.bool()[:, None], rew2, th.zeros_like(rew2))
         done2 = (done2.bool() & running.bool())
@@ -242,12 +307,10 @@ class VecLiarSelfPlay:
         # the ego collects both transitions of the step; the last done wins (agents.py:44-47)
         ego.update((rew1[:, 0] + rew2[:, 0]).contiguous(), done.to(th.float32))
         ego.flush_rewards()
-        self.obs_ego = th.where((running.bool() & ~done2)[:, None], obs_ego, self.obs_ego)
+        self.obs_ego.copy_(th.where((running.bool() & ~done2)[:, None], obs_ego, self.obs_ego))
         done8 = done.to(th.uint8)
-        n_done = int(done8.sum().item())
-        if n_done:
-            self.episodes += n_done
-            self._deal(done8)
+        self._episodes_dev += done8.sum()
+        self._deal(done8, c)
         return done8
 
     def rollout_and_learn(self, n_steps: int) -> None:

@@ -1,10 +1,36 @@
-import sys, os, time
+"""steady-state throughput of the device-resident Liar's Dice self-play (BASELINE config 2: PPO-vs-PPO, n_envs = 256)"""
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch as th
-from pantheonrl_amd.trainer import run
+import torch as th  # noqa: E402
+
+from pantheonrl_amd import PPO  # noqa: E402
+from pantheonrl_amd.envs.vec import RaggedVecOnPolicyAgent, VecLiarsDice, VecLiarSelfPlay  # noqa: E402
+from pantheonrl_amd.vec import VecOnPolicyAgent  # noqa: E402
+
+E, T = 256, 128
+native = os.environ.get("LIAR_NATIVE", "1") != "0"
+spaces = type("S", (), dict(observation_space=VecLiarsDice.observation_space, action_space=VecLiarsDice.action_space,
+                            _is_dummy_space_env=True))()
+models = [PPO("MlpPolicy", spaces, n_steps=T, n_envs=E, batch_size=E * T // 4, n_epochs=10, seed=s) for s in (0, 1)]
+for m in models:
+    m.device_permutations = True
+ego, alt = VecOnPolicyAgent(models[0]), RaggedVecOnPolicyAgent(models[1])
+sp = VecLiarSelfPlay(E, ego, alt, seed=3, native=native)
+sp.rollout_and_learn(T)
+th.cuda.synchronize()
+iters = 5
 t0 = time.perf_counter()
-ego, partners, env = run(["LiarsDice-v0", "PPO", "PPO", "--n-envs", "256", "-t", str(256 * 128 * 6), "--seed", "1"])
+for _ in range(iters):
+    sp.rollout_and_learn(T)
 th.cuda.synchronize()
 dt = time.perf_counter() - t0
-print("liar on-device self-play: %.2f s for %d ego steps -> %.0f ego steps/s; episodes %d; partner updates %d" % (
-    dt, 256 * 128 * 6, 256 * 128 * 6 / dt, env.episodes, partners[0].iteration))
+t1 = time.perf_counter()
+for _ in range(T):
+    sp.step()
+th.cuda.synchronize()
+dr = time.perf_counter() - t1
+print(f"native={native}: {iters} iterations (rollout + updates) {dt / iters * 1e3:.1f} ms each -> {E * T * iters / dt:,.0f} ego "
+      f"steps/s; rollout alone {dr / T * 1e6:.0f} us per vector step; episodes {sp.episodes}, partner updates {alt.iteration}")
