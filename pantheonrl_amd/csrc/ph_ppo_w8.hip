@@ -58,9 +58,9 @@ struct W8Meta {
 };
 
 constexpr int W8_NT = 512, W8_R = 64;
-constexpr int W8_LDS_FLOATS = 4 * 4096 + 64 * 8 + 64 * 8 + 64 + 64 + 16 + 3 * 64 + 64;
+constexpr int W8_LDS_FLOATS = 4 * 4096 + 64 * 8 + 64 * 8 + 64 + 64 + 16 + 3 * 64 + 64 + 64 * 4;
 
-template <bool VALU, int NET>
+template <bool VALU>
 __device__ __forceinline__ void w8_body(const GradArgs& a) {
   PH_STAMP(a.prof, 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -80,8 +80,9 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
   float* rold = radv + R;           // [R] old log-prob | old values
   float* ract = rold + R;           // [R] action index
   int* rowphys = (int*)(ract + R);  // [R] physical buffer row, -1 = padding
+  float* stat = (float*)(rowphys + R);   // [R][4] per-row running sums of the minibatch statistics (kept out of the registers)
 
-  constexpr int net = NET;
+  const int net = blockIdx.y;
   const int oW1 = net == 0 ? lay.pi_W1 : lay.vf_W1, oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1;
   const int oW2 = net == 0 ? lay.pi_W2 : lay.vf_W2, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
   float* slab = a.slabs + (size_t)blockIdx.x * lay.P;
@@ -189,7 +190,7 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
   float gh = 0.f;               // policy: d act_W[j = tid & 63][k = wave] (complete) | value: d val_W[j] partial of 8 rows
   float gb1 = 0.f, gb2 = 0.f;   // bias-gradient partials: column tid & 63, rows 8*wave .. 8*wave+7
   float ghb = 0.f;              // policy: d act_b[lane] partial (lane < 8) | value: d val_b partial
-  float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f, st4 = 0.f;   // policy loss, value loss, -entropy, clip count, KL sums
+  if (threadIdx.x < R * 4) stat[threadIdx.x] = 0.f;   // policy: loss, -entropy, clip count, KL sums | value: squared error
 
   bool first = true;
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, first = false) {
@@ -273,7 +274,7 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
       float h[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) h[m] = bufC[sidx(r, q + 8 * m)];
-      if constexpr (net == 0) {
+      if (net == 0) {
         float z[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) z[k] = 0.f;
@@ -328,10 +329,10 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
         const float g_lp = -inv_nb * adv * ratio * gate * live;
         const float g_en = -a.ent_coef * inv_nb * live;
         if (valid && q == 0) {
-          st0 += -fminf(pl1, pl2);
-          st2 += -ent;
-          st3 += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
-          st4 += (ratio - 1.0f) - lr;
+          stat[r * 4 + 0] += -fminf(pl1, pl2);
+          stat[r * 4 + 1] += -ent;
+          stat[r * 4 + 2] += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
+          stat[r * 4 + 3] += (ratio - 1.0f) - lr;
         }
         float (&dz)[8] = pr;   // dL/dlogit k replaces the probability it is computed from
 #pragma unroll
@@ -378,7 +379,7 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
         }
         const float err = vp - retn;
         const float dv = valid ? a.vf_coef * 2.0f * err * inv_nb * pass : 0.f;
-        if (valid && q == 0) st1 += err * err;
+        if (valid && q == 0) stat[r * 4] += err * err;
         if (q == 0) dzs[r] = dv;
 #pragma unroll
         for (int m = 0; m < 8; ++m) dz2[m] = dv * wv[m] * (1.0f - h[m] * h[m]);
@@ -390,7 +391,7 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
     // ---- SD: head-weight gradients from H2 (bufC) and dL/dhead (dzs) ----
     {
       const int col = tid & 63, part = tid >> 6;            // part == wave
-      if constexpr (net == 0) {
+      if (net == 0) {
         // d act_W[col][k = wave] over all 64 rows, 8 rows of operands in flight
 #pragma unroll 1
         for (int r0 = 0; r0 < R; r0 += 8) {
@@ -504,19 +505,29 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
       }
     }
     w8_barrier();
-#pragma unroll 1
+#pragma unroll 4
     for (int e = tid; e < 64 * 64; e += W8_NT) {
       slab[oW2 + e] = bufB[e];
       if ((e >> 6) < nd.F) slab[oW1 + e] = bufC[e];
     }
     if (net == 0 && wave < nk) slab[lay.act_W + lane * nk + wave] = gh;   // d act_W[j = lane][k = wave], summed over all rows
-    float st[NSTATP] = {st0, st1, st2, st3, st4, 0.f, 0.f, 0.f};
+    // per-row statistic sums -> wave 0 folds them (the partial record uses the slots of the four-wave kernels: 0 policy
+    // loss, 1 value loss, 2 -entropy, 3 clip count, 4 KL)
+    float st[NSTATP] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (wave == 0) {
+      const float s0 = stat[lane * 4 + 0], s1 = stat[lane * 4 + 1], s2 = stat[lane * 4 + 2], s3 = stat[lane * 4 + 3];
+      if (net == 0) {
+        st[0] = s0; st[2] = s1; st[3] = s2; st[4] = s3;
+      } else {
+        st[1] = s0;
+      }
 #pragma unroll
-    for (int k = 0; k < NSTATP; ++k) {
-      float v = st[k];
+      for (int k = 0; k < 5; ++k) {
+        float v = st[k];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      st[k] = v;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        st[k] = v;
+      }
     }
     float* part = bufA;  // [5][8 waves][64]
     part[(0 * 8 + wave) * 64 + lane] = gb1;
@@ -535,7 +546,7 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
     w8_barrier();
     auto wsum = [&](int which, int idx) {
       float v = part[(which * 8 + 0) * 64 + idx];
-#pragma unroll 1
+#pragma unroll
       for (int w = 1; w < 8; ++w) v += part[(which * 8 + w) * 64 + idx];
       return v;
     };
@@ -554,8 +565,7 @@ __device__ __forceinline__ void w8_body(const GradArgs& a) {
 template <bool VALU>
 __global__ __launch_bounds__(W8_NT, 4) void ppo_grad_w8_kernel(GradArgs a) {
   if (*a.stop_flag) return;
-  if (blockIdx.y == 0) w8_body<VALU, 0>(a);
-  else w8_body<VALU, 1>(a);
+  w8_body<VALU>(a);
 }
 
 bool grad_w8_eligible(const NetDims& nd) {
