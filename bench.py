@@ -132,10 +132,32 @@ def cpu_baseline(args):
     t0 = time.perf_counter()
     synthetic_iteration(pol, buf, hp, obs, rew, done)
     dt = time.perf_counter() - t0
-    return {"value": T * E / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
-            "os_cpu_count": os.cpu_count(),
-            "sample": f"1 PPO iteration of 1 agent (n_envs={E}, n_steps={T}, batch={args.batch_size}, "
-                      f"n_epochs={args.n_epochs}) = {T * E} agent-steps in {dt:.2f}s, torch threads={cores}"}
+    out = {"value": T * E / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+           "os_cpu_count": os.cpu_count(),
+           "sample": f"1 PPO iteration of 1 agent (n_envs={E}, n_steps={T}, batch={args.batch_size}, "
+                     f"n_epochs={args.n_epochs}) = {T * E} agent-steps in {dt:.2f}s, torch threads={cores}"}
+    # SURVEY.md 8d also asks for (i) the reference's own semantics -- E = 1, n_steps = 2048, batch 64, 10 epochs: batch-1
+    # forwards and 320 Adam steps per 2048 transitions (agents.py:111-203 on SB3 defaults) -- and for one host thread.
+    # Bounded samples: a quarter rollout of (i) on all threads and on one thread (the update dominates and scales with it).
+    try:
+        def timed_e1(threads):
+            th.set_num_threads(threads)
+            T1 = 512
+            pol1 = MlpPolicyOracle(obs_spec, act_spec)
+            buf1 = RolloutBufferOracle(T1, 1, obs_spec.stored_len, act_spec.stored_len)
+            idx = np.arange(T1) % T
+            o1, r1, d1 = obs[idx][:, :1], rew[idx][:, :1], done[idx][:, :1]
+            t1 = time.perf_counter()
+            synthetic_iteration(pol1, buf1, PPOHyper(batch_size=64, n_epochs=10), o1, r1, d1)
+            return T1 / (time.perf_counter() - t1)
+        out["reference_semantics_E1"] = {"value": timed_e1(cores), "cores": cores, "unit": "agent-steps/s",
+                                         "sample": "n_envs=1, 512 of the 2048 default n_steps, batch 64, 10 epochs"}
+        out["reference_semantics_E1_single_thread"] = {"value": timed_e1(1), "cores": 1, "unit": "agent-steps/s",
+                                                       "sample": "same, torch.set_num_threads(1)"}
+        th.set_num_threads(cores)
+    except Exception as exc:  # noqa: BLE001 -- extra figures, never fatal
+        out["reference_semantics_E1"] = {"error": str(exc)}
+    return out
 
 
 def roofline(args, agent):
