@@ -842,31 +842,20 @@ int ph_liar_selfplay_step(ph_ctx* ctx, const ph_liar_selfplay* sp, int ego_pos, 
                           s.ego_actions, nullptr, s.ego_values, s.ego_log_probs, nullptr, nullptr, s.ego_rb, ego_pos,
                           s.ego_episode_start, nullptr, 0))
       return 1;
-    PH_HIP(ph::launch_liar_step(s.hands, s.history, s.nmoves, s.ego_actions, s.ones8, nullptr, s.obs_next, s.rew1, s.done1,
-                                s.n, st));
     PH_HIP(ph::launch_liar_sp_after_ego(s, st));
     // partner replies where the game goes on (obs_next = its observation there)
     if (ph_policy_forward_ragged(ctx, s.spec, s.alt_params, s.obs_next, nullptr, s.alt_seed, 2 * counter, 0, s.alt_actions,
                                  s.alt_values, s.alt_log_probs, s.alt_rb, s.alt_pos, s.can, s.es_alt))
       return 1;
-    PH_HIP(ph::launch_liar_sp_commit(s, s.running, st));
-    PH_HIP(ph::launch_liar_step(s.hands, s.history, s.nmoves, s.alt_actions, s.zeros8, s.running, s.obs_next, s.rew2,
-                                s.done2, s.n, st));
-    PH_HIP(ph::launch_liar_sp_after_alt(s, s.ego_rb->rewards + (size_t)ego_pos * s.n, st));
   }
-  // finished tables (flagged in s.done) are re-dealt; where the partner opens the new game it moves once
-  PH_HIP(ph::launch_liar_reset(s.hands, s.history, s.nmoves, s.done, s.ego_first, s.dice_seed, counter, s.probegostart, s.n,
-                               st));
-  PH_HIP(ph::launch_liar_sp_openers(s, st));
-  PH_HIP(ph::launch_liar_obs(s.hands, s.history, s.nmoves, s.zeros8, s.alt_opens, s.obs_alt, s.n, st));
+  // reply played and credited; finished tables (flagged in s.done) are re-dealt; where the partner opens the new game it
+  // moves once
+  PH_HIP(ph::launch_liar_sp_after_reply(s, deal_only ? nullptr : s.ego_rb->rewards + (size_t)ego_pos * s.n, counter,
+                                        deal_only, st));
   if (ph_policy_forward_ragged(ctx, s.spec, s.alt_params, s.obs_alt, nullptr, s.alt_seed, 2 * counter + 1, 0, s.alt_actions,
                                s.alt_values, s.alt_log_probs, s.alt_rb, s.alt_pos, s.can, s.es_alt))
     return 1;
-  PH_HIP(ph::launch_liar_sp_commit(s, s.alt_opens, st));
-  PH_HIP(ph::launch_liar_step(s.hands, s.history, s.nmoves, s.alt_actions, s.zeros8, s.alt_opens, s.obs_next, s.rew2,
-                              s.done2, s.n, st));
-  PH_HIP(ph::launch_liar_sp_opened(s, st));
-  PH_HIP(ph::launch_liar_obs(s.hands, s.history, s.nmoves, s.ones8, s.ego_opens, s.obs_ego, s.n, st));
+  PH_HIP(ph::launch_liar_sp_after_opening(s, st));
   return 0;
 }
 

@@ -22,24 +22,27 @@ hipError_t launch_rps_step(const int* ego_act, const int* alt_act, float* ego_re
 
 constexpr int LD_SIDES = 6, LD_DICE = 6, LD_MAXMOVES = 12;
 
-// One move of Liar's Dice in every environment with active[e] != 0.
+// LiarEnv.getObs (liar.py:53-56): a hand + the history padded with the null move [6, 0]
+__device__ __forceinline__ void liar_write_obs(const int* hand, const int* hist, int nm, float* o) {
+  for (int k = 0; k < 6; ++k) o[k] = (float)hand[k];
+  for (int m = 0; m < LD_MAXMOVES; ++m) {
+    o[6 + 2 * m] = (float)(m < nm ? hist[2 * m] : LD_SIDES);
+    o[7 + 2 * m] = (float)(m < nm ? hist[2 * m + 1] : 0);
+  }
+}
+
+// One move of Liar's Dice in table e.
 //   hands   (n, 12) int32 : ego histogram (6) then partner histogram (6)
 //   history (n, 24) int32 : moves newest first (side, count-1); nmoves (n) int32
-//   actions (n, 2)  int32 : raw (side, count-1) proposed by whoever moves; is_ego (n) u8 says who that is
+//   actions (n, 2)  int32 : raw (side, count-1) proposed by whoever moves; `ego` says who that is
 // Outputs: obs_next (n, 30) f32 = observation of the OTHER player (liar.py:53-56), rew (n, 2) f32 (ego, partner),
 //          done (n) u8.  History / nmoves are updated in place.
-__global__ void liar_step_kernel(const int* __restrict__ hands, int* __restrict__ history, int* __restrict__ nmoves,
-                                 const int* __restrict__ actions, const unsigned char* __restrict__ is_ego,
-                                 const unsigned char* __restrict__ active, float* __restrict__ obs_next,
-                                 float* __restrict__ rew, unsigned char* __restrict__ done, int n) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  if (active && !active[e]) return;
+__device__ __forceinline__ void liar_move(int e, const int* hands, int* history, int* nmoves, const int* actions, bool ego,
+                                          float* obs_next, float* rew, unsigned char* done) {
   const int* hand = hands + (size_t)e * 12;
   int* hist = history + (size_t)e * 24;
   int nm = nmoves[e];
   int a0 = actions[2 * e], a1 = actions[2 * e + 1];
-  const bool ego = is_ego[e] != 0;
   // sanitize_action (liar.py:58-67)
   bool call = false;
   if (nm > 0) {
@@ -68,17 +71,36 @@ __global__ void liar_step_kernel(const int* __restrict__ hands, int* __restrict_
     nm += 1;
     nmoves[e] = nm;
   }
-  // getObs(not isego): the other player's hand + history padded with the null move [6, 0]
-  float* o = obs_next + (size_t)e * 30;
-  const int* oh = hand + (ego ? 6 : 0);
-  for (int k = 0; k < 6; ++k) o[k] = (float)oh[k];
-  for (int m = 0; m < LD_MAXMOVES; ++m) {
-    o[6 + 2 * m] = (float)(m < nm ? hist[2 * m] : LD_SIDES);
-    o[7 + 2 * m] = (float)(m < nm ? hist[2 * m + 1] : 0);
-  }
+  liar_write_obs(hand + (ego ? 6 : 0), hist, nm, obs_next + (size_t)e * 30);  // getObs(not isego)
   rew[2 * e] = r_ego;
   rew[2 * e + 1] = r_alt;
   done[e] = d;
+}
+
+// LiarEnv.multi_reset of table e: N_DICE dice per player from Philox4x32-10 (one draw per die, like the reference's
+// randint per die), empty history, first mover ~ Bernoulli(probegostart)
+__device__ __forceinline__ void liar_deal(int e, int* hands, int* history, int* nmoves, unsigned char* ego_first,
+                                          uint64_t seed, uint64_t counter, float probegostart) {
+  int* hand = hands + (size_t)e * 12;
+  for (int k = 0; k < 12; ++k) hand[k] = 0;
+  for (int die = 0; die < 2 * LD_DICE; ++die) {
+    const float u = philox_uniform(seed, counter, (uint32_t)e, (uint32_t)die);
+    int side = (int)(u * LD_SIDES);
+    side = side >= LD_SIDES ? LD_SIDES - 1 : side;
+    hand[(die < LD_DICE ? 0 : 6) + side] += 1;
+  }
+  for (int k = 0; k < 24; ++k) history[(size_t)e * 24 + k] = 0;
+  nmoves[e] = 0;
+  ego_first[e] = philox_uniform(seed, counter, (uint32_t)e, 100u) < probegostart ? 1 : 0;
+}
+
+__global__ void liar_step_kernel(const int* hands, int* history, int* nmoves, const int* actions,
+                                 const unsigned char* __restrict__ is_ego, const unsigned char* __restrict__ active,
+                                 float* obs_next, float* rew, unsigned char* done, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  if (active && !active[e]) return;
+  liar_move(e, hands, history, nmoves, actions, is_ego[e] != 0, obs_next, rew, done);
 }
 hipError_t launch_liar_step(const int* hands, int* history, int* nmoves, const int* actions, const unsigned char* is_ego,
                             const unsigned char* active, float* obs_next, float* rew, unsigned char* done, int n,
@@ -95,15 +117,7 @@ __global__ void liar_obs_kernel(const int* __restrict__ hands, const int* __rest
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   if (active && !active[e]) return;
-  const int* hand = hands + (size_t)e * 12 + (is_ego[e] ? 0 : 6);
-  const int* hist = history + (size_t)e * 24;
-  const int nm = nmoves[e];
-  float* o = obs_out + (size_t)e * 30;
-  for (int k = 0; k < 6; ++k) o[k] = (float)hand[k];
-  for (int m = 0; m < LD_MAXMOVES; ++m) {
-    o[6 + 2 * m] = (float)(m < nm ? hist[2 * m] : LD_SIDES);
-    o[7 + 2 * m] = (float)(m < nm ? hist[2 * m + 1] : 0);
-  }
+  liar_write_obs(hands + (size_t)e * 12 + (is_ego[e] ? 0 : 6), history + (size_t)e * 24, nmoves[e], obs_out + (size_t)e * 30);
 }
 hipError_t launch_liar_obs(const int* hands, const int* history, const int* nmoves, const unsigned char* is_ego,
                            const unsigned char* active, float* obs_out, int n, hipStream_t s) {
@@ -112,25 +126,13 @@ hipError_t launch_liar_obs(const int* hands, const int* history, const int* nmov
   return hipGetLastError();
 }
 
-// LiarEnv.multi_reset for every env with reset_mask[e] != 0: N_DICE dice per player from Philox4x32-10 (one draw per
-// die, like the reference's randint per die), empty history, first mover ~ Bernoulli(probegostart)
 __global__ void liar_reset_kernel(int* __restrict__ hands, int* __restrict__ history, int* __restrict__ nmoves,
                                   const unsigned char* __restrict__ reset_mask, unsigned char* __restrict__ ego_first,
                                   uint64_t seed, uint64_t counter, float probegostart, int n) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   if (reset_mask && !reset_mask[e]) return;
-  int* hand = hands + (size_t)e * 12;
-  for (int k = 0; k < 12; ++k) hand[k] = 0;
-  for (int die = 0; die < 2 * LD_DICE; ++die) {
-    const float u = philox_uniform(seed, counter, (uint32_t)e, (uint32_t)die);
-    int side = (int)(u * LD_SIDES);
-    side = side >= LD_SIDES ? LD_SIDES - 1 : side;
-    hand[(die < LD_DICE ? 0 : 6) + side] += 1;
-  }
-  for (int k = 0; k < 24; ++k) history[(size_t)e * 24 + k] = 0;
-  nmoves[e] = 0;
-  ego_first[e] = philox_uniform(seed, counter, (uint32_t)e, 100u) < probegostart ? 1 : 0;
+  liar_deal(e, hands, history, nmoves, ego_first, seed, counter, probegostart);
 }
 hipError_t launch_liar_reset(int* hands, int* history, int* nmoves, const unsigned char* reset_mask,
                              unsigned char* ego_first, unsigned long long seed, unsigned long long counter,
@@ -142,7 +144,9 @@ hipError_t launch_liar_reset(int* hands, int* history, int* nmoves, const unsign
 
 // ---- vectorised Liar's Dice self-play: the step loop's book-keeping, one lane per table ------------------------------------
 // (MultiAgentEnv._update_players / _get_actions, multiagentenv.py:149-170, and OnPolicyAgent.update, agents.py:186-203,
-// applied to n tables; the partner's rollout rows are ragged: table e writes row alt_pos[e])
+// applied to n tables; the partner's rollout rows are ragged: table e writes row alt_pos[e]).  A table's state is touched
+// by its own lane only, so everything between two policy forwards is ONE launch: a vectorised step is
+//   ego forward | after_ego | partner forward | after_reply | partner forward (openers) | after_opening
 __device__ __forceinline__ void liar_sp_credit(const ph_liar_selfplay& s, float* alt_rewards, int alt_T, int e, float r, bool done,
                                                bool credited) {
   const bool m = credited && s.alt_open[e];
@@ -158,20 +162,8 @@ __device__ __forceinline__ void liar_sp_prepare(const ph_liar_selfplay& s, int a
   s.can[e] = (requested && s.alt_pos[e] < alt_T) ? 1 : 0;
   s.es_alt[e] = s.alt_boundary[e] ? 1.f : 0.f;
 }
-// after the ego's move: credit the partner where it already acted this game, find the tables that go on
-__global__ void liar_sp_after_ego_kernel(ph_liar_selfplay s, float* alt_rewards, int alt_T) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= s.n) return;
-  const bool d1 = s.done1[e] != 0;
-  liar_sp_credit(s, alt_rewards, alt_T, e, s.rew1[2 * e + 1], d1, s.alt_acted[e] != 0);
-  s.running[e] = d1 ? 0 : 1;
-  liar_sp_prepare(s, alt_T, e, !d1);
-}
-// after a partner forward: advance the recorded columns, open / close the reward window, mark the partner as having acted
-__global__ void liar_sp_commit_kernel(ph_liar_selfplay s, const unsigned char* __restrict__ requested) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= s.n) return;
-  if (!requested[e]) return;
+// after a partner forward: advance the recorded column, open / close the reward window, mark the partner as having acted
+__device__ __forceinline__ void liar_sp_commit(const ph_liar_selfplay& s, int e) {
   if (s.can[e]) {
     s.alt_pos[e] += 1;
     s.alt_boundary[e] = 0;
@@ -182,60 +174,80 @@ __global__ void liar_sp_commit_kernel(ph_liar_selfplay s, const unsigned char* _
   }
   s.alt_acted[e] = 1;
 }
-// after the partner's reply: credit both, the ego's reward row / episode flags / next observation, finished games
-__global__ void liar_sp_after_alt_kernel(ph_liar_selfplay s, float* alt_rewards, int alt_T, float* __restrict__ ego_rew_row) {
+
+// the ego has moved (its forward wrote ego_actions): play the move, credit the partner where it already acted this game,
+// find the tables that go on and prepare the partner's reply there
+__global__ void liar_sp_after_ego_kernel(ph_liar_selfplay s, float* alt_rewards, int alt_T) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= s.n) return;
-  const bool run = s.running[e] != 0;
-  const bool d2 = run && s.done2[e] != 0;
-  liar_sp_credit(s, alt_rewards, alt_T, e, s.rew2[2 * e + 1], d2, run);
-  const bool done = s.done1[e] != 0 || d2;
-  ego_rew_row[e] += s.rew1[2 * e] + (run ? s.rew2[2 * e] : 0.f);    // both transitions of the step (agents.py:44-47)
-  s.ego_episode_start[e] = done ? 1.f : 0.f;
-  if (run && !d2) {
-    for (int k = 0; k < 30; ++k) s.obs_ego[(size_t)e * 30 + k] = s.obs_next[(size_t)e * 30 + k];
-  }
-  s.done[e] = done ? 1 : 0;
-  if (done) {
-    s.alt_acted[e] = 0;
-    atomicAdd(s.episodes, 1ull);
-  }
+  liar_move(e, s.hands, s.history, s.nmoves, s.ego_actions, true, s.obs_next, s.rew1, s.done1);
+  const bool d1 = s.done1[e] != 0;
+  liar_sp_credit(s, alt_rewards, alt_T, e, s.rew1[2 * e + 1], d1, s.alt_acted[e] != 0);
+  s.running[e] = d1 ? 0 : 1;
+  liar_sp_prepare(s, alt_T, e, !d1);
 }
-// after the re-deal: who opens the new games; the partner's opening forward is prepared like any other
-__global__ void liar_sp_openers_kernel(ph_liar_selfplay s, int alt_T) {
+// the partner has replied where the game went on: play that move, credit both, the ego's reward row / episode flags /
+// next observation; then (also the whole of a deal-only call) re-deal the finished tables, find who opens the new games
+// and prepare the partner's opening forward
+__global__ void liar_sp_after_reply_kernel(ph_liar_selfplay s, float* alt_rewards, int alt_T, float* ego_rew_row,
+                                           uint64_t counter, int deal_only) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= s.n) return;
-  const bool fresh = s.done[e] != 0, ego_first = s.ego_first[e] != 0;
+  if (!deal_only) {
+    const bool run = s.running[e] != 0;
+    if (run) {
+      liar_sp_commit(s, e);
+      liar_move(e, s.hands, s.history, s.nmoves, s.alt_actions, false, s.obs_next, s.rew2, s.done2);
+    }
+    const bool d2 = run && s.done2[e] != 0;
+    liar_sp_credit(s, alt_rewards, alt_T, e, s.rew2[2 * e + 1], d2, run);
+    const bool done = s.done1[e] != 0 || d2;
+    ego_rew_row[e] += s.rew1[2 * e] + (run ? s.rew2[2 * e] : 0.f);    // both transitions of the step (agents.py:44-47)
+    s.ego_episode_start[e] = done ? 1.f : 0.f;
+    if (run && !d2) {
+      for (int k = 0; k < 30; ++k) s.obs_ego[(size_t)e * 30 + k] = s.obs_next[(size_t)e * 30 + k];
+    }
+    s.done[e] = done ? 1 : 0;
+    if (done) {
+      s.alt_acted[e] = 0;
+      atomicAdd(s.episodes, 1ull);
+    }
+  }
+  const bool fresh = s.done[e] != 0;
+  if (fresh) liar_deal(e, s.hands, s.history, s.nmoves, s.ego_first, s.dice_seed, counter, s.probegostart);
+  const bool ego_first = s.ego_first[e] != 0;
   s.alt_opens[e] = (fresh && !ego_first) ? 1 : 0;
   s.ego_opens[e] = (fresh && ego_first) ? 1 : 0;
   if (fresh) s.alt_acted[e] = 0;
   liar_sp_prepare(s, alt_T, e, fresh && !ego_first);
+  if (fresh && !ego_first)
+    liar_write_obs(s.hands + (size_t)e * 12 + 6, s.history + (size_t)e * 24, s.nmoves[e], s.obs_alt + (size_t)e * 30);
 }
-// after the partner's opening move: the ego's observation of those tables
-__global__ void liar_sp_opened_kernel(ph_liar_selfplay s) {
+// the partner has opened the new games it starts: play that move; the ego's observation of every fresh table
+__global__ void liar_sp_after_opening_kernel(ph_liar_selfplay s) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= s.n || !s.alt_opens[e]) return;
-  for (int k = 0; k < 30; ++k) s.obs_ego[(size_t)e * 30 + k] = s.obs_next[(size_t)e * 30 + k];
+  if (e >= s.n) return;
+  if (s.alt_opens[e]) {
+    liar_sp_commit(s, e);
+    liar_move(e, s.hands, s.history, s.nmoves, s.alt_actions, false, s.obs_next, s.rew2, s.done2);
+    for (int k = 0; k < 30; ++k) s.obs_ego[(size_t)e * 30 + k] = s.obs_next[(size_t)e * 30 + k];
+  }
+  if (s.ego_opens[e])
+    liar_write_obs(s.hands + (size_t)e * 12, s.history + (size_t)e * 24, s.nmoves[e], s.obs_ego + (size_t)e * 30);
 }
 #define PH_SP_GRID(s) dim3(((s).n + 255) / 256), dim3(256)
 hipError_t launch_liar_sp_after_ego(const ph_liar_selfplay& s, hipStream_t st) {
   hipLaunchKernelGGL(liar_sp_after_ego_kernel, PH_SP_GRID(s), 0, st, s, s.alt_rb->rewards, s.alt_rb->T);
   return hipGetLastError();
 }
-hipError_t launch_liar_sp_commit(const ph_liar_selfplay& s, const unsigned char* requested, hipStream_t st) {
-  hipLaunchKernelGGL(liar_sp_commit_kernel, PH_SP_GRID(s), 0, st, s, requested);
+hipError_t launch_liar_sp_after_reply(const ph_liar_selfplay& s, float* ego_rew_row, unsigned long long counter, int deal_only,
+                                      hipStream_t st) {
+  hipLaunchKernelGGL(liar_sp_after_reply_kernel, PH_SP_GRID(s), 0, st, s, s.alt_rb->rewards, s.alt_rb->T, ego_rew_row,
+                     (uint64_t)counter, deal_only);
   return hipGetLastError();
 }
-hipError_t launch_liar_sp_after_alt(const ph_liar_selfplay& s, float* ego_rew_row, hipStream_t st) {
-  hipLaunchKernelGGL(liar_sp_after_alt_kernel, PH_SP_GRID(s), 0, st, s, s.alt_rb->rewards, s.alt_rb->T, ego_rew_row);
-  return hipGetLastError();
-}
-hipError_t launch_liar_sp_openers(const ph_liar_selfplay& s, hipStream_t st) {
-  hipLaunchKernelGGL(liar_sp_openers_kernel, PH_SP_GRID(s), 0, st, s, s.alt_rb->T);
-  return hipGetLastError();
-}
-hipError_t launch_liar_sp_opened(const ph_liar_selfplay& s, hipStream_t st) {
-  hipLaunchKernelGGL(liar_sp_opened_kernel, PH_SP_GRID(s), 0, st, s);
+hipError_t launch_liar_sp_after_opening(const ph_liar_selfplay& s, hipStream_t st) {
+  hipLaunchKernelGGL(liar_sp_after_opening_kernel, PH_SP_GRID(s), 0, st, s);
   return hipGetLastError();
 }
 

@@ -197,10 +197,9 @@ hipError_t launch_liar_step(const int* hands, int* history, int* nmoves, const i
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
 // device-side book-keeping of the vectorised Liar's Dice self-play step (ph_envs.hip)
 hipError_t launch_liar_sp_after_ego(const ph_liar_selfplay& s, hipStream_t st);
-hipError_t launch_liar_sp_commit(const ph_liar_selfplay& s, const unsigned char* requested, hipStream_t st);
-hipError_t launch_liar_sp_after_alt(const ph_liar_selfplay& s, float* ego_rew_row, hipStream_t st);
-hipError_t launch_liar_sp_openers(const ph_liar_selfplay& s, hipStream_t st);
-hipError_t launch_liar_sp_opened(const ph_liar_selfplay& s, hipStream_t st);
+hipError_t launch_liar_sp_after_reply(const ph_liar_selfplay& s, float* ego_rew_row, unsigned long long counter, int deal_only,
+                                      hipStream_t st);
+hipError_t launch_liar_sp_after_opening(const ph_liar_selfplay& s, hipStream_t st);
 // peer-to-peer action exchange (ph_envs.hip)
 hipError_t launch_p2p_push(const ph_p2p& x, const int* local, int t, hipStream_t s);
 hipError_t launch_p2p_wait(const ph_p2p& x, int t, hipStream_t s);

@@ -147,6 +147,74 @@ __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDim
   return act;
 }
 
+// General action head of one row, one lane per row, the row's logits z[0..L) in LDS (modified in place): optional mask
+// offset, logits output, then per action component sampling / argmax / given action, log-prob, entropy and the
+// rollout-buffer writes (Discrete and MultiDiscrete; Discrete with <= 8 logits takes the register path)
+__device__ __forceinline__ void general_row_tail(const FwdArgs& a, const NetDims& nd, int g, float* z) {
+  const uint64_t ctr = a.counter + (a.epoch ? (uint64_t)(*a.epoch) << 32 : 0ull);
+  const bool small = nd.A == 1 && nd.L <= 8;
+  if (a.mask && !small) {  // modular/policies.py:330-333 : logits - 30*(~mask)
+    for (int k = 0; k < nd.L; ++k) z[k] = z[k] - 30.0f * (1.0f - (float)(a.mask[(size_t)g * nd.L + k] != 0));
+  }
+  if (a.logits && !small)
+    for (int k = 0; k < nd.L; ++k) a.logits[(size_t)g * nd.L + k] = z[k];
+  float logp = 0.f, ent = 0.f;
+  if (small) {
+    // fast path (Discrete action space, <= 8 logits): the row lives in registers, one exp per logit
+    float zr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) zr[k] = (k < nd.L) ? z[k] : 0.f;
+    discrete8_row_tail(a, nd, g, zr);
+    return;
+  } else
+  for (int c = 0; c < nd.A; ++c) {
+    const int lo = nd.act_off[c], nk = nd.act_off[c + 1] - lo;
+    float m = z[lo];
+    for (int k = 1; k < nk; ++k) m = fmaxf(m, z[lo + k]);
+    float se = 0.f;
+    for (int k = 0; k < nk; ++k) se += fast_exp(z[lo + k] - m);
+    const float lse = m + fast_log(se);
+    int act;
+    if (a.given_actions) {
+      act = (int)a.given_actions[(size_t)g * nd.A + c];
+      act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
+    } else if (a.deterministic) {
+      act = 0;
+      float best = z[lo];
+      for (int k = 1; k < nk; ++k)
+        if (z[lo + k] > best) { best = z[lo + k]; act = k; }
+    } else {
+      const float u = a.uniforms ? a.uniforms[(size_t)g * nd.A + c]
+                                 : philox_uniform(a.seed, ctr, (uint32_t)g, (uint32_t)c);
+      float cum = 0.f;
+      act = 0;
+      for (int k = 0; k < nk - 1; ++k) {  // inverse CDF: count prefix sums <= u
+        cum += fast_exp(z[lo + k] - lse);
+        act += (u >= cum) ? 1 : 0;
+      }
+    }
+    float e = 0.f;
+    for (int k = 0; k < nk; ++k) {
+      const float lp = z[lo + k] - lse;
+      e -= fast_exp(lp) * lp;
+    }
+    logp += z[lo + act] - lse;
+    ent += e;
+    if (a.act_i32) a.act_i32[(size_t)g * nd.A + c] = act;
+    if (a.act_f32) a.act_f32[(size_t)g * nd.A + c] = (float)act;
+    if (a.rb_act) {
+      const long long ridx = rb_row(a, g);
+      if (ridx >= 0) a.rb_act[(size_t)ridx * nd.A + c] = (float)act;
+    }
+  }
+  if (a.logp) a.logp[g] = logp;
+  if (a.entropy) a.entropy[g] = ent;
+  if (a.rb_logp) {
+    const long long ridx = rb_row(a, g);
+    if (ridx >= 0) a.rb_logp[ridx] = logp;
+  }
+}
+
 template <int R, int LP, bool VALU>
 __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -272,73 +340,7 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
   PH_STAMP(a.prof, 6);
 
   // ---- distribution: one lane per row ----
-  if (tid < R && rowphys[tid] >= 0) {
-    const int g = row0 + tid;
-    float* z = outs + tid * LDO;
-    const uint64_t ctr = a.counter + (a.epoch ? (uint64_t)(*a.epoch) << 32 : 0ull);
-    const bool small = nd.A == 1 && nd.L <= 8;
-    if (a.mask && !small) {  // modular/policies.py:330-333 : logits - 30*(~mask)
-      for (int k = 0; k < nd.L; ++k) z[k] = z[k] - 30.0f * (1.0f - (float)(a.mask[(size_t)g * nd.L + k] != 0));
-    }
-    if (a.logits && !small)
-      for (int k = 0; k < nd.L; ++k) a.logits[(size_t)g * nd.L + k] = z[k];
-    float logp = 0.f, ent = 0.f;
-    if (small) {
-      // fast path (Discrete action space, <= 8 logits): the row lives in registers, one exp per logit
-      float zr[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) zr[k] = (k < nd.L) ? z[k] : 0.f;
-      discrete8_row_tail(a, nd, g, zr);
-      PH_STAMP(a.prof, 7);
-      return;
-    } else
-    for (int c = 0; c < nd.A; ++c) {
-      const int lo = nd.act_off[c], nk = nd.act_off[c + 1] - lo;
-      float m = z[lo];
-      for (int k = 1; k < nk; ++k) m = fmaxf(m, z[lo + k]);
-      float se = 0.f;
-      for (int k = 0; k < nk; ++k) se += fast_exp(z[lo + k] - m);
-      const float lse = m + fast_log(se);
-      int act;
-      if (a.given_actions) {
-        act = (int)a.given_actions[(size_t)g * nd.A + c];
-        act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
-      } else if (a.deterministic) {
-        act = 0;
-        float best = z[lo];
-        for (int k = 1; k < nk; ++k)
-          if (z[lo + k] > best) { best = z[lo + k]; act = k; }
-      } else {
-        const float u = a.uniforms ? a.uniforms[(size_t)g * nd.A + c]
-                                   : philox_uniform(a.seed, ctr, (uint32_t)g, (uint32_t)c);
-        float cum = 0.f;
-        act = 0;
-        for (int k = 0; k < nk - 1; ++k) {  // inverse CDF: count prefix sums <= u
-          cum += fast_exp(z[lo + k] - lse);
-          act += (u >= cum) ? 1 : 0;
-        }
-      }
-      float e = 0.f;
-      for (int k = 0; k < nk; ++k) {
-        const float lp = z[lo + k] - lse;
-        e -= fast_exp(lp) * lp;
-      }
-      logp += z[lo + act] - lse;
-      ent += e;
-      if (a.act_i32) a.act_i32[(size_t)g * nd.A + c] = act;
-      if (a.act_f32) a.act_f32[(size_t)g * nd.A + c] = (float)act;
-      if (a.rb_act) {
-        const long long ridx = rb_row(a, g);
-        if (ridx >= 0) a.rb_act[(size_t)ridx * nd.A + c] = (float)act;
-      }
-    }
-    if (a.logp) a.logp[g] = logp;
-    if (a.entropy) a.entropy[g] = ent;
-    if (a.rb_logp) {
-      const long long ridx = rb_row(a, g);
-      if (ridx >= 0) a.rb_logp[ridx] = logp;
-    }
-  }
+  if (tid < R && rowphys[tid] >= 0) general_row_tail(a, nd, row0 + tid, outs + tid * LDO);
   PH_STAMP(a.prof, 7);
 }
 
@@ -546,6 +548,197 @@ static hipError_t launch_fwd16_variant(const FwdArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- 16-row variant for one-hot observations (Discrete / MultiDiscrete spaces) with any action head ----------------------
+// SB3 feeds the one-hot encoding through a dense first layer (F = 270 for Liar's Dice: 5 feature chunks, each a global ->
+// LDS -> MFMA round trip in the general kernel).  A one-hot row times W1 is the sum of D rows of W1: sixteen lanes per
+// observation row gather those rows (16 bytes per lane, all D loads in flight at once) and add them in component order,
+// which is the dense layer's k-ordered accumulation with the zero terms left out.  Layer 2 and the head run as in the
+// 16-row kernel above (one 16x16 output tile per wave); the head is the general Discrete / MultiDiscrete row tail.
+template <bool VALU>
+__device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int R = 16, NT = 256, LDO = 33, FS = 64;
+  const NetDims& nd = a.nd;
+  float* xs = smem;                 // [16][LDH]  H2
+  float* hs = xs + R * LDH;         // [16][LDH]  H1
+  float* w2s = hs + R * LDH;        // [64][LDH]
+  float* wos = w2s + HID * LDH;     // policy: act_W [64][LDH], columns >= L zero | value: val_W [64]
+  float* outs = wos + HID * LDH;    // [16][LDO] logits
+  float* b2s = outs + R * LDO;      // [64]
+  float* hbs = b2s + HID;           // act_b [32] | val_b
+  int* feat = (int*)(hbs + 32);     // [16][FS] hot row of W1 per (row, component), -1 = none
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int net = blockIdx.y;
+  const int row0 = blockIdx.x * R;
+  const ph_layout& lay = nd.lay;
+  const float* W1 = a.params + (net == 0 ? lay.pi_W1 : lay.vf_W1);
+  const float* B1 = a.params + (net == 0 ? lay.pi_b1 : lay.vf_b1);
+  const float* W2 = a.params + (net == 0 ? lay.pi_W2 : lay.vf_W2);
+  const float* B2 = a.params + (net == 0 ? lay.pi_b2 : lay.vf_b2);
+  const int D = nd.D;
+
+  PH_STAMP(a.prof, 0);
+  // the observation -> feature-row loads go first: the gather below waits for nothing issued after them
+  for (int e = tid; e < R * FS; e += NT) {
+    const int r = e >> 6, comp = e & 63, row = row0 + r;
+    int f = -1;
+    if (comp < D && row < a.n) {
+      const int lo = nd.obs_off[comp], nn = nd.obs_off[comp + 1] - lo;
+      int x = (int)a.obs[(size_t)row * D + comp];
+      x = x < 0 ? 0 : (x >= nn ? nn - 1 : x);
+      f = lo + x;
+    }
+    feat[e] = f;
+  }
+  WStage<NT> w2r;
+  w2r.issue(W2, 0, HID);
+  const int gr = tid >> 4, gl = tid & 15;   // gather: row gr, hidden units 4*gl .. 4*gl+3
+  float b1v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b1v[i] = B1[4 * gl + i];
+  float bias2 = 0.f, hb = 0.f, hv[8];
+  if (tid < HID) bias2 = B2[tid];
+  if (net == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {   // act_W [64][L] -> [64][32], zero padded
+      const int e = tid + NT * i, j = e >> 5, k = e & 31;
+      hv[i] = (k < nd.L) ? a.params[lay.act_W + j * nd.L + k] : 0.f;
+    }
+    if (tid < 32) hb = (tid < nd.L) ? a.params[lay.act_b + tid] : 0.f;
+  } else {
+    hv[0] = (tid < HID) ? a.params[lay.val_W + tid] : 0.f;
+    if (tid == 0) hb = a.params[lay.val_b];
+  }
+  lds_only_barrier();  // feat visible
+  PH_STAMP(a.prof, 1);
+
+  // ---- layer 1: gather-sum of W1 rows in component order ----
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const float* w1l = W1 + 4 * gl;
+    const int* fr = feat + gr * FS;
+    for (int c0 = 0; c0 < D; c0 += 16) {
+      float4 w[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int f = fr[c0 + u];   // components >= D read -1 (c0 + u < FS always: D <= 64)
+        w[u] = (f >= 0) ? *reinterpret_cast<const float4*>(w1l + (size_t)f * HID) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (c0 == 0) {   // everything staged for the later layers is committed while the first gather batch is in flight
+        w2r.commit(w2s);
+        if (tid < HID) b2s[tid] = bias2;
+        if (net == 0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int e = tid + NT * i;
+            wos[(e >> 5) * LDH + (e & 31)] = hv[i];
+          }
+          if (tid < 32) hbs[tid] = hb;
+        } else {
+          if (tid < HID) wos[tid] = hv[0];
+          if (tid == 0) hbs[0] = hb;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        acc.x += w[u].x;
+        acc.y += w[u].y;
+        acc.z += w[u].z;
+        acc.w += w[u].w;
+      }
+    }
+    float* h = hs + gr * LDH + 4 * gl;
+    h[0] = fast_tanh(acc.x + b1v[0]);
+    h[1] = fast_tanh(acc.y + b1v[1]);
+    h[2] = fast_tanh(acc.z + b1v[2]);
+    h[3] = fast_tanh(acc.w + b1v[3]);
+  }
+  lds_only_barrier();
+  PH_STAMP(a.prof, 3);
+
+  // one 16x16 output tile per wave: D[row 4g+r][col col0 + c] = sum_k A[row][k] W[k][col]; two accumulator chains
+  auto layer = [&](const float* A, const float* W, int col0) -> f32x4 {
+    f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = A + c * LDH + g;
+    const float* bp = W + g * LDH + col0 + c;
+    float av[16], bv[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      av[s] = ap[4 * s];
+      bv[s] = bp[4 * s * LDH];
+    }
+#pragma unroll
+    for (int s = 0; s < 16; s += 2) {
+      e = mma16<VALU>(av[s], bv[s], e, lane);
+      o = mma16<VALU>(av[s + 1], bv[s + 1], o, lane);
+    }
+    return e + o;
+  };
+  {
+    const f32x4 z2 = layer(hs, w2s, 16 * wave);
+    const float b = b2s[16 * wave + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xs[(4 * g + r) * LDH + 16 * wave + c] = fast_tanh(z2[r] + b);
+  }
+  lds_only_barrier();
+  PH_STAMP(a.prof, 5);
+
+  if (net == 0) {
+    // ---- policy head: logits [16][32] as two 16x16 tiles (waves 0, 1), then one lane per row ----
+    if (wave < 2) {
+      const f32x4 z3 = layer(xs, wos, 16 * wave);
+      const float b = hbs[16 * wave + c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) outs[(4 * g + r) * LDO + 16 * wave + c] = z3[r] + b;
+    }
+    lds_only_barrier();
+    PH_STAMP(a.prof, 6);
+    if (tid < R && row0 + tid < a.n) general_row_tail(a, nd, row0 + tid, outs + tid * LDO);
+  } else {
+    // ---- value head: wave 0, four lanes per row, quad-DPP reduction; every wave copies observations ----
+    if (wave == 0) {
+      const int r = lane >> 2, q = lane & 3;
+      float v = 0.f;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int j = 8 * q + (m & 7) + 32 * (m >> 3);
+        v = __builtin_fmaf(xs[r * LDH + j], wos[j], v);
+      }
+      v = quad_sum_f(v) + hbs[0];
+      if (q == 0 && row0 + r < a.n) value_row_tail(a, row0 + r, v);
+    }
+    copy_obs_rows(a, row0, (a.n - row0 < R) ? a.n - row0 : R, nd.D);
+  }
+  PH_STAMP(a.prof, 7);
+}
+
+template <bool VALU>
+__global__ __launch_bounds__(256) void policy_fwd16h_kernel(FwdArgs a) {
+  policy_fwd16h_body<VALU>(a);
+}
+
+static size_t fwd16h_lds_bytes() {
+  return sizeof(float) * (size_t)(2 * 16 * LDH + 2 * HID * LDH + 16 * 33 + HID + 32 + 16 * 64);
+}
+
+// one-hot observations of at most 64 components, at most 32 logits (any number of action components)
+static bool fwd16h_eligible(const NetDims& nd, int n) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("PH_FWD16H");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  return enabled && nd.obs_kind != PH_SPACE_BOX && nd.obs_off && nd.D <= 64 && nd.Lp == 32 && n < 16384;
+}
+
+template <bool VALU>
+static hipError_t launch_fwd16h_variant(const FwdArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((policy_fwd16h_kernel<VALU>), dim3((a.n + 15) / 16, 2), dim3(256), fwd16h_lds_bytes(), s, a);
+  return hipGetLastError();
+}
+
 template <int R, int LP, bool VALU>
 __global__ __launch_bounds__(R * 4) void policy_fwd_kernel(FwdArgs a) {
   policy_fwd_body<R, LP, VALU>(a);
@@ -613,6 +806,7 @@ hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s) {
   const bool lp64 = a.nd.Lp == 64;
   if (a.nd.Lp != 32 && a.nd.Lp != 64) return hipErrorInvalidValue;
   if (fwd16_eligible(a.nd, a.n)) return gemm_mode != 0 ? launch_fwd16_variant<true>(a, s) : launch_fwd16_variant<false>(a, s);
+  if (fwd16h_eligible(a.nd, a.n)) return gemm_mode != 0 ? launch_fwd16h_variant<true>(a, s) : launch_fwd16h_variant<false>(a, s);
   if (gemm_mode != 0) return lp64 ? launch_fwd_variant<32, 64, true>(a, s) : launch_fwd_variant<32, 32, true>(a, s);
   if (big) return lp64 ? launch_fwd_variant<64, 64, false>(a, s) : launch_fwd_variant<64, 32, false>(a, s);
   return lp64 ? launch_fwd_variant<32, 64, false>(a, s) : launch_fwd_variant<32, 32, false>(a, s);

@@ -1015,13 +1015,13 @@ def test_trainer_n_envs_runs_device_selfplay(game, tmp_path):
 
 
 def test_opt_in_kernel_variants_pass_the_gradient_and_forward_parity_tests():
-    """PH_GRAD_RP=1 / PH_GRAD_W8=1 (row-parallel and eight-wave gradient kernels), PH_GRAD_FAST=0 / PH_FWD16=0 (general kernels on the small shapes): the
+    """PH_GRAD_RP=1 / PH_GRAD_W8=1 (row-parallel and eight-wave gradient kernels), PH_GRAD_FAST=0 / PH_FWD16=0 / PH_FWD16H=0 (general kernels on the small and the one-hot shapes): the
     variant switches are read once per process, so each combination runs the parity tests in its own interpreter."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for env in ({"PH_GRAD_RP": "1"}, {"PH_GRAD_W8": "1"}, {"PH_GRAD_FAST": "0", "PH_FWD16": "0"}):
+    for env in ({"PH_GRAD_RP": "1"}, {"PH_GRAD_W8": "1"}, {"PH_GRAD_FAST": "0", "PH_FWD16": "0", "PH_FWD16H": "0"}):
         out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu", "-k",
                               "minibatch_gradient or forward_matches_oracle or mfma_and_valu or train_matches_oracle"],
                              cwd=root, env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
