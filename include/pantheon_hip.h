@@ -284,7 +284,9 @@ int ph_rps_step(ph_ctx *ctx, const int *ego_actions, const int *alt_actions, flo
  * active[e] != 0 (NULL = all).  hands (n,12) int32 = ego histogram then partner histogram; history (n,24) int32 moves
  * newest first, nmoves (n) int32 -- both updated in place; actions (n,2) int32 raw (side, count-1) of the mover,
  * is_ego (n) u8 = who moves.  Outputs: obs_next (n,30) f32 observation of the OTHER player, rewards (n,2) f32
- * (ego, partner), done (n) u8. */
+ * (ego, partner), done (n) u8.  hands / history must be 16-byte aligned, actions / obs / rewards 8-byte aligned (the
+ * kernels move a table's state with 16-byte accesses); the same holds for ph_liar_reset / ph_liar_obs and the arrays
+ * of ph_liar_selfplay. */
 int ph_liar_step(ph_ctx *ctx, const int *hands, int *history, int *nmoves, const int *actions,
                  const unsigned char *is_ego, const unsigned char *active, float *obs_next, float *rewards,
                  unsigned char *done, int n);

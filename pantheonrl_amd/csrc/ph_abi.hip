@@ -805,6 +805,8 @@ int ph_liar_step(ph_ctx* ctx, const int* hands, int* history, int* nmoves, const
   if (!hands || !history || !nmoves || !actions || !is_ego || !obs_next || !rewards || !done)
     return fail("ph_liar_step: null argument");
   if (n <= 0) return fail("ph_liar_step: n must be positive");
+  if (((uintptr_t)hands | (uintptr_t)history) % 16 || ((uintptr_t)actions | (uintptr_t)obs_next | (uintptr_t)rewards) % 8)
+    return fail("ph_liar_step: hands/history must be 16-byte aligned, actions/obs_next/rewards 8-byte aligned");
   PH_HIP(ph::launch_liar_step(hands, history, nmoves, actions, is_ego, active, obs_next, rewards, done, n, ctx->stream));
   return 0;
 }
@@ -815,6 +817,7 @@ int ph_liar_reset(ph_ctx* ctx, int* hands, int* history, int* nmoves, const unsi
   if (!ctx) return fail("null ctx");
   if (!hands || !history || !nmoves || !ego_first) return fail("ph_liar_reset: null argument");
   if (n <= 0) return fail("ph_liar_reset: n must be positive");
+  if (((uintptr_t)hands | (uintptr_t)history) % 16) return fail("ph_liar_reset: hands/history must be 16-byte aligned");
   PH_HIP(ph::launch_liar_reset(hands, history, nmoves, reset_mask, ego_first, seed, counter, probegostart, n, ctx->stream));
   return 0;
 }
@@ -824,6 +827,8 @@ int ph_liar_obs(ph_ctx* ctx, const int* hands, const int* history, const int* nm
   if (!ctx) return fail("null ctx");
   if (!hands || !history || !nmoves || !is_ego || !obs_out) return fail("ph_liar_obs: null argument");
   if (n <= 0) return fail("ph_liar_obs: n must be positive");
+  if (((uintptr_t)hands | (uintptr_t)history) % 16 || (uintptr_t)obs_out % 8)
+    return fail("ph_liar_obs: hands/history must be 16-byte aligned, obs_out 8-byte aligned");
   PH_HIP(ph::launch_liar_obs(hands, history, nmoves, is_ego, active, obs_out, n, ctx->stream));
   return 0;
 }
@@ -834,6 +839,10 @@ int ph_liar_selfplay_step(ph_ctx* ctx, const ph_liar_selfplay* sp, int ego_pos, 
   if (s.n <= 0 || !s.spec || !s.ego_rb || !s.alt_rb) return fail("ph_liar_selfplay_step: incomplete description");
   if (check_rb(s.ego_rb) || check_rb(s.alt_rb)) return 1;
   if (s.ego_rb->E != s.n || s.alt_rb->E != s.n) return fail("ph_liar_selfplay_step: buffers must have E = n");
+  if (((uintptr_t)s.hands | (uintptr_t)s.history) % 16 ||
+      ((uintptr_t)s.ego_actions | (uintptr_t)s.alt_actions | (uintptr_t)s.obs_ego | (uintptr_t)s.obs_alt | (uintptr_t)s.obs_next |
+       (uintptr_t)s.rew1 | (uintptr_t)s.rew2) % 8)
+    return fail("ph_liar_selfplay_step: hands/history must be 16-byte aligned, actions/observations/rewards 8-byte aligned");
   hipStream_t st = ctx->stream;
   if (!deal_only) {
     if (ego_pos < 0 || ego_pos >= s.ego_rb->T) return fail("ph_liar_selfplay_step: ego_pos out of range (buffer full?)");

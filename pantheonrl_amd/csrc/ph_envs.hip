@@ -22,31 +22,63 @@ hipError_t launch_rps_step(const int* ego_act, const int* alt_act, float* ego_re
 
 constexpr int LD_SIDES = 6, LD_DICE = 6, LD_MAXMOVES = 12;
 
-// LiarEnv.getObs (liar.py:53-56): a hand + the history padded with the null move [6, 0]
-__device__ __forceinline__ void liar_write_obs(const int* hand, const int* hist, int nm, float* o) {
-  for (int k = 0; k < 6; ++k) o[k] = (float)hand[k];
-  for (int m = 0; m < LD_MAXMOVES; ++m) {
-    o[6 + 2 * m] = (float)(m < nm ? hist[2 * m] : LD_SIDES);
-    o[7 + 2 * m] = (float)(m < nm ? hist[2 * m + 1] : 0);
+// A table's state lives in registers while a lane works on it: 16-byte loads / stores of the (12) hand and (24) history rows,
+// every index a compile-time constant (a loop of dependent global loads and stores costs a memory latency per iteration).
+struct LiarTable {
+  int hand[12];   // ego histogram (6) then partner histogram (6)
+  int hist[24];   // moves newest first (side, count-1)
+  int nm;
+};
+__device__ __forceinline__ void liar_load(LiarTable& t, int e, const int* hands, const int* history, const int* nmoves) {
+  const int4* hp = reinterpret_cast<const int4*>(hands + (size_t)e * 12);
+  const int4* qp = reinterpret_cast<const int4*>(history + (size_t)e * 24);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int4 v = hp[i];
+    t.hand[4 * i] = v.x; t.hand[4 * i + 1] = v.y; t.hand[4 * i + 2] = v.z; t.hand[4 * i + 3] = v.w;
   }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int4 v = qp[i];
+    t.hist[4 * i] = v.x; t.hist[4 * i + 1] = v.y; t.hist[4 * i + 2] = v.z; t.hist[4 * i + 3] = v.w;
+  }
+  t.nm = nmoves[e];
+}
+__device__ __forceinline__ void liar_store_history(const LiarTable& t, int e, int* history, int* nmoves) {
+  int4* qp = reinterpret_cast<int4*>(history + (size_t)e * 24);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) qp[i] = make_int4(t.hist[4 * i], t.hist[4 * i + 1], t.hist[4 * i + 2], t.hist[4 * i + 3]);
+  nmoves[e] = t.nm;
+}
+__device__ __forceinline__ void liar_store_hands(const LiarTable& t, int e, int* hands) {
+  int4* hp = reinterpret_cast<int4*>(hands + (size_t)e * 12);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) hp[i] = make_int4(t.hand[4 * i], t.hand[4 * i + 1], t.hand[4 * i + 2], t.hand[4 * i + 3]);
 }
 
-// One move of Liar's Dice in table e.
-//   hands   (n, 12) int32 : ego histogram (6) then partner histogram (6)
-//   history (n, 24) int32 : moves newest first (side, count-1); nmoves (n) int32
+// LiarEnv.getObs (liar.py:53-56): a player's hand + the history padded with the null move [6, 0]; o = 30 floats, 8-byte aligned
+__device__ __forceinline__ void liar_write_obs(const LiarTable& t, bool ego, float* o) {
+  float2* o2 = reinterpret_cast<float2*>(o);
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    o2[k] = make_float2((float)(ego ? t.hand[2 * k] : t.hand[6 + 2 * k]), (float)(ego ? t.hand[2 * k + 1] : t.hand[7 + 2 * k]));
+#pragma unroll
+  for (int m = 0; m < LD_MAXMOVES; ++m)
+    o2[3 + m] = make_float2((float)(m < t.nm ? t.hist[2 * m] : LD_SIDES), (float)(m < t.nm ? t.hist[2 * m + 1] : 0));
+}
+// One move of Liar's Dice in table e (state in t, written back when it changes).
 //   actions (n, 2)  int32 : raw (side, count-1) proposed by whoever moves; `ego` says who that is
 // Outputs: obs_next (n, 30) f32 = observation of the OTHER player (liar.py:53-56), rew (n, 2) f32 (ego, partner),
 //          done (n) u8.  History / nmoves are updated in place.
-__device__ __forceinline__ void liar_move(int e, const int* hands, int* history, int* nmoves, const int* actions, bool ego,
+__device__ __forceinline__ void liar_move(LiarTable& t, int e, int* history, int* nmoves, const int* actions, bool ego,
                                           float* obs_next, float* rew, unsigned char* done) {
-  const int* hand = hands + (size_t)e * 12;
-  int* hist = history + (size_t)e * 24;
-  int nm = nmoves[e];
-  int a0 = actions[2 * e], a1 = actions[2 * e + 1];
+  const int nm = t.nm;
+  const int2 act = *reinterpret_cast<const int2*>(actions + 2 * (size_t)e);
+  int a0 = act.x, a1 = act.y;
   // sanitize_action (liar.py:58-67)
   bool call = false;
   if (nm > 0) {
-    if (a1 <= hist[1] || a0 == LD_SIDES) call = true;
+    if (a1 <= t.hist[1] || a0 == LD_SIDES) call = true;
   } else if (a0 == LD_SIDES) {
     a0 = 0;
     a1 = 0;
@@ -57,40 +89,48 @@ __device__ __forceinline__ void liar_move(int e, const int* hands, int* history,
   if (call) {
     bool bluff = false;  // eval_bluff (liar.py:69-75)
     if (nm > 0) {
-      const int side = hist[0];
-      bluff = hist[1] > hand[side] + hand[6 + side] - 1;
+      const int side = t.hist[0];
+      int have = 0;
+#pragma unroll
+      for (int k = 0; k < LD_SIDES; ++k) have += (k == side) ? t.hand[k] + t.hand[6 + k] : 0;
+      bluff = t.hist[1] > have - 1;
     }
     const bool ego_wins = (bluff == ego);
     r_ego = ego_wins ? 1.f : -1.f;
     r_alt = -r_ego;
     d = 1;
   } else if (nm < LD_MAXMOVES) {
-    for (int k = 2 * nm - 1; k >= 0; --k) hist[k + 2] = hist[k];
-    hist[0] = a0;
-    hist[1] = a1;
-    nm += 1;
-    nmoves[e] = nm;
+#pragma unroll
+    for (int k = 21; k >= 0; --k) t.hist[k + 2] = (k < 2 * nm) ? t.hist[k] : t.hist[k + 2];
+    t.hist[0] = a0;
+    t.hist[1] = a1;
+    t.nm = nm + 1;
+    liar_store_history(t, e, history, nmoves);
   }
-  liar_write_obs(hand + (ego ? 6 : 0), hist, nm, obs_next + (size_t)e * 30);  // getObs(not isego)
-  rew[2 * e] = r_ego;
-  rew[2 * e + 1] = r_alt;
+  liar_write_obs(t, !ego, obs_next + (size_t)e * 30);  // getObs(not isego)
+  *reinterpret_cast<float2*>(rew + 2 * (size_t)e) = make_float2(r_ego, r_alt);
   done[e] = d;
 }
 
 // LiarEnv.multi_reset of table e: N_DICE dice per player from Philox4x32-10 (one draw per die, like the reference's
 // randint per die), empty history, first mover ~ Bernoulli(probegostart)
-__device__ __forceinline__ void liar_deal(int e, int* hands, int* history, int* nmoves, unsigned char* ego_first,
+__device__ __forceinline__ void liar_deal(LiarTable& t, int e, int* hands, int* history, int* nmoves, unsigned char* ego_first,
                                           uint64_t seed, uint64_t counter, float probegostart) {
-  int* hand = hands + (size_t)e * 12;
-  for (int k = 0; k < 12; ++k) hand[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) t.hand[k] = 0;
+#pragma unroll
   for (int die = 0; die < 2 * LD_DICE; ++die) {
     const float u = philox_uniform(seed, counter, (uint32_t)e, (uint32_t)die);
     int side = (int)(u * LD_SIDES);
     side = side >= LD_SIDES ? LD_SIDES - 1 : side;
-    hand[(die < LD_DICE ? 0 : 6) + side] += 1;
+#pragma unroll
+    for (int k = 0; k < LD_SIDES; ++k) t.hand[(die < LD_DICE ? 0 : 6) + k] += (k == side) ? 1 : 0;
   }
-  for (int k = 0; k < 24; ++k) history[(size_t)e * 24 + k] = 0;
-  nmoves[e] = 0;
+#pragma unroll
+  for (int k = 0; k < 24; ++k) t.hist[k] = 0;
+  t.nm = 0;
+  liar_store_hands(t, e, hands);
+  liar_store_history(t, e, history, nmoves);
   ego_first[e] = philox_uniform(seed, counter, (uint32_t)e, 100u) < probegostart ? 1 : 0;
 }
 
@@ -100,7 +140,9 @@ __global__ void liar_step_kernel(const int* hands, int* history, int* nmoves, co
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   if (active && !active[e]) return;
-  liar_move(e, hands, history, nmoves, actions, is_ego[e] != 0, obs_next, rew, done);
+  LiarTable t;
+  liar_load(t, e, hands, history, nmoves);
+  liar_move(t, e, history, nmoves, actions, is_ego[e] != 0, obs_next, rew, done);
 }
 hipError_t launch_liar_step(const int* hands, int* history, int* nmoves, const int* actions, const unsigned char* is_ego,
                             const unsigned char* active, float* obs_next, float* rew, unsigned char* done, int n,
@@ -117,7 +159,9 @@ __global__ void liar_obs_kernel(const int* __restrict__ hands, const int* __rest
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   if (active && !active[e]) return;
-  liar_write_obs(hands + (size_t)e * 12 + (is_ego[e] ? 0 : 6), history + (size_t)e * 24, nmoves[e], obs_out + (size_t)e * 30);
+  LiarTable t;
+  liar_load(t, e, hands, history, nmoves);
+  liar_write_obs(t, is_ego[e] != 0, obs_out + (size_t)e * 30);
 }
 hipError_t launch_liar_obs(const int* hands, const int* history, const int* nmoves, const unsigned char* is_ego,
                            const unsigned char* active, float* obs_out, int n, hipStream_t s) {
@@ -132,7 +176,8 @@ __global__ void liar_reset_kernel(int* __restrict__ hands, int* __restrict__ his
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   if (reset_mask && !reset_mask[e]) return;
-  liar_deal(e, hands, history, nmoves, ego_first, seed, counter, probegostart);
+  LiarTable t;
+  liar_deal(t, e, hands, history, nmoves, ego_first, seed, counter, probegostart);
 }
 hipError_t launch_liar_reset(int* hands, int* history, int* nmoves, const unsigned char* reset_mask,
                              unsigned char* ego_first, unsigned long long seed, unsigned long long counter,
@@ -180,7 +225,9 @@ __device__ __forceinline__ void liar_sp_commit(const ph_liar_selfplay& s, int e)
 __global__ void liar_sp_after_ego_kernel(ph_liar_selfplay s, float* alt_rewards, int alt_T) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= s.n) return;
-  liar_move(e, s.hands, s.history, s.nmoves, s.ego_actions, true, s.obs_next, s.rew1, s.done1);
+  LiarTable t;
+  liar_load(t, e, s.hands, s.history, s.nmoves);
+  liar_move(t, e, s.history, s.nmoves, s.ego_actions, true, s.obs_next, s.rew1, s.done1);
   const bool d1 = s.done1[e] != 0;
   liar_sp_credit(s, alt_rewards, alt_T, e, s.rew1[2 * e + 1], d1, s.alt_acted[e] != 0);
   s.running[e] = d1 ? 0 : 1;
@@ -193,20 +240,20 @@ __global__ void liar_sp_after_reply_kernel(ph_liar_selfplay s, float* alt_reward
                                            uint64_t counter, int deal_only) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= s.n) return;
+  LiarTable t;
+  liar_load(t, e, s.hands, s.history, s.nmoves);
   if (!deal_only) {
     const bool run = s.running[e] != 0;
     if (run) {
       liar_sp_commit(s, e);
-      liar_move(e, s.hands, s.history, s.nmoves, s.alt_actions, false, s.obs_next, s.rew2, s.done2);
+      liar_move(t, e, s.history, s.nmoves, s.alt_actions, false, s.obs_next, s.rew2, s.done2);
     }
     const bool d2 = run && s.done2[e] != 0;
     liar_sp_credit(s, alt_rewards, alt_T, e, s.rew2[2 * e + 1], d2, run);
     const bool done = s.done1[e] != 0 || d2;
     ego_rew_row[e] += s.rew1[2 * e] + (run ? s.rew2[2 * e] : 0.f);    // both transitions of the step (agents.py:44-47)
     s.ego_episode_start[e] = done ? 1.f : 0.f;
-    if (run && !d2) {
-      for (int k = 0; k < 30; ++k) s.obs_ego[(size_t)e * 30 + k] = s.obs_next[(size_t)e * 30 + k];
-    }
+    if (run && !d2) liar_write_obs(t, true, s.obs_ego + (size_t)e * 30);   // = obs_next of the move just played
     s.done[e] = done ? 1 : 0;
     if (done) {
       s.alt_acted[e] = 0;
@@ -214,26 +261,27 @@ __global__ void liar_sp_after_reply_kernel(ph_liar_selfplay s, float* alt_reward
     }
   }
   const bool fresh = s.done[e] != 0;
-  if (fresh) liar_deal(e, s.hands, s.history, s.nmoves, s.ego_first, s.dice_seed, counter, s.probegostart);
+  if (fresh) liar_deal(t, e, s.hands, s.history, s.nmoves, s.ego_first, s.dice_seed, counter, s.probegostart);
   const bool ego_first = s.ego_first[e] != 0;
   s.alt_opens[e] = (fresh && !ego_first) ? 1 : 0;
   s.ego_opens[e] = (fresh && ego_first) ? 1 : 0;
   if (fresh) s.alt_acted[e] = 0;
   liar_sp_prepare(s, alt_T, e, fresh && !ego_first);
-  if (fresh && !ego_first)
-    liar_write_obs(s.hands + (size_t)e * 12 + 6, s.history + (size_t)e * 24, s.nmoves[e], s.obs_alt + (size_t)e * 30);
+  if (fresh && !ego_first) liar_write_obs(t, false, s.obs_alt + (size_t)e * 30);
 }
 // the partner has opened the new games it starts: play that move; the ego's observation of every fresh table
 __global__ void liar_sp_after_opening_kernel(ph_liar_selfplay s) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= s.n) return;
-  if (s.alt_opens[e]) {
+  const bool alt_opens = s.alt_opens[e] != 0, ego_opens = s.ego_opens[e] != 0;
+  if (!alt_opens && !ego_opens) return;
+  LiarTable t;
+  liar_load(t, e, s.hands, s.history, s.nmoves);
+  if (alt_opens) {
     liar_sp_commit(s, e);
-    liar_move(e, s.hands, s.history, s.nmoves, s.alt_actions, false, s.obs_next, s.rew2, s.done2);
-    for (int k = 0; k < 30; ++k) s.obs_ego[(size_t)e * 30 + k] = s.obs_next[(size_t)e * 30 + k];
+    liar_move(t, e, s.history, s.nmoves, s.alt_actions, false, s.obs_next, s.rew2, s.done2);
   }
-  if (s.ego_opens[e])
-    liar_write_obs(s.hands + (size_t)e * 12, s.history + (size_t)e * 24, s.nmoves[e], s.obs_ego + (size_t)e * 30);
+  liar_write_obs(t, true, s.obs_ego + (size_t)e * 30);   // after the partner's opening move, or of the fresh deal
 }
 #define PH_SP_GRID(s) dim3(((s).n + 255) / 256), dim3(256)
 hipError_t launch_liar_sp_after_ego(const ph_liar_selfplay& s, hipStream_t st) {
