@@ -818,7 +818,8 @@ int ph_liar_reset(ph_ctx* ctx, int* hands, int* history, int* nmoves, const unsi
   if (!hands || !history || !nmoves || !ego_first) return fail("ph_liar_reset: null argument");
   if (n <= 0) return fail("ph_liar_reset: n must be positive");
   if (((uintptr_t)hands | (uintptr_t)history) % 16) return fail("ph_liar_reset: hands/history must be 16-byte aligned");
-  PH_HIP(ph::launch_liar_reset(hands, history, nmoves, reset_mask, ego_first, seed, counter, probegostart, n, ctx->stream));
+  PH_HIP(ph::launch_liar_reset(hands, history, nmoves, reset_mask, ego_first, seed, counter, ctx->rng_epoch, probegostart, n,
+                               ctx->stream));
   return 0;
 }
 
@@ -860,7 +861,7 @@ int ph_liar_selfplay_step(ph_ctx* ctx, const ph_liar_selfplay* sp, int ego_pos, 
   // reply played and credited; finished tables (flagged in s.done) are re-dealt; where the partner opens the new game it
   // moves once
   PH_HIP(ph::launch_liar_sp_after_reply(s, deal_only ? nullptr : s.ego_rb->rewards + (size_t)ego_pos * s.n, counter,
-                                        deal_only, st));
+                                        ctx->rng_epoch, deal_only, st));
   if (ph_policy_forward_ragged(ctx, s.spec, s.alt_params, s.obs_alt, nullptr, s.alt_seed, 2 * counter + 1, 0, s.alt_actions,
                                s.alt_values, s.alt_log_probs, s.alt_rb, s.alt_pos, s.can, s.es_alt))
     return 1;

@@ -172,18 +172,19 @@ hipError_t launch_liar_obs(const int* hands, const int* history, const int* nmov
 
 __global__ void liar_reset_kernel(int* __restrict__ hands, int* __restrict__ history, int* __restrict__ nmoves,
                                   const unsigned char* __restrict__ reset_mask, unsigned char* __restrict__ ego_first,
-                                  uint64_t seed, uint64_t counter, float probegostart, int n) {
+                                  uint64_t seed, uint64_t counter, const unsigned long long* __restrict__ epoch,
+                                  float probegostart, int n) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   if (reset_mask && !reset_mask[e]) return;
   LiarTable t;
-  liar_deal(t, e, hands, history, nmoves, ego_first, seed, counter, probegostart);
+  liar_deal(t, e, hands, history, nmoves, ego_first, seed, counter + (epoch ? (uint64_t)(*epoch) << 32 : 0ull), probegostart);
 }
 hipError_t launch_liar_reset(int* hands, int* history, int* nmoves, const unsigned char* reset_mask,
                              unsigned char* ego_first, unsigned long long seed, unsigned long long counter,
-                             float probegostart, int n, hipStream_t s) {
+                             const unsigned long long* epoch, float probegostart, int n, hipStream_t s) {
   hipLaunchKernelGGL(liar_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, s, hands, history, nmoves, reset_mask,
-                     ego_first, seed, counter, probegostart, n);
+                     ego_first, seed, counter, epoch, probegostart, n);
   return hipGetLastError();
 }
 
@@ -237,7 +238,7 @@ __global__ void liar_sp_after_ego_kernel(ph_liar_selfplay s, float* alt_rewards,
 // next observation; then (also the whole of a deal-only call) re-deal the finished tables, find who opens the new games
 // and prepare the partner's opening forward
 __global__ void liar_sp_after_reply_kernel(ph_liar_selfplay s, float* alt_rewards, int alt_T, float* ego_rew_row,
-                                           uint64_t counter, int deal_only) {
+                                           uint64_t counter, const unsigned long long* __restrict__ epoch, int deal_only) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= s.n) return;
   LiarTable t;
@@ -261,7 +262,9 @@ __global__ void liar_sp_after_reply_kernel(ph_liar_selfplay s, float* alt_reward
     }
   }
   const bool fresh = s.done[e] != 0;
-  if (fresh) liar_deal(t, e, s.hands, s.history, s.nmoves, s.ego_first, s.dice_seed, counter, s.probegostart);
+  if (fresh)
+    liar_deal(t, e, s.hands, s.history, s.nmoves, s.ego_first, s.dice_seed, counter + (epoch ? (uint64_t)(*epoch) << 32 : 0ull),
+              s.probegostart);
   const bool ego_first = s.ego_first[e] != 0;
   s.alt_opens[e] = (fresh && !ego_first) ? 1 : 0;
   s.ego_opens[e] = (fresh && ego_first) ? 1 : 0;
@@ -288,10 +291,10 @@ hipError_t launch_liar_sp_after_ego(const ph_liar_selfplay& s, hipStream_t st) {
   hipLaunchKernelGGL(liar_sp_after_ego_kernel, PH_SP_GRID(s), 0, st, s, s.alt_rb->rewards, s.alt_rb->T);
   return hipGetLastError();
 }
-hipError_t launch_liar_sp_after_reply(const ph_liar_selfplay& s, float* ego_rew_row, unsigned long long counter, int deal_only,
-                                      hipStream_t st) {
+hipError_t launch_liar_sp_after_reply(const ph_liar_selfplay& s, float* ego_rew_row, unsigned long long counter,
+                                      const unsigned long long* epoch, int deal_only, hipStream_t st) {
   hipLaunchKernelGGL(liar_sp_after_reply_kernel, PH_SP_GRID(s), 0, st, s, s.alt_rb->rewards, s.alt_rb->T, ego_rew_row,
-                     (uint64_t)counter, deal_only);
+                     (uint64_t)counter, epoch, deal_only);
   return hipGetLastError();
 }
 hipError_t launch_liar_sp_after_opening(const ph_liar_selfplay& s, hipStream_t st) {

@@ -184,7 +184,7 @@ hipError_t launch_liar_obs(const int* hands, const int* history, const int* nmov
                            const unsigned char* active, float* obs_out, int n, hipStream_t s);
 hipError_t launch_liar_reset(int* hands, int* history, int* nmoves, const unsigned char* reset_mask,
                              unsigned char* ego_first, unsigned long long seed, unsigned long long counter,
-                             float probegostart, int n, hipStream_t s);
+                             const unsigned long long* epoch, float probegostart, int n, hipStream_t s);
 hipError_t launch_reward_add(float* rew_row, const float* reward, const unsigned char* env_mask, int E, hipStream_t s);
 hipError_t launch_reward_add_joint(float* rew_row, const float* base, const int* joint, int E, int n_seats, int seat,
                                    const int* partner_seat, float bonus, hipStream_t s);
@@ -197,8 +197,8 @@ hipError_t launch_liar_step(const int* hands, int* history, int* nmoves, const i
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
 // device-side book-keeping of the vectorised Liar's Dice self-play step (ph_envs.hip)
 hipError_t launch_liar_sp_after_ego(const ph_liar_selfplay& s, hipStream_t st);
-hipError_t launch_liar_sp_after_reply(const ph_liar_selfplay& s, float* ego_rew_row, unsigned long long counter, int deal_only,
-                                      hipStream_t st);
+hipError_t launch_liar_sp_after_reply(const ph_liar_selfplay& s, float* ego_rew_row, unsigned long long counter,
+                                      const unsigned long long* epoch, int deal_only, hipStream_t st);
 hipError_t launch_liar_sp_after_opening(const ph_liar_selfplay& s, hipStream_t st);
 // peer-to-peer action exchange (ph_envs.hip)
 hipError_t launch_p2p_push(const ph_p2p& x, const int* local, int t, hipStream_t s);

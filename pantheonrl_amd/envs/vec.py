@@ -174,8 +174,9 @@ class VecLiarSelfPlay:
     where the partner opens the new game -- the partner moves once more, so every table is back at the ego's turn.
     The ego is a rectangular VecOnPolicyAgent (one row per table per step); the partner is ragged.
 
-    native=True (default): the whole step is ONE engine call (`ph_liar_selfplay_step`: ~15 launches, every mask stays on the
-    device, no host synchronisation).  native=False walks the same step with the per-call entry points and torch masks -- the
+    native=True (default): the whole step is ONE engine call (`ph_liar_selfplay_step`: the three policy forwards and ONE
+    book-keeping launch after each -- a table's state is touched by its own lane only -- every mask stays on the device, no host
+    synchronisation).  native=False walks the same step with the per-call entry points and torch masks -- the
     readable statement of the protocol, and the bit-exact cross-check of the native step (both use the same RNG counters:
     step c -> ego forward c, partner forwards 2c and 2c+1, dice c)."""
 
@@ -241,10 +242,11 @@ class VecLiarSelfPlay:
         s.zeros8, s.ones8 = self.zeros8.data_ptr(), self.ones8.data_ptr()
         self._desc = s
 
-    def _native_call(self, counter: int, deal_only: bool = False) -> None:
+    def _native_call(self, counter: int, deal_only: bool = False, ego_pos: int = -1) -> None:
         self._bind()
         ctx, rb = self.env.ctx, self.ego.model.rollout_buffer
-        nat.check(ctx.lib.ph_liar_selfplay_step(ctx.handle, C.byref(self._desc), int(rb.pos), int(counter), int(deal_only)))
+        nat.check(ctx.lib.ph_liar_selfplay_step(ctx.handle, C.byref(self._desc), int(rb.pos if ego_pos < 0 else ego_pos),
+                                                int(counter), int(deal_only)))
 
     def _deal(self, reset_mask: th.Tensor, c: int) -> None:
         """(reference path) re-deal the tables in reset_mask; where the partner opens, it moves once"""
@@ -320,3 +322,70 @@ class VecLiarSelfPlay:
         self.ego.learn_from_buffer()
         if self.alt.full():
             self.alt.learn_from_buffer()
+
+
+class LiarIterationGraph:
+    """One whole iteration of the device-resident Liar's Dice self-play as ONE hipGraph: n_steps vectorised steps (6 launches
+    each), the ego's GAE pass and its PPO update.  Everything a replay must vary is device-resident: every random stream is
+    keyed (RNG epoch word, counter) with the step-local counter baked into the graph and ONE epoch word -- shared by the
+    forwards, the dice and the minibatch permutations of both learners -- advanced by the graph's last node.  The partner
+    trains between replays whenever all its columns are full (the one host decision of the loop, as in
+    `VecLiarSelfPlay.rollout_and_learn`).  `capture=False` runs the same body launch by launch (the graph's cross-check)."""
+
+    def __init__(self, sp: VecLiarSelfPlay, n_steps: int, capture: bool = True, warmup: int = 2):
+        assert sp.native, "the graph replays the engine-side step"
+        self.sp, self.T = sp, int(n_steps)
+        ego, alt = sp.ego, sp.alt
+        assert self.T == ego.model.n_steps and ego.model.rollout_buffer.pos == 0
+        self.stream = th.cuda.Stream(device=sp.dev)
+        self.epoch_word = th.zeros(1, dtype=th.int64, device=sp.dev)
+        for agent in (ego, alt):
+            ctx = agent.model.policy.ctx
+            nat.check(ctx.lib.ph_ctx_set_rng_epoch(ctx.handle, self.epoch_word.data_ptr()))
+            agent.model.device_permutations = True
+        self.graph_id = None
+        th.cuda.synchronize(sp.dev)
+        with th.cuda.stream(self.stream):
+            self._perm_seed = ego.model.permutation_seed + 1
+            for _ in range(warmup):          # outside capture: sizes the workspaces, allocates the statistics buffers
+                self._iteration(eager=True)
+            self.stream.synchronize()
+            if capture:
+                ctx = sp.env.ctx
+                sp._bind()
+                nat.check(ctx.lib.ph_graph_begin(ctx.handle))
+                try:
+                    self._body()
+                finally:
+                    gid = C.c_int(-1)
+                    nat.check(ctx.lib.ph_graph_end(ctx.handle, C.byref(gid)))
+                self.graph_id = gid.value
+
+    def _body(self) -> None:
+        sp, ego = self.sp, self.sp.ego
+        for t in range(self.T):
+            sp._native_call(t + 1, ego_pos=t)
+        ego.compute_returns()
+        ego.model.permutation_seed = self._perm_seed - 1     # train() pre-increments: the same baked seed in every replay
+        ego.model.train(sync_stats=False)
+        ctx = sp.env.ctx
+        nat.check(ctx.lib.ph_rng_epoch_advance(ctx.handle))
+
+    def _iteration(self, eager: bool) -> None:
+        sp, ego, alt = self.sp, self.sp.ego, self.sp.alt
+        if eager:
+            self._body()
+        else:
+            sp._bind()
+            ctx = sp.env.ctx
+            nat.check(ctx.lib.ph_graph_launch(ctx.handle, self.graph_id))
+        ego.finish_update()
+        sp.steps_done += self.T
+        ego.num_timesteps += self.T * sp.E
+        alt.num_timesteps += self.T * sp.E
+        if alt.full():
+            alt.learn_from_buffer()
+
+    def launch(self) -> None:
+        with th.cuda.stream(self.stream):
+            self._iteration(eager=self.graph_id is None)

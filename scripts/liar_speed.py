@@ -32,5 +32,19 @@ for _ in range(T):
     sp.step()
 th.cuda.synchronize()
 dr = time.perf_counter() - t1
+sp.ego.learn_from_buffer()
+if native and os.environ.get("LIAR_GRAPH", "1") != "0":
+    from pantheonrl_amd.envs.vec import LiarIterationGraph  # noqa: E402
+    g = LiarIterationGraph(sp, T)
+    for _ in range(2):
+        g.launch()
+    th.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(10):
+        g.launch()
+    th.cuda.synchronize()
+    dg = (time.perf_counter() - t2) / 10
+    print(f"hipGraph iteration (rollout + ego update in one graph, partner updates between replays): {dg * 1e3:.1f} ms each -> "
+          f"{E * T / dg:,.0f} ego steps/s")
 print(f"native={native}: {iters} iterations (rollout + updates) {dt / iters * 1e3:.1f} ms each -> {E * T * iters / dt:,.0f} ego "
       f"steps/s; rollout alone {dr / T * 1e6:.0f} us per vector step; episodes {sp.episodes}, partner updates {alt.iteration}")

@@ -969,6 +969,33 @@ def test_vec_liars_dice_native_step_is_bitwise_the_per_call_step():
         assert np.array_equal(x, y), key
 
 
+def test_liar_iteration_graph_replays_the_launch_by_launch_iteration_bitwise():
+    """LiarIterationGraph: n_steps vectorised steps + the ego's GAE and update as ONE hipGraph (step-local RNG counters baked
+    in, one device epoch word advanced per replay) against the same body executed launch by launch: identical game state,
+    buffers and parameters of both learners after several iterations, and the iterations differ from each other."""
+    from pantheonrl_amd.envs.vec import LiarIterationGraph
+    E, T_ego, T_alt = 48, 8, 6
+    runs = []
+    for capture in (True, False):
+        sp, ego, alt, _ = _liar_selfplay(E, T_ego, T_alt, seed=5)
+        g = LiarIterationGraph(sp, T_ego, capture=capture)
+        assert (g.graph_id is not None) == capture
+        snaps = []
+        for _ in range(4):
+            g.launch()
+            snaps.append(ego.model.rollout_buffer.host()["actions"].copy())
+        th.cuda.synchronize()
+        runs.append(dict(hands=sp.env.hands.cpu().numpy(), hist=sp.env.history.cpu().numpy(), obs=sp.obs_ego.cpu().numpy(),
+                         pos=alt.pos.cpu().numpy(), episodes=sp.episodes, alt_it=alt.iteration, ego_it=ego.iteration,
+                         steps=sp.steps_done, pe=ego.model.policy.get_flat_params(), pa=alt.model.policy.get_flat_params(),
+                         snaps=np.stack(snaps), epoch=int(g.epoch_word.item())))
+    a, b = runs
+    assert a["ego_it"] == 6 and a["alt_it"] >= 1 and a["episodes"] > E and a["epoch"] == 6 and a["steps"] == 6 * T_ego
+    assert not np.array_equal(a["snaps"][0], a["snaps"][1])           # a replay draws fresh random numbers
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+
+
 def test_vec_liars_dice_partner_trains_when_every_column_is_full():
     E, T_ego, T_alt = 64, 8, 4
     sp, ego, alt, _ = _liar_selfplay(E, T_ego, T_alt, seed=3)
