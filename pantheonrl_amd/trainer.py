@@ -197,8 +197,15 @@ def run_vectorised(args):
     else:
         alt = RaggedVecOnPolicyAgent(models[1])
         env = VecLiarSelfPlay(E, ego, alt, seed=args.seed or 0, **args.env_config)
-        for _ in range(iterations):
-            env.rollout_and_learn(n_steps)
+        if iterations >= 4 and env.native:
+            # two launch-by-launch iterations size the workspaces, the rest replay one hipGraph per iteration
+            from .envs.vec import LiarIterationGraph
+            graph = LiarIterationGraph(env, n_steps, warmup=2)
+            for _ in range(iterations - 2):
+                graph.launch()
+        else:
+            for _ in range(iterations):
+                env.rollout_and_learn(n_steps)
     th.cuda.synchronize()
     print(f"vectorised self-play: {iterations} iterations x {E} envs x {n_steps} steps; "
           f"ego updates {ego.iteration}, partner updates {alt.iteration}")
