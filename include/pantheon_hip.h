@@ -292,7 +292,8 @@ int ph_liar_step(ph_ctx *ctx, const int *hands, int *history, int *nmoves, const
                  unsigned char *done, int n);
 
 /* LiarEnv.multi_reset <- liar.py:96-102 for every env with reset_mask[e] != 0 (NULL = all): dice from Philox4x32-10
- * keyed (seed, counter [+ the context's RNG epoch word << 32, when one is attached], env, die), empty history; ego_first (n) u8 <- first mover ~ Bernoulli(probegostart)
+ * keyed (seed, counter [+ the context's RNG epoch word << 32, when one is attached], env, die/4; die%4 selects the word),
+ * empty history; ego_first (n) u8 <- first mover ~ Bernoulli(probegostart)
  * (TurnBasedEnv.n_reset, multiagentenv.py:323-326). */
 int ph_liar_reset(ph_ctx *ctx, int *hands, int *history, int *nmoves, const unsigned char *reset_mask,
                   unsigned char *ego_first, unsigned long long seed, unsigned long long counter, float probegostart,

@@ -169,6 +169,13 @@ __device__ __host__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
     k1 += 0xBB67AE85u;
   }
 }
+// four uniforms in [0,1) with 24 random bits each for (seed, counter, row, block): all four words of one Philox call
+__device__ __host__ inline void philox_uniform4(uint64_t seed, uint64_t counter, uint32_t row, uint32_t block, float (&u)[4]) {
+  uint32_t c[4] = {row, block, (uint32_t)counter, (uint32_t)(counter >> 32)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = (float)(c[i] >> 8) * (1.0f / 16777216.0f);
+}
 // uniform in [0,1) with 24 random bits for (seed, counter, row, component)
 __device__ __host__ inline float philox_uniform(uint64_t seed, uint64_t counter, uint32_t row, uint32_t comp) {
   uint32_t c[4] = {row, comp, (uint32_t)counter, (uint32_t)(counter >> 32)};

@@ -112,19 +112,25 @@ __device__ __forceinline__ void liar_move(LiarTable& t, int e, int* history, int
   done[e] = d;
 }
 
-// LiarEnv.multi_reset of table e: N_DICE dice per player from Philox4x32-10 (one draw per die, like the reference's
-// randint per die), empty history, first mover ~ Bernoulli(probegostart)
+// LiarEnv.multi_reset of table e: N_DICE dice per player from Philox4x32-10 (one 24-bit draw per die, like the reference's
+// randint per die: die d is word d%4 of Philox block d/4 keyed (seed, counter, e)), empty history, first mover ~
+// Bernoulli(probegostart) from word 0 of block 100
 __device__ __forceinline__ void liar_deal(LiarTable& t, int e, int* hands, int* history, int* nmoves, unsigned char* ego_first,
                                           uint64_t seed, uint64_t counter, float probegostart) {
 #pragma unroll
   for (int k = 0; k < 12; ++k) t.hand[k] = 0;
 #pragma unroll
-  for (int die = 0; die < 2 * LD_DICE; ++die) {
-    const float u = philox_uniform(seed, counter, (uint32_t)e, (uint32_t)die);
-    int side = (int)(u * LD_SIDES);
-    side = side >= LD_SIDES ? LD_SIDES - 1 : side;
+  for (int blk = 0; blk < 2 * LD_DICE / 4; ++blk) {
+    float u4[4];
+    philox_uniform4(seed, counter, (uint32_t)e, (uint32_t)blk, u4);
 #pragma unroll
-    for (int k = 0; k < LD_SIDES; ++k) t.hand[(die < LD_DICE ? 0 : 6) + k] += (k == side) ? 1 : 0;
+    for (int i = 0; i < 4; ++i) {
+      const int die = 4 * blk + i;
+      int side = (int)(u4[i] * LD_SIDES);
+      side = side >= LD_SIDES ? LD_SIDES - 1 : side;
+#pragma unroll
+      for (int k = 0; k < LD_SIDES; ++k) t.hand[(die < LD_DICE ? 0 : 6) + k] += (k == side) ? 1 : 0;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 24; ++k) t.hist[k] = 0;
