@@ -31,6 +31,10 @@ def init_from_env(backend: Optional[str] = None) -> bool:
     return True
 
 
+_generation = {"p2p": 0, "rccl": 0}   # per-process rendezvous counters: every attach uses fresh store keys (ranks attach in
+                                        # lockstep, so the n-th attach of every rank meets under the same key)
+
+
 class ActionExchange:
     """all-gather of per-step actions: local (A_local, E) int32 -> joint (world * A_local, E) int32.
 
@@ -75,11 +79,13 @@ class ActionExchange:
             bases[self.rank] = base.value
             if self.world > 1:
                 store = dist.distributed_c10d._get_default_store()
-                store.set(f"pantheonrl_amd/p2p/{self.rank}", bytes(handle))
+                _generation["p2p"] += 1          # a key is written once: a peer can never pick up a previous attach's handle
+                gen = _generation["p2p"]
+                store.set(f"pantheonrl_amd/p2p/{gen}/{self.rank}", bytes(handle))
                 for p in range(self.world):
                     if p == self.rank:
                         continue
-                    peer = (C.c_ubyte * 64).from_buffer_copy(store.get(f"pantheonrl_amd/p2p/{p}"))
+                    peer = (C.c_ubyte * 64).from_buffer_copy(store.get(f"pantheonrl_amd/p2p/{gen}/{p}"))
                     mapped = C.c_void_p()
                     nat.check(ctx.lib.ph_p2p_open(ctx.handle, peer, C.byref(mapped)))
                     bases[p] = mapped.value
@@ -221,11 +227,13 @@ class ActionExchange:
             ident = (C.c_ubyte * 128)()
             if self.world > 1:
                 store = dist.distributed_c10d._get_default_store()
+                _generation["rccl"] += 1
+                key = f"pantheonrl_amd/rccl_id/{_generation['rccl']}"
                 if self.rank == 0:
                     nat.check(ctx.lib.ph_comm_unique_id(ident))
-                    store.set("pantheonrl_amd/rccl_id", bytes(ident))
+                    store.set(key, bytes(ident))
                 else:
-                    ident = (C.c_ubyte * 128).from_buffer_copy(store.get("pantheonrl_amd/rccl_id"))
+                    ident = (C.c_ubyte * 128).from_buffer_copy(store.get(key))
             elif os.environ.get("PANTHEON_FORCE_RCCL", "0") == "1":   # one-rank communicator: exercises the RCCL plumbing
                 nat.check(ctx.lib.ph_comm_unique_id(ident))
             else:
