@@ -336,7 +336,9 @@ def main():
                    "n_envs": args.n_envs, "n_steps": args.n_steps, "obs_dim": agents[0].model.policy.layout.D,
                    "features": agents[0].model.policy.layout.F, "n_logits": agents[0].model.policy.layout.L,
                    "batch_size": args.batch_size, "n_epochs": args.n_epochs, "agents_per_gpu": len(agents),
-                   "parallelism": f"agent-per-gpu x{world} ({'per-step RCCL action all-gather' if distributed else 'single process'})",
+                   "parallelism": f"agent-per-gpu x{world} (" + (
+                       f"per-step action all-gather over xGMI, route {getattr(exchange, 'route', '?')}" if distributed
+                       else "single process") + ")",
                    "exchange": ({"route": exchange.route, **exchange.route_log, "p2p_timeouts": exchange.p2p_timeouts()}
                                 if exchange is not None and hasattr(exchange, "route") else None),
                    "launch_mode": mode},
