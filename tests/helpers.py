@@ -13,6 +13,10 @@ CONFIGS = {
     "overcooked": (SpaceSpec("box", dim=62), SpaceSpec("discrete", nvec=(6,))),
     "mpe8": (SpaceSpec("box", dim=48), SpaceSpec("discrete", nvec=(5,))),
     "wide": (SpaceSpec("box", dim=130), SpaceSpec("multidiscrete", nvec=(3, 30, 7))),  # 3 feature chunks, Lp=64
+    # one-hot observations with heads the 8-logit fast path does not take (policy_fwd16h_kernel): three action components
+    # filling all 32 logit lanes (the middle one straddles the 16-lane DPP row boundary); one 20-way Discrete head
+    "onehot32": (SpaceSpec("multidiscrete", nvec=(3, 4, 5, 2, 6)), SpaceSpec("multidiscrete", nvec=(5, 16, 11))),
+    "discrete20": (SpaceSpec("discrete", nvec=(5,)), SpaceSpec("discrete", nvec=(20,))),
 }
 
 

@@ -153,7 +153,7 @@ def test_forward_matches_oracle(name, n):
     assert np.array_equal(d[gap_ok], d_ref[gap_ok])
 
 
-@pytest.mark.parametrize("name", ["overcooked", "liar", "wide"])
+@pytest.mark.parametrize("name", ["overcooked", "liar", "wide", "onehot32", "discrete20"])
 def test_evaluate_actions_matches_oracle(name):
     orac = H.oracle_policy(name, seed=4)
     pol = H.device_policy(name, orac)
@@ -186,13 +186,13 @@ def test_mfma_and_valu_tiles_agree_bitwise():
         assert np.array_equal(v0, v1)
 
 
-def test_action_mask_is_integer_exact():
+@pytest.mark.parametrize("name,L", [("mpe8", 5), ("discrete20", 20)])
+def test_action_mask_is_integer_exact(name, L):
     """mask path (observation.py action_mask -> modular/policies.py:330-333 -> pettingzoo.py:81-82)."""
-    name = "mpe8"
     orac = H.oracle_policy(name, seed=6)
     pol = H.device_policy(name, orac)
     rng = np.random.default_rng(2)
-    n, L = 4096, 5
+    n = 4096
     obs = H.sample_obs(H.CONFIGS[name][0], n, rng)
     mask = (rng.random((n, L)) < 0.6)
     mask[np.arange(n), rng.integers(0, L, n)] = True  # at least one legal action
