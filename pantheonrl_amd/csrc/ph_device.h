@@ -242,6 +242,37 @@ template <int R, int NT>
 struct XStage {
   static constexpr int ITERS = R * HID / NT;
   float v[ITERS];
+  const int* feat_lds = nullptr;   // [R][D] hot feature row of every (row, component) of the tile, or null
+  // Discrete family: the one-hot position of every (row, component) of the tile, once per tile -- the feature chunks are then
+  // built without touching global memory (a chunk built straight from the observations costs a dependent round trip per
+  // 256 elements, per chunk, in the forward pass and again for dW1).  All loads of a batch of 8 are in flight together.
+  __device__ __forceinline__ void build_feat(int* feat, const int* rowphys, const float* obs, const NetDims& nd, int tid) {
+    const int total = R * nd.D;
+    for (int e0 = 0; e0 < total; e0 += 8 * NT) {
+      int fv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = e0 + tid + NT * i;
+        fv[i] = -(1 << 20);
+        if (e < total) {
+          const int r = e / nd.D, comp = e - r * nd.D;
+          const int ph_row = rowphys[r];
+          if (ph_row >= 0) {
+            const int lo = nd.obs_off[comp], n = nd.obs_off[comp + 1] - lo;
+            int x = (int)obs[(size_t)ph_row * nd.D + comp];
+            x = x < 0 ? 0 : (x >= n ? n - 1 : x);
+            fv[i] = lo + x;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = e0 + tid + NT * i;
+        if (e < total) feat[e] = fv[i];
+      }
+    }
+    feat_lds = feat;
+  }
   __device__ __forceinline__ void issue(const int* rowphys, const float* obs, const NetDims& nd, int c, int tid = -1) {
     if (nd.obs_kind != PH_SPACE_BOX) return;
     if (tid < 0) tid = threadIdx.x;
@@ -260,6 +291,16 @@ struct XStage {
       const int kk = tid & 63;
 #pragma unroll
       for (int i = 0; i < ITERS; ++i) dst[((tid + NT * i) >> 6) * LDH + kk] = v[i];
+      return;
+    }
+    if (feat_lds) {   // hot feature rows precomputed once per tile (build_feat): the chunk is built from LDS alone
+      const int base = c * HID;
+      for (int e = tid; e < R * HID; e += NT) dst[(e >> 6) * LDH + (e & 63)] = 0.f;
+      __syncthreads();
+      for (int e = tid; e < R * nd.D; e += NT) {
+        const int f = feat_lds[e] - base;   // padding rows hold a large negative value
+        if (f >= 0 && f < HID) dst[(e / nd.D) * LDH + f] = 1.f;
+      }
       return;
     }
     const int base = c * HID;

@@ -166,7 +166,7 @@ struct AdamArgs {
 };
 
 size_t fwd_lds_bytes(int R, int Lp);
-size_t grad_lds_bytes(int R, int Lp, bool w2g);
+size_t grad_lds_bytes(int R, int Lp, bool w2g, int onehot_D);
 int grad_variant();
 hipError_t launch_transpose_w2(const float* params, int pi_W2, int vf_W2, float* w2t, hipStream_t s);
 hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s);

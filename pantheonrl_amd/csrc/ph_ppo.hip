@@ -41,6 +41,7 @@ __global__ __launch_bounds__(R * 4, W2G ? 3 : 2) void ppo_grad_kernel(GradArgs a
   float* rdv = rold + R;               // [R] dL/dv (value net)
   float* red = rdv + R;                // [NSTATP * 4] cross-wave stat reduction
   int* rowphys = (int*)(red + NSTATP * 4);  // [R]
+  int* feat = rowphys + R;             // [R][D] one-hot positions of the tile (Discrete-family observations only)
   float* wos = regW;
   float* outs = regW + HID * LDO;
 
@@ -117,6 +118,10 @@ __global__ __launch_bounds__(R * 4, W2G ? 3 : 2) void ppo_grad_kernel(GradArgs a
     XStage<R, NT> xr;
     WStage<NT> w1r;
     WoStage<NT> wor;
+    // One-hot observations: the hot feature row of every (row, component) once per tile; the chunks of S1 and S7 are then
+    // built from LDS.  (Replacing S1 by a gather-sum of W1 rows, as the 16-row forward kernel does, measured no faster at 64
+    // rows per workgroup: 491 KB of gathered rows per workgroup against 69 KB of W1 streamed once through LDS.)
+    if (nd.obs_kind != PH_SPACE_BOX) xr.build_feat(feat, rowphys, a.rb_obs, nd, tid);   // read after the barrier in commit
     for (int c = 0; c < nd.nchunk; ++c) {
       if (c > 0) __syncthreads();  // previous chunk consumed
       xr.issue(rowphys, a.rb_obs, nd, c, tid);
@@ -466,16 +471,16 @@ __global__ __launch_bounds__(R * 4, W2G ? 3 : 2) void ppo_grad_kernel(GradArgs a
 }
 
 
-size_t grad_lds_bytes(int R, int Lp, bool w2g) {
+size_t grad_lds_bytes(int R, int Lp, bool w2g, int onehot_D) {
   const int LDO = Lp + 1;
   const int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
-  return sizeof(float) * (size_t)(2 * R * LDH + regW_sz + (w2g ? 0 : HID * LDH) + 3 * 64 + 3 * R + NSTATP * 4 + R);
+  return sizeof(float) * (size_t)(2 * R * LDH + regW_sz + (w2g ? 0 : HID * LDH) + 3 * 64 + 3 * R + NSTATP * 4 + R + R * onehot_D);
 }
 
 template <int LP, bool VALU, bool W2G>
 static hipError_t launch_grad_variant(const GradArgs& a, int nwg, hipStream_t s) {
   constexpr int R = 64;
-  const size_t lds = grad_lds_bytes(R, LP, W2G);
+  const size_t lds = grad_lds_bytes(R, LP, W2G, a.nd.obs_kind != PH_SPACE_BOX ? a.nd.D : 0);
   dim3 grid(nwg, 2), block(R * 4);
   static size_t allowed = 0;  // > 64 KiB of dynamic LDS is opt-in, once per kernel (kept out of graph capture)
   if (lds > allowed) {

@@ -13,6 +13,10 @@ from pantheonrl_amd.vec import SyntheticRollouts, VecOnPolicyAgent, run_iteratio
 
 E, T = int(os.environ.get("E", 1024)), int(os.environ.get("T", 128))
 obs_space, act_space = sp.Box(-np.inf, np.inf, (62,)), sp.Discrete(6)
+LIAR = os.environ.get("SHAPE", "overcooked") == "liar"   # Liar's Dice shapes: general gradient kernel, 5 feature chunks
+if LIAR:
+    E = int(os.environ.get("E", 256))
+    obs_space, act_space = sp.MultiDiscrete([7] * 6 + [7, 12] * 12), sp.MultiDiscrete([7, 12])
 env = type("S", (), dict(observation_space=obs_space, action_space=act_space, _is_dummy_space_env=True))()
 model = PPO("MlpPolicy", env, n_steps=T, n_envs=E, batch_size=E * T // 4, n_epochs=2, seed=0)
 model.device_permutations = True
@@ -49,14 +53,16 @@ for rep in range(2):
     agent.n_steps = 0
     agent.get_action(data.obs[0])
     th.cuda.synchronize()
-if os.environ.get("PH_FWD16", "1") != "0":
+if LIAR:
+    pass   # the one-hot forward has its own script (scripts/liar_fwd_profile.py)
+elif os.environ.get("PH_FWD16", "1") != "0":
     report("policy_fwd16", (E + 15) // 16, 2, ["staging (W1, W2, X, head) + barriers", "L1 mma+tanh", "L2 mma+tanh",
                                               "head + tail"], slots=[0, 1, 3, 5, 7])
 else:
     report("policy_fwd", (E + 31) // 32, 2, ["all staging loads+commit", "(chunk loop entry)", "L1 mma", "H1 tanh",
                                             "L2 mma+tanh", "head mma", "sampling / value+obs copy"])
 st = stamps.cpu().numpy().reshape(-1, 16)[:(E + 31) // 32]
-for lab, a0, a1 in (("issue W2/W1/Wo/bias", 0, 8), ("barrier(rowphys)", 8, 9), ("X issue + W2 commit", 9, 10),
+for lab, a0, a1 in () if LIAR else (("issue W2/W1/Wo/bias", 0, 8), ("barrier(rowphys)", 8, 9), ("X issue + W2 commit", 9, 10),
                     ("W1/Wo/bias commit", 10, 11), ("X commit + barrier", 11, 1)):
     print(f"    fwd prologue  {lab:<24} median {np.median(st[:, a1] - st[:, a0]):>8.0f}")
 # grad
@@ -76,7 +82,7 @@ elif os.environ.get("PH_GRAD_RP", "0") == "1":
     report("ppo_grad_rp", min((model.batch_size + 127) // 128, 128), 2,
            ["prologue + T0", "P1 S1 mma+tanh", "P1 S2 mma+tanh", "P1 head + B1", "P2 dW2 (all rows)", "P2 dH1, dZ1, B2, B3",
             "P3 dW1 + B4", "remaining steps", "epilogue"], slots=[0, 1, 2, 3, 4, 5, 6, 7, 12, 13])
-elif os.environ.get("PH_GRAD_FAST", "1") != "0":
+elif os.environ.get("PH_GRAD_FAST", "1") != "0" and not LIAR:
     report("ppo_grad_fast", nwg, 2, ["prologue + T0 (rows, X, W1, W2)", "S1 mma+tanh", "S2 mma+tanh", "SH head (VALU)",
                                      "S6a fetch_rows", "S6a W1 issue", "S6a side work", "S6a dW2 mma", "S6a dH1 mma", "S6b dZ1, X, W1", "S7 dW1", "remaining tiles",
                                      "epilogue"], slots=[0, 1, 2, 3, 4, 8, 9, 10, 11, 5, 6, 7, 12, 13])
