@@ -228,9 +228,11 @@ int ph_selfplay_rollout(ph_ctx *ctx, int n_calls, const ph_step_call *calls /* h
  *  ph_p2p_wait(t): until flags_local[src] >= stamp(t) for every src.   stamp(t) = (*epoch) * T + t + 1.
  *  ph_selfplay_rollout_p2p: T x { ph_policy_step_multi, push, wait } in one host call.  When every call fits the 16-row
  *      step kernel the exchange is folded INTO the step launch with the stamp in-band: a policy workgroup stores each row's
- *      action as ONE 8-byte word (stamp << 32 | action) into every rank's `ll` area (slot = t mod 3; 8-byte stores are
+ *      action as ONE 8-byte word (stamp << 32 | action) into every rank's `ll` area (slot = t mod ll_slots; 8-byte stores are
  *      single-copy atomic, so no fence, flag or arrival counter is needed), and the value workgroups of the next step poll
- *      exactly the two words they consume (own seat, partner seat) until the stamp matches.  After the last step the
+ *      exactly the two words they consume (own seat, partner seat) until the stamp matches.  A rank therefore waits for
+ *      its partner's rank only and can run up to world-1 steps ahead of some other rank: ll_slots must be >= T so that no
+ *      slot is reused inside an iteration (the unpack of step T-1 waits for every rank, which bounds the skew per iteration).  After the last step the
  *      words of step T-1 are unpacked into this rank's plain receive slot for ordinary consumers. */
 #define PH_MAX_RANKS 16
 #define PH_IPC_HANDLE_BYTES 64
@@ -238,7 +240,8 @@ typedef struct ph_p2p {
   int world, rank, count, T;
   int *joint[2][PH_MAX_RANKS];                 /* [parity][peer] -> that peer's (world*count) int32 receive slot */
   unsigned long long *flags[PH_MAX_RANKS];     /* [peer] -> that peer's (world) stamp array */
-  unsigned long long *ll[3][PH_MAX_RANKS];     /* [t mod 3][peer] -> that peer's (world*count) stamp-in-band words */
+  unsigned long long *ll[PH_MAX_RANKS];        /* [peer] -> that peer's ll_slots x (world*count) stamp-in-band words */
+  int ll_slots;                                /* slot of step t = t mod ll_slots; >= T (see above) */
   const unsigned long long *epoch;             /* device word advanced once per iteration (ph_rng_epoch_advance) */
   unsigned long long *error;                   /* local device word: number of timed-out waits */
   unsigned long long timeout_cycles;           /* bound of one wait in wall_clock64() ticks (100 MHz) */

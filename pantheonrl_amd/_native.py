@@ -79,7 +79,7 @@ PH_MAX_RANKS = 16
 class PhP2P(C.Structure):
     """ph_p2p: the peer-to-peer exchange as seen from one rank"""
     _fields_ = [("world", C.c_int), ("rank", C.c_int), ("count", C.c_int), ("T", C.c_int),
-                ("joint", (C.c_void_p * PH_MAX_RANKS) * 2), ("flags", C.c_void_p * PH_MAX_RANKS), ("ll", (C.c_void_p * PH_MAX_RANKS) * 3),
+                ("joint", (C.c_void_p * PH_MAX_RANKS) * 2), ("flags", C.c_void_p * PH_MAX_RANKS), ("ll", C.c_void_p * PH_MAX_RANKS), ("ll_slots", C.c_int),
                 ("epoch", C.c_void_p), ("error", C.c_void_p), ("timeout_cycles", C.c_ulonglong)]
 
 

@@ -513,7 +513,8 @@ int step_multi_impl(ph_ctx* ctx, int n_calls, const ph_step_call* calls, const p
     m.px.a_local = n_calls;
     for (int i = 0; i < n_calls; ++i) {
       if (!m.a[i].joint) continue;   // consumers of the previous step's joint action read the stamp-in-band words
-      m.a[i].joint_ll = x->ll[(t + 2) % 3][x->rank];
+      const int prev = t >= 1 ? t - 1 : x->T - 1;   // step whose joint action this launch consumes (t = 0: last step of the previous iteration)
+      m.a[i].joint_ll = x->ll[x->rank] + (size_t)(prev % x->ll_slots) * x->world * x->count;
       m.a[i].ll_epoch = x->epoch;
       m.a[i].ll_T = x->T;
       m.a[i].ll_t = t - 1;
@@ -672,8 +673,8 @@ int check_p2p(const ph_p2p* x) {
     return fail("ph_p2p: bad world / rank / count / T");
   if (!x->epoch || !x->error) return fail("ph_p2p: epoch and error words are required");
   for (int p = 0; p < x->world; ++p)
-    if (!x->joint[0][p] || !x->joint[1][p] || !x->flags[p] || !x->ll[0][p] || !x->ll[1][p] || !x->ll[2][p])
-      return fail("ph_p2p: unmapped peer");
+    if (!x->joint[0][p] || !x->joint[1][p] || !x->flags[p] || !x->ll[p]) return fail("ph_p2p: unmapped peer");
+  if (x->ll_slots < x->T) return fail("ph_p2p: ll_slots must be >= T (a slot must not be reused inside an iteration)");
   return 0;
 }
 }  // namespace

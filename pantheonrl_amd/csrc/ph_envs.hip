@@ -359,7 +359,8 @@ __global__ __launch_bounds__(256) void p2p_ll_push_kernel(ph_p2p x, const int* _
   if (i >= x.count) return;
   const unsigned long long w = ((unsigned long long)p2p_stamp32(*x.epoch, x.T, t) << 32) | (unsigned long long)(unsigned)local[i];
   for (int p = 0; p < x.world; ++p)
-    __hip_atomic_store(x.ll[t % 3][p] + (size_t)x.rank * x.count + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(x.ll[p] + (size_t)(t % x.ll_slots) * x.world * x.count + (size_t)x.rank * x.count + i, w, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 hipError_t launch_p2p_ll_push(const ph_p2p& x, const int* local, int t, hipStream_t s) {
   hipLaunchKernelGGL(p2p_ll_push_kernel, dim3((x.count + 255) / 256), dim3(256), 0, s, x, local, t);
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void p2p_ll_unpack_kernel(ph_p2p x, int t) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= x.world * x.count) return;
   const unsigned want = p2p_stamp32(*x.epoch, x.T, t);
-  const unsigned long long* word = x.ll[t % 3][x.rank] + i;
+  const unsigned long long* word = x.ll[x.rank] + (size_t)(t % x.ll_slots) * x.world * x.count + i;
   const long long t0 = wall_clock64();
   unsigned long long v;
   while (true) {

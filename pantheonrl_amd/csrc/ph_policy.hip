@@ -495,12 +495,12 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a, const ph_p2p
       for (int k = 0; k < 8; ++k) z[k] = quad_sum_f(z[k]) + ((k < nk) ? hbs[k] : 0.f);
       if (q == 0 && grow < a.n) {
         const int act = discrete8_row_tail(a, nd, grow, z);
-        if (px) {  // push: (stamp << 32 | action) as one 8-byte store into every rank's receive area, slot t mod 3
-          const size_t off = (size_t)(px->rank * px_a_local + agent) * a.n + grow;
+        if (px) {  // push: (stamp << 32 | action) as one 8-byte store into every rank's receive area, slot t mod ll_slots
+          const size_t off = (size_t)(px_t % px->ll_slots) * px->world * px->count + (size_t)(px->rank * px_a_local + agent) * a.n + grow;
           const unsigned long long w =
               ((unsigned long long)p2p_stamp32(*px->epoch, px->T, px_t) << 32) | (unsigned long long)(unsigned)act;
           for (int p = 0; p < px->world; ++p)
-            __hip_atomic_store(px->ll[px_t % 3][p] + off, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(px->ll[p] + off, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     } else {

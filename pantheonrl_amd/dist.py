@@ -70,9 +70,12 @@ class ActionExchange:
         try:
             count = self.local.numel()
             slot = self.world * count * 4
-            ll_slot = self.world * count * 8       # stamp-in-band words of the fused route: 3 slots
+            # stamp-in-band words of the fused route: one slot per step of an iteration.  A rank only waits for its partner's
+            # rank, so it may run up to world-1 steps ahead of another one; a slot must not be reused inside an iteration
+            ll_slot = self.world * count * 8
+            ll_slots = max(int(n_steps), 4)
             ll_base = 2 * slot + self.world * 8 + 64
-            nbytes = ll_base + 3 * ll_slot
+            nbytes = ll_base + ll_slots * ll_slot
             base, handle = C.c_void_p(), (C.c_ubyte * 64)()
             nat.check(ctx.lib.ph_p2p_alloc(ctx.handle, nbytes, C.byref(base), handle))
             bases = [None] * self.world
@@ -94,8 +97,8 @@ class ActionExchange:
             for p in range(self.world):
                 x.joint[0][p], x.joint[1][p] = bases[p], bases[p] + slot
                 x.flags[p] = bases[p] + 2 * slot
-                for k in range(3):
-                    x.ll[k][p] = bases[p] + ll_base + k * ll_slot
+                x.ll[p] = bases[p] + ll_base
+            x.ll_slots = ll_slots
             x.epoch = epoch_word.data_ptr()
             x.error = base.value + 2 * slot + self.world * 8
             x.timeout_cycles = int(timeout_s * 1e8)
