@@ -1184,13 +1184,16 @@ def test_peer_to_peer_exchange_single_rank_matches_the_copy_route():
         assert np.array_equal(x, y)
 
 
-def test_peer_to_peer_exchange_between_two_processes():
-    """two ranks (sharing this GPU) map each other's receive areas through HIP IPC and exchange 3 x 8 steps"""
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_to_peer_exchange_between_processes(world):
+    """ranks (sharing this GPU) map each other's receive areas through HIP IPC and exchange 3 x 8 steps, then drive the fused
+    rollout.  Four ranks time-slicing one GPU skew by several steps along the partner chain: with fewer stamp-in-band slots
+    than steps a fast rank overwrote words a slow one had not read (polls timed out); two ranks cannot show that."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", os.path.join(root, "tests", "scripts", "p2p_two_rank.py")]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(29531 + world), os.path.join(root, "tests", "scripts", "p2p_two_rank.py")]
     out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and out.stdout.count("P2P_OK") == 2, (out.stdout[-1500:], out.stderr[-3000:])
+    assert out.returncode == 0 and out.stdout.count("P2P_OK") == world, (out.stdout[-1500:], out.stderr[-3000:])
