@@ -7,9 +7,11 @@ environment steps over n_envs=1024 synthetic Overcooked-shaped environments (pol
 rows (SURVEY.md 8d "throughput mode").  Inputs are synthetic, seeded, and already resident in HBM when the timed
 region starts.  value = agent-steps/s summed over all agents on all GPUs.
 
-Launch: `python bench.py` (N=1) or
+Launch: `python bench.py` (N=1), `python bench.py --gpus N` (spawns its own N ranks through torch.distributed.run), or
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
+One rank per GPU (rank r -> device LOCAL_RANK); `--gpus` larger than the visible device count is an error, and so is a
+WORLD_SIZE that disagrees with `--gpus`.
 """
 from __future__ import annotations
 
@@ -74,7 +76,8 @@ def parse():
     ap.add_argument("--n-epochs", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=0, help="0 = n_envs*n_steps/4")
     ap.add_argument("--agents-per-gpu", type=int, default=2,
-                    help="self-play pair per GPU (ego PPO + partner PPO, trainer.py ... PPO PPO)")
+                    help="2 = a self-play pair per GPU (ego PPO + partner PPO, trainer.py ... PPO PPO: the headline config); "
+                         "1 = north_star's one agent per GPU (N agents on N GPUs, every step's partner is on another rank)")
     ap.add_argument("--mode", choices=("auto", "graph", "jointgraph", "eager", "fusedstep"), default="auto",
                     help="graph: one hipGraph per agent-iteration (N=1 default); fusedstep: one fused launch of all local "
                          "agents + one action exchange per env step (the N>1 path; at N=1 the exchange is a local copy); "
@@ -180,8 +183,6 @@ def roofline(args, agent):
     achieved = flops / (ms.value * 1e-3) / 1e12
     small = lay.F <= 64 and lay.A == 1 and lay.L <= 8 and os.environ.get("PH_GRAD_FAST", "1") != "0"
     kernel = "ppo_grad_fast_kernel<false>" if small else "ppo_grad_kernel<64,LP,false>"
-    if small and os.environ.get("PH_GRAD_RP", "0") == "1":
-        kernel = "ppo_grad_rp_kernel<false>"
     out = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": 157.3,
            "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None, "launch_ms": ms.value,
            "flops_per_launch": flops}
@@ -231,11 +232,37 @@ def roofline(args, agent):
     return out
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks on this node."""
+    import socket
+    import subprocess
+    n_dev = th.cuda.device_count() if th.cuda.is_available() else 0
+    if args.backend == "nccl" and args.gpus > n_dev:
+        print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"self-launch: {' '.join(cmd)}")
+    env = dict(os.environ, PANTHEON_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
+    args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={os.environ.get('WORLD_SIZE')} "
+                         "(launch with --nproc-per-node equal to --gpus)")
     # RCCL prints a version banner to stdout at communicator creation: keep fd 1 clean for the one JSON line
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    args = parse()
     if args.n_envs <= 0:
         args.n_envs = WORKLOADS[args.workload]["n_envs"]
     if args.batch_size <= 0:
@@ -248,6 +275,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     if args.backend != "nccl":
         local_rank = local_rank % th.cuda.device_count()   # several ranks per GPU: functional test only
+    elif local_rank >= th.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but only {th.cuda.device_count()} are visible")
     th.cuda.set_device(local_rank)
     device = th.device("cuda", local_rank)
     distributed = pdist.init_from_env(args.backend)
@@ -307,21 +336,40 @@ def main():
             tdist.barrier()
             th.cuda.synchronize(device)
 
+    # per-iteration durations from events on every agent stream (the engine's launches go to these very streams), recorded
+    # inside the timed region: a few host microseconds each, no synchronisation
+    marks = [[th.cuda.Event(enable_timing=True) for _ in streams] for _ in range(args.steps + 1)]
+
+    def mark(i):
+        for ev, st in zip(marks[i], streams if mode != "fusedstep" else [streams[0]] * len(streams)):
+            ev.record(st)
+
     log(f"mode={mode}; warmup x{args.warmup}")
     for _ in range(args.warmup):
         iteration()
     barrier()
     log(f"timing x{args.steps}")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    mark(0)
+    for i in range(args.steps):
         iteration()
+        mark(i + 1)
     barrier()
     dt = time.perf_counter() - t0
     log(f"timed region {dt:.3f}s")
+    per_iter = [max(marks[i][k].elapsed_time(marks[i + 1][k]) for k in range(len(streams))) for i in range(args.steps)]
+    ranks_seen, devices_seen = 1, 1
     if distributed:
         tmax = th.tensor([dt], dtype=th.float64, device=device)
         tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
         dt = float(tmax.item())
+        one = th.ones(1, dtype=th.float64, device=device)
+        tdist.all_reduce(one)                        # communicator size as the collective itself sees it
+        ranks_seen = int(one.item())
+        ids = [None] * world
+        tdist.all_gather_object(ids, str(th.cuda.get_device_properties(device).uuid) if hasattr(
+            th.cuda.get_device_properties(device), "uuid") else f"{os.uname().nodename}:{local_rank}")
+        devices_seen = len(set(ids))
 
     steps_per_iter = args.n_envs * args.n_steps * len(agents) * world
     value = steps_per_iter * args.steps / dt
@@ -330,19 +378,26 @@ def main():
                   else f"env-steps/sec (all agents) {args.workload} shapes",
         "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": WORKLOADS[args.workload]["name"] + " (two independent PPO learners per GPU), synthetic "
-                               "(n_envs, n_steps, obs_dim) rollouts",
+        "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen, "devices_seen": devices_seen,
+        "iteration_ms": {"min": float(np.min(per_iter)), "median": float(np.median(per_iter)),
+                         "max": float(np.max(per_iter)), "source": "HIP events on the agents' streams, rank 0"},
+        "config": {"workload": WORKLOADS[args.workload]["name"] + (
+                       " (two independent PPO learners per GPU)" if len(agents) == 2 else
+                       f" ({len(agents)} independent PPO learner(s) per GPU)") + ", synthetic (n_envs, n_steps, obs_dim) rollouts",
                    "n_envs": args.n_envs, "n_steps": args.n_steps, "obs_dim": agents[0].model.policy.layout.D,
                    "features": agents[0].model.policy.layout.F, "n_logits": agents[0].model.policy.layout.L,
                    "batch_size": args.batch_size, "n_epochs": args.n_epochs, "agents_per_gpu": len(agents),
-                   "parallelism": f"agent-per-gpu x{world} (" + (
+                   "parallelism": f"{len(agents)} agent(s) per gpu x{world} gpu(s) = {len(agents) * world} learners (" + (
                        f"per-step action all-gather over xGMI, route {getattr(exchange, 'route', '?')}" if distributed
                        else "single process") + ")",
                    "exchange": ({"route": exchange.route, **exchange.route_log, "p2p_timeouts": exchange.p2p_timeouts()}
                                 if exchange is not None and hasattr(exchange, "route") else None),
                    "launch_mode": mode},
     }
+    if exchange is not None and hasattr(exchange, "route") and exchange.p2p_timeouts() != 0:
+        raise SystemExit(f"bench.py: rank {rank}: {exchange.p2p_timeouts()} peer-to-peer polls timed out -- the run is invalid")
+    if distributed and ranks_seen != args.gpus:
+        raise SystemExit(f"bench.py: the collective saw {ranks_seen} ranks, --gpus is {args.gpus}")
     if rank == 0:
         if not args.no_roofline:
             result["roofline"] = roofline(args, agents[0])

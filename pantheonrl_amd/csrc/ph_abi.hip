@@ -35,6 +35,7 @@ struct SpecCache {
   ph_spec spec;
   int* obs_off = nullptr;  // device prefix sums
   int* act_off = nullptr;
+  int* slab_map = nullptr; // device: slab position -> parameter index for register-order gradient slabs, or null
 };
 
 }  // namespace
@@ -57,7 +58,6 @@ struct ph_ctx {
   size_t advpart_cap = 0;
   int* perm_idx = nullptr;   // (n_epochs, N) minibatch order of the current train() call, written by adv_stats
   size_t perm_idx_cap = 0;
-  float* w2t = nullptr;      // [2][64][64] (W2G gradient-kernel variant)
   float* scalars = nullptr;  // [4]
   int* stop_flag = nullptr;  // [1]
   std::vector<SpecCache> specs;
@@ -152,9 +152,23 @@ int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd) {
       PH_HIP(hipMalloc((void**)&c.obs_off, oo.size() * sizeof(int)));
       PH_HIP(hipMemcpy(c.obs_off, oo.data(), oo.size() * sizeof(int), hipMemcpyHostToDevice));
     }
+    {   // does this spec run on the gradient kernel with register-order slabs?  then its slab table goes to the device once
+      ph::NetDims probe;
+      probe.lay = nd->lay;
+      probe.nchunk = (nd->lay.F + PH_HIDDEN - 1) / PH_HIDDEN;
+      probe.A = nd->lay.A;
+      probe.L = nd->lay.L;
+      if (ph::grad_uses_reg_slabs(probe)) {
+        std::vector<int> m(2 * ph::RS_NET);
+        ph::grad_slab_map(nd->lay, m.data());
+        PH_HIP(hipMalloc((void**)&c.slab_map, m.size() * sizeof(int)));
+        PH_HIP(hipMemcpy(c.slab_map, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice));
+      }
+    }
     ctx->specs.push_back(c);
     hit = &ctx->specs.back();
   }
+  nd->slab_map = hit->slab_map;
   nd->obs_kind = spec->obs.kind;
   nd->D = nd->lay.D;
   nd->F = nd->lay.F;
@@ -211,8 +225,7 @@ int ph_ctx_create(int device, ph_ctx** out) {
   ph_ctx* c = new ph_ctx();
   c->device = device;
   c->num_cu = prop.multiProcessorCount;
-  if (hipMalloc((void**)&c->w2t, 2 * 64 * 64 * sizeof(float)) != hipSuccess ||
-      hipMalloc((void**)&c->scalars, 4 * sizeof(float)) != hipSuccess ||
+  if (hipMalloc((void**)&c->scalars, 4 * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&c->stop_flag, sizeof(int)) != hipSuccess) {
     delete c;
     return fail("hipMalloc(ctx scalars) failed");
@@ -233,9 +246,10 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (g) (void)hipGraphExecDestroy(g);
   for (auto& s : ctx->specs) {
     if (s.obs_off) (void)hipFree(s.obs_off);
+    if (s.slab_map) (void)hipFree(s.slab_map);
     if (s.act_off) (void)hipFree(s.act_off);
   }
-  void* ptrs[] = {ctx->advpart, ctx->p2p_dev, ctx->w2t, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->scalars, ctx->stop_flag};
+  void* ptrs[] = {ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->scalars, ctx->stop_flag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -914,19 +928,21 @@ void fill_grad_args(ph::GradArgs& g, const ph::NetDims& nd, const float* params,
   g.statpart = ctx->statpart;
   g.stop_flag = ctx->stop_flag;
   g.prof = ctx->prof;
-  g.w2t = ctx->w2t;
 }
 
-int ensure_train_ws(ph_ctx* ctx, int P, int nwg_max, int n_mb_total, size_t n_idx = 0) {
+// floats per gradient slab: the canonical parameter layout, or the register-order layout of ppo_grad_fast_kernel
+int slab_len_of(const ph::NetDims& nd) { return nd.slab_map ? 2 * ph::RS_NET : nd.lay.P; }
+
+int ensure_train_ws(ph_ctx* ctx, int P, int slab_len, int nwg_max, int n_mb_total, size_t n_idx = 0) {
   if (ctx->capturing) {
-    if ((size_t)nwg_max * P > ctx->slabs_cap || (size_t)n_mb_total * 2 > ctx->advstats_cap || n_idx > ctx->perm_idx_cap)
+    if ((size_t)nwg_max * slab_len > ctx->slabs_cap || (size_t)n_mb_total * 2 > ctx->advstats_cap || n_idx > ctx->perm_idx_cap)
       return fail("workspace would grow inside graph capture: run the same call once outside capture first");
     return 0;
   }
-  if (ensure(ctx->slabs, ctx->slabs_cap, (size_t)nwg_max * P)) return 1;
+  if (ensure(ctx->slabs, ctx->slabs_cap, (size_t)nwg_max * slab_len)) return 1;
   if (ensure(ctx->statpart, ctx->statpart_cap, (size_t)2 * nwg_max * ph::NSTATP)) return 1;
   if (ensure(ctx->grad, ctx->grad_cap, (size_t)P)) return 1;
-  if (ensure(ctx->blocksq, ctx->blocksq_cap, (size_t)ph::reduce_blocks(P))) return 1;
+  if (ensure(ctx->blocksq, ctx->blocksq_cap, (size_t)ph::reduce_blocks(slab_len))) return 1;
   if (ensure(ctx->advstats, ctx->advstats_cap, (size_t)n_mb_total * 2)) return 1;
   if (ensure(ctx->advpart, ctx->advpart_cap, (size_t)n_mb_total * 2 * ph::ADV_SPLIT)) return 1;
   if (n_idx && ensure(ctx->perm_idx, ctx->perm_idx_cap, n_idx)) return 1;
@@ -949,7 +965,6 @@ struct TrainPlan {
   float* stats;
   int n_epochs, batch_size, gemm_mode, N, n_mb, P;
   uint32_t hb;
-  bool w2g;
 };
 
 // validation, workspace, stop-flag reset and the advantage statistics / minibatch order of every minibatch
@@ -977,11 +992,9 @@ int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_s
   t.n_mb = (t.N + batch_size - 1) / batch_size;
   t.P = t.nd.lay.P;
   const MbPlan big = plan_minibatch(ctx, t.nd, batch_size < t.N ? batch_size : t.N);
-  if (ensure_train_ws(ctx, t.P, big.nwg, n_epochs * t.n_mb, perms ? 0 : (size_t)n_epochs * t.N)) return 1;
+  if (ensure_train_ws(ctx, t.P, slab_len_of(t.nd), big.nwg, n_epochs * t.n_mb, perms ? 0 : (size_t)n_epochs * t.N)) return 1;
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
-  t.w2g = ph::grad_variant() == 1;
-  if (t.w2g) PH_HIP(ph::launch_transpose_w2(opt->params, t.nd.lay.pi_W2, t.nd.lay.vf_W2, ctx->w2t, s));
   t.hb = ph::feistel_half_bits((uint32_t)t.N);
   ph::AdvStatArgs aa;
   aa.rb_adv = rb->advantages;
@@ -1036,6 +1049,8 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
   r.nslab = pl.nwg;
   r.nstatpart = 2 * pl.nwg;
   r.P = t.P;
+  r.slab_len = slab_len_of(t.nd);
+  r.map = t.nd.slab_map;
   r.grad = ctx->grad;
   r.blocksq = ctx->blocksq;
   r.statpart = ctx->statpart;
@@ -1055,7 +1070,7 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
   ad.v = t.opt->adam_v;
   ad.grad = ctx->grad;
   ad.blocksq = ctx->blocksq;
-  ad.nblk = ph::reduce_blocks(t.P);
+  ad.nblk = ph::reduce_blocks(slab_len_of(t.nd));
   ad.P = t.P;
   ad.step = t.opt->step;
   ad.scalars = ctx->scalars;
@@ -1066,9 +1081,6 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
   ad.eps = t.hp->adam_eps;
   ad.max_norm = t.hp->max_grad_norm;
   ad.stats_out = r.stats_out;
-  ad.w2t = t.w2g ? ctx->w2t : nullptr;
-  ad.pi_W2 = t.nd.lay.pi_W2;
-  ad.vf_W2 = t.nd.lay.vf_W2;
   PH_HIP(ph::launch_ppo_adam(ad, s));
   return 0;
 }
@@ -1135,7 +1147,7 @@ int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params,
   if (resolve(ctx, spec, &nd)) return 1;
   const int P = nd.lay.P;
   const MbPlan pl = plan_minibatch(ctx, nd, nb);
-  if (ensure_train_ws(ctx, P, pl.nwg, 1)) return 1;
+  if (ensure_train_ws(ctx, P, slab_len_of(nd), pl.nwg, 1)) return 1;
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
   ph::AdvStatArgs aa;
@@ -1161,13 +1173,14 @@ int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params,
   g.nb = nb;
   g.advstats = ctx->advstats;
   g.ntiles = pl.ntiles;
-  if (ph::grad_variant() == 1) PH_HIP(ph::launch_transpose_w2(params, nd.lay.pi_W2, nd.lay.vf_W2, ctx->w2t, s));
   PH_HIP(ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s));
   ph::ReduceArgs r;
   r.slabs = ctx->slabs;
   r.nslab = pl.nwg;
   r.nstatpart = 2 * pl.nwg;
   r.P = P;
+  r.slab_len = slab_len_of(nd);
+  r.map = nd.slab_map;
   r.grad = grad_out;
   r.blocksq = ctx->blocksq;
   r.statpart = ctx->statpart;
@@ -1193,7 +1206,7 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   const int N = rb->T * rb->E;
   const int nb = batch_size < N ? batch_size : N;
   const MbPlan pl = plan_minibatch(ctx, nd, nb);
-  if (ensure_train_ws(ctx, nd.lay.P, pl.nwg, 1, (size_t)N)) return 1;
+  if (ensure_train_ws(ctx, nd.lay.P, slab_len_of(nd), pl.nwg, 1, (size_t)N)) return 1;
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
   ph::AdvStatArgs aa;
@@ -1222,7 +1235,6 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   g.nb = nb;
   g.advstats = ctx->advstats;
   g.ntiles = pl.ntiles;
-  if (ph::grad_variant() == 1) PH_HIP(ph::launch_transpose_w2(params, nd.lay.pi_W2, nd.lay.vf_W2, ctx->w2t, s));
   PH_HIP(ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s));  // warm
   PH_HIP(hipEventRecord(ctx->ev0, s));
   for (int i = 0; i < reps; ++i) PH_HIP(ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s));

@@ -26,49 +26,14 @@ __device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2
 // the logits.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
-#if defined(PH_TANH_EXPONLY)
+// tanh(x) = 1 - 2 / (e^{2x} + 1): two quarter-rate ops and three plain ones, absolute error <= 2e-7 over the whole range (the
+// relative error grows for |x| < 1e-3, where the absolute one is ~1e-8).  f32 MFMA and VALU instructions of a SIMD do not
+// overlap on gfx950 (scripts/ubench, profiles/r02_ubench_*.txt), so every VALU op of the layer epilogues is paid in full: the
+// round-1 form (odd polynomial below |x| = 0.3, this expression above: 15 plain ops) cost 1 us per gradient launch more.
 __device__ __forceinline__ float fast_tanh(float x) {
   const float e = __builtin_amdgcn_exp2f(x * (2.0f * 1.44269504088896340736f));
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
-#elif !defined(PH_TANH_RATIONAL)
-// polynomial for |x| < 0.3 (next Taylor term < 1.6e-8), 1 - 2/(e^{2x}+1) otherwise; abs. error <= 2e-7.  A/B on the same
-// box against the rational form below (11-FMA Horner chain + one rcp): 59.0 vs 62.0 us per ppo_grad launch, 6.69 vs
-// 7.04 ms per bench iteration -- the short dependency chains of this form win although it has more instructions.
-__device__ __forceinline__ float fast_tanh(float x) {
-  const float ax = __builtin_fabsf(x);
-  const float x2 = x * x;
-  float p = 62.0f / 2835.0f;
-  p = __builtin_fmaf(p, x2, -17.0f / 315.0f);
-  p = __builtin_fmaf(p, x2, 2.0f / 15.0f);
-  p = __builtin_fmaf(p, x2, -1.0f / 3.0f);
-  p = __builtin_fmaf(p * x2, x, x);
-  const float e = __builtin_amdgcn_exp2f(ax * (2.0f * 1.44269504088896340736f));
-  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-  return ax < 0.3f ? p : __builtin_copysignf(t, x);
-}
-#else
-__device__ __forceinline__ float fast_tanh(float x) {
-  // odd/even rational minimax approximation x*P(x^2)/Q(x^2) on the clamped argument (|x| <= 7.905: beyond it tanh
-  // rounds to +-1 in float32): 11 FMAs and ONE quarter-rate op (rcp), no exp, ~2 ulp over the whole range including
-  // tiny |x| (the exp-based form 1 - 2/(e^{2x}+1) loses relative accuracy there and needs two quarter-rate ops)
-  const float c = fminf(fmaxf(x, -7.90531110763549805f), 7.90531110763549805f);
-  const float x2 = c * c;
-  float p = -2.76076847742355e-16f;
-  p = __builtin_fmaf(p, x2, 2.00018790482477e-13f);
-  p = __builtin_fmaf(p, x2, -8.60467152213735e-11f);
-  p = __builtin_fmaf(p, x2, 5.12229709037114e-08f);
-  p = __builtin_fmaf(p, x2, 1.48572235717979e-05f);
-  p = __builtin_fmaf(p, x2, 6.37261928875436e-04f);
-  p = __builtin_fmaf(p, x2, 4.89352455891786e-03f);
-  p *= c;
-  float q = 1.19825839466702e-06f;
-  q = __builtin_fmaf(q, x2, 1.18534705686654e-04f);
-  q = __builtin_fmaf(q, x2, 2.26843463243900e-03f);
-  q = __builtin_fmaf(q, x2, 4.89352518554385e-03f);
-  return p * __builtin_amdgcn_rcpf(q);
-}
-#endif
 
 // One 32x32 output tile  acc += A[m0:m0+32, k0:k0+klen] * B[k0:k0+klen, n0:n0+32]  with both operands in
 // LDS.  A(m,k) = TA ? A[k*lda+m] : A[m*lda+k];  B(k,n) = TB ? B[n*ldb+k] : B[k*ldb+n].
@@ -229,6 +194,7 @@ struct NetDims {
   int nchunk;       // ceil(F / 64) feature chunks of the first layer
   const int* obs_off;  // device: prefix sums of obs nvec (D+1) for the one-hot path, else nullptr
   const int* act_off;  // device: prefix sums of act nvec (A+1)
+  const int* slab_map; // device: slab position -> parameter index when the spec runs on register-order slabs, else nullptr
   ph_layout lay;
 };
 

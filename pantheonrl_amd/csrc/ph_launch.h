@@ -92,7 +92,6 @@ struct GradArgs {
   float* statpart;         // [2*gridDim.x][NSTATP]
   const int* stop_flag;    // device flag set by the KL early stop
   long long* prof;         // debug: per-workgroup phase timestamps (clock64), or null
-  const float* w2t;        // [2][64][64] transposed W2 copies (W2G variant), or null
   int ntiles;
 };
 
@@ -137,6 +136,8 @@ struct AdvStatArgs {
 struct ReduceArgs {
   const float* slabs;
   int nslab, P;
+  int slab_len;          // floats per slab (P for the canonical layout)
+  const int* map;        // slab position -> parameter index (-1 = padding), or null = identity (canonical slabs)
   float* grad;
   float* blocksq;        // [gridDim.x]
   const float* statpart; // [nstatpart][NSTATP] per-workgroup partial sums of the grad kernel
@@ -161,14 +162,10 @@ struct AdamArgs {
   int* stop_flag;
   float lr, beta1, beta2, eps, max_norm;
   float* stats_out;       // [PH_NSTAT] or null: writes grad_norm at [6]
-  float* w2t;             // transposed W2 copies to refresh, or null
-  int pi_W2, vf_W2;
 };
 
 size_t fwd_lds_bytes(int R, int Lp);
-size_t grad_lds_bytes(int R, int Lp, bool w2g, int onehot_D);
-int grad_variant();
-hipError_t launch_transpose_w2(const float* params, int pi_W2, int vf_W2, float* w2t, hipStream_t s);
+size_t grad_lds_bytes(int R, int Lp, int onehot_D);
 hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s);
 hipError_t launch_policy_fwd_multi(const FwdMulti& m, int n_agents, hipStream_t s);
 hipError_t launch_fix_illegal(int* actions, const unsigned char* mask, int n, int L, hipStream_t s);
@@ -205,21 +202,20 @@ hipError_t launch_p2p_push(const ph_p2p& x, const int* local, int t, hipStream_t
 hipError_t launch_p2p_wait(const ph_p2p& x, int t, hipStream_t s);
 hipError_t launch_p2p_ll_unpack(const ph_p2p& x, int t, hipStream_t s);
 hipError_t launch_p2p_ll_push(const ph_p2p& x, const int* local, int t, hipStream_t s);
-// single-chunk / small-Discrete-head variant (ph_ppo_fast.hip); eligible() says whether the spec fits it
+// single-chunk / small-Discrete-head kernel (ph_ppo_fast.hip); eligible() says whether the spec fits it.  Its slabs are in
+// the MFMA accumulators' register order -- [net][RS_NET] floats per workgroup (16-byte stores, 1 KB contiguous per wave
+// instruction) -- and the reduce kernel maps slab positions to parameter indices through the table grad_slab_map fills.
+constexpr int RS_NET = 8960;
+constexpr int RS_W2 = 0, RS_W1 = 4096, RS_B1 = 8192, RS_B2 = 8256, RS_HW = 8320, RS_HB = 8832;
 bool grad_fast_eligible(const NetDims& nd);
-// eight-wave phased variant (ph_ppo_w8.hip): same tiling as the fast kernel (64-row tiles, <= #CU workgroups per net)
-bool grad_w8_eligible(const NetDims& nd);
-hipError_t launch_ppo_grad_w8(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
-// row-parallel variant (ph_ppo_rp.hip): Box observations, single chunk, small Discrete head; rows walked in 16-row blocks
-bool grad_rp_eligible(const NetDims& nd);
-void grad_rp_plan(int nb, int num_cu, int* ntiles16, int* nwg);
-hipError_t launch_ppo_grad_rp(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
+bool grad_uses_reg_slabs(const NetDims& nd);
+void grad_slab_map(const ph_layout& lay, int* map /* host, 2 * RS_NET */);
 // tiles (GradArgs.ntiles) and workgroups per net that launch_ppo_grad will use for a minibatch of nb rows
 void grad_plan(const NetDims& nd, int nb, int num_cu, int* ntiles, int* nwg);
 hipError_t launch_ppo_grad_fast(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s);
-int reduce_blocks(int P);
+int reduce_blocks(int slab_len);
 hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_set_int(int* p, int v, hipStream_t s);
 hipError_t launch_epoch_advance(unsigned long long* p, hipStream_t s);

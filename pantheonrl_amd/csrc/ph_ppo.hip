@@ -19,8 +19,8 @@ namespace ph {
 // Weight-gradient tiles accumulate across the tiles of a workgroup in its private slab: the MFMA accumulator is
 // initialised from the slab (the loads hide under the operand prefetch of the tile product), then stored back.
 // (No-return L2 float atomics instead of the reload measured 8 % slower on the whole kernel.)
-template <int R, int LP, bool VALU, bool W2G>
-__global__ __launch_bounds__(R * 4, W2G ? 3 : 2) void ppo_grad_kernel(GradArgs a) {
+template <int R, int LP, bool VALU>
+__global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   if (*a.stop_flag) return;
   PH_STAMP(a.prof, 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -32,8 +32,8 @@ __global__ __launch_bounds__(R * 4, W2G ? 3 : 2) void ppo_grad_kernel(GradArgs a
   float* bufB = bufA + R * LDH;        // [R][LDH]  H1 -> dZ1
   float* regW = bufB + R * LDH;        // W1 chunk [64][LDH]  |  Wo [64][LDO] + OUT [R][LDO]
   constexpr int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
-  float* w2s = regW + regW_sz;         // [64][LDH]  (absent when W2G: W2 / W2^T are read from global as MFMA operands)
-  float* b1s = w2s + (W2G ? 0 : HID * LDH);  // [64]
+  float* w2s = regW + regW_sz;         // [64][LDH]
+  float* b1s = w2s + HID * LDH;        // [64]
   float* b2s = b1s + HID;              // [64]
   float* bos = b2s + HID;              // act_b [Lp]  (policy)  |  val_W [64] (value)
   float* radv = bos + 64;              // [R] normalised advantage (policy) | returns (value)
@@ -56,9 +56,7 @@ __global__ __launch_bounds__(R * 4, W2G ? 3 : 2) void ppo_grad_kernel(GradArgs a
   // prologue: W2 and the bias vectors are issued now and committed after the first tile's row metadata, so their
   // latency overlaps the index gathers of S0
   WStage<NT> w2r;
-  if constexpr (!W2G) w2r.issue(a.params + oW2, 0, HID);
-  const float* w2g = a.params + oW2;                       // W2 [k][j]
-  const float* w2tg = a.w2t + (size_t)net * HID * HID;     // W2^T [j][k]
+  w2r.issue(a.params + oW2, 0, HID);
   float bias1 = 0.f, bias2 = 0.f, bias3 = 0.f;
   if (tid < HID) {
     bias1 = a.params[oB1 + tid];
@@ -93,7 +91,7 @@ __global__ __launch_bounds__(R * 4, W2G ? 3 : 2) void ppo_grad_kernel(GradArgs a
     }
   };
   stage_rows(blockIdx.x);  // overlaps the W2 / bias loads issued above
-  if constexpr (!W2G) w2r.commit(w2s);
+  w2r.commit(w2s);
   if (tid < HID) {
     b1s[tid] = bias1;
     b2s[tid] = bias2;
@@ -146,8 +144,7 @@ __global__ __launch_bounds__(R * 4, W2G ? 3 : 2) void ppo_grad_kernel(GradArgs a
     // ---- S2: H2 = tanh(H1 W2 + b2) -> bufA ----
     {
       f32x16 acc2 = {0};
-      if constexpr (W2G) acc2 = tile_mma<false, false, VALU>(bufB, LDH, w2g, HID, mt * 32, nt * 32, 0, HID, acc2, lane);
-      else acc2 = tile_mma<false, false, VALU>(bufB, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc2, lane);
+      acc2 = tile_mma<false, false, VALU>(bufB, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc2, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
@@ -398,8 +395,7 @@ __global__ __launch_bounds__(R * 4, W2G ? 3 : 2) void ppo_grad_kernel(GradArgs a
         for (int r = 0; r < R; ++r) s += bufA[r * LDH + tid];
         slab[oB2 + tid] = s;
       }
-      if constexpr (W2G) dh1 = tile_mma<false, false, VALU>(bufA, LDH, w2tg, HID, mt * 32, nt * 32, 0, HID, dh1, lane);
-      else dh1 = tile_mma<false, true, VALU>(bufA, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1, lane);
+      dh1 = tile_mma<false, true, VALU>(bufA, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1, lane);
     }
     __syncthreads();  // dZ2 (bufA) and H1 (bufB) fully consumed
     if (first) PH_STAMP(a.prof, 10);
@@ -471,70 +467,47 @@ __global__ __launch_bounds__(R * 4, W2G ? 3 : 2) void ppo_grad_kernel(GradArgs a
 }
 
 
-size_t grad_lds_bytes(int R, int Lp, bool w2g, int onehot_D) {
+size_t grad_lds_bytes(int R, int Lp, int onehot_D) {
   const int LDO = Lp + 1;
   const int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
-  return sizeof(float) * (size_t)(2 * R * LDH + regW_sz + (w2g ? 0 : HID * LDH) + 3 * 64 + 3 * R + NSTATP * 4 + R + R * onehot_D);
+  return sizeof(float) * (size_t)(2 * R * LDH + regW_sz + HID * LDH + 3 * 64 + 3 * R + NSTATP * 4 + R + R * onehot_D);
 }
 
-template <int LP, bool VALU, bool W2G>
+template <int LP, bool VALU>
 static hipError_t launch_grad_variant(const GradArgs& a, int nwg, hipStream_t s) {
   constexpr int R = 64;
-  const size_t lds = grad_lds_bytes(R, LP, W2G, a.nd.obs_kind != PH_SPACE_BOX ? a.nd.D : 0);
+  const size_t lds = grad_lds_bytes(R, LP, a.nd.obs_kind != PH_SPACE_BOX ? a.nd.D : 0);
   dim3 grid(nwg, 2), block(R * 4);
-  static size_t allowed = 0;  // > 64 KiB of dynamic LDS is opt-in, once per kernel (kept out of graph capture)
-  if (lds > allowed) {
-    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<R, LP, VALU, W2G>,
+  static size_t allowed[64] = {0};  // > 64 KiB of dynamic LDS is opt-in per kernel and device (kept out of graph capture)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev = (dev >= 0 && dev < 64) ? dev : 0;
+  if (lds > allowed[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<R, LP, VALU>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    allowed = lds;
+    allowed[dev] = lds;
   }
-  hipLaunchKernelGGL((ppo_grad_kernel<R, LP, VALU, W2G>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((ppo_grad_kernel<R, LP, VALU>), grid, block, lds, s, a);
   return hipGetLastError();
 }
 
-// variant 0: W2 staged in LDS, 2 workgroups / CU.  variant 1 ("W2G"): W2 and W2^T read from global as MFMA operands,
-// 52 KB LDS and <= 168 VGPRs -> 3 workgroups / CU.
-int grad_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("PH_GRAD_W2G");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v;
-}
+// The single-chunk / small-head kernel (ph_ppo_fast.hip) writes its slabs in the MFMA accumulators' register order; the
+// general kernel accumulates in canonical parameter order.
+bool grad_uses_reg_slabs(const NetDims& nd) { return grad_fast_eligible(nd); }
 
 void grad_plan(const NetDims& nd, int nb, int num_cu, int* ntiles, int* nwg) {
-  if (grad_rp_eligible(nd)) {
-    grad_rp_plan(nb, num_cu, ntiles, nwg);
-    return;
-  }
   // 64-row tiles; 2 nets x nwg workgroups, two resident per CU: nwg = #CUs covers the chip, more tiles are walked
   *ntiles = (nb + 63) / 64;
   *nwg = *ntiles < num_cu ? *ntiles : num_cu;
 }
 
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s) {
-  if (grad_rp_eligible(a.nd)) return launch_ppo_grad_rp(a, nwg, gemm_mode, s);
-  if (grad_w8_eligible(a.nd)) return launch_ppo_grad_w8(a, nwg, gemm_mode, s);
   if (grad_fast_eligible(a.nd)) return launch_ppo_grad_fast(a, nwg, gemm_mode, s);
   if (a.nd.Lp != 32 && a.nd.Lp != 64) return hipErrorInvalidValue;
   const bool lp64 = a.nd.Lp == 64;
-  if (gemm_mode != 0) return lp64 ? launch_grad_variant<64, true, false>(a, nwg, s) : launch_grad_variant<32, true, false>(a, nwg, s);
-  if (grad_variant() == 1) return lp64 ? launch_grad_variant<64, false, true>(a, nwg, s) : launch_grad_variant<32, false, true>(a, nwg, s);
-  return lp64 ? launch_grad_variant<64, false, false>(a, nwg, s) : launch_grad_variant<32, false, false>(a, nwg, s);
-}
-
-// W2^T copies ([net][j][k]) for the W2G variant: refreshed by ppo_adam_kernel after every step, built here once
-__global__ void transpose_w2_kernel(const float* __restrict__ params, int pi_W2, int vf_W2, float* __restrict__ w2t) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // 2 * 4096
-  if (e >= 2 * HID * HID) return;
-  const int net = e / (HID * HID), r = e - net * HID * HID, k = r / HID, j = r - k * HID;
-  w2t[(size_t)net * HID * HID + j * HID + k] = params[(net == 0 ? pi_W2 : vf_W2) + r];
-}
-hipError_t launch_transpose_w2(const float* params, int pi_W2, int vf_W2, float* w2t, hipStream_t s) {
-  hipLaunchKernelGGL(transpose_w2_kernel, dim3((2 * HID * HID + 255) / 256), dim3(256), 0, s, params, pi_W2, vf_W2, w2t);
-  return hipGetLastError();
+  if (gemm_mode != 0) return lp64 ? launch_grad_variant<64, true>(a, nwg, s) : launch_grad_variant<32, true>(a, nwg, s);
+  return lp64 ? launch_grad_variant<64, false>(a, nwg, s) : launch_grad_variant<32, false>(a, nwg, s);
 }
 
 // ---- advantage statistics of every minibatch of a train() call: mean and unbiased std (torch .mean()/.std()) ----
@@ -637,20 +610,20 @@ __global__ __launch_bounds__(RED_PARAMS * RED_GROUPS) void ppo_reduce_kernel(Red
     return;
   }
   const int pl = tid & (RED_PARAMS - 1), grp = tid >> RED_SHIFT;
-  const int p = blockIdx.x * RED_PARAMS + pl;
+  const int p = blockIdx.x * RED_PARAMS + pl;   // slab position
   {
     const int per = (a.nslab + RED_GROUPS - 1) / RED_GROUPS;
     const int k0 = grp * per, k1 = (k0 + per < a.nslab) ? k0 + per : a.nslab;
     float acc[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-    if (p < a.P) {
+    if (p < a.slab_len) {
       int k = k0;
       for (; k + 7 < k1; k += 8) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] += a.slabs[(size_t)(k + u) * a.P + p];
+        for (int u = 0; u < 8; ++u) acc[u] += a.slabs[(size_t)(k + u) * a.slab_len + p];
       }
-      for (; k < k1; ++k) acc[0] += a.slabs[(size_t)k * a.P + p];
+      for (; k < k1; ++k) acc[0] += a.slabs[(size_t)k * a.slab_len + p];
     }
     gsum[grp][pl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
@@ -660,7 +633,9 @@ __global__ __launch_bounds__(RED_PARAMS * RED_GROUPS) void ppo_reduce_kernel(Red
     if (tid < RED_PARAMS) {
 #pragma unroll
       for (int j = 0; j < RED_GROUPS; ++j) g += gsum[j][tid];
-      if (p < a.P) a.grad[p] = g;
+      // canonical slabs: position = parameter index; register-order slabs (ppo_grad_fast_kernel): through the table
+      const int dst = p < a.slab_len ? (a.map ? a.map[p] : p) : -1;
+      if (dst >= 0) a.grad[dst] = g;
       else g = 0.f;
     }
     float q = g * g;
@@ -702,9 +677,9 @@ __global__ __launch_bounds__(RED_PARAMS * RED_GROUPS) void ppo_reduce_kernel(Red
     }
   }
 }
-int reduce_blocks(int P) { return (P + RED_PARAMS - 1) / RED_PARAMS; }
+int reduce_blocks(int slab_len) { return (slab_len + RED_PARAMS - 1) / RED_PARAMS; }
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(ppo_reduce_kernel, dim3(reduce_blocks(a.P)), dim3(RED_PARAMS * RED_GROUPS), 0, s, a);
+  hipLaunchKernelGGL(ppo_reduce_kernel, dim3(reduce_blocks(a.slab_len)), dim3(RED_PARAMS * RED_GROUPS), 0, s, a);
   return hipGetLastError();
 }
 
@@ -744,11 +719,6 @@ __global__ __launch_bounds__(256) void ppo_adam_kernel(AdamArgs a) {
   a.v[p] = v;
   const float pn = a.params[p] - ss_s * (m / denom);                   // param.addcdiv_(exp_avg, denom, -step_size)
   a.params[p] = pn;
-  if (a.w2t) {  // keep the transposed W2 copies of the W2G gradient kernel current
-    int r = p - a.pi_W2, net = 0;
-    if (r < 0 || r >= HID * HID) { r = p - a.vf_W2; net = 1; }
-    if (r >= 0 && r < HID * HID) a.w2t[(size_t)net * HID * HID + (r % HID) * HID + r / HID] = pn;
-  }
 }
 hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(ppo_adam_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);

@@ -8,7 +8,9 @@
 //     each owning 16 hidden units, quad-DPP reductions -- instead of four barrier-separated phases around 32-wide padded
 //     MFMA tiles of a 6-wide head;
 //   * weight- and bias-gradient accumulators live in registers across the row tiles of a workgroup and are stored to
-//     the workgroup's slab once (no slab read-modify-write per tile, no store drain at barriers);
+//     the workgroup's slab once (no slab read-modify-write per tile, no store drain at barriers), in the accumulators' own
+//     register order: 16-byte stores, 1 KB contiguous per wave instruction; the reduce kernel maps slab positions to
+//     parameter indices through a per-spec table (grad_slab_map);
 //   * barriers wait for LDS only (s_waitcnt lgkmcnt(0); s_barrier), so global loads issued in one phase -- the next
 //     tile's gathered rows, its per-row scalars, the W1 refill -- stay in flight across phases and are consumed later.
 // LDS: bufA/bufB/bufC/W2 (4 x [64][65] f32) + head weights + per-row scalars = 72.9 KB -> two workgroups per CU.
@@ -95,7 +97,7 @@ struct XRegs {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int p = __builtin_amdgcn_readlane(physv, i);
-      v[i] = obs[(size_t)(p < 0 ? 0 : p) * nd.D + f];
+      v[i] = __builtin_nontemporal_load(obs + (size_t)(p < 0 ? 0 : p) * nd.D + f);   // read once per epoch and net
     }
   }
   __device__ __forceinline__ void commit(float* dst, int physv, const NetDims& nd, int wave, int lane) const {
@@ -134,7 +136,6 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
   const bool box = nd.obs_kind == PH_SPACE_BOX;
   const int oW1 = net == 0 ? lay.pi_W1 : lay.vf_W1, oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1;
   const int oW2 = net == 0 ? lay.pi_W2 : lay.vf_W2, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
-  float* slab = a.slabs + (size_t)blockIdx.x * lay.P;
   const float inv_nb = 1.0f / (float)a.nb;
   const int nk = nd.L;
 
@@ -177,10 +178,9 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
   RowMeta meta;
   {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    meta = row_scalars(row_index(blockIdx.x, wave, lane));
-    if (box) xt.issue(meta.phys, a.rb_obs, nd, lane);
     w1r.issue(a.params + oW1, 0, nd.F);
     w2r.issue(a.params + oW2, 0, HID);
+    const int n0 = row_index(blockIdx.x, wave, lane);
     float bias1 = 0.f, bias2 = 0.f, hv0 = 0.f, hv1 = 0.f, hb = 0.f;
     if (tid < HID) {
       bias1 = a.params[oB1 + tid];
@@ -198,6 +198,8 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
       if (tid < HID) hv0 = a.params[lay.val_W + tid];
       if (tid == 0) hb = a.params[lay.val_b];
     }
+    meta = row_scalars(n0);
+    if (box) xt.issue(meta.phys, a.rb_obs, nd, lane);
     w1r.commit(bufC);
     w2r.commit(w2s);
     if (tid < HID) {
@@ -469,17 +471,15 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
   // ---- epilogue: accumulators -> slab (once), cross-wave sums in a fixed order ----
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mt = wave >> 1, nt = wave & 1, li = lane & 31, lh = lane >> 5;
+    // the workgroup's slab half in the accumulators' own register order: 16-byte stores, 1 KB contiguous per wave instruction
+    float* rslab = a.slabs + ((size_t)blockIdx.x * 2 + net) * RS_NET;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int k = mt * 32 + drow(r, lh), col = nt * 32 + li;
-      slab[oW2 + k * HID + col] = gW2[r];
-      if (k < nd.F) slab[oW1 + (size_t)k * HID + col] = gW1[r];
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int o = ((wave * 4 + r4) * 64 + lane) * 4;
+      *reinterpret_cast<float4*>(rslab + RS_W2 + o) = make_float4(gW2[4 * r4], gW2[4 * r4 + 1], gW2[4 * r4 + 2], gW2[4 * r4 + 3]);
+      *reinterpret_cast<float4*>(rslab + RS_W1 + o) = make_float4(gW1[4 * r4], gW1[4 * r4 + 1], gW1[4 * r4 + 2], gW1[4 * r4 + 3]);
     }
-    if (net == 0) {
-      if (2 * wave < nk) slab[lay.act_W + lane * nk + 2 * wave] = gh0;
-      if (2 * wave + 1 < nk) slab[lay.act_W + lane * nk + 2 * wave + 1] = gh1;
-    }
+    if (net == 0) *reinterpret_cast<float2*>(rslab + RS_HW + lane * 8 + 2 * wave) = make_float2(gh0, gh1);
 #pragma unroll
     for (int k = 0; k < NSTATP; ++k) {
       float v = st[k];
@@ -502,12 +502,12 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
              part[(which * 4 + 3) * 64 + idx];
     };
     if (tid < HID) {
-      slab[oB1 + tid] = wsum(0, tid);
-      slab[oB2 + tid] = wsum(1, tid);
-      if (net == 1) slab[lay.val_W + tid] = wsum(2, tid);
+      rslab[RS_B1 + tid] = wsum(0, tid);
+      rslab[RS_B2 + tid] = wsum(1, tid);
+      if (net == 1) rslab[RS_HW + tid] = wsum(2, tid);
     }
-    if (net == 0 && tid < nk) slab[lay.act_b + tid] = wsum(3, tid);
-    if (net == 1 && tid == 0) slab[lay.val_b] = wsum(3, 0);
+    if (net == 0 && tid < 8) rslab[RS_HB + tid] = wsum(3, tid);
+    if (net == 1 && tid == 0) rslab[RS_HB] = wsum(3, 0);
     if (tid < NSTATP) a.statpart[((size_t)net * gridDim.x + blockIdx.x) * NSTATP + tid] = wsum(4, tid);
   }
   PH_STAMP(a.prof, 13);
@@ -529,7 +529,10 @@ bool grad_fast_eligible(const NetDims& nd) {
 template <bool VALU>
 static hipError_t launch_fast_variant(const GradArgs& a, int nwg, hipStream_t s) {
   const size_t lds = grad_fast_lds_bytes();
-  static bool allowed = false;  // > 64 KiB of dynamic LDS is opt-in, once per kernel (kept out of graph capture)
+  static bool allowed_dev[64] = {false};  // > 64 KiB of dynamic LDS is opt-in per kernel and device (kept out of graph capture)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  bool& allowed = allowed_dev[(dev >= 0 && dev < 64) ? dev : 0];
   if (!allowed) {
     hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_fast_kernel<VALU>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -538,6 +541,36 @@ static hipError_t launch_fast_variant(const GradArgs& a, int nwg, hipStream_t s)
   }
   hipLaunchKernelGGL((ppo_grad_fast_kernel<VALU>), dim3(nwg, 2), dim3(256), lds, s, a);
   return hipGetLastError();
+}
+
+// slab position -> parameter index (-1 = padding) for both nets of one workgroup's register-order slab: [net][RS_NET]
+void grad_slab_map(const ph_layout& lay, int* map) {
+  const int F = lay.F, L = lay.L;
+  for (int net = 0; net < 2; ++net) {
+    int* m = map + net * RS_NET;
+    for (int i = 0; i < RS_NET; ++i) m[i] = -1;
+    const int oW1 = net == 0 ? lay.pi_W1 : lay.vf_W1, oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1;
+    const int oW2 = net == 0 ? lay.pi_W2 : lay.vf_W2, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
+    for (int s = 0; s < HID * HID; ++s) {   // position = ((wave * 4 + r4) * 64 + lane) * 4 + j holds accumulator r = 4 * r4 + j
+      const int wave = s >> 10, r4 = (s >> 8) & 3, lane = (s >> 2) & 63, j = s & 3;
+      const int r = 4 * r4 + j, mt = wave >> 1, nt = wave & 1;
+      const int k = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = nt * 32 + (lane & 31);
+      m[RS_W2 + s] = oW2 + k * HID + col;
+      if (k < F) m[RS_W1 + s] = oW1 + k * HID + col;
+    }
+    for (int i = 0; i < HID; ++i) {
+      m[RS_B1 + i] = oB1 + i;
+      m[RS_B2 + i] = oB2 + i;
+    }
+    if (net == 0) {
+      for (int j = 0; j < HID; ++j)
+        for (int k = 0; k < L && k < 8; ++k) m[RS_HW + j * 8 + k] = lay.act_W + j * L + k;
+      for (int k = 0; k < L && k < 8; ++k) m[RS_HB + k] = lay.act_b + k;
+    } else {
+      for (int j = 0; j < HID; ++j) m[RS_HW + j] = lay.val_W + j;
+      m[RS_HB] = lay.val_b;
+    }
+  }
 }
 
 hipError_t launch_ppo_grad_fast(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s) {

@@ -1,5 +1,5 @@
 """ph_bench_ppo_grad timing at the bench size (overcooked): prints us per launch.  Same-box A/B of kernel variants:
-PANTHEON_HIP_LIB=<other build> or PH_GRAD_RP / PH_GRAD_W8 / PH_GRAD_FAST switches."""
+PANTHEON_HIP_LIB=<other build> (scripts/build_variants.sh) or the PH_GRAD_FAST switch."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch as th
@@ -19,4 +19,4 @@ hp = model.hyper(); ms = C.c_float(0); rb.pos = T
 for rep in range(3):
     nat.check(pol.ctx.lib.ph_bench_ppo_grad(pol.ctx.handle, C.byref(pol.spec), pol.params.data_ptr(), C.byref(rb.c_struct()),
                                             C.byref(hp), int(model.batch_size), 200, 0, C.byref(ms)))
-print(os.environ.get("PANTHEON_HIP_LIB", "default").split("/")[-1], os.environ.get("PH_GRAD_RP", ""), "us/launch %.2f" % (ms.value * 1e3))
+print(os.environ.get("PANTHEON_HIP_LIB", "default").split("/")[-1], "us/launch %.2f" % (ms.value * 1e3))

@@ -75,14 +75,7 @@ nat.check(lib.ph_bench_ppo_grad(h, C.byref(pol.spec), pol.params.data_ptr(), C.b
 th.cuda.synchronize()
 nwg = min((model.batch_size + 63) // 64, 256)
 print(f"ppo_grad launch {ms.value * 1e3:.1f} us, {nwg} workgroups per net")
-if os.environ.get("PH_GRAD_W8", "0") == "1":
-    report("ppo_grad_w8", nwg, 2, ["prologue + T0", "S1 mma+tanh", "S2 mma+tanh", "SH head", "S6a side + dW2", "S6a dH1",
-                                   "S6b", "S7 dW1", "remaining tiles", "epilogue"], slots=[0, 1, 2, 3, 4, 5, 6, 7, 8, 12, 13])
-elif os.environ.get("PH_GRAD_RP", "0") == "1":
-    report("ppo_grad_rp", min((model.batch_size + 127) // 128, 128), 2,
-           ["prologue + T0", "P1 S1 mma+tanh", "P1 S2 mma+tanh", "P1 head + B1", "P2 dW2 (all rows)", "P2 dH1, dZ1, B2, B3",
-            "P3 dW1 + B4", "remaining steps", "epilogue"], slots=[0, 1, 2, 3, 4, 5, 6, 7, 12, 13])
-elif os.environ.get("PH_GRAD_FAST", "1") != "0" and not LIAR:
+if os.environ.get("PH_GRAD_FAST", "1") != "0" and not LIAR:
     report("ppo_grad_fast", nwg, 2, ["prologue + T0 (rows, X, W1, W2)", "S1 mma+tanh", "S2 mma+tanh", "SH head (VALU)",
                                      "S6a fetch_rows", "S6a W1 issue", "S6a side work", "S6a dW2 mma", "S6a dH1 mma", "S6b dZ1, X, W1", "S7 dW1", "remaining tiles",
                                      "epilogue"], slots=[0, 1, 2, 3, 4, 8, 9, 10, 11, 5, 6, 7, 12, 13])

@@ -46,3 +46,30 @@ def test_bench_two_ranks_agent_per_rank_path():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["launch_mode"] == "fusedstep"
     assert "all-gather" in d["config"]["parallelism"]
+    assert d["ranks_seen"] == 2
+
+
+@pytest.mark.parametrize("agents_per_gpu", [2, 1])
+def test_bench_gpus_flag_spawns_its_own_ranks(agents_per_gpu):
+    """`python bench.py --gpus 2` with no launcher around it must run two ranks (round 1 silently ran one): here both share
+    the one GPU of the test box over gloo; with --agents-per-gpu 1 every step's partner lives on the other rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo",
+                        "--no-roofline", "--agents-per-gpu", str(agents_per_gpu)], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["value"] > 0
+    assert d["config"]["agents_per_gpu"] == agents_per_gpu
+    assert f"= {2 * agents_per_gpu} learners" in d["config"]["parallelism"]
+    assert d["iteration_ms"]["min"] <= d["iteration_ms"]["median"] <= d["iteration_ms"]["max"]
+
+
+def test_bench_refuses_more_gpus_than_visible_and_a_mismatched_world():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", *SMALL], capture_output=True,
+                       text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "visible" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *SMALL], capture_output=True,
+                       text=True, timeout=300, cwd=ROOT, env={**env, "WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "disagrees" in r.stderr

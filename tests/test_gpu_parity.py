@@ -1041,14 +1041,14 @@ def test_trainer_n_envs_runs_device_selfplay(game, tmp_path):
     assert np.array_equal(again.policy.get_flat_params(), ego.policy.get_flat_params())
 
 
-def test_opt_in_kernel_variants_pass_the_gradient_and_forward_parity_tests():
-    """PH_GRAD_RP=1 / PH_GRAD_W8=1 (row-parallel and eight-wave gradient kernels), PH_GRAD_FAST=0 / PH_FWD16=0 / PH_FWD16H=0 (general kernels on the small and the one-hot shapes): the
-    variant switches are read once per process, so each combination runs the parity tests in its own interpreter."""
+def test_general_kernels_pass_the_gradient_and_forward_parity_tests_on_the_small_shapes():
+    """PH_GRAD_FAST=0 / PH_FWD16=0 / PH_FWD16H=0 route the small and the one-hot shapes through the general kernels (the ones
+    the wide shapes always use): the switches are read once per process, so the parity tests run in their own interpreter."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for env in ({"PH_GRAD_RP": "1"}, {"PH_GRAD_W8": "1"}, {"PH_GRAD_FAST": "0", "PH_FWD16": "0", "PH_FWD16H": "0"}):
+    for env in ({"PH_GRAD_FAST": "0", "PH_FWD16": "0", "PH_FWD16H": "0"},):
         out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu", "-k",
                               "minibatch_gradient or forward_matches_oracle or mfma_and_valu or train_matches_oracle"],
                              cwd=root, env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
