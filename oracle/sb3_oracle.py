@@ -416,3 +416,42 @@ def synthetic_iteration(policy: MlpPolicyOracle, buf: RolloutBufferOracle, hp: P
         last_starts = done_seq[t].astype(np.float32)    # agents.py:197
     buf.compute_returns_and_advantage(values, last_starts)  # quirk D-1: V(o_{T-1})
     ppo_train(policy, buf, hp)
+
+
+# --------------------------------------------------------------------------------------
+# the ego's rollout loop: OnPolicyAlgorithm.collect_rollouts of SB3 1.7.0
+# --------------------------------------------------------------------------------------
+def collect_rollouts(policy: MlpPolicyOracle, buf: RolloutBufferOracle, env, last_obs: np.ndarray,
+                     last_episode_starts: np.ndarray, gamma: float = 0.99, forced_actions=None):
+    """SB3 1.7.0 ``collect_rollouts`` for the ego (reference call site trainer.py:413 -> ``ego.learn``; in-tree witness of
+    the loop's shape: adap_learn.py:400-473, an older SB3 copy).  ``env`` is a VecEnv-like object:
+    ``step(actions) -> (obs, rewards, dones, infos)`` with auto-reset and ``infos[i]["terminal_observation"]``.
+
+    The part the in-tree copy predates [SB3-mem, v1.5+]: when an episode ends by TIME LIMIT
+    (``infos[i].get("TimeLimit.truncated", False)``) the transition's reward is bootstrapped with the value of the terminal
+    observation, ``rewards[i] += gamma * V(terminal_observation)``, before the row is added.
+    ``forced_actions[t]`` (E, A) teacher-forces the sampled actions.  Returns (new_obs, dones)."""
+    T, E = buf.T, buf.E
+    buf.reset()
+    new_obs, dones = last_obs, np.zeros(E, bool)
+    for t in range(T):
+        with th.no_grad():
+            actions, values, logp = policy.forward(th.as_tensor(np.asarray(last_obs, np.float32)))
+            if forced_actions is not None:
+                actions = th.as_tensor(np.asarray(forced_actions[t])).reshape(actions.shape)
+                values, logp, _ = policy.evaluate_actions(th.as_tensor(np.asarray(last_obs, np.float32)), actions)
+        act_np = actions.numpy()
+        new_obs, rewards, dones, infos = env.step(act_np)
+        rewards = np.asarray(rewards, np.float32).copy()
+        for i, done in enumerate(dones):
+            if done and infos[i].get("terminal_observation") is not None and infos[i].get("TimeLimit.truncated", False):
+                with th.no_grad():
+                    term = th.as_tensor(np.asarray(infos[i]["terminal_observation"], np.float32)).reshape(1, -1)
+                    terminal_value = policy.predict_values(term)[0]
+                rewards[i] += (gamma * terminal_value).numpy().reshape(())
+        buf.add(np.asarray(last_obs, np.float32), act_np.reshape(E, -1), rewards, last_episode_starts, values, logp)
+        last_obs, last_episode_starts = new_obs, np.asarray(dones, np.float32)
+    with th.no_grad():
+        values = policy.predict_values(th.as_tensor(np.asarray(new_obs, np.float32)))
+    buf.compute_returns_and_advantage(values, np.asarray(dones, np.float32))
+    return new_obs, dones

@@ -20,6 +20,7 @@ import torch as th
 
 from ..logger import configure_logger, safe_mean
 from .observation import Observation
+from .trajsaver import TransitionsMinimal
 from .util import action_from_policy, clip_actions, resample_noise
 
 
@@ -145,3 +146,40 @@ class OnPolicyAgent(Agent):
             eps.append(running)
         lg.record("time/total_timesteps", self.num_timesteps, exclude="tensorboard")
         lg.dump(step=self.num_timesteps)
+
+
+class OffPolicyAgent(Agent):
+    """The reference also wraps SB3's off-policy learners (agents.py:211-362).  They are outside the on-policy PPO path this
+    engine implements (out of scope), so the name exists only to fail with a clear message."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("OffPolicyAgent (SB3 off-policy algorithms) is not part of the MI355X on-policy PPO "
+                                  "engine; use OnPolicyAgent(pantheonrl_amd.PPO(...))")
+
+    def get_action(self, obs: Observation, record: bool = True) -> np.ndarray:   # pragma: no cover
+        raise NotImplementedError
+
+    def update(self, reward: float, done: bool) -> None:                         # pragma: no cover
+        raise NotImplementedError
+
+
+class RecordingAgentWrapper(Agent):
+    """An agent that behaves like `realagent` and keeps every (observation, action) pair it produced -- the data source of
+    behaviour cloning (agents.py:365-413).  `get_transitions()` hands them over as a `TransitionsMinimal`."""
+
+    def __init__(self, realagent: Agent):
+        self.realagent = realagent
+        self.allobs: list = []
+        self.allacts: list = []
+
+    def get_action(self, obs: Observation, record: bool = True) -> np.ndarray:
+        action = self.realagent.get_action(obs, record)
+        self.allobs.append(obs.obs)
+        self.allacts.append(action)
+        return action
+
+    def update(self, reward: float, done: bool) -> None:
+        self.realagent.update(reward, done)
+
+    def get_transitions(self) -> TransitionsMinimal:
+        return TransitionsMinimal(np.array(self.allobs), np.array(self.allacts))

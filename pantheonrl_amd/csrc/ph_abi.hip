@@ -77,6 +77,23 @@ struct ph_ctx {
 
 namespace {
 
+// Every entry point that takes a context runs with the context's device current and restores the caller's device on
+// return: a process that holds models on several GPUs (or whose torch current device differs) would otherwise allocate
+// workspaces and launch on whichever device happened to be current (ph_ctx_create used to leave its device selected).
+struct DevGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DevGuard(const ph_ctx* ctx) {
+    if (!ctx) return;
+    if (hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+  }
+  ~DevGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DevGuard(const DevGuard&) = delete;
+  DevGuard& operator=(const DevGuard&) = delete;
+};
+
 template <typename T>
 int ensure(T*& p, size_t& cap, size_t n) {
   if (n <= cap) return 0;
@@ -217,7 +234,9 @@ int ph_ctx_create(int device, ph_ctx** out) {
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) return fail("no HIP device visible: the PantheonRL MI355X engine has no CPU fallback");
   if (device < 0 || device >= n) return fail("device index out of range");
-  PH_HIP(hipSetDevice(device));
+  ph_ctx probe;                    // the caller's current device is restored on every return path
+  probe.device = device;
+  DevGuard dev_guard(&probe);
   hipDeviceProp_t prop;
   PH_HIP(hipGetDeviceProperties(&prop, device));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -239,8 +258,8 @@ int ph_ctx_create(int device, ph_ctx** out) {
 }
 
 int ph_ctx_destroy(ph_ctx* ctx) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return 0;
-  (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto g : ctx->graphs)
     if (g) (void)hipGraphExecDestroy(g);
@@ -261,18 +280,21 @@ int ph_ctx_destroy(ph_ctx* ctx) {
 }
 
 int ph_ctx_set_stream(ph_ctx* ctx, void* hip_stream) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   ctx->stream = (hipStream_t)hip_stream;
   return 0;
 }
 
 int ph_ctx_sync(ph_ctx* ctx) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   PH_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 
 int ph_graph_begin(ph_ctx* ctx) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (ctx->capturing) return fail("already capturing");
   if (ctx->stream == nullptr) return fail("graph capture needs a non-default stream (ph_ctx_set_stream)");
@@ -282,6 +304,7 @@ int ph_graph_begin(ph_ctx* ctx) {
 }
 
 int ph_graph_end(ph_ctx* ctx, int* graph_id_out) {
+  DevGuard dev_guard(ctx);
   if (!ctx || !graph_id_out) return fail("null ctx/graph_id_out");
   if (!ctx->capturing) return fail("not capturing");
   ctx->capturing = false;
@@ -297,6 +320,7 @@ int ph_graph_end(ph_ctx* ctx, int* graph_id_out) {
 }
 
 int ph_graph_launch(ph_ctx* ctx, int graph_id) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (graph_id < 0 || graph_id >= (int)ctx->graphs.size()) return fail("bad graph id");
   PH_HIP(hipGraphLaunch(ctx->graphs[graph_id], ctx->stream));
@@ -304,11 +328,13 @@ int ph_graph_launch(ph_ctx* ctx, int graph_id) {
 }
 
 int ph_ctx_set_rng_epoch(ph_ctx* ctx, unsigned long long* epoch_dev) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   ctx->rng_epoch = epoch_dev;
   return 0;
 }
 int ph_rng_epoch_advance(ph_ctx* ctx) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (!ctx->rng_epoch) return fail("ph_rng_epoch_advance: no epoch word attached");
   PH_HIP(ph::launch_epoch_advance(ctx->rng_epoch, ctx->stream));
@@ -316,17 +342,20 @@ int ph_rng_epoch_advance(ph_ctx* ctx) {
 }
 
 int ph_debug_set_profile_buffer(ph_ctx* ctx, long long* stamps_dev) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   ctx->prof = stamps_dev;
   return 0;
 }
 
 int ph_timer_start(ph_ctx* ctx) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   PH_HIP(hipEventRecord(ctx->ev0, ctx->stream));
   return 0;
 }
 int ph_timer_stop(ph_ctx* ctx, float* ms_out) {
+  DevGuard dev_guard(ctx);
   if (!ctx || !ms_out) return fail("null ctx/ms_out");
   PH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
   PH_HIP(hipEventSynchronize(ctx->ev1));
@@ -339,6 +368,7 @@ int ph_layout_of(const ph_spec* spec, ph_layout* out) { return layout_of(spec, o
 // ---- K1 ----
 int ph_buffer_add(ph_ctx* ctx, const ph_spec* spec, const ph_rollout* rb, int pos, const float* obs,
                   const float* actions, const float* episode_start, const float* values, const float* log_probs) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   ph_layout lay;
   if (layout_of(spec, &lay) || check_rb(rb)) return 1;
@@ -353,6 +383,7 @@ int ph_buffer_add(ph_ctx* ctx, const ph_spec* spec, const ph_rollout* rb, int po
 
 int ph_buffer_add_reward(ph_ctx* ctx, const ph_rollout* rb, int pos, const float* reward,
                          const unsigned char* env_mask) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (check_rb(rb)) return 1;
   if (pos < 0 || pos >= rb->T) return fail("ph_buffer_add_reward: pos out of range");
@@ -363,6 +394,7 @@ int ph_buffer_add_reward(ph_ctx* ctx, const ph_rollout* rb, int pos, const float
 
 int ph_buffer_add_reward_joint(ph_ctx* ctx, const ph_rollout* rb, int pos, const float* base_reward,
                                const int* joint_actions, int n_seats, int seat, const int* partner_seat, float bonus) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (check_rb(rb)) return 1;
   if (pos < 0 || pos >= rb->T) return fail("ph_buffer_add_reward_joint: pos out of range");
@@ -374,6 +406,7 @@ int ph_buffer_add_reward_joint(ph_ctx* ctx, const ph_rollout* rb, int pos, const
 }
 
 int ph_buffer_reset(ph_ctx* ctx, const ph_spec* spec, const ph_rollout* rb) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   ph_layout lay;
   if (layout_of(spec, &lay) || check_rb(rb)) return 1;
@@ -388,6 +421,7 @@ int ph_buffer_reset(ph_ctx* ctx, const ph_spec* spec, const ph_rollout* rb) {
 // ---- K2 ----
 int ph_gae(ph_ctx* ctx, const ph_rollout* rb, const float* last_values, const float* dones, double gamma,
            double gae_lambda, int mode) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (check_rb(rb)) return 1;
   if (!last_values || !dones) return fail("ph_gae: null last_values/dones");
@@ -404,6 +438,7 @@ int ph_policy_forward(ph_ctx* ctx, const ph_spec* spec, const float* params, con
                       float* actions_f32, float* values, float* log_probs, float* entropy, float* logits,
                       const ph_rollout* rb, int pos, const float* episode_start_in, const float* pending_reward,
                       int gemm_mode) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (!params || !obs) return fail("ph_policy_forward: null params/obs");
   if ((uintptr_t)params % 16 != 0) return fail("ph_policy_forward: params must be 16-byte aligned");
@@ -457,6 +492,7 @@ namespace {
 int step_multi_impl(ph_ctx* ctx, int n_calls, const ph_step_call* calls, const ph_p2p* x, int t);
 }
 int ph_policy_step_multi(ph_ctx* ctx, int n_calls, const ph_step_call* calls) {
+  DevGuard dev_guard(ctx);
   return step_multi_impl(ctx, n_calls, calls, nullptr, 0);
 }
 namespace {
@@ -590,12 +626,12 @@ int ph_comm_unique_id(unsigned char* id_out) {
 }
 
 int ph_comm_init(ph_ctx* ctx, const unsigned char* id, int world, int rank) {
+  DevGuard dev_guard(ctx);
   if (!ctx || !id) return fail("ph_comm_init: null argument");
   if (world < 1 || rank < 0 || rank >= world) return fail("ph_comm_init: bad world / rank");
   if (ctx->comm) return fail("ph_comm_init: this context already has a communicator");
   RcclApi* r = rccl_api();
   if (!r) return fail("ph_comm_init: librccl.so could not be loaded");
-  PH_HIP(hipSetDevice(ctx->device));
   ncclUniqueId uid;
   std::memcpy(uid.internal, id, PH_COMM_ID_BYTES);
   void* comm = nullptr;
@@ -608,6 +644,7 @@ int ph_comm_init(ph_ctx* ctx, const unsigned char* id, int world, int rank) {
 }
 
 int ph_comm_destroy(ph_ctx* ctx) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (ctx->comm) {
     RcclApi* r = rccl_api();
@@ -620,6 +657,7 @@ int ph_comm_destroy(ph_ctx* ctx) {
 }
 
 int ph_all_gather_i32(ph_ctx* ctx, const int* local, int* joint, int count) {
+  DevGuard dev_guard(ctx);
   if (!ctx || !local || !joint || count <= 0) return fail("ph_all_gather_i32: bad argument");
   if (!ctx->comm) {  // single process: the joint action is the local one
     PH_HIP(hipMemcpyAsync(joint, local, (size_t)count * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
@@ -633,6 +671,7 @@ int ph_all_gather_i32(ph_ctx* ctx, const int* local, int* joint, int count) {
 
 int ph_selfplay_rollout(ph_ctx* ctx, int n_calls, const ph_step_call* calls, int T, const int* local, int* joint,
                         int count) {
+  DevGuard dev_guard(ctx);
   if (!ctx || !calls || T <= 0) return fail("ph_selfplay_rollout: bad argument");
   for (int t = 0; t < T; ++t) {
     if (ph_policy_step_multi(ctx, n_calls, calls + (size_t)t * n_calls)) return 1;
@@ -643,8 +682,8 @@ int ph_selfplay_rollout(ph_ctx* ctx, int n_calls, const ph_step_call* calls, int
 
 // ---- peer-to-peer exchange buffers ---------------------------------------------------------------------------------------
 int ph_p2p_alloc(ph_ctx* ctx, size_t bytes, void** ptr_out, unsigned char* handle_out) {
+  DevGuard dev_guard(ctx);
   if (!ctx || !ptr_out || !handle_out || bytes == 0) return fail("ph_p2p_alloc: bad argument");
-  PH_HIP(hipSetDevice(ctx->device));
   void* p = nullptr;
   PH_HIP(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
   hipError_t e = hipMemset(p, 0, bytes);
@@ -661,8 +700,8 @@ int ph_p2p_alloc(ph_ctx* ctx, size_t bytes, void** ptr_out, unsigned char* handl
   return 0;
 }
 int ph_p2p_open(ph_ctx* ctx, const unsigned char* handle, void** ptr_out) {
+  DevGuard dev_guard(ctx);
   if (!ctx || !handle || !ptr_out) return fail("ph_p2p_open: bad argument");
-  PH_HIP(hipSetDevice(ctx->device));
   hipIpcMemHandle_t hd;
   std::memcpy(&hd, handle, PH_IPC_HANDLE_BYTES);
   void* p = nullptr;
@@ -671,11 +710,13 @@ int ph_p2p_open(ph_ctx* ctx, const unsigned char* handle, void** ptr_out) {
   return 0;
 }
 int ph_p2p_close(ph_ctx* ctx, void* ptr) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (ptr) PH_HIP(hipIpcCloseMemHandle(ptr));
   return 0;
 }
 int ph_p2p_free(ph_ctx* ctx, void* ptr) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (ptr) PH_HIP(hipFree(ptr));
   return 0;
@@ -693,24 +734,28 @@ int check_p2p(const ph_p2p* x) {
 }
 }  // namespace
 int ph_p2p_push(ph_ctx* ctx, const ph_p2p* x, const int* local, int t) {
+  DevGuard dev_guard(ctx);
   if (!ctx || !local) return fail("ph_p2p_push: null argument");
   if (check_p2p(x)) return 1;
   PH_HIP(ph::launch_p2p_push(*x, local, t, ctx->stream));
   return 0;
 }
 int ph_p2p_wait(ph_ctx* ctx, const ph_p2p* x, int t) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (check_p2p(x)) return 1;
   PH_HIP(ph::launch_p2p_wait(*x, t, ctx->stream));
   return 0;
 }
 int ph_p2p_ll_push(ph_ctx* ctx, const ph_p2p* x, const int* local, int t) {
+  DevGuard dev_guard(ctx);
   if (!ctx || !local) return fail("ph_p2p_ll_push: null argument");
   if (check_p2p(x)) return 1;
   PH_HIP(ph::launch_p2p_ll_push(*x, local, t, ctx->stream));
   return 0;
 }
 int ph_p2p_ll_unpack(ph_ctx* ctx, const ph_p2p* x, int t) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (check_p2p(x)) return 1;
   PH_HIP(ph::launch_p2p_ll_unpack(*x, t, ctx->stream));
@@ -718,6 +763,7 @@ int ph_p2p_ll_unpack(ph_ctx* ctx, const ph_p2p* x, int t) {
 }
 int ph_selfplay_rollout_p2p(ph_ctx* ctx, int n_calls, const ph_step_call* calls, int T, const int* local,
                             const ph_p2p* x) {
+  DevGuard dev_guard(ctx);
   if (!ctx || !calls || !local || T <= 0) return fail("ph_selfplay_rollout_p2p: bad argument");
   if (check_p2p(x)) return 1;
   bool fused = x->count == n_calls * calls[0].n && getenv("PH_P2P_UNFUSED") == nullptr;
@@ -745,6 +791,7 @@ int ph_policy_forward_ragged(ph_ctx* ctx, const ph_spec* spec, const float* para
                              const unsigned char* action_mask, unsigned long long seed, unsigned long long counter,
                              int deterministic, int* actions_i32, float* values, float* log_probs, const ph_rollout* rb,
                              const int* pos_env, const unsigned char* record_mask, const float* episode_start_in) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (!params || !obs || !pos_env || !record_mask || !episode_start_in)
     return fail("ph_policy_forward_ragged: null argument");
@@ -781,6 +828,7 @@ int ph_policy_forward_ragged(ph_ctx* ctx, const ph_spec* spec, const float* para
 
 int ph_buffer_add_reward_ragged(ph_ctx* ctx, const ph_rollout* rb, const int* pos_env, const float* reward,
                                 const unsigned char* env_mask) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (check_rb(rb)) return 1;
   if (!pos_env || !reward) return fail("ph_buffer_add_reward_ragged: null argument");
@@ -789,6 +837,7 @@ int ph_buffer_add_reward_ragged(ph_ctx* ctx, const ph_rollout* rb, const int* po
 }
 
 int ph_ragged_advance(ph_ctx* ctx, const ph_rollout* rb, int* pos_env, const unsigned char* record_mask) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (check_rb(rb)) return 1;
   if (!pos_env || !record_mask) return fail("ph_ragged_advance: null argument");
@@ -797,6 +846,7 @@ int ph_ragged_advance(ph_ctx* ctx, const ph_rollout* rb, int* pos_env, const uns
 }
 
 int ph_fix_illegal_actions(ph_ctx* ctx, int* actions, const unsigned char* action_mask, int n, int L) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (!actions || !action_mask) return fail("ph_fix_illegal_actions: null argument");
   if (n <= 0 || L <= 0) return fail("ph_fix_illegal_actions: bad sizes");
@@ -806,6 +856,7 @@ int ph_fix_illegal_actions(ph_ctx* ctx, int* actions, const unsigned char* actio
 
 // ---- vectorised game rules ----
 int ph_rps_step(ph_ctx* ctx, const int* ego_actions, const int* alt_actions, float* ego_reward, float* alt_reward, int n) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (!ego_actions || !alt_actions || !ego_reward || !alt_reward) return fail("ph_rps_step: null argument");
   if (n <= 0) return fail("ph_rps_step: n must be positive");
@@ -816,6 +867,7 @@ int ph_rps_step(ph_ctx* ctx, const int* ego_actions, const int* alt_actions, flo
 int ph_liar_step(ph_ctx* ctx, const int* hands, int* history, int* nmoves, const int* actions,
                  const unsigned char* is_ego, const unsigned char* active, float* obs_next, float* rewards,
                  unsigned char* done, int n) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (!hands || !history || !nmoves || !actions || !is_ego || !obs_next || !rewards || !done)
     return fail("ph_liar_step: null argument");
@@ -829,6 +881,7 @@ int ph_liar_step(ph_ctx* ctx, const int* hands, int* history, int* nmoves, const
 int ph_liar_reset(ph_ctx* ctx, int* hands, int* history, int* nmoves, const unsigned char* reset_mask,
                   unsigned char* ego_first, unsigned long long seed, unsigned long long counter, float probegostart,
                   int n) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (!hands || !history || !nmoves || !ego_first) return fail("ph_liar_reset: null argument");
   if (n <= 0) return fail("ph_liar_reset: n must be positive");
@@ -840,6 +893,7 @@ int ph_liar_reset(ph_ctx* ctx, int* hands, int* history, int* nmoves, const unsi
 
 int ph_liar_obs(ph_ctx* ctx, const int* hands, const int* history, const int* nmoves, const unsigned char* is_ego,
                 const unsigned char* active, float* obs_out, int n) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (!hands || !history || !nmoves || !is_ego || !obs_out) return fail("ph_liar_obs: null argument");
   if (n <= 0) return fail("ph_liar_obs: n must be positive");
@@ -850,6 +904,7 @@ int ph_liar_obs(ph_ctx* ctx, const int* hands, const int* history, const int* nm
 }
 
 int ph_liar_selfplay_step(ph_ctx* ctx, const ph_liar_selfplay* sp, int ego_pos, unsigned long long counter, int deal_only) {
+  DevGuard dev_guard(ctx);
   if (!ctx || !sp) return fail("ph_liar_selfplay_step: null argument");
   const ph_liar_selfplay& s = *sp;
   if (s.n <= 0 || !s.spec || !s.ego_rb || !s.alt_rb) return fail("ph_liar_selfplay_step: incomplete description");
@@ -886,6 +941,7 @@ int ph_liar_selfplay_step(ph_ctx* ctx, const ph_liar_selfplay* sp, int ego_pos, 
 
 int ph_framestack_push(ph_ctx* ctx, float* stack, const float* obs, const unsigned char* reset_mask,
                        const float* default_obs, int n, int D, int numframes) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (!stack || !obs) return fail("ph_framestack_push: null argument");
   if (n <= 0 || D <= 0 || numframes <= 0) return fail("ph_framestack_push: bad sizes");
@@ -1090,6 +1146,7 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
 int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const ph_rollout* rb,
                  const ph_ppo_hyper* hp, int n_epochs, int batch_size, const int* perms,
                  unsigned long long perm_seed, float* stats, int gemm_mode) {
+  DevGuard dev_guard(ctx);
   TrainPlan t;
   if (train_prepare(t, ctx, spec, opt, rb, hp, n_epochs, batch_size, perms, perm_seed, stats, gemm_mode)) return 1;
   for (int mbi = 0; mbi < n_epochs * t.n_mb; ++mbi) {
@@ -1138,6 +1195,7 @@ int ph_ppo_train_multi(const ph_train_call* calls, int n_calls) {
 int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, const ph_rollout* rb,
                           const ph_ppo_hyper* hp, const int* indices, int nb, float* grad_out, float* stats_out,
                           int gemm_mode) {
+  DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   if (!params || !hp || !indices || !grad_out) return fail("ph_ppo_minibatch_grad: null argument");
   if ((uintptr_t)params % 16 != 0) return fail("ph_ppo_minibatch_grad: params must be 16-byte aligned");
@@ -1198,6 +1256,7 @@ int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params,
 
 int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, const ph_rollout* rb,
                       const ph_ppo_hyper* hp, int batch_size, int reps, int gemm_mode, float* avg_ms_out) {
+  DevGuard dev_guard(ctx);
   if (!ctx || !params || !hp || !avg_ms_out) return fail("ph_bench_ppo_grad: null argument");
   if (check_rb(rb)) return 1;
   if (batch_size <= 0 || reps <= 0) return fail("ph_bench_ppo_grad: bad sizes");
@@ -1248,6 +1307,7 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
 
 int ph_bench_gae(ph_ctx* ctx, const ph_rollout* rb, const float* last_values, const float* dones, double gamma,
                  double gae_lambda, int mode, int reps, float* avg_ms_out) {
+  DevGuard dev_guard(ctx);
   if (!ctx || !last_values || !dones || !avg_ms_out) return fail("ph_bench_gae: null argument");
   if (check_rb(rb)) return 1;
   if (reps <= 0 || mode < 0 || mode > 2) return fail("ph_bench_gae: bad arguments");

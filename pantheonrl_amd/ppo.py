@@ -146,7 +146,7 @@ class ActorCriticPolicy:
     as one flat input-major vector (layout in include/pantheon_hip.h)."""
 
     def __init__(self, observation_space, action_space, lr: float = 3e-4, device="cuda",
-                 ortho_init: bool = True, seed: Optional[int] = None):
+                 ortho_init: bool = True, seed: Optional[int] = None, sampling_stream: int = 0):
         self.device = _require_cuda(device)
         self.observation_space, self.action_space = observation_space, action_space
         self.spec = sp.make_spec(observation_space, action_space)
@@ -160,6 +160,15 @@ class ActorCriticPolicy:
         self.opt_step = th.zeros(1, dtype=th.int32, device=self.device)
         self.lr = float(lr)
         self._seed = int(seed) if seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
+        if sampling_stream:
+            # Philox key of this model's action sampling.  The reference draws every agent's actions from ONE global torch
+            # stream, so two agents built with the same --seed still sample independently; here each model owns a counter-based
+            # stream, and two models keyed by the bare seed would draw identical uniforms step after step (an RPS PPO-vs-PPO
+            # run would start with nothing but ties).  Stream k of seed s gets the key splitmix64(s, k).
+            z = (self._seed * 0x9E3779B97F4A7C15 + int(sampling_stream) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+            self._seed = int((z ^ (z >> 31)) & 0x7FFFFFFFFFFFFFFF)
         self._counter = 0
         self._init_weights(ortho_init)
 
@@ -326,7 +335,7 @@ class PPO:
                  ent_coef: float = 0.0, vf_coef: float = 0.5, max_grad_norm: float = 0.5,
                  target_kl: Optional[float] = None, tensorboard_log: Optional[str] = None, verbose: int = 0,
                  seed: Optional[int] = None, device="cuda", n_envs: Optional[int] = None, use_sde: bool = False,
-                 sde_sample_freq: int = -1, _init_setup_model: bool = True):
+                 sde_sample_freq: int = -1, _init_setup_model: bool = True, sampling_stream: int = 0):
         if policy not in ("MlpPolicy", ActorCriticPolicy):
             raise ValueError("the MI355X engine implements SB3's MlpPolicy")
         if use_sde:
@@ -338,6 +347,7 @@ class PPO:
         self.max_grad_norm, self.target_kl = max_grad_norm, target_kl
         self.tensorboard_log, self.verbose, self.seed = tensorboard_log, verbose, seed
         self.use_sde, self.sde_sample_freq = False, sde_sample_freq
+        self.sampling_stream = int(sampling_stream)
         self.num_timesteps, self._n_updates, self._custom_logger = 0, 0, False
         self.ep_info_buffer: deque = deque(maxlen=100)
         self._logger: Optional[Logger] = None
@@ -375,7 +385,7 @@ class PPO:
 
     def _setup_model(self) -> None:
         self.policy = ActorCriticPolicy(self.observation_space, self.action_space, lr=self.learning_rate,
-                                        device=self.device, seed=self.seed)
+                                        device=self.device, seed=self.seed, sampling_stream=self.sampling_stream)
         self.rollout_buffer = RolloutBuffer(self.n_steps, self.observation_space, self.action_space, self.device,
                                             self.policy.ctx, self.policy.spec, gae_lambda=self.gae_lambda,
                                             gamma=self.gamma, n_envs=self.n_envs)
@@ -435,8 +445,15 @@ class PPO:
             st = stats.cpu().numpy()
             self.last_train_stats = st
             applied = st[:, 7] > 0
-            used = st[applied] if applied.any() else st[:1]
+            # SB3 appends a minibatch's losses BEFORE the KL check (adap_learn.py:282-327), so the minibatch that triggers the
+            # early stop is in the logged means although its optimizer step is skipped; later minibatches never run
+            n_used = int(applied.sum()) + (1 if not applied.all() else 0)
+            used = st[:max(n_used, 1)]
             lg = self.logger
+            ret = rb.returns.flatten()
+            var_y = float(ret.var(unbiased=False))     # explained_variance(values, returns), adap_learn.py:350-352
+            ev = float("nan") if var_y == 0 else 1.0 - float((ret - rb.values.flatten()).var(unbiased=False)) / var_y
+            lg.record("train/explained_variance", ev)
             lg.record("train/entropy_loss", float(used[:, 2].mean()))
             lg.record("train/policy_gradient_loss", float(used[:, 0].mean()))
             lg.record("train/value_loss", float(used[:, 1].mean()))
@@ -481,21 +498,31 @@ class PPO:
             m._n_updates += m.n_epochs
 
     # -- OnPolicyAlgorithm.learn() for the ego (trainer.py:413) -----------------------------------------
-    def collect_rollouts(self) -> bool:
+    def collect_rollouts(self, forced_uniforms=None) -> bool:
+        """SB3 1.7.0 OnPolicyAlgorithm.collect_rollouts for the ego (trainer.py:413).  `forced_uniforms[t]` (E, A) teacher-forces
+        the sampling uniforms of step t (tests)."""
         env, rb, pol = self.env, self.rollout_buffer, self.policy
         rb.reset()
         dones = np.zeros(self.n_envs, dtype=bool)
         new_obs = self._last_obs
-        for _ in range(self.n_steps):
-            actions, _, _ = pol.forward_and_store(self._last_obs, rb, self._last_episode_starts)
+        for t in range(self.n_steps):
+            actions, _, _ = pol.forward_and_store(self._last_obs, rb, self._last_episode_starts,
+                                                  uniforms=None if forced_uniforms is None else forced_uniforms[t])
             act_np = actions.cpu().numpy()
             new_obs, rewards, dones, infos = env.step(act_np)
             self.num_timesteps += self.n_envs
-            for info in infos:
+            rewards = np.asarray(rewards, np.float32).copy()
+            for idx, info in enumerate(infos):
                 ep = info.get("episode") if isinstance(info, dict) else None
                 if ep is not None:
                     self.ep_info_buffer.append(ep)
-            rb.add_reward(np.asarray(rewards, np.float32))
+                # an episode cut by a time limit is not a terminal state: bootstrap the cut-off return with the value of
+                # the terminal observation [SB3 1.7.0: rewards[idx] += gamma * V(terminal_observation)], in float32
+                if (isinstance(info, dict) and dones[idx] and info.get("terminal_observation") is not None
+                        and info.get("TimeLimit.truncated", False)):
+                    v_term = pol.predict_values(np.asarray(info["terminal_observation"], np.float32).reshape(1, -1))
+                    rewards[idx] += np.float32(self.gamma) * np.float32(v_term.reshape(-1)[0].item())
+            rb.add_reward(rewards)
             self._last_obs = new_obs
             self._last_episode_starts = np.asarray(dones, np.float32)
         values = pol.predict_values(new_obs)  # ego bootstraps with V(o_T) (SURVEY.md D-1)
@@ -538,7 +565,8 @@ class PPO:
 
     # -- save / load (trainer.py:419-432, 140-157).  Own container; see DESIGN.md for the SB3 mapping. --------------
     _HP = ("learning_rate", "n_steps", "batch_size", "n_epochs", "gamma", "gae_lambda", "clip_range", "clip_range_vf",
-           "normalize_advantage", "ent_coef", "vf_coef", "max_grad_norm", "target_kl", "seed", "n_envs")
+           "normalize_advantage", "ent_coef", "vf_coef", "max_grad_norm", "target_kl", "seed", "n_envs", "tensorboard_log",
+           "verbose", "sampling_stream")
 
     @staticmethod
     def _space_to_json(space) -> Dict[str, Any]:
@@ -582,10 +610,20 @@ class PPO:
     def load(cls, path: str, env=None, device="cuda", **kwargs) -> "PPO":
         path = path if str(path).endswith(".zip") else str(path) + ".zip"
         with zipfile.ZipFile(path) as zf:
-            data = json.loads(zf.read("data"))
+            try:
+                data = json.loads(zf.read("data"))
+            except Exception as exc:  # noqa: BLE001
+                raise ValueError(f"{path}: unreadable 'data' entry ({exc})") from exc
+            if data.get("format") != "pantheonrl_amd-1":
+                # a stable-baselines3 zip keeps cloudpickled objects (schedules, gym spaces) under "data": they cannot be
+                # rebuilt without SB3 / gym.  Its policy.pth uses the same module names as ours -- convert with
+                # PPO(...).policy.load_state_dict(torch.load("policy.pth")) after constructing the model from its spaces.
+                raise ValueError(f"{path} is not a pantheonrl_amd checkpoint (format tag {data.get('format')!r}); "
+                                 "stable-baselines3 zips are not readable here -- see PPO.load's comment for the "
+                                 "state_dict route")
             sd = th.load(io.BytesIO(zf.read("policy.pth")), map_location="cpu")
             opt = th.load(io.BytesIO(zf.read("policy.optimizer.pth")), map_location="cpu")
-        hp = {k: data[k] for k in cls._HP}
+        hp = {k: data[k] for k in cls._HP if k in data}
         hp.update(kwargs)
         model = cls(env=None, device=device, **hp)
         model.observation_space = cls._space_from_json(data["observation_space"])

@@ -104,6 +104,9 @@ def gen_partner(kind: str, config: dict, altenv, ego, args, index: int):
     config.update(env=altenv, device=args.device, verbose=args.verbose_partner)
     if args.seed is not None:
         config["seed"] = args.seed
+    # same seed as the ego (same initial weights, as in the reference: set_random_seed(seed) runs before every model's
+    # init), but an action-sampling stream of its own -- see ActorCriticPolicy.__init__
+    config["sampling_stream"] = index + 1
     return OnPolicyAgent(PPO(policy="MlpPolicy", **config), **agentarg)
 
 
@@ -196,7 +199,12 @@ def run_vectorised(args):
             selfplay_iteration(env, ego, alt, n_steps)
     else:
         alt = RaggedVecOnPolicyAgent(models[1])
-        env = VecLiarSelfPlay(E, ego, alt, seed=args.seed or 0, **args.env_config)
+        # the dice get a Philox key of their own: keyed by the bare seed they would BE the ego's sampling uniforms (same key,
+        # same step counter, same row); without --seed every run deals a fresh sequence
+        import random as _random
+        base = args.seed if args.seed is not None else _random.SystemRandom().randrange(2 ** 31)
+        dice_seed = ((base * 0x9E3779B97F4A7C15) ^ 0xD1CE0D1CE0D1CE) & 0x7FFFFFFFFFFFFFFF
+        env = VecLiarSelfPlay(E, ego, alt, seed=dice_seed, **args.env_config)
         if iterations >= 4 and env.native:
             # two launch-by-launch iterations size the workspaces, the rest replay one hipGraph per iteration
             from .envs.vec import LiarIterationGraph

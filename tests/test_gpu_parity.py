@@ -1197,3 +1197,168 @@ def test_peer_to_peer_exchange_between_processes(world):
            "127.0.0.1", "--master-port", str(29531 + world), os.path.join(root, "tests", "scripts", "p2p_two_rank.py")]
     out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.count("P2P_OK") == world, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# round 2: sizes and chains the round-1 suite only property-tested, reference-semantics run, truncation bootstrap
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,T,E,nb", [("overcooked", 128, 1024, 32768), ("liar", 128, 256, 8192)])
+def test_full_size_minibatch_gradient_matches_autograd(name, T, E, nb):
+    """One whole minibatch of BASELINE configs 3 and 2 at their real sizes (32 768 rows of Overcooked-simple; 8 192 rows of
+    Liar's Dice with F = 270 one-hot features and two action components) against autograd on the oracle.  A sum over nb
+    rows in another order: tolerance 2e-4 of the largest gradient entry, as for the small shapes."""
+    idx = np.random.default_rng(nb).permutation(T * E)[:nb]
+    g, g_ref, st, st_ref, lay = _grad_pair(name, T, E, idx, orc.PPOHyper())
+    _assert_grads(g, g_ref, lay)
+    for i, k in enumerate(("policy_loss", "value_loss", "entropy_loss", "clip_fraction", "approx_kl", "loss")):
+        assert abs(st[i] - st_ref[k]) <= 1e-5 + 1e-4 * abs(st_ref[k]), (k, st[i], st_ref[k])
+
+
+@pytest.mark.parametrize("name,T,E", [("overcooked", 128, 1024), ("liar", 128, 256)])
+def test_full_size_one_epoch_train_matches_oracle(name, T, E):
+    """train() for one epoch at the bench sizes (batch = E*T/4: four dependent Adam steps over the whole buffer), teacher-forced
+    permutation, against the oracle's PPO.train(): per-minibatch statistics and the parameters after the fourth step."""
+    hp = orc.PPOHyper(batch_size=T * E // 4, n_epochs=1)
+    model, orac, stats_ref = _train_pair(name, T, E, hp, seed=33)
+    st = model.last_train_stats
+    assert len(stats_ref) == st.shape[0] == 4 and int(model.policy.opt_step.item()) == 4
+    p, p_ref = model.policy.get_flat_params(), orac.flat_params()
+    assert np.abs(p - p_ref).max() <= 2e-6 * 4 + 1e-6, np.abs(p - p_ref).max()
+    for i, s in enumerate(stats_ref):
+        for j, k in enumerate(("policy_loss", "value_loss", "entropy_loss", "clip_fraction", "approx_kl", "loss",
+                               "grad_norm")):
+            assert abs(st[i, j] - s[k]) <= 2e-4 + 2e-3 * abs(s[k]), (i, k, st[i, j], s[k])
+
+
+def test_reference_semantics_320_step_chain():
+    """How the reference actually runs a partner (agents.py:111-203 on SB3's defaults): n_envs = 1, n_steps = 2048, batch 64,
+    10 epochs = 320 dependent Adam steps per rollout, np.random.permutation order teacher-forced.  A priori one Adam step
+    moves a parameter by at most ~lr = 3e-4 and the two normalised updates disagree by the f32 noise of the gradients, so a
+    drift of up to ~1e-5 after 320 steps would be unremarkable; measured on MI355X: max |dW| = 1.2e-7 (one ulp of a weight of
+    magnitude 1) while the chain moves the weights by up to 6.2e-2.  Asserted: <= 2e-6 absolute, losses within 1e-3."""
+    hp = orc.PPOHyper(batch_size=64, n_epochs=10)
+    model, orac, stats_ref = _train_pair("overcooked", 2048, 1, hp, seed=77)
+    st = model.last_train_stats
+    assert st.shape[0] == len(stats_ref) == 320 and int(model.policy.opt_step.item()) == 320
+    p, p_ref = model.policy.get_flat_params(), orac.flat_params()
+    drift = np.abs(p - p_ref).max()
+    moved = np.abs(p_ref - H.oracle_policy("overcooked", seed=77).flat_params()).max()
+    print(f"320-step chain: max |dW| = {drift:.3e}, the chain itself moved the weights by up to {moved:.3e}")
+    assert moved > 5e-3 and drift <= 2e-6, (drift, moved)
+    for i in (0, 1, 31, 32, 160, 319):
+        for j, k in enumerate(("policy_loss", "value_loss", "entropy_loss", "approx_kl", "loss", "grad_norm")):
+            jj = j if j < 3 else j + 1
+            assert abs(st[i, jj] - stats_ref[i][k]) <= 1e-3 + 5e-3 * abs(stats_ref[i][k]), (i, k, st[i, jj], stats_ref[i][k])
+
+
+def test_models_built_with_the_same_seed_sample_independently():
+    """trainer.py RPS-v0 PPO PPO --seed S: ego and partner start from the same weights (as in the reference) but must not draw
+    the same uniforms step after step -- the partner's model gets sampling_stream = index + 1."""
+    from pantheonrl_amd.ppo import PPO
+    from pantheonrl_amd.spaces import Discrete
+    env = type("E", (), dict(observation_space=Discrete(1), action_space=Discrete(3), _is_dummy_space_env=True))()
+    ego = PPO("MlpPolicy", env, n_steps=8, seed=5)
+    alt = PPO("MlpPolicy", env, n_steps=8, seed=5, sampling_stream=1)
+    twin = PPO("MlpPolicy", env, n_steps=8, seed=5)
+    assert np.array_equal(ego.policy.get_flat_params(), alt.policy.get_flat_params())
+    obs = np.zeros((512, 1), np.float32)
+    a_ego = ego.policy.forward(obs)[0].cpu().numpy()
+    a_alt = alt.policy.forward(obs)[0].cpu().numpy()
+    a_twin = twin.policy.forward(obs)[0].cpu().numpy()
+    assert np.array_equal(a_ego, a_twin)                       # the bare seed still reproduces
+    assert 0.5 < (a_ego != a_alt).mean() < 0.8                 # independent uniform 3-way draws differ 2/3 of the time
+
+
+def test_device_games_reproduce_the_committed_traces():
+    """ph_rps_step / ph_liar_step against tests/golden/liar_hand_worked.json (worked by hand from the reference's liar.py) and
+    tests/golden/game_traces.npz (seeded restatement output, see make_game_traces.py) -- no Python game runs here."""
+    import json
+    import os
+    from pantheonrl_amd import _native as nat
+    from pantheonrl_amd.envs.vec import VecLiarsDice, VecRPS
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ctx, dev = nat.Context(0), th.device("cuda", 0)
+    games = json.load(open(os.path.join(here, "liar_hand_worked.json")))["games"]
+    G, S = len(games), max(len(g["steps"]) for g in games)
+    hands = np.array([g["egohand"] + g["althand"] for g in games], np.int32)
+    vec = VecLiarsDice(G, ctx, dev)
+    vec.reset(hands)
+    for s in range(S):
+        alive = np.array([s < len(g["steps"]) for g in games])
+        acts = np.array([g["steps"][s]["raw"] if a else [0, 0] for g, a in zip(games, alive)], np.int32)
+        is_ego = np.array([g["steps"][s]["is_ego"] if a else False for g, a in zip(games, alive)])
+        obs, rew, done = vec.player_step(_dev(acts), _dev(is_ego.astype(np.uint8)), _dev(alive.astype(np.uint8)))
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        for i in np.nonzero(alive)[0]:
+            want = games[i]["steps"][s]
+            assert obs[i].tolist() == want["obs"] and rew[i].tolist() == want["rew"] and bool(done[i]) == want["done"], (i, s)
+    z = np.load(os.path.join(here, "game_traces.npz"))
+    env = VecRPS(len(z["rps_ego"]), ctx, dev)
+    r0, r1, d = env.step(_dev(z["rps_ego"]), _dev(z["rps_alt"]))
+    assert np.array_equal(r0.cpu().numpy(), z["rps_ego_reward"]) and np.array_equal(r1.cpu().numpy(), -z["rps_ego_reward"])
+    E = z["liar_hands"].shape[0]
+    vec = VecLiarsDice(E, ctx, dev)
+    vec.reset(z["liar_hands"])
+    turn = z["liar_ego_first"].astype(bool)
+    for s in range(z["liar_acts"].shape[0]):
+        alive = z["liar_alive"][s].astype(bool)
+        obs, rew, done = vec.player_step(_dev(z["liar_acts"][s]), _dev(turn.astype(np.uint8)), _dev(alive.astype(np.uint8)))
+        assert np.array_equal(obs.cpu().numpy()[alive], z["liar_obs"][s][alive])
+        assert np.array_equal(rew.cpu().numpy()[alive], z["liar_rew"][s][alive])
+        assert np.array_equal(done.cpu().numpy()[alive].astype(bool), z["liar_done"][s][alive].astype(bool))
+        turn = ~turn
+
+
+class _TimeLimitVec:
+    """scripted 3-env VecEnv: observations are a function of (env, step) only, episodes end by time limit every `horizon`
+    steps in env 0 (truncated), by a true terminal every 5 steps in env 1, never in env 2."""
+    num_envs = 3
+
+    def __init__(self, D=62, horizon=4):
+        from pantheonrl_amd.spaces import Box, Discrete
+        self.observation_space, self.action_space = Box(-np.inf, np.inf, (D,)), Discrete(6)
+        self.D, self.horizon, self.t = D, horizon, 0
+
+    def _obs(self, t):
+        return np.stack([np.sin(0.37 * (t + 1) * (e + 1) + 0.11 * np.arange(self.D)) for e in range(3)]).astype(np.float32)
+
+    def reset(self):
+        self.t = 0
+        return self._obs(0)
+
+    def step(self, actions):
+        self.t += 1
+        obs = self._obs(self.t)
+        rew = np.array([0.5, -0.25, 1.0], np.float32) * (1 + (self.t % 3))
+        dones = np.array([self.t % self.horizon == 0, self.t % 5 == 0, False])
+        infos = [{}, {}, {}]
+        for e in range(3):
+            if dones[e]:
+                infos[e]["terminal_observation"] = obs[e].copy()
+                obs[e] = 0.1 * (e + 1)                          # the auto-reset observation
+        if dones[0]:
+            infos[0]["TimeLimit.truncated"] = True
+        return obs, rew, dones, infos
+
+
+def test_collect_rollouts_bootstraps_time_limit_truncations():
+    """SB3 1.7.0's ego loop: rewards[i] += gamma * V(terminal_observation) when an episode is cut by a time limit, and only
+    then.  Device PPO.collect_rollouts against the oracle's restatement on a scripted VecEnv, actions teacher-forced."""
+    from pantheonrl_amd.ppo import PPO
+    T, E = 12, 3
+    orac = H.oracle_policy("overcooked", seed=3)
+    env_d, env_o = _TimeLimitVec(), _TimeLimitVec()
+    model = PPO("MlpPolicy", env_d, n_steps=T, n_envs=E, batch_size=12, n_epochs=1, seed=0)
+    model.policy.set_flat_params(orac.flat_params())
+    model._last_obs, model._last_episode_starts = env_d.reset(), np.ones(E, np.float32)
+    u = np.random.default_rng(0).random((T, E, 1)).astype(np.float32)
+    model.collect_rollouts(forced_uniforms=u)
+    dev = model.rollout_buffer.host()
+    ob = orc.RolloutBufferOracle(T, E, 62, 1)
+    orc.collect_rollouts(orac, ob, env_o, env_o.reset(), np.ones(E, np.float32), forced_actions=dev["actions"])
+    plain = np.stack([np.array([0.5, -0.25, 1.0], np.float32) * (1 + (t % 3)) for t in range(1, T + 1)])
+    boosted = np.abs(ob.rewards - plain) > 0
+    assert boosted[:, 0].tolist() == [(t % 4 == 0) for t in range(1, T + 1)] and not boosted[:, 1:].any()
+    assert np.abs(dev["rewards"] - ob.rewards).max() <= 2e-6
+    assert np.array_equal(dev["episode_starts"], ob.episode_starts)
+    assert np.abs(dev["values"] - ob.values).max() <= 2e-5 and np.abs(dev["advantages"] - ob.advantages).max() <= 1e-4

@@ -407,3 +407,55 @@ def test_recorders_and_npy_wire_format(tmp_path):
     assert np.array_equal(again.obs, ego.obs) and again[0]["acts"].shape == (2,) and len(again[1:3]) == 2
     with pytest.raises(ValueError):
         TransitionsMinimal(np.zeros((3, 2)), np.zeros((2, 1)))
+
+
+def test_recording_agent_wrapper_and_offpolicy_refusal(tmp_path):
+    """RecordingAgentWrapper (reference agents.py:365-413): delegates both callbacks and keeps every (obs, action) pair;
+    the pairs come back as a TransitionsMinimal that survives the .npy round trip.  OffPolicyAgent is outside the
+    on-policy path and says so."""
+    from pantheonrl_amd.common import OffPolicyAgent, RecordingAgentWrapper, TransitionsMinimal
+    env = RPSEnv()
+    inner = Scripted(action=2)
+    rec = RecordingAgentWrapper(inner)
+    env.add_partner_agent(rec)
+    for ego_move in (0, 1, 2):
+        env.reset()
+        env.step(ego_move)
+    assert [e[0] for e in inner.log] == ["act", "upd", "upd"] * 3            # both callbacks reach the real agent
+    tr = rec.get_transitions()
+    assert isinstance(tr, TransitionsMinimal) and len(tr) == 3
+    assert tr.obs.tolist() == [[0]] * 3 and tr.acts.tolist() == [2, 2, 2]
+    tr.write_transition(str(tmp_path / "rec.npy"))
+    back = TransitionsMinimal.read_transition(str(tmp_path / "rec.npy"), env.observation_space, env.action_space)
+    assert np.array_equal(back.obs.reshape(-1), tr.obs.reshape(-1)) and np.array_equal(back.acts.reshape(-1), tr.acts)
+    with pytest.raises(NotImplementedError, match="on-policy"):
+        OffPolicyAgent(object())
+
+
+def test_games_reproduce_the_hand_worked_traces_and_the_committed_fixture():
+    """tests/golden/liar_hand_worked.json: games worked by hand from the reference's liar.py (the independent anchor);
+    tests/golden/game_traces.npz: seeded traces written by make_game_traces.py from this restatement (pins drift)."""
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for g in json.load(open(os.path.join(here, "liar_hand_worked.json")))["games"]:
+        t = LiarEnv()
+        t.history, t.egohand, t.althand = [], list(g["egohand"]), list(g["althand"])
+        for s in g["steps"]:
+            o, r, d, _ = t.player_step(np.asarray(s["raw"]), s["is_ego"])
+            assert np.asarray(o).tolist() == s["obs"] and list(r) == s["rew"] and d == s["done"], (g["note"], s)
+    z = np.load(os.path.join(here, "game_traces.npz"))
+    assert np.array_equal(rps_payoff(z["rps_ego"], z["rps_alt"]).astype(np.float32), z["rps_ego_reward"])
+    E = z["liar_hands"].shape[0]
+    turn = z["liar_ego_first"].astype(bool)
+    tables = []
+    for e in range(E):
+        t = LiarEnv()
+        t.history, t.egohand, t.althand = [], z["liar_hands"][e, :6].tolist(), z["liar_hands"][e, 6:].tolist()
+        tables.append(t)
+    for s in range(z["liar_acts"].shape[0]):
+        for e in np.nonzero(z["liar_alive"][s])[0]:
+            o, r, d, _ = tables[e].player_step(z["liar_acts"][s, e], bool(turn[e]))
+            assert np.array_equal(np.asarray(o, np.float32), z["liar_obs"][s, e]) and tuple(r) == tuple(z["liar_rew"][s, e])
+            assert bool(d) == bool(z["liar_done"][s, e])
+        turn = ~turn
