@@ -135,8 +135,26 @@ class ActionExchange:
         if route == "auto":
             route = "rccl" if self.world == 1 else "measure"
         if route in ("rccl", "measure") and self.native_ctx is None:
-            if not self.attach_native(ctx) and route == "rccl":
-                route = "torch"
+            attached = self._everyone(self.attach_native(ctx)) if self.world > 1 else self.attach_native(ctx)
+            verified = False
+            if attached:
+                # the engine-side all-gather must reproduce torch.distributed's on a known pattern before it is trusted
+                try:
+                    pattern = th.arange(self.local.numel(), dtype=th.int32, device=self.local.device).view_as(self.local)
+                    self.local.copy_(pattern * 7 + 1000003 * (self.rank + 1))
+                    got = self.gather_inplace().clone()
+                    if self.local.is_cuda:
+                        th.cuda.synchronize(self.local.device)
+                    verified = bool(th.equal(got, self._torch_gather()))
+                except Exception:  # noqa: BLE001
+                    verified = False
+                verified = self._everyone(verified)
+            self._rccl_verified = verified
+            log["rccl_verified"] = verified
+            if not verified:
+                self.native_ctx = None
+                if route == "rccl":
+                    route = "torch"
         if route == "measure":
             def timed(step_fn, k=32):
                 th.cuda.synchronize()
@@ -149,10 +167,7 @@ class ActionExchange:
             vdev = self.local.device if dist.get_backend(self.group) == "nccl" else "cpu"
             baseline = "rccl" if self.native_ctx is not None else "torch"
 
-            def everyone(flag: bool) -> bool:      # the same decision on every rank, whatever happened locally
-                v = th.tensor([1.0 if flag else 0.0], device=vdev)
-                dist.all_reduce(v, op=dist.ReduceOp.MIN)
-                return bool(v.item() > 0.5)
+            everyone = self._everyone
             log["rccl_us"] = 1e6 * timed(lambda t: self.gather_inplace())
             T_test = max(int(n_steps), 32)
             ok = everyone(self.attach_p2p(ctx, epoch_word, T_test))
@@ -184,14 +199,64 @@ class ActionExchange:
             if use_p2p:
                 route = "p2p"        # (the descriptor keeps T_test >= n_steps: stamps stay unique and monotonic)
             else:
-                self.p2p, route = None, baseline
+                self.p2p, self._p2p_slots, route = None, None, baseline
                 if baseline == "torch":
                     self.native_ctx = None
         elif route == "p2p":
-            if not self.attach_p2p(ctx, epoch_word, n_steps):
-                route = "rccl" if self.attach_native(ctx) else "torch"
+            if not self._everyone(self.attach_p2p(ctx, epoch_word, n_steps)):
+                self.p2p, self._p2p_slots = None, None
+                route = "rccl" if (self.native_ctx is not None or self._everyone(self.attach_native(ctx))) else "torch"
         self.route, self.route_log = route, log
         return route
+
+    def _torch_gather(self) -> th.Tensor:
+        """all-gather of `self.local` through torch.distributed alone (the route of last resort and the yardstick the native
+        routes are verified against); returns a fresh (n_seats, n_envs) tensor"""
+        out = th.empty_like(self.joint)
+        if self.world == 1:
+            out.copy_(self.local)
+        elif self.local.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = th.empty(self.joint.shape, dtype=self.joint.dtype)
+            dist.all_gather_into_tensor(host, self.local.cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, self.local, group=self.group)
+        return out
+
+    def _everyone(self, flag: bool) -> bool:
+        """the same verdict on every rank, whatever happened locally (a rank that failed must take the others with it)"""
+        if self.world == 1:
+            return bool(flag)
+        vdev = self.local.device if dist.get_backend(self.group) == "nccl" else "cpu"
+        v = th.tensor([1.0 if flag else 0.0], device=vdev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(v.item() > 0.5)
+
+    def verify_route(self, last_slot: th.Tensor) -> bool:
+        """After a real iteration: does the joint action this rank consumed for the last step equal what torch.distributed
+        gathers from the same local actions?  (`self.local` still holds the last step's actions.)  All ranks get the same
+        answer; a peer-to-peer timeout also counts as a failure."""
+        ok = True
+        try:
+            if self.local.is_cuda:
+                th.cuda.synchronize(self.local.device)
+            want = self._torch_gather()
+            ok = bool(th.equal(last_slot, want)) and self.p2p_timeouts() == 0
+        except Exception:  # noqa: BLE001
+            ok = False
+        return self._everyone(ok)
+
+    def demote(self) -> str:
+        """give up the native route in use: peer-to-peer -> engine-side RCCL if that one verified, else torch.distributed"""
+        was = getattr(self, "route", "torch")
+        self.p2p = None
+        self._p2p_slots = None
+        if was == "p2p" and self.native_ctx is not None and getattr(self, "_rccl_verified", False):
+            self.route = "rccl"
+        else:
+            self.native_ctx, self.route = None, "torch"
+        self.route_log = dict(getattr(self, "route_log", {}), demoted_from=was, chosen=self.route)
+        return self.route
 
     def joint_slot(self, parity: int) -> th.Tensor:
         """the (n_seats, n_envs) joint-action buffer holding steps of this parity (one buffer unless peer-to-peer)"""

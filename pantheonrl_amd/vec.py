@@ -299,7 +299,14 @@ class FusedSelfPlayRollout:
             a.actions = exchange.local[i].view(a.E, 1)       # forward writes straight into the exchange buffer
             a.model.device_permutations = True
             nat.check(a.model.policy.ctx.lib.ph_ctx_set_rng_epoch(a.model.policy.ctx.handle, self.epoch_word.data_ptr()))
-        # prebuilt launch records: one contiguous [T][n] array (ph_selfplay_rollout walks it), `calls[t]` = step t's slice
+        self.route_checked = False
+        self._build_calls()
+
+    def _build_calls(self) -> None:
+        """prebuilt launch records: one contiguous [T][n] array (ph_selfplay_rollout walks it), `calls[t]` = step t's slice.
+        They hold pointers into the exchange's joint-action buffers, so they are rebuilt when the exchange route changes."""
+        agents, datas, exchange, bonus = self.agents, self.datas, self.exchange, self.bonus
+        n = len(agents)
         self._all_calls = (nat.PhStepCall * (n * self.T))()
         self.calls = []
         for t in range(self.T):
@@ -337,6 +344,17 @@ class FusedSelfPlayRollout:
             for t in range(T):
                 nat.check(lib.ph_policy_step_multi(h, len(agents), self.calls[t]))
                 ex.gather_inplace()
+        if not self.route_checked and getattr(ex, "world", 1) > 1 and hasattr(ex, "verify_route"):
+            # first real iteration on this node: the joint action consumed for the last step must be what torch.distributed
+            # gathers from the same local actions, on every rank, with no poll timed out -- otherwise the native route is
+            # dropped for good (one synchronising check, once)
+            self.route_checked = True
+            if not ex.verify_route(ex.joint_slot(T - 1)):
+                import sys
+                print(f"[pantheonrl_amd.vec] exchange route {ex.route!r} failed verification after the first iteration; "
+                      f"falling back to {ex.demote()!r}", file=sys.stderr)
+                ex.gather_inplace()          # the last step's joint action again, through the route now in use
+                self._build_calls()
         # the last step's reward (no further forward to carry it)
         for i, (a, d) in enumerate(zip(agents, self.datas)):
             a.bind_stream()

@@ -74,6 +74,31 @@ with th.cuda.stream(stream):
             bad = got != expect.astype(np.float32)
             assert not bad.any(), (rank, it, i, "mismatching rows per step", bad.sum(1).tolist(), "timeouts", ex2.p2p_timeouts())
 assert ex2.p2p_timeouts() == 0, ex2.p2p_timeouts()
+assert roll.route_checked and ex2.route == "p2p"       # the post-iteration verification ran and kept the route
+dist.barrier()
+
+# ---- phase 3: a route that fails its verification after the first real iteration is dropped on every rank, and the run goes on
+ex3 = pdist.ActionExchange(A_LOCAL, E2, device)
+ex3.requested_route = "p2p"
+with th.cuda.stream(stream):
+    roll3 = FusedSelfPlayRollout(agents, datas, ex3, stream, bonus=BONUS, update_graphs=False)
+    assert ex3.route == "p2p"
+    ex3.verify_route = lambda slot: False                  # as if a peer's words had not arrived
+    for it in range(2):
+        dist.barrier()
+        roll3.run_iteration(it)
+        stream.synchronize()
+        if it == 0:
+            assert ex3.route in ("rccl", "torch") and ex3.p2p is None and ex3.route_log.get("demoted_from") == "p2p", ex3.route_log
+            continue                                       # (the iteration that exposed the failure is not checked)
+        mine = th.stack([a.model.rollout_buffer.actions[..., 0].cpu() for a in agents])
+        everyone = [th.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        seats = th.cat(everyone).numpy()
+        for i, (a, d) in enumerate(zip(agents, datas)):
+            seat = ex3.seat(i)
+            expect = d.rewards.cpu().numpy() + BONUS * (seats[seat] == seats[ex3.partner_of(seat, it)])
+            assert np.array_equal(a.model.rollout_buffer.rewards.cpu().numpy(), expect.astype(np.float32)), (rank, i)
 dist.barrier()
 print(f"P2P_OK rank {rank}/{world}", flush=True)
 dist.destroy_process_group()
