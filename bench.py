@@ -78,10 +78,12 @@ def parse():
     ap.add_argument("--agents-per-gpu", type=int, default=2,
                     help="2 = a self-play pair per GPU (ego PPO + partner PPO, trainer.py ... PPO PPO: the headline config); "
                          "1 = north_star's one agent per GPU (N agents on N GPUs, every step's partner is on another rank)")
-    ap.add_argument("--mode", choices=("auto", "graph", "jointgraph", "eager", "fusedstep"), default="auto",
+    ap.add_argument("--mode", choices=("auto", "graph", "jointgraph", "eager", "fusedstep", "roundrobin"), default="auto",
                     help="graph: one hipGraph per agent-iteration (N=1 default); fusedstep: one fused launch of all local "
                          "agents + one action exchange per env step (the N>1 path; at N=1 the exchange is a local copy); "
-                         "eager: per-agent launches")
+                         "eager: per-agent launches; roundrobin: BASELINE config 4 -- one ego (rank 0, hosting the environments) "
+                         "against --gpus - 1 partners, one agent per GPU, per-environment round-robin partner ids, partner "
+                         "observations routed from the ego's rank (pantheonrl_amd/roundrobin.py)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "exercise the N>1 code path with several ranks on ONE GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -251,6 +253,63 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def bench_roundrobin(args, device, rank, world, json_fd, tdist):
+    """BASELINE config 4: ego vs (world - 1) on-policy partners, exactly one partner active per episode and environment,
+    one agent per GPU.  value = agent-steps/s of the ego plus the partners (every environment step has one ego action and one
+    partner action, so 2 * n_envs * n_steps per iteration, whatever the number of partners)."""
+    from pantheonrl_amd import PPO, roundrobin as rr, spaces as sp
+    from pantheonrl_amd.vec import SyntheticRollouts
+    if world < 2:
+        raise SystemExit("bench.py --mode roundrobin needs --gpus >= 2 (ego + at least one partner)")
+    wl = WORKLOADS[args.workload]
+    if len(wl["act"]) != 1:
+        raise SystemExit("bench.py --mode roundrobin runs the single-Discrete-action workloads (overcooked, mpe8, rps)")
+    K = world - 1
+    obs_space = sp.Box(-np.inf, np.inf, (wl["obs"][1],)) if wl["obs"][0] == "box" else (
+        sp.Discrete(wl["obs"][1][0]) if len(wl["obs"][1]) == 1 else sp.MultiDiscrete(wl["obs"][1]))
+    act_space = sp.Discrete(wl["act"][0])
+    env = type("SpacesOnly", (), dict(observation_space=obs_space, action_space=act_space, _is_dummy_space_env=True))()
+    model = PPO("MlpPolicy", env, n_steps=args.n_steps, n_envs=args.n_envs, batch_size=args.batch_size,
+                n_epochs=args.n_epochs, seed=1000 * rank, device=device)
+    model.device_permutations = True
+    data_ego = SyntheticRollouts(obs_space, args.n_envs, args.n_steps, wl["horizon"], 0, device)
+    data_alt = SyntheticRollouts(obs_space, args.n_envs, args.n_steps, wl["horizon"], 1, device) if rank == 0 else None
+    side = rr.make_rank(model, K, args.n_steps, data_ego=data_ego, obs_alt=None if data_alt is None else data_alt.obs)
+
+    def barrier():
+        th.cuda.synchronize(device)
+        tdist.barrier()
+        th.cuda.synchronize(device)
+    for _ in range(args.warmup):
+        side.run_iteration()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        side.run_iteration()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = th.tensor([dt], dtype=th.float64, device=device if args.backend == "nccl" else "cpu")
+    tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    upd = th.tensor([float(getattr(side, "updates", 0))], dtype=th.float64, device=device if args.backend == "nccl" else "cpu")
+    tdist.all_reduce(upd)
+    if rank == 0:
+        value = 2.0 * args.n_envs * args.n_steps * args.steps / dt
+        result = {"metric": f"env-steps/sec (all agents) {args.workload} shapes, ego vs {K} round-robin partners",
+                  "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                  "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                  "dtype": "f32", "data": "synthetic", "ranks_seen": world,
+                  "config": {"workload": wl["name"] + f", ego vs {K} OnPolicy partners, round-robin per environment",
+                             "n_envs": args.n_envs, "n_steps": args.n_steps, "batch_size": args.batch_size,
+                             "n_epochs": args.n_epochs, "partner_updates": int(upd.item()),
+                             "parallelism": f"one agent per gpu x{world} (ego + {K} partners; per step one broadcast of the "
+                                            "routing block and one all-gather of actions, torch.distributed "
+                                            f"{args.backend})", "launch_mode": "roundrobin"}}
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -282,6 +341,8 @@ def main():
     distributed = pdist.init_from_env(args.backend)
     import torch.distributed as tdist
 
+    if args.mode == "roundrobin":
+        return bench_roundrobin(args, device, rank, world, json_fd, tdist)
     from pantheonrl_amd.vec import IterationGraph, run_iteration_eager
     log(f"building {args.agents_per_gpu} agents, n_envs={args.n_envs}, n_steps={args.n_steps}, batch={args.batch_size}")
     agents, datas = build_agents(args, device)

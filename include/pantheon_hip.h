@@ -139,6 +139,20 @@ int ph_buffer_add_reward(ph_ctx *ctx, const ph_rollout *rb, int pos, const float
 int ph_buffer_add_reward_joint(ph_ctx *ctx, const ph_rollout *rb, int pos, const float *base_reward /* (E) */,
                                const int *joint_actions, int n_seats, int seat, const int *partner_seat /* device */,
                                float bonus);
+/* One-agent-per-GPU round-robin layout (BASELINE config 4: ego vs K OnPolicy partners, exactly one partner active per episode):
+ * the synthetic 2-player SimultaneousEnv transition of n environments on the ego's rank <- MultiAgentEnv.step / reset,
+ * multiagentenv.py:149-243, with the per-environment partner id the reference keeps in `partnerids` (:105-125).
+ *   joint_actions (1 + n_partners, n) int32: row 0 the ego's actions, row 1 + k partner k's (all-gathered over RCCL)
+ *   partnerid (n) int32 in/out: the partner of each environment; where done[e] != 0 it advances to (id + 1) % n_partners --
+ *       resample_round_robin at that environment's own reset (:118-125,224)
+ *   reward_out (n): base_reward[e] + bonus * [ego action == its partner's action] (Overcooked's reward is shared, so this is
+ *       both players' reward); alt_action_out (n) or NULL: the partner action each environment consumed
+ *   next_block (n, block_ld) f32 or NULL: header columns 0..2 of the next step's routing block are written --
+ *       [partner id of the next step | reward_out | done] -- the block the ego's rank sends to the partner ranks together
+ *       with the partner-seat observations in columns 3.. */
+int ph_roundrobin_env_step(ph_ctx *ctx, const int *joint_actions, int *partnerid, const float *base_reward,
+                           const float *done, float *reward_out, int *alt_action_out, float *next_block, int block_ld,
+                           int n_partners, float bonus, int n);
 /* RolloutBuffer.reset() <- agents.py:157 : zero-fills every array */
 int ph_buffer_reset(ph_ctx *ctx, const ph_spec *spec, const ph_rollout *rb);
 

@@ -104,6 +104,7 @@ class PhLiarSelfPlay(C.Structure):
 
 SIGNATURES = {
     "ph_abi_version": [],
+    "ph_roundrobin_env_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.c_float, _i],
     "ph_last_error": [],
     "ph_device_count": [C.POINTER(_i)],
     "ph_ctx_create": [_i, C.POINTER(_vp)],

@@ -405,6 +405,20 @@ int ph_buffer_add_reward_joint(ph_ctx* ctx, const ph_rollout* rb, int pos, const
   return 0;
 }
 
+int ph_roundrobin_env_step(ph_ctx* ctx, const int* joint_actions, int* partnerid, const float* base_reward, const float* done,
+                           float* reward_out, int* alt_action_out, float* next_block, int block_ld, int n_partners,
+                           float bonus, int n) {
+  DevGuard dev_guard(ctx);
+  if (!ctx) return fail("null ctx");
+  if (!joint_actions || !partnerid || !base_reward || !done || !reward_out)
+    return fail("ph_roundrobin_env_step: null argument");
+  if (n <= 0 || n_partners <= 0) return fail("ph_roundrobin_env_step: bad sizes");
+  if (next_block && block_ld < 3) return fail("ph_roundrobin_env_step: routing block rows need >= 3 header columns");
+  PH_HIP(ph::launch_roundrobin_env_step(joint_actions, partnerid, base_reward, done, reward_out, alt_action_out, next_block,
+                                        block_ld, n_partners, bonus, n, ctx->stream));
+  return 0;
+}
+
 int ph_buffer_reset(ph_ctx* ctx, const ph_spec* spec, const ph_rollout* rb) {
   DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");

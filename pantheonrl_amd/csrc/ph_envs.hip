@@ -20,6 +20,42 @@ hipError_t launch_rps_step(const int* ego_act, const int* alt_act, float* ego_re
   return hipGetLastError();
 }
 
+// Synthetic 2-player SimultaneousEnv transition of the one-agent-per-GPU round-robin layout (BASELINE config 4; reference
+// multiagentenv.py:149-243 with E environments): environment e is currently partnered with partner partnerid[e].  From the
+// all-gathered actions (row 0 = ego, row 1 + k = partner k) it takes the action of e's partner, pays the shared reward
+// base[e] + bonus * [ego action == partner action], and, where the episode ends, advances e's partner id round-robin -- the
+// next reset's resample_round_robin (multiagentenv.py:118-125,224) of that environment alone.  The header columns of the next
+// step's routing block [partner id | the reward and done flag just produced] are written for the partner ranks.
+__global__ void roundrobin_env_step_kernel(const int* __restrict__ joint, int* __restrict__ partnerid,
+                                           const float* __restrict__ base, const float* __restrict__ done,
+                                           float* __restrict__ reward_out, int* __restrict__ alt_action_out,
+                                           float* __restrict__ next_block, int block_ld, int n_partners, float bonus, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  int pid = partnerid[e];
+  pid = pid < 0 ? 0 : (pid >= n_partners ? n_partners - 1 : pid);
+  const int a_ego = joint[e], a_alt = joint[(size_t)(1 + pid) * n + e];
+  const float r = base[e] + ((a_ego == a_alt) ? bonus : 0.f);
+  reward_out[e] = r;
+  if (alt_action_out) alt_action_out[e] = a_alt;
+  const float d = done[e];
+  const int next = (d != 0.f) ? (pid + 1) % n_partners : pid;
+  partnerid[e] = next;
+  if (next_block) {
+    float* row = next_block + (size_t)e * block_ld;
+    row[0] = (float)next;
+    row[1] = r;
+    row[2] = d;
+  }
+}
+hipError_t launch_roundrobin_env_step(const int* joint, int* partnerid, const float* base, const float* done, float* reward_out,
+                                      int* alt_action_out, float* next_block, int block_ld, int n_partners, float bonus, int n,
+                                      hipStream_t s) {
+  hipLaunchKernelGGL(roundrobin_env_step_kernel, dim3((n + 255) / 256), dim3(256), 0, s, joint, partnerid, base, done,
+                     reward_out, alt_action_out, next_block, block_ld, n_partners, bonus, n);
+  return hipGetLastError();
+}
+
 constexpr int LD_SIDES = 6, LD_DICE = 6, LD_MAXMOVES = 12;
 
 // A table's state lives in registers while a lane works on it: 16-byte loads / stores of the (12) hand and (24) history rows,

@@ -187,6 +187,9 @@ hipError_t launch_reward_add_joint(float* rew_row, const float* base, const int*
                                    const int* partner_seat, float bonus, hipStream_t s);
 hipError_t launch_framestack_push(float* stack, const float* obs, const unsigned char* reset_mask,
                                   const float* default_obs, int n, int D, int nf, hipStream_t s);
+hipError_t launch_roundrobin_env_step(const int* joint, int* partnerid, const float* base, const float* done, float* reward_out,
+                                      int* alt_action_out, float* next_block, int block_ld, int n_partners, float bonus, int n,
+                                      hipStream_t s);
 hipError_t launch_rps_step(const int* ego_act, const int* alt_act, float* ego_rew, float* alt_rew, int n, hipStream_t s);
 hipError_t launch_liar_step(const int* hands, int* history, int* nmoves, const int* actions, const unsigned char* is_ego,
                             const unsigned char* active, float* obs_next, float* rew, unsigned char* done, int n,

@@ -73,3 +73,16 @@ def test_bench_refuses_more_gpus_than_visible_and_a_mismatched_world():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *SMALL], capture_output=True,
                        text=True, timeout=300, cwd=ROOT, env={**env, "WORLD_SIZE": "2", "RANK": "0"})
     assert r.returncode != 0 and "disagrees" in r.stderr
+
+
+def test_bench_round_robin_mode_four_ranks():
+    """BASELINE config 4 as a bench mode: ego + 3 partners, one agent per rank (here sharing the box's GPU over gloo)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--mode", "roundrobin", "--workload", "rps", "--n-envs", "48",
+                        "--n-steps", "8", "--n-epochs", "1", "--steps", "3", "--warmup", "1", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 4 and d["value"] > 0 and d["config"]["launch_mode"] == "roundrobin"
+    # one-step episodes: every environment changes partner at every step, so each partner's 8-row columns fill after 24 steps
+    assert d["config"]["partner_updates"] >= 1

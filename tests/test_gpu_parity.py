@@ -1362,3 +1362,22 @@ def test_collect_rollouts_bootstraps_time_limit_truncations():
     assert np.abs(dev["rewards"] - ob.rewards).max() <= 2e-6
     assert np.array_equal(dev["episode_starts"], ob.episode_starts)
     assert np.abs(dev["values"] - ob.values).max() <= 2e-5 and np.abs(dev["advantages"] - ob.advantages).max() <= 1e-4
+
+
+def test_round_robin_partners_one_agent_per_rank_replayed_through_multiagentenv():
+    """BASELINE config 4 (ego vs 3 OnPolicy partners, one agent per rank; here 4 ranks share the test box's GPU over gloo):
+    every environment of the device run is replayed through the Python MultiAgentEnv loop with round-robin partner
+    selection and must give the ego's and all three partners' buffers row by row; then a run with short partner buffers
+    checks that a partner trains once all its columns are full."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # second run: one-step episodes (every environment changes partner at every step, so all columns of a partner fill at the
+    # same rate) and 4-row partner buffers: full after 12 steps
+    for extra, port in (({}, 29561), ({"RR_T_PARTNER": "4", "RR_HORIZON": "1"}, 29562)):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "scripts", "roundrobin_ranks.py")]
+        out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env={**os.environ, **extra})
+        assert out.returncode == 0 and out.stdout.count("RR_OK") == 4, (out.stdout[-1500:], out.stderr[-3000:])
+        assert ("RR_REPLAY_OK" in out.stdout) == (not extra)
