@@ -420,6 +420,52 @@ int ph_bench_gae(ph_ctx *ctx, const ph_rollout *rb, const float *last_values, co
  * the kernels run the identical integer code, so this is the bit-exact statement of the minibatch order. */
 int ph_feistel_indices(int n, unsigned long long perm_seed, int epoch, int start, int count, int *out /* host */);
 
+/* ---- owning handle: one agent = its rollout buffer, weights and Adam state on the device ----------------------------------
+ *   The pointer-level entry points above take device memory owned by the caller (the Python host uses torch
+ * allocations).  This layer is the same path for a binder that has NO device runtime of its own: the handle owns every device
+ * allocation, every array crossing the boundary is a HOST array (copied in / out), every call is complete on return.
+ * Mapping to the reference's call sites:
+ *   ph_agent_create / destroy        <- PPO.__init__(env, n_steps, gamma, gae_lambda, seed, device)    trainer.py:108-126,196-203
+ *   ph_agent_set/get_params          <- policy.load_state_dict / state_dict (flat layout: ph_layout)    trainer.py:140-157,419-432
+ *   ph_agent_set/get_optimizer       <- policy.optimizer.state_dict()
+ *   ph_agent_buffer_reset            <- rollout_buffer.reset()                                          agents.py:157
+ *   ph_agent_act(record=1)           <- policy.forward(obs) + rollout_buffer.add(..., reward = 0, ...)  util.py:63-81, agents.py:162-179
+ *   ph_agent_act(record=0)           <- policy.forward(obs) alone (StaticPolicyAgent)                   agents.py:54-79
+ *   ph_agent_add_reward              <- rollout_buffer.rewards[pos - 1] += reward                       agents.py:198
+ *   ph_agent_gae                     <- rollout_buffer.compute_returns_and_advantage(last_values, dones) agents.py:127-130
+ *   ph_agent_train                   <- model.train()                                                   agents.py:155
+ *   ph_agent_export / import_buffer  <- the buffer's arrays as SB3 lays them out, (T, E, ...) float32
+ * Errors: non-zero return, message from ph_agent_last_error() (thread-local). */
+typedef struct ph_agent ph_agent;
+const char *ph_agent_last_error(void);
+int ph_agent_create(int device, const ph_spec *spec /* host */, int n_envs, int n_steps, double gamma, double gae_lambda,
+                    unsigned long long seed, ph_agent **out /* host */);
+int ph_agent_destroy(ph_agent *agent);
+int ph_agent_layout(const ph_agent *agent, ph_layout *out /* host */);
+int ph_agent_set_params(ph_agent *agent, const float *params /* host (P) */);
+int ph_agent_get_params(ph_agent *agent, float *params_out /* host (P) */);
+int ph_agent_set_optimizer(ph_agent *agent, const float *adam_m /* host (P) */, const float *adam_v /* host (P) */, int step);
+int ph_agent_get_optimizer(ph_agent *agent, float *adam_m_out, float *adam_v_out, int *step_out /* host, any may be NULL */);
+int ph_agent_buffer_reset(ph_agent *agent);
+int ph_agent_pos(const ph_agent *agent, int *pos_out /* host */);
+/* obs (E,D) host; action_mask (E,L) u8 or NULL; uniforms (E,A) or NULL (NULL = Philox keyed by the handle's seed and call
+ * counter); record != 0 writes the transition at the buffer's write row with episode_start (E) and advances it.
+ * Outputs (host, any may be NULL): actions (E,A) int32, values (E), log_probs (E). */
+int ph_agent_act(ph_agent *agent, const float *obs, const unsigned char *action_mask, const float *uniforms,
+                 int deterministic, int record, const float *episode_start, int *actions_out, float *values_out,
+                 float *log_probs_out);
+int ph_agent_add_reward(ph_agent *agent, const float *reward /* host (E) */, const unsigned char *env_mask /* host (E) or NULL */);
+int ph_agent_gae(ph_agent *agent, const float *last_values /* host (E) */, const float *dones /* host (E) */, int mode);
+/* perms (n_epochs, T*E) host int32 or NULL (keyed Feistel order from perm_seed); stats_out host
+ * (n_epochs * ceil(T*E / batch_size), PH_NSTAT) or NULL */
+int ph_agent_train(ph_agent *agent, const ph_ppo_hyper *hyper /* host */, int n_epochs, int batch_size, const int *perms,
+                   unsigned long long perm_seed, float *stats_out);
+int ph_agent_export_buffer(ph_agent *agent, float *observations, float *actions, float *rewards, float *episode_starts,
+                           float *values, float *log_probs, float *advantages, float *returns /* host, any may be NULL */);
+int ph_agent_import_buffer(ph_agent *agent, const float *observations, const float *actions, const float *rewards,
+                           const float *episode_starts, const float *values, const float *log_probs, const float *advantages,
+                           const float *returns /* host, any may be NULL */, int pos);
+
 #ifdef __cplusplus
 }
 #endif

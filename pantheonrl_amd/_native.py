@@ -162,6 +162,23 @@ SIGNATURES = {
                           C.POINTER(C.c_float)],
     "ph_bench_gae": [_vp, C.POINTER(PhRollout), _vp, _vp, _d, _d, _i, _i, C.POINTER(C.c_float)],
     "ph_feistel_indices": [_i, _ull, _i, _i, _i, C.POINTER(_i)],
+    # owning-handle layer (host arrays in and out; see include/pantheon_hip.h)
+    "ph_agent_last_error": [],
+    "ph_agent_create": [_i, C.POINTER(PhSpec), _i, _i, _d, _d, _ull, C.POINTER(_vp)],
+    "ph_agent_destroy": [_vp],
+    "ph_agent_layout": [_vp, C.POINTER(PhLayout)],
+    "ph_agent_set_params": [_vp, _vp],
+    "ph_agent_get_params": [_vp, _vp],
+    "ph_agent_set_optimizer": [_vp, _vp, _vp, _i],
+    "ph_agent_get_optimizer": [_vp, _vp, _vp, C.POINTER(_i)],
+    "ph_agent_buffer_reset": [_vp],
+    "ph_agent_pos": [_vp, C.POINTER(_i)],
+    "ph_agent_act": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "ph_agent_add_reward": [_vp, _vp, _vp],
+    "ph_agent_gae": [_vp, _vp, _vp, _i],
+    "ph_agent_train": [_vp, C.POINTER(PhPpoHyper), _i, _i, _vp, _ull, _vp],
+    "ph_agent_export_buffer": [_vp] + [_vp] * 8,
+    "ph_agent_import_buffer": [_vp] + [_vp] * 8 + [_i],
 }
 
 _lib: Optional[C.CDLL] = None
@@ -187,7 +204,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "ph_last_error" else C.c_int
+        fn.restype = C.c_char_p if name in ("ph_last_error", "ph_agent_last_error") else C.c_int
     if lib.ph_abi_version() != 1:
         raise NativeError("libpantheon_hip.so ABI version mismatch")
     _lib = lib

@@ -86,3 +86,16 @@ def test_bench_round_robin_mode_four_ranks():
     assert d["n_gpus"] == 4 and d["value"] > 0 and d["config"]["launch_mode"] == "roundrobin"
     # one-step episodes: every environment changes partner at every step, so each partner's 8-row columns fill after 24 steps
     assert d["config"]["partner_updates"] >= 1
+
+
+def test_bench_config5_shape_one_agent_per_rank_four_ranks():
+    """BASELINE config 5's layout (PettingZoo MPE simple_spread shapes, ONE learner per GPU, every step's actions all-gathered):
+    four ranks stand in for the eight here, sharing the box's GPU over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "mpe8", "--agents-per-gpu", "1",
+                        *SMALL, "--backend", "gloo", "--no-roofline"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 4 and d["ranks_seen"] == 4 and d["config"]["agents_per_gpu"] == 1 and d["config"]["obs_dim"] == 48
+    assert "= 4 learners" in d["config"]["parallelism"]
