@@ -420,6 +420,39 @@ int ph_bench_gae(ph_ctx *ctx, const ph_rollout *rb, const float *last_values, co
  * the kernels run the identical integer code, so this is the bit-exact statement of the minibatch order. */
 int ph_feistel_indices(int n, unsigned long long perm_seed, int epoch, int start, int count, int *out /* host */);
 
+/* ---- behavioural cloning --------------------------------------------------------------------------
+ * BC <- pantheonrl/algos/bc.py:180-366 on FeedForward32Policy <- pantheonrl/common/util.py:114-123: SB3 ActorCriticPolicy with
+ * net_arch = [32, 32], ONE shared tanh trunk feeding action_net and value_net.  Parameter vector (float32, input-major):
+ *   W1[F][32] b1[32] W2[32][32] b2[32] act_W[32][L] act_b[L] val_W[32] val_b[1]
+ *  ph_bc_forward: policy.forward / evaluate_actions of that architecture (argument meaning as ph_policy_forward).
+ *  ph_bc_train:   BC.train (bc.py:305-353): for every epoch, for every consecutive slice of `batch_size` entries of that epoch's
+ *      visiting order (the last may be short; DataLoader(shuffle=True) draws one permutation per epoch -- `order` teacher-forces
+ *      it): loss = -mean(log_prob) - ent_weight * mean(entropy) + l2_weight * sum(w^2) / 2 (bc.py:291-303), backward, one
+ *      torch.optim.Adam step (no gradient clipping).  max_batches > 0 stops after that many minibatches (`n_batches` mode).
+ *      The whole chain runs inside ONE launch of one persistent workgroup (parameters resident in LDS).
+ *      stats (minibatches, PH_BC_NSTAT) or NULL: {neglogp, entropy, ent_loss, prob_true_act, l2_norm, l2_loss, loss, rows}
+ *      (bc.py:305-313).  Limits: P <= 12288 parameters (F <= ~330 features). */
+#define PH_BC_HIDDEN 32
+#define PH_BC_NSTAT 8
+typedef struct ph_bc_layout {
+  int D, F, A, L, P;
+  int W1, b1, W2, b2, act_W, act_b, val_W, val_b; /* offsets */
+} ph_bc_layout;
+typedef struct ph_bc_hyper { /* BC defaults: bc.py:189-191; torch.optim.Adam defaults */
+  float learning_rate; /* 1e-3  */
+  float adam_beta1, adam_beta2, adam_eps; /* 0.9, 0.999, 1e-8 */
+  float ent_weight;    /* 1e-3  */
+  float l2_weight;     /* 0.0   */
+} ph_bc_hyper;
+int ph_bc_layout_of(const ph_spec *spec /* host */, ph_bc_layout *out /* host */);
+int ph_bc_forward(ph_ctx *ctx, const ph_spec *spec, const float *params, const float *obs, int n,
+                  const unsigned char *action_mask, const float *uniforms, const float *given_actions,
+                  unsigned long long seed, unsigned long long counter, int deterministic, int *actions_i32, float *values,
+                  float *log_probs, float *entropy, float *logits);
+int ph_bc_train(ph_ctx *ctx, const ph_spec *spec, const ph_opt_state *opt, const float *obs /* (N,D) */,
+                const float *acts /* (N,A) f32 */, const int *order /* (n_epochs, N) int32 */, int N, int batch_size,
+                int n_epochs, int max_batches, const ph_bc_hyper *hyper /* host */, float *stats);
+
 /* ---- owning handle: one agent = its rollout buffer, weights and Adam state on the device ----------------------------------
  *   The pointer-level entry points above take device memory owned by the caller (the Python host uses torch
  * allocations).  This layer is the same path for a binder that has NO device runtime of its own: the handle owns every device

@@ -455,3 +455,104 @@ def collect_rollouts(policy: MlpPolicyOracle, buf: RolloutBufferOracle, env, las
         values = policy.predict_values(th.as_tensor(np.asarray(new_obs, np.float32)))
     buf.compute_returns_and_advantage(values, np.asarray(dones, np.float32))
     return new_obs, dones
+
+
+# --------------------------------------------------------------------------------------
+# Behavioural cloning: FeedForward32Policy + BC._calculate_loss + BC.train  (reference pantheonrl/algos/bc.py)
+# --------------------------------------------------------------------------------------
+BC_HIDDEN = 32
+
+
+class FeedForward32Oracle(nn.Module):
+    """``FeedForward32Policy`` (pantheonrl/common/util.py:114-123): SB3 ActorCriticPolicy with ``net_arch=[32, 32]`` -- in SB3
+    1.7.0 a plain list of ints is a SHARED trunk, so policy and value heads sit on the same 32-32 tanh network.  Orthogonal
+    init with SB3's gains (sqrt(2) trunk, 0.01 action_net, 1 value_net; modular/policies.py:229-241)."""
+
+    def __init__(self, obs_space: SpaceSpec, act_space: SpaceSpec, ortho_init: bool = True):
+        super().__init__()
+        self.obs_space, self.act_space = obs_space, act_space
+        Fdim, L = obs_space.flat_len, act_space.flat_len
+        self.shared_net = nn.Sequential(nn.Linear(Fdim, BC_HIDDEN), nn.Tanh(), nn.Linear(BC_HIDDEN, BC_HIDDEN), nn.Tanh())
+        self.action_net = nn.Linear(BC_HIDDEN, L)
+        self.value_net = nn.Linear(BC_HIDDEN, 1)
+        if ortho_init:
+            for mod, gain in ((self.shared_net, np.sqrt(2)), (self.action_net, 0.01), (self.value_net, 1.0)):
+                for m in mod.modules():
+                    if isinstance(m, nn.Linear):
+                        nn.init.orthogonal_(m.weight, gain=gain)
+                        m.bias.data.fill_(0.0)
+
+    def _latent(self, obs: th.Tensor) -> th.Tensor:
+        return self.shared_net(preprocess_obs(obs, self.obs_space))
+
+    def logits(self, obs: th.Tensor) -> th.Tensor:
+        return self.action_net(self._latent(obs))
+
+    def evaluate_actions(self, obs: th.Tensor, actions: th.Tensor):
+        """-> (values (n,1), log_prob (n,), entropy (n,))"""
+        latent = self._latent(obs)
+        z = self.action_net(latent)
+        actions = actions.long().reshape(obs.shape[0], -1)
+        logp, ent = 0.0, 0.0
+        for c, zc in enumerate(th.split(z, list(self.act_space.nvec), dim=1)):
+            dist = th.distributions.Categorical(logits=zc)
+            logp = logp + dist.log_prob(actions[:, c])
+            ent = ent + dist.entropy()
+        return self.value_net(latent), logp, ent
+
+    def _linears(self):
+        return (self.shared_net[0], self.shared_net[2], self.action_net)
+
+    def flat_params(self) -> np.ndarray:
+        """[W1(F,32) b1 W2(32,32) b2 act_W(32,L) act_b val_W(32) val_b], weights input-major (ph_bc_layout)"""
+        out = []
+        for lin in self._linears():
+            out += [lin.weight.detach().t().contiguous().reshape(-1), lin.bias.detach()]
+        out += [self.value_net.weight.detach().reshape(-1), self.value_net.bias.detach()]
+        return th.cat(out).numpy().astype(np.float32).copy()
+
+    def load_flat_params(self, flat: np.ndarray) -> None:
+        flat, o = th.as_tensor(np.asarray(flat, np.float32)), 0
+        with th.no_grad():
+            for lin in self._linears():
+                n = lin.weight.numel()
+                lin.weight.copy_(flat[o:o + n].reshape(lin.in_features, lin.out_features).t())
+                o += n
+                lin.bias.copy_(flat[o:o + lin.bias.numel()])
+                o += lin.bias.numel()
+            self.value_net.weight.copy_(flat[o:o + BC_HIDDEN].reshape(1, BC_HIDDEN))
+            self.value_net.bias.copy_(flat[o + BC_HIDDEN:o + BC_HIDDEN + 1])
+        assert o + BC_HIDDEN + 1 == flat.numel()
+
+
+def bc_loss(policy: FeedForward32Oracle, obs: th.Tensor, acts: th.Tensor, ent_weight: float = 1e-3, l2_weight: float = 0.0):
+    """``BC._calculate_loss`` (bc.py:270-315): returns (loss, stats_dict)."""
+    _, log_prob, entropy = policy.evaluate_actions(obs, acts)
+    prob_true_act = th.exp(log_prob).mean()
+    log_prob, entropy = log_prob.mean(), entropy.mean()
+    l2_norm = sum(th.sum(th.square(w)) for w in policy.parameters()) / 2     # divide by 2 to cancel the square's gradient
+    ent_loss, neglogp, l2_loss = -ent_weight * entropy, -log_prob, l2_weight * l2_norm
+    loss = neglogp + ent_loss + l2_loss
+    return loss, dict(neglogp=neglogp.item(), loss=loss.item(), entropy=entropy.item(), ent_loss=ent_loss.item(),
+                      prob_true_act=prob_true_act.item(), l2_norm=l2_norm.item(), l2_loss=l2_loss.item())
+
+
+def bc_train(policy: FeedForward32Oracle, obs_data: np.ndarray, acts_data: np.ndarray, orders: Sequence[np.ndarray],
+             batch_size: int = 32, ent_weight: float = 1e-3, l2_weight: float = 0.0, optimizer=None,
+             max_batches: int = 0) -> List[dict]:
+    """``BC.train`` (bc.py:316-353): for every epoch walk the DataLoader -- consecutive slices of ``batch_size`` rows of that
+    epoch's shuffled order (``orders[epoch]`` teacher-forces ``shuffle=True``; the last slice may be short) -- and take one
+    optimizer step per batch.  Optimizer: ``torch.optim.Adam(policy.parameters())`` with torch's defaults (bc.py:186-237)."""
+    opt = optimizer or th.optim.Adam(policy.parameters())
+    out = []
+    for order in orders:
+        for start in range(0, len(order), batch_size):
+            idx = np.asarray(order[start:start + batch_size])
+            loss, stats = bc_loss(policy, th.as_tensor(obs_data[idx]), th.as_tensor(acts_data[idx]), ent_weight, l2_weight)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            out.append(stats)
+            if max_batches and len(out) >= max_batches:
+                return out
+    return out

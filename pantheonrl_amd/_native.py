@@ -50,6 +50,20 @@ class PhPpoHyper(C.Structure):
                 ("adam_beta2", C.c_float), ("adam_eps", C.c_float)]
 
 
+class PhBcLayout(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("D", "F", "A", "L", "P", "W1", "b1", "W2", "b2", "act_W", "act_b", "val_W", "val_b")]
+
+
+class PhBcHyper(C.Structure):
+    _fields_ = [("learning_rate", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
+                ("ent_weight", C.c_float), ("l2_weight", C.c_float)]
+
+
+PH_BC_HIDDEN = 32
+PH_BC_NSTAT = 8
+BC_STAT_NAMES = ("neglogp", "entropy", "ent_loss", "prob_true_act", "l2_norm", "l2_loss", "loss", "rows")
+
+
 class PhStepCall(C.Structure):
     _fields_ = [("spec", C.POINTER(PhSpec)), ("params", C.c_void_p), ("obs", C.c_void_p), ("n", C.c_int),
                 ("action_mask", C.c_void_p), ("seed", C.c_ulonglong), ("counter", C.c_ulonglong),
@@ -162,6 +176,9 @@ SIGNATURES = {
                           C.POINTER(C.c_float)],
     "ph_bench_gae": [_vp, C.POINTER(PhRollout), _vp, _vp, _d, _d, _i, _i, C.POINTER(C.c_float)],
     "ph_feistel_indices": [_i, _ull, _i, _i, _i, C.POINTER(_i)],
+    "ph_bc_layout_of": [C.POINTER(PhSpec), C.POINTER(PhBcLayout)],
+    "ph_bc_forward": [_vp, C.POINTER(PhSpec), _vp, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, _vp, _vp],
+    "ph_bc_train": [_vp, C.POINTER(PhSpec), C.POINTER(PhOptState), _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(PhBcHyper), _vp],
     # owning-handle layer (host arrays in and out; see include/pantheon_hip.h)
     "ph_agent_last_error": [],
     "ph_agent_create": [_i, C.POINTER(PhSpec), _i, _i, _d, _d, _ull, C.POINTER(_vp)],

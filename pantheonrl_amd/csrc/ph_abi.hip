@@ -1341,6 +1341,65 @@ int ph_bench_gae(ph_ctx* ctx, const ph_rollout* rb, const float* last_values, co
   return 0;
 }
 
+// ---- behavioural cloning on the shared 32-32 policy ----
+int ph_bc_layout_of(const ph_spec* spec, ph_bc_layout* o) {
+  ph_layout big;
+  if (!o) return fail("null layout");
+  if (layout_of(spec, &big)) return 1;
+  const int H = PH_BC_HIDDEN;
+  o->D = big.D;
+  o->F = big.F;
+  o->A = big.A;
+  o->L = big.L;
+  int off = 0;
+  o->W1 = off; off += big.F * H;
+  o->b1 = off; off += H;
+  o->W2 = off; off += H * H;
+  o->b2 = off; off += H;
+  o->act_W = off; off += H * big.L;
+  o->act_b = off; off += big.L;
+  o->val_W = off; off += H;
+  o->val_b = off; off += 1;
+  o->P = off;
+  return 0;
+}
+
+int ph_bc_forward(ph_ctx* ctx, const ph_spec* spec, const float* params, const float* obs, int n,
+                  const unsigned char* action_mask, const float* uniforms, const float* given_actions,
+                  unsigned long long seed, unsigned long long counter, int deterministic, int* actions_i32, float* values,
+                  float* log_probs, float* entropy, float* logits) {
+  DevGuard dev_guard(ctx);
+  if (!ctx) return fail("null ctx");
+  if (!params || !obs || n <= 0) return fail("ph_bc_forward: bad argument");
+  ph::NetDims nd;
+  if (resolve(ctx, spec, &nd)) return 1;
+  ph_bc_layout lay;
+  if (ph_bc_layout_of(spec, &lay)) return 1;
+  if ((size_t)lay.P * sizeof(float) > 150 * 1024) return fail("ph_bc_forward: policy too large for the LDS-resident forward");
+  PH_HIP(ph::launch_bc_forward(nd, lay, params, obs, n, action_mask, uniforms, given_actions, seed, counter, deterministic,
+                               actions_i32, values, log_probs, entropy, logits, ctx->stream));
+  return 0;
+}
+
+int ph_bc_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const float* obs, const float* acts,
+                const int* order, int N, int batch_size, int n_epochs, int max_batches, const ph_bc_hyper* hyper,
+                float* stats) {
+  DevGuard dev_guard(ctx);
+  if (!ctx) return fail("null ctx");
+  if (!opt || !opt->params || !opt->adam_m || !opt->adam_v || !opt->step) return fail("ph_bc_train: null optimizer state");
+  if (!obs || !acts || !order || !hyper) return fail("ph_bc_train: null argument");
+  if (N <= 0 || batch_size <= 0 || n_epochs <= 0) return fail("ph_bc_train: N, batch_size and n_epochs must be positive");
+  ph::NetDims nd;
+  if (resolve(ctx, spec, &nd)) return 1;
+  ph_bc_layout lay;
+  if (ph_bc_layout_of(spec, &lay)) return 1;
+  if (lay.P > 256 * 48) return fail("ph_bc_train: more than 12288 parameters (the persistent workgroup owns 48 per thread)");
+  if (ph::bc_train_lds_bytes(nd.F, nd.L, lay.P) > 160 * 1024) return fail("ph_bc_train: working set exceeds the CU's 160 KiB of LDS");
+  PH_HIP(ph::launch_bc_train(nd, lay, opt->params, opt->adam_m, opt->adam_v, opt->step, obs, acts, order, N, batch_size,
+                             n_epochs, max_batches, *hyper, stats, ctx->stream));
+  return 0;
+}
+
 int ph_feistel_indices(int n, unsigned long long perm_seed, int epoch, int start, int count, int* out) {
   if (!out) return fail("ph_feistel_indices: null out");
   if (n <= 0 || start < 0 || count < 0 || (long long)start + count > n) return fail("ph_feistel_indices: bad range");

@@ -221,6 +221,15 @@ hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s);
 int reduce_blocks(int slab_len);
 hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_set_int(int* p, int v, hipStream_t s);
+// behavioural cloning on the shared 32-32 policy (ph_bc.hip)
+size_t bc_train_lds_bytes(int F, int L, int P);
+hipError_t launch_bc_train(const NetDims& nd, const ph_bc_layout& lay, float* params, float* adam_m, float* adam_v, int* step,
+                           const float* obs, const float* acts, const int* order, int N, int batch, int n_epochs,
+                           int max_batches, const ph_bc_hyper& hp, float* stats, hipStream_t s);
+hipError_t launch_bc_forward(const NetDims& nd, const ph_bc_layout& lay, const float* params, const float* obs, int n,
+                             const unsigned char* mask, const float* uniforms, const float* given, uint64_t seed,
+                             uint64_t counter, int deterministic, int* act_i32, float* values, float* logp, float* entropy,
+                             float* logits, hipStream_t s);
 hipError_t launch_epoch_advance(unsigned long long* p, hipStream_t s);
 
 }  // namespace ph

@@ -1,0 +1,102 @@
+"""-m gpu: behavioural cloning (reference pantheonrl/algos/bc.py) on the persistent-workgroup kernel against the oracle's
+restatement of BC._calculate_loss / BC.train on FeedForward32Policy."""
+import numpy as np
+import pytest
+import torch as th
+
+from oracle import sb3_oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(name, N, seed=0):
+    from pantheonrl_amd.bc import BC
+    from pantheonrl_amd.common import TransitionsMinimal
+    obs_s, act_s = H.CONFIGS[name]
+    rng = np.random.default_rng(seed)
+    obs = H.sample_obs(obs_s, N, rng)
+    acts = np.stack([rng.integers(0, k, size=N) for k in act_s.nvec], axis=1).astype(np.float32)
+    th.manual_seed(seed)
+    orac = orc.FeedForward32Oracle(obs_s, act_s)
+    with th.no_grad():          # biases and the 0.01-gain head perturbed so that the logits are not ~uniform
+        g = th.Generator().manual_seed(seed + 1)
+        for p in orac.parameters():
+            p.add_(0.2 * th.randn(p.shape, generator=g) * (1.0 if p.ndim == 1 else 0.3))
+    clone = BC(H.to_space(obs_s), H.to_space(act_s), expert_data=TransitionsMinimal(obs, acts if acts.shape[1] > 1 else acts[:, 0]))
+    clone.policy.set_flat_params(orac.flat_params())
+    return clone, orac, obs, acts
+
+
+@pytest.mark.parametrize("name", ["overcooked", "liar", "rps", "mpe8"])
+def test_bc_forward_matches_oracle(name):
+    clone, orac, obs, acts = _pair(name, 300)
+    with th.no_grad():
+        z_ref = orac.logits(th.as_tensor(obs)).numpy()
+        v_ref, lp_ref, h_ref = orac.evaluate_actions(th.as_tensor(obs), th.as_tensor(acts))
+    assert np.abs(clone.policy.get_logits(obs).cpu().numpy() - z_ref).max() <= 2e-5
+    v, lp, h = clone.policy.evaluate_actions(obs, acts)
+    assert np.abs(v.cpu().numpy() - v_ref.numpy()).max() <= 2e-5
+    assert np.abs(lp.cpu().numpy() - lp_ref.numpy()).max() <= 2e-5 and np.abs(h.cpu().numpy() - h_ref.numpy()).max() <= 2e-5
+    greedy = clone.policy.forward(obs, deterministic=True)[0].cpu().numpy().reshape(len(obs), -1)
+    split = np.cumsum((0,) + H.CONFIGS[name][1].nvec)
+    for c in range(len(split) - 1):
+        zc = z_ref[:, split[c]:split[c + 1]]
+        top2 = np.sort(zc, axis=1)[:, -2:] if zc.shape[1] > 1 else np.stack([zc[:, 0] - 1, zc[:, 0]], 1)
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-4
+        assert np.array_equal(greedy[clear, c], zc.argmax(1)[clear])
+
+
+@pytest.mark.parametrize("name,N,epochs,l2", [("overcooked", 100, 3, 0.0), ("overcooked", 77, 2, 1e-3), ("liar", 96, 2, 0.0),
+                                              ("rps", 40, 4, 0.0)])
+def test_bc_train_matches_oracle(name, N, epochs, l2):
+    """a chain of ceil(N/32) * epochs Adam steps inside ONE launch, shuffles teacher-forced: parameters, Adam moments and every
+    minibatch's statistics against BC.train on the oracle (last batch of an epoch is short when 32 does not divide N)"""
+    clone, orac, obs, acts = _pair(name, N, seed=3)
+    clone.l2_weight = l2
+    orders = np.stack([np.random.default_rng(10 + ep).permutation(N) for ep in range(epochs)])
+    st = clone.train(n_epochs=epochs, orders=orders)
+    ref = orc.bc_train(orac, obs, acts, orders, 32, ent_weight=1e-3, l2_weight=l2)
+    assert st.shape[0] == len(ref) == epochs * (-(-N // 32)) and int(clone.opt_step.item()) == len(ref)
+    for i, s in enumerate(ref):
+        for j, k in enumerate(("neglogp", "entropy", "ent_loss", "prob_true_act", "l2_norm", "l2_loss", "loss")):
+            assert abs(st[i, j] - s[k]) <= 2e-5 + 2e-4 * abs(s[k]), (i, k, st[i, j], s[k])
+    # Adam's lr is 1e-3 and eps 1e-8: each step moves every weight by ~1e-3, so f32 noise in a gradient entry near zero can
+    # flip a step's direction for that entry -- bound: a few such entries times the step size
+    d = np.abs(clone.policy.get_flat_params() - orac.flat_params())
+    assert np.median(d) <= 2e-6 and d.max() <= 2.5e-3 * 1.0, (np.median(d), d.max())
+    assert (d > 1e-4).mean() <= 0.01, (d > 1e-4).mean()
+
+
+def test_bc_n_batches_mode_save_and_reconstruct(tmp_path):
+    from pantheonrl_amd.bc import reconstruct_policy
+    from pantheonrl_amd.common import Observation, StaticPolicyAgent
+    clone, orac, obs, acts = _pair("overcooked", 100, seed=5)
+    orders = np.stack([np.random.default_rng(ep).permutation(100) for ep in range(2)])
+    st = clone.train(n_batches=5, orders=orders)            # 5 of the 8 minibatches two epochs would give
+    ref = orc.bc_train(orac, obs, acts, orders, 32, max_batches=5)
+    assert st.shape[0] == 5 and int(clone.opt_step.item()) == 5 and abs(st[4, 6] - ref[4]["loss"]) <= 1e-4
+    with pytest.raises(ValueError):
+        clone.train()
+    clone.save_policy(str(tmp_path / "bc.pt"))
+    again = reconstruct_policy(str(tmp_path / "bc.pt"))
+    assert np.array_equal(again.get_flat_params(), clone.policy.get_flat_params())
+    agent = StaticPolicyAgent(again)                          # the cloned policy sits in a seat like any fixed partner
+    a = agent.get_action(Observation(obs[0]))
+    assert 0 <= int(a) < 6
+
+
+def test_bc_learns_the_expert_on_a_separable_problem():
+    """end to end on the .npy wire format the recorders write (trajsaver): an 'expert' whose action is a function of the
+    observation is cloned to > 95 % agreement"""
+    from pantheonrl_amd.bc import BC
+    from pantheonrl_amd.common import TransitionsMinimal
+    from pantheonrl_amd.spaces import Box, Discrete
+    rng = np.random.default_rng(0)
+    obs = rng.standard_normal((2048, 8)).astype(np.float32)
+    acts = (obs[:, :4].argmax(1)).astype(np.float32)
+    clone = BC(Box(-np.inf, np.inf, (8,)), Discrete(4), expert_data=TransitionsMinimal(obs, acts))
+    st = clone.train(n_epochs=20)
+    assert st[-10:, 0].mean() < 0.5 * st[:10, 0].mean()      # neglogp went down
+    pred = clone.policy.forward(obs, deterministic=True)[0].cpu().numpy().reshape(-1)
+    assert (pred == acts).mean() > 0.95
