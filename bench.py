@@ -229,6 +229,12 @@ def roofline(args, agent):
         if rec["kernel"].split("::")[-1] == kernel:    # the committed counters belong to this kernel
             out["traffic"] = rec["hbm_bytes_per_launch"]
             out["traffic_source"] = rec["source"]
+            ig = rec.get("in_graph")
+            if ig:   # the same kernel inside the whole-iteration graphs (committed rocprofv3 kernel trace of this command)
+                out["in_graph"] = {"avg_launch_ms": ig["avg_us"] * 1e-3, "achieved": flops / (ig["avg_us"] * 1e-6) / 1e12,
+                                   "frac": flops / (ig["avg_us"] * 1e-6) / 1e12 / 157.3, "source": ig["source"]}
+            if "sq" in rec:
+                out["mfma_util_percent"] = rec["sq"].get("MfmaUtil_percent")
     except Exception:  # noqa: BLE001
         pass
     return out

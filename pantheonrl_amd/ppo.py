@@ -158,7 +158,7 @@ class ActorCriticPolicy:
         self.adam_m = th.zeros_like(self.params)
         self.adam_v = th.zeros_like(self.params)
         self.opt_step = th.zeros(1, dtype=th.int32, device=self.device)
-        self.lr = float(lr)
+        self.lr = float(lr(1.0)) if callable(lr) else float(lr)   # a schedule: its value at the start (informational)
         self._seed = int(seed) if seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
         if sampling_stream:
             # Philox key of this model's action sampling.  The reference draws every agent's actions from ONE global torch
@@ -405,10 +405,18 @@ class PPO:
         self._custom_logger = True
 
     # -- PPO.train() (agents.py:155) -----------------------------------------------------------------------------------
+    @staticmethod
+    def _schedule(value, progress_remaining: float) -> float:
+        """SB3 get_schedule_fn: a constant, or a callable of progress_remaining (1 at the start of learn(), 0 at the end)"""
+        return float(value(progress_remaining)) if callable(value) else float(value)
+
     def hyper(self) -> nat.PhPpoHyper:
+        """this train() call's hyper-parameters; learning_rate / clip_range / clip_range_vf may be schedules evaluated at
+        _current_progress_remaining (adap_learn.py:233-244: _update_learning_rate, clip_range(progress))"""
         h = nat.PhPpoHyper()
-        h.learning_rate, h.clip_range = float(self.learning_rate), float(self.clip_range)
-        h.clip_range_vf = -1.0 if self.clip_range_vf is None else float(self.clip_range_vf)
+        prog = getattr(self, "_current_progress_remaining", 1.0)
+        h.learning_rate, h.clip_range = self._schedule(self.learning_rate, prog), self._schedule(self.clip_range, prog)
+        h.clip_range_vf = -1.0 if self.clip_range_vf is None else self._schedule(self.clip_range_vf, prog)
         h.ent_coef, h.vf_coef, h.max_grad_norm = float(self.ent_coef), float(self.vf_coef), float(self.max_grad_norm)
         h.target_kl = -1.0 if self.target_kl is None else float(self.target_kl)
         h.normalize_advantage = int(bool(self.normalize_advantage))
@@ -461,7 +469,8 @@ class PPO:
             lg.record("train/clip_fraction", float(used[:, 3].mean()))
             lg.record("train/loss", float(used[-1, 5]))
             lg.record("train/n_updates", self._n_updates, exclude="tensorboard")
-            lg.record("train/clip_range", self.clip_range)
+            lg.record("train/clip_range", float(hp.clip_range))
+            lg.record("train/learning_rate", float(hp.learning_rate))
 
     def _train_call(self, keep: list) -> "nat.PhTrainCall":
         """this learner's train() arguments as a ph_train_call (device permutations; statistics stay on the device)"""
@@ -543,10 +552,27 @@ class PPO:
             self._last_obs = self.env.reset()
             self._last_episode_starts = np.ones(self.n_envs, np.float32)
         self.start_time = time.time()
+        self._total_timesteps, start_steps = total_timesteps, self.num_timesteps
         iteration = 0
+        # callback: SB3's BaseCallback protocol where available (init_callback / on_training_start / on_rollout_end /
+        # on_training_end), or a plain callable(locals, globals) -> bool called once per rollout; False stops training
+        cb_obj = callback if hasattr(callback, "on_rollout_end") else None
+        if cb_obj is not None and hasattr(cb_obj, "init_callback"):
+            cb_obj.init_callback(self)
+        if cb_obj is not None and hasattr(cb_obj, "on_training_start"):
+            cb_obj.on_training_start(locals(), globals())
         while self.num_timesteps < total_timesteps:
             self.collect_rollouts()
             iteration += 1
+            # SB3 _update_current_progress_remaining(num_timesteps, total_timesteps)
+            self._current_progress_remaining = 1.0 - float(self.num_timesteps - start_steps) / float(
+                max(total_timesteps - start_steps, 1))
+            if cb_obj is not None:
+                cb_obj.on_rollout_end()
+                if getattr(cb_obj, "stop_training", False):
+                    break
+            elif callable(callback) and callback(locals(), globals()) is False:
+                break
             if log_interval is not None and iteration % log_interval == 0:
                 lg = self.logger
                 fps = int(self.num_timesteps / max(time.time() - self.start_time, 1e-9))
@@ -558,6 +584,8 @@ class PPO:
                 lg.record("time/total_timesteps", self.num_timesteps, exclude="tensorboard")
                 lg.dump(step=self.num_timesteps)
             self.train()
+        if cb_obj is not None and hasattr(cb_obj, "on_training_end"):
+            cb_obj.on_training_end()
         return self
 
     def predict(self, obs, deterministic: bool = False):
@@ -593,6 +621,10 @@ class PPO:
         import os
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         data = {k: getattr(self, k) for k in self._HP}
+        prog = getattr(self, "_current_progress_remaining", 1.0)
+        for k in ("learning_rate", "clip_range", "clip_range_vf"):      # a schedule is stored as its current value
+            if callable(data[k]):
+                data[k] = self._schedule(data[k], prog)
         data.update(observation_space=self._space_to_json(self.observation_space),
                     action_space=self._space_to_json(self.action_space), num_timesteps=self.num_timesteps,
                     _n_updates=self._n_updates, format="pantheonrl_amd-1")

@@ -1381,3 +1381,22 @@ def test_round_robin_partners_one_agent_per_rank_replayed_through_multiagentenv(
         out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env={**os.environ, **extra})
         assert out.returncode == 0 and out.stdout.count("RR_OK") == 4, (out.stdout[-1500:], out.stderr[-3000:])
         assert ("RR_REPLAY_OK" in out.stdout) == (not extra)
+
+
+def test_learn_schedules_and_callback():
+    """learning_rate / clip_range as SB3 schedules of progress_remaining (adap_learn.py:233-244) and learn(callback=...)"""
+    from pantheonrl_amd.ppo import PPO
+    env = _TimeLimitVec(horizon=1000)
+    seen = []
+    model = PPO("MlpPolicy", env, n_steps=8, n_envs=3, batch_size=12, n_epochs=1, seed=0,
+                learning_rate=lambda p: 1e-3 * p, clip_range=lambda p: 0.1 + 0.1 * p)
+    model.learn(total_timesteps=4 * 24, callback=lambda loc, glob: seen.append(loc["self"].num_timesteps) or True)
+    assert seen == [24, 48, 72, 96]
+    assert model._current_progress_remaining == 0.0
+    h = model.hyper()
+    assert h.learning_rate == 0.0 and abs(h.clip_range - 0.1) < 1e-7
+    model._current_progress_remaining = 0.5
+    assert abs(model.hyper().learning_rate - 5e-4) < 1e-9 and abs(model.hyper().clip_range - 0.15) < 1e-7
+    stop = PPO("MlpPolicy", _TimeLimitVec(horizon=1000), n_steps=8, n_envs=3, batch_size=12, n_epochs=1, seed=0)
+    stop.learn(total_timesteps=10 ** 6, callback=lambda loc, glob: loc["self"].num_timesteps < 48)
+    assert stop.num_timesteps == 48                       # a callback returning False ends training
