@@ -431,7 +431,7 @@ int ph_feistel_indices(int n, unsigned long long perm_seed, int epoch, int start
  *      torch.optim.Adam step (no gradient clipping).  max_batches > 0 stops after that many minibatches (`n_batches` mode).
  *      The whole chain runs inside ONE launch of one persistent workgroup (parameters resident in LDS).
  *      stats (minibatches, PH_BC_NSTAT) or NULL: {neglogp, entropy, ent_loss, prob_true_act, l2_norm, l2_loss, loss, rows}
- *      (bc.py:305-313).  Limits: P <= 12288 parameters (F <= ~330 features). */
+ *      (bc.py:305-313).  Limit: parameters, their gradient and one 32-row tile must fit the CU's 160 KiB of LDS (F <= ~500). */
 #define PH_BC_HIDDEN 32
 #define PH_BC_NSTAT 8
 typedef struct ph_bc_layout {

@@ -1393,8 +1393,7 @@ int ph_bc_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const
   if (resolve(ctx, spec, &nd)) return 1;
   ph_bc_layout lay;
   if (ph_bc_layout_of(spec, &lay)) return 1;
-  if (lay.P > 256 * 48) return fail("ph_bc_train: more than 12288 parameters (the persistent workgroup owns 48 per thread)");
-  if (ph::bc_train_lds_bytes(nd.F, nd.L, lay.P) > 160 * 1024) return fail("ph_bc_train: working set exceeds the CU's 160 KiB of LDS");
+  if (ph::bc_train_lds_bytes(nd.F, nd.L, lay.P, nd.A) > 160 * 1024) return fail("ph_bc_train: working set exceeds the CU's 160 KiB of LDS");
   PH_HIP(ph::launch_bc_train(nd, lay, opt->params, opt->adam_m, opt->adam_v, opt->step, obs, acts, order, N, batch_size,
                              n_epochs, max_batches, *hyper, stats, ctx->stream));
   return 0;

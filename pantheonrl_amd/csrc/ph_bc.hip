@@ -7,8 +7,8 @@
 // A run is therefore a chain of thousands of tiny dependent steps (~0.3 MFLOP each).  One launch per step would spend its time
 // on launch boundaries; spreading one step over the chip would spend it on inter-workgroup hand-offs.  Here ONE persistent
 // workgroup runs the whole chain inside a single launch: the parameter vector lives in LDS from the first minibatch to the
-// last, every gradient entry is computed by the thread that owns the parameter (no gradient buffer, no reduction pass) and
-// that thread applies torch's Adam update on the spot; the moments stream through L2.  A 32x32 output tile on f32 MFMA would
+// last, every gradient entry is computed by the thread that owns the parameter (no atomics, no reduction pass) and that thread
+// applies torch's Adam update on the spot; the moments stream through L2.  A 32x32 output tile on f32 MFMA would
 // occupy one wave for 2 K cycles at the VALU's own f32 rate (guide section 3); the same tile as plain FMAs is spread over all
 // four SIMDs of the CU, so the products here are VALU loops on LDS operands.
 #include "ph_launch.h"
@@ -18,7 +18,6 @@ namespace ph {
 constexpr int BH = PH_BC_HIDDEN;       // hidden width of the shared trunk
 constexpr int BR = 32;                 // rows per tile (the reference's batch size)
 constexpr int BLD = BH + 1;            // padded leading dimension of the 32-wide activation tiles
-constexpr int BC_MAXOWN = 48;          // parameters owned per thread (P <= 256 * 48)
 
 struct BcArgs {
   NetDims nd;            // obs_kind, D, F, A, L, obs_off, act_off (lay / Lp / nchunk unused)
@@ -60,8 +59,9 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
   float* dz2s = dz1s + BR * BLD;    // [BR][BLD]
   float* zs = dz2s + BR * BLD;      // [BR][L + 1] logits -> dL/dlogits
   float* red = zs + BR * (L + 1);   // [8]
-  float* rowst = red + 8;           // [BR][4] per-row log-prob, entropy, exp(log-prob), valid
-  int* rowidx = (int*)(rowst + BR * 4);  // [BR] dataset row, -1 = padding
+  int* rowidx = (int*)(red + 8);    // [BR] dataset row, -1 = padding
+  float* gs = (float*)(rowidx + BR);   // (P) gradient of the minibatch when it spans several 32-row tiles
+  int* rowact = (int*)(gs + P);        // [BR][A] expert actions of the tile
   __shared__ float bcorr[2];        // lr / (1 - beta1^t), sqrt(1 - beta2^t)
 
   const int tid = threadIdx.x;
@@ -72,21 +72,30 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
   const int per_epoch = (a.N + a.batch - 1) / a.batch;
   int total = a.n_epochs * per_epoch;
   if (a.max_batches > 0 && a.max_batches < total) total = a.max_batches;
+  // beta^t of Adam's bias corrections as running products in fp64 (thread 0; one pow at the start instead of two per step)
+  double b1t = pow((double)a.beta1, (double)step0), b2t = pow((double)a.beta2, (double)step0);
 
+#if defined(PH_BC_PROF)
+  long long prof[16] = {0}, last = clock64();
+#define BC_STAMP(i) do { if (tid == 0) { const long long now = clock64(); prof[i] += now - last; last = now; } } while (0)
+#else
+#define BC_STAMP(i) do { } while (0)
+#endif
   for (int mb = 0; mb < total; ++mb) {
     const int ep = mb / per_epoch, b = mb - ep * per_epoch;
     const int start = b * a.batch;
     const int nb = (a.N - start < a.batch) ? a.N - start : a.batch;
     const float inv_nb = 1.0f / (float)nb;
-    float g[BC_MAXOWN];     // gradient of the parameters this thread owns (p = tid + 256 * i), summed over the batch's tiles
-#pragma unroll
-    for (int i = 0; i < BC_MAXOWN; ++i) g[i] = 0.f;
     float s_lp = 0.f, s_h = 0.f, s_pt = 0.f;   // batch sums of log-prob, entropy, prob of the true action (threads < BR)
 
     for (int t0 = 0; t0 < nb; t0 += BR) {
       // ---- tile rows and features ----
       if (tid < BR) rowidx[tid] = (t0 + tid < nb) ? a.order[(size_t)ep * a.N + start + t0 + tid] : -1;
       __syncthreads();
+      for (int e = tid; e < BR * nd.A; e += 256) {
+        const int row = rowidx[e / nd.A];
+        rowact[e] = row >= 0 ? (int)a.acts[(size_t)row * nd.A + (e % nd.A)] : 0;
+      }
       if (nd.obs_kind == PH_SPACE_BOX) {
         for (int e = tid; e < BR * F; e += 256) {
           const int r = e / F, f = e - r * F, row = rowidx[r];
@@ -105,12 +114,14 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
         }
       }
       __syncthreads();
+      BC_STAMP(0);
       const int r = tid >> 3, cg = tid & 7;   // thread (row, group of 4 hidden units)
       // ---- H1 = tanh(X W1 + b1) ----
       {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         const float* w = ps + lay.W1 + 4 * cg;
         const float* x = xs + r * FP;
+#pragma unroll 8
         for (int k = 0; k < F; ++k) {
           const float xv = x[k];
 #pragma unroll
@@ -120,6 +131,7 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
         for (int j = 0; j < 4; ++j) h1s[r * BLD + 4 * cg + j] = bc_tanh(acc[j] + ps[lay.b1 + 4 * cg + j]);
       }
       __syncthreads();
+      BC_STAMP(1);
       // ---- H2 = tanh(H1 W2 + b2) ----
       {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -134,6 +146,7 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
         for (int j = 0; j < 4; ++j) h2s[r * BLD + 4 * cg + j] = bc_tanh(acc[j] + ps[lay.b2 + 4 * cg + j]);
       }
       __syncthreads();
+      BC_STAMP(2);
       // ---- logits = H2 act_W + act_b ----
       for (int c = cg; c < L; c += 8) {
         float z = ps[lay.act_b + c];
@@ -142,6 +155,7 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
         zs[r * (L + 1) + c] = z;
       }
       __syncthreads();
+      BC_STAMP(3);
       // ---- per row: log-prob of the expert action, entropy, dL/dlogits (one lane per row; sums over action components) ----
       if (tid < BR) {
         float* z = zs + tid * (L + 1);
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
             float se = 0.f;
             for (int c = 0; c < n; ++c) se += __expf(z[lo + c] - mx);
             const float lse = mx + __logf(se);
-            int act = (int)a.acts[(size_t)row * nd.A + comp];
+            int act = rowact[tid * nd.A + comp];
             act = act < 0 ? 0 : (act >= n ? n - 1 : act);
             float h = 0.f;
             for (int c = 0; c < n; ++c) {
@@ -178,6 +192,7 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
         }
       }
       __syncthreads();
+      BC_STAMP(4);
       // ---- dZ2 = (dlogits act_W^T) * (1 - H2^2) ----
       {
 #pragma unroll
@@ -190,6 +205,7 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
         }
       }
       __syncthreads();
+      BC_STAMP(5);
       // ---- dZ1 = (dZ2 W2^T) * (1 - H1^2) ----
       {
 #pragma unroll
@@ -203,24 +219,46 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
         }
       }
       __syncthreads();
+      BC_STAMP(6);
       // ---- owner-computes gradients: every parameter's sum over the tile's rows, by the thread that will update it ----
+      {
+        // W1[f][j] and W2[k][j]: thread tid owns column j = tid & 31 of rows f = (tid >> 5) + 8 i.  The 32 values of
+        // dZ[:, j] are read once into registers; each entry is then 32 independent LDS reads and one FMA chain.
+        const int j = tid & (BH - 1), f0 = tid >> 5;
+        float d[BR];
 #pragma unroll
-      for (int i = 0; i < BC_MAXOWN; ++i) {
-        const int p = tid + 256 * i;
-        if (p >= P) break;
+        for (int rr = 0; rr < BR; ++rr) d[rr] = dz1s[rr * BLD + j];
+        for (int f = f0; f < F; f += 8) {
+          float x[BR];
+#pragma unroll
+          for (int rr = 0; rr < BR; ++rr) x[rr] = xs[rr * FP + f];
+          float s = 0.f;
+#pragma unroll
+          for (int rr = 0; rr < BR; ++rr) s = __builtin_fmaf(x[rr], d[rr], s);
+          const int p = lay.W1 + f * BH + j;
+          gs[p] = (t0 == 0) ? s : gs[p] + s;
+        }
+#pragma unroll
+        for (int rr = 0; rr < BR; ++rr) d[rr] = dz2s[rr * BLD + j];
+        for (int k = f0; k < BH; k += 8) {
+          float x[BR];
+#pragma unroll
+          for (int rr = 0; rr < BR; ++rr) x[rr] = h1s[rr * BLD + k];
+          float s = 0.f;
+#pragma unroll
+          for (int rr = 0; rr < BR; ++rr) s = __builtin_fmaf(x[rr], d[rr], s);
+          const int p = lay.W2 + k * BH + j;
+          gs[p] = (t0 == 0) ? s : gs[p] + s;
+        }
+      }
+      BC_STAMP(7);
+      for (int p = lay.b1 + tid; p < P; p += 256) {   // biases and the head: the remaining few hundred entries
+        if (p >= lay.W2 && p < lay.b2) continue;       // W2 done above
         float s = 0.f;
-        if (p < lay.b1) {                       // W1[f][j]
-          const int f = p / BH, j = p - f * BH;
-#pragma unroll 8
-          for (int rr = 0; rr < BR; ++rr) s = __builtin_fmaf(xs[rr * FP + f], dz1s[rr * BLD + j], s);
-        } else if (p < lay.W2) {                // b1[j]
+        if (p < lay.W2) {                       // b1[j]
           const int j = p - lay.b1;
 #pragma unroll 8
           for (int rr = 0; rr < BR; ++rr) s += dz1s[rr * BLD + j];
-        } else if (p < lay.b2) {                // W2[k][j]
-          const int q = p - lay.W2, k = q / BH, j = q - k * BH;
-#pragma unroll 8
-          for (int rr = 0; rr < BR; ++rr) s = __builtin_fmaf(h1s[rr * BLD + k], dz2s[rr * BLD + j], s);
         } else if (p < lay.act_W) {             // b2[j]
           const int j = p - lay.b2;
 #pragma unroll 8
@@ -234,26 +272,24 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
 #pragma unroll 8
           for (int rr = 0; rr < BR; ++rr) s += zs[rr * (L + 1) + c];
         }                                       // value_net receives no gradient from the BC loss (only the l2 term)
-        g[i] += s;
+        gs[p] = (t0 == 0) ? s : gs[p] + s;      // each entry is touched by its owner only
       }
       __syncthreads();
     }
 
+    BC_STAMP(8);
     // ---- statistics (before the update, like the reference's stats_dict) and Adam ----
     float sq = 0.f;
-#pragma unroll
-    for (int i = 0; i < BC_MAXOWN; ++i) {
-      const int p = tid + 256 * i;
-      if (p < P) sq = __builtin_fmaf(ps[p], ps[p], sq);
-    }
+    for (int p = tid; p < P; p += 256) sq = __builtin_fmaf(ps[p], ps[p], sq);
     const float l2_norm = 0.5f * block_sum(sq, red, tid);
     const float mean_lp = block_sum(tid < BR ? s_lp : 0.f, red, tid) * inv_nb;
     const float mean_h = block_sum(tid < BR ? s_h : 0.f, red, tid) * inv_nb;
     const float mean_pt = block_sum(tid < BR ? s_pt : 0.f, red, tid) * inv_nb;
     if (tid == 0) {
-      const double t = (double)(step0 + mb + 1);
-      bcorr[0] = (float)((double)a.lr / (1.0 - pow((double)a.beta1, t)));
-      bcorr[1] = (float)sqrt(1.0 - pow((double)a.beta2, t));
+      b1t *= (double)a.beta1;
+      b2t *= (double)a.beta2;
+      bcorr[0] = (float)((double)a.lr / (1.0 - b1t));
+      bcorr[1] = (float)sqrt(1.0 - b2t);
       if (a.stats) {
         float* st = a.stats + (size_t)mb * PH_BC_NSTAT;
         const float neglogp = -mean_lp, ent_loss = -a.ent_weight * mean_h, l2_loss = a.l2_weight * l2_norm;
@@ -268,13 +304,12 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
       }
     }
     __syncthreads();
+    BC_STAMP(9);
     const float step_size = bcorr[0], bc2s = bcorr[1];
-#pragma unroll
-    for (int i = 0; i < BC_MAXOWN; ++i) {
-      const int p = tid + 256 * i;
-      if (p >= P) break;
+#pragma unroll 4
+    for (int p = tid; p < P; p += 256) {
       const float w = ps[p];
-      const float gr = g[i] + a.l2_weight * w;
+      const float gr = gs[p] + a.l2_weight * w;
       const float m0 = a.adam_m[p], v0 = a.adam_v[p];
       const float m = m0 + (gr - m0) * (1.0f - a.beta1);           // exp_avg.lerp_(grad, 1 - beta1)
       const float v = v0 * a.beta2 + (1.0f - a.beta2) * gr * gr;   // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
@@ -284,12 +319,17 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
     }
     __syncthreads();
   }
+  BC_STAMP(10);
   for (int p = tid; p < P; p += 256) a.params[p] = ps[p];
   if (tid == 0) *a.step = step0 + total;
+#if defined(PH_BC_PROF)
+  if (tid == 0 && a.stats)
+    for (int i = 0; i < 16; ++i) a.stats[i] = (float)((double)prof[i] / (double)total);
+#endif
 }
 
-size_t bc_train_lds_bytes(int F, int L, int P) {
-  return sizeof(float) * (size_t)(((P + 3) & ~3) + BR * (F + 1) + 4 * BR * BLD + BR * (L + 1) + 8 + BR * 4 + BR);
+size_t bc_train_lds_bytes(int F, int L, int P, int A) {
+  return sizeof(float) * (size_t)(((P + 3) & ~3) + BR * (F + 1) + 4 * BR * BLD + BR * (L + 1) + 8 + BR + P + BR * A);
 }
 
 struct BcTrainLaunch {
@@ -321,7 +361,7 @@ hipError_t launch_bc_train(const NetDims& nd, const ph_bc_layout& lay, float* pa
   a.ent_weight = hp.ent_weight;
   a.l2_weight = hp.l2_weight;
   a.stats = stats;
-  const size_t lds = bc_train_lds_bytes(nd.F, nd.L, lay.P);
+  const size_t lds = bc_train_lds_bytes(nd.F, nd.L, lay.P, nd.A);
   static size_t allowed[64] = {0};
   int dev = 0;
   (void)hipGetDevice(&dev);

@@ -222,7 +222,7 @@ int reduce_blocks(int slab_len);
 hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_set_int(int* p, int v, hipStream_t s);
 // behavioural cloning on the shared 32-32 policy (ph_bc.hip)
-size_t bc_train_lds_bytes(int F, int L, int P);
+size_t bc_train_lds_bytes(int F, int L, int P, int A);
 hipError_t launch_bc_train(const NetDims& nd, const ph_bc_layout& lay, float* params, float* adam_m, float* adam_v, int* step,
                            const float* obs, const float* acts, const int* order, int N, int batch, int n_epochs,
                            int max_batches, const ph_bc_hyper& hp, float* stats, hipStream_t s);
