@@ -289,6 +289,12 @@ int ph_policy_forward_ragged(ph_ctx *ctx, const ph_spec *spec, const float *para
 int ph_buffer_add_reward_ragged(ph_ctx *ctx, const ph_rollout *rb, const int *pos_env, const float *reward,
                                 const unsigned char *env_mask);
 int ph_ragged_advance(ph_ctx *ctx, const ph_rollout *rb, int *pos_env, const unsigned char *record_mask);
+/* ph_buffer_compact_columns: dst (T, n, .) <- columns cols[0..n) (device int32, environment indices, any order) of src
+ * (T, E, .), all eight arrays.  A partner whose environments reach it at different rates (turn-based games, round-robin
+ * partner selection) trains on the columns that are full -- the E-environment reading of "train once n_steps of its own
+ * transitions are in the buffer" (agents.py:126) -- instead of waiting for every environment. */
+int ph_buffer_compact_columns(ph_ctx *ctx, const ph_spec *spec, const ph_rollout *src, const ph_rollout *dst,
+                              const int *cols /* device (n) */, int n);
 
 /* env-side illegal-action fix-up: action not legal -> first legal index <- pettingzoo.py:81-82.  Integer, bit-exact. */
 int ph_fix_illegal_actions(ph_ctx *ctx, int *actions /* (n) in/out */, const unsigned char *action_mask /* (n,L) */,

@@ -146,6 +146,7 @@ SIGNATURES = {
                                  _vp, _vp, _vp],
     "ph_buffer_add_reward_ragged": [_vp, C.POINTER(PhRollout), _vp, _vp, _vp],
     "ph_ragged_advance": [_vp, C.POINTER(PhRollout), _vp, _vp],
+    "ph_buffer_compact_columns": [_vp, C.POINTER(PhSpec), C.POINTER(PhRollout), C.POINTER(PhRollout), _vp, _i],
     "ph_fix_illegal_actions": [_vp, _vp, _vp, _i, _i],
     "ph_rps_step": [_vp, _vp, _vp, _vp, _vp, _i],
     "ph_liar_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],

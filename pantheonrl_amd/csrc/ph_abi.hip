@@ -381,6 +381,18 @@ int ph_buffer_add(ph_ctx* ctx, const ph_spec* spec, const ph_rollout* rb, int po
   return 0;
 }
 
+int ph_buffer_compact_columns(ph_ctx* ctx, const ph_spec* spec, const ph_rollout* src, const ph_rollout* dst,
+                              const int* cols, int n) {
+  DevGuard dev_guard(ctx);
+  if (!ctx) return fail("null ctx");
+  ph_layout lay;
+  if (layout_of(spec, &lay) || check_rb(src) || check_rb(dst)) return 1;
+  if (!cols || n <= 0 || n > src->E) return fail("ph_buffer_compact_columns: bad column list");
+  if (dst->T != src->T || dst->E != n) return fail("ph_buffer_compact_columns: destination must be (T, n)");
+  PH_HIP(ph::launch_buffer_compact(*src, *dst, cols, n, lay.D, lay.A, ctx->stream));
+  return 0;
+}
+
 int ph_buffer_add_reward(ph_ctx* ctx, const ph_rollout* rb, int pos, const float* reward,
                          const unsigned char* env_mask) {
   DevGuard dev_guard(ctx);

@@ -222,6 +222,51 @@ hipError_t launch_buffer_add(float* d_obs, float* d_act, float* d_rew, float* d_
   return hipGetLastError();
 }
 
+// columns cols[0..n) of a (T, E, .) rollout buffer -> a compact (T, n, .) buffer (all eight arrays).  A partner whose
+// environments reach it at different rates trains on the columns that are full (envs/vec.py::RaggedVecOnPolicyAgent).
+struct CompactArgs {
+  ph_rollout src, dst;
+  const int* cols;
+  int n, D, A;
+};
+__global__ void buffer_compact_kernel(CompactArgs a) {
+  const int T = a.src.T, E = a.src.E, n = a.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, g0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = g0; i < (size_t)T * n * a.D; i += stride) {
+    const size_t row = i / a.D, f = i - row * a.D, t = row / n, c = row - t * n;
+    a.dst.observations[i] = a.src.observations[(t * E + a.cols[c]) * a.D + f];
+  }
+  for (size_t i = g0; i < (size_t)T * n * a.A; i += stride) {
+    const size_t row = i / a.A, f = i - row * a.A, t = row / n, c = row - t * n;
+    a.dst.actions[i] = a.src.actions[(t * E + a.cols[c]) * a.A + f];
+  }
+  for (size_t i = g0; i < (size_t)T * n; i += stride) {
+    const size_t t = i / n, c = i - t * n, j = t * E + a.cols[c];
+    a.dst.rewards[i] = a.src.rewards[j];
+    a.dst.episode_starts[i] = a.src.episode_starts[j];
+    a.dst.values[i] = a.src.values[j];
+    a.dst.log_probs[i] = a.src.log_probs[j];
+    a.dst.advantages[i] = a.src.advantages[j];
+    a.dst.returns[i] = a.src.returns[j];
+  }
+}
+hipError_t launch_buffer_compact(const ph_rollout& src, const ph_rollout& dst, const int* cols, int n, int D, int A,
+                                 hipStream_t s) {
+  CompactArgs a;
+  a.src = src;
+  a.dst = dst;
+  a.cols = cols;
+  a.n = n;
+  a.D = D;
+  a.A = A;
+  size_t work = (size_t)src.T * n * (D > 0 ? D : 1);
+  int blocks = (int)((work + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(buffer_compact_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 __global__ void reward_add_kernel(float* __restrict__ rew_row, const float* __restrict__ reward,
                                   const unsigned char* __restrict__ env_mask, int E) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;

@@ -174,6 +174,8 @@ hipError_t launch_gae(const float* rew, const float* val, const float* es, const
 hipError_t launch_buffer_add(float* d_obs, float* d_act, float* d_rew, float* d_es, float* d_val, float* d_lp,
                              const float* obs, const float* act, const float* es, const float* val, const float* lp,
                              int E, int D, int A, hipStream_t s);
+hipError_t launch_buffer_compact(const ph_rollout& src, const ph_rollout& dst, const int* cols, int n, int D, int A,
+                                 hipStream_t s);
 hipError_t launch_reward_add_ragged(float* rewards, const int* pos_env, const float* reward, const unsigned char* mask,
                                     int T, int E, hipStream_t s);
 hipError_t launch_ragged_advance(int* pos_env, const unsigned char* mask, int T, int E, hipStream_t s);

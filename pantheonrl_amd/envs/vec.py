@@ -97,6 +97,10 @@ class RaggedVecOnPolicyAgent:
       * `episode_start` of a row = an episode ended since the previous recorded row (agents.py:176,197),
       * GAE bootstraps with V of the last recorded observation and dones = "the game ended before the next action"
         (agents.py:127-130, quirk D-1).
+    `min_full` (default E = wait for every column) lowers the trigger: the learner trains as soon as that many columns are
+    full, on exactly the full columns (compacted into a (T, n) buffer, `ph_buffer_compact_columns`), and only those columns
+    start over.  Round-robin partner selection needs this: an environment spends whole episodes with other partners, so
+    waiting for all columns starves the learner and drops the transitions that keep arriving in already-full columns.
     """
 
     def __init__(self, model):
@@ -112,6 +116,8 @@ class RaggedVecOnPolicyAgent:
         self.boundary, self.term, self.open = u8(1), u8(0), u8(0)
         self.iteration = 0
         self.num_timesteps = 0
+        self.min_full = E
+        self._compact = {}          # n -> RolloutBuffer (T, n) reused between partial updates
         self._lib, self._h = pol.ctx.lib, pol.ctx.handle
         self._spec, self._rb = C.byref(pol.spec), C.byref(rb.c_struct())
 
@@ -149,10 +155,43 @@ class RaggedVecOnPolicyAgent:
         self.term = (self.term.bool() | (m & d)).to(th.uint8)
 
     def full(self) -> bool:
-        return bool((self.pos >= self.T).all().item())
+        return int((self.pos >= self.T).sum().item()) >= min(self.min_full, self.E)
+
+    def _learn_from_columns(self, cols: th.Tensor) -> None:
+        """GAE + PPO update on the full columns `cols` only; the other columns keep filling"""
+        from ..ppo import RolloutBuffer
+        model, rb = self.model, self.model.rollout_buffer
+        pol = model.policy
+        n = int(cols.numel())
+        sub = self._compact.get(n)
+        if sub is None:
+            sub = self._compact[n] = RolloutBuffer(rb.buffer_size, rb.observation_space, rb.action_space, rb.device, pol.ctx,
+                                                   pol.spec, gae_lambda=rb.gae_lambda, gamma=rb.gamma, n_envs=n)
+        pol._bind()
+        cols32 = cols.to(th.int32).contiguous()
+        nat.check(self._lib.ph_buffer_compact_columns(self._h, self._spec, self._rb, C.byref(sub.c_struct()),
+                                                      cols32.data_ptr(), n))
+        last_v = self.values.index_select(0, cols).contiguous()
+        dones = self.term.to(th.float32).index_select(0, cols).contiguous()
+        nat.check(self._lib.ph_gae(self._h, C.byref(sub.c_struct()), last_v.data_ptr(), dones.data_ptr(), rb.gamma,
+                                   rb.gae_lambda, int(rb.gae_mode)))
+        sub.pos, sub.full = sub.buffer_size, True
+        model.rollout_buffer = sub
+        try:
+            model.train(sync_stats=False)
+        finally:
+            model.rollout_buffer = rb
+        self.pos[cols] = 0
+        self.open[cols] = 0
+        self.term[cols] = 0
+        self.iteration += 1
 
     def learn_from_buffer(self) -> None:
         model, rb = self.model, self.model.rollout_buffer
+        ready = self.pos >= self.T
+        if not bool(ready.all().item()):
+            self._learn_from_columns(th.nonzero(ready).reshape(-1))
+            return
         model.policy._bind()
         dones = self.term.to(th.float32)
         nat.check(self._lib.ph_gae(self._h, self._rb, self.values.data_ptr(), dones.data_ptr(), rb.gamma, rb.gae_lambda,

@@ -153,5 +153,8 @@ def make_rank(model, n_partners: int, steps_per_iteration: int, data_ego=None, o
     rb = model.rollout_buffer
     if rank == 0:
         return RoundRobinEgoRank(VecOnPolicyAgent(model), data_ego, obs_alt, n_partners, bonus)
-    return RoundRobinPartnerRank(RaggedVecOnPolicyAgent(model), rank - 1, n_partners, rb.n_envs, model.policy.layout.D,
-                                 steps_per_iteration)
+    agent = RaggedVecOnPolicyAgent(model)
+    # an environment is with this partner one episode in K: train on the full columns once about half of the columns that can
+    # be active at a time are full, instead of waiting K - 1 episodes for the rest
+    agent.min_full = max(1, rb.n_envs // (2 * n_partners))
+    return RoundRobinPartnerRank(agent, rank - 1, n_partners, rb.n_envs, model.policy.layout.D, steps_per_iteration)

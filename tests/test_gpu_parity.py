@@ -1373,9 +1373,9 @@ def test_round_robin_partners_one_agent_per_rank_replayed_through_multiagentenv(
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # second run: one-step episodes (every environment changes partner at every step, so all columns of a partner fill at the
-    # same rate) and 4-row partner buffers: full after 12 steps
-    for extra, port in (({}, 29561), ({"RR_T_PARTNER": "4", "RR_HORIZON": "1"}, 29562)):
+    # second run: 4-row partner buffers and 5-step episodes: environments change partner at different times, so a partner's
+    # columns fill at different rates -- it trains on its full columns (min_full) instead of waiting for all of them
+    for extra, port in (({}, 29561), ({"RR_T_PARTNER": "4"}, 29562)):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
                "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "scripts", "roundrobin_ranks.py")]
         out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env={**os.environ, **extra})
@@ -1400,3 +1400,60 @@ def test_learn_schedules_and_callback():
     stop = PPO("MlpPolicy", _TimeLimitVec(horizon=1000), n_steps=8, n_envs=3, batch_size=12, n_epochs=1, seed=0)
     stop.learn(total_timesteps=10 ** 6, callback=lambda loc, glob: loc["self"].num_timesteps < 48)
     assert stop.num_timesteps == 48                       # a callback returning False ends training
+
+
+def test_ragged_partner_trains_on_its_full_columns_only():
+    """RaggedVecOnPolicyAgent.min_full < E: the update runs on exactly the full columns (compacted, ph_buffer_compact_columns)
+    and equals -- bitwise -- the update of a fresh model whose (T, n) buffer holds those columns; the other columns keep
+    their rows and positions.  (Round-robin partner selection needs this: see DESIGN.md section 5.)"""
+    from pantheonrl_amd.envs.vec import RaggedVecOnPolicyAgent
+    from pantheonrl_amd.ppo import PPO
+    name, T, E = "overcooked", 6, 10
+    obs_s, act_s = H.CONFIGS[name]
+    env = type("E", (), dict(observation_space=H.to_space(obs_s), action_space=H.to_space(act_s), _is_dummy_space_env=True))()
+    orac = H.oracle_policy(name, seed=2)
+
+    def model(n_envs):
+        m = PPO("MlpPolicy", env, n_steps=T, n_envs=n_envs, batch_size=8, n_epochs=2, seed=0)
+        m.policy.set_flat_params(orac.flat_params())
+        m.device_permutations = True
+        return m
+    big = model(E)
+    agent = RaggedVecOnPolicyAgent(big)
+    agent.min_full = 3
+    rng = np.random.default_rng(0)
+    # environments 1, 4, 7 and 8 are asked to act at every step, the others at every third step
+    often = np.zeros(E, bool)
+    often[[1, 4, 7, 8]] = True
+    step = 0
+    while not agent.full():
+        mask = often | (step % 3 == 0)
+        agent.get_action(_dev(rng.standard_normal((E, 62)).astype(np.float32)), _dev(mask.astype(np.uint8)))
+        agent.update(_dev(rng.standard_normal(E).astype(np.float32)), _dev((rng.random(E) < 0.2).astype(np.float32)),
+                     _dev(mask.astype(np.uint8)))
+        step += 1
+    th.cuda.synchronize()
+    pos = agent.pos.cpu().numpy().copy()
+    cols = np.nonzero(pos >= T)[0]
+    assert cols.tolist() == [1, 4, 7, 8] and pos[0] < T
+    before = big.rollout_buffer.host()
+    last_v, term = agent.values.cpu().numpy().copy(), agent.term.cpu().numpy().astype(np.float32)
+    # the same update on a fresh (T, 4) model fed those columns
+    small = model(len(cols))
+    for k in ("observations", "actions", "rewards", "episode_starts", "values", "log_probs"):
+        getattr(small.rollout_buffer, k).copy_(th.as_tensor(before[k][:, cols]))
+    small.rollout_buffer.pos, small.rollout_buffer.full = T, True
+    small.rollout_buffer.compute_returns_and_advantage(last_v[cols], term[cols])
+    small.permutation_seed = big.permutation_seed
+    small.train(sync_stats=False)
+    agent.learn_from_buffer()
+    th.cuda.synchronize()
+    assert np.array_equal(big.policy.get_flat_params(), small.policy.get_flat_params())
+    assert not np.array_equal(big.policy.get_flat_params(), orac.flat_params())
+    after, pos2 = big.rollout_buffer.host(), agent.pos.cpu().numpy()
+    assert (pos2[cols] == 0).all() and np.array_equal(np.delete(pos2, cols), np.delete(pos, cols)) and agent.iteration == 1
+    rest = np.setdiff1d(np.arange(E), cols)
+    for k in ("observations", "actions", "rewards", "episode_starts", "values", "log_probs"):
+        assert np.array_equal(after[k][:, rest], before[k][:, rest]), k
+    agent.min_full = E                                          # default trigger: every column
+    assert not agent.full()
