@@ -36,6 +36,15 @@ struct BcArgs {
 
 __device__ __forceinline__ float bc_tanh(float x) { return fast_tanh(x); }
 
+// debug: -DPH_BC_PROF makes thread 0 accumulate the shader clock per phase (scripts/bc_phase_profile.py)
+#if defined(PH_BC_PROF)
+#define BC_PROF_DECL long long prof[16] = {0}, last = clock64()
+#define BC_STAMP(i) do { if (tid == 0) { const long long now = clock64(); prof[i] += now - last; last = now; } } while (0)
+#else
+#define BC_PROF_DECL do { } while (0)
+#define BC_STAMP(i) do { } while (0)
+#endif
+
 // block-wide sum of one float per thread (256 threads), result broadcast; red = 8 floats of LDS
 __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
 #pragma unroll
@@ -75,12 +84,7 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
   // beta^t of Adam's bias corrections as running products in fp64 (thread 0; one pow at the start instead of two per step)
   double b1t = pow((double)a.beta1, (double)step0), b2t = pow((double)a.beta2, (double)step0);
 
-#if defined(PH_BC_PROF)
-  long long prof[16] = {0}, last = clock64();
-#define BC_STAMP(i) do { if (tid == 0) { const long long now = clock64(); prof[i] += now - last; last = now; } } while (0)
-#else
-#define BC_STAMP(i) do { } while (0)
-#endif
+  BC_PROF_DECL;
   for (int mb = 0; mb < total; ++mb) {
     const int ep = mb / per_epoch, b = mb - ep * per_epoch;
     const int start = b * a.batch;
@@ -328,6 +332,411 @@ __global__ __launch_bounds__(256) void bc_train_kernel(BcArgs a) {
 #endif
 }
 
+
+// ---- the same chain with the five products on MFMA tiles ----------------------------------------------------------------------
+// The VALU loops above are LDS-latency bound (scripts/bc_phase_profile.py: 59 k cycles per 32-row step, of which 19 k are the
+// moments' round trip + the next rows' dependent gather, 9.6 k dZ1, 9.3 k the weight-gradient columns).  Here
+//   * X.W1, H1.W2, H2.act_W and dZ2.W2^T are split over the four waves along K (each wave 32x32 v_mfma_f32_32x32x2_f32 partial
+//     tiles over a quarter of K, summed through LDS): one MFMA instruction does 2 048 MACs for two operand reads per lane;
+//   * dW1 / dW2 / d act_W are whole 32x32 tiles over the 32 rows, dealt to the waves round-robin, stored to the gradient
+//     buffer straight from the accumulators;
+//   * the dataset rows of the NEXT tile (index -> observation / action gather, two dependent HBM round trips) are fetched into
+//     registers while the current tile computes; the index of the tile after that rides one step further ahead;
+//   * Adam's moments live in LDS beside the parameters when they fit (else they stream through L2).
+// Box or one-hot observations with D <= 128 stored components, heads up to 64 logits; other shapes take the kernel above.
+constexpr int BC_XR = 16;   // raw observation values prefetched per thread: 32 rows * D / 256
+
+struct BcTile {   // which rows of the visiting order a tile covers
+  int ep, start, t0, nb;
+};
+
+template <bool moments_in_lds>
+__global__ __launch_bounds__(256) void bc_train_mfma_kernel(BcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const NetDims& nd = a.nd;
+  const ph_bc_layout& lay = a.lay;
+  const int F = nd.F, L = nd.L, P = lay.P, D = nd.D;
+  const int Fpad = (F + 31) & ~31, XP = Fpad + 1;       // K of layer 1 padded so that a quarter of it is a multiple of 8
+  const int nLt = (L + 31) >> 5, ZP = 32 * nLt + 1;     // logits in nLt column tiles
+  const int Lk = (L + 7) & ~7;                          // K of dZ2 = dlogits . act_W^T
+  const int P4 = (P + 3) & ~3;
+  float* ps = smem;                       // (P) parameters, resident for the whole run
+  float* gs = ps + P4;                    // (P) gradient of the minibatch
+  float* ms = gs + P4;                    // (P) exp_avg     } only when moments_in_lds
+  float* vs = ms + (moments_in_lds ? P4 : 0);   // (P) exp_avg_sq
+  float* xs = vs + (moments_in_lds ? P4 : 0);   // [BR][XP] features, columns F..Fpad-1 zero
+  float* h1s = xs + BR * XP;              // [BR][BLD]
+  float* h2s = h1s + BR * BLD;
+  float* dz1s = h2s + BR * BLD;
+  float* dz2s = dz1s + BR * BLD;
+  float* zs = dz2s + BR * BLD;            // [BR][ZP] logits -> dL/dlogits (columns L..Lk-1 zero)
+  float* part = zs + BR * ZP;             // [4][BR][BLD] split-K partial tiles
+  float* red = part + 4 * BR * BLD;       // [4][4] block reduction
+  int* rowidx = (int*)(red + 16);         // [BR] dataset row of the current tile, -1 = padding
+  int* rownext = rowidx + BR;             // [BR] dataset row of the next tile
+  int* rowact = rownext + BR;             // [BR][A]
+  __shared__ float bcorr[2];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  for (int p = tid; p < P; p += 256) {
+    ps[p] = a.params[p];
+    if (moments_in_lds) {
+      ms[p] = a.adam_m[p];
+      vs[p] = a.adam_v[p];
+    }
+  }
+  for (int e = tid; e < BR * XP; e += 256) xs[e] = 0.f;
+  for (int e = tid; e < BR * ZP; e += 256) zs[e] = 0.f;
+  const int step0 = *a.step;
+  const int per_epoch = (a.N + a.batch - 1) / a.batch;
+  int total = a.n_epochs * per_epoch;
+  if (a.max_batches > 0 && a.max_batches < total) total = a.max_batches;
+  double b1t = pow((double)a.beta1, (double)step0), b2t = pow((double)a.beta2, (double)step0);
+  BC_PROF_DECL;
+
+  // flat tile sequence over (minibatch, 32-row tile)
+  auto tile_of = [&](int mb, int t0) -> BcTile {
+    BcTile t;
+    t.ep = mb / per_epoch;
+    const int b = mb - t.ep * per_epoch;
+    t.start = b * a.batch;
+    t.nb = (a.N - t.start < a.batch) ? a.N - t.start : a.batch;
+    t.t0 = t0;
+    return t;
+  };
+  auto advance = [&](int& mb, int& t0) {   // -> the tile after (mb, t0); mb == total when the run is over
+    const BcTile t = tile_of(mb, t0);
+    if (t0 + BR < t.nb) t0 += BR;
+    else { mb += 1; t0 = 0; }
+  };
+  auto index_of = [&](int mb, int t0) -> int {   // dataset row this thread (tid < BR) serves in that tile, -1 = none
+    if (tid >= BR || mb >= total) return -1;
+    const BcTile t = tile_of(mb, t0);
+    return (t0 + tid < t.nb) ? a.order[(size_t)t.ep * a.N + t.start + t0 + tid] : -1;
+  };
+  const int n_raw = BR * D;               // raw observation values of a tile, n_raw <= 256 * BC_XR
+  float xr[BC_XR];
+  int ar = 0;
+  auto gather = [&](const int* rows) {    // issue the loads of a tile's rows; nothing here waits for them
+#pragma unroll
+    for (int i = 0; i < BC_XR; ++i) {
+      const int e = tid + 256 * i;
+      xr[i] = 0.f;
+      if (e < n_raw) {
+        const int r = e / D, row = rows[r];
+        if (row >= 0) xr[i] = a.obs[(size_t)row * D + (e - r * D)];
+      }
+    }
+    ar = 0;
+    if (tid < BR * nd.A) {
+      const int row = rows[tid / nd.A];
+      if (row >= 0) ar = (int)a.acts[(size_t)row * nd.A + (tid % nd.A)];
+    }
+  };
+
+  // pipeline fill: rows of tile 0 in registers, index of tile 1 in a register
+  int mb_n = 0, t0_n = 0;                 // the tile whose rows sit in xr / ar
+  if (tid < BR) rownext[tid] = index_of(0, 0);
+  __syncthreads();
+  gather(rownext);
+  int mb_i = 0, t0_i = 0;                 // the tile whose index sits in idx_ahead
+  advance(mb_i, t0_i);
+  int idx_ahead = index_of(mb_i, t0_i);
+
+  for (int mb = 0; mb < total; ++mb) {
+    const BcTile cur = tile_of(mb, 0);
+    const int nb = cur.nb;
+    const float inv_nb = 1.0f / (float)nb;
+    float s_lp = 0.f, s_h = 0.f, s_pt = 0.f;
+    if (tid == 255) {   // this step's bias corrections (fp64, off the critical path: consumed after the statistics barrier)
+      b1t *= (double)a.beta1;
+      b2t *= (double)a.beta2;
+      bcorr[0] = (float)((double)a.lr / (1.0 - b1t));
+      bcorr[1] = (float)sqrt(1.0 - b2t);
+    }
+
+    for (int t0 = 0; t0 < nb; t0 += BR) {
+      // ---- P0: the prefetched rows land in LDS; the next tile's rows and the index after that are requested ----
+      if (tid < BR) rowidx[tid] = rownext[tid];
+      if (tid < BR * nd.A) rowact[tid] = ar;
+      if (nd.obs_kind == PH_SPACE_BOX) {
+#pragma unroll
+        for (int i = 0; i < BC_XR; ++i) {
+          const int e = tid + 256 * i;
+          if (e < n_raw) xs[(e / D) * XP + (e % D)] = xr[i];
+        }
+      } else {
+        for (int e = tid; e < BR * F; e += 256) xs[(e / F) * XP + (e % F)] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < BC_XR; ++i) {
+          const int e = tid + 256 * i;
+          if (e < n_raw) {
+            const int r = e / D, comp = e - r * D;
+            if (rownext[r] >= 0) {
+              const int lo = nd.obs_off[comp], n = nd.obs_off[comp + 1] - lo;
+              int x = (int)xr[i];
+              x = x < 0 ? 0 : (x >= n ? n - 1 : x);
+              xs[r * XP + lo + x] = 1.f;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (tid < BR) rownext[tid] = idx_ahead;      // rows of the next tile (index fetched one step ago)
+      __syncthreads();
+      mb_n = mb_i;
+      t0_n = t0_i;
+      gather(rownext);                             // consumed at the next P0
+      advance(mb_i, t0_i);
+      idx_ahead = index_of(mb_i, t0_i);            // consumed one step later
+      BC_STAMP(0);
+
+      const int r = tid >> 3, cg = tid & 7;        // thread (row, group of 4 hidden units) of the VALU epilogues
+      // ---- P1: H1 = tanh(X W1 + b1): split-K partial tiles, then the sum ----
+      {
+        f32x16 acc = {0};
+        acc = tile_mma<false, false, false>(xs, XP, ps + lay.W1, BH, 0, 0, wave * (Fpad >> 2), Fpad >> 2, acc, lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) part[(wave * BR + drow(q, lh)) * BLD + li] = acc[q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 4 * cg + j, o = r * BLD + c;
+        h1s[o] = bc_tanh(((part[o] + part[BR * BLD + o]) + (part[2 * BR * BLD + o] + part[3 * BR * BLD + o])) + ps[lay.b1 + c]);
+      }
+      __syncthreads();
+      BC_STAMP(1);
+      // ---- P2: H2 = tanh(H1 W2 + b2) ----
+      {
+        f32x16 acc = {0};
+        acc = tile_mma<false, false, false>(h1s, BLD, ps + lay.W2, BH, 0, 0, wave * 8, 8, acc, lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) part[(wave * BR + drow(q, lh)) * BLD + li] = acc[q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 4 * cg + j, o = r * BLD + c;
+        h2s[o] = bc_tanh(((part[o] + part[BR * BLD + o]) + (part[2 * BR * BLD + o] + part[3 * BR * BLD + o])) + ps[lay.b2 + c]);
+      }
+      __syncthreads();
+      BC_STAMP(2);
+      // ---- P3: logits = H2 act_W + act_b (columns >= L of a tile are garbage and never read) ----
+      for (int nt = 0; nt < nLt; ++nt) {
+        f32x16 acc = {0};
+        acc = tile_mma<false, false, false>(h2s, BLD, ps + lay.act_W, L, 0, 32 * nt, wave * 8, 8, acc, lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) part[(wave * BR + drow(q, lh)) * BLD + li] = acc[q];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cc = 4 * cg + j, c = 32 * nt + cc, o = r * BLD + cc;
+          if (c < L) zs[r * ZP + c] = ((part[o] + part[BR * BLD + o]) + (part[2 * BR * BLD + o] + part[3 * BR * BLD + o])) + ps[lay.act_b + c];
+        }
+        __syncthreads();
+      }
+      BC_STAMP(3);
+      // ---- P4: per row: log-prob of the expert action, entropy, dL/dlogits ----
+      if (tid < BR) {
+        float* z = zs + tid * ZP;
+        if (rowidx[tid] >= 0) {
+          float lp = 0.f, ent = 0.f;
+          for (int comp = 0; comp < nd.A; ++comp) {
+            const int lo = nd.act_off[comp], n = nd.act_off[comp + 1] - lo;
+            float mx = -3.0e38f;
+            for (int c = 0; c < n; ++c) mx = fmaxf(mx, z[lo + c]);
+            float se = 0.f;
+            for (int c = 0; c < n; ++c) se += __expf(z[lo + c] - mx);
+            const float lse = mx + __logf(se);
+            int act = rowact[tid * nd.A + comp];
+            act = act < 0 ? 0 : (act >= n ? n - 1 : act);
+            float h = 0.f;
+            for (int c = 0; c < n; ++c) {
+              const float lq = z[lo + c] - lse;
+              h -= __expf(lq) * lq;
+            }
+            lp += z[lo + act] - lse;
+            ent += h;
+            for (int c = 0; c < n; ++c) {
+              const float lq = z[lo + c] - lse, pc = __expf(lq);
+              z[lo + c] = -inv_nb * (((c == act) ? 1.f : 0.f) - pc) + a.ent_weight * inv_nb * pc * (lq + h);
+            }
+          }
+          s_lp += lp;
+          s_h += ent;
+          s_pt += __expf(lp);
+        } else {
+          for (int c = 0; c < L; ++c) z[c] = 0.f;
+        }
+        for (int c = L; c < Lk; ++c) z[c] = 0.f;      // K padding of the next product
+      }
+      __syncthreads();
+      BC_STAMP(4);
+      // ---- P5: dZ2 = (dlogits act_W^T) * (1 - H2^2): K = Lk is small, one wave ----
+      if (wave == 0) {
+        f32x16 acc = {0};
+        acc = tile_mma<false, true, false>(zs, ZP, ps + lay.act_W, L, 0, 0, 0, Lk, acc, lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int o = drow(q, lh) * BLD + li;
+          const float hv = h2s[o];
+          dz2s[o] = acc[q] * (1.0f - hv * hv);
+        }
+      }
+      __syncthreads();
+      BC_STAMP(5);
+      // ---- P6: dZ1 = (dZ2 W2^T) * (1 - H1^2) ----
+      {
+        f32x16 acc = {0};
+        acc = tile_mma<false, true, false>(dz2s, BLD, ps + lay.W2, BH, 0, 0, wave * 8, 8, acc, lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) part[(wave * BR + drow(q, lh)) * BLD + li] = acc[q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o = r * BLD + 4 * cg + j;
+        const float hv = h1s[o];
+        dz1s[o] = ((part[o] + part[BR * BLD + o]) + (part[2 * BR * BLD + o] + part[3 * BR * BLD + o])) * (1.0f - hv * hv);
+      }
+      __syncthreads();
+      BC_STAMP(6);
+      // ---- P7: weight gradients as whole tiles over the 32 rows, dealt to the waves; biases by single lanes ----
+      {
+        const int nW1 = Fpad >> 5, ntiles = nW1 + 1 + nLt;
+        const bool first = t0 == 0;
+        for (int ti = wave; ti < ntiles; ti += 4) {
+          f32x16 acc = {0};
+          if (ti < nW1) {                       // dW1[f][j] = sum_r X[r][f] dZ1[r][j]
+            acc = tile_mma<true, false, false>(xs, XP, dz1s, BLD, 32 * ti, 0, 0, BR, acc, lane);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const int f = 32 * ti + drow(q, lh);
+              if (f < F) {
+                const int p = lay.W1 + f * BH + li;
+                gs[p] = first ? acc[q] : gs[p] + acc[q];
+              }
+            }
+          } else if (ti == nW1) {               // dW2[k][j] = sum_r H1[r][k] dZ2[r][j]
+            acc = tile_mma<true, false, false>(h1s, BLD, dz2s, BLD, 0, 0, 0, BR, acc, lane);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const int p = lay.W2 + drow(q, lh) * BH + li;
+              gs[p] = first ? acc[q] : gs[p] + acc[q];
+            }
+          } else {                              // d act_W[k][c] = sum_r H2[r][k] dlogits[r][c]
+            const int nt = ti - nW1 - 1;
+            acc = tile_mma<true, false, false>(h2s, BLD, zs, ZP, 0, 32 * nt, 0, BR, acc, lane);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const int c = 32 * nt + li;
+              if (c < L) {
+                const int p = lay.act_W + drow(q, lh) * L + c;
+                gs[p] = first ? acc[q] : gs[p] + acc[q];
+              }
+            }
+          }
+        }
+        if (tid < 2 * BH + L) {                 // b1 | b2 | act_b: column sums
+          const float* src = tid < BH ? dz1s + tid : (tid < 2 * BH ? dz2s + (tid - BH) : zs + (tid - 2 * BH));
+          const int ld = tid < 2 * BH ? BLD : ZP;
+          float sum = 0.f;
+#pragma unroll 8
+          for (int rr = 0; rr < BR; ++rr) sum += src[rr * ld];
+          const int p = tid < BH ? lay.b1 + tid : (tid < 2 * BH ? lay.b2 + (tid - BH) : lay.act_b + (tid - 2 * BH));
+          gs[p] = first ? sum : gs[p] + sum;
+        }
+        if (first && tid < BH + 1) gs[lay.val_W + tid] = 0.f;   // value_net: no gradient from the BC loss (only l2)
+      }
+      __syncthreads();
+      BC_STAMP(7);
+    }
+
+    // ---- P8: statistics (before the update, like the reference's stats_dict) and Adam ----
+    float sq = 0.f;
+    for (int p = tid; p < P; p += 256) sq = __builtin_fmaf(ps[p], ps[p], sq);
+    float v4[4] = {sq, tid < BR ? s_lp : 0.f, tid < BR ? s_h : 0.f, tid < BR ? s_pt : 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v4[k] += __shfl_down(v4[k], off, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[wave * 4 + k] = v4[k];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float t4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t4[k] = (red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]);
+      if (a.stats) {
+        float* st = a.stats + (size_t)mb * PH_BC_NSTAT;
+        const float l2_norm = 0.5f * t4[0], mean_lp = t4[1] * inv_nb, mean_h = t4[2] * inv_nb;
+        const float neglogp = -mean_lp, ent_loss = -a.ent_weight * mean_h, l2_loss = a.l2_weight * l2_norm;
+        st[0] = neglogp;
+        st[1] = mean_h;
+        st[2] = ent_loss;
+        st[3] = t4[3] * inv_nb;
+        st[4] = l2_norm;
+        st[5] = l2_loss;
+        st[6] = neglogp + ent_loss + l2_loss;
+        st[7] = (float)nb;
+      }
+    }
+    __syncthreads();
+    BC_STAMP(8);
+    // torch's update with the two divisions and the square root on the hardware's 1-ulp v_rcp_f32 / v_sqrt_f32 (the IEEE
+    // sequences cost ~60 instructions per parameter here -- the Adam loop was the longest phase of a step); the resulting
+    // last-bit differences are far inside what 1e-3-sized Adam steps do to a near-zero gradient entry anyway
+    const float step_size = bcorr[0], inv_bc2s = __builtin_amdgcn_rcpf(bcorr[1]);
+#pragma unroll 4
+    for (int p = tid; p < P; p += 256) {
+      const float w = ps[p];
+      const float gr = gs[p] + a.l2_weight * w;
+      float m0, v0;
+      if constexpr (moments_in_lds) {
+        m0 = ms[p];
+        v0 = vs[p];
+      } else {
+        m0 = a.adam_m[p];
+        v0 = a.adam_v[p];
+      }
+      const float m = m0 + (gr - m0) * (1.0f - a.beta1);
+      const float v = v0 * a.beta2 + (1.0f - a.beta2) * gr * gr;
+      if constexpr (moments_in_lds) {
+        ms[p] = m;
+        vs[p] = v;
+      } else {
+        a.adam_m[p] = m;
+        a.adam_v[p] = v;
+      }
+      ps[p] = w - step_size * m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * inv_bc2s + a.eps);
+    }
+    __syncthreads();
+    BC_STAMP(9);
+  }
+  for (int p = tid; p < P; p += 256) {
+    a.params[p] = ps[p];
+    if (moments_in_lds) {
+      a.adam_m[p] = ms[p];
+      a.adam_v[p] = vs[p];
+    }
+  }
+  if (tid == 0) *a.step = step0 + total;
+#if defined(PH_BC_PROF)
+  if (tid == 0 && a.stats)
+    for (int i = 0; i < 16; ++i) a.stats[i] = (float)((double)prof[i] / (double)total);
+#endif
+}
+
+static size_t bc_mfma_lds_bytes(int F, int L, int P, int A, bool moments) {
+  const int Fpad = (F + 31) & ~31, XP = Fpad + 1, nLt = (L + 31) >> 5, ZP = 32 * nLt + 1, P4 = (P + 3) & ~3;
+  return sizeof(float) * (size_t)(P4 * (moments ? 4 : 2) + BR * XP + 4 * BR * BLD + BR * ZP + 4 * BR * BLD + 16 + 2 * BR + BR * A);
+}
+
 size_t bc_train_lds_bytes(int F, int L, int P, int A) {
   return sizeof(float) * (size_t)(((P + 3) & ~3) + BR * (F + 1) + 4 * BR * BLD + BR * (L + 1) + 8 + BR + P + BR * A);
 }
@@ -361,11 +770,31 @@ hipError_t launch_bc_train(const NetDims& nd, const ph_bc_layout& lay, float* pa
   a.ent_weight = hp.ent_weight;
   a.l2_weight = hp.l2_weight;
   a.stats = stats;
-  const size_t lds = bc_train_lds_bytes(nd.F, nd.L, lay.P, nd.A);
-  static size_t allowed[64] = {0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   dev = (dev >= 0 && dev < 64) ? dev : 0;
+  static int use_mfma = -1;
+  if (use_mfma < 0) {
+    const char* e = getenv("PH_BC_MFMA");
+    use_mfma = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (use_mfma && BR * nd.D <= 256 * BC_XR && BR * nd.A <= 256 && nd.L <= 64 &&
+      bc_mfma_lds_bytes(nd.F, nd.L, lay.P, nd.A, false) <= 160 * 1024) {
+    const bool moments = bc_mfma_lds_bytes(nd.F, nd.L, lay.P, nd.A, true) <= 160 * 1024;
+    const size_t lds = bc_mfma_lds_bytes(nd.F, nd.L, lay.P, nd.A, moments);
+    static size_t allowed_m[2][64] = {{0}};
+    if (lds > allowed_m[moments][dev]) {
+      hipError_t e = moments ? hipFuncSetAttribute((const void*)bc_train_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                             : hipFuncSetAttribute((const void*)bc_train_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      allowed_m[moments][dev] = lds;
+    }
+    if (moments) hipLaunchKernelGGL(bc_train_mfma_kernel<true>, dim3(1), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(bc_train_mfma_kernel<false>, dim3(1), dim3(256), lds, s, a);
+    return hipGetLastError();
+  }
+  const size_t lds = bc_train_lds_bytes(nd.F, nd.L, lay.P, nd.A);
+  static size_t allowed[64] = {0};
   if (lds > allowed[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)bc_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
