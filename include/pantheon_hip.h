@@ -364,6 +364,12 @@ typedef struct ph_liar_selfplay {
   const unsigned char *zeros8, *ones8;       /* (n) constants */
 } ph_liar_selfplay;
 int ph_liar_selfplay_step(ph_ctx *ctx, const ph_liar_selfplay *s, int ego_pos, unsigned long long counter, int deal_only);
+/* n_steps of those vectorised steps -- ego rows ego_pos .. ego_pos + n_steps - 1, step t with counter + t -- in ONE persistent
+ * launch: tables are independent, so one workgroup owns 16 tables for the whole rollout and runs the three forwards and the
+ * book-keeping of every step with workgroup barriers in place of kernel boundaries.  Bitwise the result of n_steps calls of
+ * ph_liar_selfplay_step(deal_only = 0).  Needs the 16-row one-hot forward's shape class (<= 64 observation components,
+ * <= 32 logits). */
+int ph_liar_selfplay_rollout(ph_ctx *ctx, const ph_liar_selfplay *s, int ego_pos, int n_steps, unsigned long long counter);
 
 /* Frame stack as a device ring buffer <- HistoryQueue.add / reset, wrappers.py:37-71, applied to
  * n environments: stack (n, numframes*D) f32 holds the last numframes observations NEWEST FIRST; for envs with

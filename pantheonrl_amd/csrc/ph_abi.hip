@@ -965,6 +965,68 @@ int ph_liar_selfplay_step(ph_ctx* ctx, const ph_liar_selfplay* sp, int ego_pos, 
   return 0;
 }
 
+int ph_liar_selfplay_rollout(ph_ctx* ctx, const ph_liar_selfplay* sp, int ego_pos, int n_steps, unsigned long long counter) {
+  DevGuard dev_guard(ctx);
+  if (!ctx || !sp) return fail("ph_liar_selfplay_rollout: null argument");
+  const ph_liar_selfplay& s = *sp;
+  if (s.n <= 0 || !s.spec || !s.ego_rb || !s.alt_rb) return fail("ph_liar_selfplay_rollout: incomplete description");
+  if (check_rb(s.ego_rb) || check_rb(s.alt_rb)) return 1;
+  if (s.ego_rb->E != s.n || s.alt_rb->E != s.n) return fail("ph_liar_selfplay_rollout: buffers must have E = n");
+  if (n_steps <= 0 || ego_pos < 0 || ego_pos + n_steps > s.ego_rb->T)
+    return fail("ph_liar_selfplay_rollout: ego_pos + n_steps exceeds the ego's buffer");
+  if (((uintptr_t)s.hands | (uintptr_t)s.history) % 16 ||
+      ((uintptr_t)s.ego_actions | (uintptr_t)s.alt_actions | (uintptr_t)s.obs_ego | (uintptr_t)s.obs_alt | (uintptr_t)s.obs_next |
+       (uintptr_t)s.rew1 | (uintptr_t)s.rew2) % 8)
+    return fail("ph_liar_selfplay_rollout: hands/history must be 16-byte aligned, actions/observations/rewards 8-byte aligned");
+  if (((uintptr_t)s.ego_params | (uintptr_t)s.alt_params) % 16) return fail("ph_liar_selfplay_rollout: params must be 16-byte aligned");
+  ph::FwdArgs ego, reply, opening;
+  std::memset(&ego, 0, sizeof(ego));
+  if (resolve(ctx, s.spec, &ego.nd)) return 1;
+  if (!ph::liar_rollout_eligible(ego.nd, s.n))
+    return fail("ph_liar_selfplay_rollout: the spec does not fit the 16-row one-hot forward (use ph_liar_selfplay_step)");
+  // exactly the argument records ph_liar_selfplay_step's three forwards build (ph_policy_forward / _ragged)
+  ego.params = s.ego_params;
+  ego.obs = s.obs_ego;
+  ego.n = s.n;
+  ego.seed = s.ego_seed;
+  ego.epoch = ctx->rng_epoch;
+  ego.act_i32 = s.ego_actions;
+  ego.values = s.ego_values;
+  ego.logp = s.ego_log_probs;
+  const size_t row = (size_t)ego_pos * s.n;
+  ego.rb_obs = s.ego_rb->observations + row * ego.nd.D;
+  ego.rb_act = s.ego_rb->actions + row * ego.nd.A;
+  ego.rb_rew = s.ego_rb->rewards + row;
+  ego.rb_es = s.ego_rb->episode_starts + row;
+  ego.rb_val = s.ego_rb->values + row;
+  ego.rb_logp = s.ego_rb->log_probs + row;
+  ego.es_in = s.ego_episode_start;
+  std::memset(&reply, 0, sizeof(reply));
+  reply.nd = ego.nd;
+  reply.params = s.alt_params;
+  reply.obs = s.obs_next;
+  reply.n = s.n;
+  reply.seed = s.alt_seed;
+  reply.epoch = ctx->rng_epoch;
+  reply.act_i32 = s.alt_actions;
+  reply.values = s.alt_values;
+  reply.logp = s.alt_log_probs;
+  reply.rb_obs = s.alt_rb->observations;
+  reply.rb_act = s.alt_rb->actions;
+  reply.rb_rew = s.alt_rb->rewards;
+  reply.rb_es = s.alt_rb->episode_starts;
+  reply.rb_val = s.alt_rb->values;
+  reply.rb_logp = s.alt_rb->log_probs;
+  reply.es_in = s.es_alt;
+  reply.pos_env = s.alt_pos;
+  reply.rec_mask = s.can;
+  reply.rb_T = s.alt_rb->T;
+  opening = reply;
+  opening.obs = s.obs_alt;
+  PH_HIP(ph::launch_liar_rollout(s, ego, reply, opening, n_steps, counter, ctx->rng_epoch, s.ego_rb->rewards + row, ctx->stream));
+  return 0;
+}
+
 int ph_framestack_push(ph_ctx* ctx, float* stack, const float* obs, const unsigned char* reset_mask,
                        const float* default_obs, int n, int D, int numframes) {
   DevGuard dev_guard(ctx);

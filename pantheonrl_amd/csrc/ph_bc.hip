@@ -436,7 +436,6 @@ __global__ __launch_bounds__(256) void bc_train_mfma_kernel(BcArgs a) {
   };
 
   // pipeline fill: rows of tile 0 in registers, index of tile 1 in a register
-  int mb_n = 0, t0_n = 0;                 // the tile whose rows sit in xr / ar
   if (tid < BR) rownext[tid] = index_of(0, 0);
   __syncthreads();
   gather(rownext);
@@ -486,8 +485,6 @@ __global__ __launch_bounds__(256) void bc_train_mfma_kernel(BcArgs a) {
       __syncthreads();
       if (tid < BR) rownext[tid] = idx_ahead;      // rows of the next tile (index fetched one step ago)
       __syncthreads();
-      mb_n = mb_i;
-      t0_n = t0_i;
       gather(rownext);                             // consumed at the next P0
       advance(mb_i, t0_i);
       idx_ahead = index_of(mb_i, t0_i);            // consumed one step later

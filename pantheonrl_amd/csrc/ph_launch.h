@@ -202,6 +202,11 @@ hipError_t launch_liar_sp_after_ego(const ph_liar_selfplay& s, hipStream_t st);
 hipError_t launch_liar_sp_after_reply(const ph_liar_selfplay& s, float* ego_rew_row, unsigned long long counter,
                                       const unsigned long long* epoch, int deal_only, hipStream_t st);
 hipError_t launch_liar_sp_after_opening(const ph_liar_selfplay& s, hipStream_t st);
+// persistent Liar's Dice rollout (ph_policy.hip: liar_rollout_kernel)
+bool liar_rollout_eligible(const NetDims& nd, int n);
+hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, const FwdArgs& reply, const FwdArgs& opening,
+                               int n_steps, unsigned long long counter0, const unsigned long long* epoch, float* ego_rew_row0,
+                               hipStream_t st);
 // peer-to-peer action exchange (ph_envs.hip)
 hipError_t launch_p2p_push(const ph_p2p& x, const int* local, int t, hipStream_t s);
 hipError_t launch_p2p_wait(const ph_p2p& x, int t, hipStream_t s);

@@ -7,6 +7,7 @@
 // 1 -> value net workgroup (values + the observation copy into the rollout buffer).  Each workgroup keeps the
 // 64x64 weight blocks in LDS and runs every layer as 32x32 v_mfma_f32_32x32x2_f32 tiles, one tile per wave.
 #include "ph_launch.h"
+#include "ph_liar.h"
 
 namespace ph {
 
@@ -63,14 +64,17 @@ __device__ __forceinline__ void value_row_tail(const FwdArgs& a, int g, float v)
 }
 
 // RolloutBuffer.add copies the observation (agents.py:172-173): rows [row0, row0 + nrow) by the whole workgroup
-__device__ __forceinline__ void copy_obs_rows(const FwdArgs& a, int row0, int nrow, int D) {
+__device__ __forceinline__ void copy_obs_rows(const FwdArgs& a, int row0, int nrow, int D, int tid = -1, int nt = 0) {
   if (!a.rb_obs) return;
-  const int tid = threadIdx.x;
+  if (tid < 0) {
+    tid = threadIdx.x;
+    nt = blockDim.x;
+  }
   if (!a.pos_env) {
     const size_t off = (size_t)row0 * D;
-    for (int e = tid; e < nrow * D; e += blockDim.x) a.rb_obs[off + e] = a.obs[off + e];
+    for (int e = tid; e < nrow * D; e += nt) a.rb_obs[off + e] = a.obs[off + e];
   } else {
-    for (int e = tid; e < nrow * D; e += blockDim.x) {
+    for (int e = tid; e < nrow * D; e += nt) {
       const int r = e / D, d = e - r * D;
       const long long ridx = rb_row(a, row0 + r);
       if (ridx >= 0) a.rb_obs[(size_t)ridx * D + d] = a.obs[(size_t)(row0 + r) * D + d];
@@ -636,9 +640,14 @@ __device__ __forceinline__ void head_tail32(const FwdArgs& a, const NetDims& nd,
 // observation row gather those rows (16 bytes per lane, all D loads in flight at once) and add them in component order,
 // which is the dense layer's k-ordered accumulation with the zero terms left out.  Layer 2 and the head run as in the
 // 16-row kernel above (one 16x16 output tile per wave); the head is the general Discrete / MultiDiscrete row tail.
-template <bool VALU>
-__device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// FUSED: called from a 512-thread workgroup whose lower half runs the policy net and whose upper half runs the value net of
+// the same 16 rows (liar_rollout_kernel): tid / net / row0 / LDS base come from the caller, and the value half executes the
+// barrier the policy half has around its logits so that both halves reach every workgroup barrier.
+template <bool VALU, bool FUSED = false>
+__device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in = 0, int net_in = 0, int tid_in = 0,
+                                                   float* smem_in = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+  float* smem = FUSED ? smem_in : smem_dyn;
   constexpr int R = 16, NT = 256, LDO = 33, FS = 64;
   const NetDims& nd = a.nd;
   float* xs = smem;                 // [16][LDH]  H2
@@ -653,10 +662,10 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a) {
   int* seg = aoff + 40;             // [3][32] per logit: first / last lane of its component, component index
   long long* ridxs = (long long*)(seg + 96);          // [16] rollout-buffer row of each observation row (-1 = not recorded)
 
-  const int tid = threadIdx.x;
+  const int tid = FUSED ? tid_in : (int)threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
-  const int net = blockIdx.y;
-  const int row0 = blockIdx.x * R;
+  const int net = FUSED ? net_in : (int)blockIdx.y;
+  const int row0 = FUSED ? row0_in : (int)blockIdx.x * R;
   const ph_layout& lay = nd.lay;
   const float* W1 = a.params + (net == 0 ? lay.pi_W1 : lay.vf_W1);
   const float* B1 = a.params + (net == 0 ? lay.pi_b1 : lay.vf_b1);
@@ -664,7 +673,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a) {
   const float* B2 = a.params + (net == 0 ? lay.pi_b2 : lay.vf_b2);
   const int D = nd.D;
 
-  PH_STAMP(a.prof, 0);
+  if constexpr (!FUSED) PH_STAMP(a.prof, 0);
   // Every global load that does not depend on the observations is issued here, back to back (a kernel starts with cold
   // caches: each dependent round trip costs ~1 us at this occupancy).  The observation -> feature-row loads go first.
   // (Staging the whole of W1 -- 69 KB per net for Liar's Dice -- into LDS so that the gather stays on the CU measured
@@ -685,7 +694,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a) {
   long long ridxv = -1;
   if (net == 0 && tid < R && row0 + tid < a.n && (a.rb_act || a.rb_logp)) ridxv = rb_row(a, row0 + tid);
   WStage<NT> w2r;
-  w2r.issue(W2, 0, HID);
+  w2r.issue(W2, 0, HID, tid);
   const int gr = tid >> 4, gl = tid & 15;   // gather: row gr, hidden units 4*gl .. 4*gl+3
   float b1v[4];
 #pragma unroll
@@ -710,7 +719,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a) {
   for (int i = 0; i < R * FS / NT; ++i) feat[tid + NT * i] = fv[i];
   if (net == 0 && tid < R) ridxs[tid] = ridxv;
   lds_only_barrier();  // feat visible
-  PH_STAMP(a.prof, 1);
+  if constexpr (!FUSED) PH_STAMP(a.prof, 1);
 
   // ---- layer 1: gather-sum of W1 rows in component order; everything staged for the later layers is committed while the
   // gather loads are in flight ----
@@ -723,7 +732,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a) {
     const int f = fr[u];
     w[u] = (f >= 0) ? *reinterpret_cast<const float4*>(w1l + (size_t)f * HID) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  w2r.commit(w2s);
+  w2r.commit(w2s, tid);
   if (tid < HID) b2s[tid] = bias2;
   if (net == 0) {
 #pragma unroll
@@ -767,7 +776,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a) {
     h[3] = fast_tanh(acc.w + b1v[3]);
   }
   lds_only_barrier();
-  PH_STAMP(a.prof, 3);
+  if constexpr (!FUSED) PH_STAMP(a.prof, 3);
   if (net == 0 && tid < 32) {   // component of logit `tid` (read by the head after two more barriers)
     int lo = tid, last = tid, comp = -1;
     for (int cc = 0; cc < nd.A; ++cc) {
@@ -808,7 +817,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a) {
     for (int r = 0; r < 4; ++r) xs[(4 * g + r) * LDH + 16 * wave + c] = fast_tanh(z2[r] + b);
   }
   lds_only_barrier();
-  PH_STAMP(a.prof, 5);
+  if constexpr (!FUSED) PH_STAMP(a.prof, 5);
 
   if (net == 0) {
     // ---- policy head: logits [16][32] as two 16x16 tiles (waves 0, 1), then one lane per row ----
@@ -819,7 +828,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a) {
       for (int r = 0; r < 4; ++r) outs[(4 * g + r) * LDO + 16 * wave + c] = z3[r] + b;
     }
     lds_only_barrier();
-    PH_STAMP(a.prof, 6);
+    if constexpr (!FUSED) PH_STAMP(a.prof, 6);
     {
       const int k = tid & 31, lo = seg[k], last = seg[32 + k], comp = seg[64 + k];
 #pragma unroll
@@ -829,6 +838,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a) {
       }
     }
   } else {
+    if constexpr (FUSED) lds_only_barrier();   // the policy half's barrier after its logits
     // ---- value head: wave 0, four lanes per row, quad-DPP reduction; every wave copies observations ----
     if (wave == 0) {
       const int r = lane >> 2, q = lane & 3;
@@ -841,9 +851,9 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a) {
       v = quad_sum_f(v) + hbs[0];
       if (q == 0 && row0 + r < a.n) value_row_tail(a, row0 + r, v);
     }
-    copy_obs_rows(a, row0, (a.n - row0 < R) ? a.n - row0 : R, nd.D);
+    copy_obs_rows(a, row0, (a.n - row0 < R) ? a.n - row0 : R, nd.D, tid, NT);
   }
-  PH_STAMP(a.prof, 7);
+  if constexpr (!FUSED) PH_STAMP(a.prof, 7);
 }
 
 template <bool VALU>
@@ -853,6 +863,224 @@ __global__ __launch_bounds__(256) void policy_fwd16h_kernel(FwdArgs a) {
 
 static size_t fwd16h_lds_bytes() {
   return sizeof(float) * (size_t)(2 * 16 * LDH + 2 * HID * LDH + 16 * 33 + HID + 32 + 16 * 64 + 40 + 96 + 2 * 16);
+}
+
+// ---- persistent Liar's Dice self-play rollout ------------------------------------------------------------------------------------
+// n_steps vectorised MultiAgentEnv.step calls of ph_liar_selfplay_step in ONE launch: tables are independent, so one 512-thread
+// workgroup owns 16 tables for the whole rollout -- ego forward -> move -> partner reply -> move / credit / re-deal -> partner
+// opening -> move -- with workgroup barriers where the launch-by-launch walk has kernel boundaries.  The lower half of the
+// workgroup runs the policy net of the acting agent, the upper half its value net (policy_fwd16h_body<.., FUSED>), sixteen lanes
+// run the per-table book-keeping (ph_liar.h: the very functions of the per-step kernels), so every number is bitwise what
+// 6 x n_steps launches produce; what disappears is their ~1 us per dependent cold-cache round trip and the launch boundaries.
+struct LiarRolloutArgs {
+  ph_liar_selfplay s;
+  FwdArgs ego, reply, opening;        // the three forwards of a step; ego.rb_* point at row ego_pos0
+  int n_steps;
+  unsigned long long counter0;        // step t uses counter0 + t (ego forward, dice), 2c and 2c + 1 (partner forwards)
+  const unsigned long long* epoch;
+  float* alt_rewards;
+  int alt_T;
+  float* ego_rew_row0;                // ego rewards row of step 0
+};
+
+static size_t fwd16h_lds_bytes();
+
+// The 16 tables a workgroup owns keep their whole state in LDS for the rollout: game state, the three observation arrays, the
+// action / reward / flag scratch of the step and the partner's per-table book-keeping are mirrored in at the start, the
+// argument records get pointers REBASED into the mirror (mirror - row0 * stride, so that the unchanged code indexes them with the
+// global table number through generic addressing), and everything is written back at the end.  What still goes to HBM per step
+// is what must: the rollout-buffer rows, the partner's late rewards and the value / log-prob outputs.
+struct LiarMirror {
+  // element counts per table
+  static constexpr int I_HANDS = 12, I_HIST = 24, F_OBS = 30;
+  int* hands;      // [16][12]
+  int* history;    // [16][24]
+  int* nmoves;     // [16]
+  int* alt_pos;    // [16]
+  int* ego_act;    // [16][2]
+  int* alt_act;    // [16][2]
+  float* obs_ego;  // [16][30]
+  float* obs_alt;
+  float* obs_next;
+  float* rew1;     // [16][2]
+  float* rew2;
+  float* es_alt;   // [16]
+  float* es_ego;   // [16]
+  unsigned char* u8;   // [12][16]: ego_first, alt_boundary, alt_term, alt_open, alt_acted, done1, done2, running, can,
+                       //           alt_opens, ego_opens, done
+};
+constexpr int LIAR_MIRROR_BYTES = 16 * (12 + 24 + 1 + 1 + 2 + 2) * 4 + 16 * (3 * 30 + 2 + 2 + 1 + 1) * 4 + 12 * 16;
+
+template <typename T>
+__device__ __forceinline__ T* rebase(T* mirror, int row0, int per) { return mirror - (size_t)row0 * per; }
+
+__global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, int half_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem_roll[];
+  const int tid512 = threadIdx.x, half = tid512 >> 8, tid = tid512 & 255;
+  float* sm = smem_roll + (size_t)half * half_floats;
+  const int row0 = blockIdx.x * 16;
+  const ph_liar_selfplay& g = r.s;              // the global arrays
+  const int nrow = (g.n - row0 < 16) ? g.n - row0 : 16;
+
+  // ---- mirror in ----
+  LiarMirror m;
+  {
+    int* ip = (int*)(smem_roll + 2 * (size_t)half_floats);     // 16-byte aligned: half_floats is a multiple of 4
+    m.hands = ip;
+    m.history = m.hands + 16 * 12;
+    m.nmoves = m.history + 16 * 24;
+    m.alt_pos = m.nmoves + 16;
+    m.ego_act = m.alt_pos + 16;
+    m.alt_act = m.ego_act + 32;
+    float* fp = (float*)(m.alt_act + 32);
+    m.obs_ego = fp;
+    m.obs_alt = m.obs_ego + 16 * 30;
+    m.obs_next = m.obs_alt + 16 * 30;
+    m.rew1 = m.obs_next + 16 * 30;
+    m.rew2 = m.rew1 + 32;
+    m.es_alt = m.rew2 + 32;
+    m.es_ego = m.es_alt + 16;
+    m.u8 = (unsigned char*)(m.es_ego + 16);
+  }
+  auto copy_in = [&](auto* dst, const auto* src, int per) {
+    for (int i = tid512; i < nrow * per; i += 512) dst[i] = src[(size_t)row0 * per + i];
+  };
+  copy_in(m.hands, g.hands, 12);
+  copy_in(m.history, g.history, 24);
+  copy_in(m.nmoves, g.nmoves, 1);
+  copy_in(m.alt_pos, g.alt_pos, 1);
+  copy_in(m.ego_act, g.ego_actions, 2);
+  copy_in(m.alt_act, g.alt_actions, 2);
+  copy_in(m.obs_ego, g.obs_ego, 30);
+  copy_in(m.obs_alt, g.obs_alt, 30);
+  copy_in(m.obs_next, g.obs_next, 30);
+  copy_in(m.rew1, g.rew1, 2);
+  copy_in(m.rew2, g.rew2, 2);
+  copy_in(m.es_alt, g.es_alt, 1);
+  copy_in(m.es_ego, g.ego_episode_start, 1);
+  unsigned char* gu8[12] = {g.ego_first, g.alt_boundary, g.alt_term, g.alt_open, g.alt_acted, g.done1, g.done2, g.running, g.can,
+                            g.alt_opens, g.ego_opens, g.done};
+#pragma unroll
+  for (int k = 0; k < 12; ++k)
+    if (tid512 < nrow) m.u8[16 * k + tid512] = gu8[k][row0 + tid512];
+
+  // ---- the description and the argument records, rebased into the mirror ----
+  ph_liar_selfplay s = g;
+  s.hands = rebase(m.hands, row0, 12);
+  s.history = rebase(m.history, row0, 24);
+  s.nmoves = rebase(m.nmoves, row0, 1);
+  s.alt_pos = rebase(m.alt_pos, row0, 1);
+  s.ego_actions = rebase(m.ego_act, row0, 2);
+  s.alt_actions = rebase(m.alt_act, row0, 2);
+  s.obs_ego = rebase(m.obs_ego, row0, 30);
+  s.obs_alt = rebase(m.obs_alt, row0, 30);
+  s.obs_next = rebase(m.obs_next, row0, 30);
+  s.rew1 = rebase(m.rew1, row0, 2);
+  s.rew2 = rebase(m.rew2, row0, 2);
+  s.es_alt = rebase(m.es_alt, row0, 1);
+  s.ego_episode_start = rebase(m.es_ego, row0, 1);
+  s.ego_first = rebase(m.u8 + 0 * 16, row0, 1);
+  s.alt_boundary = rebase(m.u8 + 1 * 16, row0, 1);
+  s.alt_term = rebase(m.u8 + 2 * 16, row0, 1);
+  s.alt_open = rebase(m.u8 + 3 * 16, row0, 1);
+  s.alt_acted = rebase(m.u8 + 4 * 16, row0, 1);
+  s.done1 = rebase(m.u8 + 5 * 16, row0, 1);
+  s.done2 = rebase(m.u8 + 6 * 16, row0, 1);
+  s.running = rebase(m.u8 + 7 * 16, row0, 1);
+  s.can = rebase(m.u8 + 8 * 16, row0, 1);
+  s.alt_opens = rebase(m.u8 + 9 * 16, row0, 1);
+  s.ego_opens = rebase(m.u8 + 10 * 16, row0, 1);
+  s.done = rebase(m.u8 + 11 * 16, row0, 1);
+  __syncthreads();
+
+  const int e = row0 + tid512;                  // the table lane tid512 < 16 keeps the books of
+  const bool keeper = tid512 < 16 && e < g.n;
+  // one inlined copy of the forward body: the three forwards of a step are a loop whose argument record is selected with
+  // scalar selects (three inlined copies cost 1.4 KB of scratch per lane and 649 spilled SGPRs)
+  for (int ph = 0; ph < 3 * r.n_steps; ++ph) {
+    const int t = ph / 3, f = ph - 3 * t;
+    const unsigned long long counter = r.counter0 + (unsigned long long)t;
+    const size_t row = (size_t)t * g.n;
+    FwdArgs a = (f == 0) ? r.ego : ((f == 1) ? r.reply : r.opening);
+    a.counter = (f == 0) ? counter : 2ull * counter + (unsigned long long)(f - 1);
+    if (f == 0) {
+      a.rb_obs += row * a.nd.D;
+      a.rb_act += row * a.nd.A;
+      a.rb_rew += row;
+      a.rb_es += row;
+      a.rb_val += row;
+      a.rb_logp += row;
+      a.obs = s.obs_ego;
+      a.es_in = s.ego_episode_start;
+      a.act_i32 = s.ego_actions;
+    } else {
+      a.obs = (f == 1) ? s.obs_next : s.obs_alt;
+      a.es_in = s.es_alt;
+      a.act_i32 = s.alt_actions;
+      a.pos_env = s.alt_pos;
+      a.rec_mask = s.can;
+    }
+    policy_fwd16h_body<false, true>(a, row0, half, tid, sm);
+    __syncthreads();
+    if (keeper) {
+      if (f == 0) liar_sp_after_ego_lane(s, e, r.alt_rewards, r.alt_T);
+      else if (f == 1) liar_sp_after_reply_lane(s, e, r.alt_rewards, r.alt_T, r.ego_rew_row0 + row, counter, r.epoch, 0);
+      else liar_sp_after_opening_lane(s, e);
+    }
+    __syncthreads();
+  }
+
+  // ---- mirror out ----
+  auto copy_out = [&](auto* dst, const auto* src, int per) {
+    for (int i = tid512; i < nrow * per; i += 512) dst[(size_t)row0 * per + i] = src[i];
+  };
+  copy_out(g.hands, m.hands, 12);
+  copy_out(g.history, m.history, 24);
+  copy_out(g.nmoves, m.nmoves, 1);
+  copy_out(g.alt_pos, m.alt_pos, 1);
+  copy_out(g.ego_actions, m.ego_act, 2);
+  copy_out(g.alt_actions, m.alt_act, 2);
+  copy_out(g.obs_ego, m.obs_ego, 30);
+  copy_out(g.obs_alt, m.obs_alt, 30);
+  copy_out(g.obs_next, m.obs_next, 30);
+  copy_out(g.rew1, m.rew1, 2);
+  copy_out(g.rew2, m.rew2, 2);
+  copy_out(g.es_alt, m.es_alt, 1);
+  copy_out(g.ego_episode_start, m.es_ego, 1);
+#pragma unroll
+  for (int k = 0; k < 12; ++k)
+    if (tid512 < nrow) gu8[k][row0 + tid512] = m.u8[16 * k + tid512];
+}
+
+static bool fwd16h_eligible(const NetDims& nd, int n);
+bool liar_rollout_eligible(const NetDims& nd, int n) { return fwd16h_eligible(nd, n); }
+
+hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, const FwdArgs& reply, const FwdArgs& opening,
+                               int n_steps, unsigned long long counter0, const unsigned long long* epoch, float* ego_rew_row0,
+                               hipStream_t st) {
+  LiarRolloutArgs r;
+  r.s = s;
+  r.ego = ego;
+  r.reply = reply;
+  r.opening = opening;
+  r.n_steps = n_steps;
+  r.counter0 = counter0;
+  r.epoch = epoch;
+  r.alt_rewards = s.alt_rb->rewards;
+  r.alt_T = s.alt_rb->T;
+  r.ego_rew_row0 = ego_rew_row0;
+  const size_t half = (fwd16h_lds_bytes() + 15) & ~(size_t)15, lds = 2 * half + ((LIAR_MIRROR_BYTES + 15) & ~15);
+  static bool allowed[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev = (dev >= 0 && dev < 64) ? dev : 0;
+  if (!allowed[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)liar_rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    allowed[dev] = true;
+  }
+  hipLaunchKernelGGL(liar_rollout_kernel, dim3((s.n + 15) / 16), dim3(512), lds, st, r, (int)(half / sizeof(float)));
+  return hipGetLastError();
 }
 
 // one-hot observations of at most 64 components, at most 32 logits (any number of action components)

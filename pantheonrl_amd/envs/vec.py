@@ -235,6 +235,8 @@ class VecLiarSelfPlay:
         self.ones8, self.zeros8 = u8(1), u8(0)
         self._episodes_dev = th.zeros(1, dtype=th.int64, device=dev)
         self.steps_done = 0
+        import os
+        self.persistent = self.native and os.environ.get("LIAR_PERSISTENT", "1") != "0"   # whole rollouts as one launch
         if self.native:
             self._build_native()
             self._done.fill_(1)
@@ -286,6 +288,14 @@ class VecLiarSelfPlay:
         ctx, rb = self.env.ctx, self.ego.model.rollout_buffer
         nat.check(ctx.lib.ph_liar_selfplay_step(ctx.handle, C.byref(self._desc), int(rb.pos if ego_pos < 0 else ego_pos),
                                                 int(counter), int(deal_only)))
+
+    def rollout_persistent(self, n_steps: int, first_counter: int, ego_pos: int = 0) -> None:
+        """n_steps vectorised steps as ONE persistent launch (`ph_liar_selfplay_rollout`: one workgroup owns 16 tables for the
+        whole rollout; bitwise the result of n_steps `_native_call`s with counters first_counter, first_counter + 1, ...)"""
+        self._bind()
+        ctx = self.env.ctx
+        nat.check(ctx.lib.ph_liar_selfplay_rollout(ctx.handle, C.byref(self._desc), int(ego_pos), int(n_steps),
+                                                   int(first_counter)))
 
     def _deal(self, reset_mask: th.Tensor, c: int) -> None:
         """(reference path) re-deal the tables in reset_mask; where the partner opens, it moves once"""
@@ -356,16 +366,25 @@ class VecLiarSelfPlay:
 
     def rollout_and_learn(self, n_steps: int) -> None:
         """n_steps vectorised steps, the ego's update, and the partner's whenever all its columns are full"""
-        for _ in range(n_steps):
-            self.step()
+        ego, rb = self.ego, self.ego.model.rollout_buffer
+        if self.native and self.persistent and rb.pos == 0 and n_steps == rb.buffer_size and ego.n_steps == 0:
+            self.rollout_persistent(n_steps, self.steps_done + 1, 0)
+            self.steps_done += n_steps
+            rb.pos, rb.full = n_steps, True
+            ego.n_steps += n_steps
+            ego.num_timesteps += n_steps * self.E
+            self.alt.num_timesteps += n_steps * self.E
+        else:
+            for _ in range(n_steps):
+                self.step()
         self.ego.learn_from_buffer()
         if self.alt.full():
             self.alt.learn_from_buffer()
 
 
 class LiarIterationGraph:
-    """One whole iteration of the device-resident Liar's Dice self-play as ONE hipGraph: n_steps vectorised steps (6 launches
-    each), the ego's GAE pass and its PPO update.  Everything a replay must vary is device-resident: every random stream is
+    """One whole iteration of the device-resident Liar's Dice self-play as ONE hipGraph: n_steps vectorised steps (one
+    persistent launch, or 6 launches each with LIAR_PERSISTENT=0), the ego's GAE pass and its PPO update.  Everything a replay must vary is device-resident: every random stream is
     keyed (RNG epoch word, counter) with the step-local counter baked into the graph and ONE epoch word -- shared by the
     forwards, the dice and the minibatch permutations of both learners -- advanced by the graph's last node.  The partner
     trains between replays whenever all its columns are full (the one host decision of the loop, as in
@@ -402,8 +421,11 @@ class LiarIterationGraph:
 
     def _body(self) -> None:
         sp, ego = self.sp, self.sp.ego
-        for t in range(self.T):
-            sp._native_call(t + 1, ego_pos=t)
+        if sp.persistent:
+            sp.rollout_persistent(self.T, 1, 0)      # the T steps as ONE launch (counters 1..T, as below)
+        else:
+            for t in range(self.T):
+                sp._native_call(t + 1, ego_pos=t)
         ego.compute_returns()
         ego.model.permutation_seed = self._perm_seed - 1     # train() pre-increments: the same baked seed in every replay
         ego.model.train(sync_stats=False)

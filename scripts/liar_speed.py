@@ -33,6 +33,15 @@ for _ in range(T):
 th.cuda.synchronize()
 dr = time.perf_counter() - t1
 sp.ego.learn_from_buffer()
+if native and sp.persistent:
+    alt.pos.zero_()
+    th.cuda.synchronize()
+    t3 = time.perf_counter()
+    sp.rollout_persistent(T, 1, 0)
+    th.cuda.synchronize()
+    dp = time.perf_counter() - t3
+    print(f"persistent rollout (one launch for {T} steps): {dp * 1e3:.2f} ms = {dp / T * 1e6:.1f} us per vector step")
+    alt.pos.zero_()
 if native and os.environ.get("LIAR_GRAPH", "1") != "0":
     from pantheonrl_amd.envs.vec import LiarIterationGraph  # noqa: E402
     g = LiarIterationGraph(sp, T)

@@ -1457,3 +1457,37 @@ def test_ragged_partner_trains_on_its_full_columns_only():
         assert np.array_equal(after[k][:, rest], before[k][:, rest]), k
     agent.min_full = E                                          # default trigger: every column
     assert not agent.full()
+
+
+def test_liar_persistent_rollout_is_bitwise_the_step_by_step_walk():
+    """ph_liar_selfplay_rollout (ONE launch: a workgroup owns 16 tables for all n_steps) against n_steps calls of
+    ph_liar_selfplay_step with the same counters: identical game state, observations, both rollout buffers, the partner's
+    book-keeping and -- after both learners trained on them -- identical parameters.  E = 40 leaves the last workgroup with
+    8 live tables."""
+    E, T_ego, T_alt = 40, 8, 6
+    runs = []
+    for persistent in (True, False):
+        sp, ego, alt, _ = _liar_selfplay(E, T_ego, T_alt, seed=23)
+        sp.persistent = persistent
+        alt.model.rollout_buffer.gae_mode = ego.model.rollout_buffer.gae_mode = 1
+        trained = 0
+        for _ in range(4):
+            sp.rollout_and_learn(T_ego)          # T_ego steps (one launch or 6 * T_ego), ego update, partner update when full
+            trained += alt.iteration
+        th.cuda.synchronize()
+        be, ba = ego.model.rollout_buffer.host(), alt.model.rollout_buffer.host()
+        runs.append(dict(hands=sp.env.hands.cpu().numpy(), hist=sp.env.history.cpu().numpy(), obs=sp.obs_ego.cpu().numpy(),
+                         pos=alt.pos.cpu().numpy(), flags=np.stack([t.cpu().numpy() for t in (alt.boundary, alt.term, alt.open)]),
+                         acted=sp.alt_acted.cpu().numpy(), episodes=sp.episodes, trained=alt.iteration, ego_it=ego.iteration,
+                         pe=ego.model.policy.get_flat_params(), pa=alt.model.policy.get_flat_params(),
+                         ev=ego.values.cpu().numpy(), av=alt.values.cpu().numpy(),
+                         **{"e_" + k: v for k, v in be.items()}, **{"a_" + k: v for k, v in ba.items()}))
+    a, b = runs
+    assert a["ego_it"] == 4 and a["trained"] >= 1 and a["episodes"] > E
+    pos = a["pos"]
+    for key in a:
+        x, y = a[key], b[key]
+        if key.startswith("a_") and getattr(x, "ndim", 0) >= 2:      # only the recorded rows of the ragged buffer are defined
+            rows = np.arange(x.shape[0])[:, None] < pos[None, :]
+            x, y = x[rows], y[rows]
+        assert np.array_equal(x, y), key
