@@ -383,12 +383,16 @@ class VecLiarSelfPlay:
 
 
 class LiarIterationGraph:
-    """One whole iteration of the device-resident Liar's Dice self-play as ONE hipGraph: n_steps vectorised steps (one
-    persistent launch, or 6 launches each with LIAR_PERSISTENT=0), the ego's GAE pass and its PPO update.  Everything a replay must vary is device-resident: every random stream is
-    keyed (RNG epoch word, counter) with the step-local counter baked into the graph and ONE epoch word -- shared by the
-    forwards, the dice and the minibatch permutations of both learners -- advanced by the graph's last node.  The partner
-    trains between replays whenever all its columns are full (the one host decision of the loop, as in
-    `VecLiarSelfPlay.rollout_and_learn`).  `capture=False` runs the same body launch by launch (the graph's cross-check)."""
+    """One whole iteration of the device-resident Liar's Dice self-play with everything a replay must vary resident on the device:
+    every random stream is keyed (RNG epoch word, counter) with the step-local counter baked in, and ONE epoch word -- shared by
+    the forwards, the dice and the minibatch permutations of both learners -- is advanced once per iteration.
+
+    Persistent mode (default): the rollout is ONE launch (`ph_liar_selfplay_rollout`); then the ego's GAE pass + PPO update replay
+    from a hipGraph on this object's stream while -- whenever all its columns are full, the one host decision of the loop -- the
+    partner's update runs beside it on a second stream (the general gradient kernel holds one workgroup per CU at this batch
+    size, so two learners' launches fill the CUs instead of taking turns); the epoch word is advanced after both joined.
+    LIAR_PERSISTENT=0: n_steps x 6 launches + the ego's update as one graph, the partner's update after it (round 1).
+    `capture=False` runs the same body launch by launch (the graph's cross-check)."""
 
     def __init__(self, sp: VecLiarSelfPlay, n_steps: int, capture: bool = True, warmup: int = 2):
         assert sp.native, "the graph replays the engine-side step"
@@ -396,12 +400,15 @@ class LiarIterationGraph:
         ego, alt = sp.ego, sp.alt
         assert self.T == ego.model.n_steps and ego.model.rollout_buffer.pos == 0
         self.stream = th.cuda.Stream(device=sp.dev)
+        self.side = th.cuda.Stream(device=sp.dev)
+        self._fork, self._join = th.cuda.Event(), th.cuda.Event()
         self.epoch_word = th.zeros(1, dtype=th.int64, device=sp.dev)
         for agent in (ego, alt):
             ctx = agent.model.policy.ctx
             nat.check(ctx.lib.ph_ctx_set_rng_epoch(ctx.handle, self.epoch_word.data_ptr()))
             agent.model.device_permutations = True
         self.graph_id = None
+        self.split = bool(sp.persistent)          # rollout launch | ego-update graph || partner update | epoch advance
         th.cuda.synchronize(sp.dev)
         with th.cuda.stream(self.stream):
             self._perm_seed = ego.model.permutation_seed + 1
@@ -413,26 +420,56 @@ class LiarIterationGraph:
                 sp._bind()
                 nat.check(ctx.lib.ph_graph_begin(ctx.handle))
                 try:
-                    self._body()
+                    self._update_body() if self.split else self._body()
                 finally:
                     gid = C.c_int(-1)
                     nat.check(ctx.lib.ph_graph_end(ctx.handle, C.byref(gid)))
                 self.graph_id = gid.value
 
-    def _body(self) -> None:
-        sp, ego = self.sp, self.sp.ego
-        if sp.persistent:
-            sp.rollout_persistent(self.T, 1, 0)      # the T steps as ONE launch (counters 1..T, as below)
-        else:
-            for t in range(self.T):
-                sp._native_call(t + 1, ego_pos=t)
+    def _update_body(self) -> None:
+        ego = self.sp.ego
         ego.compute_returns()
         ego.model.permutation_seed = self._perm_seed - 1     # train() pre-increments: the same baked seed in every replay
         ego.model.train(sync_stats=False)
+
+    def _body(self) -> None:
+        sp = self.sp
+        for t in range(self.T):
+            sp._native_call(t + 1, ego_pos=t)
+        self._update_body()
         ctx = sp.env.ctx
         nat.check(ctx.lib.ph_rng_epoch_advance(ctx.handle))
 
+    def _iteration_split(self, eager: bool) -> None:
+        sp, ego, alt = self.sp, self.sp.ego, self.sp.alt
+        main = th.cuda.current_stream(sp.dev)
+        sp.rollout_persistent(self.T, 1, 0)                   # the T steps as ONE launch (counters 1..T)
+        train_alt = alt.full()                                # host decision (synchronises on the rollout)
+        if train_alt:
+            self._fork.record(main)
+            self.side.wait_event(self._fork)
+            with th.cuda.stream(self.side):
+                alt.learn_from_buffer()                       # beside the ego's update
+                self._join.record(self.side)
+        sp._bind()
+        ctx = sp.env.ctx
+        if eager:
+            self._update_body()
+        else:
+            nat.check(ctx.lib.ph_graph_launch(ctx.handle, self.graph_id))
+        if train_alt:
+            main.wait_event(self._join)
+        sp._bind()
+        nat.check(ctx.lib.ph_rng_epoch_advance(ctx.handle))    # after BOTH learners drew their minibatch orders
+        ego.finish_update()
+        sp.steps_done += self.T
+        ego.num_timesteps += self.T * sp.E
+        alt.num_timesteps += self.T * sp.E
+
     def _iteration(self, eager: bool) -> None:
+        if self.split:
+            self._iteration_split(eager)
+            return
         sp, ego, alt = self.sp, self.sp.ego, self.sp.alt
         if eager:
             self._body()

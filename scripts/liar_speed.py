@@ -53,7 +53,7 @@ if native and os.environ.get("LIAR_GRAPH", "1") != "0":
         g.launch()
     th.cuda.synchronize()
     dg = (time.perf_counter() - t2) / 10
-    print(f"hipGraph iteration (rollout + ego update in one graph, partner updates between replays): {dg * 1e3:.1f} ms each -> "
+    print(f"iteration (persistent rollout launch, ego update graph || partner update on a second stream): {dg * 1e3:.1f} ms each -> "
           f"{E * T / dg:,.0f} ego steps/s")
 print(f"native={native}: {iters} iterations (rollout + updates) {dt / iters * 1e3:.1f} ms each -> {E * T * iters / dt:,.0f} ego "
       f"steps/s; rollout alone {dr / T * 1e6:.0f} us per vector step; episodes {sp.episodes}, partner updates {alt.iteration}")
