@@ -68,6 +68,33 @@ def test_bc_train_matches_oracle(name, N, epochs, l2):
     assert (d > 1e-4).mean() <= 0.01, (d > 1e-4).mean()
 
 
+@pytest.mark.parametrize("batch", [50, 7, 200])
+def test_bc_other_batch_sizes_span_several_tiles_or_part_of_one(batch):
+    """batch sizes other than the reference's 32: 50 rows = two 32-row tiles whose gradients add up, 7 rows = part of a tile,
+    200 > N = the whole data set in one minibatch of four tiles"""
+    from pantheonrl_amd.bc import BC
+    from pantheonrl_amd.common import TransitionsMinimal
+    name, N = "overcooked", 120
+    obs_s, act_s = H.CONFIGS[name]
+    rng = np.random.default_rng(4)
+    obs = H.sample_obs(obs_s, N, rng)
+    acts = rng.integers(0, 6, size=(N, 1)).astype(np.float32)
+    th.manual_seed(4)
+    orac = orc.FeedForward32Oracle(obs_s, act_s)
+    clone = BC(H.to_space(obs_s), H.to_space(act_s), expert_data=TransitionsMinimal(obs, acts[:, 0]), batch_size=batch,
+               l2_weight=1e-4)
+    clone.policy.set_flat_params(orac.flat_params())
+    orders = np.stack([np.random.default_rng(ep).permutation(N) for ep in range(2)])
+    st = clone.train(n_epochs=2, orders=orders)
+    ref = orc.bc_train(orac, obs, acts, orders, batch, ent_weight=1e-3, l2_weight=1e-4)
+    assert st.shape[0] == len(ref) == 2 * (-(-N // batch)) and [int(r) for r in st[:, 7]] == [min(batch, N - b * batch) for _ in range(2) for b in range(-(-N // batch))]
+    for i, srow in enumerate(ref):
+        for j, k in enumerate(("neglogp", "entropy", "ent_loss", "prob_true_act", "l2_norm", "l2_loss", "loss")):
+            assert abs(st[i, j] - srow[k]) <= 2e-5 + 2e-4 * abs(srow[k]), (i, k, st[i, j], srow[k])
+    d = np.abs(clone.policy.get_flat_params() - orac.flat_params())
+    assert np.median(d) <= 2e-6 and (d > 1e-4).mean() <= 0.01, (np.median(d), (d > 1e-4).mean())
+
+
 def test_bc_n_batches_mode_save_and_reconstruct(tmp_path):
     from pantheonrl_amd.bc import reconstruct_policy
     from pantheonrl_amd.common import Observation, StaticPolicyAgent
@@ -100,3 +127,16 @@ def test_bc_learns_the_expert_on_a_separable_problem():
     assert st[-10:, 0].mean() < 0.5 * st[:10, 0].mean()      # neglogp went down
     pred = clone.policy.forward(obs, deterministic=True)[0].cpu().numpy().reshape(-1)
     assert (pred == acts).mean() > 0.95
+
+
+def test_bc_valu_kernel_passes_the_same_parity_tests():
+    """PH_BC_MFMA=0 routes every shape through bc_train_kernel (the VALU-loop kernel that takes the shapes the MFMA-tile kernel
+    does not: > 128 stored observation components, > 64 logits); the switch is read once per process"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_bc.py", "-x", "-q", "-m", "gpu", "-k",
+                          "train_matches_oracle or other_batch_sizes or n_batches_mode"], cwd=root,
+                         env={**os.environ, "PH_BC_MFMA": "0"}, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
