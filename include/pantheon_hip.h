@@ -417,6 +417,49 @@ int ph_ppo_minibatch_grad(ph_ctx *ctx, const ph_spec *spec, const float *params,
                           const ph_ppo_hyper *hyper /* host */, const int *indices, int nb, float *grad_out,
                           float *stats_out, int gemm_mode);
 
+/* ---- ADAP: PPO.train() with the context term ("ADAP loss terms as fused-update variants") ------------
+ * ADAP.train() <- pantheonrl/algos/adap/adap_learn.py:229-371 is PPO.train() whose minibatch loss gains
+ *     context_loss_coeff * get_context_kl_loss(...)                         adap_learn.py:313-320, adap/util.py:97-131
+ * The rollout rows carry the context in their LAST context_size components (adap_learn.py:448-452, agent.py:117-121) and
+ * AdapPolicy is the MlpPolicy over features ++ context (adap/policies.py:104-119, 136-146), so `spec->obs` is the Box of
+ * length (environment observation + context_size).  Per minibatch: min(num_state_samples, nb) states of the minibatch
+ * (th.randperm(B)[:num_state_samples]) are re-evaluated under num_context_samples sampled contexts; the term is the mean
+ * over context pairs (a before b, itertools.combinations) of mean_s exp(-KL(pi(.|s,a) || pi(.|s,b))).
+ *   state_idx   device (n_minibatches, num_state_samples) int32 positions WITHIN each minibatch (teacher-forced
+ *               randperm; only the first min(num_state_samples, nb) of a row are read) or NULL = the head of a keyed
+ *               Feistel permutation of [0, nb) drawn in the kernel from (seed, rng epoch, minibatch number)
+ *   contexts    device (n_minibatches, num_context_samples, context_size) f32 (teacher-forced sampler) or NULL = drawn in
+ *               the kernel from a Philox stream keyed the same way, through `sampler` (adap/util.py:42-77)
+ *   context_loss, used_state_idx, used_contexts   device outputs with the shapes above ((n_minibatches) for the loss) or
+ *               NULL: the raw term and the samples each minibatch actually used
+ * n_minibatches = n_epochs * ceil(T*E / batch_size) for ph_adap_train, 1 for ph_adap_minibatch_grad.
+ * stats[.][5] (loss) includes the term; the gradient norm, the clip and the Adam step see the gradient of the whole loss.
+ * Box observations and categorical action families only; 2 <= num_context_samples <= 16. */
+#define PH_CTX_L2 0              /* "l2": uniform in [-1,1)^n scaled to unit length      util.py:42-51 */
+#define PH_CTX_UNIT_SQUARE 1     /* "unit_square": uniform in [-1,1)^n                   util.py:54-59 */
+#define PH_CTX_POSITIVE_SQUARE 2 /* "positive_square": uniform in [0,1)^n                util.py:62-67 */
+#define PH_CTX_CATEGORICAL 3     /* "categorical": one-hot                               util.py:70-77 */
+typedef struct ph_adap_loss {     /* defaults: ADAP.__init__ adap_learn.py:111-116 */
+  int context_size;               /* 3    */
+  int num_context_samples;        /* 5    */
+  int num_state_samples;          /* 32   */
+  int sampler;                    /* PH_CTX_L2 */
+  float context_loss_coeff;       /* 0.1  */
+  const int *state_idx;
+  const float *contexts;
+  unsigned long long seed;
+  float *context_loss;
+  int *used_state_idx;
+  float *used_contexts;
+} ph_adap_loss;
+int ph_adap_train(ph_ctx *ctx, const ph_spec *spec, const ph_opt_state *opt, const ph_rollout *rb,
+                  const ph_ppo_hyper *hyper /* host */, int n_epochs, int batch_size, const int *perms,
+                  unsigned long long perm_seed, float *stats, int gemm_mode, const ph_adap_loss *adap /* host */);
+/* ph_ppo_minibatch_grad with the context term: grad_out = d (ppo loss + coeff * context loss) / d params */
+int ph_adap_minibatch_grad(ph_ctx *ctx, const ph_spec *spec, const float *params, const ph_rollout *rb,
+                           const ph_ppo_hyper *hyper /* host */, const int *indices, int nb, float *grad_out,
+                           float *stats_out, int gemm_mode, const ph_adap_loss *adap /* host */);
+
 /* Measurement hook for bench.py's roofline: enqueue ONLY the ppo_grad kernel (the dominant kernel of PPO.train) `reps`
  * times for the first minibatch (size min(batch_size, T*E), in-kernel permutation) between two HIP events on the ctx
  * stream; *avg_ms_out = mean launch duration.  Optimizer state is not touched.  Synchronises. */

@@ -370,17 +370,78 @@ def ppo_minibatch_loss(policy: MlpPolicyOracle, mb: dict, hp: PPOHyper):
     return loss, stats
 
 
+# --------------------------------------------------------------------------------------
+# ADAP's context term (pantheonrl/algos/adap): PPO loss + context_loss_coeff * context loss
+# --------------------------------------------------------------------------------------
+def adap_sample_contexts(sampler: str, ctx_size: int, num: int, uniforms: np.ndarray) -> np.ndarray:
+    """The SAMPLERS of adap/util.py:42-77 with th.rand teacher-forced by ``uniforms`` (num, ctx_size) in [0,1):
+    "l2": 2u-1 scaled to unit length (util.py:42-51), "unit_square": 2u-1 (54-59), "positive_square": u (62-67),
+    "categorical": one-hot at floor(u[:,0] * ctx_size) (70-77: th.randint teacher-forced by the first uniform)."""
+    u = th.as_tensor(np.asarray(uniforms, np.float32)).reshape(num, ctx_size)
+    if sampler == "l2":
+        c = u * 2 - 1
+        c = c / (th.sum(c ** 2, dim=-1).reshape(num, 1)) ** (1 / 2)
+    elif sampler == "unit_square":
+        c = u * 2 - 1
+    elif sampler == "positive_square":
+        c = u
+    elif sampler == "categorical":
+        c = th.zeros(num, ctx_size)
+        c[th.arange(num), th.clamp((u[:, 0] * ctx_size).long(), max=ctx_size - 1)] = 1
+    else:
+        raise ValueError(sampler)
+    return c.numpy()
+
+
+@dataclass
+class AdapTerm:
+    """ADAP.__init__ defaults adap_learn.py:111-116; per-minibatch samples teacher-force th.randperm and the sampler."""
+    context_size: int = 3
+    context_loss_coeff: float = 0.1
+    state_idx: Optional[Sequence[np.ndarray]] = None    # [minibatch] -> (<= num_state_samples,) positions in the minibatch
+    contexts: Optional[Sequence[np.ndarray]] = None     # [minibatch] -> (num_context_samples, context_size)
+
+
+def adap_context_loss(policy: MlpPolicyOracle, observations: th.Tensor, context_size: int, state_idx, contexts) -> th.Tensor:
+    """``get_context_kl_loss`` (adap/util.py:97-131): the observations carry the rollout's context in their last
+    ``context_size`` components (adap_learn.py:448-452); the sampled states are re-evaluated under every sampled context
+    (AdapPolicy._get_latent: features ++ context, adap/policies.py:104-119) and the loss is the mean over context pairs
+    (a, b), a before b, of mean_s exp(-KL(pi(.|s,a) || pi(.|s,b)))."""
+    from itertools import combinations
+    original = observations[:, :-context_size]
+    states = original[th.as_tensor(np.asarray(state_idx, np.int64))]
+    n = states.shape[0]
+    dists = []
+    for c in np.asarray(contexts, np.float32):
+        feats = th.cat((states, th.as_tensor(c).reshape(1, -1).repeat(n, 1)), dim=1)
+        dists.append([th.distributions.Categorical(logits=z) for z in policy._split(policy.logits(feats))])
+    cls = []
+    for a, b in combinations(dists, 2):
+        # util.py:16-39: MultiCategorical -> sum of the per-component KLs; Categorical -> torch's kl_divergence
+        kl = sum(th.distributions.kl.kl_divergence(p, q) for p, q in zip(a, b))
+        cls.append(th.mean(th.exp(-kl)))
+    return sum(cls) / len(cls)
+
+
 def ppo_train(policy: MlpPolicyOracle, buf: RolloutBufferOracle, hp: PPOHyper,
-              perms: Optional[Sequence[np.ndarray]] = None) -> List[dict]:
-    """SB3 ``PPO.train()``.  ``perms[epoch]`` teacher-forces ``np.random.permutation``."""
+              perms: Optional[Sequence[np.ndarray]] = None, adap: Optional[AdapTerm] = None) -> List[dict]:
+    """SB3 ``PPO.train()``.  ``perms[epoch]`` teacher-forces ``np.random.permutation``.  With ``adap`` the
+    loss of every minibatch gains ``context_loss_coeff * context_loss`` (ADAP.train, adap_learn.py:313-320)."""
     for g in policy.optimizer.param_groups:
         g["lr"] = hp.learning_rate
     all_stats: List[dict] = []
     continue_training = True
+    mbi = -1
     for epoch in range(hp.n_epochs):
         idx = None if perms is None else np.asarray(perms[epoch])
         for mb in buf.get(hp.batch_size, idx):
+            mbi += 1
             loss, stats = ppo_minibatch_loss(policy, mb, hp)
+            if adap is not None:
+                cl = adap_context_loss(policy, mb["observations"], adap.context_size, adap.state_idx[mbi], adap.contexts[mbi])
+                loss = loss + adap.context_loss_coeff * cl
+                stats["context_loss"] = cl.item()
+                stats["loss"] = loss.item()
             if hp.target_kl is not None and stats["approx_kl"] > 1.5 * hp.target_kl:
                 continue_training = False
                 stats["stopped"] = True

@@ -8,5 +8,6 @@ from . import _native  # noqa: F401
 from .common import (Agent, DummyEnv, MultiAgentEnv, Observation, OnPolicyAgent, PlayerException,  # noqa: F401
                      SimultaneousEnv, StaticPolicyAgent, TurnBasedEnv)
 from .ppo import PPO, ActorCriticPolicy, RolloutBuffer  # noqa: F401
+from .adap import ADAP, AdapAgent, AdapPolicy  # noqa: F401
 
 __version__ = "0.1.0"

@@ -61,6 +61,17 @@ class PhBcHyper(C.Structure):
 
 PH_BC_HIDDEN = 32
 PH_BC_NSTAT = 8
+
+
+class PhAdapLoss(C.Structure):
+    """ph_adap_loss: ADAP's context term (adap_learn.py:111-116, adap/util.py:97-131)"""
+    _fields_ = [("context_size", C.c_int), ("num_context_samples", C.c_int), ("num_state_samples", C.c_int),
+                ("sampler", C.c_int), ("context_loss_coeff", C.c_float), ("state_idx", C.c_void_p), ("contexts", C.c_void_p),
+                ("seed", C.c_ulonglong), ("context_loss", C.c_void_p), ("used_state_idx", C.c_void_p),
+                ("used_contexts", C.c_void_p)]
+
+
+CONTEXT_SAMPLERS = {"l2": 0, "unit_square": 1, "positive_square": 2, "categorical": 3}
 BC_STAT_NAMES = ("neglogp", "entropy", "ent_loss", "prob_true_act", "l2_norm", "l2_loss", "loss", "rows")
 
 
@@ -174,6 +185,10 @@ SIGNATURES = {
     "ph_selfplay_rollout_p2p": [_vp, _i, C.POINTER(PhStepCall), _i, _vp, C.POINTER(PhP2P)],
     "ph_ppo_minibatch_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _vp, _i, _vp,
                               _vp, _i],
+    "ph_adap_train": [_vp, C.POINTER(PhSpec), C.POINTER(PhOptState), C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i,
+                      _vp, _ull, _vp, _i, C.POINTER(PhAdapLoss)],
+    "ph_adap_minibatch_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _vp, _i, _vp,
+                               _vp, _i, C.POINTER(PhAdapLoss)],
     "ph_bench_ppo_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i, _i,
                           C.POINTER(C.c_float)],
     "ph_bench_gae": [_vp, C.POINTER(PhRollout), _vp, _vp, _d, _d, _i, _i, C.POINTER(C.c_float)],

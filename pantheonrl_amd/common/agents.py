@@ -90,7 +90,7 @@ class OnPolicyAgent(Agent):
 
         fused = record and hasattr(model.policy, "forward_and_store")
         if fused:  # forward + RolloutBuffer.add(reward=0) in one launch
-            shaped = np.asarray(raw_obs).reshape((-1,) + tuple(buf.obs_shape))
+            shaped = self._shape_obs(raw_obs, buf)
             act_t, values, log_probs = model.policy.forward_and_store(
                 shaped, buf, self._last_episode_starts,
                 action_mask=None if mask is None else np.asarray(mask).reshape(shaped.shape[0], -1))
@@ -110,6 +110,10 @@ class OnPolicyAgent(Agent):
         self.num_timesteps += 1
         self.values = values
         return clip_actions(actions, model)[0]
+
+    def _shape_obs(self, raw_obs, buf) -> np.ndarray:
+        """the observation as rows for the policy (AdapAgent: rows without the context, which the policy appends)"""
+        return np.asarray(raw_obs).reshape((-1,) + tuple(buf.obs_shape))
 
     def update(self, reward: float, done: bool) -> None:
         buf = self.model.rollout_buffer

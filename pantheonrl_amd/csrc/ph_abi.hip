@@ -58,6 +58,10 @@ struct ph_ctx {
   size_t advpart_cap = 0;
   int* perm_idx = nullptr;   // (n_epochs, N) minibatch order of the current train() call, written by adv_stats
   size_t perm_idx_cap = 0;
+  float* adap_extra = nullptr;   // [workgroups][P] gradient slabs of ADAP's context term
+  size_t adap_extra_cap = 0;
+  float* adap_loss = nullptr;    // [workgroups] partial sums of the raw term
+  size_t adap_loss_cap = 0;
   float* scalars = nullptr;  // [4]
   int* stop_flag = nullptr;  // [1]
   std::vector<SpecCache> specs;
@@ -268,7 +272,8 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (s.slab_map) (void)hipFree(s.slab_map);
     if (s.act_off) (void)hipFree(s.act_off);
   }
-  void* ptrs[] = {ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->scalars, ctx->stop_flag};
+  void* ptrs[] = {ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->scalars, ctx->stop_flag,
+                  ctx->adap_extra, ctx->adap_loss};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1109,7 +1114,71 @@ struct TrainPlan {
   float* stats;
   int n_epochs, batch_size, gemm_mode, N, n_mb, P;
   uint32_t hb;
+  const ph_adap_loss* adap = nullptr;   // ADAP's context term, or null = plain PPO
 };
+
+// ---- ADAP's context term: validation, workspace, the launch next to a minibatch's gradient launch ----
+int adap_check(ph_ctx* ctx, const ph::NetDims& nd, const ph_adap_loss* ad, const char* who) {
+  const std::string w(who);
+  if (nd.obs_kind != PH_SPACE_BOX) return fail(w + ": the context term needs Box observations (observation ++ context)");
+  if (ad->context_size <= 0 || ad->context_size >= nd.F) return fail(w + ": context_size must be in (0, observation length)");
+  if (ad->num_context_samples < 2 || ad->num_context_samples > ph::ADAP_ROWS)
+    return fail(w + ": num_context_samples must be in [2, 16]");
+  if (ad->num_state_samples <= 0) return fail(w + ": num_state_samples must be positive");
+  if (ad->sampler < PH_CTX_L2 || ad->sampler > PH_CTX_CATEGORICAL) return fail(w + ": unknown context sampler");
+  if (ph::adap_lds_bytes(nd, ad->num_context_samples, ad->context_size) > 160 * 1024)
+    return fail(w + ": observation / action space too large for the context kernel's LDS tile");
+  const size_t nwg = (size_t)ph::adap_workgroups(ad->num_context_samples, ad->num_state_samples);
+  if (ctx->capturing) {
+    if (nwg * nd.lay.P > ctx->adap_extra_cap || nwg > ctx->adap_loss_cap)
+      return fail("workspace would grow inside graph capture: run the same call once outside capture first");
+    return 0;
+  }
+  if (ensure(ctx->adap_extra, ctx->adap_extra_cap, nwg * nd.lay.P)) return 1;
+  if (ensure(ctx->adap_loss, ctx->adap_loss_cap, nwg)) return 1;
+  return 0;
+}
+
+// the context launch of minibatch number `mbi` (rows idx[0..nb)); fills the reduce launch's additional-term fields
+int adap_launch(ph_ctx* ctx, const ph::NetDims& nd, const float* params, const ph_rollout* rb, const ph_adap_loss* ad,
+                const int* idx, int nb, int mbi, ph::ReduceArgs* r) {
+  const int C = ad->num_context_samples, S = ad->num_state_samples, cs = ad->context_size;
+  const int n_states = S < nb ? S : nb;   // util.py:106-108
+  const int nwg = ph::adap_workgroups(C, n_states);
+  ph::AdapArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.nd = nd;
+  a.params = params;
+  a.rb_obs = rb->observations;
+  a.T = rb->T;
+  a.E = rb->E;
+  a.idx = idx;
+  a.nb = nb;
+  a.ctx_size = cs;
+  a.n_ctx = C;
+  a.n_states = n_states;
+  a.sampler = ad->sampler;
+  a.coef = ad->context_loss_coeff;
+  a.state_idx = ad->state_idx ? ad->state_idx + (size_t)mbi * S : nullptr;
+  a.contexts = ad->contexts ? ad->contexts + (size_t)mbi * C * cs : nullptr;
+  a.seed = ad->seed;
+  a.epoch = ctx->rng_epoch;
+  a.mbi = (uint32_t)mbi;
+  a.nb_hb = ph::feistel_half_bits((uint32_t)nb);
+  a.extra = ctx->adap_extra;
+  a.loss_part = ctx->adap_loss;
+  a.used_state_idx = ad->used_state_idx ? ad->used_state_idx + (size_t)mbi * S : nullptr;
+  a.used_contexts = ad->used_contexts ? ad->used_contexts + (size_t)mbi * C * cs : nullptr;
+  a.stop_flag = ctx->stop_flag;
+  PH_HIP(ph::launch_adap_context(a, nwg, ctx->stream));
+  r->extra = ctx->adap_extra;
+  r->n_extra = nwg;
+  r->extra_loss = ctx->adap_loss;
+  r->extra_norm = 1.0f / (float)((C * (C - 1) / 2) * n_states);
+  r->extra_coef = ad->context_loss_coeff;
+  r->extra_loss_out = ad->context_loss ? ad->context_loss + mbi : nullptr;
+  return 0;
+}
 
 // validation, workspace, stop-flag reset and the advantage statistics / minibatch order of every minibatch
 int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const ph_rollout* rb,
@@ -1206,6 +1275,11 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
   r.stop_flag = ctx->stop_flag;
   r.step = t.opt->step;
   r.scalars = ctx->scalars;
+  if (t.adap) {
+    const int ep = mbi / t.n_mb, start = (mbi - ep * t.n_mb) * t.batch_size;
+    const int* idx = (t.perms ? t.perms : ctx->perm_idx) + (size_t)ep * t.N + start;
+    if (adap_launch(ctx, t.nd, t.opt->params, t.rb, t.adap, idx, pl.nb, mbi, &r)) return 1;
+  }
   PH_HIP(ph::launch_ppo_reduce(r, s));
 
   ph::AdamArgs ad;
@@ -1231,18 +1305,36 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
 
 }  // namespace
 
-int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const ph_rollout* rb,
-                 const ph_ppo_hyper* hp, int n_epochs, int batch_size, const int* perms,
-                 unsigned long long perm_seed, float* stats, int gemm_mode) {
-  DevGuard dev_guard(ctx);
+namespace {
+int train_run(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const ph_rollout* rb, const ph_ppo_hyper* hp,
+              int n_epochs, int batch_size, const int* perms, unsigned long long perm_seed, float* stats, int gemm_mode,
+              const ph_adap_loss* adap) {
   TrainPlan t;
   if (train_prepare(t, ctx, spec, opt, rb, hp, n_epochs, batch_size, perms, perm_seed, stats, gemm_mode)) return 1;
+  if (adap && adap_check(ctx, t.nd, adap, "ph_adap_train")) return 1;
+  t.adap = adap;
   for (int mbi = 0; mbi < n_epochs * t.n_mb; ++mbi) {
     MbPlan pl;
     if (train_launch_grad(t, mbi, &pl)) return 1;
     if (train_launch_step(t, mbi, pl)) return 1;
   }
   return 0;
+}
+}  // namespace
+
+int ph_ppo_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const ph_rollout* rb,
+                 const ph_ppo_hyper* hp, int n_epochs, int batch_size, const int* perms,
+                 unsigned long long perm_seed, float* stats, int gemm_mode) {
+  DevGuard dev_guard(ctx);
+  return train_run(ctx, spec, opt, rb, hp, n_epochs, batch_size, perms, perm_seed, stats, gemm_mode, nullptr);
+}
+
+int ph_adap_train(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const ph_rollout* rb,
+                  const ph_ppo_hyper* hp, int n_epochs, int batch_size, const int* perms,
+                  unsigned long long perm_seed, float* stats, int gemm_mode, const ph_adap_loss* adap) {
+  DevGuard dev_guard(ctx);
+  if (!adap) return fail("ph_adap_train: null context-term description");
+  return train_run(ctx, spec, opt, rb, hp, n_epochs, batch_size, perms, perm_seed, stats, gemm_mode, adap);
 }
 
 int ph_ppo_train_multi(const ph_train_call* calls, int n_calls) {
@@ -1280,10 +1372,31 @@ int ph_ppo_train_multi(const ph_train_call* calls, int n_calls) {
   return 0;
 }
 
+namespace {
+int minibatch_grad_run(ph_ctx* ctx, const ph_spec* spec, const float* params, const ph_rollout* rb, const ph_ppo_hyper* hp,
+                       const int* indices, int nb, float* grad_out, float* stats_out, int gemm_mode,
+                       const ph_adap_loss* adap);
+}  // namespace
+
 int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, const ph_rollout* rb,
                           const ph_ppo_hyper* hp, const int* indices, int nb, float* grad_out, float* stats_out,
                           int gemm_mode) {
   DevGuard dev_guard(ctx);
+  return minibatch_grad_run(ctx, spec, params, rb, hp, indices, nb, grad_out, stats_out, gemm_mode, nullptr);
+}
+
+int ph_adap_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, const ph_rollout* rb,
+                           const ph_ppo_hyper* hp, const int* indices, int nb, float* grad_out, float* stats_out,
+                           int gemm_mode, const ph_adap_loss* adap) {
+  DevGuard dev_guard(ctx);
+  if (!adap) return fail("ph_adap_minibatch_grad: null context-term description");
+  return minibatch_grad_run(ctx, spec, params, rb, hp, indices, nb, grad_out, stats_out, gemm_mode, adap);
+}
+
+namespace {
+int minibatch_grad_run(ph_ctx* ctx, const ph_spec* spec, const float* params, const ph_rollout* rb, const ph_ppo_hyper* hp,
+                       const int* indices, int nb, float* grad_out, float* stats_out, int gemm_mode,
+                       const ph_adap_loss* adap) {
   if (!ctx) return fail("null ctx");
   if (!params || !hp || !indices || !grad_out) return fail("ph_ppo_minibatch_grad: null argument");
   if ((uintptr_t)params % 16 != 0) return fail("ph_ppo_minibatch_grad: params must be 16-byte aligned");
@@ -1338,9 +1451,14 @@ int ph_ppo_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const float* params,
   r.stop_flag = ctx->stop_flag;
   r.step = nullptr;
   r.scalars = ctx->scalars;
+  if (adap) {
+    if (adap_check(ctx, nd, adap, "ph_adap_minibatch_grad")) return 1;
+    if (adap_launch(ctx, nd, params, rb, adap, indices, nb, 0, &r)) return 1;
+  }
   PH_HIP(ph::launch_ppo_reduce(r, s));
   return 0;
 }
+}  // namespace
 
 int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, const ph_rollout* rb,
                       const ph_ppo_hyper* hp, int batch_size, int reps, int gemm_mode, float* avg_ms_out) {

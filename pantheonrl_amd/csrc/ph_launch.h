@@ -148,6 +148,13 @@ struct ReduceArgs {
   int* stop_flag;
   int* step;             // optimizer step counter (incremented here when the step will be applied), may be null
   float* scalars;        // [4]: kl, applied, stop-requested
+  // an additional loss term whose gradient arrives as n_extra slabs in canonical parameter order (ADAP's context loss)
+  const float* extra = nullptr;       // [n_extra][P], already scaled by the term's coefficient
+  int n_extra = 0;
+  const float* extra_loss = nullptr;  // [n_extra] partial sums of the raw term
+  float extra_norm = 0.f;             // raw term = extra_norm * sum(extra_loss)
+  float extra_coef = 0.f;             // loss statistic += extra_coef * raw term
+  float* extra_loss_out = nullptr;    // [1] raw term of this minibatch, or null
 };
 
 struct AdamArgs {
@@ -204,6 +211,33 @@ hipError_t launch_liar_sp_after_reply(const ph_liar_selfplay& s, float* ego_rew_
 hipError_t launch_liar_sp_after_opening(const ph_liar_selfplay& s, hipStream_t st);
 // persistent Liar's Dice rollout (ph_policy.hip: liar_rollout_kernel)
 bool liar_rollout_eligible(const NetDims& nd, int n);
+
+// ---- ADAP's context loss (ph_adap.hip) ------------------------------------------------------------------------------
+constexpr int ADAP_ROWS = 16;   // (state, context) rows of one workgroup
+struct AdapArgs {
+  NetDims nd;
+  const float* params;
+  const float* rb_obs;
+  int T, E;
+  const int* idx;          // env-major index of every minibatch element (nb)
+  int nb;
+  int ctx_size, n_ctx, n_states;   // n_states = min(num_state_samples, nb)
+  int sampler;             // PH_CTX_*
+  float coef;              // context_loss_coeff
+  const int* state_idx;    // (n_states) positions in the minibatch, or null = head of a keyed permutation of [0, nb)
+  const float* contexts;   // (n_ctx, ctx_size), or null = drawn in the kernel
+  uint64_t seed;
+  const unsigned long long* epoch;
+  uint32_t mbi, nb_hb;     // minibatch number within the train() call; Feistel half width for nb
+  float* extra;            // [gridDim.x][P]
+  float* loss_part;        // [gridDim.x]
+  int* used_state_idx;     // (n_states) out or null
+  float* used_contexts;    // (n_ctx, ctx_size) out or null
+  const int* stop_flag;
+};
+int adap_workgroups(int n_ctx, int n_states);
+size_t adap_lds_bytes(const NetDims& nd, int n_ctx, int ctx_size);
+hipError_t launch_adap_context(const AdapArgs& a, int nwg, hipStream_t s);
 hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, const FwdArgs& reply, const FwdArgs& opening,
                                int n_steps, unsigned long long counter0, const unsigned long long* epoch, float* ego_rew_row0,
                                hipStream_t st);

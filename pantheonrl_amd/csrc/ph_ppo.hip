@@ -635,8 +635,12 @@ __global__ __launch_bounds__(RED_PARAMS * RED_GROUPS) void ppo_reduce_kernel(Red
       for (int j = 0; j < RED_GROUPS; ++j) g += gsum[j][tid];
       // canonical slabs: position = parameter index; register-order slabs (ppo_grad_fast_kernel): through the table
       const int dst = p < a.slab_len ? (a.map ? a.map[p] : p) : -1;
-      if (dst >= 0) a.grad[dst] = g;
-      else g = 0.f;
+      if (dst >= 0) {
+        for (int k = 0; k < a.n_extra; ++k) g += a.extra[(size_t)k * a.P + dst];   // the additional term, fixed order
+        a.grad[dst] = g;
+      } else {
+        g = 0.f;
+      }
     }
     float q = g * g;
     for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
@@ -673,6 +677,13 @@ __global__ __launch_bounds__(RED_PARAMS * RED_GROUPS) void ppo_reduce_kernel(Red
         a.stats_out[5] = pl_ + a.ent_coef * el + a.vf_coef * vl;
         a.stats_out[6] = 0.f;
         a.stats_out[7] = stop ? 0.f : 1.f;
+      }
+      if (a.n_extra > 0) {   // raw additional term of this minibatch (adap_learn.py:313-320: loss += coeff * context_loss)
+        float raw = 0.f;
+        for (int k = 0; k < a.n_extra; ++k) raw += a.extra_loss[k];
+        raw *= a.extra_norm;
+        if (a.extra_loss_out) *a.extra_loss_out = raw;
+        if (a.stats_out) a.stats_out[5] += a.extra_coef * raw;
       }
     }
   }

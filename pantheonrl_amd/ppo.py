@@ -444,9 +444,7 @@ class PPO:
         hp = self.hyper()
         pol._bind()
         self.permutation_seed += 1
-        nat.check(pol.ctx.lib.ph_ppo_train(pol.ctx.handle, C.byref(pol.spec), C.byref(opt), C.byref(rb.c_struct()),
-                                           C.byref(hp), int(self.n_epochs), int(self.batch_size), nat.ptr(perm_t),
-                                           int(self.permutation_seed), stats.data_ptr(), int(pol.gemm_mode)))
+        self._train_native(pol, opt, rb, hp, perm_t, stats)
         self._n_updates += self.n_epochs
         self._stats_dev = stats
         if sync_stats:
@@ -471,6 +469,12 @@ class PPO:
             lg.record("train/n_updates", self._n_updates, exclude="tensorboard")
             lg.record("train/clip_range", float(hp.clip_range))
             lg.record("train/learning_rate", float(hp.learning_rate))
+
+    def _train_native(self, pol, opt, rb, hp, perm_t, stats) -> None:
+        """the update itself; subclasses with an additional loss term (ADAP) issue their own entry point here"""
+        nat.check(pol.ctx.lib.ph_ppo_train(pol.ctx.handle, C.byref(pol.spec), C.byref(opt), C.byref(rb.c_struct()),
+                                           C.byref(hp), int(self.n_epochs), int(self.batch_size), nat.ptr(perm_t),
+                                           int(self.permutation_seed), stats.data_ptr(), int(pol.gemm_mode)))
 
     def _train_call(self, keep: list) -> "nat.PhTrainCall":
         """this learner's train() arguments as a ph_train_call (device permutations; statistics stay on the device)"""
@@ -529,14 +533,22 @@ class PPO:
                 # the terminal observation [SB3 1.7.0: rewards[idx] += gamma * V(terminal_observation)], in float32
                 if (isinstance(info, dict) and dones[idx] and info.get("terminal_observation") is not None
                         and info.get("TimeLimit.truncated", False)):
-                    v_term = pol.predict_values(np.asarray(info["terminal_observation"], np.float32).reshape(1, -1))
+                    v_term = self._terminal_value(np.asarray(info["terminal_observation"], np.float32).reshape(1, -1), idx)
                     rewards[idx] += np.float32(self.gamma) * np.float32(v_term.reshape(-1)[0].item())
             rb.add_reward(rewards)
             self._last_obs = new_obs
             self._last_episode_starts = np.asarray(dones, np.float32)
+            self._after_step(dones)
         values = pol.predict_values(new_obs)  # ego bootstraps with V(o_T)
         rb.compute_returns_and_advantage(last_values=values, dones=np.asarray(dones, np.float32))
         return True
+
+    def _terminal_value(self, terminal_obs: np.ndarray, env_index: int) -> th.Tensor:
+        """V(terminal observation) of environment column `env_index` for the time-limit bootstrap"""
+        return self.policy.predict_values(terminal_obs)
+
+    def _after_step(self, dones) -> None:
+        """hook after every vectorised environment step of collect_rollouts (ADAP re-draws contexts here)"""
 
     def learn(self, total_timesteps: int, log_interval: int = 1, tb_log_name: str = "PPO",
               reset_num_timesteps: bool = True, callback=None, **_ignored) -> "PPO":

@@ -3,10 +3,11 @@
     python -m pantheonrl_amd.trainer RPS-v0 PPO PPO --preset 1 --seed 0 -t 10000        (BASELINE config 1)
 
 Same positional arguments and flags as the reference for the part of the surface that sits on the PPO path:
-env in {RPS-v0, LiarsDice-v0}; ego in {PPO, LOAD}; each partner in {PPO, FIXED, DEFAULT}; JSON configs splatted into
-the constructors; `--framestack`, `--preset 1`, `--ego-save/--alt-save`, `--tensorboard-log/-name`, `--seed`,
-`--device`, `--total-timesteps`.  `--record FILE` writes the episode transitions in the reference's `.npy` format.  ADAP / ModularAlgorithm / BC agents
-and `--share-latent` belong to components outside the PPO rollout+update path and raise EnvException.
+env in {RPS-v0, LiarsDice-v0}; ego in {PPO, ADAP, LOAD}; each partner in {PPO, ADAP, FIXED, DEFAULT}; JSON configs splatted
+into the constructors; `--framestack`, `--preset 1`, `--ego-save/--alt-save`, `--tensorboard-log/-name`, `--seed`, `--device`,
+`--total-timesteps`, `--share-latent` (ADAP ego + ADAP partners act under the ego's context).  `--record FILE` writes the episode
+transitions in the reference's `.npy` format.  ADAP_MULT / ModularAlgorithm / BC agents belong to components outside the PPO
+rollout+update path and raise EnvException.
 """
 from __future__ import annotations
 
@@ -14,16 +15,19 @@ import argparse
 import json
 from typing import List, Tuple
 
+import numpy as np
+
 from . import envs as _envs
 from .common import OnPolicyAgent, StaticPolicyAgent
 from .common.wrappers import frame_wrap, recorder_wrap
 from .envs.liar import LiarDefaultAgent, LiarEnv
 from .envs.rps import RPSEnv, RPSWeightedAgent
+from .adap import ADAP, AdapAgent, AdapPolicy
 from .ppo import PPO
 
-EGO_LIST = ["PPO", "LOAD"]
-PARTNER_LIST = ["PPO", "DEFAULT", "FIXED"]
-OUT_OF_SCOPE = {"ADAP", "ADAP_MULT", "ModularAlgorithm", "BC"}
+EGO_LIST = ["PPO", "ADAP", "LOAD"]
+PARTNER_LIST = ["PPO", "ADAP", "DEFAULT", "FIXED"]
+OUT_OF_SCOPE = {"ADAP_MULT", "ModularAlgorithm", "BC"}
 
 
 class EnvException(Exception):
@@ -45,9 +49,21 @@ def input_check(args) -> None:
     if len(args.alt_config) != len(args.alt):
         raise EnvException("number of partners is different from number of --alt-config")
     if args.share_latent:
-        raise EnvException("--share-latent belongs to the ADAP component (out of scope)")
+        latent_check(args)
     if args.framestack > 1 and args.env_config.get("framestack_incompatible", False):
         raise EnvException("this environment cannot be frame-stacked")
+
+
+def latent_check(args) -> None:
+    """--share-latent: every agent must be ADAP with the ego's context size and sampler (trainer.py:65-89)"""
+    if args.ego != "ADAP" or not all(v == "ADAP" for v in args.alt):
+        raise EnvException("both agents must be ADAP to share latent spaces")
+    args.ego_config.setdefault("context_size", 3)
+    args.ego_config.setdefault("context_sampler", "l2")
+    for conf in args.alt_config:
+        for key in ("context_size", "context_sampler"):
+            if conf.setdefault(key, args.ego_config[key]) != args.ego_config[key]:
+                raise EnvException("both agents must have similar configs to share latent spaces")
 
 
 def generate_env(args) -> Tuple[object, object]:
@@ -63,6 +79,12 @@ def generate_env(args) -> Tuple[object, object]:
 
 
 def gen_load(config: dict, policy_type: str, location: str):
+    if policy_type == "ADAP":       # trainer.py:140-147: a fixed ADAP policy acts under a given latent value
+        if "latent_val" not in config:
+            raise EnvException("latent_val needs to be specified for FIXED ADAP policy")
+        agent = ADAP.load(location, device=config.get("device", "cuda"))
+        agent.policy.set_context(np.asarray(config.pop("latent_val"), np.float32))
+        return agent
     if policy_type != "PPO":
         raise EnvException("Not a valid FIXED/LOAD policy")
     return PPO.load(location, device=config.get("device", "cuda"))
@@ -78,6 +100,8 @@ def generate_ego(env, args):
         model = gen_load(kwargs, kwargs["type"], kwargs["location"])
         model.set_env(env)
         return model
+    if args.ego == "ADAP":          # trainer.py:127-128
+        return ADAP(policy=AdapPolicy, **kwargs)
     return PPO(policy="MlpPolicy", **kwargs)
 
 
@@ -107,6 +131,9 @@ def gen_partner(kind: str, config: dict, altenv, ego, args, index: int):
     # same seed as the ego (same initial weights, as in the reference: set_random_seed(seed) runs before every model's
     # init), but an action-sampling stream of its own -- see ActorCriticPolicy.__init__
     config["sampling_stream"] = index + 1
+    if kind == "ADAP":              # trainer.py:205-213
+        shared = ego.policy if args.share_latent else None
+        return AdapAgent(ADAP(policy=AdapPolicy, **config), latent_syncer=shared, **agentarg)
     return OnPolicyAgent(PPO(policy="MlpPolicy", **config), **agentarg)
 
 

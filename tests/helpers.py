@@ -17,6 +17,10 @@ CONFIGS = {
     # filling all 32 logit lanes (the middle one straddles the 16-lane DPP row boundary); one 20-way Discrete head
     "onehot32": (SpaceSpec("multidiscrete", nvec=(3, 4, 5, 2, 6)), SpaceSpec("multidiscrete", nvec=(5, 16, 11))),
     "discrete20": (SpaceSpec("discrete", nvec=(5,)), SpaceSpec("discrete", nvec=(20,))),
+    # ADAP: the stored observation is (environment observation ++ context) -- adap_learn.py:448-452
+    "adap_oc": (SpaceSpec("box", dim=62 + 3), SpaceSpec("discrete", nvec=(6,))),            # two feature chunks
+    "adap_small": (SpaceSpec("box", dim=35 + 3), SpaceSpec("discrete", nvec=(5,))),         # the 64-row fast gradient kernel
+    "adap_multi": (SpaceSpec("box", dim=20 + 4), SpaceSpec("multidiscrete", nvec=(3, 9, 4))),
 }
 
 
