@@ -8,7 +8,8 @@ What it is
 A from-scratch CPU restatement (numpy + torch-CPU, float32) of the arithmetic
 that PantheonRL's ``OnPolicyAgent`` delegates to ``stable-baselines3==1.7.0``
 (reference ``setup.py:17``): the rollout buffer, the GAE pass, the MlpPolicy
-forward / evaluate_actions and ``PPO.train()``.
+forward / evaluate_actions and ``PPO.train()``, plus PantheonRL's own ADAP context
+term (``pantheonrl/algos/adap/util.py:97-131``, whose module imports gym / SB3).
 
 PARITY UNPINNED.  stable-baselines3 is not vendored under /root/reference and
 is not installed in this image, and the reference has no tests or golden

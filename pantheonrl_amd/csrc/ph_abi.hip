@@ -58,7 +58,7 @@ struct ph_ctx {
   size_t advpart_cap = 0;
   int* perm_idx = nullptr;   // (n_epochs, N) minibatch order of the current train() call, written by adv_stats
   size_t perm_idx_cap = 0;
-  float* adap_extra = nullptr;   // [workgroups][P] gradient slabs of ADAP's context term
+  float* adap_extra = nullptr;   // [workgroups][policy-side parameters] gradient slabs of ADAP's context term
   size_t adap_extra_cap = 0;
   float* adap_loss = nullptr;    // [workgroups] partial sums of the raw term
   size_t adap_loss_cap = 0;
@@ -1130,11 +1130,11 @@ int adap_check(ph_ctx* ctx, const ph::NetDims& nd, const ph_adap_loss* ad, const
     return fail(w + ": observation / action space too large for the context kernel's LDS tile");
   const size_t nwg = (size_t)ph::adap_workgroups(ad->num_context_samples, ad->num_state_samples);
   if (ctx->capturing) {
-    if (nwg * nd.lay.P > ctx->adap_extra_cap || nwg > ctx->adap_loss_cap)
+    if (nwg * ph::adap_slab_floats(nd.lay) > ctx->adap_extra_cap || nwg > ctx->adap_loss_cap)
       return fail("workspace would grow inside graph capture: run the same call once outside capture first");
     return 0;
   }
-  if (ensure(ctx->adap_extra, ctx->adap_extra_cap, nwg * nd.lay.P)) return 1;
+  if (ensure(ctx->adap_extra, ctx->adap_extra_cap, nwg * ph::adap_slab_floats(nd.lay))) return 1;
   if (ensure(ctx->adap_loss, ctx->adap_loss_cap, nwg)) return 1;
   return 0;
 }
@@ -1170,9 +1170,14 @@ int adap_launch(ph_ctx* ctx, const ph::NetDims& nd, const float* params, const p
   a.used_state_idx = ad->used_state_idx ? ad->used_state_idx + (size_t)mbi * S : nullptr;
   a.used_contexts = ad->used_contexts ? ad->used_contexts + (size_t)mbi * C * cs : nullptr;
   a.stop_flag = ctx->stop_flag;
+  a.prof = ctx->prof;
   PH_HIP(ph::launch_adap_context(a, nwg, ctx->stream));
   r->extra = ctx->adap_extra;
   r->n_extra = nwg;
+  r->extra_len = ph::adap_slab_floats(nd.lay);
+  r->extra_cut = nd.lay.vf_W1;
+  r->extra_lo = nd.lay.act_W;
+  r->extra_hi = nd.lay.val_W;
   r->extra_loss = ctx->adap_loss;
   r->extra_norm = 1.0f / (float)((C * (C - 1) / 2) * n_states);
   r->extra_coef = ad->context_loss_coeff;

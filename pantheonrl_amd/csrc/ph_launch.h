@@ -149,8 +149,10 @@ struct ReduceArgs {
   int* step;             // optimizer step counter (incremented here when the step will be applied), may be null
   float* scalars;        // [4]: kl, applied, stop-requested
   // an additional loss term whose gradient arrives as n_extra slabs in canonical parameter order (ADAP's context loss)
-  const float* extra = nullptr;       // [n_extra][P], already scaled by the term's coefficient
-  int n_extra = 0;
+  // Slab layout: the parameters [0, extra_cut) followed by the parameters [extra_lo, extra_hi) -- the policy network and the
+  // action head; the value side receives nothing from the term.
+  const float* extra = nullptr;       // [n_extra][extra_len], already scaled by the term's coefficient
+  int n_extra = 0, extra_len = 0, extra_cut = 0, extra_lo = 0, extra_hi = 0;
   const float* extra_loss = nullptr;  // [n_extra] partial sums of the raw term
   float extra_norm = 0.f;             // raw term = extra_norm * sum(extra_loss)
   float extra_coef = 0.f;             // loss statistic += extra_coef * raw term
@@ -229,13 +231,15 @@ struct AdapArgs {
   uint64_t seed;
   const unsigned long long* epoch;
   uint32_t mbi, nb_hb;     // minibatch number within the train() call; Feistel half width for nb
-  float* extra;            // [gridDim.x][P]
+  float* extra;            // [gridDim.x][adap_slab_floats(lay)]
   float* loss_part;        // [gridDim.x]
   int* used_state_idx;     // (n_states) out or null
   float* used_contexts;    // (n_ctx, ctx_size) out or null
   const int* stop_flag;
+  long long* prof;         // debug: per-workgroup phase timestamps (clock64), or null
 };
 int adap_workgroups(int n_ctx, int n_states);
+int adap_slab_floats(const ph_layout& lay);
 size_t adap_lds_bytes(const NetDims& nd, int n_ctx, int ctx_size);
 hipError_t launch_adap_context(const AdapArgs& a, int nwg, hipStream_t s);
 hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, const FwdArgs& reply, const FwdArgs& opening,

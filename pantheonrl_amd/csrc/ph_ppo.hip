@@ -636,7 +636,11 @@ __global__ __launch_bounds__(RED_PARAMS * RED_GROUPS) void ppo_reduce_kernel(Red
       // canonical slabs: position = parameter index; register-order slabs (ppo_grad_fast_kernel): through the table
       const int dst = p < a.slab_len ? (a.map ? a.map[p] : p) : -1;
       if (dst >= 0) {
-        for (int k = 0; k < a.n_extra; ++k) g += a.extra[(size_t)k * a.P + dst];   // the additional term, fixed order
+        if (a.n_extra > 0) {   // the additional term's slabs, fixed order
+          const int e = dst < a.extra_cut ? dst : ((dst >= a.extra_lo && dst < a.extra_hi) ? a.extra_cut + (dst - a.extra_lo) : -1);
+          if (e >= 0)
+            for (int k = 0; k < a.n_extra; ++k) g += a.extra[(size_t)k * a.extra_len + e];
+        }
         a.grad[dst] = g;
       } else {
         g = 0.f;

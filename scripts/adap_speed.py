@@ -4,13 +4,14 @@ two feature chunks, general gradient kernel) and at a 59 + 3 shape that stays on
 
     python scripts/adap_speed.py            # prints one line per (shape, learner)
 """
+import os
 import sys
 import time
 
 import numpy as np
 import torch as th
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pantheonrl_amd import PPO, spaces as sp          # noqa: E402
 from pantheonrl_amd.adap import ADAP                   # noqa: E402
 
