@@ -197,6 +197,8 @@ int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd) {
   nd->L = nd->lay.L;
   nd->Lp = ((nd->L + 31) / 32) * 32;
   nd->nchunk = (nd->F + PH_HIDDEN - 1) / PH_HIDDEN;
+  nd->head16 = spec->act.n <= 4;
+  for (int i = 0; i < spec->act.n && i < 4; ++i) nd->head16 = nd->head16 && spec->act.nvec[i] <= 16;
   nd->obs_off = hit->obs_off;
   nd->act_off = hit->act_off;
   return 0;

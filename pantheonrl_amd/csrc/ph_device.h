@@ -191,6 +191,7 @@ struct NetDims {
   int obs_kind;     // PH_SPACE_*
   int D, F, A, L;   // stored obs len, features, stored action len, logits
   int Lp;           // logits padded to a multiple of 32 (MFMA N tile)
+  int head16;       // 1: at most 4 action components of at most 16 logits each (the gradient kernel's per-component head phase)
   int nchunk;       // ceil(F / 64) feature chunks of the first layer
   const int* obs_off;  // device: prefix sums of obs nvec (D+1) for the one-hot path, else nullptr
   const int* act_off;  // device: prefix sums of act nvec (A+1)
@@ -238,6 +239,26 @@ struct XStage {
       }
     }
     feat_lds = feat;
+  }
+  // feature -> observation component table for commit_onehot: fcomp[f] for f < nchunk * 64 (features >= F map to component 0,
+  // whose hot position can never equal them).  Two global loads per thread, then LDS writes; caller barriers afterwards.
+  __device__ __forceinline__ static void build_fcomp(int* fcomp, const NetDims& nd, int tid) {
+    for (int comp = tid; comp < nd.D; comp += NT) {
+      const int lo = nd.obs_off[comp], hi = nd.obs_off[comp + 1];
+      for (int f = lo; f < hi; ++f) fcomp[f] = comp;
+    }
+    for (int f = nd.F + tid; f < nd.nchunk * HID; f += NT) fcomp[f] = 0;
+  }
+  // One-hot chunk c straight from the tile's hot positions: lane column kk = feature c*64 + kk belongs to ONE component, so
+  // X[r][kk] = (hot position of that component in row r == feature).  No zero fill, no scatter, no barrier inside.
+  __device__ __forceinline__ void commit_onehot(float* dst, const int* fcomp, const NetDims& nd, int c, int tid) const {
+    const int kk = tid & 63, f = c * HID + kk;
+    const int* fr = feat_lds + fcomp[f];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int row = (tid + NT * i) >> 6;
+      dst[row * LDH + kk] = (fr[row * nd.D] == f) ? 1.f : 0.f;
+    }
   }
   __device__ __forceinline__ void issue(const int* rowphys, const float* obs, const NetDims& nd, int c, int tid = -1) {
     if (nd.obs_kind != PH_SPACE_BOX) return;

@@ -174,7 +174,7 @@ struct AdamArgs {
 };
 
 size_t fwd_lds_bytes(int R, int Lp);
-size_t grad_lds_bytes(int R, int Lp, int onehot_D);
+size_t grad_lds_bytes(int R, int Lp, int onehot_D, int nchunk);
 hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s);
 hipError_t launch_policy_fwd_multi(const FwdMulti& m, int n_agents, hipStream_t s);
 hipError_t launch_fix_illegal(int* actions, const unsigned char* mask, int n, int L, hipStream_t s);

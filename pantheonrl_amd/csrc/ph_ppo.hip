@@ -19,7 +19,10 @@ namespace ph {
 // Weight-gradient tiles accumulate across the tiles of a workgroup in its private slab: the MFMA accumulator is
 // initialised from the slab (the loads hide under the operand prefetch of the tile product), then stored back.
 // (No-return L2 float atomics instead of the reload measured 8 % slower on the whole kernel.)
-template <int R, int LP, bool VALU>
+// OH: Discrete-family (one-hot) observations -- the chunk loops below differ; H16: the per-component head phase (nd.head16).
+// Compile-time so that the Box / small-head instantiations keep their register budget (the one-hot loop holds the next
+// chunk's W1 rows in registers across the products, the per-component head 32 logit slots).
+template <int R, int LP, bool VALU, bool OH, bool H16>
 __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   if (*a.stop_flag) return;
   PH_STAMP(a.prof, 0);
@@ -40,8 +43,12 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   float* rold = radv + R;              // [R] old log-prob (policy) | old values (value)
   float* rdv = rold + R;               // [R] dL/dv (value net)
   float* red = rdv + R;                // [NSTATP * 4] cross-wave stat reduction
-  int* rowphys = (int*)(red + NSTATP * 4);  // [R]
+  float* hlp = red + NSTATP * 4;       // [R][4] log-prob of the taken action, per action component (head16 shapes)
+  float* hen = hlp + 4 * R;            // [R][4] entropy per action component
+  int* rowphys = (int*)(hen + 4 * R);  // [R]
   int* feat = rowphys + R;             // [R][D] one-hot positions of the tile (Discrete-family observations only)
+  constexpr bool onehot = OH;
+  int* fcomp = feat + R * nd.D;        // [nchunk * 64] observation component of every feature (one-hot only)
   float* wos = regW;
   float* outs = regW + HID * LDO;
 
@@ -91,6 +98,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     }
   };
   stage_rows(blockIdx.x);  // overlaps the W2 / bias loads issued above
+  if constexpr (onehot) XStage<R, NT>::build_fcomp(fcomp, nd, tid);
   w2r.commit(w2s);
   if (tid < HID) {
     b1s[tid] = bias1;
@@ -116,20 +124,38 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     XStage<R, NT> xr;
     WStage<NT> w1r;
     WoStage<NT> wor;
-    // One-hot observations: the hot feature row of every (row, component) once per tile; the chunks of S1 and S7 are then
-    // built from LDS.  (Replacing S1 by a gather-sum of W1 rows, as the 16-row forward kernel does, measured no faster at 64
-    // rows per workgroup: 491 KB of gathered rows per workgroup against 69 KB of W1 streamed once through LDS.)
-    if (nd.obs_kind != PH_SPACE_BOX) xr.build_feat(feat, rowphys, a.rb_obs, nd, tid);   // read after the barrier in commit
-    for (int c = 0; c < nd.nchunk; ++c) {
-      if (c > 0) __syncthreads();  // previous chunk consumed
-      xr.issue(rowphys, a.rb_obs, nd, c, tid);
-      w1r.issue(a.params + oW1, c * HID, nd.F, tid);
-      xr.commit(bufA, rowphys, a.rb_obs, nd, c, tid);
-      w1r.commit(regW, tid);
-      __syncthreads();
-      if (first) PH_STAMP(a.prof, 2);
-      if (net == 0 && c == nd.nchunk - 1) wor.issue(a.params + lay.act_W, nd.L, Lp, tid);  // lands during the MFMAs
-      acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
+    if constexpr (onehot) {
+      // One-hot observations: the hot feature row of every (row, component) once per tile; the chunks of S1 and S7 are then
+      // built from LDS (commit_onehot: no zero fill, no scatter).  (Replacing S1 by a gather-sum of W1 rows, as the 16-row
+      // forward kernel does, measured no faster at 64 rows per workgroup: 491 KB of gathered rows per workgroup against 69 KB
+      // of W1 streamed once through LDS.)  A minibatch of this shape class is one tile per workgroup and one workgroup per CU
+      // (8 192 rows = 128 tiles), so nothing else hides a chunk's W1 load: chunk c + 1's rows are loaded into registers while
+      // chunk c's products run and committed after the barrier that frees the single LDS buffer -- the loop pays the load
+      // latency once, not once per chunk.
+      w1r.issue(a.params + oW1, 0, nd.F, tid);
+      xr.build_feat(feat, rowphys, a.rb_obs, nd, tid);
+      for (int c = 0; c < nd.nchunk; ++c) {
+        __syncthreads();  // previous chunk consumed; (first chunk) the tile's hot positions visible
+        xr.commit_onehot(bufA, fcomp, nd, c, tid);
+        w1r.commit(regW, tid);
+        __syncthreads();
+        if (first) PH_STAMP(a.prof, 2);
+        if (c + 1 < nd.nchunk) w1r.issue(a.params + oW1, (c + 1) * HID, nd.F, tid);
+        else if (net == 0) wor.issue(a.params + lay.act_W, nd.L, Lp, tid);  // lands during the MFMAs
+        acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
+      }
+    } else {
+      for (int c = 0; c < nd.nchunk; ++c) {
+        if (c > 0) __syncthreads();  // previous chunk consumed
+        xr.issue(rowphys, a.rb_obs, nd, c, tid);
+        w1r.issue(a.params + oW1, c * HID, nd.F, tid);
+        xr.commit(bufA, rowphys, a.rb_obs, nd, c, tid);
+        w1r.commit(regW, tid);
+        __syncthreads();
+        if (first) PH_STAMP(a.prof, 2);
+        if (net == 0 && c == nd.nchunk - 1) wor.issue(a.params + lay.act_W, nd.L, Lp, tid);  // lands during the MFMAs
+        acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
+      }
     }
     if (first) PH_STAMP(a.prof, 3);
 #pragma unroll
@@ -171,7 +197,82 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       if (first) PH_STAMP(a.prof, 6);
 
       // ---- S4: clipped-surrogate + entropy loss per row, dL/dlogits written over OUT ----
-      if (tid < R) {
+      if constexpr (H16) {
+        // MultiDiscrete heads / up to 16 logits per component (Liar's Dice: 7 + 12): wave c takes action component c of every
+        // row; a thread reads its component's logits in ONE batch of LDS reads and keeps them in registers -- one exp per
+        // logit -- instead of one lane per row walking every component in five dependent passes over LDS (17 k cycles per
+        // tile for 19 logits).  The per-component log-prob and entropy meet in LDS; the row's scalars are then recomputed by
+        // each of its component threads.  log-prob = z[a] - (m + log sum exp(z - m)), accumulated over components in order.
+        const int hrow = tid & (R - 1), hcomp = tid / R;
+        const bool hon = hcomp < nd.A;
+        const int physh = rowphys[hrow];
+        int lo = 0, nk = 0, act = 0;
+        float zc[16], pc[16], hc = 0.f;
+        float* zrow = outs + hrow * LDO;
+        if (hon) {
+          lo = nd.act_off[hcomp];
+          nk = nd.act_off[hcomp + 1] - lo;
+          if (physh >= 0) {
+            act = (int)a.rb_act[(size_t)physh * nd.A + hcomp];   // in flight during the LDS reads
+#pragma unroll
+            for (int k = 0; k < 16; ++k) zc[k] = (k < nk) ? zrow[lo + k] : -3.0e38f;
+            float m = zc[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) m = fmaxf(m, zc[k]);
+            float se = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+              pc[k] = (k < nk) ? fast_exp(zc[k] - m) : 0.f;
+              if (k < nk) se += pc[k];
+            }
+            const float lse = m + fast_log(se), inv = __builtin_amdgcn_rcpf(se);
+            act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
+            float zact = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+              zact = (k == act) ? zc[k] : zact;
+              pc[k] *= inv;
+              zc[k] -= lse;                                   // log-probability of the slot
+              if (k < nk) hc -= pc[k] * zc[k];
+            }
+            hlp[hrow * 4 + hcomp] = zact - lse;
+            hen[hrow * 4 + hcomp] = hc;
+          }
+        }
+        __syncthreads();
+        if (hon) {
+          if (physh < 0) {
+            for (int k = 0; k < nk; ++k) zrow[lo + k] = 0.f;
+          } else {
+            float logp = 0.f, ent = 0.f;
+            for (int c = 0; c < nd.A; ++c) {
+              logp += hlp[hrow * 4 + c];
+              ent += hen[hrow * 4 + c];
+            }
+            const float adv = radv[hrow];
+            const float lr = logp - rold[hrow];
+            const float ratio = fast_exp(lr);
+            const float lo_c = 1.0f - a.clip, hi_c = 1.0f + a.clip;
+            const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
+            const float pl1 = adv * ratio, pl2 = adv * rc;
+            const float inr = (ratio >= lo_c && ratio <= hi_c) ? 1.f : 0.f;
+            const float gate = (pl1 < pl2) ? 1.f : ((pl1 > pl2) ? inr : 0.5f + 0.5f * inr);   // torch.min / clamp backward
+            const float g_lp = -inv_nb * adv * ratio * gate;
+            const float g_en = -a.ent_coef * inv_nb;
+            if (hcomp == 0) {
+              st[0] += -fminf(pl1, pl2);
+              st[2] += -ent;
+              st[3] += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
+              st[4] += (ratio - 1.0f) - lr;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+              if (k < nk) zrow[lo + k] = g_lp * (((k == act) ? 1.f : 0.f) - pc[k]) + g_en * (-pc[k] * (zc[k] + hc));
+          }
+        }
+        if (tid < R)
+          for (int k = nd.L; k < Lp; ++k) zrow[k] = 0.f;
+      } else if (tid < R) {
         float* z = outs + tid * LDO;
         const int phys = rowphys[tid];
         if (phys < 0) {
@@ -406,7 +507,8 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       const float h = bufB[row * LDH + col];
       bufB[row * LDH + col] = dh1[r] * (1.0f - h * h);
     }
-    xr.commit(bufA, rowphys, a.rb_obs, nd, 0, tid);
+    if constexpr (onehot) xr.commit_onehot(bufA, fcomp, nd, 0, tid);
+    else xr.commit(bufA, rowphys, a.rb_obs, nd, 0, tid);
     __syncthreads();
     if (first) PH_STAMP(a.prof, 11);
     // ---- S7: dW1 = X^T dZ1 per feature chunk ; d b1 ----
@@ -418,8 +520,12 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     for (int c = 0; c < nd.nchunk; ++c) {
       if (c > 0) {
         __syncthreads();  // previous chunk consumed
-        xr.issue(rowphys, a.rb_obs, nd, c, tid);
-        xr.commit(bufA, rowphys, a.rb_obs, nd, c, tid);
+        if constexpr (onehot) {
+          xr.commit_onehot(bufA, fcomp, nd, c, tid);
+        } else {
+          xr.issue(rowphys, a.rb_obs, nd, c, tid);
+          xr.commit(bufA, rowphys, a.rb_obs, nd, c, tid);
+        }
         __syncthreads();
       }
       f32x16 g = {0};
@@ -467,29 +573,37 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
 }
 
 
-size_t grad_lds_bytes(int R, int Lp, int onehot_D) {
+size_t grad_lds_bytes(int R, int Lp, int onehot_D, int nchunk) {
   const int LDO = Lp + 1;
   const int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
-  return sizeof(float) * (size_t)(2 * R * LDH + regW_sz + HID * LDH + 3 * 64 + 3 * R + NSTATP * 4 + R + R * onehot_D);
+  return sizeof(float) * (size_t)(2 * R * LDH + regW_sz + HID * LDH + 3 * 64 + 3 * R + NSTATP * 4 + 8 * R + R + R * onehot_D +
+                                  (onehot_D ? nchunk * HID : 0));
 }
 
-template <int LP, bool VALU>
+template <int LP, bool VALU, bool OH, bool H16>
 static hipError_t launch_grad_variant(const GradArgs& a, int nwg, hipStream_t s) {
   constexpr int R = 64;
-  const size_t lds = grad_lds_bytes(R, LP, a.nd.obs_kind != PH_SPACE_BOX ? a.nd.D : 0);
+  const size_t lds = grad_lds_bytes(R, LP, OH ? a.nd.D : 0, a.nd.nchunk);
   dim3 grid(nwg, 2), block(R * 4);
   static size_t allowed[64] = {0};  // > 64 KiB of dynamic LDS is opt-in per kernel and device (kept out of graph capture)
   int dev = 0;
   (void)hipGetDevice(&dev);
   dev = (dev >= 0 && dev < 64) ? dev : 0;
   if (lds > allowed[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<R, LP, VALU>,
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<R, LP, VALU, OH, H16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     allowed[dev] = lds;
   }
-  hipLaunchKernelGGL((ppo_grad_kernel<R, LP, VALU>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((ppo_grad_kernel<R, LP, VALU, OH, H16>), grid, block, lds, s, a);
   return hipGetLastError();
+}
+template <int LP, bool VALU>
+static hipError_t launch_grad_shape(const GradArgs& a, int nwg, hipStream_t s) {
+  const bool oh = a.nd.obs_kind != PH_SPACE_BOX;
+  const bool h16 = a.nd.head16 && !(a.nd.A == 1 && a.nd.L <= 8);   // a small Discrete head keeps its one-lane-per-row phase
+  if (oh) return h16 ? launch_grad_variant<LP, VALU, true, true>(a, nwg, s) : launch_grad_variant<LP, VALU, true, false>(a, nwg, s);
+  return h16 ? launch_grad_variant<LP, VALU, false, true>(a, nwg, s) : launch_grad_variant<LP, VALU, false, false>(a, nwg, s);
 }
 
 // The single-chunk / small-head kernel (ph_ppo_fast.hip) writes its slabs in the MFMA accumulators' register order; the
@@ -506,8 +620,8 @@ hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_
   if (grad_fast_eligible(a.nd)) return launch_ppo_grad_fast(a, nwg, gemm_mode, s);
   if (a.nd.Lp != 32 && a.nd.Lp != 64) return hipErrorInvalidValue;
   const bool lp64 = a.nd.Lp == 64;
-  if (gemm_mode != 0) return lp64 ? launch_grad_variant<64, true>(a, nwg, s) : launch_grad_variant<32, true>(a, nwg, s);
-  return lp64 ? launch_grad_variant<64, false>(a, nwg, s) : launch_grad_variant<32, false>(a, nwg, s);
+  if (gemm_mode != 0) return lp64 ? launch_grad_shape<64, true>(a, nwg, s) : launch_grad_shape<32, true>(a, nwg, s);
+  return lp64 ? launch_grad_shape<64, false>(a, nwg, s) : launch_grad_shape<32, false>(a, nwg, s);
 }
 
 // ---- advantage statistics of every minibatch of a train() call: mean and unbiased std (torch .mean()/.std()) ----

@@ -37,7 +37,7 @@ for rep in range(3):
 nwg = 11
 blk = stamps.cpu().numpy().reshape(-1, 16)[:nwg]
 labels = ["stage weights", "samples", "X gather", "H1, H2", "logits", "softmax, KL, exp", "dlogits", "dZ2, dZ1", "dW1, dW2",
-          "biases, head, zeros"]
+          "biases, head"]
 d = np.diff(blk[:, :len(labels) + 1].astype(np.float64), axis=1)
 print(f"adap_context_kernel: {nwg} workgroups, total {np.median(blk[:, len(labels)] - blk[:, 0]):.0f} cycles (median)")
 for lab, col in zip(labels, d.T):
