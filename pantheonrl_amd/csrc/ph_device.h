@@ -254,11 +254,12 @@ struct XStage {
   __device__ __forceinline__ void commit_onehot(float* dst, const int* fcomp, const NetDims& nd, int c, int tid) const {
     const int kk = tid & 63, f = c * HID + kk;
     const int* fr = feat_lds + fcomp[f];
+    int hot[ITERS];   // all reads first: the compiler cannot tell that dst and the hot positions never alias
 #pragma unroll
-    for (int i = 0; i < ITERS; ++i) {
-      const int row = (tid + NT * i) >> 6;
-      dst[row * LDH + kk] = (fr[row * nd.D] == f) ? 1.f : 0.f;
-    }
+    for (int i = 0; i < ITERS; ++i) hot[i] = fr[((tid + NT * i) >> 6) * nd.D];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) dst[((tid + NT * i) >> 6) * LDH + kk] = (hot[i] == f) ? 1.f : 0.f;
   }
   __device__ __forceinline__ void issue(const int* rowphys, const float* obs, const NetDims& nd, int c, int tid = -1) {
     if (nd.obs_kind != PH_SPACE_BOX) return;

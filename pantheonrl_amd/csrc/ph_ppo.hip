@@ -123,7 +123,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     f32x16 acc = {0};
     XStage<R, NT> xr;
     WStage<NT> w1r;
-    WoStage<NT> wor;
+    WoStage<NT, LP> wor;   // sized by the head width of this instantiation
     if constexpr (onehot) {
       // One-hot observations: the hot feature row of every (row, component) once per tile; the chunks of S1 and S7 are then
       // built from LDS (commit_onehot: no zero fill, no scatter).  (Replacing S1 by a gather-sum of W1 rows, as the 16-row
@@ -134,14 +134,14 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       // latency once, not once per chunk.
       w1r.issue(a.params + oW1, 0, nd.F, tid);
       xr.build_feat(feat, rowphys, a.rb_obs, nd, tid);
+      if (net == 0) wor.issue(a.params + lay.act_W, nd.L, Lp, tid);   // consumed after the loop
       for (int c = 0; c < nd.nchunk; ++c) {
         __syncthreads();  // previous chunk consumed; (first chunk) the tile's hot positions visible
         xr.commit_onehot(bufA, fcomp, nd, c, tid);
         w1r.commit(regW, tid);
         __syncthreads();
         if (first) PH_STAMP(a.prof, 2);
-        if (c + 1 < nd.nchunk) w1r.issue(a.params + oW1, (c + 1) * HID, nd.F, tid);
-        else if (net == 0) wor.issue(a.params + lay.act_W, nd.L, Lp, tid);  // lands during the MFMAs
+        if (c + 1 < nd.nchunk) w1r.issue(a.params + oW1, (c + 1) * HID, nd.F, tid);   // in flight during the products
         acc = tile_mma<false, false, VALU>(bufA, LDH, regW, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
       }
     } else {
@@ -158,10 +158,11 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       }
     }
     if (first) PH_STAMP(a.prof, 3);
+    {
+      const int col = nt * 32 + li;
+      const float bb = b1s[col];   // once: inside the loop it is re-read (and waited for) after every store to bufB
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
-      bufB[row * LDH + col] = fast_tanh(acc[r] + b1s[col]);
+      for (int r = 0; r < 16; ++r) bufB[(mt * 32 + drow(r, lh)) * LDH + col] = fast_tanh(acc[r] + bb);
     }
     __syncthreads();  // every wave is done with the W1 chunk in regW and H1 is complete
     if (net == 0) wor.commit(wos, Lp, LDO, tid);
@@ -171,11 +172,10 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     {
       f32x16 acc2 = {0};
       acc2 = tile_mma<false, false, VALU>(bufB, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc2, lane);
+      const int col = nt * 32 + li;
+      const float bb = b2s[col];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
-        bufA[row * LDH + col] = fast_tanh(acc2[r] + b2s[col]);
-      }
+      for (int r = 0; r < 16; ++r) bufA[(mt * 32 + drow(r, lh)) * LDH + col] = fast_tanh(acc2[r] + bb);
     }
     __syncthreads();
     if (first) PH_STAMP(a.prof, 5);
@@ -187,11 +187,10 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
         const int hm = wave / ntn, hn = wave - hm * ntn;
         f32x16 acc3 = {0};
         acc3 = tile_mma<false, false, VALU>(bufA, LDH, wos, LDO, hm * 32, hn * 32, 0, HID, acc3, lane);
+        const int col = hn * 32 + li;
+        const float bb = bos[col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = hm * 32 + drow(r, lh), col = hn * 32 + li;
-          outs[row * LDO + col] = acc3[r] + bos[col];
-        }
+        for (int r = 0; r < 16; ++r) outs[(hm * 32 + drow(r, lh)) * LDO + col] = acc3[r] + bb;
       }
       __syncthreads();
       if (first) PH_STAMP(a.prof, 6);
@@ -425,12 +424,12 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       {
         f32x16 d = {0};
         d = tile_mma<false, true, VALU>(outs, LDO, wos, LDO, mt * 32, nt * 32, 0, Lp, d, lane);
+        float hv[16];   // all reads, then all writes: interleaved, every read waits behind the previous (possibly aliasing) store
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
-          const float h = bufA[row * LDH + col];
-          bufA[row * LDH + col] = d[r] * (1.0f - h * h);
-        }
+        for (int r = 0; r < 16; ++r) hv[r] = bufA[(mt * 32 + drow(r, lh)) * LDH + nt * 32 + li];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bufA[(mt * 32 + drow(r, lh)) * LDH + nt * 32 + li] = d[r] * (1.0f - hv[r] * hv[r]);
       }
       __syncthreads();
     } else {
@@ -501,11 +500,13 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     __syncthreads();  // dZ2 (bufA) and H1 (bufB) fully consumed
     if (first) PH_STAMP(a.prof, 10);
     // ---- S6b: dZ1 = dH1 * (1 - H1^2) in place over H1; X chunk 0 lands in bufA ----
+    {
+      float hv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
-      const float h = bufB[row * LDH + col];
-      bufB[row * LDH + col] = dh1[r] * (1.0f - h * h);
+      for (int r = 0; r < 16; ++r) hv[r] = bufB[(mt * 32 + drow(r, lh)) * LDH + nt * 32 + li];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bufB[(mt * 32 + drow(r, lh)) * LDH + nt * 32 + li] = dh1[r] * (1.0f - hv[r] * hv[r]);
     }
     if constexpr (onehot) xr.commit_onehot(bufA, fcomp, nd, 0, tid);
     else xr.commit(bufA, rowphys, a.rb_obs, nd, 0, tid);
