@@ -1008,6 +1008,7 @@ int ph_liar_selfplay_rollout(ph_ctx* ctx, const ph_liar_selfplay* sp, int ego_po
   ego.rb_val = s.ego_rb->values + row;
   ego.rb_logp = s.ego_rb->log_probs + row;
   ego.es_in = s.ego_episode_start;
+  ego.prof = ctx->prof;   // debug stamps (scripts/liar_rollout_profile.py)
   std::memset(&reply, 0, sizeof(reply));
   reply.nd = ego.nd;
   reply.params = s.alt_params;

@@ -131,12 +131,17 @@ __device__ __forceinline__ void liar_deal(LiarTable& t, int e, int* hands, int* 
 // applied to n tables; the partner's rollout rows are ragged: table e writes row alt_pos[e]).  A table's state is touched
 // by its own lane only, so everything between two policy forwards is ONE launch: a vectorised step is
 //   ego forward | after_ego | partner forward | after_reply | partner forward (openers) | after_opening
+__device__ __forceinline__ void liar_add_f32(float* p, float v) {
+  (void)__builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)p, v);
+}
 __device__ __forceinline__ void liar_sp_credit(const ph_liar_selfplay& s, float* alt_rewards, int alt_T, int e, float r, bool done,
                                                bool credited) {
   const bool m = credited && s.alt_open[e];
   if (m) {
     const int p = s.alt_pos[e];
-    if (p >= 1 && p <= alt_T) alt_rewards[(size_t)(p - 1) * s.n + e] += r;
+    // no-return float atomic: the address is this table's alone, so the sum is the plain "+=" -- but the lane does not wait a
+    // round trip to HBM for the old value in the middle of its book-keeping
+    if (p >= 1 && p <= alt_T) liar_add_f32(alt_rewards + (size_t)(p - 1) * s.n + e, r);
   }
   if (done) s.alt_boundary[e] = 1;
   if (m && done) s.alt_term[e] = 1;
@@ -187,7 +192,7 @@ __device__ __forceinline__ void liar_sp_after_reply_lane(const ph_liar_selfplay&
     const bool d2 = run && s.done2[e] != 0;
     liar_sp_credit(s, alt_rewards, alt_T, e, s.rew2[2 * e + 1], d2, run);
     const bool done = s.done1[e] != 0 || d2;
-    ego_rew_row[e] += s.rew1[2 * e] + (run ? s.rew2[2 * e] : 0.f);    // both transitions of the step (agents.py:44-47)
+    liar_add_f32(ego_rew_row + e, s.rew1[2 * e] + (run ? s.rew2[2 * e] : 0.f));   // both transitions of the step (agents.py:44-47)
     s.ego_episode_start[e] = done ? 1.f : 0.f;
     if (run && !d2) liar_write_obs(t, true, s.obs_ego + (size_t)e * 30);   // = obs_next of the move just played
     s.done[e] = done ? 1 : 0;

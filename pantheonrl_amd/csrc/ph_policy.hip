@@ -82,11 +82,17 @@ __device__ __forceinline__ void copy_obs_rows(const FwdArgs& a, int row0, int nr
   }
 }
 
+// Philox counter of a forward: the caller's step counter in the low word, the RNG epoch (a device word the iteration graphs
+// advance between replays) in the high one.  Kernels evaluate it FIRST, with their staging loads: read where the sampling tail
+// needs it, the epoch is a dependent round trip to L2 at the end of every forward.
+__device__ __forceinline__ uint64_t fwd_counter(const FwdArgs& a) {
+  return a.counter + (a.epoch ? (uint64_t)(*a.epoch) << 32 : 0ull);
+}
+
 // Discrete action space with <= 8 logits, one lane per row, the row's logits in registers (z[k >= L] ignored): optional
 // mask offset, logits output, sampling / argmax / given action, log-prob, entropy and the rollout-buffer writes
-__device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDims& nd, int g, float (&zr)[8]) {
+__device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDims& nd, int g, float (&zr)[8], uint64_t ctr) {
   const int nk = nd.L;
-  const uint64_t ctr = a.counter + (a.epoch ? (uint64_t)(*a.epoch) << 32 : 0ull);
   if (a.mask) {  // modular/policies.py:330-333 : logits - 30*(~mask)
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -154,8 +160,7 @@ __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDim
 // General action head of one row, one lane per row, the row's logits z[0..L) in LDS (modified in place): optional mask
 // offset, logits output, then per action component sampling / argmax / given action, log-prob, entropy and the
 // rollout-buffer writes (Discrete and MultiDiscrete; Discrete with <= 8 logits takes the register path)
-__device__ __forceinline__ void general_row_tail(const FwdArgs& a, const NetDims& nd, int g, float* z) {
-  const uint64_t ctr = a.counter + (a.epoch ? (uint64_t)(*a.epoch) << 32 : 0ull);
+__device__ __forceinline__ void general_row_tail(const FwdArgs& a, const NetDims& nd, int g, float* z, uint64_t ctr) {
   const bool small = nd.A == 1 && nd.L <= 8;
   if (a.mask && !small) {  // modular/policies.py:330-333 : logits - 30*(~mask)
     for (int k = 0; k < nd.L; ++k) z[k] = z[k] - 30.0f * (1.0f - (float)(a.mask[(size_t)g * nd.L + k] != 0));
@@ -168,7 +173,7 @@ __device__ __forceinline__ void general_row_tail(const FwdArgs& a, const NetDims
     float zr[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) zr[k] = (k < nd.L) ? z[k] : 0.f;
-    discrete8_row_tail(a, nd, g, zr);
+    discrete8_row_tail(a, nd, g, zr, ctr);
     return;
   } else
   for (int c = 0; c < nd.A; ++c) {
@@ -248,6 +253,7 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
   const float* B2 = a.params + (net == 0 ? lay.pi_b2 : lay.vf_b2);
 
   PH_STAMP(a.prof, 0);
+  const uint64_t ctr = fwd_counter(a);   // the epoch word's load goes out with the staging loads
   // ---- every staging load of the kernel is issued here, back to back: one memory latency in total ----
   if (tid < R) rowphys[tid] = (row0 + tid < a.n) ? row0 + tid : -1;
   WStage<NT> w2r, w1r;
@@ -344,7 +350,7 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
   PH_STAMP(a.prof, 6);
 
   // ---- distribution: one lane per row ----
-  if (tid < R && rowphys[tid] >= 0) general_row_tail(a, nd, row0 + tid, outs + tid * LDO);
+  if (tid < R && rowphys[tid] >= 0) general_row_tail(a, nd, row0 + tid, outs + tid * LDO, ctr);
   PH_STAMP(a.prof, 7);
 }
 
@@ -394,6 +400,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a, const ph_p2p
   const int nk = nd.L;
 
   PH_STAMP(a.prof, 0);
+  const uint64_t ctr = fwd_counter(a);   // the epoch word's load goes out with the staging loads
   // every global load of the kernel is issued here; row indices are trivial (row0 + r), so X needs no metadata pass
   if (tid < R) rowphys[tid] = (row0 + tid < a.n) ? row0 + tid : -1;
   WStage<NT> w1r, w2r;
@@ -498,7 +505,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a, const ph_p2p
 #pragma unroll
       for (int k = 0; k < 8; ++k) z[k] = quad_sum_f(z[k]) + ((k < nk) ? hbs[k] : 0.f);
       if (q == 0 && grow < a.n) {
-        const int act = discrete8_row_tail(a, nd, grow, z);
+        const int act = discrete8_row_tail(a, nd, grow, z, ctr);
         if (px) {  // push: (stamp << 32 | action) as one 8-byte store into every rank's receive area, slot t mod ll_slots
           const size_t off = (size_t)(px_t % px->ll_slots) * px->world * px->count + (size_t)(px->rank * px_a_local + agent) * a.n + grow;
           const unsigned long long w =
@@ -590,10 +597,9 @@ __device__ __forceinline__ float sum32_upper(float v) {
   return v + dpp_f<0x142>(v);
 }
 __device__ __forceinline__ void head_tail32(const FwdArgs& a, const NetDims& nd, int g, bool row_ok, long long ridx, float z,
-                                            int k, int lo, int last, int comp) {
+                                            int k, int lo, int last, int comp, uint64_t ctr) {
   const bool own = row_ok && comp >= 0;     // this lane holds a real logit of a real row
   const int nk = last - lo + 1;
-  const uint64_t ctr = a.counter + (a.epoch ? (uint64_t)(*a.epoch) << 32 : 0ull);
   if (own && a.mask) z = z - 30.0f * (1.0f - (float)(a.mask[(size_t)g * nd.L + k] != 0));  // modular/policies.py:330-333
   if (own && a.logits) a.logits[(size_t)g * nd.L + k] = z;
   const float M = __shfl(seg_scan32<true>(z, k, lo), last, 32);
@@ -674,6 +680,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   const int D = nd.D;
 
   if constexpr (!FUSED) PH_STAMP(a.prof, 0);
+  const uint64_t ctr = fwd_counter(a);   // (FUSED: the caller folded the epoch into a.counter and passes no pointer)
   // Every global load that does not depend on the observations is issued here, back to back (a kernel starts with cold
   // caches: each dependent round trip costs ~1 us at this occupancy).  The observation -> feature-row loads go first.
   // (Staging the whole of W1 -- 69 KB per net for Liar's Dice -- into LDS so that the gather stays on the CU measured
@@ -834,7 +841,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {   // 32 lanes per row, 8 rows per pass
         const int r = pass * 8 + (tid >> 5);
-        head_tail32(a, nd, row0 + r, row0 + r < a.n, ridxs[r], outs[r * LDO + k], k, lo, last, comp);
+        head_tail32(a, nd, row0 + r, row0 + r < a.n, ridxs[r], outs[r * LDO + k], k, lo, last, comp, ctr);
       }
     }
   } else {
@@ -997,12 +1004,15 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
   const bool keeper = tid512 < 16 && e < g.n;
   // one inlined copy of the forward body: the three forwards of a step are a loop whose argument record is selected with
   // scalar selects (three inlined copies cost 1.4 KB of scratch per lane and 649 spilled SGPRs)
+  // the RNG epoch is constant for the launch: read once here instead of by every forward's sampling tail and every re-deal
+  const unsigned long long epoch_hi = r.epoch ? (unsigned long long)(*r.epoch) << 32 : 0ull;
   for (int ph = 0; ph < 3 * r.n_steps; ++ph) {
     const int t = ph / 3, f = ph - 3 * t;
     const unsigned long long counter = r.counter0 + (unsigned long long)t;
     const size_t row = (size_t)t * g.n;
     FwdArgs a = (f == 0) ? r.ego : ((f == 1) ? r.reply : r.opening);
-    a.counter = (f == 0) ? counter : 2ull * counter + (unsigned long long)(f - 1);
+    a.counter = ((f == 0) ? counter : 2ull * counter + (unsigned long long)(f - 1)) + epoch_hi;
+    a.epoch = nullptr;
     if (f == 0) {
       a.rb_obs += row * a.nd.D;
       a.rb_act += row * a.nd.A;
@@ -1020,14 +1030,18 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
       a.pos_env = s.alt_pos;
       a.rec_mask = s.can;
     }
+    long long* prof = (t == 2) ? r.ego.prof : nullptr;   // debug stamps of the third step (scripts/liar_rollout_profile.py)
+    if (f == 0) PH_STAMP(prof, 8);
     policy_fwd16h_body<false, true>(a, row0, half, tid, sm);
     __syncthreads();
+    PH_STAMP(prof, 9 + 2 * f);
     if (keeper) {
       if (f == 0) liar_sp_after_ego_lane(s, e, r.alt_rewards, r.alt_T);
-      else if (f == 1) liar_sp_after_reply_lane(s, e, r.alt_rewards, r.alt_T, r.ego_rew_row0 + row, counter, r.epoch, 0);
+      else if (f == 1) liar_sp_after_reply_lane(s, e, r.alt_rewards, r.alt_T, r.ego_rew_row0 + row, counter + epoch_hi, nullptr, 0);
       else liar_sp_after_opening_lane(s, e);
     }
     __syncthreads();
+    PH_STAMP(prof, 10 + 2 * f);
   }
 
   // ---- mirror out ----
