@@ -83,8 +83,9 @@ __device__ __forceinline__ void copy_obs_rows(const FwdArgs& a, int row0, int nr
 }
 
 // Philox counter of a forward: the caller's step counter in the low word, the RNG epoch (a device word the iteration graphs
-// advance between replays) in the high one.  Kernels evaluate it FIRST, with their staging loads: read where the sampling tail
-// needs it, the epoch is a dependent round trip to L2 at the end of every forward.
+// advance between replays) in the high one.  A launch that knows the epoch (the persistent Liar's Dice rollout reads it once)
+// folds it into a.counter and passes no pointer, which removes a dependent round trip to L2 from every sampling tail.
+// (Reading the word at the top of the single-step kernels instead measured slower: 6.5 -> 7.0 us per policy_fwd16 launch.)
 __device__ __forceinline__ uint64_t fwd_counter(const FwdArgs& a) {
   return a.counter + (a.epoch ? (uint64_t)(*a.epoch) << 32 : 0ull);
 }
@@ -173,7 +174,7 @@ __device__ __forceinline__ void general_row_tail(const FwdArgs& a, const NetDims
     float zr[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) zr[k] = (k < nd.L) ? z[k] : 0.f;
-    discrete8_row_tail(a, nd, g, zr, ctr);
+    discrete8_row_tail(a, nd, g, zr, fwd_counter(a));
     return;
   } else
   for (int c = 0; c < nd.A; ++c) {
@@ -253,7 +254,6 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
   const float* B2 = a.params + (net == 0 ? lay.pi_b2 : lay.vf_b2);
 
   PH_STAMP(a.prof, 0);
-  const uint64_t ctr = fwd_counter(a);   // the epoch word's load goes out with the staging loads
   // ---- every staging load of the kernel is issued here, back to back: one memory latency in total ----
   if (tid < R) rowphys[tid] = (row0 + tid < a.n) ? row0 + tid : -1;
   WStage<NT> w2r, w1r;
@@ -350,7 +350,7 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
   PH_STAMP(a.prof, 6);
 
   // ---- distribution: one lane per row ----
-  if (tid < R && rowphys[tid] >= 0) general_row_tail(a, nd, row0 + tid, outs + tid * LDO, ctr);
+  if (tid < R && rowphys[tid] >= 0) general_row_tail(a, nd, row0 + tid, outs + tid * LDO, fwd_counter(a));
   PH_STAMP(a.prof, 7);
 }
 
@@ -400,7 +400,6 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a, const ph_p2p
   const int nk = nd.L;
 
   PH_STAMP(a.prof, 0);
-  const uint64_t ctr = fwd_counter(a);   // the epoch word's load goes out with the staging loads
   // every global load of the kernel is issued here; row indices are trivial (row0 + r), so X needs no metadata pass
   if (tid < R) rowphys[tid] = (row0 + tid < a.n) ? row0 + tid : -1;
   WStage<NT> w1r, w2r;
@@ -454,6 +453,9 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a, const ph_p2p
       av[s] = ap[4 * s];
       bv[s] = bp[4 * s * LDH];
     }
+    // keep all 32 operand reads ahead of the products: left to itself the scheduler (in the 512-thread rollout kernel) emits
+    // read - wait - MFMA sixteen times, one LDS latency per product
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 16; s += 2) {
       e = mma16<VALU>(av[s], bv[s], e, lane);
@@ -505,7 +507,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a, const ph_p2p
 #pragma unroll
       for (int k = 0; k < 8; ++k) z[k] = quad_sum_f(z[k]) + ((k < nk) ? hbs[k] : 0.f);
       if (q == 0 && grow < a.n) {
-        const int act = discrete8_row_tail(a, nd, grow, z, ctr);
+        const int act = discrete8_row_tail(a, nd, grow, z, fwd_counter(a));
         if (px) {  // push: (stamp << 32 | action) as one 8-byte store into every rank's receive area, slot t mod ll_slots
           const size_t off = (size_t)(px_t % px->ll_slots) * px->world * px->count + (size_t)(px->rank * px_a_local + agent) * a.n + grow;
           const unsigned long long w =
@@ -680,7 +682,6 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   const int D = nd.D;
 
   if constexpr (!FUSED) PH_STAMP(a.prof, 0);
-  const uint64_t ctr = fwd_counter(a);   // (FUSED: the caller folded the epoch into a.counter and passes no pointer)
   // Every global load that does not depend on the observations is issued here, back to back (a kernel starts with cold
   // caches: each dependent round trip costs ~1 us at this occupancy).  The observation -> feature-row loads go first.
   // (Staging the whole of W1 -- 69 KB per net for Liar's Dice -- into LDS so that the gather stays on the CU measured
@@ -810,6 +811,9 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
       av[s] = ap[4 * s];
       bv[s] = bp[4 * s * LDH];
     }
+    // keep all 32 operand reads ahead of the products: left to itself the scheduler (in the 512-thread rollout kernel) emits
+    // read - wait - MFMA sixteen times, one LDS latency per product
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 16; s += 2) {
       e = mma16<VALU>(av[s], bv[s], e, lane);
@@ -841,7 +845,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {   // 32 lanes per row, 8 rows per pass
         const int r = pass * 8 + (tid >> 5);
-        head_tail32(a, nd, row0 + r, row0 + r < a.n, ridxs[r], outs[r * LDO + k], k, lo, last, comp, ctr);
+        head_tail32(a, nd, row0 + r, row0 + r < a.n, ridxs[r], outs[r * LDO + k], k, lo, last, comp, fwd_counter(a));
       }
     }
   } else {
@@ -849,12 +853,16 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
     // ---- value head: wave 0, four lanes per row, quad-DPP reduction; every wave copies observations ----
     if (wave == 0) {
       const int r = lane >> 2, q = lane & 3;
-      float v = 0.f;
+      float v = 0.f, hx[16], hw[16];
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         const int j = 8 * q + (m & 7) + 32 * (m >> 3);
-        v = __builtin_fmaf(xs[r * LDH + j], wos[j], v);
+        hx[m] = xs[r * LDH + j];
+        hw[m] = wos[j];
       }
+      __builtin_amdgcn_sched_barrier(0);   // the 32 reads in flight together, then the (ordered) sum
+#pragma unroll
+      for (int m = 0; m < 16; ++m) v = __builtin_fmaf(hx[m], hw[m], v);
       v = quad_sum_f(v) + hbs[0];
       if (q == 0 && row0 + r < a.n) value_row_tail(a, row0 + r, v);
     }

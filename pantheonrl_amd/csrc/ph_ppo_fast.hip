@@ -255,11 +255,10 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
     {
       f32x16 acc = {0};
       acc = tile_mma<false, false, VALU>(bufA, LDH, bufC, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
+      const int col = nt * 32 + li;
+      const float bb = b1s[col];   // once: read inside the loop it is re-fetched, and waited for, behind every store to bufB
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
-        bufB[row * LDH + col] = fast_tanh(acc[r] + b1s[col]);
-      }
+      for (int r = 0; r < 16; ++r) bufB[(mt * 32 + drow(r, lh)) * LDH + col] = fast_tanh(acc[r] + bb);
     }
     lds_barrier();
     if (first) PH_STAMP(a.prof, 2);
@@ -269,11 +268,10 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
     {
       f32x16 acc = {0};
       acc = tile_mma<false, false, VALU>(bufB, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
+      const int col = nt * 32 + li;
+      const float bb = b2s[col];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
-        bufA[row * LDH + col] = fast_tanh(acc[r] + b2s[col]);
-      }
+      for (int r = 0; r < 16; ++r) bufA[(mt * 32 + drow(r, lh)) * LDH + col] = fast_tanh(acc[r] + bb);
     }
     lds_barrier();
     if (first) PH_STAMP(a.prof, 3);
@@ -446,11 +444,13 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
     if (first) PH_STAMP(a.prof, 5);
 
     // ---- S6b: dZ1 = dH1 * (1 - H1^2) in place; X back into bufA; W1 back into bufC ----
+    {
+      float hv[16];   // all reads, then all writes: interleaved, every read waits behind the previous (possibly aliasing) store
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + drow(r, lh), col = nt * 32 + li;
-      const float hv = bufB[row * LDH + col];
-      bufB[row * LDH + col] = dh1[r] * (1.0f - hv * hv);
+      for (int r = 0; r < 16; ++r) hv[r] = bufB[(mt * 32 + drow(r, lh)) * LDH + nt * 32 + li];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bufB[(mt * 32 + drow(r, lh)) * LDH + nt * 32 + li] = dh1[r] * (1.0f - hv[r] * hv[r]);
     }
     if (box) xt.commit(bufA, meta.phys, nd, wave, lane);
     else xs.commit(bufA, rowphys, a.rb_obs, nd, 0, tid);
