@@ -453,9 +453,6 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a, const ph_p2p
       av[s] = ap[4 * s];
       bv[s] = bp[4 * s * LDH];
     }
-    // keep all 32 operand reads ahead of the products: left to itself the scheduler (in the 512-thread rollout kernel) emits
-    // read - wait - MFMA sixteen times, one LDS latency per product
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 16; s += 2) {
       e = mma16<VALU>(av[s], bv[s], e, lane);
