@@ -17,6 +17,12 @@ CONFIGS = {
     # filling all 32 logit lanes (the middle one straddles the 16-lane DPP row boundary); one 20-way Discrete head
     "onehot32": (SpaceSpec("multidiscrete", nvec=(3, 4, 5, 2, 6)), SpaceSpec("multidiscrete", nvec=(5, 16, 11))),
     "discrete20": (SpaceSpec("discrete", nvec=(5,)), SpaceSpec("discrete", nvec=(20,))),
+    # every instantiation of the general gradient kernel (observation kind x head class x logit padding): four 16-way action
+    # components = 64 logits through the per-component head phase; one-hot observations of exactly two 64-feature chunks with
+    # a 20-way head (one lane per row); a 17-way component (too wide for the per-component phase) beside a small one
+    "quad16": (SpaceSpec("box", dim=20), SpaceSpec("multidiscrete", nvec=(16, 16, 16, 16))),
+    "onehot128": (SpaceSpec("multidiscrete", nvec=(32, 32, 32, 32)), SpaceSpec("discrete", nvec=(20,))),
+    "onehot17": (SpaceSpec("multidiscrete", nvec=(9, 40, 30)), SpaceSpec("multidiscrete", nvec=(17, 3))),
     # ADAP: the stored observation is (environment observation ++ context) -- adap_learn.py:448-452
     "adap_oc": (SpaceSpec("box", dim=62 + 3), SpaceSpec("discrete", nvec=(6,))),            # two feature chunks
     "adap_small": (SpaceSpec("box", dim=35 + 3), SpaceSpec("discrete", nvec=(5,))),         # the 64-row fast gradient kernel

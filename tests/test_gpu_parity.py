@@ -1041,6 +1041,26 @@ def test_trainer_n_envs_runs_device_selfplay(game, tmp_path):
     assert np.array_equal(again.policy.get_flat_params(), ego.policy.get_flat_params())
 
 
+@pytest.mark.parametrize("name,T,E,nb", [("quad16", 16, 8, 100), ("onehot128", 16, 8, 128), ("onehot17", 16, 6, 77),
+                                          ("onehot32", 16, 8, 90), ("discrete20", 16, 8, 64), ("adap_multi", 16, 6, 70)])
+def test_every_general_gradient_kernel_instantiation_matches_autograd(name, T, E, nb):
+    """ppo_grad_kernel<64, LP, ., OH, H16>: Box / one-hot observations x per-component / one-lane-per-row head x 32 / 64 padded
+    logits: gradient and statistics against autograd, MFMA against the fmaf-chain restatement bit for bit, and a two-epoch
+    update chain."""
+    idx = np.random.default_rng(nb).permutation(T * E)[:nb]
+    hp = orc.PPOHyper(ent_coef=0.01)
+    g, g_ref, st, st_ref, lay = _grad_pair(name, T, E, idx, hp)
+    _assert_grads(g, g_ref, lay)
+    for i, k in enumerate(("policy_loss", "value_loss", "entropy_loss", "clip_fraction", "approx_kl", "loss")):
+        assert abs(st[i] - st_ref[k]) <= 1e-5 + 1e-4 * abs(st_ref[k]), (k, st[i], st_ref[k])
+    g1 = _grad_pair(name, T, E, idx, hp, gemm_mode=1)[0]
+    assert np.array_equal(g, g1), np.abs(g - g1).max()
+    hp2 = orc.PPOHyper(batch_size=nb // 2 + 3, n_epochs=2, ent_coef=0.01)
+    model, orac, stats_ref = _train_pair(name, T, E, hp2)
+    p, p_ref = model.policy.get_flat_params(), orac.flat_params()
+    assert np.abs(p - p_ref).max() <= 2e-6 * len(stats_ref) + 1e-6, np.abs(p - p_ref).max()
+
+
 def test_general_kernels_pass_the_gradient_and_forward_parity_tests_on_the_small_shapes():
     """PH_GRAD_FAST=0 / PH_FWD16=0 / PH_FWD16H=0 route the small and the one-hot shapes through the general kernels (the ones
     the wide shapes always use): the switches are read once per process, so the parity tests run in their own interpreter."""
@@ -1202,11 +1222,14 @@ def test_peer_to_peer_exchange_between_processes(world):
 # ----------------------------------------------------------------------------------------------------------------
 # round 2: sizes and chains the round-1 suite only property-tested, reference-semantics run, truncation bootstrap
 # ----------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name,T,E,nb", [("overcooked", 128, 1024, 32768), ("liar", 128, 256, 8192)])
+@pytest.mark.parametrize("name,T,E,nb", [("overcooked", 128, 1024, 32768), ("liar", 128, 256, 8192),
+                                          ("adap_oc", 128, 256, 32768), ("liar", 128, 256, 32768)])
 def test_full_size_minibatch_gradient_matches_autograd(name, T, E, nb):
     """One whole minibatch of BASELINE configs 3 and 2 at their real sizes (32 768 rows of Overcooked-simple; 8 192 rows of
     Liar's Dice with F = 270 one-hot features and two action components) against autograd on the oracle.  A sum over nb
-    rows in another order: tolerance 2e-4 of the largest gradient entry, as for the small shapes."""
+    rows in another order: tolerance 2e-4 of the largest gradient entry, as for the small shapes.  The 32 768-row cases of
+    the 65-feature Box shape (Overcooked + ADAP context) and of Liar's Dice make every workgroup of the general kernel walk
+    two tiles (slab read-modify-write, row metadata of the next tile staged behind the current one)."""
     idx = np.random.default_rng(nb).permutation(T * E)[:nb]
     g, g_ref, st, st_ref, lay = _grad_pair(name, T, E, idx, orc.PPOHyper())
     _assert_grads(g, g_ref, lay)
