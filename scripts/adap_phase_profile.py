@@ -35,10 +35,10 @@ for rep in range(3):
                                                  g.data_ptr(), st.data_ptr(), 0, C.byref(ad)))
     th.cuda.synchronize()
 nwg = 11
-blk = stamps.cpu().numpy().reshape(-1, 16)[:nwg]
-labels = ["stage weights", "samples", "X gather", "H1, H2", "logits", "softmax, KL, exp", "dlogits", "dZ2, dZ1", "dW1, dW2",
-          "biases, head"]
-d = np.diff(blk[:, :len(labels) + 1].astype(np.float64), axis=1)
-print(f"adap_context_kernel: {nwg} workgroups, total {np.median(blk[:, len(labels)] - blk[:, 0]):.0f} cycles (median)")
-for lab, col in zip(labels, d.T):
-    print(f"    {lab:<24} median {np.median(col):>9.0f}   max {col.max():>9.0f}")
+blk = stamps.cpu().numpy().reshape(-1, 16)[:nwg].astype(np.float64)
+phases = [("weights || samples", 0, 2), ("X gather", 2, 3), ("H1, H2 (MFMA)", 3, 4), ("logits (MFMA)", 4, 5),
+          ("softmax, pairwise KL, dlogits", 5, 7), ("dZ2, dZ1 (MFMA)", 7, 8), ("dW1, dW2, d act_W (MFMA)", 8, 9), ("biases", 9, 10)]
+print(f"adap_context_kernel: {nwg} workgroups, total {np.median(blk[:, 10] - blk[:, 0]):.0f} cycles (median)")
+for lab, i, j in phases:
+    col = blk[:, j] - blk[:, i]
+    print(f"    {lab:<32} median {np.median(col):>9.0f}   max {col.max():>9.0f}")
