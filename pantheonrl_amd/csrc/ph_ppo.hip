@@ -22,6 +22,39 @@ namespace ph {
 // OH: Discrete-family (one-hot) observations -- the chunk loops below differ; H16: the per-component head phase (nd.head16).
 // Compile-time so that the Box / small-head instantiations keep their register budget (the one-hot loop holds the next
 // chunk's W1 rows in registers across the products, the per-component head 32 logit slots).
+// s + sum_{r < n} p[r * stride] in row order, 16 LDS reads in flight at a time (written as a plain loop the compiler emits one
+// read - wait - add per element: 64 LDS latencies on the wave that also owns an MFMA tile of the phase)
+template <int N>
+__device__ __forceinline__ float lds_colsum(const float* p, int stride, float s) {
+#pragma unroll
+  for (int r0 = 0; r0 < N; r0 += 16) {
+    float t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = p[(r0 + i) * stride];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += t[i];
+  }
+  return s;
+}
+// s + sum_{r < n} p[r * stride] * q[r], same batching
+template <int N>
+__device__ __forceinline__ float lds_coldot(const float* p, int stride, const float* q, int qstride, float s) {
+#pragma unroll
+  for (int r0 = 0; r0 < N; r0 += 16) {
+    float t[16], u[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      t[i] = p[(r0 + i) * stride];
+      u[i] = q[(r0 + i) * qstride];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s = __builtin_fmaf(t[i], u[i], s);
+  }
+  return s;
+}
+
 template <int R, int LP, bool VALU, bool OH, bool H16>
 __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   if (*a.stop_flag) return;
@@ -414,7 +447,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       if (tid >= NT - 64 && tid - (NT - 64) < nd.L) {  // last wave: bias gradient
         const int k = tid - (NT - 64);
         float s = first ? 0.f : slab[lay.act_b + k];
-        for (int r = 0; r < R; ++r) s += outs[r * LDO + k];
+        s = lds_colsum<R>(outs + k, LDO, s);
         slab[lay.act_b + k] = s;
       }
       __syncthreads();
@@ -439,7 +472,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
         float dv = 0.f;
         if (phys >= 0) {
           float v = 0.f;
-          for (int j = 0; j < HID; ++j) v = __builtin_fmaf(bufA[tid * LDH + j], bos[j], v);
+          v = lds_coldot<HID>(bufA + tid * LDH, 1, bos, 1, v);
           v += a.params[lay.val_b];
           const float retn = radv[tid], oldv = rold[tid];
           float vp = v, pass = 1.f;
@@ -458,11 +491,11 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       // ---- S5a: d val_W[j] = sum_r H2[r][j] dv[r] ; d val_b = sum_r dv[r] ----
       if (tid < HID) {
         float s = first ? 0.f : slab[lay.val_W + tid];
-        for (int r = 0; r < R; ++r) s = __builtin_fmaf(bufA[r * LDH + tid], rdv[r], s);
+        s = lds_coldot<R>(bufA + tid, LDH, rdv, 1, s);
         slab[lay.val_W + tid] = s;
       } else if (tid == HID) {
         float s = first ? 0.f : slab[lay.val_b];
-        for (int r = 0; r < R; ++r) s += rdv[r];
+        s = lds_colsum<R>(rdv, 1, s);
         slab[lay.val_b] = s;
       }
       __syncthreads();
@@ -492,7 +525,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       for (int r = 0; r < 16; ++r) slab[oW2 + (mt * 32 + drow(r, lh)) * HID + nt * 32 + li] = g[r];
       if (tid < HID) {
         float s = first ? 0.f : slab[oB2 + tid];
-        for (int r = 0; r < R; ++r) s += bufA[r * LDH + tid];
+        s = lds_colsum<R>(bufA + tid, LDH, s);
         slab[oB2 + tid] = s;
       }
       dh1 = tile_mma<false, true, VALU>(bufA, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1, lane);
@@ -515,7 +548,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     // ---- S7: dW1 = X^T dZ1 per feature chunk ; d b1 ----
     if (tid < HID) {
       float s = first ? 0.f : slab[oB1 + tid];
-      for (int r = 0; r < R; ++r) s += bufB[r * LDH + tid];
+      s = lds_colsum<R>(bufB + tid, LDH, s);
       slab[oB1 + tid] = s;
     }
     for (int c = 0; c < nd.nchunk; ++c) {
