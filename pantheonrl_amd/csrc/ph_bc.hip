@@ -350,6 +350,21 @@ struct BcTile {   // which rows of the visiting order a tile covers
   int ep, start, t0, nb;
 };
 
+// the four split-K partial tiles of element o, all reads issued together (4 unrolled elements: 16 reads in flight)
+#define BC_PART4(dst, base)                                                                                        \
+  do {                                                                                                             \
+    float pa_[4], pb_[4], pc_[4], pd_[4];                                                                          \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                             \
+      const int o_ = (base) + j_;                                                                                  \
+      pa_[j_] = part[o_];                                                                                          \
+      pb_[j_] = part[BR * BLD + o_];                                                                               \
+      pc_[j_] = part[2 * BR * BLD + o_];                                                                           \
+      pd_[j_] = part[3 * BR * BLD + o_];                                                                           \
+    }                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)(dst)[j_] = (pa_[j_] + pb_[j_]) + (pc_[j_] + pd_[j_]);         \
+  } while (0)
+
 template <bool moments_in_lds>
 __global__ __launch_bounds__(256) void bc_train_mfma_kernel(BcArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -499,10 +514,13 @@ __global__ __launch_bounds__(256) void bc_train_mfma_kernel(BcArgs a) {
         for (int q = 0; q < 16; ++q) part[(wave * BR + drow(q, lh)) * BLD + li] = acc[q];
       }
       __syncthreads();
+      {
+        float sum4[4], b4[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = 4 * cg + j, o = r * BLD + c;
-        h1s[o] = bc_tanh(((part[o] + part[BR * BLD + o]) + (part[2 * BR * BLD + o] + part[3 * BR * BLD + o])) + ps[lay.b1 + c]);
+        for (int j = 0; j < 4; ++j) b4[j] = ps[lay.b1 + 4 * cg + j];
+        BC_PART4(sum4, r * BLD + 4 * cg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h1s[r * BLD + 4 * cg + j] = bc_tanh(sum4[j] + b4[j]);
       }
       __syncthreads();
       BC_STAMP(1);
@@ -514,10 +532,13 @@ __global__ __launch_bounds__(256) void bc_train_mfma_kernel(BcArgs a) {
         for (int q = 0; q < 16; ++q) part[(wave * BR + drow(q, lh)) * BLD + li] = acc[q];
       }
       __syncthreads();
+      {
+        float sum4[4], b4[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = 4 * cg + j, o = r * BLD + c;
-        h2s[o] = bc_tanh(((part[o] + part[BR * BLD + o]) + (part[2 * BR * BLD + o] + part[3 * BR * BLD + o])) + ps[lay.b2 + c]);
+        for (int j = 0; j < 4; ++j) b4[j] = ps[lay.b2 + 4 * cg + j];
+        BC_PART4(sum4, r * BLD + 4 * cg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h2s[r * BLD + 4 * cg + j] = bc_tanh(sum4[j] + b4[j]);
       }
       __syncthreads();
       BC_STAMP(2);
@@ -528,10 +549,14 @@ __global__ __launch_bounds__(256) void bc_train_mfma_kernel(BcArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) part[(wave * BR + drow(q, lh)) * BLD + li] = acc[q];
         __syncthreads();
+        {
+          float sum4[4];
+          BC_PART4(sum4, r * BLD + 4 * cg);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int cc = 4 * cg + j, c = 32 * nt + cc, o = r * BLD + cc;
-          if (c < L) zs[r * ZP + c] = ((part[o] + part[BR * BLD + o]) + (part[2 * BR * BLD + o] + part[3 * BR * BLD + o])) + ps[lay.act_b + c];
+          for (int j = 0; j < 4; ++j) {
+            const int c = 32 * nt + 4 * cg + j;
+            if (c < L) zs[r * ZP + c] = sum4[j] + ps[lay.act_b + c];
+          }
         }
         __syncthreads();
       }
@@ -576,12 +601,12 @@ __global__ __launch_bounds__(256) void bc_train_mfma_kernel(BcArgs a) {
       if (wave == 0) {
         f32x16 acc = {0};
         acc = tile_mma<false, true, false>(zs, ZP, ps + lay.act_W, L, 0, 0, 0, Lk, acc, lane);
+        float hv[16];   // all reads, then all writes (the compiler serialises read - wait - write pairs it cannot prove disjoint)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int o = drow(q, lh) * BLD + li;
-          const float hv = h2s[o];
-          dz2s[o] = acc[q] * (1.0f - hv * hv);
-        }
+        for (int q = 0; q < 16; ++q) hv[q] = h2s[drow(q, lh) * BLD + li];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dz2s[drow(q, lh) * BLD + li] = acc[q] * (1.0f - hv[q] * hv[q]);
       }
       __syncthreads();
       BC_STAMP(5);
@@ -593,11 +618,20 @@ __global__ __launch_bounds__(256) void bc_train_mfma_kernel(BcArgs a) {
         for (int q = 0; q < 16; ++q) part[(wave * BR + drow(q, lh)) * BLD + li] = acc[q];
       }
       __syncthreads();
+      {
+        float hv[4], pa[4], pb[4], pc[4], pd[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int o = r * BLD + 4 * cg + j;
-        const float hv = h1s[o];
-        dz1s[o] = ((part[o] + part[BR * BLD + o]) + (part[2 * BR * BLD + o] + part[3 * BR * BLD + o])) * (1.0f - hv * hv);
+        for (int j = 0; j < 4; ++j) {
+          const int o = r * BLD + 4 * cg + j;
+          hv[j] = h1s[o];
+          pa[j] = part[o];
+          pb[j] = part[BR * BLD + o];
+          pc[j] = part[2 * BR * BLD + o];
+          pd[j] = part[3 * BR * BLD + o];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dz1s[r * BLD + 4 * cg + j] = ((pa[j] + pb[j]) + (pc[j] + pd[j])) * (1.0f - hv[j] * hv[j]);
       }
       __syncthreads();
       BC_STAMP(6);
