@@ -65,10 +65,12 @@ class AdapPolicy(ActorCriticPolicy):
         self.observation_space = observation_space
         self.env_obs_len = int(np.prod(sp.obs_stored_shape(observation_space)))   # stored length of a raw observation
         self.context: Optional[np.ndarray] = None   # (1, ctx) shared by every row, or (n, ctx) one per environment column
+        self._context_dev: Optional[th.Tensor] = None
 
     def set_context(self, ctxt) -> None:            # policies.py:96-97
         self.context = np.asarray(ctxt.detach().cpu() if isinstance(ctxt, th.Tensor) else ctxt, np.float32).reshape(
             -1, self.context_size)
+        self._context_dev = th.as_tensor(self.context).to(self.device)   # one upload per change, not one per forward
 
     def get_context(self) -> np.ndarray:            # policies.py:99-100
         return self.context
@@ -91,7 +93,7 @@ class AdapPolicy(ActorCriticPolicy):
         t = self.features(t.reshape(-1, self.env_obs_len))
         if self.context is None:
             raise nat.NativeError("AdapPolicy: no context set")
-        c = th.as_tensor(self.context).to(self.device)
+        c = self._context_dev
         if c.shape[0] != t.shape[0]:
             if c.shape[0] != 1:
                 raise nat.NativeError(f"AdapPolicy: {c.shape[0]} contexts for {t.shape[0]} observation rows")

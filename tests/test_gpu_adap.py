@@ -100,6 +100,8 @@ def _assert_grads(g, g_ref):
     ("adap_oc", 16, 8, 128, 2, 7),       # one pair
     ("adap_small", 16, 8, 64, 16, 5),    # one state per workgroup, 120 pairs
     ("adap_small", 16, 8, 64, 8, 33),
+    ("adap_oc", 128, 256, 32768, 5, 32),  # a whole bench-size minibatch (two-chunk general gradient kernel + the term)
+    ("adap_small", 128, 256, 32768, 5, 32),   # the same on the 64-row fast gradient kernel
 ])
 def test_context_term_gradient_matches_autograd(name, T, E, nb, n_ctx, n_states):
     idx = np.random.default_rng(nb).permutation(T * E)[:nb]
