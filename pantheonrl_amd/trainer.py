@@ -85,9 +85,23 @@ def gen_load(config: dict, policy_type: str, location: str):
         agent = ADAP.load(location, device=config.get("device", "cuda"))
         agent.policy.set_context(np.asarray(config.pop("latent_val"), np.float32))
         return agent
+    if policy_type == "BC":         # trainer.py:152-153: BCShell(reconstruct_policy(location)) -- an object with a .policy
+        from .bc import reconstruct_policy
+        return _bc_shell(reconstruct_policy(location, device=config.get("device", "cuda")))
     if policy_type != "PPO":
         raise EnvException("Not a valid FIXED/LOAD policy")
     return PPO.load(location, device=config.get("device", "cuda"))
+
+
+class _BCShell:
+    """pantheonrl.algos.bc.BCShell (bc.py:29-31): just enough of a model for StaticPolicyAgent / tester.py"""
+
+    def __init__(self, policy):
+        self.policy = policy
+
+
+def _bc_shell(policy) -> _BCShell:
+    return _BCShell(policy)
 
 
 def generate_ego(env, args):

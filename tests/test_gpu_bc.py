@@ -140,3 +140,28 @@ def test_bc_valu_kernel_passes_the_same_parity_tests():
                           "train_matches_oracle or other_batch_sizes or n_batches_mode"], cwd=root,
                          env={**os.environ, "PH_BC_MFMA": "0"}, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+def test_record_clone_and_test_pipeline(tmp_path, monkeypatch):
+    """the reference's three CLIs chained (trainer.py --record -> bctrainer.py -> tester.py, README "behavioural cloning"
+    workflow): a PPO ego is trained against the fixed-rock default partner while the joint trajectory is recorded, a clone is
+    fitted to the ego's side of it, and both the clone and the saved ego are then played through tester.py"""
+    from pantheonrl_amd import bctrainer, tester, trainer
+    monkeypatch.chdir(tmp_path)
+    cfg = '{"n_steps": 64, "batch_size": 32, "n_epochs": 2}'
+    trainer.run(["RPS-v0", "PPO", "DEFAULT", "--seed", "1", "-t", "256", "--ego-config", cfg, "--alt-config", '{"r": 1}',
+                 "--record", "demo.npy", "--ego-save", "m/ego"])
+    clone = bctrainer.run(["RPS-v0", "demo.npy", "--total-epochs", "3", "--save", "m/clone.pt"])
+    assert clone.last_stats is not None and np.isfinite(clone.last_stats).all()
+    alt_clone = bctrainer.run(["RPS-v0", "demo.npy", "--choose-alt", "-t", "1"])     # the partner's side of the same file
+    assert alt_clone.policy.layout.P == clone.policy.layout.P
+    for argv in (["RPS-v0", "BC", "DEFAULT", "--ego-load", "m/clone.pt", "--alt-config", '{"r": 1}', "-t", "12"],
+                 ["RPS-v0", "PPO", "PPO", "--ego-load", "m/ego", "--alt-load", "m/ego", "-t", "12", "--record", "eval.npy"],
+                 ["RPS-v0", "PPO", "BC", "--ego-load", "m/ego", "--alt-load", "m/clone.pt", "-t", "5"]):
+        rewards = tester.run(argv)
+        assert len(rewards) == int(argv[argv.index("-t") + 1]) and all(r in (-1.0, 0.0, 1.0) for r in rewards)
+    assert (tmp_path / "eval.npy").exists()
+    with pytest.raises(trainer.EnvException):
+        tester.run(["RPS-v0", "PPO", "DEFAULT", "-t", "1"])                          # no --ego-load
+    with pytest.raises(trainer.EnvException):
+        tester.run(["RPS-v0", "PPO", "PPO", "--ego-load", "m/ego", "-t", "1"])      # partner type needs --alt-load

@@ -468,3 +468,19 @@ def test_games_reproduce_the_hand_worked_traces_and_the_committed_fixture():
             assert np.array_equal(np.asarray(o, np.float32), z["liar_obs"][s, e]) and tuple(r) == tuple(z["liar_rew"][s, e])
             assert bool(d) == bool(z["liar_done"][s, e])
         turn = ~turn
+
+
+def test_tester_and_bctrainer_cli_surface():
+    """tester.py:14-31 / bctrainer.py:26-67: flags and the load-iff-not-DEFAULT rule (no GPU: nothing is constructed)"""
+    from pantheonrl_amd import bctrainer, tester, trainer
+    a = tester.build_parser().parse_args(["RPS-v0", "PPO", "DEFAULT", "--ego-load", "m/ego", "-t", "7", "--alt-config", '{"r": 2}',
+                                          "-f", "3", "--render", "-r", "out.npy"])
+    tester.input_check(a)
+    assert (a.total_episodes, a.framestack, a.record, a.alt_config, a.ego_config) == (7, 3, "out.npy", {"r": 2}, {"verbose": 1})
+    for bad in (["RPS-v0", "PPO", "DEFAULT"], ["RPS-v0", "PPO", "PPO", "--ego-load", "x"],
+                ["RPS-v0", "PPO", "DEFAULT", "--ego-load", "x", "--alt-load", "y"], ["RPS-v0", "ModularAlgorithm", "PPO", "--ego-load", "x"]):
+        with pytest.raises(trainer.EnvException):
+            tester.input_check(tester.build_parser().parse_args(bad))
+    b = bctrainer.build_parser().parse_args(["LiarsDice-v0", "demo.npy", "--choose-alt", "-t", "4", "--l2", "0.01", "--save", "c.pt"])
+    assert (b.env, b.trajectory, b.choose_alt, b.total_epochs, b.l2, b.save, b.framestack) == ("LiarsDice-v0", "demo.npy", True, 4,
+                                                                                             0.01, "c.pt", 1)
