@@ -84,6 +84,12 @@ def parse():
                          "eager: per-agent launches; roundrobin: BASELINE config 4 -- one ego (rank 0, hosting the environments) "
                          "against --gpus - 1 partners, one agent per GPU, per-environment round-robin partner ids, partner "
                          "observations routed from the ego's rank (pantheonrl_amd/roundrobin.py)")
+    ap.add_argument("--rollout", choices=("stepwise", "scripted"), default="scripted",
+                    help="N=1 graph mode only.  scripted (default): the synthetic transitions are a script resident in HBM, so the "
+                         "n_steps steps of a learner run as ONE launch (ph_scripted_rollout; bitwise the stepwise walk, test "
+                         "test_scripted_rollout_is_bitwise_the_per_step_walk); the line then also carries the stepwise figure "
+                         "(`stepwise_rollout`).  stepwise: one launch per environment step (get_action / update per step, as an "
+                         "external environment or the N>1 per-step action exchange drives them)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "exercise the N>1 code path with several ranks on ONE GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -365,7 +371,7 @@ def main():
         exchange.requested_route = os.environ.get("PANTHEON_EXCHANGE", "auto")
 
     if mode == "graph":
-        graphs = [IterationGraph(a, d, s) for a, d, s in zip(agents, datas, streams)]
+        graphs = [IterationGraph(a, d, s, scripted=args.rollout == "scripted") for a, d, s in zip(agents, datas, streams)]
 
         def iteration():
             for g in graphs:
@@ -459,12 +465,31 @@ def main():
                        else "single process") + ")",
                    "exchange": ({"route": exchange.route, **exchange.route_log, "p2p_timeouts": exchange.p2p_timeouts()}
                                 if exchange is not None and hasattr(exchange, "route") else None),
-                   "launch_mode": mode},
+                   "launch_mode": mode,
+                   "rollout": (args.rollout if mode == "graph" else "stepwise")},
     }
     if exchange is not None and hasattr(exchange, "route") and exchange.p2p_timeouts() != 0:
         raise SystemExit(f"bench.py: rank {rank}: {exchange.p2p_timeouts()} peer-to-peer polls timed out -- the run is invalid")
     if distributed and ranks_seen != args.gpus:
         raise SystemExit(f"bench.py: the collective saw {ranks_seen} ranks, --gpus is {args.gpus}")
+    if mode == "graph" and args.rollout == "scripted":
+        # the same iteration with one launch per environment step, timed in the same process on the same agents: what the
+        # scripted rollout saves is launch boundaries, nothing else (the two walks are bitwise equal)
+        sgraphs = [IterationGraph(a, d, s) for a, d, s in zip(agents, datas, streams)]
+        for _ in range(2):
+            for g in sgraphs:
+                g.launch()
+        barrier()
+        k2 = max(1, min(args.steps, 10))
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            for g in sgraphs:
+                g.launch()
+        barrier()
+        dt2 = time.perf_counter() - t1
+        result["stepwise_rollout"] = {"value": steps_per_iter * k2 / dt2, "unit": "agent-steps/s", "ms_per_step": 1e3 * dt2 / k2,
+                                      "steps": k2, "note": "one launch per environment step inside the iteration graphs "
+                                      "(--rollout stepwise); the N>1 layouts exchange actions every step and run this way"}
     if rank == 0:
         if not args.no_roofline:
             result["roofline"] = roofline(args, agents[0])

@@ -371,6 +371,22 @@ int ph_liar_selfplay_step(ph_ctx *ctx, const ph_liar_selfplay *s, int ego_pos, u
  * <= 32 logits). */
 int ph_liar_selfplay_rollout(ph_ctx *ctx, const ph_liar_selfplay *s, int ego_pos, int n_steps, unsigned long long counter);
 
+/* n_steps vectorised agent steps against a SCRIPTED environment -- observations, rewards and dones of every step already
+ * resident on the device (the synthetic rollout driver of SURVEY.md 8d; a recorded trajectory being replayed) -- in ONE launch:
+ * a workgroup stages the network once and walks the steps of its 16 environments.  Exactly, bit for bit,
+ *     for t in 0 .. n_steps-1:  ph_policy_forward(obs_seq[t], counter0 + t, rb, pos0 + t,
+ *                                                 episode_start_in = t ? done_seq[t-1] : episode_start0,
+ *                                                 pending_reward   = t ? rew_seq[t-1]  : NULL)
+ *     ph_buffer_add_reward(rb, pos0 + n_steps - 1, rew_seq[n_steps-1], NULL)
+ * i.e. OnPolicyAgent.get_action / update per step (agents.py:111-203) with the launch boundaries removed; actions / values /
+ * log_probs (n, .) end up holding the last step's outputs, as after the per-step calls.  obs_seq (n_steps, n, D), rew_seq and
+ * done_seq (n_steps, n) f32.  Shapes of the 16-row forward only (one feature chunk, one Discrete head of <= 8 logits,
+ * n < 16384); anything else is an error, not a slower path. */
+int ph_scripted_rollout(ph_ctx *ctx, const ph_spec *spec, const float *params, const float *obs_seq, const float *rew_seq,
+                        const float *done_seq, int n, int n_steps, const float *episode_start0, unsigned long long seed,
+                        unsigned long long counter0, int *actions_i32, float *values, float *log_probs, const ph_rollout *rb,
+                        int pos0, int gemm_mode);
+
 /* Frame stack as a device ring buffer <- HistoryQueue.add / reset, wrappers.py:37-71, applied to
  * n environments: stack (n, numframes*D) f32 holds the last numframes observations NEWEST FIRST; for envs with
  * reset_mask[e] != 0 the history is first refilled with default_obs (D, NULL = zeros), then obs (n, D) is pushed. */

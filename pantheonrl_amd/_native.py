@@ -166,6 +166,8 @@ SIGNATURES = {
     "ph_liar_selfplay_step": [_vp, C.POINTER(PhLiarSelfPlay), _i, _ull, _i],
     "ph_liar_selfplay_rollout": [_vp, C.POINTER(PhLiarSelfPlay), _i, _i, _ull],
     "ph_framestack_push": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "ph_scripted_rollout": [_vp, C.POINTER(PhSpec), _vp, _vp, _vp, _vp, _i, _i, _vp, _ull, _ull, _vp, _vp, _vp,
+                            C.POINTER(PhRollout), _i, _i],
     "ph_ppo_train": [_vp, C.POINTER(PhSpec), C.POINTER(PhOptState), C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i,
                      _vp, _ull, _vp, _i],
     "ph_ppo_train_multi": [C.POINTER(PhTrainCall), _i],

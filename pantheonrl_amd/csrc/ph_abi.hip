@@ -521,6 +521,51 @@ int ph_policy_forward(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   return 0;
 }
 
+int ph_scripted_rollout(ph_ctx* ctx, const ph_spec* spec, const float* params, const float* obs_seq, const float* rew_seq,
+                        const float* done_seq, int n, int n_steps, const float* episode_start0, unsigned long long seed,
+                        unsigned long long counter0, int* actions_i32, float* values, float* log_probs, const ph_rollout* rb,
+                        int pos0, int gemm_mode) {
+  DevGuard dev_guard(ctx);
+  if (!ctx) return fail("null ctx");
+  if (!params || !obs_seq || !rew_seq || !done_seq || !episode_start0) return fail("ph_scripted_rollout: null argument");
+  if ((uintptr_t)params % 16 != 0) return fail("ph_scripted_rollout: params must be 16-byte aligned");
+  if (n <= 0 || n_steps <= 0) return fail("ph_scripted_rollout: n and n_steps must be positive");
+  if (check_rb(rb)) return 1;
+  if (n != rb->E) return fail("ph_scripted_rollout: n must equal the rollout buffer's E");
+  if (pos0 < 0 || pos0 + n_steps > rb->T) return fail("ph_scripted_rollout: rows pos0 .. pos0 + n_steps - 1 must lie in the buffer");
+  ph::FwdArgs a;
+  std::memset(&a, 0, sizeof(a));
+  if (resolve(ctx, spec, &a.nd)) return 1;
+  if (!ph::fwd16_eligible(a.nd, n))
+    return fail("ph_scripted_rollout: needs the 16-row forward's shape class (one feature chunk, one Discrete head of <= 8 logits, "
+                "n < 16384); use ph_policy_forward per step");
+  a.params = params;
+  a.obs = obs_seq;
+  a.n = n;
+  a.seed = seed;
+  a.counter = counter0;
+  a.epoch = ctx->rng_epoch;
+  a.prof = ctx->prof;
+  a.act_i32 = actions_i32;
+  a.values = values;
+  a.logp = log_probs;
+  const size_t row = (size_t)pos0 * rb->E;
+  a.rb_obs = rb->observations + row * a.nd.D;
+  a.rb_act = rb->actions + row * a.nd.A;
+  a.rb_rew = rb->rewards + row;
+  a.rb_es = rb->episode_starts + row;
+  a.rb_val = rb->values + row;
+  a.rb_logp = rb->log_probs + row;
+  a.es_in = episode_start0;
+  ph::ScriptedSteps sc;
+  sc.n_steps = n_steps;
+  sc.obs_seq = obs_seq;
+  sc.rew_seq = rew_seq;
+  sc.done_seq = done_seq;
+  PH_HIP(ph::launch_policy_fwd16_rollout(a, sc, gemm_mode, ctx->stream));
+  return 0;
+}
+
 namespace {
 int step_multi_impl(ph_ctx* ctx, int n_calls, const ph_step_call* calls, const ph_p2p* x, int t);
 }

@@ -51,6 +51,16 @@ struct FwdArgs {
   float bonus;
 };
 
+// T steps of the 16-row forward against a scripted environment inside one launch (policy_fwd16_rollout_kernel): the per-step
+// argument record is derived from the step-0 record `a` -- observation / reward / done rows t of the three sequences, rollout
+// buffer rows pos0 + t, Philox counter counter0 + t
+struct ScriptedSteps {
+  int n_steps;
+  const float* obs_seq;    // (T, n, D)
+  const float* rew_seq;    // (T, n)
+  const float* done_seq;   // (T, n)
+};
+
 constexpr int MAX_LOCAL_AGENTS = 4;
 // peer-to-peer exchange fused into the step launch (policy_fwd16_multi_kernel): the policy workgroups store every row's sampled
 // action, stamp in-band, straight into every rank's receive area; consumers poll the words they need.  x.world == 0: off.
@@ -65,6 +75,7 @@ struct FwdMulti {
   P2PStep px;
 };
 bool fwd16_eligible(const NetDims& nd, int n);
+hipError_t launch_policy_fwd16_rollout(const FwdArgs& a, const ScriptedSteps& sc, int gemm_mode, hipStream_t s);
 
 struct GradArgs {
   NetDims nd;

@@ -372,12 +372,15 @@ __device__ __forceinline__ float quad_sum_f(float v) {
   return v;
 }
 
+// sc != nullptr: the scripted rollout -- the weights are staged once and the step below runs sc->n_steps times, each time on
+// the next rows of the observation / reward / done sequences and of the rollout buffer (see ScriptedSteps)
 template <bool VALU>
-__device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a, const ph_p2p* px = nullptr, int px_t = 0, int px_a_local = 0,
-                                                  int agent = 0) {
+__device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2p* px = nullptr, int px_t = 0, int px_a_local = 0,
+                                                  int agent = 0, const ScriptedSteps* sc = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16, NT = 256;
-  const NetDims& nd = a.nd;
+  const NetDims& nd = a0.nd;
+  FwdArgs a = a0;
   float* xs = smem;                 // [16][LDH]  X, later H2
   float* hs = xs + R * LDH;         // [16][LDH]  H1
   float* w1s = hs + R * LDH;        // [64][LDH]
@@ -423,6 +426,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a, const ph_p2p
   }
   XStage<R, NT> xr;
   lds_only_barrier();  // rowphys visible
+  if (sc) a.obs = sc->obs_seq;
   xr.issue(rowphys, a.obs, nd, 0);
   w1r.commit(w1s);
   w2r.commit(w2s);
@@ -441,6 +445,34 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a, const ph_p2p
   xr.commit(xs, rowphys, a.obs, nd, 0);
   lds_only_barrier();
   PH_STAMP(a.prof, 1);
+
+  const int n_steps = sc ? sc->n_steps : 1;
+  unsigned long long epoch_hi = 0ull;
+  if (sc) {   // the RNG epoch word is constant for the launch: one read instead of one per sampling tail
+    epoch_hi = a0.epoch ? (unsigned long long)(*a0.epoch) << 32 : 0ull;
+    a.epoch = nullptr;
+    a.counter = a0.counter + epoch_hi;
+  }
+  for (int t = 0; t < n_steps; ++t) {
+  if (t > 0) {   // (scripted rollout) the next step's argument record and observation rows; the weights stay where they are
+    const size_t row = (size_t)t * a0.n;
+    a.obs = sc->obs_seq + row * nd.D;
+    a.counter = a0.counter + (unsigned long long)t + epoch_hi;
+    a.rb_obs = a0.rb_obs + row * nd.D;
+    a.rb_act = a0.rb_act + row * nd.A;
+    a.rb_rew = a0.rb_rew + row;
+    a.rb_es = a0.rb_es + row;
+    a.rb_val = a0.rb_val + row;
+    a.rb_logp = a0.rb_logp + row;
+    a.es_in = sc->done_seq + (row - a0.n);          // Agent.update(reward, done) of the previous step:
+    a.pending_reward = sc->rew_seq + (row - a0.n);  //   last_episode_starts = done, rewards[pos - 1] += reward
+    a.prev_rew = a0.rb_rew + (row - a0.n);
+    a.prof = nullptr;
+    lds_only_barrier();   // the previous step's head is done with xs (H2)
+    xr.issue(rowphys, a.obs, nd, 0);
+    xr.commit(xs, rowphys, a.obs, nd, 0);
+    lds_only_barrier();
+  }
 
   // one 16x16 output tile per wave: D[row 4g+r][col 16*wave + c] = sum_k A[row][k] W[k][col]; two accumulator chains
   auto layer = [&](const float* A, const float* W) -> f32x4 {
@@ -518,16 +550,25 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a, const ph_p2p
 #pragma unroll
       for (int m = 0; m < 16; ++m) v = __builtin_fmaf(h[m], hw[8 * q + (m & 7) + 32 * (m >> 3)], v);
       v = quad_sum_f(v) + hbs[0];
-      if (q == 0 && grow < a.n) value_row_tail(a, grow, v);
+      if (q == 0 && grow < a.n) {
+        value_row_tail(a, grow, v);
+        // (scripted rollout) the last step's own reward: the flush that precedes GAE on the launch-by-launch path
+        if (sc && t == n_steps - 1) a.rb_rew[grow] += sc->rew_seq[(size_t)t * a0.n + grow];
+      }
     }
   }
   if (net == 1) copy_obs_rows(a, row0, (a.n - row0 < R) ? a.n - row0 : R, nd.D);
   PH_STAMP(a.prof, 7);
+  }
 }
 
 template <bool VALU>
 __global__ __launch_bounds__(256) void policy_fwd16_kernel(FwdArgs a) {
   policy_fwd16_body<VALU>(a);
+}
+template <bool VALU>
+__global__ __launch_bounds__(256) void policy_fwd16_rollout_kernel(FwdArgs a, ScriptedSteps sc) {
+  policy_fwd16_body<VALU>(a, nullptr, 0, 0, 0, &sc);
 }
 __global__ __launch_bounds__(256) void policy_fwd16_multi_kernel(FwdMulti m) {
   policy_fwd16_body<false>(m.a[blockIdx.z], m.px.x, m.px.t, m.px.a_local, blockIdx.z);
@@ -555,6 +596,14 @@ static hipError_t launch_fwd16_variant(const FwdArgs& a, hipStream_t s) {
     allowed = true;
   }
   hipLaunchKernelGGL((policy_fwd16_kernel<VALU>), dim3((a.n + 15) / 16, 2), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_policy_fwd16_rollout(const FwdArgs& a, const ScriptedSteps& sc, int gemm_mode, hipStream_t s) {
+  const size_t lds = fwd16_lds_bytes();
+  dim3 grid((a.n + 15) / 16, 2), block(256);
+  if (gemm_mode != 0) hipLaunchKernelGGL((policy_fwd16_rollout_kernel<true>), grid, block, lds, s, a, sc);
+  else hipLaunchKernelGGL((policy_fwd16_rollout_kernel<false>), grid, block, lds, s, a, sc);
   return hipGetLastError();
 }
 

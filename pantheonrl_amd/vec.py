@@ -68,6 +68,27 @@ class VecOnPolicyAgent:
         self.num_timesteps += self.E
         return self.actions
 
+    def rollout_scripted(self, data: "SyntheticRollouts") -> None:
+        """data.T x (get_action(data.obs[t]); update(data.rewards[t], data.dones[t])) as ONE launch (ph_scripted_rollout): the
+        environment is a script -- every step's observation, reward and done already sit in HBM -- so nothing has to return to
+        the host, or even to a launch boundary, between steps.  Bitwise the per-step calls (test); needs an empty buffer of
+        exactly data.T rows and the 16-row forward's shape class (raises otherwise)."""
+        model = self.model
+        pol, rb = model.policy, model.rollout_buffer
+        if rb.pos != 0 or data.T != rb.buffer_size or data.E != self.E:
+            raise nat.NativeError("rollout_scripted: needs an empty rollout buffer of data.T rows and data.E environments")
+        self.flush_rewards()
+        nat.check(self._lib.ph_scripted_rollout(
+            self._h, self._spec, pol.params.data_ptr(), data.obs.data_ptr(), data.rewards.data_ptr(), data.dones.data_ptr(),
+            self.E, data.T, self._last_episode_starts.data_ptr(), pol._seed, pol._counter + 1, self.actions.data_ptr(),
+            self.values.data_ptr(), self.log_probs.data_ptr(), self._rb, 0, int(pol.gemm_mode)))
+        pol._counter += data.T
+        rb.pos, rb.full = data.T, True
+        self.n_steps += data.T
+        self.num_timesteps += data.T * self.E
+        self._last_episode_starts = data.dones[data.T - 1]
+        self._pending = None          # the last step's reward is already in its row
+
     def update(self, reward: th.Tensor, done: th.Tensor, env_mask: Optional[th.Tensor] = None) -> None:
         if self._pending is not None or env_mask is not None:
             self.flush_rewards()              # a second update for the same action: rewards add up (agents.py:44-47)
@@ -161,34 +182,37 @@ class SyntheticRollouts:
         self.T, self.E = T, E
 
 
-def run_iteration_eager(agent: VecOnPolicyAgent, data: SyntheticRollouts) -> None:
+def run_iteration_eager(agent: VecOnPolicyAgent, data: SyntheticRollouts, scripted: bool = False) -> None:
     """one PPO iteration: T x (get_action, update), then GAE + train at the head of the next get_action -- here
-    invoked explicitly so an iteration is self-contained."""
+    invoked explicitly so an iteration is self-contained.  scripted: the T steps as one launch (rollout_scripted)."""
     agent.bind_stream()
-    for t in range(data.T):
-        agent.get_action(data.obs[t])
-        agent.update(data.rewards[t], data.dones[t])
+    if scripted:
+        agent.rollout_scripted(data)
+    else:
+        for t in range(data.T):
+            agent.get_action(data.obs[t])
+            agent.update(data.rewards[t], data.dones[t])
     agent.learn_from_buffer()
 
 
 class IterationGraph:
     """One whole PPO iteration of one agent captured as a hipGraph on the agent's own stream."""
 
-    def __init__(self, agent: VecOnPolicyAgent, data: SyntheticRollouts, stream: th.cuda.Stream):
-        self.agent, self.data, self.stream = agent, data, stream
+    def __init__(self, agent: VecOnPolicyAgent, data: SyntheticRollouts, stream: th.cuda.Stream, scripted: bool = False):
+        self.agent, self.data, self.stream, self.scripted = agent, data, stream, scripted
         pol = agent.model.policy
         self.epoch_word = th.zeros(1, dtype=th.int64, device=pol.device)
         nat.check(pol.ctx.lib.ph_ctx_set_rng_epoch(pol.ctx.handle, self.epoch_word.data_ptr()))
         agent.model.device_permutations = True   # in-kernel Feistel permutations: nothing host-generated per replay
         with th.cuda.stream(stream):
-            run_iteration_eager(agent, data)     # warm-up outside capture: sizes the workspace, caches the spec
-            run_iteration_eager(agent, data)
+            run_iteration_eager(agent, data, scripted)     # warm-up outside capture: sizes the workspace, caches the spec
+            run_iteration_eager(agent, data, scripted)
             stream.synchronize()
             agent.bind_stream()
             lib, h = pol.ctx.lib, pol.ctx.handle
             nat.check(lib.ph_graph_begin(h))
             try:
-                run_iteration_eager(agent, data)
+                run_iteration_eager(agent, data, scripted)
                 nat.check(lib.ph_rng_epoch_advance(h))
             finally:
                 gid = C.c_int(-1)

@@ -1514,3 +1514,59 @@ def test_liar_persistent_rollout_is_bitwise_the_step_by_step_walk():
             rows = np.arange(x.shape[0])[:, None] < pos[None, :]
             x, y = x[rows], y[rows]
         assert np.array_equal(x, y), key
+
+
+@pytest.mark.parametrize("E,T", [(96, 12), (40, 7), (1024, 128)])
+def test_scripted_rollout_is_bitwise_the_per_step_walk(E, T):
+    """ph_scripted_rollout (ONE launch: a workgroup stages the network once and walks the T steps of its 16 environments)
+    against T x (get_action, update): identical rollout-buffer rows (observations, actions, values, log-probs, episode starts,
+    rewards incl. the last step's), identical cached outputs of the last step, and -- after GAE and the update -- identical
+    advantages and parameters, over two iterations (the second starts from the first's last dones).  E = 40 leaves the last
+    workgroup with 8 live rows; (1024, 128) is the bench size."""
+    from pantheonrl_amd.vec import run_iteration_eager
+    runs = []
+    for scripted in (False, True):
+        _, model, agent, data = _vec_setup(T=T, E=E, seed=5, n_epochs=1)
+        model.device_permutations = True
+        snaps = []
+        for it in range(2):
+            agent.bind_stream()
+            if scripted:
+                agent.rollout_scripted(data)
+            else:
+                for t in range(data.T):
+                    agent.get_action(data.obs[t])
+                    agent.update(data.rewards[t], data.dones[t])
+                agent.flush_rewards()
+            th.cuda.synchronize()
+            snap = {k: v.copy() for k, v in model.rollout_buffer.host().items() if k not in ("advantages", "returns")}
+            snap.update(act=agent.actions.cpu().numpy(), val=agent.values.cpu().numpy(), lp=agent.log_probs.cpu().numpy(),
+                        es=agent._last_episode_starts.cpu().numpy(), counter=model.policy._counter)
+            agent.learn_from_buffer()
+            th.cuda.synchronize()
+            snap.update(adv=model.rollout_buffer.advantages.cpu().numpy(), params=model.policy.get_flat_params())
+            snaps.append(snap)
+        runs.append(snaps)
+    for a, b in zip(*runs):
+        for key in a:
+            assert np.array_equal(a[key], b[key]), key
+    assert not np.array_equal(runs[0][0]["params"], runs[0][1]["params"])
+
+
+def test_scripted_rollout_refuses_other_shapes_and_a_used_buffer():
+    from pantheonrl_amd import _native as nat
+    _, model, agent, data = _vec_setup(T=8, E=32, seed=1)
+    agent.bind_stream()
+    agent.get_action(data.obs[0])
+    with pytest.raises(nat.NativeError):
+        agent.rollout_scripted(data)                        # buffer not empty
+    from pantheonrl_amd import PPO
+    from pantheonrl_amd.vec import SyntheticRollouts, VecOnPolicyAgent
+    obs_s, act_s = H.CONFIGS["liar"]
+    env = type("E", (), dict(observation_space=H.to_space(obs_s), action_space=H.to_space(act_s), _is_dummy_space_env=True))()
+    liar = PPO("MlpPolicy", env, n_steps=8, n_envs=32, batch_size=64, n_epochs=1, seed=0)
+    ag = VecOnPolicyAgent(liar)
+    d = SyntheticRollouts(env.observation_space, 32, 8, 6, 0, liar.device)
+    ag.bind_stream()
+    with pytest.raises(nat.NativeError, match="16-row forward"):
+        ag.rollout_scripted(d)                              # one-hot observations / two action components: no silent slow path
