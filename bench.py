@@ -5,7 +5,10 @@ A "step" (--steps K) is ONE whole PPO iteration of every learning agent on this 
 environment steps over n_envs=1024 synthetic Overcooked-shaped environments (policy forward + rollout-buffer row write
 + late reward `+=` per step), the GAE pass, and PPO.train() with n_epochs=10 over minibatches of n_envs*n_steps/4
 rows (SURVEY.md 8d "throughput mode").  Inputs are synthetic, seeded, and already resident in HBM when the timed
-region starts.  value = agent-steps/s summed over all agents on all GPUs.
+region starts.  value = agent-steps/s summed over all agents on all GPUs.  At N=1 the 128 steps of a learner's rollout run
+as ONE launch by default (--rollout scripted: the synthetic transitions are a script in HBM; bitwise the per-step walk) and
+the line also carries the figure with one launch per environment step (`stepwise_rollout`, --rollout stepwise), which is
+how the N>1 layouts -- they exchange actions every step -- run.
 
 Launch: `python bench.py` (N=1), `python bench.py --gpus N` (spawns its own N ranks through torch.distributed.run), or
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -371,6 +374,12 @@ def main():
         exchange.requested_route = os.environ.get("PANTHEON_EXCHANGE", "auto")
 
     if mode == "graph":
+        if args.rollout == "scripted":
+            lay = agents[0].model.policy.layout
+            if not (lay.F <= 64 and lay.A == 1 and lay.L <= 8 and args.n_envs < 16384):
+                # the one-launch rollout exists for the 16-row forward's shape class only (ph_scripted_rollout refuses others)
+                log(f"workload {args.workload}: shapes outside the one-launch rollout's class -> --rollout stepwise")
+                args.rollout = "stepwise"
         graphs = [IterationGraph(a, d, s, scripted=args.rollout == "scripted") for a, d, s in zip(agents, datas, streams)]
 
         def iteration():

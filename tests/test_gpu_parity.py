@@ -450,10 +450,9 @@ def test_rps_ppo_vs_ppo_plumbing():
 # ----------------------------------------------------------------------------------------------------------------
 # vectorised agent (n_envs = E) and the captured iteration graph
 # ----------------------------------------------------------------------------------------------------------------
-def _vec_setup(T=12, E=96, seed=0, n_epochs=2):
+def _vec_setup(T=12, E=96, seed=0, n_epochs=2, name="overcooked"):
     from pantheonrl_amd import PPO
     from pantheonrl_amd.vec import SyntheticRollouts, VecOnPolicyAgent
-    name = "overcooked"
     orac = H.oracle_policy(name, seed=seed)
     obs_s, act_s = H.CONFIGS[name]
     env = type("E", (), dict(observation_space=H.to_space(obs_s), action_space=H.to_space(act_s),
@@ -1516,17 +1515,17 @@ def test_liar_persistent_rollout_is_bitwise_the_step_by_step_walk():
         assert np.array_equal(x, y), key
 
 
-@pytest.mark.parametrize("E,T", [(96, 12), (40, 7), (1024, 128)])
-def test_scripted_rollout_is_bitwise_the_per_step_walk(E, T):
+@pytest.mark.parametrize("E,T,name", [(96, 12, "overcooked"), (40, 7, "overcooked"), (1024, 128, "overcooked"),
+                                      (64, 9, "rps"), (48, 10, "mpe8")])
+def test_scripted_rollout_is_bitwise_the_per_step_walk(E, T, name):
     """ph_scripted_rollout (ONE launch: a workgroup stages the network once and walks the T steps of its 16 environments)
     against T x (get_action, update): identical rollout-buffer rows (observations, actions, values, log-probs, episode starts,
     rewards incl. the last step's), identical cached outputs of the last step, and -- after GAE and the update -- identical
     advantages and parameters, over two iterations (the second starts from the first's last dones).  E = 40 leaves the last
-    workgroup with 8 live rows; (1024, 128) is the bench size."""
-    from pantheonrl_amd.vec import run_iteration_eager
+    workgroup with 8 live rows; (1024, 128) is the bench size; "rps" has one-hot observations."""
     runs = []
     for scripted in (False, True):
-        _, model, agent, data = _vec_setup(T=T, E=E, seed=5, n_epochs=1)
+        _, model, agent, data = _vec_setup(T=T, E=E, seed=5, n_epochs=1, name=name)
         model.device_permutations = True
         snaps = []
         for it in range(2):
