@@ -122,7 +122,7 @@ def build_agents(args, device):
 
 def cpu_baseline(args):
     """the oracle executed SB3-style (per-step add with host copies, Python-loop GAE, eager autograd) on the host
-    cores of this box: ONE iteration of ONE agent at the same sizes (a bounded sample of the workload)."""
+    cores of this box: whole iterations of ONE agent at the same sizes for ~10 s (a bounded sample of the workload)."""
     from oracle.sb3_oracle import (MlpPolicyOracle, PPOHyper, RolloutBufferOracle, SpaceSpec, synthetic_iteration)
     cores = usable_cores()
     th.set_num_threads(cores)
@@ -143,13 +143,17 @@ def cpu_baseline(args):
     rew = rng.standard_normal((T, E), dtype=np.float32)
     done = rng.random((T, E)) < 1.0 / wl["horizon"]
     hp = PPOHyper(batch_size=args.batch_size, n_epochs=args.n_epochs)
+    # a bounded sample of the same workload: whole iterations of one agent until ~10 s of CPU work (at most 16 iterations)
     t0 = time.perf_counter()
-    synthetic_iteration(pol, buf, hp, obs, rew, done)
+    n_it = 0
+    while n_it < 16 and (n_it == 0 or time.perf_counter() - t0 < 10.0):
+        synthetic_iteration(pol, buf, hp, obs, rew, done)
+        n_it += 1
     dt = time.perf_counter() - t0
-    out = {"value": T * E / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+    out = {"value": n_it * T * E / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
            "os_cpu_count": os.cpu_count(),
-           "sample": f"1 PPO iteration of 1 agent (n_envs={E}, n_steps={T}, batch={args.batch_size}, "
-                     f"n_epochs={args.n_epochs}) = {T * E} agent-steps in {dt:.2f}s, torch threads={cores}"}
+           "sample": f"{n_it} PPO iteration(s) of 1 agent (n_envs={E}, n_steps={T}, batch={args.batch_size}, "
+                     f"n_epochs={args.n_epochs}) = {n_it * T * E} agent-steps in {dt:.2f}s, torch threads={cores}"}
     # SURVEY.md 8d also asks for (i) the reference's own semantics -- E = 1, n_steps = 2048, batch 64, 10 epochs: batch-1
     # forwards and 320 Adam steps per 2048 transitions (agents.py:111-203 on SB3 defaults) -- and for one host thread.
     # Bounded samples: a quarter rollout of (i) on all threads and on one thread (the update dominates and scales with it).
