@@ -1516,7 +1516,7 @@ def test_liar_persistent_rollout_is_bitwise_the_step_by_step_walk():
 
 
 @pytest.mark.parametrize("E,T,name", [(96, 12, "overcooked"), (40, 7, "overcooked"), (1024, 128, "overcooked"),
-                                      (64, 9, "rps"), (48, 10, "mpe8")])
+                                      (64, 9, "rps"), (48, 10, "mpe8"), (32, 1, "overcooked"), (17, 2, "overcooked")])
 def test_scripted_rollout_is_bitwise_the_per_step_walk(E, T, name):
     """ph_scripted_rollout (ONE launch: a workgroup stages the network once and walks the T steps of its 16 environments)
     against T x (get_action, update): identical rollout-buffer rows (observations, actions, values, log-probs, episode starts,
