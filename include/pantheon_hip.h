@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define PH_ABI_VERSION 1
+#define PH_ABI_VERSION 2   /* 2: + ph_agent_*, ph_bc_*, ph_adap_*, ph_scripted_rollout, ph_liar_selfplay_rollout, ph_roundrobin_env_step,
+                                  ph_buffer_compact_columns (additions only: every v1 signature is unchanged) */
 #define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
 #define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
 #define PH_MAX_LOGITS 64 /* max total policy logits L */
