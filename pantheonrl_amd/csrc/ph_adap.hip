@@ -9,10 +9,12 @@
 //
 // Here that term is ONE small launch per minibatch next to the PPO gradient launch: workgroup w takes ADAP_ROWS / C of the
 // sampled states, stages the policy network's weights in LDS in one batch of loads (they are L2-resident: the gradient launch
-// reads them too), runs the states' C context rows through the network, forms the pairwise terms and back-propagates them; every parameter's partial derivative is computed by one
-// thread from LDS operands and written, already scaled by coeff / (pairs * states), to the workgroup's own slab in the
-// canonical parameter order.  ppo_reduce_kernel adds the slabs to the PPO gradient in a fixed order before the norm, so the
-// clip and the Adam step see the gradient of the whole loss exactly as the reference's single backward() does.
+// reads them too) while one wave walks sample -> minibatch order -> buffer row, and treats the states' C context rows as ONE
+// 16-row M tile of v_mfma_f32_16x16x4_f32 for the forward products, the two backward products and the weight gradients
+// (K = the 16 rows).  Between them thread (row, logit) forms the pairwise KL terms of its state on 16-lane DPP rows.  The
+// gradients are written, already scaled by coeff / (pairs * states), to the workgroup's own slab of the policy-side
+// parameters; ppo_reduce_kernel adds the slabs to the PPO gradient in a fixed order before the norm, so the clip and the Adam
+// step see the gradient of the whole loss exactly as the reference's single backward() does.
 #include "ph_launch.h"
 
 namespace ph {
