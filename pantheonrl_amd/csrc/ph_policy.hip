@@ -699,7 +699,7 @@ __device__ __forceinline__ void head_tail32(const FwdArgs& a, const NetDims& nd,
 // barrier the policy half has around its logits so that both halves reach every workgroup barrier.
 template <bool VALU, bool FUSED = false>
 __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in = 0, int net_in = 0, int tid_in = 0,
-                                                   float* smem_in = nullptr) {
+                                                   float* smem_in = nullptr, int row_end_in = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
   float* smem = FUSED ? smem_in : smem_dyn;
   constexpr int R = 16, NT = 256, LDO = 33, FS = 64;
@@ -720,6 +720,9 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int net = FUSED ? net_in : (int)blockIdx.y;
   const int row0 = FUSED ? row0_in : (int)blockIdx.x * R;
+  // rows [row0, n_end) are this workgroup's; the persistent rollout may own fewer than 16 tables per workgroup (a.n stays the
+  // row stride of the ragged rollout-buffer addressing)
+  const int n_end = FUSED ? row_end_in : a.n;
   const ph_layout& lay = nd.lay;
   const float* W1 = a.params + (net == 0 ? lay.pi_W1 : lay.vf_W1);
   const float* B1 = a.params + (net == 0 ? lay.pi_b1 : lay.vf_b1);
@@ -727,7 +730,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   const float* B2 = a.params + (net == 0 ? lay.pi_b2 : lay.vf_b2);
   const int D = nd.D;
 
-  if constexpr (!FUSED) PH_STAMP(a.prof, 0);
+  PH_STAMP(a.prof, 0);
   // Every global load that does not depend on the observations is issued here, back to back (a kernel starts with cold
   // caches: each dependent round trip costs ~1 us at this occupancy).  The observation -> feature-row loads go first.
   // (Staging the whole of W1 -- 69 KB per net for Liar's Dice -- into LDS so that the gather stays on the CU measured
@@ -737,7 +740,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   for (int i = 0; i < R * FS / NT; ++i) {
     const int e = tid + NT * i, r = e >> 6, comp = e & 63, row = row0 + r;
     int f = -1;
-    if (comp < D && row < a.n) {
+    if (comp < D && row < n_end) {
       const int lo = nd.obs_off[comp], nn = nd.obs_off[comp + 1] - lo;
       int x = (int)a.obs[(size_t)row * D + comp];
       x = x < 0 ? 0 : (x >= nn ? nn - 1 : x);
@@ -746,7 +749,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
     fv[i] = f;
   }
   long long ridxv = -1;
-  if (net == 0 && tid < R && row0 + tid < a.n && (a.rb_act || a.rb_logp)) ridxv = rb_row(a, row0 + tid);
+  if (net == 0 && tid < R && row0 + tid < n_end && (a.rb_act || a.rb_logp)) ridxv = rb_row(a, row0 + tid);
   WStage<NT> w2r;
   w2r.issue(W2, 0, HID, tid);
   const int gr = tid >> 4, gl = tid & 15;   // gather: row gr, hidden units 4*gl .. 4*gl+3
@@ -773,7 +776,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   for (int i = 0; i < R * FS / NT; ++i) feat[tid + NT * i] = fv[i];
   if (net == 0 && tid < R) ridxs[tid] = ridxv;
   lds_only_barrier();  // feat visible
-  if constexpr (!FUSED) PH_STAMP(a.prof, 1);
+  PH_STAMP(a.prof, 1);
 
   // ---- layer 1: gather-sum of W1 rows in component order; everything staged for the later layers is committed while the
   // gather loads are in flight ----
@@ -830,7 +833,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
     h[3] = fast_tanh(acc.w + b1v[3]);
   }
   lds_only_barrier();
-  if constexpr (!FUSED) PH_STAMP(a.prof, 3);
+  PH_STAMP(a.prof, 3);
   if (net == 0 && tid < 32) {   // component of logit `tid` (read by the head after two more barriers)
     int lo = tid, last = tid, comp = -1;
     for (int cc = 0; cc < nd.A; ++cc) {
@@ -874,7 +877,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
     for (int r = 0; r < 4; ++r) xs[(4 * g + r) * LDH + 16 * wave + c] = fast_tanh(z2[r] + b);
   }
   lds_only_barrier();
-  if constexpr (!FUSED) PH_STAMP(a.prof, 5);
+  PH_STAMP(a.prof, 5);
 
   if (net == 0) {
     // ---- policy head: logits [16][32] as two 16x16 tiles (waves 0, 1), then one lane per row ----
@@ -885,13 +888,14 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
       for (int r = 0; r < 4; ++r) outs[(4 * g + r) * LDO + 16 * wave + c] = z3[r] + b;
     }
     lds_only_barrier();
-    if constexpr (!FUSED) PH_STAMP(a.prof, 6);
+    PH_STAMP(a.prof, 6);
     {
       const int k = tid & 31, lo = seg[k], last = seg[32 + k], comp = seg[64 + k];
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {   // 32 lanes per row, 8 rows per pass
+        if (pass == 1 && row0 + 8 >= n_end) break;   // no live row in the second pass (workgroup-uniform)
         const int r = pass * 8 + (tid >> 5);
-        head_tail32(a, nd, row0 + r, row0 + r < a.n, ridxs[r], outs[r * LDO + k], k, lo, last, comp, fwd_counter(a));
+        head_tail32(a, nd, row0 + r, row0 + r < n_end, ridxs[r], outs[r * LDO + k], k, lo, last, comp, fwd_counter(a));
       }
     }
   } else {
@@ -910,11 +914,11 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
 #pragma unroll
       for (int m = 0; m < 16; ++m) v = __builtin_fmaf(hx[m], hw[m], v);
       v = quad_sum_f(v) + hbs[0];
-      if (q == 0 && row0 + r < a.n) value_row_tail(a, row0 + r, v);
+      if (q == 0 && row0 + r < n_end) value_row_tail(a, row0 + r, v);
     }
-    copy_obs_rows(a, row0, (a.n - row0 < R) ? a.n - row0 : R, nd.D, tid, NT);
+    copy_obs_rows(a, row0, (n_end - row0 < R) ? n_end - row0 : R, nd.D, tid, NT);
   }
-  if constexpr (!FUSED) PH_STAMP(a.prof, 7);
+  PH_STAMP(a.prof, 7);
 }
 
 template <bool VALU>
@@ -928,7 +932,7 @@ static size_t fwd16h_lds_bytes() {
 
 // ---- persistent Liar's Dice self-play rollout ------------------------------------------------------------------------------------
 // n_steps vectorised MultiAgentEnv.step calls of ph_liar_selfplay_step in ONE launch: tables are independent, so one 512-thread
-// workgroup owns 16 tables for the whole rollout -- ego forward -> move -> partner reply -> move / credit / re-deal -> partner
+// workgroup owns up to 16 tables (launch_liar_rollout: as few as spreads them over every CU) for the whole rollout -- ego forward -> move -> partner reply -> move / credit / re-deal -> partner
 // opening -> move -- with workgroup barriers where the launch-by-launch walk has kernel boundaries.  The lower half of the
 // workgroup runs the policy net of the acting agent, the upper half its value net (policy_fwd16h_body<.., FUSED>), sixteen lanes
 // run the per-table book-keeping (ph_liar.h: the very functions of the per-step kernels), so every number is bitwise what
@@ -946,7 +950,7 @@ struct LiarRolloutArgs {
 
 static size_t fwd16h_lds_bytes();
 
-// The 16 tables a workgroup owns keep their whole state in LDS for the rollout: game state, the three observation arrays, the
+// The (at most 16) tables a workgroup owns keep their whole state in LDS for the rollout: game state, the three observation arrays, the
 // action / reward / flag scratch of the step and the partner's per-table book-keeping are mirrored in at the start, the
 // argument records get pointers REBASED into the mirror (mirror - row0 * stride, so that the unchanged code indexes them with the
 // global table number through generic addressing), and everything is written back at the end.  What still goes to HBM per step
@@ -975,13 +979,13 @@ constexpr int LIAR_MIRROR_BYTES = 16 * (12 + 24 + 1 + 1 + 2 + 2) * 4 + 16 * (3 *
 template <typename T>
 __device__ __forceinline__ T* rebase(T* mirror, int row0, int per) { return mirror - (size_t)row0 * per; }
 
-__global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, int half_floats) {
+__global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, int half_floats, int rpw) {
   extern __shared__ __attribute__((aligned(16))) float smem_roll[];
   const int tid512 = threadIdx.x, half = tid512 >> 8, tid = tid512 & 255;
   float* sm = smem_roll + (size_t)half * half_floats;
-  const int row0 = blockIdx.x * 16;
+  const int row0 = blockIdx.x * rpw;            // rpw <= 16 tables per workgroup (the forward's tile is 16 rows, the rest padding)
   const ph_liar_selfplay& g = r.s;              // the global arrays
-  const int nrow = (g.n - row0 < 16) ? g.n - row0 : 16;
+  const int nrow = (g.n - row0 < rpw) ? g.n - row0 : rpw;
 
   // ---- mirror in ----
   LiarMirror m;
@@ -1055,7 +1059,7 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
   __syncthreads();
 
   const int e = row0 + tid512;                  // the table lane tid512 < 16 keeps the books of
-  const bool keeper = tid512 < 16 && e < g.n;
+  const bool keeper = tid512 < nrow;
   // one inlined copy of the forward body: the three forwards of a step are a loop whose argument record is selected with
   // scalar selects (three inlined copies cost 1.4 KB of scratch per lane and 649 spilled SGPRs)
   // the RNG epoch is constant for the launch: read once here instead of by every forward's sampling tail and every re-deal
@@ -1086,7 +1090,7 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
     }
     long long* prof = (t == 2) ? r.ego.prof : nullptr;   // debug stamps of the third step (scripts/liar_rollout_profile.py)
     if (f == 0) PH_STAMP(prof, 8);
-    policy_fwd16h_body<false, true>(a, row0, half, tid, sm);
+    policy_fwd16h_body<false, true>(a, row0, half, tid, sm, row0 + nrow);
     __syncthreads();
     PH_STAMP(prof, 9 + 2 * f);
     if (keeper) {
@@ -1147,7 +1151,24 @@ hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, co
     if (e != hipSuccess) return e;
     allowed[dev] = true;
   }
-  hipLaunchKernelGGL(liar_rollout_kernel, dim3((s.n + 15) / 16), dim3(512), lds, st, r, (int)(half / sizeof(float)));
+  // Tables per workgroup.  The forward's tile is 16 rows, but its one-hot first layer gathers D rows of W1 (256 B each) per
+  // table, forward and net through ONE CU's L2 port, and a 256-table game on a 256-CU part leaves 240 CUs idle at 16 tables
+  // per workgroup: spread the tables over as many CUs as there are (3.58 -> 2.99 ms per 128-step rollout of 256 tables;
+  // 8 / 4 / 2 tables per workgroup: 3.32 / 3.12 / 3.04 ms).  Rows are independent in every phase, so the numbers do not change.
+  static int forced = -1, cus[64] = {0};
+  if (forced < 0) {
+    const char* e = getenv("PH_LIAR_RPW");
+    const int v = e ? atoi(e) : 0;
+    forced = (v >= 1 && v <= 16) ? v : 0;
+  }
+  if (cus[dev] == 0) {
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    cus[dev] = n_cu;
+  }
+  int rpw = forced ? forced : (s.n + cus[dev] - 1) / cus[dev];
+  rpw = rpw < 1 ? 1 : (rpw > 16 ? 16 : rpw);
+  hipLaunchKernelGGL(liar_rollout_kernel, dim3((s.n + rpw - 1) / rpw), dim3(512), lds, st, r, (int)(half / sizeof(float)), rpw);
   return hipGetLastError();
 }
 

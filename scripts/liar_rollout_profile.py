@@ -27,9 +27,10 @@ models[0].rollout_buffer.pos = 0
 ego.n_steps = 0
 sp.rollout_persistent(T, 1, 0)
 th.cuda.synchronize()
-st = stamps.cpu().numpy().reshape(-1, 16)[:E // 16].astype(np.float64)
+st = stamps.cpu().numpy().reshape(-1, 16).astype(np.float64)
+st = st[st[:, 8] > 0]                    # the workgroups of the launch (tables per workgroup: launch_liar_rollout)
 med = lambda a, b: np.median(st[:, b] - st[:, a])   # noqa: E731
-print(f"step 2 of the rollout, {E // 16} workgroups (cycles, median)")
+print(f"step 2 of the rollout, {len(st)} workgroups (cycles, median)")
 print(f"  ego forward                {med(8, 9):8.0f}")
 print(f"  book-keeping after ego     {med(9, 10):8.0f}")
 print(f"  reply forward              {med(10, 11):8.0f}")
@@ -37,3 +38,9 @@ print(f"  book-keeping after reply   {med(11, 12):8.0f}")
 print(f"  opening forward            {med(12, 13):8.0f}")
 print(f"  book-keeping after opening {med(13, 14):8.0f}")
 print(f"  whole step                 {med(8, 14):8.0f}")
+print("ego forward of the last step, by phase (policy half):")
+print(f"  loads issued, hot positions -> LDS + barrier   {med(0, 1):8.0f}")
+print(f"  W1 row gather + staging commits + tanh + barrier {med(1, 3):6.0f}")
+print(f"  layer 2 + barrier                              {med(3, 5):8.0f}")
+print(f"  head products + barrier                        {med(5, 6):8.0f}")
+print(f"  row tails (softmax, sample, buffer rows)       {med(6, 7):8.0f}")
