@@ -946,6 +946,7 @@ struct LiarRolloutArgs {
   float* alt_rewards;
   int alt_T;
   float* ego_rew_row0;                // ego rewards row of step 0
+  int no_skip;                        // PH_LIAR_SKIP=0: run every partner forward, needed or not (A/B switch)
 };
 
 static size_t fwd16h_lds_bytes();
@@ -1068,30 +1069,53 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
     const int t = ph / 3, f = ph - 3 * t;
     const unsigned long long counter = r.counter0 + (unsigned long long)t;
     const size_t row = (size_t)t * g.n;
-    FwdArgs a = (f == 0) ? r.ego : ((f == 1) ? r.reply : r.opening);
-    a.counter = ((f == 0) ? counter : 2ull * counter + (unsigned long long)(f - 1)) + epoch_hi;
-    a.epoch = nullptr;
-    if (f == 0) {
-      a.rb_obs += row * a.nd.D;
-      a.rb_act += row * a.nd.A;
-      a.rb_rew += row;
-      a.rb_es += row;
-      a.rb_val += row;
-      a.rb_logp += row;
-      a.obs = s.obs_ego;
-      a.es_in = s.ego_episode_start;
-      a.act_i32 = s.ego_actions;
-    } else {
-      a.obs = (f == 1) ? s.obs_next : s.obs_alt;
-      a.es_in = s.es_alt;
-      a.act_i32 = s.alt_actions;
-      a.pos_env = s.alt_pos;
-      a.rec_mask = s.can;
-    }
     long long* prof = (t == 2) ? r.ego.prof : nullptr;   // debug stamps of the third step (scripts/liar_rollout_profile.py)
     if (f == 0) PH_STAMP(prof, 8);
-    policy_fwd16h_body<false, true>(a, row0, half, tid, sm, row0 + nrow);
-    __syncthreads();
+    // A partner forward none of this workgroup's tables asks for is skipped: the reply where every game ended with the ego's
+    // move (running = 0), the opening where no fresh game starts with the partner (alt_opens = 0).  For such tables the
+    // launch-by-launch walk computes a forward whose only outputs are scratch (alt_actions / the log-prob cache of a table
+    // that does not move; nothing is recorded, no random stream advances -- Philox is keyed by (counter, table)), so every
+    // defined number stays what it was.  With one table per workgroup ~9 of 10 opening forwards go away, and with them the
+    // opening's book-keeping pass wherever no table starts a fresh game at all.
+    bool need = true;
+    if (f != 0 && !r.no_skip) {
+      const unsigned char* fl = m.u8 + (f == 1 ? 7 : 9) * 16;   // running | alt_opens, written before the last barrier
+      int any = 0, fresh = 0;
+      for (int i = 0; i < nrow; ++i) {
+        any |= fl[i];
+        fresh |= m.u8[10 * 16 + i];                             // ego_opens
+      }
+      need = __builtin_amdgcn_readfirstlane(any) != 0;
+      if (f == 2 && !need && __builtin_amdgcn_readfirstlane(fresh) == 0) {   // liar_sp_after_opening_lane would return at once
+        PH_STAMP(prof, 13);
+        PH_STAMP(prof, 14);
+        continue;
+      }
+    }
+    if (need) {
+      FwdArgs a = (f == 0) ? r.ego : ((f == 1) ? r.reply : r.opening);
+      a.counter = ((f == 0) ? counter : 2ull * counter + (unsigned long long)(f - 1)) + epoch_hi;
+      a.epoch = nullptr;
+      if (f == 0) {
+        a.rb_obs += row * a.nd.D;
+        a.rb_act += row * a.nd.A;
+        a.rb_rew += row;
+        a.rb_es += row;
+        a.rb_val += row;
+        a.rb_logp += row;
+        a.obs = s.obs_ego;
+        a.es_in = s.ego_episode_start;
+        a.act_i32 = s.ego_actions;
+      } else {
+        a.obs = (f == 1) ? s.obs_next : s.obs_alt;
+        a.es_in = s.es_alt;
+        a.act_i32 = s.alt_actions;
+        a.pos_env = s.alt_pos;
+        a.rec_mask = s.can;
+      }
+      policy_fwd16h_body<false, true>(a, row0, half, tid, sm, row0 + nrow);
+      __syncthreads();
+    }
     PH_STAMP(prof, 9 + 2 * f);
     if (keeper) {
       if (f == 0) liar_sp_after_ego_lane(s, e, r.alt_rewards, r.alt_T);
@@ -1155,12 +1179,15 @@ hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, co
   // table, forward and net through ONE CU's L2 port, and a 256-table game on a 256-CU part leaves 240 CUs idle at 16 tables
   // per workgroup: spread the tables over as many CUs as there are (3.58 -> 2.99 ms per 128-step rollout of 256 tables;
   // 8 / 4 / 2 tables per workgroup: 3.32 / 3.12 / 3.04 ms).  Rows are independent in every phase, so the numbers do not change.
-  static int forced = -1, cus[64] = {0};
+  static int forced = -1, cus[64] = {0}, no_skip = 0;
   if (forced < 0) {
     const char* e = getenv("PH_LIAR_RPW");
     const int v = e ? atoi(e) : 0;
     forced = (v >= 1 && v <= 16) ? v : 0;
+    const char* k = getenv("PH_LIAR_SKIP");
+    no_skip = (k && k[0] == '0') ? 1 : 0;
   }
+  r.no_skip = no_skip;
   if (cus[dev] == 0) {
     int n_cu = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
