@@ -1179,15 +1179,13 @@ hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, co
   // table, forward and net through ONE CU's L2 port, and a 256-table game on a 256-CU part leaves 240 CUs idle at 16 tables
   // per workgroup: spread the tables over as many CUs as there are (3.58 -> 2.99 ms per 128-step rollout of 256 tables;
   // 8 / 4 / 2 tables per workgroup: 3.32 / 3.12 / 3.04 ms).  Rows are independent in every phase, so the numbers do not change.
-  static int forced = -1, cus[64] = {0}, no_skip = 0;
-  if (forced < 0) {
-    const char* e = getenv("PH_LIAR_RPW");
-    const int v = e ? atoi(e) : 0;
-    forced = (v >= 1 && v <= 16) ? v : 0;
-    const char* k = getenv("PH_LIAR_SKIP");
-    no_skip = (k && k[0] == '0') ? 1 : 0;
-  }
-  r.no_skip = no_skip;
+  static int cus[64] = {0};
+  // read per launch (two getenv calls against a 2 ms kernel) so that one test process can walk the settings
+  const char* e_rpw = getenv("PH_LIAR_RPW");
+  const int v_rpw = e_rpw ? atoi(e_rpw) : 0;
+  const int forced = (v_rpw >= 1 && v_rpw <= 16) ? v_rpw : 0;
+  const char* e_skip = getenv("PH_LIAR_SKIP");
+  r.no_skip = (e_skip && e_skip[0] == '0') ? 1 : 0;
   if (cus[dev] == 0) {
     int n_cu = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;

@@ -1481,11 +1481,17 @@ def test_ragged_partner_trains_on_its_full_columns_only():
     assert not agent.full()
 
 
-def test_liar_persistent_rollout_is_bitwise_the_step_by_step_walk():
-    """ph_liar_selfplay_rollout (ONE launch: a workgroup owns 16 tables for all n_steps) against n_steps calls of
+@pytest.mark.parametrize("rpw,skip", [(None, None), (16, None), (3, None), (1, "0"), (16, "0")])
+def test_liar_persistent_rollout_is_bitwise_the_step_by_step_walk(monkeypatch, rpw, skip):
+    """ph_liar_selfplay_rollout (ONE launch: a workgroup owns up to 16 tables for all n_steps) against n_steps calls of
     ph_liar_selfplay_step with the same counters: identical game state, observations, both rollout buffers, the partner's
-    book-keeping and -- after both learners trained on them -- identical parameters.  E = 40 leaves the last workgroup with
-    8 live tables."""
+    book-keeping and -- after both learners trained on them -- identical parameters.  Default: one table per workgroup
+    (40 tables on 256 CUs) and partner forwards no table of the workgroup asks for skipped; PH_LIAR_RPW = 16 leaves the last
+    workgroup with 8 live tables, 3 with one; PH_LIAR_SKIP = 0 runs every forward."""
+    if rpw is not None:
+        monkeypatch.setenv("PH_LIAR_RPW", str(rpw))
+    if skip is not None:
+        monkeypatch.setenv("PH_LIAR_SKIP", skip)
     E, T_ego, T_alt = 40, 8, 6
     runs = []
     for persistent in (True, False):
