@@ -9,7 +9,8 @@ A from-scratch CPU restatement (numpy + torch-CPU, float32) of the arithmetic
 that PantheonRL's ``OnPolicyAgent`` delegates to ``stable-baselines3==1.7.0``
 (reference ``setup.py:17``): the rollout buffer, the GAE pass, the MlpPolicy
 forward / evaluate_actions and ``PPO.train()``, plus PantheonRL's own ADAP context
-term (``pantheonrl/algos/adap/util.py:97-131``, whose module imports gym / SB3).
+term (``pantheonrl/algos/adap/util.py:97-131``, whose module imports gym / SB3) and -- ahead of any device path --
+``ModularPolicy`` / ``ModularAlgorithm.train`` (``pantheonrl/algos/modular``).
 
 PARITY UNPINNED.  stable-baselines3 is not vendored under /root/reference and
 is not installed in this image, and the reference has no tests or golden
@@ -517,6 +518,169 @@ def collect_rollouts(policy: MlpPolicyOracle, buf: RolloutBufferOracle, env, las
         values = policy.predict_values(th.as_tensor(np.asarray(new_obs, np.float32)))
     buf.compute_returns_and_advantage(values, np.asarray(dones, np.float32))
     return new_obs, dones
+
+
+# --------------------------------------------------------------------------------------
+# ModularAlgorithm / ModularPolicy (pantheonrl/algos/modular): restated ahead of a device path -- the engine does not
+# implement it yet; these functions pin what that path will have to reproduce.
+# --------------------------------------------------------------------------------------
+class ModularPolicyOracle(MlpPolicyOracle):
+    """``ModularPolicy`` (modular/policies.py:40-395) with the FlattenExtractor defaults: the main network is the ordinary
+    MlpPolicy; every partner owns a second MlpExtractor whose INPUT is the main policy latent (``:254``: input_dim =
+    latent_dim_pi; forward ``:281``), with pi / vf towers 64-64 (``:101-105``), an action head and a value head
+    (``:214-219``).  Logits and values are sums (``:325-328``: main_logits + partner_logits, or partner_logits alone with
+    ``nomain``; ``:286``: value_net(latent_vf) + partner_value_net(partner_latent_vf)).  Orthogonal gains as for the main
+    network (``:229-241``).  ``baseline`` shares one partner module between all partners (``:255-257``)."""
+
+    def __init__(self, obs_space: SpaceSpec, act_space: SpaceSpec, num_partners: int = 1, lr: float = 3e-4,
+                 ortho_init: bool = True, nomain: bool = False, baseline: bool = False):
+        super().__init__(obs_space, act_space, lr=lr, ortho_init=ortho_init)
+        self.num_partners, self.nomain = int(num_partners), bool(nomain)
+        L = act_space.flat_len
+
+        def module():
+            m = nn.ModuleDict(dict(
+                pi=nn.Sequential(nn.Linear(HIDDEN, HIDDEN), nn.Tanh(), nn.Linear(HIDDEN, HIDDEN), nn.Tanh()),
+                vf=nn.Sequential(nn.Linear(HIDDEN, HIDDEN), nn.Tanh(), nn.Linear(HIDDEN, HIDDEN), nn.Tanh()),
+                act=nn.Linear(HIDDEN, L), val=nn.Linear(HIDDEN, 1)))
+            if ortho_init:
+                for mod, gain in ((m["pi"], np.sqrt(2)), (m["vf"], np.sqrt(2)), (m["act"], 0.01), (m["val"], 1.0)):
+                    for lin in mod.modules():
+                        if isinstance(lin, nn.Linear):
+                            nn.init.orthogonal_(lin.weight, gain=gain)
+                            lin.bias.data.fill_(0.0)
+            return m
+        mods = [module() for _ in range(self.num_partners)]
+        if baseline:
+            mods = [mods[0]] * self.num_partners
+        self.partners = nn.ModuleList(mods)
+        self.optimizer = th.optim.Adam(self.parameters(), lr=lr, eps=1e-5)   # policies.py:263 over ALL parameters
+
+    def _towers(self, obs: th.Tensor, partner_idx: int):
+        latent_pi, latent_vf = self._latents(obs)
+        pm = self.partners[partner_idx]
+        return latent_pi, latent_vf, pm["pi"](latent_pi), pm["vf"](latent_pi), pm   # BOTH partner towers read latent_pi
+
+    def action_logits(self, obs: th.Tensor, partner_idx: int):
+        """``get_action_logits_from_obs`` (policies.py:385-395) without a mask -> (main_logits, partner_logits)."""
+        latent_pi, _, p_pi, _, pm = self._towers(obs, partner_idx)
+        return self.action_net(latent_pi), pm["act"](p_pi)
+
+    def _mean_actions(self, latent_pi, p_pi, pm, action_mask):
+        z = pm["act"](p_pi) if self.nomain else self.action_net(latent_pi) + pm["act"](p_pi)
+        if action_mask is not None:     # policies.py:330-333; the clamp at :334 discards its result
+            z = z - 30.0 * (1.0 - action_mask.float())
+        return z
+
+    def forward(self, obs: th.Tensor, partner_idx: int = 0, deterministic: bool = False,
+                uniforms: Optional[th.Tensor] = None, action_mask: Optional[th.Tensor] = None):
+        """policies.py:271-288 -> (actions (n, A), values (n, 1), log_prob (n,))"""
+        latent_pi, latent_vf, p_pi, p_vf, pm = self._towers(obs, partner_idx)
+        z = self._mean_actions(latent_pi, p_pi, pm, action_mask)
+        acts, logp = [], 0.0
+        for c, zc in enumerate(self._split(z)):
+            dist = th.distributions.Categorical(logits=zc)
+            if deterministic:
+                a = th.argmax(dist.probs, dim=1)
+            elif uniforms is not None:
+                a = inverse_cdf_sample(dist.probs, uniforms[:, c])
+            else:
+                a = dist.sample()
+            acts.append(a)
+            logp = logp + dist.log_prob(a)
+        return th.stack(acts, dim=1), self.value_net(latent_vf) + pm["val"](p_vf), logp
+
+    def evaluate_actions(self, obs: th.Tensor, actions: th.Tensor, partner_idx: int = 0,
+                         action_mask: Optional[th.Tensor] = None):
+        """policies.py:364-383 -> (values (n, 1), log_prob (n,), entropy (n,))"""
+        latent_pi, latent_vf, p_pi, p_vf, pm = self._towers(obs, partner_idx)
+        z = self._mean_actions(latent_pi, p_pi, pm, action_mask)
+        actions = actions.long().reshape(obs.shape[0], -1)
+        logp, ent = 0.0, 0.0
+        for c, zc in enumerate(self._split(z)):
+            dist = th.distributions.Categorical(logits=zc)
+            logp = logp + dist.log_prob(actions[:, c])
+            ent = ent + dist.entropy()
+        return self.value_net(latent_vf) + pm["val"](p_vf), logp, ent
+
+    def flat_params(self) -> np.ndarray:
+        """the main network in MlpPolicyOracle's layout, then per partner [pi_W1 pi_b1 pi_W2 pi_b2 vf_W1 vf_b1 vf_W2 vf_b2
+        act_W(H,L) act_b val_W(H) val_b], weights input-major"""
+        out = [th.as_tensor(super().flat_params())]
+        for pm in self.partners:
+            for seq in (pm["pi"], pm["vf"]):
+                for idx in (0, 2):
+                    out += [seq[idx].weight.detach().t().contiguous().reshape(-1), seq[idx].bias.detach()]
+            out += [pm["act"].weight.detach().t().contiguous().reshape(-1), pm["act"].bias.detach(),
+                    pm["val"].weight.detach().reshape(-1), pm["val"].bias.detach()]
+        return th.cat(out).numpy().astype(np.float32).copy()
+
+
+def modular_marginal_regularization(policy: ModularPolicyOracle, observations: th.Tensor) -> th.Tensor:
+    """modular/learn.py:298-318 for a single Categorical head: every partner's (main_logits, partner_logits) on the minibatch;
+    main_probs = mean over partners of softmax(main_logits) (the same tensor num_partners times), composed_probs = mean over
+    partners of softmax(main_logits + partner_logits); loss = mean over rows of sum_a |main_probs - composed_probs|."""
+    pairs = [policy.action_logits(observations, k) for k in range(policy.num_partners)]
+    main = th.stack([m for m, _ in pairs])
+    composed = main + th.stack([p for _, p in pairs])
+    main_probs = th.mean(th.exp(main - main.logsumexp(dim=-1, keepdim=True)), dim=0)
+    composed_probs = th.mean(th.exp(composed - composed.logsumexp(dim=-1, keepdim=True)), dim=0)
+    return th.mean(th.sum(th.abs(main_probs - composed_probs), dim=1))
+
+
+def modular_minibatch_loss(policy: ModularPolicyOracle, mb: dict, hp: PPOHyper, partner_idx: int, marginal_reg_coef: float):
+    """One minibatch of ModularAlgorithm.train (modular/learn.py:244-318): the PPO terms with the partner's module in the
+    network (advantages are ALWAYS normalised: no normalize_advantage switch, no len > 1 guard, ``:260-261``), plus
+    ``marginal_reg_coef * marginal_regularization_loss`` (``:318``).  approx_kl is the plain mean(old_log_prob - log_prob)
+    of ``:327``, not SB3 1.7's estimator."""
+    actions = mb["actions"]
+    if policy.act_space.kind == "discrete":
+        actions = actions.long().flatten()
+    values, log_prob, entropy = policy.evaluate_actions(mb["observations"], actions, partner_idx=partner_idx)
+    values = values.flatten()
+    advantages = mb["advantages"]
+    advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+    ratio = th.exp(log_prob - mb["old_log_prob"])
+    policy_loss = -th.min(advantages * ratio, advantages * th.clamp(ratio, 1 - hp.clip_range, 1 + hp.clip_range)).mean()
+    if hp.clip_range_vf is None:
+        values_pred = values
+    else:
+        values_pred = mb["old_values"] + th.clamp(values - mb["old_values"], -hp.clip_range_vf, hp.clip_range_vf)
+    value_loss = F.mse_loss(mb["returns"], values_pred)
+    entropy_loss = -th.mean(entropy)
+    reg = modular_marginal_regularization(policy, mb["observations"])
+    loss = policy_loss + hp.ent_coef * entropy_loss + hp.vf_coef * value_loss + marginal_reg_coef * reg
+    stats = dict(policy_loss=policy_loss.item(), value_loss=value_loss.item(), entropy_loss=entropy_loss.item(),
+                 marginal_reg=reg.item(), loss=loss.item(),
+                 approx_kl=th.mean(mb["old_log_prob"] - log_prob).item())
+    return loss, stats
+
+
+def modular_train(policy: ModularPolicyOracle, bufs: Sequence[RolloutBufferOracle], hp: PPOHyper, marginal_reg_coef: float = 0.0,
+                  perms: Optional[Sequence[Sequence[np.ndarray]]] = None) -> List[dict]:
+    """``ModularAlgorithm.train`` (modular/learn.py:221-351): partner by partner (one rollout buffer each, ``:134-144``),
+    ``n_epochs`` passes over that partner's buffer; the optimiser step comes BEFORE the KL bookkeeping and the target-KL test
+    ends the partner's epoch loop only after a whole epoch (``:320-334``: mean of the epoch's KLs).  ``perms[partner][epoch]``
+    teacher-forces the buffer's permutation."""
+    for g in policy.optimizer.param_groups:
+        g["lr"] = hp.learning_rate
+    all_stats: List[dict] = []
+    for k, buf in enumerate(bufs):
+        for epoch in range(hp.n_epochs):
+            kls = []
+            idx = None if perms is None else np.asarray(perms[k][epoch])
+            for mb in buf.get(hp.batch_size, idx):
+                loss, stats = modular_minibatch_loss(policy, mb, hp, k, marginal_reg_coef)
+                policy.optimizer.zero_grad()
+                loss.backward()
+                stats["grad_norm"] = float(th.nn.utils.clip_grad_norm_(policy.parameters(), hp.max_grad_norm))
+                policy.optimizer.step()
+                stats["partner"] = k
+                kls.append(stats["approx_kl"])
+                all_stats.append(stats)
+            if hp.target_kl is not None and np.mean(kls) > 1.5 * hp.target_kl:
+                break
+    return all_stats
 
 
 # --------------------------------------------------------------------------------------

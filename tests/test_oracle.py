@@ -279,3 +279,134 @@ def test_adap_context_samplers_have_the_reference_shapes():
         c = fn(3, 16, rng)
         assert c.shape == (16, 3) and c.dtype == np.float32
     assert np.abs(np.linalg.norm(SAMPLERS["l2"](3, 16, rng), axis=1) - 1).max() < 1e-6
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# ModularPolicy / ModularAlgorithm (pantheonrl/algos/modular) -- oracle only: the engine has no device path for it yet
+# ----------------------------------------------------------------------------------------------------------------
+def _modular(num_partners=2, seed=3, **kw):
+    th.manual_seed(seed)
+    return orc.ModularPolicyOracle(orc.SpaceSpec("box", dim=6), orc.SpaceSpec("discrete", nvec=(5,)),
+                                   num_partners=num_partners, **kw)
+
+
+def _filled_buffer(pol, partner, T=8, E=4, seed=0):
+    rng = np.random.default_rng(seed)
+    buf = orc.RolloutBufferOracle(T, E, 6, 1)
+    es = np.ones(E, np.float32)
+    for t in range(T):
+        obs = rng.standard_normal((E, 6)).astype(np.float32)
+        with th.no_grad():
+            a, v, lp = pol.forward(th.as_tensor(obs), partner_idx=partner,
+                                   uniforms=th.as_tensor(rng.random((E, 1)).astype(np.float32)))
+        buf.add(obs, a.numpy().astype(np.float32), rng.standard_normal(E).astype(np.float32), es, v.flatten(), lp)
+        es = (rng.random(E) < 0.2).astype(np.float32)
+    buf.compute_returns_and_advantage(np.zeros(E, np.float32), es)
+    return buf
+
+
+def test_modular_policy_reduces_to_the_main_policy_when_the_partner_heads_are_silent():
+    """logits = main + partner, value = main + partner (modular/policies.py:286,325-328): with a partner's two heads zeroed
+    the network IS the main MlpPolicy -- same values / log-probs / entropy, marginal regulariser exactly 0 -- and the
+    partner towers still read the main policy latent (policies.py:254,281), not the features."""
+    pol = _modular()
+    plain = orc.MlpPolicyOracle(pol.obs_space, pol.act_space)
+    plain.load_flat_params(pol.flat_params()[:plain.flat_params().size])
+    with th.no_grad():
+        for pm in pol.partners:
+            for head in (pm["act"], pm["val"]):
+                head.weight.zero_()
+                head.bias.zero_()
+    rng = np.random.default_rng(1)
+    obs = th.as_tensor(rng.standard_normal((9, 6)).astype(np.float32))
+    acts = th.as_tensor(rng.integers(0, 5, size=(9, 1)))
+    want = plain.evaluate_actions(obs, acts)
+    for k in range(2):
+        got = pol.evaluate_actions(obs, acts, partner_idx=k)
+        for g, w in zip(got, want):
+            np.testing.assert_allclose(g.detach().numpy(), w.detach().numpy(), atol=1e-6)
+    assert orc.modular_marginal_regularization(pol, obs).item() == 0.0
+    # the partner towers' input is the 64-wide policy latent whatever the observation width is
+    assert pol.partners[0]["pi"][0].in_features == orc.HIDDEN and pol.partners[0]["vf"][0].in_features == orc.HIDDEN
+
+
+def test_modular_marginal_regularization_known_answer():
+    """modular/learn.py:309-316 by hand: main logits 0 (uniform over 4 actions), two partners whose logits are constants d1, d2
+    -> mean_rows sum_a | 1/4 - (softmax(d1) + softmax(d2)) / 2 |"""
+    th.manual_seed(0)
+    pol = orc.ModularPolicyOracle(orc.SpaceSpec("box", dim=3), orc.SpaceSpec("discrete", nvec=(4,)), num_partners=2)
+    d = [np.array([0.5, -0.2, 0.1, 0.0], np.float32), np.array([-1.0, 0.3, 0.0, 0.7], np.float32)]
+    with th.no_grad():
+        pol.action_net.weight.zero_()
+        pol.action_net.bias.zero_()
+        for pm, dk in zip(pol.partners, d):
+            pm["act"].weight.zero_()
+            pm["act"].bias.copy_(th.as_tensor(dk))
+    obs = th.as_tensor(np.random.default_rng(0).standard_normal((5, 3)).astype(np.float32))
+    sm = [np.exp(x.astype(np.float64)) / np.exp(x.astype(np.float64)).sum() for x in d]
+    want = np.abs(0.25 - (sm[0] + sm[1]) / 2).sum()
+    assert abs(orc.modular_marginal_regularization(pol, obs).item() - want) < 1e-6
+
+
+def test_modular_train_first_step_is_ppo_on_the_main_network_and_reaches_it_through_the_partner():
+    """(i) silent partner heads + marginal_reg_coef 0 + no gradient clipping: the first optimiser step moves the main network
+    exactly as PPO.train moves the plain MlpPolicy on the same minibatch (Adam is per-parameter) and leaves the partner TOWERS where they were
+    (their gradient is head^T dlogits = 0) while the partner heads move.  (ii) with live partner heads the main policy
+    trunk receives gradient through the partner module: d(main pi trunk) differs from the plain policy's."""
+    pol = _modular(num_partners=1)
+    plain = orc.MlpPolicyOracle(pol.obs_space, pol.act_space)
+    n_main = plain.flat_params().size
+    plain.load_flat_params(pol.flat_params()[:n_main])
+    with th.no_grad():
+        for head in (pol.partners[0]["act"], pol.partners[0]["val"]):
+            head.weight.zero_()
+            head.bias.zero_()
+    buf = _filled_buffer(pol, 0)
+    # no clipping: clip_grad_norm_ runs over ALL parameters (learn.py:324), so the moving partner heads would rescale the main
+    # network's gradient through the shared norm
+    hp = orc.PPOHyper(n_epochs=1, batch_size=32, max_grad_norm=1e9)
+    perm = [np.random.default_rng(5).permutation(32)]
+    before = pol.flat_params()
+    st_m = orc.modular_train(pol, [buf], hp, 0.0, perms=[perm])
+    st_p = orc.ppo_train(plain, buf, hp, perms=perm)
+    assert len(st_m) == 1 and abs(st_m[0]["loss"] - st_p[0]["loss"]) < 1e-6 and st_m[0]["marginal_reg"] == 0.0
+    after = pol.flat_params()
+    np.testing.assert_allclose(after[:n_main], plain.flat_params(), atol=1e-7)
+    towers = 2 * (2 * (64 * 64 + 64))
+    assert np.array_equal(after[n_main:n_main + towers], before[n_main:n_main + towers])
+    assert not np.array_equal(after[n_main + towers:], before[n_main + towers:])
+    # (ii)
+    pol2 = _modular(num_partners=1, seed=4)
+    plain2 = orc.MlpPolicyOracle(pol2.obs_space, pol2.act_space)
+    plain2.load_flat_params(pol2.flat_params()[:n_main])
+    buf2 = _filled_buffer(pol2, 0, seed=2)
+    mb = next(iter(buf2.get(32, np.arange(32))))
+    pol2.optimizer.zero_grad()
+    orc.modular_minibatch_loss(pol2, mb, hp, 0, 0.5)[0].backward()
+    g = pol2.policy_net[0].weight.grad
+    assert g is not None and float(g.abs().max()) > 0
+    assert float(pol2.partners[0]["vf"][0].weight.grad.abs().max()) > 0     # value loss reaches the partner's vf tower
+    assert float(pol2.value_net_mlp[0].weight.grad.abs().max()) > 0
+
+
+def test_modular_train_walks_partner_by_partner_with_one_buffer_each():
+    """modular/learn.py:237-243: partner 0's epochs over buffer 0, then partner 1's over buffer 1; a partner's minibatches never
+    touch the other partner's module unless the marginal regulariser (which evaluates EVERY partner, :307) is on."""
+    pol = _modular(num_partners=2, seed=6)
+    bufs = [_filled_buffer(pol, k, seed=10 + k) for k in range(2)]
+    hp = orc.PPOHyper(n_epochs=2, batch_size=16)
+    n_main = orc.MlpPolicyOracle(pol.obs_space, pol.act_space).flat_params().size
+    per = (pol.flat_params().size - n_main) // 2
+    before = pol.flat_params()
+    stats = orc.modular_train(pol, bufs[:1], hp, 0.0)
+    assert [s["partner"] for s in stats] == [0] * 4
+    after = pol.flat_params()
+    assert np.array_equal(after[n_main + per:], before[n_main + per:]) and not np.array_equal(after[n_main:n_main + per],
+                                                                                              before[n_main:n_main + per])
+    stats = orc.modular_train(pol, bufs, hp, 0.3)
+    assert [s["partner"] for s in stats] == [0] * 4 + [1] * 4 and all(s["marginal_reg"] > 0 for s in stats)
+    # with the regulariser on, partner 1's module moves during partner 0's minibatches too
+    pol3 = _modular(num_partners=2, seed=6)
+    b3 = pol3.flat_params()
+    orc.modular_train(pol3, bufs[:1], hp, 0.3)
+    assert not np.array_equal(pol3.flat_params()[n_main + per:], b3[n_main + per:])
