@@ -620,12 +620,16 @@ def modular_marginal_regularization(policy: ModularPolicyOracle, observations: t
     """modular/learn.py:298-318 for a single Categorical head: every partner's (main_logits, partner_logits) on the minibatch;
     main_probs = mean over partners of softmax(main_logits) (the same tensor num_partners times), composed_probs = mean over
     partners of softmax(main_logits + partner_logits); loss = mean over rows of sum_a |main_probs - composed_probs|."""
-    pairs = [policy.action_logits(observations, k) for k in range(policy.num_partners)]
-    main = th.stack([m for m, _ in pairs])
-    composed = main + th.stack([p for _, p in pairs])
-    main_probs = th.mean(th.exp(main - main.logsumexp(dim=-1, keepdim=True)), dim=0)
-    composed_probs = th.mean(th.exp(composed - composed.logsumexp(dim=-1, keepdim=True)), dim=0)
-    return th.mean(th.sum(th.abs(main_probs - composed_probs), dim=1))
+    def probs(z):                      # exp(z - logsumexp z), the reference's way of writing the softmax (:313-314)
+        return (z - th.logsumexp(z, dim=-1, keepdim=True)).exp()
+    z_main, z_sum = [], []
+    for k in range(policy.num_partners):
+        zm, zp = policy.action_logits(observations, k)
+        z_main.append(zm)
+        z_sum.append(zm + zp)
+    p_alone = probs(th.stack(z_main)).mean(dim=0)          # (rows, actions)
+    p_with_partner = probs(th.stack(z_sum)).mean(dim=0)
+    return (p_alone - p_with_partner).abs().sum(dim=1).mean()
 
 
 def modular_minibatch_loss(policy: ModularPolicyOracle, mb: dict, hp: PPOHyper, partner_idx: int, marginal_reg_coef: float):
