@@ -366,10 +366,13 @@ typedef struct ph_liar_selfplay {
 } ph_liar_selfplay;
 int ph_liar_selfplay_step(ph_ctx *ctx, const ph_liar_selfplay *s, int ego_pos, unsigned long long counter, int deal_only);
 /* n_steps of those vectorised steps -- ego rows ego_pos .. ego_pos + n_steps - 1, step t with counter + t -- in ONE persistent
- * launch: tables are independent, so one workgroup owns 16 tables for the whole rollout and runs the three forwards and the
- * book-keeping of every step with workgroup barriers in place of kernel boundaries.  Bitwise the result of n_steps calls of
- * ph_liar_selfplay_step(deal_only = 0).  Needs the 16-row one-hot forward's shape class (<= 64 observation components,
- * <= 32 logits). */
+ * launch: tables are independent, so one workgroup owns up to 16 tables (as few as spreads n over the CUs) for the whole rollout
+ * and runs the three forwards and the book-keeping of every step with workgroup barriers in place of kernel boundaries.  The
+ * game state, observations, both rollout buffers, the partner's book-keeping, the cached values and the episode count are
+ * bitwise the result of n_steps calls of ph_liar_selfplay_step(deal_only = 0).  A partner forward that none of a workgroup's
+ * tables asks for (no game running after the ego's move; no fresh game opened by the partner) is not executed: the scratch
+ * outputs such a forward would have left for tables that do not move (partner action / log-prob cache entries nothing reads)
+ * are then stale.  Needs the 16-row one-hot forward's shape class (<= 64 observation components, <= 32 logits). */
 int ph_liar_selfplay_rollout(ph_ctx *ctx, const ph_liar_selfplay *s, int ego_pos, int n_steps, unsigned long long counter);
 
 /* n_steps vectorised agent steps against a SCRIPTED environment -- observations, rewards and dones of every step already

@@ -935,8 +935,10 @@ static size_t fwd16h_lds_bytes() {
 // workgroup owns up to 16 tables (launch_liar_rollout: as few as spreads them over every CU) for the whole rollout -- ego forward -> move -> partner reply -> move / credit / re-deal -> partner
 // opening -> move -- with workgroup barriers where the launch-by-launch walk has kernel boundaries.  The lower half of the
 // workgroup runs the policy net of the acting agent, the upper half its value net (policy_fwd16h_body<.., FUSED>), sixteen lanes
-// run the per-table book-keeping (ph_liar.h: the very functions of the per-step kernels), so every number is bitwise what
-// 6 x n_steps launches produce; what disappears is their ~1 us per dependent cold-cache round trip and the launch boundaries.
+// run the per-table book-keeping (ph_liar.h: the very functions of the per-step kernels), so every number that is read again
+// (game state, observations, both buffers, book-keeping, cached values) is bitwise what 6 x n_steps launches produce; what
+// disappears is their ~1 us per dependent cold-cache round trip, the launch boundaries, and the partner forwards whose outputs
+// would be scratch (see the loop).
 struct LiarRolloutArgs {
   ph_liar_selfplay s;
   FwdArgs ego, reply, opening;        // the three forwards of a step; ego.rb_* point at row ego_pos0
