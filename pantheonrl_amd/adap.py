@@ -113,7 +113,11 @@ class ADAP(PPO):
         self.context_loss_coeff, self.context_size = float(context_loss_coeff), int(context_size)
         self.num_context_samples, self.num_state_samples = int(num_context_samples), int(num_state_samples)
         self.context_sampler = context_sampler
-        self.context_rng = np.random.default_rng(kwargs.get("seed"))
+        # One generator per learner: trainer.py hands the ego and every ADAP partner the same --seed, and the reference draws all
+        # contexts from ONE global torch stream (adap/util.py:42-77), so agents never see each other's draws.  The seed is
+        # therefore salted with the learner's sampling stream (as the action-sampling key is); its state travels with save/load.
+        seed, stream = kwargs.get("seed"), int(kwargs.get("sampling_stream", 0) or 0)
+        self.context_rng = np.random.default_rng() if seed is None else np.random.default_rng([int(seed), stream])
         self.last_context_losses: Optional[np.ndarray] = None
         super().__init__("MlpPolicy", env, *args, **kwargs)
 
@@ -121,6 +125,17 @@ class ADAP(PPO):
 
     def sample_context(self, num: int = 1) -> np.ndarray:
         return SAMPLERS[self.context_sampler](self.context_size, num, self.context_rng)
+
+    def _extra_state(self) -> dict:                 # saved under "extra" by PPO.save
+        ctx = self.policy.get_context()
+        return {"context_rng": self.context_rng.bit_generator.state,
+                "context": None if ctx is None else np.asarray(ctx, np.float32).tolist()}
+
+    def _load_extra_state(self, extra: dict) -> None:
+        if extra.get("context_rng") is not None:    # continue the stream instead of replaying it from the seed
+            self.context_rng.bit_generator.state = extra["context_rng"]
+        if extra.get("context") is not None:
+            self.policy.set_context(np.asarray(extra["context"], np.float32))
 
     def _setup_model(self) -> None:                 # adap_learn.py:208-215
         self.policy = AdapPolicy(self.observation_space, self.action_space, context_size=self.context_size,

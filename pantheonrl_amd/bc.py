@@ -187,13 +187,44 @@ class BC:
         opt.step = self.opt_step.data_ptr()
         hp = self.hyper()
         pol.ctx.set_stream(th.cuda.current_stream(self.device).cuda_stream)
-        nat.check(pol.ctx.lib.ph_bc_train(pol.ctx.handle, C.byref(pol.spec), C.byref(opt), self._obs.data_ptr(),
-                                          self._acts.data_ptr(), order_t.data_ptr(), N, self.batch_size, epochs,
-                                          0 if n_batches is None else int(n_batches), C.byref(hp), stats.data_ptr()))
+
+        def launch(order_ptr, n_rows, n_ep, max_b, stats_row):
+            nat.check(pol.ctx.lib.ph_bc_train(pol.ctx.handle, C.byref(pol.spec), C.byref(opt), self._obs.data_ptr(),
+                                              self._acts.data_ptr(), order_ptr, n_rows, self.batch_size, n_ep, max_b, C.byref(hp),
+                                              stats.data_ptr() + 4 * nat.PH_BC_NSTAT * stats_row))
+        if on_batch_end is None and on_epoch_end is None:
+            # the whole run as ONE launch of the persistent workgroup (parameters never leave LDS)
+            launch(order_t.data_ptr(), N, epochs, 0 if n_batches is None else int(n_batches), 0)
+        else:
+            # A callback must see the state the reference's loop shows it (bc.py:333-353: on_batch_end after every optimizer
+            # step, on_epoch_end after every pass): the run is cut at the callback's granularity -- one launch per epoch, or
+            # one per batch -- with the optimizer state carried on the device: same kernel, same order of steps (the results
+            # differ from the single launch only through the rounding of Adam's bias corrections, which one launch carries as
+            # running fp64 products and a fresh launch restarts from pow(beta, step)).
+            done = 0
+            for ep in range(epochs):
+                left = total - done
+                if left <= 0:
+                    break
+                row = order_t.data_ptr() + 4 * N * ep
+                if on_batch_end is None:
+                    nb = min(per_epoch, left)
+                    launch(row, N, 1, 0 if nb == per_epoch else nb, done)
+                    done += nb
+                else:
+                    for b in range(min(per_epoch, left)):
+                        lo = b * self.batch_size
+                        launch(row + 4 * lo, min(self.batch_size, N - lo), 1, 0, done)
+                        done += 1
+                        on_batch_end()
+                if on_epoch_end is not None and (n_batches is None or done < total):   # n_batches: the loop returns mid-epoch (bc.py:141-143)
+                    on_epoch_end()
         self.last_stats = stats.cpu().numpy()
-        if on_epoch_end is not None:
-            for _ in range(epochs):
-                on_epoch_end()
+        if log_interval and getattr(self, "logger", None) is not None:
+            for b in range(0, total, int(log_interval)):      # bc.py:343-347: every log_interval batches
+                for k, name in enumerate(nat.BC_STAT_NAMES):
+                    self.logger.record(f"bc/{name}", float(self.last_stats[b, k]))
+                self.logger.dump(step=b)
         return self.last_stats
 
     def save_policy(self, policy_path: str) -> None:

@@ -574,6 +574,13 @@ __global__ __launch_bounds__(256) void policy_fwd16_multi_kernel(FwdMulti m) {
   policy_fwd16_body<false>(m.a[blockIdx.z], m.px.x, m.px.t, m.px.a_local, blockIdx.z);
 }
 
+// index of the current device into the per-device "LDS opt-in done" tables of the launchers below
+static int current_device_slot() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return (dev >= 0 && dev < 64) ? dev : 0;
+}
+
 static size_t fwd16_lds_bytes() { return sizeof(float) * (size_t)(2 * 16 * LDH + 2 * HID * LDH + HID * 8 + 2 * HID + 8 + 16); }
 
 bool fwd16_eligible(const NetDims& nd, int n) {
@@ -587,8 +594,9 @@ bool fwd16_eligible(const NetDims& nd, int n) {
 
 template <bool VALU>
 static hipError_t launch_fwd16_variant(const FwdArgs& a, hipStream_t s) {
-  static bool allowed = false;  // dynamic LDS above 64 KiB is opt-in, once per kernel
+  static bool allowed_dev[64] = {false};  // dynamic LDS above 64 KiB is opt-in, per kernel and device
   const size_t lds = fwd16_lds_bytes();
+  bool& allowed = allowed_dev[current_device_slot()];
   if (!allowed && lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)policy_fwd16_kernel<VALU>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -1238,7 +1246,9 @@ template <int R, int LP, bool VALU>
 static hipError_t launch_fwd_variant(const FwdArgs& a, hipStream_t s) {
   dim3 grid((a.n + R - 1) / R, 2), block(R * 4);
   const size_t lds = fwd_lds_bytes(R, LP);
-  static size_t allowed = 64 * 1024;  // dynamic LDS above 64 KiB is opt-in, once per kernel
+  static size_t allowed_dev[64] = {0};  // dynamic LDS above 64 KiB is opt-in, per kernel and device (hipFuncSetAttribute)
+  size_t& allowed = allowed_dev[current_device_slot()];
+  if (allowed == 0) allowed = 64 * 1024;
   if (lds > allowed) {
     hipError_t e = hipFuncSetAttribute((const void*)policy_fwd_kernel<R, LP, VALU>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1253,7 +1263,9 @@ template <int R, int LP>
 static hipError_t launch_fwd_multi_variant(const FwdMulti& m, int n_agents, hipStream_t s) {
   dim3 grid((m.a[0].n + R - 1) / R, 2, n_agents), block(R * 4);
   const size_t lds = fwd_lds_bytes(R, LP);
-  static size_t allowed = 64 * 1024;
+  static size_t allowed_dev[64] = {0};
+  size_t& allowed = allowed_dev[current_device_slot()];
+  if (allowed == 0) allowed = 64 * 1024;
   if (lds > allowed) {
     hipError_t e = hipFuncSetAttribute((const void*)policy_fwd_multi_kernel<R, LP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -139,16 +139,19 @@ class ActionExchange:
             verified = False
             if attached:
                 # the engine-side all-gather must reproduce torch.distributed's on a known pattern before it is trusted
+                # Only the native call sits inside the try: a rank whose native gather throws must still take part in the
+                # torch.distributed gather and the verdict all-reduce below, or the other ranks block in mismatched collectives.
+                pattern = th.arange(self.local.numel(), dtype=th.int32, device=self.local.device).view_as(self.local)
+                self.local.copy_(pattern * 7 + 1000003 * (self.rank + 1))
+                got = None
                 try:
-                    pattern = th.arange(self.local.numel(), dtype=th.int32, device=self.local.device).view_as(self.local)
-                    self.local.copy_(pattern * 7 + 1000003 * (self.rank + 1))
                     got = self.gather_inplace().clone()
                     if self.local.is_cuda:
                         th.cuda.synchronize(self.local.device)
-                    verified = bool(th.equal(got, self._torch_gather()))
                 except Exception:  # noqa: BLE001
-                    verified = False
-                verified = self._everyone(verified)
+                    got = None
+                want = self._torch_gather()           # every rank, unconditionally
+                verified = self._everyone(got is not None and bool(th.equal(got, want)))
             self._rccl_verified = verified
             log["rccl_verified"] = verified
             if not verified:
@@ -237,11 +240,15 @@ class ActionExchange:
         gathers from the same local actions?  (`self.local` still holds the last step's actions.)  All ranks get the same
         answer; a peer-to-peer timeout also counts as a failure."""
         ok = True
-        try:
+        try:                                      # local work only: nothing in here is a collective
             if self.local.is_cuda:
                 th.cuda.synchronize(self.local.device)
-            want = self._torch_gather()
-            ok = bool(th.equal(last_slot, want)) and self.p2p_timeouts() == 0
+            ok = self.p2p_timeouts() == 0
+        except Exception:  # noqa: BLE001
+            ok = False
+        want = self._torch_gather()               # every rank, unconditionally: the collective sequence is identical on all ranks
+        try:
+            ok = ok and bool(th.equal(last_slot, want))
         except Exception:  # noqa: BLE001
             ok = False
         return self._everyone(ok)

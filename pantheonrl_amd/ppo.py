@@ -511,19 +511,28 @@ class PPO:
             m._n_updates += m.n_epochs
 
     # -- OnPolicyAlgorithm.learn() for the ego (trainer.py:413) -----------------------------------------
-    def collect_rollouts(self, forced_uniforms=None) -> bool:
+    def collect_rollouts(self, forced_uniforms=None, callback=None) -> bool:
         """SB3 1.7.0 OnPolicyAlgorithm.collect_rollouts for the ego (trainer.py:413).  `forced_uniforms[t]` (E, A) teacher-forces
-        the sampling uniforms of step t (tests)."""
+        the sampling uniforms of step t (tests).  `callback`: an SB3-style BaseCallback -- on_rollout_start() before the first
+        step, update_locals(locals()) + on_step() after every vectorised environment step (a False return ends the rollout and
+        learn(), as in SB3: the witness is modular/learn.py:173,195-196), on_rollout_end() is learn()'s."""
         env, rb, pol = self.env, self.rollout_buffer, self.policy
         rb.reset()
         dones = np.zeros(self.n_envs, dtype=bool)
         new_obs = self._last_obs
+        if callback is not None and hasattr(callback, "on_rollout_start"):
+            callback.on_rollout_start()
         for t in range(self.n_steps):
             actions, _, _ = pol.forward_and_store(self._last_obs, rb, self._last_episode_starts,
                                                   uniforms=None if forced_uniforms is None else forced_uniforms[t])
             act_np = actions.cpu().numpy()
             new_obs, rewards, dones, infos = env.step(act_np)
             self.num_timesteps += self.n_envs
+            if callback is not None and hasattr(callback, "on_step"):
+                if hasattr(callback, "update_locals"):
+                    callback.update_locals(locals())
+                if callback.on_step() is False:
+                    return False
             rewards = np.asarray(rewards, np.float32).copy()
             for idx, info in enumerate(infos):
                 ep = info.get("episode") if isinstance(info, dict) else None
@@ -550,6 +559,13 @@ class PPO:
     def _after_step(self, dones) -> None:
         """hook after every vectorised environment step of collect_rollouts (ADAP re-draws contexts here)"""
 
+    def _extra_state(self) -> dict:
+        """JSON-serialisable learner state beyond the hyper-parameters (ADAP: context generator and current contexts)"""
+        return {}
+
+    def _load_extra_state(self, extra: dict) -> None:
+        pass
+
     def learn(self, total_timesteps: int, log_interval: int = 1, tb_log_name: str = "PPO",
               reset_num_timesteps: bool = True, callback=None, **_ignored) -> "PPO":
         if self.env is None or not hasattr(self.env, "step"):
@@ -566,15 +582,17 @@ class PPO:
         self.start_time = time.time()
         self._total_timesteps, start_steps = total_timesteps, self.num_timesteps
         iteration = 0
-        # callback: SB3's BaseCallback protocol where available (init_callback / on_training_start / on_rollout_end /
-        # on_training_end), or a plain callable(locals, globals) -> bool called once per rollout; False stops training
+        # callback: SB3's BaseCallback protocol where available (init_callback / on_training_start / on_rollout_start /
+        # on_step per vectorised step / on_rollout_end / on_training_end), or a plain callable(locals, globals) -> bool called
+        # once per rollout; False stops training
         cb_obj = callback if hasattr(callback, "on_rollout_end") else None
         if cb_obj is not None and hasattr(cb_obj, "init_callback"):
             cb_obj.init_callback(self)
         if cb_obj is not None and hasattr(cb_obj, "on_training_start"):
             cb_obj.on_training_start(locals(), globals())
         while self.num_timesteps < total_timesteps:
-            self.collect_rollouts()
+            if self.collect_rollouts(callback=cb_obj) is False:
+                break
             iteration += 1
             # SB3 _update_current_progress_remaining(num_timesteps, total_timesteps)
             self._current_progress_remaining = 1.0 - float(self.num_timesteps - start_steps) / float(
@@ -639,7 +657,7 @@ class PPO:
                 data[k] = self._schedule(data[k], prog)
         data.update(observation_space=self._space_to_json(self.observation_space),
                     action_space=self._space_to_json(self.action_space), num_timesteps=self.num_timesteps,
-                    _n_updates=self._n_updates, format="pantheonrl_amd-1")
+                    _n_updates=self._n_updates, format="pantheonrl_amd-1", extra=self._extra_state())
         pol = self.policy
         with zipfile.ZipFile(path, "w") as zf:
             zf.writestr("data", json.dumps(data))
@@ -681,4 +699,5 @@ class PPO:
         model.policy.adam_v.copy_(opt["exp_avg_sq"])
         model.policy.opt_step.fill_(int(opt["step"]))
         model.num_timesteps, model._n_updates = data["num_timesteps"], data["_n_updates"]
+        model._load_extra_state(data.get("extra") or {})
         return model

@@ -347,3 +347,28 @@ def test_trainer_adap_object_graph_with_shared_latent(tmp_path, monkeypatch):
     assert loaded.context_size == 3 and np.array_equal(loaded.policy.get_flat_params(), ego.policy.get_flat_params())
     trainer.run(["RPS-v0", "PPO", "FIXED", "--seed", "3", "-t", "64", "--ego-config", cfg, "--alt-config",
                  '{"type": "ADAP", "location": "m/ego", "latent_val": [0.0, 1.0, 0.0]}'])
+
+
+def test_context_streams_are_per_learner_and_survive_save_load(tmp_path):
+    """trainer.py gives the ego and every ADAP partner the same --seed; the reference draws every context from one global
+    torch stream (adap/util.py:42-77), so two learners never act under each other's draws: here the generator is keyed by
+    (seed, sampling_stream), and a loaded model continues its stream instead of replaying it from the seed."""
+    from pantheonrl_amd.adap import ADAP
+    hp = orc.PPOHyper(batch_size=8, n_epochs=1)
+    ego = _adap_model("adap_small", 8, 2, hp, seed=7)
+    from pantheonrl_amd import spaces as sp
+    obs_s, act_s = H.CONFIGS["adap_small"]
+    env = type("E", (), dict(observation_space=sp.Box(-np.inf, np.inf, (obs_s.dim - 3,)), action_space=H.to_space(act_s),
+                             _is_dummy_space_env=True))()
+    alt = ADAP("AdapPolicy", env, n_steps=8, n_envs=2, batch_size=8, n_epochs=1, seed=7, sampling_stream=1)
+    twin = ADAP("AdapPolicy", env, n_steps=8, n_envs=2, batch_size=8, n_epochs=1, seed=7, sampling_stream=1)
+    assert not np.array_equal(ego.policy.get_context(), alt.policy.get_context())     # same seed, different learners
+    assert np.array_equal(alt.policy.get_context(), twin.policy.get_context())        # ... yet reproducible
+    a = [ego.sample_context(1) for _ in range(4)]
+    b = [alt.sample_context(1) for _ in range(4)]
+    assert all(not np.array_equal(x, y) for x, y in zip(a, b))
+    alt.save(str(tmp_path / "alt"))
+    nxt = alt.sample_context(3)
+    back = ADAP.load(str(tmp_path / "alt"))
+    assert np.array_equal(back.policy.get_context(), alt.policy.get_context())
+    assert np.array_equal(back.sample_context(3), nxt)                                # continues, does not restart

@@ -113,6 +113,34 @@ def test_bc_n_batches_mode_save_and_reconstruct(tmp_path):
     assert 0 <= int(a) < 6
 
 
+def test_bc_callbacks_observe_intermediate_state_and_do_not_change_the_result():
+    """on_batch_end / on_epoch_end (bc.py:100-160: EpochOrBatchIteratorWithProgress): the run is cut into one launch per batch
+    (or per epoch) so a callback sees the parameters after exactly the steps taken so far; the final parameters are those of
+    the single-launch run up to the rounding of Adam's bias corrections (one launch carries beta^t as a running fp64 product,
+    a fresh launch starts from pow(beta, t): <= 1e-6 after 12 steps).  With n_batches the loop returns mid-epoch: no
+    on_epoch_end for the last epoch."""
+    orders = np.stack([np.random.default_rng(ep).permutation(100) for ep in range(3)])
+    one, _, _, _ = _pair("overcooked", 100, seed=5)
+    one.train(n_epochs=3, orders=orders)
+    per_batch, _, _, _ = _pair("overcooked", 100, seed=5)
+    steps, snaps, epochs_seen = [], [], []
+    per_batch.train(n_epochs=3, orders=orders, on_batch_end=lambda: (steps.append(int(per_batch.opt_step.item())),
+                                                                      snaps.append(per_batch.policy.get_flat_params().copy())),
+                    on_epoch_end=lambda: epochs_seen.append(int(per_batch.opt_step.item())))
+    assert steps == list(range(1, 13)) and epochs_seen == [4, 8, 12]
+    assert all(not np.array_equal(snaps[i], snaps[i + 1]) for i in range(11))
+    assert np.abs(per_batch.policy.get_flat_params() - one.policy.get_flat_params()).max() <= 1e-6
+    assert np.abs(per_batch.last_stats - one.last_stats).max() <= 1e-4
+    per_epoch, _, _, _ = _pair("overcooked", 100, seed=5)
+    seen = []
+    per_epoch.train(n_epochs=3, orders=orders, on_epoch_end=lambda: seen.append(int(per_epoch.opt_step.item())))
+    assert seen == [4, 8, 12] and np.abs(per_epoch.policy.get_flat_params() - one.policy.get_flat_params()).max() <= 1e-6
+    cut, _, _, _ = _pair("overcooked", 100, seed=5)
+    seen = []
+    cut.train(n_batches=6, orders=orders[:2], on_epoch_end=lambda: seen.append(int(cut.opt_step.item())))
+    assert seen == [4] and int(cut.opt_step.item()) == 6
+
+
 def test_bc_learns_the_expert_on_a_separable_problem():
     """end to end on the .npy wire format the recorders write (trajsaver): an 'expert' whose action is a function of the
     observation is cloned to > 95 % agreement"""

@@ -1424,6 +1424,38 @@ def test_learn_schedules_and_callback():
     assert stop.num_timesteps == 48                       # a callback returning False ends training
 
 
+def test_learn_drives_an_sb3_style_callback_object_per_step():
+    """SB3's BaseCallback protocol on learn(): on_rollout_start before every rollout, update_locals + on_step after every
+    vectorised environment step (the in-tree witness of SB3's loop: modular/learn.py:173,195-196), a False return from
+    on_step ends the rollout and the training without an update on the cut rollout."""
+    from pantheonrl_amd.ppo import PPO
+
+    class Cb:
+        def __init__(self, stop_at=None):
+            self.events, self.stop_at, self.n_calls, self.locals = [], stop_at, 0, None
+        def init_callback(self, model): self.model = model
+        def on_training_start(self, loc, glob): self.events.append("train_start")
+        def on_rollout_start(self): self.events.append("rollout_start")
+        def update_locals(self, loc): self.locals = loc
+        def on_step(self):
+            self.n_calls += 1
+            assert "new_obs" in self.locals and "rewards" in self.locals and "dones" in self.locals
+            return not (self.stop_at is not None and self.n_calls >= self.stop_at)
+        def on_rollout_end(self): self.events.append("rollout_end")
+        def on_training_end(self): self.events.append("train_end")
+
+    cb = Cb()
+    model = PPO("MlpPolicy", _TimeLimitVec(horizon=1000), n_steps=8, n_envs=3, batch_size=12, n_epochs=1, seed=0)
+    model.learn(total_timesteps=2 * 24, callback=cb)
+    assert cb.n_calls == 16 and cb.model is model
+    assert cb.events == ["train_start", "rollout_start", "rollout_end", "rollout_start", "rollout_end", "train_end"]
+    cut = Cb(stop_at=11)
+    m2 = PPO("MlpPolicy", _TimeLimitVec(horizon=1000), n_steps=8, n_envs=3, batch_size=12, n_epochs=1, seed=0)
+    m2.learn(total_timesteps=10 ** 6, callback=cut)
+    assert cut.n_calls == 11 and m2.num_timesteps == 33 and m2._n_updates == 1      # one full rollout trained, the second cut
+    assert cut.events == ["train_start", "rollout_start", "rollout_end", "rollout_start", "train_end"]
+
+
 def test_ragged_partner_trains_on_its_full_columns_only():
     """RaggedVecOnPolicyAgent.min_full < E: the update runs on exactly the full columns (compacted, ph_buffer_compact_columns)
     and equals -- bitwise -- the update of a fresh model whose (T, n) buffer holds those columns; the other columns keep

@@ -470,6 +470,42 @@ def test_games_reproduce_the_hand_worked_traces_and_the_committed_fixture():
         turn = ~turn
 
 
+def test_integer_fixtures_are_what_the_reference_code_produces():
+    """tests/golden/check_against_reference.py executes the reference's own liar.py / rps.py (from /root/reference, with
+    inert stand-ins for the absent `gym` names) on the committed inputs and compares every output: the integer fixtures are
+    reference output, not only restatement output.  Build container only -- the reference does not travel to the GPU box."""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("check_against_reference", os.path.join(here, "check_against_reference.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    if not os.path.isdir(chk.REFERENCE):
+        pytest.skip("the reference tree is not present on this machine")
+    liar_ns, rps_ns = chk.load_reference_games()
+    assert chk.check_hand_worked(liar_ns) == 24
+    z = dict(np.load(os.path.join(here, "game_traces.npz")))
+    for k, v in chk.replay_traces(liar_ns, rps_ns, z).items():
+        assert np.array_equal(v, z[k]), k
+    chk.check_dice(liar_ns)
+    # and the product's restatement agrees with the reference on fresh random play (not only on the committed inputs)
+    rng = np.random.default_rng(11)
+    for _ in range(200):
+        hands = rng.integers(0, 7, 12)
+        ref = chk._table(liar_ns, hands[:6], hands[6:])
+        own = LiarEnv()
+        own.history, own.egohand, own.althand = [], hands[:6].tolist(), hands[6:].tolist()
+        ego = bool(rng.integers(0, 2))
+        for _s in range(14):
+            raw = np.asarray([rng.integers(0, 7), rng.integers(0, 12)])
+            o1, r1, d1, _ = ref.player_step(raw.copy(), ego)
+            o2, r2, d2, _ = own.player_step(raw.copy(), ego)
+            assert np.array_equal(np.asarray(o1), np.asarray(o2)) and tuple(r1) == tuple(r2) and bool(d1) == bool(d2)
+            if d1:
+                break
+            ego = not ego
+
+
 def test_tester_and_bctrainer_cli_surface():
     """tester.py:14-31 / bctrainer.py:26-67: flags and the load-iff-not-DEFAULT rule (no GPU: nothing is constructed)"""
     from pantheonrl_amd import bctrainer, tester, trainer
