@@ -93,6 +93,11 @@ def parse():
                          "test_scripted_rollout_is_bitwise_the_per_step_walk); the line then also carries the stepwise figure "
                          "(`stepwise_rollout`).  stepwise: one launch per environment step (get_action / update per step, as an "
                          "external environment or the N>1 per-step action exchange drives them)")
+    ap.add_argument("--action-masks", choices=("none", "env", "policy+env"), default="none",
+                    help="fusedstep layouts: SURVEY.md 8(d)'s config-5 variant -- Bernoulli(0.8) action masks with at least one legal "
+                         "action.  env: the reference's plain PPO partner (the policy never sees the mask, agents.py:162; the "
+                         "environment replaces an illegal sample by the first legal index, pettingzoo.py:81-82; the buffer keeps the "
+                         "sample).  policy+env: ModularPolicy's -30 logit offset (modular/policies.py:330-333) as well")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "exercise the N>1 code path with several ranks on ONE GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -409,7 +414,18 @@ def main():
         # step (vec.FusedSelfPlayRollout); per-step hipGraphs measured 2x slower than direct launches here.
         from pantheonrl_amd.vec import FusedSelfPlayRollout
         th.cuda.set_stream(streams[0])
-        steps = FusedSelfPlayRollout(agents, datas, exchange, streams[0])
+        masks = None
+        if args.action_masks != "none":
+            L = agents[0].model.policy.layout.L
+            masks = []
+            for i in range(len(agents)):
+                rng = np.random.default_rng(7000 + 10 * rank + i)
+                mk = (rng.random((args.n_steps, args.n_envs, L)) < 0.8).astype(np.uint8)
+                dead = mk.sum(-1) == 0
+                mk[dead, rng.integers(0, L, size=int(dead.sum()))] = 1      # at least one legal action
+                masks.append(th.as_tensor(mk).to(device))
+        steps = FusedSelfPlayRollout(agents, datas, exchange, streams[0], masks=masks,
+                                     mask_mode=2 if args.action_masks == "env" else 1)
         it_counter = [0]
 
         def iteration():
@@ -479,7 +495,17 @@ def main():
                    "exchange": ({"route": exchange.route, **exchange.route_log, "p2p_timeouts": exchange.p2p_timeouts()}
                                 if exchange is not None and hasattr(exchange, "route") else None),
                    "launch_mode": mode,
-                   "rollout": (args.rollout if mode == "graph" else "stepwise")},
+                   "action_masks": args.action_masks if mode == "fusedstep" else "none",
+                   # how the n_steps steps of a rollout are launched: "scripted" / "persistent" = ONE launch per rollout (N = 1
+                   # graph mode; the exchange layouts with the per-step action hand-off done in-kernel), "stepwise" / "p2p" = one
+                   # launch per environment step
+                   "rollout": (args.rollout if mode == "graph" else getattr(steps, "last_rollout_mode", "stepwise")
+                               if mode == "fusedstep" else "stepwise"),
+                   # Weak-scaling efficiency is value(N) / (N * value(1)) of the DEFAULT invocations: N = 1 runs the scripted
+                   # one-launch rollout without any exchange, N > 1 the persistent one-launch exchange rollout, so both ends of the
+                   # ratio launch a rollout once; `stepwise_rollout` is the base to use if a run fell back to one launch per step.
+                   "efficiency_base": "python bench.py (N=1, launch_mode graph, rollout scripted); per-GPU work is fixed "
+                                      "(agents_per_gpu learners x n_envs x n_steps per iteration)"},
     }
     if exchange is not None and hasattr(exchange, "route") and exchange.p2p_timeouts() != 0:
         raise SystemExit(f"bench.py: rank {rank}: {exchange.p2p_timeouts()} peer-to-peer polls timed out -- the run is invalid")

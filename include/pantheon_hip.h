@@ -33,8 +33,9 @@
 extern "C" {
 #endif
 
-#define PH_ABI_VERSION 2   /* 2: + ph_agent_*, ph_bc_*, ph_adap_*, ph_scripted_rollout, ph_liar_selfplay_rollout, ph_roundrobin_env_step,
-                                  ph_buffer_compact_columns (additions only: every v1 signature is unchanged) */
+#define PH_ABI_VERSION 3   /* 2: + ph_agent_*, ph_bc_*, ph_adap_*, ph_scripted_rollout, ph_liar_selfplay_rollout, ph_roundrobin_env_step,
+                                  ph_buffer_compact_columns (additions only: every v1 signature is unchanged)
+                              3: + ph_selfplay_rollout_persistent, PH_STEP_FIX_ILLEGAL (additions only) */
 #define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
 #define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
 #define PH_MAX_LOGITS 64 /* max total policy logits L */
@@ -197,7 +198,7 @@ typedef struct ph_step_call {
   int n;
   const unsigned char *action_mask;  /* (n, L) or NULL */
   unsigned long long seed, counter;
-  int deterministic;
+  int deterministic;                 /* bit 0: argmax instead of sampling; PH_STEP_FIX_ILLEGAL / PH_STEP_MASK_ENV_ONLY: see below */
   int *actions_i32;                  /* (n, A) */
   float *values;                     /* (n) */
   float *log_probs;                  /* (n) */
@@ -210,6 +211,15 @@ typedef struct ph_step_call {
   const int *partner_seat;           /* device int; required when joint_actions != NULL */
   float bonus;
 } ph_step_call;
+/* Flags in `deterministic` besides bit 0, for a record with an action mask (single Discrete heads of <= 8 logits):
+ *  PH_STEP_FIX_ILLEGAL: actions_i32 -- what the environment and the action exchange consume -- is the ENV-SIDE fix-up of an
+ *      illegal sample (first legal index: pettingzoo.py:81-82 does this inside the environment, before base_env.step), while
+ *      the rollout-buffer row and the log-prob keep the sampled action, as the reference's agent does (it is never told).
+ *  PH_STEP_MASK_ENV_ONLY: the mask is NOT applied to the logits.  That is the reference's plain PPO agent: OnPolicyAgent
+ *      hands its policy obs.obs only (agents.py:162; action_from_policy util.py:63-81), so only ModularPolicy
+ *      (modular/policies.py:330-333) ever offsets logits; everyone else samples unmasked and the environment repairs. */
+#define PH_STEP_FIX_ILLEGAL 2
+#define PH_STEP_MASK_ENV_ONLY 4
 int ph_policy_step_multi(ph_ctx *ctx, int n_calls, const ph_step_call *calls /* host */);
 
 /* ---- agent-per-GPU action exchange over RCCL ------------------------------------------------------
@@ -274,6 +284,46 @@ int ph_p2p_ll_push(ph_ctx *ctx, const ph_p2p *x, const int *local, int t);
 int ph_p2p_ll_unpack(ph_ctx *ctx, const ph_p2p *x, int t);
 int ph_selfplay_rollout_p2p(ph_ctx *ctx, int n_calls, const ph_step_call *calls /* host, [T][n_calls] */, int T,
                             const int *local, const ph_p2p *x);
+
+/* The same T steps as ONE launch (the N > 1 counterpart of ph_scripted_rollout): when every local agent's observations,
+ * base rewards and done flags of the rollout already sit in HBM (the synthetic rollout driver of SURVEY.md 8d), the only thing
+ * that has to cross a step boundary is what multiagentenv.py:149-170 hands between agents -- each seat's action.  Here that
+ * hand-off happens INSIDE the launch: the policy workgroup of 16 environments stores each sampled action as one stamped
+ * 8-byte word into every rank's `ll` area (as ph_selfplay_rollout_p2p's fused step does), and the value workgroup of step
+ * t + 1 polls the two words it consumes (own seat, partner seat) before it credits step t's reward
+ *   rewards[t][e] += rew_seq[t][e] + bonus * [joint[seat][e] == joint[*partner_seat][e]]
+ * (the last step's reward is credited at the end of the launch).  Bitwise the launch-per-step walk of
+ * ph_selfplay_rollout_p2p followed by ph_buffer_add_reward_joint for step T - 1 (tests/test_gpu_parity.py).
+ *   Word slots: step t of an iteration whose epoch word reads e uses slot (e & 1) * x->T + t (x->T >= T), so x->ll_slots must be
+ *   >= 2 x->T (a
+ *   launch's policy workgroups run ahead of its value workgroups; alternating halves keep a faster peer's next iteration
+ *   from overwriting words this rank has not consumed).  After the launch the words of step T - 1 are unpacked into the plain
+ *   receive slot of parity (T - 1) & 1, which also makes this rank wait for every peer once per iteration.
+ *   Every workgroup of the launch must be resident at once (value workgroups poll; policy workgroups never wait):
+ *   n_calls * 2 * ceil(n / 16) workgroups, times `ranks_on_device` when several ranks share one GPU, must not exceed
+ *   2 * #CUs -- otherwise the call refuses (use ph_selfplay_rollout_p2p).  Shapes of the 16-row forward only. */
+typedef struct ph_rollout_call {
+  const ph_spec *spec;               /* host */
+  const float *params;
+  const float *obs_seq;              /* (T, n, D) */
+  const float *rew_seq;              /* (T, n) base reward of every step */
+  const float *done_seq;             /* (T, n) */
+  const unsigned char *mask_seq;     /* (T, n, L) action masks or NULL */
+  int n;
+  const float *episode_start0;       /* (n) */
+  unsigned long long seed, counter0; /* step t samples with counter0 + t */
+  int mask_mode;                     /* with mask_seq: 0 = policy-side logit offset only, 1 = offset + env-side fix-up
+                                        (PH_STEP_FIX_ILLEGAL), 2 = env-side fix-up only (+ PH_STEP_MASK_ENV_ONLY) */
+  int *actions_i32;                  /* (n) the last step's environment-side actions */
+  float *values;                     /* (n) */
+  float *log_probs;                  /* (n) */
+  const ph_rollout *rb;              /* host; rows 0 .. T-1 are written */
+  int n_seats, seat;
+  const int *partner_seat;           /* device int */
+  float bonus;
+} ph_rollout_call;
+int ph_selfplay_rollout_persistent(ph_ctx *ctx, int n_calls, const ph_rollout_call *calls /* host */, int T,
+                                   const ph_p2p *x, int ranks_on_device);
 
 /* Ragged rollout buffers for vectorised TURN-BASED games ("per-env pos"): a partner does not act in
  * every env at every step, so each env e has its own write row pos_env[e] (device int32, caller-owned).

@@ -108,6 +108,19 @@ class PhP2P(C.Structure):
                 ("epoch", C.c_void_p), ("error", C.c_void_p), ("timeout_cycles", C.c_ulonglong)]
 
 
+PH_STEP_FIX_ILLEGAL = 2
+PH_STEP_MASK_ENV_ONLY = 4
+
+
+class PhRolloutCall(C.Structure):
+    """ph_rollout_call: one local agent's whole scripted rollout in the symmetric exchange layout"""
+    _fields_ = [("spec", C.POINTER(PhSpec)), ("params", C.c_void_p), ("obs_seq", C.c_void_p), ("rew_seq", C.c_void_p),
+                ("done_seq", C.c_void_p), ("mask_seq", C.c_void_p), ("n", C.c_int), ("episode_start0", C.c_void_p),
+                ("seed", C.c_ulonglong), ("counter0", C.c_ulonglong), ("mask_mode", C.c_int), ("actions_i32", C.c_void_p),
+                ("values", C.c_void_p), ("log_probs", C.c_void_p), ("rb", C.POINTER(PhRollout)), ("n_seats", C.c_int),
+                ("seat", C.c_int), ("partner_seat", C.c_void_p), ("bonus", C.c_float)]
+
+
 class PhLiarSelfPlay(C.Structure):
     """ph_liar_selfplay: every device pointer of the vectorised Liar's Dice self-play step"""
     _fields_ = [("n", C.c_int), ("spec", C.POINTER(PhSpec)),
@@ -185,6 +198,7 @@ SIGNATURES = {
     "ph_p2p_ll_push": [_vp, C.POINTER(PhP2P), _vp, _i],
     "ph_p2p_ll_unpack": [_vp, C.POINTER(PhP2P), _i],
     "ph_selfplay_rollout_p2p": [_vp, _i, C.POINTER(PhStepCall), _i, _vp, C.POINTER(PhP2P)],
+    "ph_selfplay_rollout_persistent": [_vp, _i, C.POINTER(PhRolloutCall), _i, C.POINTER(PhP2P), _i],
     "ph_ppo_minibatch_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _vp, _i, _vp,
                               _vp, _i],
     "ph_adap_train": [_vp, C.POINTER(PhSpec), C.POINTER(PhOptState), C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i,
@@ -241,7 +255,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.argtypes = argtypes
         fn.restype = C.c_char_p if name in ("ph_last_error", "ph_agent_last_error") else C.c_int
-    if lib.ph_abi_version() != 2:
+    if lib.ph_abi_version() != 3:
         raise NativeError("libpantheon_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -562,12 +562,14 @@ int ph_scripted_rollout(ph_ctx* ctx, const ph_spec* spec, const float* params, c
   sc.obs_seq = obs_seq;
   sc.rew_seq = rew_seq;
   sc.done_seq = done_seq;
+  sc.mask_seq = nullptr;
   PH_HIP(ph::launch_policy_fwd16_rollout(a, sc, gemm_mode, ctx->stream));
   return 0;
 }
 
 namespace {
 int step_multi_impl(ph_ctx* ctx, int n_calls, const ph_step_call* calls, const ph_p2p* x, int t);
+int ensure_p2p_dev(ph_ctx* ctx, const ph_p2p* x);
 }
 int ph_policy_step_multi(ph_ctx* ctx, int n_calls, const ph_step_call* calls) {
   DevGuard dev_guard(ctx);
@@ -598,7 +600,14 @@ int step_multi_impl(ph_ctx* ctx, int n_calls, const ph_step_call* calls, const p
     a.seed = c.seed;
     a.counter = c.counter;
     a.epoch = ctx->rng_epoch;
-    a.deterministic = c.deterministic;
+    a.deterministic = c.deterministic & 1;
+    if (c.deterministic & (PH_STEP_FIX_ILLEGAL | PH_STEP_MASK_ENV_ONLY)) {
+      if (!c.action_mask) return fail("PH_STEP_FIX_ILLEGAL / PH_STEP_MASK_ENV_ONLY need an action mask");
+      if (!(a.nd.A == 1 && a.nd.L <= 8))
+        return fail("PH_STEP_FIX_ILLEGAL: single Discrete head of at most 8 logits only (use ph_fix_illegal_actions)");
+      a.env_mask = c.action_mask;
+      if (c.deterministic & PH_STEP_MASK_ENV_ONLY) a.mask = nullptr;   // the policy never sees the mask (plain PPO partner)
+    }
     a.act_i32 = c.actions_i32;
     a.values = c.values;
     a.logp = c.log_probs;
@@ -628,14 +637,7 @@ int step_multi_impl(ph_ctx* ctx, int n_calls, const ph_step_call* calls, const p
   if (x) {  // exchange fused into the launch (16-row kernel only; the caller checked eligibility)
     if (!ph::fwd16_eligible(m.a[0].nd, m.a[0].n)) return fail("fused peer-to-peer step needs the 16-row forward kernel");
     if (x->count != n_calls * m.a[0].n) return fail("ph_p2p.count must be local agents x n");
-    if (!ctx->p2p_dev) PH_HIP(hipMalloc((void**)&ctx->p2p_dev, sizeof(ph_p2p)));
-    if (!ctx->p2p_valid || std::memcmp(&ctx->p2p_host, x, sizeof(ph_p2p)) != 0) {
-      if (ctx->capturing) return fail("the peer-to-peer descriptor changed inside graph capture");
-      ctx->p2p_host = *x;
-      PH_HIP(hipMemcpyAsync(ctx->p2p_dev, &ctx->p2p_host, sizeof(ph_p2p), hipMemcpyHostToDevice, ctx->stream));
-      PH_HIP(hipStreamSynchronize(ctx->stream));
-      ctx->p2p_valid = true;
-    }
+    if (ensure_p2p_dev(ctx, x)) return 1;
     m.px.x = ctx->p2p_dev;
     m.px.t = t;
     m.px.a_local = n_calls;
@@ -862,6 +864,99 @@ int ph_selfplay_rollout_p2p(ph_ctx* ctx, int n_calls, const ph_step_call* calls,
     PH_HIP(ph::launch_p2p_push(*x, local, t, ctx->stream));
     PH_HIP(ph::launch_p2p_wait(*x, t, ctx->stream));
   }
+  return 0;
+}
+
+namespace {
+int ensure_p2p_dev(ph_ctx* ctx, const ph_p2p* x) {
+  if (!ctx->p2p_dev) PH_HIP(hipMalloc((void**)&ctx->p2p_dev, sizeof(ph_p2p)));
+  if (!ctx->p2p_valid || std::memcmp(&ctx->p2p_host, x, sizeof(ph_p2p)) != 0) {
+    if (ctx->capturing) return fail("the peer-to-peer descriptor changed inside graph capture");
+    ctx->p2p_host = *x;
+    PH_HIP(hipMemcpyAsync(ctx->p2p_dev, &ctx->p2p_host, sizeof(ph_p2p), hipMemcpyHostToDevice, ctx->stream));
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->p2p_valid = true;
+  }
+  return 0;
+}
+}  // namespace
+
+int ph_selfplay_rollout_persistent(ph_ctx* ctx, int n_calls, const ph_rollout_call* calls, int T, const ph_p2p* x,
+                                   int ranks_on_device) {
+  DevGuard dev_guard(ctx);
+  if (!ctx || !calls || T <= 0) return fail("ph_selfplay_rollout_persistent: bad argument");
+  if (n_calls <= 0 || n_calls > ph::MAX_LOCAL_AGENTS) return fail("ph_selfplay_rollout_persistent: 1..4 local agents");
+  if (check_p2p(x)) return 1;
+  if (x->T < T) return fail("ph_selfplay_rollout_persistent: ph_p2p.T must be >= the rollout length (stamps are epoch * x.T + t + 1)");
+  if (x->ll_slots < 2 * x->T) return fail("ph_selfplay_rollout_persistent: ph_p2p.ll_slots must be >= 2 * ph_p2p.T (two alternating halves)");
+  if (x->count != n_calls * calls[0].n) return fail("ph_p2p.count must be local agents x n");
+  if (ranks_on_device < 1) ranks_on_device = 1;
+  const long long wgs = (long long)n_calls * 2 * ((calls[0].n + 15) / 16) * ranks_on_device;
+  if (wgs > 2ll * ctx->num_cu)
+    return fail("ph_selfplay_rollout_persistent: the launch's workgroups would not all be resident (value workgroups poll): use "
+                "ph_selfplay_rollout_p2p");
+  ph::FwdMulti m;
+  ph::ScriptedMulti sm;
+  std::memset(&m, 0, sizeof(m));
+  std::memset(&sm, 0, sizeof(sm));
+  for (int i = 0; i < n_calls; ++i) {
+    const ph_rollout_call& c = calls[i];
+    ph::FwdArgs& a = m.a[i];
+    if (!c.params || !c.obs_seq || !c.rew_seq || !c.done_seq || !c.rb || !c.episode_start0 || !c.partner_seat)
+      return fail("ph_selfplay_rollout_persistent: null argument");
+    if ((uintptr_t)c.params % 16 != 0) return fail("ph_selfplay_rollout_persistent: params must be 16-byte aligned");
+    if (resolve(ctx, c.spec, &a.nd)) return 1;
+    if (!ph::fwd16_eligible(a.nd, c.n))
+      return fail("ph_selfplay_rollout_persistent: needs the 16-row forward's shape class (one feature chunk, one Discrete head "
+                  "of <= 8 logits, n < 16384)");
+    if (check_rb(c.rb)) return 1;
+    if (c.n != c.rb->E || c.n != calls[0].n) return fail("ph_selfplay_rollout_persistent: every call's n must equal its rollout E and agree");
+    if (c.rb->T < T) return fail("ph_selfplay_rollout_persistent: the rollout buffer has fewer than T rows");
+    if (c.n_seats <= 0 || c.seat < 0 || c.seat >= c.n_seats) return fail("ph_selfplay_rollout_persistent: bad seat description");
+    a.params = c.params;
+    a.obs = c.obs_seq;
+    a.n = c.n;
+    if (c.mask_mode < 0 || c.mask_mode > 3) return fail("ph_selfplay_rollout_persistent: mask_mode is 0..3");
+    sm.sc[i].mask_policy = (c.mask_seq && (c.mask_mode == 0 || c.mask_mode == 1)) ? 1 : 0;
+    sm.sc[i].mask_env = (c.mask_seq && (c.mask_mode == 1 || c.mask_mode == 2)) ? 1 : 0;
+    a.mask = sm.sc[i].mask_policy ? c.mask_seq : nullptr;
+    a.env_mask = sm.sc[i].mask_env ? c.mask_seq : nullptr;
+    a.seed = c.seed;
+    a.counter = c.counter0;
+    a.epoch = ctx->rng_epoch;
+    a.act_i32 = c.actions_i32;
+    a.values = c.values;
+    a.logp = c.log_probs;
+    a.rb_obs = c.rb->observations;
+    a.rb_act = c.rb->actions;
+    a.rb_rew = c.rb->rewards;
+    a.rb_es = c.rb->episode_starts;
+    a.rb_val = c.rb->values;
+    a.rb_logp = c.rb->log_probs;
+    a.es_in = c.episode_start0;
+    a.joint = x->joint[0][x->rank];      // non-null marks "the reward has a joint-action term"; the kernel reads the words
+    a.n_seats = c.n_seats;
+    a.seat = c.seat;
+    a.partner_seat = c.partner_seat;
+    a.bonus = c.bonus;
+    a.ll_epoch = x->epoch;
+    a.ll_T = x->T;
+    a.ll_timeout = x->timeout_cycles;
+    a.ll_error = x->error;
+    sm.sc[i].n_steps = T;
+    sm.sc[i].obs_seq = c.obs_seq;
+    sm.sc[i].rew_seq = c.rew_seq;
+    sm.sc[i].done_seq = c.done_seq;
+    sm.sc[i].mask_seq = c.mask_seq;
+  }
+  if (ensure_p2p_dev(ctx, x)) return 1;
+  m.px.x = ctx->p2p_dev;
+  m.px.t = 0;
+  m.px.a_local = n_calls;
+  m.px.persistent = 1;
+  PH_HIP(ph::launch_policy_fwd16_exchange_rollout(m, sm, n_calls, ctx->stream));
+  // the last step's words -> the plain receive slot (ordinary consumers, route verification); waits for every peer once
+  PH_HIP(ph::launch_p2p_ll_unpack(*x, T - 1, ctx->stream, -2));
   return 0;
 }
 

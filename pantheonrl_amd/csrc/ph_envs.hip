@@ -203,11 +203,13 @@ hipError_t launch_p2p_ll_push(const ph_p2p& x, const int* local, int t, hipStrea
 }
 
 // words of step t (stamp-in-band area) -> this rank's plain int32 receive slot of parity t & 1, for ordinary consumers
-__global__ __launch_bounds__(256) void p2p_ll_unpack_kernel(ph_p2p x, int t) {
+__global__ __launch_bounds__(256) void p2p_ll_unpack_kernel(ph_p2p x, int t, int slot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= x.world * x.count) return;
   const unsigned want = p2p_stamp32(*x.epoch, x.T, t);
-  const unsigned long long* word = x.ll[x.rank] + (size_t)(t % x.ll_slots) * x.world * x.count + i;
+  if (slot == -2) slot = p2p_persistent_slot(*x.epoch, x.T, t);   // the persistent rollout's slot of step t
+  else if (slot < 0) slot = t % x.ll_slots;
+  const unsigned long long* word = x.ll[x.rank] + (size_t)slot * x.world * x.count + i;
   const long long t0 = wall_clock64();
   unsigned long long v;
   while (true) {
@@ -221,9 +223,9 @@ __global__ __launch_bounds__(256) void p2p_ll_unpack_kernel(ph_p2p x, int t) {
   }
   x.joint[t & 1][x.rank][i] = (int)(unsigned)v;
 }
-hipError_t launch_p2p_ll_unpack(const ph_p2p& x, int t, hipStream_t s) {
+hipError_t launch_p2p_ll_unpack(const ph_p2p& x, int t, hipStream_t s, int slot) {
   const int n = x.world * x.count;
-  hipLaunchKernelGGL(p2p_ll_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, t);
+  hipLaunchKernelGGL(p2p_ll_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, t, slot);
   return hipGetLastError();
 }
 

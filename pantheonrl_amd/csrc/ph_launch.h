@@ -49,6 +49,11 @@ struct FwdArgs {
   int n_seats, seat;
   const int* partner_seat;      // device int
   float bonus;
+  const unsigned char* env_mask;  // (n, L) or null: act_i32 (what the environment / the exchange consumes) receives the
+                                  // ENV-side fix-up of an illegal sample -- the first legal index, pettingzoo.py:81-82 -- while
+                                  // the rollout buffer keeps the sampled action, as the reference's agent does.  Independent of
+                                  // `mask` (the policy-side logit offset of ModularPolicy): OnPolicyAgent hands a plain PPO
+                                  // policy obs.obs only (agents.py:162), so its samples are unmasked and the env repairs them
 };
 
 // T steps of the 16-row forward against a scripted environment inside one launch (policy_fwd16_rollout_kernel): the per-step
@@ -59,6 +64,8 @@ struct ScriptedSteps {
   const float* obs_seq;    // (T, n, D)
   const float* rew_seq;    // (T, n)
   const float* done_seq;   // (T, n)
+  const unsigned char* mask_seq;   // (T, n, L) action masks of every step, or null
+  int mask_policy, mask_env;       // which sides see them: FwdArgs.mask and / or FwdArgs.env_mask
 };
 
 constexpr int MAX_LOCAL_AGENTS = 4;
@@ -69,13 +76,27 @@ struct P2PStep {
                      // makes the compiler spill the whole argument block to scratch), or null
   int t;             // step index of this launch
   int a_local;       // local agents per rank (seat = rank * a_local + blockIdx.z)
+  int persistent;    // 1: the launch walks all T steps (policy_fwd16_exchange_rollout_kernel); word slot of step t is
+                     // p2p_persistent_slot(epoch, T, t)
 };
+// Word slot of step t in the persistent exchange rollout.  A launch's policy workgroups never wait, so they may finish all T
+// pushes while value workgroups of the same launch are still consuming early steps; the next iteration of a faster PEER must
+// then not overwrite words this rank has not read.  Iterations alternate between two halves of 2T slots: a peer can only
+// reach iteration k + 2 (the half iteration k used) after this rank pushed the last step of iteration k + 1, i.e. after this
+// rank's launch of iteration k has completed.
+__host__ __device__ inline int p2p_persistent_slot(unsigned long long epoch, int T, int t) { return (int)(epoch & 1ull) * T + t; }
 struct FwdMulti {
   FwdArgs a[MAX_LOCAL_AGENTS];
   P2PStep px;
 };
+struct ScriptedMulti {
+  ScriptedSteps sc[MAX_LOCAL_AGENTS];
+};
 bool fwd16_eligible(const NetDims& nd, int n);
 hipError_t launch_policy_fwd16_rollout(const FwdArgs& a, const ScriptedSteps& sc, int gemm_mode, hipStream_t s);
+// all T steps of every local agent of the symmetric agent-per-GPU layout in ONE launch, the per-step action hand-off done
+// in-kernel over the stamp-in-band words (m.px.persistent = 1)
+hipError_t launch_policy_fwd16_exchange_rollout(const FwdMulti& m, const ScriptedMulti& sm, int n_agents, hipStream_t s);
 
 struct GradArgs {
   NetDims nd;
@@ -259,7 +280,7 @@ hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, co
 // peer-to-peer action exchange (ph_envs.hip)
 hipError_t launch_p2p_push(const ph_p2p& x, const int* local, int t, hipStream_t s);
 hipError_t launch_p2p_wait(const ph_p2p& x, int t, hipStream_t s);
-hipError_t launch_p2p_ll_unpack(const ph_p2p& x, int t, hipStream_t s);
+hipError_t launch_p2p_ll_unpack(const ph_p2p& x, int t, hipStream_t s, int slot = -1 /* default: t mod ll_slots */);
 hipError_t launch_p2p_ll_push(const ph_p2p& x, const int* local, int t, hipStream_t s);
 // single-chunk / small-Discrete-head kernel (ph_ppo_fast.hip); eligible() says whether the spec fits it.  Its slabs are in
 // the MFMA accumulators' register order -- [net][RS_NET] floats per workgroup (16-byte stores, 1 KB contiguous per wave

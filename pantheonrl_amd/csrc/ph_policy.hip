@@ -144,7 +144,16 @@ __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDim
     zact = (k == act) ? zr[k] : zact;
   }
   const float logp = zact - lse;
-  if (a.act_i32) a.act_i32[g] = act;
+  // What the ENVIRONMENT consumes: with fix_illegal an illegal sample becomes the first legal index (pettingzoo.py:81-82 does
+  // this inside the env, before base_env.step); the agent is not told, so its buffer row and log-prob keep the sampled action.
+  int env_act = act;
+  if (a.env_mask && a.env_mask[(size_t)g * nk + act] == 0) {
+    env_act = 0;
+#pragma unroll
+    for (int k = 7; k >= 0; --k)
+      if (k < nk && a.env_mask[(size_t)g * nk + k] != 0) env_act = k;
+  }
+  if (a.act_i32) a.act_i32[g] = env_act;
   if (a.act_f32) a.act_f32[g] = (float)act;
   if (a.logp) a.logp[g] = logp;
   if (a.entropy) a.entropy[g] = ent;
@@ -155,7 +164,7 @@ __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDim
       if (a.rb_logp) a.rb_logp[ridx] = logp;
     }
   }
-  return act;
+  return env_act;
 }
 
 // General action head of one row, one lane per row, the row's logits z[0..L) in LDS (modified in place): optional mask
@@ -374,9 +383,12 @@ __device__ __forceinline__ float quad_sum_f(float v) {
 
 // sc != nullptr: the scripted rollout -- the weights are staged once and the step below runs sc->n_steps times, each time on
 // the next rows of the observation / reward / done sequences and of the rollout buffer (see ScriptedSteps)
+// px_persistent (with px and sc): the exchange rollout -- step t pushes its actions as stamp-in-band words of step t and the
+// value workgroups consume the words of step t - 1 (t >= 1), all inside the loop; the last step's reward, which the
+// launch-by-launch walk credits after the rollout from the unpacked joint action, is credited at the end of the loop.
 template <bool VALU>
 __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2p* px = nullptr, int px_t = 0, int px_a_local = 0,
-                                                  int agent = 0, const ScriptedSteps* sc = nullptr) {
+                                                  int agent = 0, const ScriptedSteps* sc = nullptr, int px_persistent = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16, NT = 256;
   const NetDims& nd = a0.nd;
@@ -453,6 +465,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
     a.epoch = nullptr;
     a.counter = a0.counter + epoch_hi;
   }
+  const unsigned long long px_epoch = (px && px_persistent) ? *px->epoch : 0ull;   // constant for the launch as well
   for (int t = 0; t < n_steps; ++t) {
   if (t > 0) {   // (scripted rollout) the next step's argument record and observation rows; the weights stay where they are
     const size_t row = (size_t)t * a0.n;
@@ -467,6 +480,13 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
     a.es_in = sc->done_seq + (row - a0.n);          // Agent.update(reward, done) of the previous step:
     a.pending_reward = sc->rew_seq + (row - a0.n);  //   last_episode_starts = done, rewards[pos - 1] += reward
     a.prev_rew = a0.rb_rew + (row - a0.n);
+    a.mask = (sc->mask_seq && sc->mask_policy) ? sc->mask_seq + row * nd.L : nullptr;
+    a.env_mask = (sc->mask_seq && sc->mask_env) ? sc->mask_seq + row * nd.L : nullptr;
+    if (px_persistent && a0.joint) {   // the joint action of step t - 1 as stamp-in-band words (value_row_tail polls them)
+      a.joint = a0.joint;
+      a.joint_ll = px->ll[px->rank] + (size_t)p2p_persistent_slot(px_epoch, px->T, t - 1) * px->world * px->count;
+      a.ll_t = t - 1;
+    }
     a.prof = nullptr;
     lds_only_barrier();   // the previous step's head is done with xs (H2)
     xr.issue(rowphys, a.obs, nd, 0);
@@ -538,9 +558,11 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
       if (q == 0 && grow < a.n) {
         const int act = discrete8_row_tail(a, nd, grow, z, fwd_counter(a));
         if (px) {  // push: (stamp << 32 | action) as one 8-byte store into every rank's receive area, slot t mod ll_slots
-          const size_t off = (size_t)(px_t % px->ll_slots) * px->world * px->count + (size_t)(px->rank * px_a_local + agent) * a.n + grow;
+          const int pt = px_t + t;
+          const int slot = px_persistent ? p2p_persistent_slot(px_epoch, px->T, pt) : pt % px->ll_slots;
+          const size_t off = (size_t)slot * px->world * px->count + (size_t)(px->rank * px_a_local + agent) * a.n + grow;
           const unsigned long long w =
-              ((unsigned long long)p2p_stamp32(*px->epoch, px->T, px_t) << 32) | (unsigned long long)(unsigned)act;
+              ((unsigned long long)p2p_stamp32(px_persistent ? px_epoch : *px->epoch, px->T, pt) << 32) | (unsigned long long)(unsigned)act;
           for (int p = 0; p < px->world; ++p)
             __hip_atomic_store(px->ll[p] + off, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -553,7 +575,20 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
       if (q == 0 && grow < a.n) {
         value_row_tail(a, grow, v);
         // (scripted rollout) the last step's own reward: the flush that precedes GAE on the launch-by-launch path
-        if (sc && t == n_steps - 1) a.rb_rew[grow] += sc->rew_seq[(size_t)t * a0.n + grow];
+        if (sc && t == n_steps - 1) {
+          float add = sc->rew_seq[(size_t)t * a0.n + grow];
+          if (px_persistent && a0.joint) {   // ph_buffer_add_reward_joint of the launch-by-launch walk: base + bonus * [own == partner's]
+            FwdArgs b = a;
+            b.joint_ll = px->ll[px->rank] + (size_t)p2p_persistent_slot(px_epoch, px->T, t) * px->world * px->count;
+            b.ll_t = t;
+            int p = *a0.partner_seat;
+            p = p < 0 ? 0 : (p >= a0.n_seats ? a0.n_seats - 1 : p);
+            const int mine = ll_read(b, b.joint_ll + (size_t)a0.seat * a0.n + grow);
+            const int theirs = ll_read(b, b.joint_ll + (size_t)p * a0.n + grow);
+            add += (mine == theirs) ? a0.bonus : 0.f;
+          }
+          a.rb_rew[grow] += add;
+        }
       }
     }
   }
@@ -572,6 +607,14 @@ __global__ __launch_bounds__(256) void policy_fwd16_rollout_kernel(FwdArgs a, Sc
 }
 __global__ __launch_bounds__(256) void policy_fwd16_multi_kernel(FwdMulti m) {
   policy_fwd16_body<false>(m.a[blockIdx.z], m.px.x, m.px.t, m.px.a_local, blockIdx.z);
+}
+// The N > 1 counterpart of policy_fwd16_rollout_kernel: every local agent's T steps in one launch, with what crosses ranks at
+// every SimultaneousEnv step (multiagentenv.py:149-170: each seat's action to everyone who needs it) done in-kernel -- the
+// policy workgroup of 16 environments stores each sampled action as one stamped 8-byte word into every rank's receive area and
+// the value workgroup of the NEXT step polls exactly the two words it consumes.  Policy workgroups never wait, so no cycle of
+// waits exists as long as every workgroup of the launch is resident (the launcher's caller checks the grid against the chip).
+__global__ __launch_bounds__(256) void policy_fwd16_exchange_rollout_kernel(FwdMulti m, ScriptedMulti sm) {
+  policy_fwd16_body<false>(m.a[blockIdx.z], m.px.x, 0, m.px.a_local, blockIdx.z, &sm.sc[blockIdx.z], 1);
 }
 
 // index of the current device into the per-device "LDS opt-in done" tables of the launchers below
@@ -612,6 +655,12 @@ hipError_t launch_policy_fwd16_rollout(const FwdArgs& a, const ScriptedSteps& sc
   dim3 grid((a.n + 15) / 16, 2), block(256);
   if (gemm_mode != 0) hipLaunchKernelGGL((policy_fwd16_rollout_kernel<true>), grid, block, lds, s, a, sc);
   else hipLaunchKernelGGL((policy_fwd16_rollout_kernel<false>), grid, block, lds, s, a, sc);
+  return hipGetLastError();
+}
+
+hipError_t launch_policy_fwd16_exchange_rollout(const FwdMulti& m, const ScriptedMulti& sm, int n_agents, hipStream_t s) {
+  hipLaunchKernelGGL(policy_fwd16_exchange_rollout_kernel, dim3((m.a[0].n + 15) / 16, 2, n_agents), dim3(256), fwd16_lds_bytes(),
+                     s, m, sm);
   return hipGetLastError();
 }
 

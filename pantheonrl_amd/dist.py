@@ -73,7 +73,8 @@ class ActionExchange:
             # stamp-in-band words of the fused route: one slot per step of an iteration.  A rank only waits for its partner's
             # rank, so it may run up to world-1 steps ahead of another one; a slot must not be reused inside an iteration
             ll_slot = self.world * count * 8
-            ll_slots = max(int(n_steps), 4)
+            # (the persistent exchange rollout alternates between two halves of 2 T slots, ph_selfplay_rollout_persistent)
+            ll_slots = max(2 * int(n_steps), 4)
             ll_base = 2 * slot + self.world * 8 + 64
             nbytes = ll_base + ll_slots * ll_slot
             base, handle = C.c_void_p(), (C.c_ubyte * 64)()
@@ -132,8 +133,10 @@ class ActionExchange:
         log = {}
         if self.local.is_cuda:
             ctx.set_stream(th.cuda.current_stream(self.local.device).cuda_stream)
+        self.ranks_on_device = self._ranks_on_device()
         if route == "auto":
-            route = "rccl" if self.world == 1 else "measure"
+            # one rank: the peer-to-peer words mapped onto this rank itself -- what the one-launch exchange rollout runs on
+            route = "p2p" if (self.world == 1 and self.local.is_cuda) else ("rccl" if self.world == 1 else "measure")
         if route in ("rccl", "measure") and self.native_ctx is None:
             attached = self._everyone(self.attach_native(ctx)) if self.world > 1 else self.attach_native(ctx)
             verified = False
@@ -211,6 +214,20 @@ class ActionExchange:
                 route = "rccl" if (self.native_ctx is not None or self._everyone(self.attach_native(ctx))) else "torch"
         self.route, self.route_log = route, log
         return route
+
+    def _ranks_on_device(self) -> int:
+        """how many ranks of the group run on this rank's GPU (1 on a real multi-GPU node; > 1 when ranks time-slice one
+        device, as the one-GPU test boxes do) -- the persistent rollout's residency bound needs it"""
+        if self.world == 1 or not self.local.is_cuda:
+            return 1
+        try:
+            props = th.cuda.get_device_properties(self.local.device)
+            me = f"{os.uname().nodename}:{getattr(props, 'uuid', self.local.device.index)}"
+            ids = [None] * self.world
+            dist.all_gather_object(ids, me, group=self.group)
+            return max(1, sum(1 for v in ids if v == me))
+        except Exception:  # noqa: BLE001
+            return self.world
 
     def _torch_gather(self) -> th.Tensor:
         """all-gather of `self.local` through torch.distributed alone (the route of last resort and the yardstick the native

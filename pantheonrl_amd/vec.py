@@ -303,8 +303,16 @@ class FusedSelfPlayRollout:
     records are prebuilt (pointers into the HBM-resident synthetic inputs), so the host does two calls per step; GAE +
     PPO update of the local agents then run concurrently on separate streams."""
 
-    def __init__(self, agents, datas, exchange, stream: th.cuda.Stream, bonus: float = 0.01, update_graphs: bool = True):
+    def __init__(self, agents, datas, exchange, stream: th.cuda.Stream, bonus: float = 0.01, update_graphs: bool = True,
+                 masks=None, mask_mode: int = 2, persistent: Optional[bool] = None):
+        """masks[i]: (T, E, L) uint8 action masks of local agent i's steps (SURVEY.md 8d, config 5 variant) or None.
+        mask_mode 2 (default) is the reference's plain PPO partner: the policy never sees the mask (agents.py:162 hands it
+        obs.obs), the environment replaces an illegal sample by the first legal index (pettingzoo.py:81-82) and the buffer row
+        keeps the sample; 1 = ModularPolicy's logit offset (policies.py:330-333) plus that fix-up; 0 = the offset only.
+        persistent: None = use the one-launch exchange rollout (ph_selfplay_rollout_persistent) whenever the peer-to-peer
+        route is up and the launch fits the chip."""
         self.agents, self.datas, self.exchange, self.stream, self.bonus = agents, datas, exchange, stream, bonus
+        self.masks, self.mask_mode, self.want_persistent = masks, int(mask_mode), persistent
         self.update_graphs, self._update_gid, self._iterations_run = update_graphs, None, 0
         dev = agents[0].model.policy.device
         n = len(agents)
@@ -338,7 +346,10 @@ class FusedSelfPlayRollout:
             for i, (a, d) in enumerate(zip(agents, datas)):
                 pol, rb, c = a.model.policy, a.model.rollout_buffer, arr[i]
                 c.spec, c.params, c.obs, c.n = C.pointer(pol.spec), pol.params.data_ptr(), d.obs[t].data_ptr(), a.E
-                c.action_mask, c.seed, c.counter, c.deterministic = None, pol._seed, t + 1, 0
+                c.action_mask = None if self.masks is None or self.masks[i] is None else self.masks[i][t].data_ptr()
+                c.seed, c.counter = pol._seed, t + 1
+                c.deterministic = 0 if not c.action_mask else (
+                    0, nat.PH_STEP_FIX_ILLEGAL, nat.PH_STEP_FIX_ILLEGAL | nat.PH_STEP_MASK_ENV_ONLY)[self.mask_mode]
                 c.actions_i32, c.values, c.log_probs = a.actions.data_ptr(), a.values.data_ptr(), a.log_probs.data_ptr()
                 c.rb, c.pos = C.pointer(rb.c_struct()), t
                 c.episode_start_in = (self.first_start if t == 0 else d.dones[t - 1]).data_ptr()
@@ -346,6 +357,34 @@ class FusedSelfPlayRollout:
                     c.pending_reward, c.joint_actions = d.rewards[t - 1].data_ptr(), exchange.joint_slot(t - 1).data_ptr()
                     c.n_seats, c.seat, c.partner_seat, c.bonus = exchange.n_seats, exchange.seat(i), self.partner[i].data_ptr(), bonus
             self.calls.append(arr)
+        # the same rollout as ONE launch (ph_selfplay_rollout_persistent): one record per local agent
+        self._roll_calls = (nat.PhRolloutCall * n)()
+        for i, (a, d) in enumerate(zip(agents, datas)):
+            pol, rb, c = a.model.policy, a.model.rollout_buffer, self._roll_calls[i]
+            c.spec, c.params, c.n = C.pointer(pol.spec), pol.params.data_ptr(), a.E
+            c.obs_seq, c.rew_seq, c.done_seq = d.obs.data_ptr(), d.rewards.data_ptr(), d.dones.data_ptr()
+            c.mask_seq = None if self.masks is None or self.masks[i] is None else self.masks[i].data_ptr()
+            c.episode_start0, c.seed, c.counter0 = self.first_start.data_ptr(), pol._seed, 1
+            c.mask_mode = self.mask_mode
+            c.actions_i32, c.values, c.log_probs = a.actions.data_ptr(), a.values.data_ptr(), a.log_probs.data_ptr()
+            c.rb = C.pointer(rb.c_struct())
+            c.n_seats, c.seat, c.partner_seat, c.bonus = exchange.n_seats, exchange.seat(i), self.partner[i].data_ptr(), bonus
+
+    def persistent_ok(self) -> bool:
+        """can this iteration's rollout run as the one-launch exchange rollout?  Needs the peer-to-peer words, the 16-row
+        forward's shapes, 2 T word slots, and every workgroup of the launch resident at once (value workgroups poll)."""
+        import os
+        ex = self.exchange
+        if self.want_persistent is False or os.environ.get("PH_EXCHANGE_PERSISTENT", "1") == "0" or ex.p2p is None:
+            return False
+        lay = self.agents[0].model.policy.layout
+        E = self.agents[0].E
+        if not (lay.F <= 64 and lay.A == 1 and lay.L <= 8 and E < 16384):
+            return False
+        if ex.p2p.T < self.T or ex.p2p.ll_slots < 2 * ex.p2p.T:
+            return False
+        n_cu = th.cuda.get_device_properties(self.agents[0].model.policy.device).multi_processor_count
+        return len(self.agents) * 2 * ((E + 15) // 16) * max(getattr(ex, "ranks_on_device", 1), 1) <= 2 * n_cu
 
     def set_pairing(self, pairing_round: int) -> None:
         ex = self.exchange
@@ -357,7 +396,13 @@ class FusedSelfPlayRollout:
         self.set_pairing(pairing_round)
         agents, lib, h, ex, T = self.agents, self._lib, self._h, self.exchange, self.T
         agents[0].bind_stream()
-        if ex.p2p is not None:
+        one_launch = self.persistent_ok()
+        self.last_rollout_mode = "persistent" if one_launch else ("p2p" if ex.p2p is not None else "stepwise")
+        if one_launch:
+            # all T steps of every local agent in ONE launch, the per-step action hand-off done in-kernel over the stamp words
+            nat.check(lib.ph_selfplay_rollout_persistent(h, len(agents), self._roll_calls, T, C.byref(ex.p2p),
+                                                         int(max(getattr(ex, "ranks_on_device", 1), 1))))
+        elif ex.p2p is not None:
             # peer-to-peer stores over xGMI: T x (fused launch, push, wait) enqueued by one native call
             nat.check(lib.ph_selfplay_rollout_p2p(h, len(agents), self._all_calls, T, ex.local.data_ptr(), C.byref(ex.p2p)))
         elif ex.native_ctx is not None and ex.native_ctx.handle.value == h.value:
@@ -384,7 +429,10 @@ class FusedSelfPlayRollout:
             a.bind_stream()
             a.model.rollout_buffer.pos = T
             a._last_episode_starts = d.dones[T - 1]
-            a.update_joint(d.rewards[T - 1], d.dones[T - 1], ex.joint_slot(T - 1), ex.seat(i), self.partner[i], self.bonus)
+            if one_launch:
+                a._pending = None       # the one-launch rollout credited the last step's reward itself
+            else:
+                a.update_joint(d.rewards[T - 1], d.dones[T - 1], ex.joint_slot(T - 1), ex.seat(i), self.partner[i], self.bonus)
         # GAE + PPO update: local learners are independent -> concurrent on forked streams; each learner's 1 + 1 + 3*40
         # launches are replayed from a hipGraph captured on its stream at the second iteration (no collective inside)
         main = th.cuda.current_stream()

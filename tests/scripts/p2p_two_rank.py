@@ -52,30 +52,41 @@ for i in range(A_LOCAL):
     m = PPO("MlpPolicy", env, n_steps=T2, n_envs=E2, batch_size=E2 * T2 // 2, n_epochs=1, seed=seed)
     agents.append(VecOnPolicyAgent(m))
     datas.append(SyntheticRollouts(obs_space, E2, T2, 400, seed, m.device))
-ex2 = pdist.ActionExchange(A_LOCAL, E2, device)
-ex2.requested_route = "p2p"
-with th.cuda.stream(stream):
-    roll = FusedSelfPlayRollout(agents, datas, ex2, stream, bonus=BONUS, update_graphs=False)
-    assert ex2.route == "p2p", ex2.route
-    for it in range(2):
-        dist.barrier()
-        roll.run_iteration(it)
-        stream.synchronize()
-        # every rank's actions of this iteration, via the rendezvous group, to rebuild the expected rewards on the host
-        mine = th.stack([a.model.rollout_buffer.actions[..., 0].cpu() for a in agents])          # (A_LOCAL, T, E)
-        everyone = [th.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(everyone, mine)
-        seats = th.cat(everyone).numpy()                                                          # (n_seats, T, E)
-        for i, (a, d) in enumerate(zip(agents, datas)):
-            seat = ex2.seat(i)
-            partner = ex2.partner_of(seat, it)
-            expect = d.rewards.cpu().numpy() + BONUS * (seats[seat] == seats[partner])
-            got = a.model.rollout_buffer.rewards.cpu().numpy()
-            bad = got != expect.astype(np.float32)
-            assert not bad.any(), (rank, it, i, "mismatching rows per step", bad.sum(1).tolist(), "timeouts", ex2.p2p_timeouts())
-assert ex2.p2p_timeouts() == 0, ex2.p2p_timeouts()
-assert roll.route_checked and ex2.route == "p2p"       # the post-iteration verification ran and kept the route
-dist.barrier()
+def rewards_as_the_joint_actions_imply(roll_, ex_, it):
+    """every rank's actions of this iteration, via the rendezvous group, to rebuild the expected rewards on the host"""
+    mine = th.stack([a.model.rollout_buffer.actions[..., 0].cpu() for a in agents])          # (A_LOCAL, T, E)
+    everyone = [th.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    seats = th.cat(everyone).numpy()                                                          # (n_seats, T, E)
+    for i, (a, d) in enumerate(zip(agents, datas)):
+        seat = ex_.seat(i)
+        partner = ex_.partner_of(seat, it)
+        expect = d.rewards.cpu().numpy() + BONUS * (seats[seat] == seats[partner])
+        got = a.model.rollout_buffer.rewards.cpu().numpy()
+        bad = got != expect.astype(np.float32)
+        assert not bad.any(), (rank, it, i, roll_.last_rollout_mode, "mismatching rows per step", bad.sum(1).tolist(),
+                               "timeouts", ex_.p2p_timeouts())
+
+
+# launch per step (push / stamp / wait inside every step launch), then the whole rollout as ONE launch per rank with the
+# hand-off in-kernel (ph_selfplay_rollout_persistent): the ranks' persistent launches run side by side on the shared GPU and
+# wait for each other's words step by step; four iterations so that both halves of the word slots are reused
+for persistent, n_it in ((False, 2), (None, 4)):
+    ex2 = pdist.ActionExchange(A_LOCAL, E2, device)
+    ex2.requested_route = "p2p"
+    with th.cuda.stream(stream):
+        roll = FusedSelfPlayRollout(agents, datas, ex2, stream, bonus=BONUS, update_graphs=False, persistent=persistent)
+        assert ex2.route == "p2p", ex2.route
+        assert ex2.ranks_on_device == (world if th.cuda.device_count() == 1 else ex2.ranks_on_device)
+        for it in range(n_it):
+            dist.barrier()
+            roll.run_iteration(it)
+            stream.synchronize()
+            assert roll.last_rollout_mode == ("p2p" if persistent is False else "persistent"), roll.last_rollout_mode
+            rewards_as_the_joint_actions_imply(roll, ex2, it)
+    assert ex2.p2p_timeouts() == 0, ex2.p2p_timeouts()
+    assert roll.route_checked and ex2.route == "p2p"       # the post-iteration verification ran and kept the route
+    dist.barrier()
 
 # ---- phase 3: a route that fails its verification after the first real iteration is dropped on every rank, and the run goes on
 ex3 = pdist.ActionExchange(A_LOCAL, E2, device)

@@ -99,3 +99,36 @@ def test_bench_config5_shape_one_agent_per_rank_four_ranks():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 4 and d["ranks_seen"] == 4 and d["config"]["agents_per_gpu"] == 1 and d["config"]["obs_dim"] == 48
     assert "= 4 learners" in d["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("n_envs,rollout", [("96", "persistent"), ("1024", "p2p")])
+def test_bench_config5_as_written_eight_ranks_one_learner_each_with_action_masks(n_envs, rollout):
+    """BASELINE config 5 as specified: PettingZoo MPE simple_spread N = 8 shapes, EIGHT learners, one per rank (here the eight
+    ranks time-slice the box's one GPU; the rendezvous is gloo, the per-step action hand-off goes through the IPC-mapped
+    peer-to-peer words), with SURVEY.md 8(d)'s action-mask variant: Bernoulli(0.8) masks, the policy does not see them (plain
+    PPO partner, agents.py:162), the environment repairs an illegal sample with the first legal index (pettingzoo.py:81-82).
+    At 96 environments the eight ranks' one-launch rollouts are resident together (in-kernel hand-off); at the config's 1024
+    they would not be, and every rank falls back to one launch per step."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PANTHEON_EXCHANGE"] = "p2p"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "mpe8", "--agents-per-gpu", "1",
+                        "--n-envs", n_envs, "--n-steps", "16", "--n-epochs", "2", "--steps", "2", "--warmup", "1",
+                        "--action-masks", "env", "--backend", "gloo", "--no-roofline"], capture_output=True, text=True,
+                       timeout=1200, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["config"]["agents_per_gpu"] == 1 and d["config"]["obs_dim"] == 48
+    assert "= 8 learners" in d["config"]["parallelism"] and d["config"]["action_masks"] == "env"
+    assert d["config"]["exchange"]["route"] == "p2p" and d["config"]["exchange"]["p2p_timeouts"] == 0
+    assert d["config"]["rollout"] == rollout
+
+
+def test_bench_fusedstep_on_one_gpu_runs_the_one_launch_exchange_rollout():
+    """`--mode fusedstep` at N = 1: the symmetric exchange layout with the peer-to-peer words mapped onto the rank itself; the
+    rollout of both learners is ONE launch (rollout = persistent) like the N = 1 default's scripted rollout"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--mode", "fusedstep", "--no-roofline",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["config"]["launch_mode"] == "fusedstep" and d["config"]["rollout"] == "persistent"
+    assert d["config"]["exchange"]["route"] == "p2p" and d["config"]["exchange"]["p2p_timeouts"] == 0

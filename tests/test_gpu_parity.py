@@ -1203,6 +1203,82 @@ def test_peer_to_peer_exchange_single_rank_matches_the_copy_route():
         assert np.array_equal(x, y)
 
 
+def _synthetic_masks(T, E, L, seed, device):
+    """SURVEY.md 8(d), config 5 variant: action masks Bernoulli(0.8) with at least one legal action forced"""
+    rng = np.random.default_rng(seed)
+    m = (rng.random((T, E, L)) < 0.8).astype(np.uint8)
+    dead = m.sum(-1) == 0
+    m[dead, rng.integers(0, L, size=int(dead.sum()))] = 1
+    return th.as_tensor(m).to(device)
+
+
+@pytest.mark.parametrize("E,T,n_agents,mask_mode", [(64, 8, 2, None), (40, 5, 2, None), (64, 8, 1, None), (96, 6, 2, 2),
+                                                     (96, 6, 2, 1), (1024, 128, 2, None)])
+def test_persistent_exchange_rollout_is_bitwise_the_per_step_walk(E, T, n_agents, mask_mode):
+    """ph_selfplay_rollout_persistent (all T steps of every local agent in ONE launch, the per-step action hand-off done
+    in-kernel over the stamp-in-band words) against ph_selfplay_rollout_p2p (one launch per step) + the last step's
+    ph_buffer_add_reward_joint: every array of both rollout buffers after each of three iterations (the word slots alternate
+    between two halves; the pairing changes), the trained parameters, the unpacked last joint action; no poll timed out.
+    mask_mode: the config-5 variant -- Bernoulli(0.8) action masks; 2 = the reference's plain PPO partner (the
+    policy never sees the mask, the environment repairs an illegal sample with the first legal index, pettingzoo.py:81-82,
+    and the buffer keeps the sample), 1 = ModularPolicy's logit offset as well.  The repaired actions are checked against
+    numpy bit for bit, and every one of them is legal."""
+    from pantheonrl_amd import PPO, spaces as sp
+    from pantheonrl_amd import dist as pdist
+    from pantheonrl_amd.vec import FusedSelfPlayRollout, SyntheticRollouts, VecOnPolicyAgent
+    masked = mask_mode is not None
+    obs_space, act_space = sp.Box(-np.inf, np.inf, (48 if masked else 62,)), sp.Discrete(5 if masked else 6)
+    env = type("S", (), dict(observation_space=obs_space, action_space=act_space, _is_dummy_space_env=True))()
+
+    def run(persistent):
+        agents, datas, masks = [], [], []
+        for seed in range(5, 5 + n_agents):
+            m = PPO("MlpPolicy", env, n_steps=T, n_envs=E, batch_size=E * T // 2, n_epochs=2, seed=seed)
+            agents.append(VecOnPolicyAgent(m))
+            datas.append(SyntheticRollouts(obs_space, E, T, 25, seed, m.device))
+            masks.append(_synthetic_masks(T, E, act_space.n, seed, m.device) if masked else None)
+        ex = pdist.ActionExchange(len(agents), E, agents[0].model.device)
+        ex.want_p2p = True
+        stream = th.cuda.Stream()
+        snaps = []
+        with th.cuda.stream(stream):
+            steps = FusedSelfPlayRollout(agents, datas, ex, stream, masks=masks if masked else None,
+                                         mask_mode=mask_mode if masked else 2, persistent=persistent)
+            assert ex.p2p is not None
+            for it in range(3):
+                steps.run_iteration(it)
+                assert steps.last_rollout_mode == ("persistent" if persistent else "p2p")
+                th.cuda.synchronize()
+                snaps.append({"joint": ex.joint_slot(T - 1).cpu().numpy().copy(), "local": ex.local.cpu().numpy().copy(),
+                              **{f"rb{i}_{k}": v.copy() for i, a in enumerate(agents)
+                                 for k, v in a.model.rollout_buffer.host().items()}})
+        assert ex.p2p_timeouts() == 0
+        return snaps, [a.model.policy.get_flat_params() for a in agents], masks
+
+    walk, w_params, masks = run(False)
+    one, o_params, _ = run(True)
+    for x, y in zip(walk, one):
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k
+    for x, y in zip(w_params, o_params):
+        assert np.array_equal(x, y)
+    if masked:
+        last = one[-1]
+        n_illegal = 0
+        for i in range(n_agents):
+            raw = last[f"rb{i}_actions"][..., 0].astype(np.int64)       # (T, E) sampled actions as the agent recorded them
+            mk = masks[i].cpu().numpy()
+            legal = np.take_along_axis(mk, raw[..., None], axis=-1)[..., 0] != 0
+            n_illegal += int((~legal).sum())
+            fixed = np.where(legal, raw, mk.argmax(-1))                 # first legal index where the sample is illegal
+            env_last = last["local"][i]                                 # what the environment / the exchange got at step T-1
+            assert np.array_equal(env_last, fixed[T - 1])
+            assert (np.take_along_axis(mk[T - 1], env_last[:, None].astype(np.int64), axis=-1) != 0).all()
+            assert np.array_equal(last["joint"][i], env_last)           # single rank: seat i of the joint action
+        # an unmasked policy (mode 2) samples illegal actions about one time in five; with the -30 offset (mode 1) never
+        assert (n_illegal > T * E * n_agents // 20) if mask_mode == 2 else (n_illegal == 0)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_peer_to_peer_exchange_between_processes(world):
     """ranks (sharing this GPU) map each other's receive areas through HIP IPC and exchange 3 x 8 steps, then drive the fused
