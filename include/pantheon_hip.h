@@ -35,11 +35,12 @@ extern "C" {
 
 #define PH_ABI_VERSION 3   /* 2: + ph_agent_*, ph_bc_*, ph_adap_*, ph_scripted_rollout, ph_liar_selfplay_rollout, ph_roundrobin_env_step,
                                   ph_buffer_compact_columns (additions only: every v1 signature is unchanged)
-                              3: + ph_selfplay_rollout_persistent, PH_STEP_FIX_ILLEGAL (additions only) */
+                              3: + ph_selfplay_rollout_persistent, PH_STEP_FIX_ILLEGAL / _MASK_ENV_ONLY, ph_modular_* (additions only) */
 #define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
 #define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
 #define PH_MAX_LOGITS 64 /* max total policy logits L */
 #define PH_NSTAT 8       /* per-minibatch stats record, see ph_ppo_train */
+#define PH_MOD_MAX 8     /* max partner modules of a ModularPolicy (ph_modular_*) */
 
 #define PH_SPACE_BOX 0      /* gym.spaces.Box, flattened length n                        */
 #define PH_SPACE_DISCRETE 1 /* Discrete(k) (n=1, nvec={k}) or MultiDiscrete(nvec) (n=len) */
@@ -544,6 +545,49 @@ int ph_bench_gae(ph_ctx *ctx, const ph_rollout *rb, const float *last_values, co
  * out[i] = perm_epoch(start + i) for i < count (env-major indices in [0, n)).  Pure CPU, needs no device;
  * the kernels run the identical integer code, so this is the bit-exact statement of the minibatch order. */
 int ph_feistel_indices(int n, unsigned long long perm_seed, int epoch, int start, int count, int *out /* host */);
+
+/* ---- ModularAlgorithm / ModularPolicy (pantheonrl/algos/modular) -----------------------------------------
+ * ModularPolicy (modular/policies.py:243-395): the ordinary MlpPolicy ("main") plus one module per partner -- a 64-64 policy
+ * tower and a 64-64 value tower that BOTH read the main policy latent (policies.py:254,281), an action head and a value head.
+ * Logits = main + partner logits (the partner's alone with `nomain`, policies.py:325-328), value = main + partner value
+ * (policies.py:286).  `baseline` shares one module between all partners (policies.py:255-257).
+ * Parameter vector: the main network in ph_layout order (P_main floats), then module m at P_main + m * P_module in the ph_layout
+ * order of a (Box(64), same action space) network.  Single Discrete head of <= 8 logits, <= 64 features.
+ *   ph_modular_layout  : both layouts and the total length.
+ *   ph_modular_forward : ModularPolicy.forward / evaluate_actions / get_action_logits_from_obs for partner `partner_idx`
+ *       (policies.py:271-288,364-395): arguments as ph_policy_forward, plus the two logit vectors the marginal regulariser reads.
+ *   ph_modular_train   : ModularAlgorithm.train (modular/learn.py:221-351): partner by partner over that partner's rollout buffer
+ *       (rbs[k], learn.py:134-144), n_epochs passes each; every minibatch is the PPO loss on the composed heads with ALWAYS
+ *       normalised advantages (learn.py:260-261) + marginal_reg_coef * marginal regularisation loss (learn.py:298-318), one
+ *       clip_grad_norm_ over the main network and every module, one Adam step (torch's per-parameter step counts: mod_first);
+ *       the target-KL test runs after a whole epoch on the mean of its KLs (learn.py:320-334) and ends that partner's epochs.
+ *       stats: (num_partners * n_epochs * n_minibatches, PH_NSTAT) = policy_loss, value_loss, entropy_loss, clip_fraction,
+ *       approx_kl (mean(old_log_prob - log_prob), learn.py:327), loss, grad_norm, marginal_reg; rows of skipped minibatches 0.
+ *   ph_modular_minibatch_grad : the gradient of one minibatch's loss w.r.t. every parameter (tests). */
+typedef struct ph_modular {
+  int num_partners;
+  int n_modules;               /* distinct modules: num_partners, or 1 with `baseline` */
+  int module_of[PH_MOD_MAX];   /* partner -> module */
+  int nomain;
+} ph_modular;
+int ph_modular_layout(const ph_spec *spec /* host */, const ph_modular *mod /* host */, ph_layout *main_out /* host */,
+                      ph_layout *module_out /* host */, int *p_total_out /* host */);
+int ph_modular_forward(ph_ctx *ctx, const ph_spec *spec, const ph_modular *mod, const float *params, int partner_idx,
+                       const float *obs, int n, const unsigned char *action_mask, const float *uniforms,
+                       const float *given_actions, unsigned long long seed, unsigned long long counter, int deterministic,
+                       int *actions_i32, float *actions_f32, float *values, float *log_probs, float *entropy,
+                       float *logits_main /* (n, L) or NULL */, float *logits_partner /* (n, L) or NULL */,
+                       const ph_rollout *rb, int pos, const float *episode_start_in, const float *pending_reward,
+                       int gemm_mode);
+int ph_modular_train(ph_ctx *ctx, const ph_spec *spec, const ph_modular *mod, const ph_opt_state *opt,
+                     int *mod_first /* device (n_modules): -1 until the module's value side first received a gradient */,
+                     const ph_rollout *rbs /* host, [num_partners] */, const ph_ppo_hyper *hyper, int n_epochs, int batch_size,
+                     const int *perms /* device (num_partners, n_epochs, T*E) or NULL */, unsigned long long perm_seed,
+                     float *stats, float marginal_reg_coef, int gemm_mode);
+int ph_modular_minibatch_grad(ph_ctx *ctx, const ph_spec *spec, const ph_modular *mod, const float *params, int partner_idx,
+                              const ph_rollout *rb, const ph_ppo_hyper *hyper, const int *indices /* device (nb) */, int nb,
+                              float marginal_reg_coef, float *grad_out /* device (P_total) */,
+                              float *stats_out /* device (PH_NSTAT) or NULL */, int gemm_mode);
 
 /* ---- behavioural cloning --------------------------------------------------------------------------
  * BC <- pantheonrl/algos/bc.py:180-366 on FeedForward32Policy <- pantheonrl/common/util.py:114-123: SB3 ActorCriticPolicy with

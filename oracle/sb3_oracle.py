@@ -521,8 +521,8 @@ def collect_rollouts(policy: MlpPolicyOracle, buf: RolloutBufferOracle, env, las
 
 
 # --------------------------------------------------------------------------------------
-# ModularAlgorithm / ModularPolicy (pantheonrl/algos/modular): restated ahead of a device path -- the engine does not
-# implement it yet; these functions pin what that path will have to reproduce.
+# ModularAlgorithm / ModularPolicy (pantheonrl/algos/modular): what ph_modular_forward / ph_modular_train (ph_modular.hip)
+# are tested against (tests/test_gpu_modular.py).
 # --------------------------------------------------------------------------------------
 class ModularPolicyOracle(MlpPolicyOracle):
     """``ModularPolicy`` (modular/policies.py:40-395) with the FlattenExtractor defaults: the main network is the ordinary
@@ -675,7 +675,12 @@ def modular_train(policy: ModularPolicyOracle, bufs: Sequence[RolloutBufferOracl
             idx = None if perms is None else np.asarray(perms[k][epoch])
             for mb in buf.get(hp.batch_size, idx):
                 loss, stats = modular_minibatch_loss(policy, mb, hp, k, marginal_reg_coef)
-                policy.optimizer.zero_grad()
+                # The reference pins torch==1.13.1 (setup.py:15), whose Optimizer.zero_grad defaults to set_to_none=False:
+                # gradients are zeroed IN PLACE, so a parameter that has received a gradient once keeps taking part in every
+                # later step (g = 0: its moments decay, its own step count advances), while one the loss has never reached
+                # (another partner's value tower before that partner's first turn) has grad None and is skipped.  torch >= 2.0
+                # flipped the default; the pinned behaviour is requested explicitly.
+                policy.optimizer.zero_grad(set_to_none=False)
                 loss.backward()
                 stats["grad_norm"] = float(th.nn.utils.clip_grad_norm_(policy.parameters(), hp.max_grad_norm))
                 policy.optimizer.step()

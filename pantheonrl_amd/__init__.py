@@ -9,5 +9,6 @@ from .common import (Agent, DummyEnv, MultiAgentEnv, Observation, OnPolicyAgent,
                      SimultaneousEnv, StaticPolicyAgent, TurnBasedEnv)
 from .ppo import PPO, ActorCriticPolicy, RolloutBuffer  # noqa: F401
 from .adap import ADAP, AdapAgent, AdapPolicy  # noqa: F401
+from .modular import ModularAlgorithm, ModularPolicy  # noqa: F401
 
 __version__ = "0.1.0"

@@ -108,6 +108,14 @@ class PhP2P(C.Structure):
                 ("epoch", C.c_void_p), ("error", C.c_void_p), ("timeout_cycles", C.c_ulonglong)]
 
 
+PH_MOD_MAX = 8
+
+
+class PhModular(C.Structure):
+    """ph_modular: partners and modules of a ModularPolicy"""
+    _fields_ = [("num_partners", C.c_int), ("n_modules", C.c_int), ("module_of", C.c_int * PH_MOD_MAX), ("nomain", C.c_int)]
+
+
 PH_STEP_FIX_ILLEGAL = 2
 PH_STEP_MASK_ENV_ONLY = 4
 
@@ -199,6 +207,13 @@ SIGNATURES = {
     "ph_p2p_ll_unpack": [_vp, C.POINTER(PhP2P), _i],
     "ph_selfplay_rollout_p2p": [_vp, _i, C.POINTER(PhStepCall), _i, _vp, C.POINTER(PhP2P)],
     "ph_selfplay_rollout_persistent": [_vp, _i, C.POINTER(PhRolloutCall), _i, C.POINTER(PhP2P), _i],
+    "ph_modular_layout": [C.POINTER(PhSpec), C.POINTER(PhModular), C.POINTER(PhLayout), C.POINTER(PhLayout), C.POINTER(_i)],
+    "ph_modular_forward": [_vp, C.POINTER(PhSpec), C.POINTER(PhModular), _vp, _i, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp,
+                           _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(PhRollout), _i, _vp, _vp, _i],
+    "ph_modular_train": [_vp, C.POINTER(PhSpec), C.POINTER(PhModular), C.POINTER(PhOptState), _vp, C.POINTER(PhRollout),
+                         C.POINTER(PhPpoHyper), _i, _i, _vp, _ull, _vp, C.c_float, _i],
+    "ph_modular_minibatch_grad": [_vp, C.POINTER(PhSpec), C.POINTER(PhModular), _vp, _i, C.POINTER(PhRollout),
+                                  C.POINTER(PhPpoHyper), _vp, _i, C.c_float, _vp, _vp, _i],
     "ph_ppo_minibatch_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _vp, _i, _vp,
                               _vp, _i],
     "ph_adap_train": [_vp, C.POINTER(PhSpec), C.POINTER(PhOptState), C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i,

@@ -77,6 +77,17 @@ struct ph_ctx {
   int num_cu = 256;
   unsigned long long* rng_epoch = nullptr;  // caller-owned device word
   long long* prof = nullptr;                // caller-owned debug stamp buffer
+  // ModularAlgorithm workspace (ph_modular_*): activations and head gradients in minibatch order, the towers' slab maps
+  struct ModWs {
+    float* act = nullptr;        // one allocation carved into the arrays below
+    size_t act_cap = 0;
+    int* maps = nullptr;         // [n_modules][n_slots][RS_NET] slab position -> parameter index, one set per trained module
+    ph_spec spec;
+    ph_modular mod;
+    bool maps_valid = false;
+    float* kl_sum = nullptr;     // [1]
+    int* scratch = nullptr;      // [2 + PH_MOD_MAX] throw-away optimizer counters of ph_modular_minibatch_grad's statistics
+  } mw;
 };
 
 namespace {
@@ -274,7 +285,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (s.slab_map) (void)hipFree(s.slab_map);
     if (s.act_off) (void)hipFree(s.act_off);
   }
-  void* ptrs[] = {ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->scalars, ctx->stop_flag,
+  void* ptrs[] = {ctx->mw.act, ctx->mw.maps, ctx->mw.kl_sum, ctx->mw.scratch, ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->scalars, ctx->stop_flag,
                   ctx->adap_extra, ctx->adap_loss};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1678,6 +1689,581 @@ int ph_bench_gae(ph_ctx* ctx, const ph_rollout* rb, const float* last_values, co
   float ms = 0.f;
   PH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   *avg_ms_out = ms / (float)reps;
+  return 0;
+}
+
+
+// ---- ModularAlgorithm / ModularPolicy (ph_modular.hip) ---------------------------------------------------------------------
+namespace {
+
+int module_layout(int L, ph_layout* o) {   // a (Box(64), same action space) network: the partner module's parameter block
+  const int H = PH_HIDDEN;
+  o->D = H;
+  o->F = H;
+  o->A = 1;
+  o->L = L;
+  int off = 0;
+  o->pi_W1 = off; off += H * H;
+  o->pi_b1 = off; off += H;
+  o->pi_W2 = off; off += H * H;
+  o->pi_b2 = off; off += H;
+  o->vf_W1 = off; off += H * H;
+  o->vf_b1 = off; off += H;
+  o->vf_W2 = off; off += H * H;
+  o->vf_b2 = off; off += H;
+  o->act_W = off; off += H * L;
+  o->act_b = off; off += L;
+  o->val_W = off; off += H;
+  o->val_b = off; off += 1;
+  o->P = off;
+  return 0;
+}
+
+int check_modular(const ph_modular* m, const ph::NetDims& nd, const char* who) {
+  const std::string w(who);
+  if (!m) return fail(w + ": null ph_modular");
+  if (m->num_partners < 1 || m->num_partners > PH_MOD_MAX) return fail(w + ": num_partners must be in [1, PH_MOD_MAX]");
+  if (m->n_modules < 1 || m->n_modules > m->num_partners) return fail(w + ": n_modules must be in [1, num_partners]");
+  for (int k = 0; k < m->num_partners; ++k)
+    if (m->module_of[k] < 0 || m->module_of[k] >= m->n_modules) return fail(w + ": module_of out of range");
+  if (nd.nchunk != 1 || nd.A != 1 || nd.L > 8)
+    return fail(w + ": the ModularPolicy path takes observations of at most 64 features and one Discrete head of at most 8 logits");
+  return 0;
+}
+
+// carve the minibatch-order activations out of one allocation
+struct ModBufs {
+  float *Lp, *zm, *zmod, *vm, *vk, *dzm, *dzmod, *dv, *dLa, *dLb;
+};
+int mod_buffers(ph_ctx* ctx, int nb, int n_mod, ModBufs* b) {
+  const size_t rows = ((size_t)nb + 63) / 64 * 64;
+  const size_t need = rows * (64 * 3 + 8 * 2 + 8 * 2 * (size_t)n_mod + 3);
+  if (need > ctx->mw.act_cap) {
+    if (ctx->capturing) return fail("workspace would grow inside graph capture: run the same call once outside capture first");
+    if (ctx->mw.act) (void)hipFree(ctx->mw.act);
+    ctx->mw.act = nullptr;
+    ctx->mw.act_cap = 0;
+    PH_HIP(hipMalloc((void**)&ctx->mw.act, need * sizeof(float)));
+    ctx->mw.act_cap = need;
+  }
+  if (!ctx->mw.kl_sum) {
+    if (ctx->capturing) return fail("first ModularPolicy call inside graph capture: call it once outside capture first");
+    PH_HIP(hipMalloc((void**)&ctx->mw.kl_sum, sizeof(float)));
+    PH_HIP(hipMemset(ctx->mw.kl_sum, 0, sizeof(float)));
+    PH_HIP(hipMalloc((void**)&ctx->mw.scratch, (2 + PH_MOD_MAX) * sizeof(int)));
+  }
+  float* p = ctx->mw.act;
+  b->Lp = p; p += rows * 64;
+  b->dLa = p; p += rows * 64;
+  b->dLb = p; p += rows * 64;
+  b->zm = p; p += rows * 8;
+  b->dzm = p; p += rows * 8;
+  b->zmod = p; p += rows * 8 * n_mod;
+  b->dzmod = p; p += rows * 8 * n_mod;
+  b->vm = p; p += rows;
+  b->vk = p; p += rows;
+  b->dv = p; p += rows;
+  return 0;
+}
+
+// slab slots of one minibatch: [main pi, main vf, module 0 pi .. module M-1 pi, trained module's vf]
+int mod_slots(const ph_modular* m) { return m->n_modules + 3; }
+
+int mod_maps(ph_ctx* ctx, const ph_spec* spec, const ph_modular* mod, const ph_layout& lay, const ph_layout& ml) {
+  if (ctx->mw.maps_valid && std::memcmp(&ctx->mw.spec, spec, sizeof(ph_spec)) == 0 &&
+      std::memcmp(&ctx->mw.mod, mod, sizeof(ph_modular)) == 0)
+    return 0;
+  if (ctx->capturing) return fail("first use of a ModularPolicy inside graph capture: call it once outside capture first");
+  const int M = mod->n_modules, NS = mod_slots(mod);
+  std::vector<int> h((size_t)M * NS * ph::RS_NET, -1);
+  for (int k = 0; k < M; ++k) {
+    int* base = h.data() + (size_t)k * NS * ph::RS_NET;
+    ph::tower_slab_map(lay.F, lay.L, 1, lay.pi_W1, lay.pi_b1, lay.pi_W2, lay.pi_b2, lay.act_W, lay.act_b, base);
+    ph::tower_slab_map(lay.F, lay.L, 2, lay.vf_W1, lay.vf_b1, lay.vf_W2, lay.vf_b2, lay.val_W, lay.val_b, base + ph::RS_NET);
+    for (int m = 0; m < M; ++m) {
+      const int o = lay.P + m * ml.P;
+      ph::tower_slab_map(64, lay.L, 1, o + ml.pi_W1, o + ml.pi_b1, o + ml.pi_W2, o + ml.pi_b2, o + ml.act_W, o + ml.act_b,
+                         base + (size_t)(2 + m) * ph::RS_NET);
+    }
+    const int o = lay.P + k * ml.P;
+    ph::tower_slab_map(64, lay.L, 2, o + ml.vf_W1, o + ml.vf_b1, o + ml.vf_W2, o + ml.vf_b2, o + ml.val_W, o + ml.val_b,
+                       base + (size_t)(2 + M) * ph::RS_NET);
+  }
+  if (ctx->mw.maps) (void)hipFree(ctx->mw.maps);
+  ctx->mw.maps = nullptr;
+  PH_HIP(hipMalloc((void**)&ctx->mw.maps, h.size() * sizeof(int)));
+  PH_HIP(hipMemcpy(ctx->mw.maps, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+  std::memcpy(&ctx->mw.spec, spec, sizeof(ph_spec));
+  std::memcpy(&ctx->mw.mod, mod, sizeof(ph_modular));
+  ctx->mw.maps_valid = true;
+  return 0;
+}
+
+// the towers' argument records
+void tower_main(ph::TowerArgs& t, const ph::NetDims& nd, const float* params, bool policy, const float* x, int x_ld,
+                const int* idx, int T, int E, int nb) {
+  const ph_layout& lay = nd.lay;
+  std::memset(&t, 0, sizeof(t));
+  t.nb = nb;
+  t.ntiles = (nb + 63) / 64;
+  t.x = x;
+  t.x_ld = x_ld;
+  t.F = nd.F;
+  t.obs_off = nd.obs_kind == PH_SPACE_BOX ? nullptr : nd.obs_off;
+  t.idx = idx;
+  t.T = T;
+  t.E = E;
+  t.W1 = params + (policy ? lay.pi_W1 : lay.vf_W1);
+  t.b1 = params + (policy ? lay.pi_b1 : lay.vf_b1);
+  t.W2 = params + (policy ? lay.pi_W2 : lay.vf_W2);
+  t.b2 = params + (policy ? lay.pi_b2 : lay.vf_b2);
+  t.hW = params + (policy ? lay.act_W : lay.val_W);
+  t.hb = params + (policy ? lay.act_b : lay.val_b);
+  t.head = policy ? 1 : 2;
+  t.L = nd.L;
+}
+void tower_module(ph::TowerArgs& t, const ph_layout& lay, const ph_layout& ml, const float* params, int m, bool policy,
+                  const float* latent, int nb) {
+  const float* base = params + lay.P + (size_t)m * ml.P;
+  std::memset(&t, 0, sizeof(t));
+  t.nb = nb;
+  t.ntiles = (nb + 63) / 64;
+  t.x = latent;
+  t.x_ld = 64;
+  t.F = 64;
+  t.W1 = base + (policy ? ml.pi_W1 : ml.vf_W1);
+  t.b1 = base + (policy ? ml.pi_b1 : ml.vf_b1);
+  t.W2 = base + (policy ? ml.pi_W2 : ml.vf_W2);
+  t.b2 = base + (policy ? ml.pi_b2 : ml.vf_b2);
+  t.hW = base + (policy ? ml.act_W : ml.val_W);
+  t.hb = base + (policy ? ml.act_b : ml.val_b);
+  t.head = policy ? 1 : 2;
+  t.L = lay.L;
+}
+
+// forward of the whole DAG for `nb` rows: main towers, then every module in `mods` (policy tower; value tower too for k_mod)
+int mod_forward_towers(ph_ctx* ctx, const ph::NetDims& nd, const ph_layout& ml, const float* params, const float* x, int x_ld,
+                       const int* idx, int T, int E, int nb, const ModBufs& b, int n_mod, int k_mod, bool all_modules,
+                       int gemm_mode, const int* stop_flag) {
+  const int ntiles = (nb + 63) / 64, nwg = ntiles < ctx->num_cu ? ntiles : ctx->num_cu;
+  ph::TowerLaunch L;
+  std::memset(&L, 0, sizeof(L));
+  L.mode = 0;
+  L.stop_flag = stop_flag;
+  tower_main(L.t[0], nd, params, true, x, x_ld, idx, T, E, nb);
+  L.t[0].h2_out = b.Lp;
+  L.t[0].head_out = b.zm;
+  tower_main(L.t[1], nd, params, false, x, x_ld, idx, T, E, nb);
+  L.t[1].head_out = b.vm;
+  PH_HIP(ph::launch_tower(L, nwg, 2, gemm_mode, ctx->stream));
+  for (int m = 0; m < n_mod; ++m) {
+    if (!all_modules && m != k_mod) continue;
+    tower_module(L.t[0], nd.lay, ml, params, m, true, b.Lp, nb);
+    L.t[0].head_out = b.zmod + (size_t)m * nb * 8;
+    int ny = 1;
+    if (m == k_mod) {
+      tower_module(L.t[1], nd.lay, ml, params, m, false, b.Lp, nb);
+      L.t[1].head_out = b.vk;
+      ny = 2;
+    }
+    PH_HIP(ph::launch_tower(L, nwg, ny, gemm_mode, ctx->stream));
+  }
+  return 0;
+}
+
+struct ModMinibatch {
+  const ph_rollout* rb;
+  const int* idx;
+  int nb;
+  const float* advstats;
+  int k_mod;
+  float reg_coef;
+  float* stats_out;
+};
+
+// forward, loss, backward and the slab reduction of one minibatch; the gradient lands in `grad`
+int mod_minibatch(ph_ctx* ctx, const ph_spec* spec, const ph_modular* mod, const ph::NetDims& nd, const ph_layout& ml,
+                  const float* params, const ph_ppo_hyper* hp, const ModMinibatch& mb, float* grad, int gemm_mode) {
+  const int nb = mb.nb, M = mod->n_modules, NS = mod_slots(mod);
+  const int ntiles = (nb + 63) / 64, nwg = ntiles < ctx->num_cu ? ntiles : ctx->num_cu;
+  ModBufs b;
+  if (mod_buffers(ctx, nb, M, &b)) return 1;
+  hipStream_t s = ctx->stream;
+  const int T = mb.rb->T, E = mb.rb->E;
+  if (mod_forward_towers(ctx, nd, ml, params, mb.rb->observations, nd.D, mb.idx, T, E, nb, b, M, mb.k_mod, true, gemm_mode,
+                         ctx->stop_flag))
+    return 1;
+  ph::ModLossArgs la;
+  std::memset(&la, 0, sizeof(la));
+  la.nb = nb;
+  la.idx = mb.idx;
+  la.T = T;
+  la.E = E;
+  la.rb_act = mb.rb->actions;
+  la.rb_logp = mb.rb->log_probs;
+  la.rb_adv = mb.rb->advantages;
+  la.rb_ret = mb.rb->returns;
+  la.rb_val = mb.rb->values;
+  la.advstats = mb.advstats;
+  la.L = nd.L;
+  la.n_mod = M;
+  la.k_mod = mb.k_mod;
+  la.nomain = mod->nomain;
+  la.zm = b.zm;
+  la.zmod = b.zmod;
+  for (int m = 0; m < M; ++m) {
+    int cnt = 0;
+    for (int k = 0; k < mod->num_partners; ++k) cnt += mod->module_of[k] == m;
+    la.weight[m] = (float)cnt / (float)mod->num_partners;
+  }
+  la.vm = b.vm;
+  la.vk = b.vk;
+  la.clip = hp->clip_range;
+  la.clip_vf = hp->clip_range_vf;
+  la.ent_coef = hp->ent_coef;
+  la.vf_coef = hp->vf_coef;
+  la.reg_coef = mb.reg_coef;
+  la.dzm = b.dzm;
+  la.dzmod = b.dzmod;
+  la.dv = b.dv;
+  la.statpart = ctx->statpart;
+  la.stop_flag = ctx->stop_flag;
+  PH_HIP(ph::launch_modular_loss(la, s));
+
+  // backward: the modules first (their dL/dX is the main policy latent's gradient), the main towers last
+  float* slabs = ctx->slabs;   // [nwg][NS][RS_NET]: tower slot t of workgroup w at (w * NS + t) * RS_NET
+  auto slot_base = [&](int slot) { return slabs + (size_t)slot * ph::RS_NET; };
+  ph::TowerLaunch L;
+  std::memset(&L, 0, sizeof(L));
+  L.mode = 1;
+  L.stop_flag = ctx->stop_flag;
+  bool first = true;
+  for (int m = 0; m < M; ++m) {
+    tower_module(L.t[0], nd.lay, ml, params, m, true, b.Lp, nb);
+    L.t[0].dhead = b.dzmod + (size_t)m * nb * 8;
+    L.t[0].dx_out = b.dLa;
+    L.t[0].dx_accumulate = first ? 0 : 1;
+    L.t[0].slab = slot_base(2 + m);
+    L.t[0].slab_stride = NS * ph::RS_NET;
+    first = false;
+    int ny = 1;
+    if (m == mb.k_mod) {
+      tower_module(L.t[1], nd.lay, ml, params, m, false, b.Lp, nb);
+      L.t[1].dhead = b.dv;
+      L.t[1].dx_out = b.dLb;
+      L.t[1].dx_accumulate = 0;
+      L.t[1].slab = slot_base(2 + M);
+      L.t[1].slab_stride = NS * ph::RS_NET;
+      ny = 2;
+    }
+    PH_HIP(ph::launch_tower(L, nwg, ny, gemm_mode, s));
+  }
+  tower_main(L.t[0], nd, params, true, mb.rb->observations, nd.D, mb.idx, T, E, nb);
+  L.t[0].dhead = b.dzm;
+  L.t[0].ext0 = b.dLa;
+  L.t[0].ext1 = b.dLb;
+  L.t[0].slab = slot_base(0);
+  L.t[0].slab_stride = NS * ph::RS_NET;
+  tower_main(L.t[1], nd, params, false, mb.rb->observations, nd.D, mb.idx, T, E, nb);
+  L.t[1].dhead = b.dv;
+  L.t[1].slab = slot_base(1);
+  L.t[1].slab_stride = NS * ph::RS_NET;
+  PH_HIP(ph::launch_tower(L, nwg, 2, gemm_mode, s));
+
+  ph::ReduceArgs r;
+  r.slabs = slabs;
+  r.nslab = nwg;
+  r.nstatpart = 0;
+  r.P = nd.lay.P + M * ml.P;
+  r.slab_len = NS * ph::RS_NET;
+  r.map = ctx->mw.maps + (size_t)mb.k_mod * NS * ph::RS_NET;
+  r.grad = grad;
+  r.blocksq = ctx->blocksq;
+  r.statpart = ctx->statpart;
+  r.stats_out = nullptr;
+  r.nb = nb;
+  r.ent_coef = 0.f;
+  r.vf_coef = 0.f;
+  r.target_kl = -1.f;
+  r.stop_flag = ctx->stop_flag;
+  r.step = nullptr;
+  r.scalars = ctx->scalars;
+  PH_HIP(ph::launch_ppo_reduce(r, s));
+  return 0;
+}
+
+int mod_workspace(ph_ctx* ctx, const ph_modular* mod, int P_total, int nb_max, int n_mb_total, size_t n_idx) {
+  const int ntiles = (nb_max + 63) / 64, nwg = ntiles < ctx->num_cu ? ntiles : ctx->num_cu;
+  const int loss_blocks = (nb_max + 255) / 256;
+  if (ensure_train_ws(ctx, P_total, mod_slots(mod) * ph::RS_NET, nwg, n_mb_total, n_idx)) return 1;
+  if (!ctx->capturing && ensure(ctx->statpart, ctx->statpart_cap, (size_t)(loss_blocks > 2 * nwg ? loss_blocks : 2 * nwg) * ph::NSTATP))
+    return 1;
+  return 0;
+}
+}  // namespace
+
+int ph_modular_layout(const ph_spec* spec, const ph_modular* mod, ph_layout* main_out, ph_layout* module_out, int* p_total_out) {
+  if (!spec || !mod) return fail("ph_modular_layout: null argument");
+  ph_layout lay, ml;
+  if (layout_of(spec, &lay)) return 1;
+  module_layout(lay.L, &ml);
+  if (mod->n_modules < 1 || mod->n_modules > PH_MOD_MAX) return fail("ph_modular_layout: n_modules must be in [1, PH_MOD_MAX]");
+  if (main_out) *main_out = lay;
+  if (module_out) *module_out = ml;
+  if (p_total_out) *p_total_out = lay.P + mod->n_modules * ml.P;
+  return 0;
+}
+
+int ph_modular_forward(ph_ctx* ctx, const ph_spec* spec, const ph_modular* mod, const float* params, int partner_idx,
+                       const float* obs, int n, const unsigned char* action_mask, const float* uniforms,
+                       const float* given_actions, unsigned long long seed, unsigned long long counter, int deterministic,
+                       int* actions_i32, float* actions_f32, float* values, float* log_probs, float* entropy,
+                       float* logits_main, float* logits_partner, const ph_rollout* rb, int pos,
+                       const float* episode_start_in, const float* pending_reward, int gemm_mode) {
+  DevGuard dev_guard(ctx);
+  if (!ctx) return fail("null ctx");
+  if (!params || !obs) return fail("ph_modular_forward: null params/obs");
+  if ((uintptr_t)params % 16 != 0) return fail("ph_modular_forward: params must be 16-byte aligned");
+  if (n <= 0) return fail("ph_modular_forward: n must be positive");
+  ph::FwdArgs a;
+  std::memset(&a, 0, sizeof(a));
+  if (resolve(ctx, spec, &a.nd)) return 1;
+  if (check_modular(mod, a.nd, "ph_modular_forward")) return 1;
+  if (partner_idx < 0 || partner_idx >= mod->num_partners) return fail("ph_modular_forward: partner_idx out of range");
+  ph_layout ml;
+  module_layout(a.nd.L, &ml);
+  const int k_mod = mod->module_of[partner_idx];
+  ModBufs b;
+  if (mod_buffers(ctx, n, mod->n_modules, &b)) return 1;
+  if (mod_forward_towers(ctx, a.nd, ml, params, obs, a.nd.D, nullptr, 0, 0, n, b, mod->n_modules, k_mod, false, gemm_mode,
+                         nullptr))
+    return 1;
+  a.params = params;
+  a.obs = obs;
+  a.n = n;
+  a.mask = action_mask;
+  a.uniforms = uniforms;
+  a.given_actions = given_actions;
+  a.seed = seed;
+  a.counter = counter;
+  a.epoch = ctx->rng_epoch;
+  a.deterministic = deterministic;
+  a.act_i32 = actions_i32;
+  a.act_f32 = actions_f32;
+  a.values = values;
+  a.logp = log_probs;
+  a.entropy = entropy;
+  if (rb) {
+    if (check_rb(rb)) return 1;
+    if (n != rb->E) return fail("ph_modular_forward: fused add needs n == rollout E");
+    if (pos < 0 || pos >= rb->T) return fail("ph_modular_forward: pos out of range (buffer full?)");
+    if (!episode_start_in) return fail("ph_modular_forward: fused add needs episode_start_in");
+    const size_t row = (size_t)pos * rb->E;
+    a.rb_obs = rb->observations + row * a.nd.D;
+    a.rb_act = rb->actions + row * a.nd.A;
+    a.rb_rew = rb->rewards + row;
+    a.rb_es = rb->episode_starts + row;
+    a.rb_val = rb->values + row;
+    a.rb_logp = rb->log_probs + row;
+    a.es_in = episode_start_in;
+    if (pending_reward) {
+      if (pos < 1) return fail("ph_modular_forward: pending_reward needs pos >= 1");
+      a.prev_rew = rb->rewards + (row - rb->E);
+      a.pending_reward = pending_reward;
+    }
+  } else if (pending_reward) {
+    return fail("ph_modular_forward: pending_reward needs the fused rollout-buffer write");
+  }
+  PH_HIP(ph::launch_modular_act(a, b.zm, b.zmod + (size_t)k_mod * n * 8, b.vm, b.vk, mod->nomain, logits_main, logits_partner,
+                                ctx->stream));
+  return 0;
+}
+
+int ph_modular_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const ph_modular* mod, const float* params, int partner_idx,
+                              const ph_rollout* rb, const ph_ppo_hyper* hp, const int* indices, int nb, float marginal_reg_coef,
+                              float* grad_out, float* stats_out, int gemm_mode) {
+  DevGuard dev_guard(ctx);
+  if (!ctx) return fail("null ctx");
+  if (!params || !hp || !indices || !grad_out) return fail("ph_modular_minibatch_grad: null argument");
+  if ((uintptr_t)params % 16 != 0) return fail("ph_modular_minibatch_grad: params must be 16-byte aligned");
+  if (check_rb(rb)) return 1;
+  if (nb <= 0) return fail("ph_modular_minibatch_grad: nb must be positive");
+  ph::NetDims nd;
+  if (resolve(ctx, spec, &nd)) return 1;
+  if (check_modular(mod, nd, "ph_modular_minibatch_grad")) return 1;
+  if (partner_idx < 0 || partner_idx >= mod->num_partners) return fail("ph_modular_minibatch_grad: partner_idx out of range");
+  ph_layout ml;
+  module_layout(nd.L, &ml);
+  const int P_total = nd.lay.P + mod->n_modules * ml.P;
+  if (mod_workspace(ctx, mod, P_total, nb, 1, 0)) return 1;
+  if (mod_maps(ctx, spec, mod, nd.lay, ml)) return 1;
+  hipStream_t s = ctx->stream;
+  PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
+  ph::AdvStatArgs aa;
+  aa.rb_adv = rb->advantages;
+  aa.T = rb->T;
+  aa.E = rb->E;
+  aa.perms = indices;
+  aa.perm_n = 0;
+  aa.perm_hb = 1;
+  aa.perm_seed = 0;
+  aa.epoch = nullptr;
+  aa.N = nb;
+  aa.batch = nb;
+  aa.n_mb = 1;
+  aa.out = ctx->advstats;
+  aa.partial = ctx->advpart;
+  aa.idx_out = nullptr;
+  PH_HIP(ph::launch_adv_stats(aa, 1, s));
+  PH_HIP(hipMemsetAsync(grad_out, 0, (size_t)P_total * sizeof(float), s));
+  ModMinibatch mb;
+  mb.rb = rb;
+  mb.idx = indices;
+  mb.nb = nb;
+  mb.advstats = ctx->advstats;
+  mb.k_mod = mod->module_of[partner_idx];
+  mb.reg_coef = marginal_reg_coef;
+  mb.stats_out = stats_out;
+  if (mod_minibatch(ctx, spec, mod, nd, ml, params, hp, mb, grad_out, gemm_mode)) return 1;
+  if (stats_out) {   // statistics without touching any optimizer state: a scratch step counter / first-use table
+    PH_HIP(hipMemsetAsync(ctx->mw.scratch, 0, (2 + PH_MOD_MAX) * sizeof(int), s));
+    ph::ModFinalizeArgs fa;
+    std::memset(&fa, 0, sizeof(fa));
+    fa.statpart = ctx->statpart;
+    fa.nstatpart = (nb + 255) / 256;
+    fa.nb = nb;
+    fa.step = ctx->mw.scratch;
+    fa.mod_first = ctx->mw.scratch + 1;
+    fa.k_mod = 0;
+    fa.kl_sum = ctx->mw.kl_sum;
+    fa.stats_out = stats_out;
+    fa.ent_coef = hp->ent_coef;
+    fa.vf_coef = hp->vf_coef;
+    fa.reg_coef = marginal_reg_coef;
+    fa.stop_flag = ctx->stop_flag;
+    PH_HIP(ph::launch_modular_finalize(fa, s));
+  }
+  return 0;
+}
+
+int ph_modular_train(ph_ctx* ctx, const ph_spec* spec, const ph_modular* mod, const ph_opt_state* opt, int* mod_first,
+                     const ph_rollout* rbs, const ph_ppo_hyper* hp, int n_epochs, int batch_size, const int* perms,
+                     unsigned long long perm_seed, float* stats, float marginal_reg_coef, int gemm_mode) {
+  DevGuard dev_guard(ctx);
+  if (!ctx) return fail("null ctx");
+  if (!opt || !opt->params || !opt->adam_m || !opt->adam_v || !opt->step || !mod_first)
+    return fail("ph_modular_train: null optimizer state");
+  if ((uintptr_t)opt->params % 16 != 0) return fail("ph_modular_train: params must be 16-byte aligned");
+  if (!hp || !rbs) return fail("ph_modular_train: null argument");
+  if (n_epochs <= 0 || batch_size <= 0) return fail("ph_modular_train: n_epochs and batch_size must be positive");
+  ph::NetDims nd;
+  if (resolve(ctx, spec, &nd)) return 1;
+  if (check_modular(mod, nd, "ph_modular_train")) return 1;
+  ph_layout ml;
+  module_layout(nd.L, &ml);
+  const int M = mod->n_modules, P_total = nd.lay.P + M * ml.P;
+  for (int k = 0; k < mod->num_partners; ++k) {
+    if (check_rb(&rbs[k])) return 1;
+    if (rbs[k].T != rbs[0].T || rbs[k].E != rbs[0].E) return fail("ph_modular_train: the partners' rollout buffers must have one shape");
+  }
+  const int N = rbs[0].T * rbs[0].E;
+  const int n_mb = (N + batch_size - 1) / batch_size;
+  const int nb_max = batch_size < N ? batch_size : N;
+  if (mod_workspace(ctx, mod, P_total, nb_max, n_epochs * n_mb, perms ? 0 : (size_t)n_epochs * N)) return 1;
+  if (mod_maps(ctx, spec, mod, nd.lay, ml)) return 1;
+  {
+    ModBufs probe;
+    if (mod_buffers(ctx, nb_max, M, &probe)) return 1;
+  }
+  hipStream_t s = ctx->stream;
+  const uint32_t hb = ph::feistel_half_bits((uint32_t)N);
+  for (int k = 0; k < mod->num_partners; ++k) {
+    const ph_rollout* rb = &rbs[k];
+    const int k_mod = mod->module_of[k];
+    PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
+    PH_HIP(hipMemsetAsync(ctx->mw.kl_sum, 0, sizeof(float), s));
+    const int* perms_k = perms ? perms + (size_t)k * n_epochs * N : nullptr;
+    ph::AdvStatArgs aa;
+    aa.rb_adv = rb->advantages;
+    aa.T = rb->T;
+    aa.E = rb->E;
+    aa.perms = perms_k;
+    aa.perm_n = (uint32_t)N;
+    aa.perm_hb = hb;
+    aa.perm_seed = perm_seed + (unsigned long long)k * 0x9E3779B97F4A7C15ull;
+    aa.epoch = ctx->rng_epoch;
+    aa.N = N;
+    aa.batch = batch_size;
+    aa.n_mb = n_mb;
+    aa.out = ctx->advstats;
+    aa.partial = ctx->advpart;
+    aa.idx_out = perms_k ? nullptr : ctx->perm_idx;
+    PH_HIP(ph::launch_adv_stats(aa, n_epochs * n_mb, s));
+    for (int ep = 0; ep < n_epochs; ++ep) {
+      for (int j = 0; j < n_mb; ++j) {
+        const int mbi = ep * n_mb + j, start = j * batch_size;
+        const int nb = (N - start < batch_size) ? N - start : batch_size;
+        float* st = stats ? stats + ((size_t)k * n_epochs * n_mb + mbi) * PH_NSTAT : nullptr;
+        ModMinibatch mb;
+        mb.rb = rb;
+        mb.idx = (perms_k ? perms_k : ctx->perm_idx) + (size_t)ep * N + start;
+        mb.nb = nb;
+        mb.advstats = ctx->advstats + 2 * (size_t)mbi;
+        mb.k_mod = k_mod;
+        mb.reg_coef = marginal_reg_coef;
+        mb.stats_out = st;
+        if (mod_minibatch(ctx, spec, mod, nd, ml, opt->params, hp, mb, ctx->grad, gemm_mode)) return 1;
+        ph::ModFinalizeArgs fa;
+        std::memset(&fa, 0, sizeof(fa));
+        fa.statpart = ctx->statpart;
+        fa.nstatpart = (nb + 255) / 256;
+        fa.nb = nb;
+        fa.step = opt->step;
+        fa.mod_first = mod_first;
+        fa.k_mod = k_mod;
+        fa.kl_sum = ctx->mw.kl_sum;
+        fa.stats_out = st;
+        fa.ent_coef = hp->ent_coef;
+        fa.vf_coef = hp->vf_coef;
+        fa.reg_coef = marginal_reg_coef;
+        fa.stop_flag = ctx->stop_flag;
+        PH_HIP(ph::launch_modular_finalize(fa, s));
+        ph::ModAdamArgs ad;
+        std::memset(&ad, 0, sizeof(ad));
+        ad.params = opt->params;
+        ad.m = opt->adam_m;
+        ad.v = opt->adam_v;
+        ad.grad = ctx->grad;
+        ad.blocksq = ctx->blocksq;
+        ad.nblk = ph::reduce_blocks(mod_slots(mod) * ph::RS_NET);
+        ad.P = P_total;
+        ad.step = opt->step;
+        ad.lr = hp->learning_rate;
+        ad.beta1 = hp->adam_beta1;
+        ad.beta2 = hp->adam_beta2;
+        ad.eps = hp->adam_eps;
+        ad.max_norm = hp->max_grad_norm;
+        ad.stats_out = st;
+        ad.n_mod = M;
+        ad.k_mod = k_mod;
+        ad.n_seg = 2 * M;
+        for (int m = 0; m < M; ++m) {
+          const int o = nd.lay.P + m * ml.P;
+          ad.seg_lo[2 * m] = o + ml.vf_W1;
+          ad.seg_hi[2 * m] = o + ml.act_W;
+          ad.seg_mod[2 * m] = m;
+          ad.seg_lo[2 * m + 1] = o + ml.val_W;
+          ad.seg_hi[2 * m + 1] = o + ml.P;
+          ad.seg_mod[2 * m + 1] = m;
+        }
+        ad.mod_first = mod_first;
+        ad.stop_flag = ctx->stop_flag;
+        PH_HIP(ph::launch_modular_adam(ad, s));
+      }
+      PH_HIP(ph::launch_modular_epoch_end(ctx->mw.kl_sum, n_mb, hp->target_kl, ctx->stop_flag, s));
+    }
+  }
+  PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
   return 0;
 }
 

@@ -309,4 +309,86 @@ hipError_t launch_bc_forward(const NetDims& nd, const ph_bc_layout& lay, const f
                              float* logits, hipStream_t s);
 hipError_t launch_epoch_advance(unsigned long long* p, hipStream_t s);
 
+// ---- ModularAlgorithm / ModularPolicy (ph_modular.hip) ---------------------------------------------------------------------
+// one 64-64 tanh tower with its head: forward (latent + head output to HBM) or backward (head gradient and up to two external
+// dL/dH2 terms from HBM -> register-order gradient slabs, optionally dL/dX)
+struct TowerArgs {
+  int nb, ntiles;
+  const float* x;        // idx != null: rollout observations (T, E, x_ld) gathered through the minibatch order; else dense [nb][x_ld]
+  int x_ld;              // floats per input row (D, or 64 for a tower reading a latent)
+  int F;                 // features (<= 64); W1 has F rows
+  const int* obs_off;    // device prefix sums of the observation nvec: one-hot features (x holds x_ld components), or null = Box
+  const int* idx;        // (nb) env-major indices, or null
+  int T, E;
+  const float *W1, *b1, *W2, *b2, *hW, *hb;
+  int head;              // 1: policy head, L logits (hW [64][L], hb [L]); 2: value head (hW [64], hb [1])
+  int L;
+  float* h2_out;         // forward: [nb][64] latent, or null
+  float* head_out;       // forward: policy [nb][8] logits incl. bias (columns >= L zero) | value [nb]
+  const float* dhead;    // backward: policy [nb][8] dL/dlogits | value [nb] dL/dv
+  const float* ext0;     // backward: [nb][64] added to dL/dH2, or null
+  const float* ext1;
+  float* dx_out;         // backward: [nb][64] dL/dX (F == 64 towers), or null
+  int dx_accumulate;     // 1: += into dx_out
+  float* slab;           // backward: this tower's slab of workgroup w at slab + w * slab_stride (RS_NET floats)
+  int slab_stride;
+};
+struct TowerLaunch {
+  TowerArgs t[2];        // blockIdx.y
+  int mode;              // 0 forward, 1 backward
+  const int* stop_flag;
+};
+size_t tower_lds_bytes();
+hipError_t launch_tower(const TowerLaunch& L, int nwg, int n_towers, int gemm_mode, hipStream_t s);
+void tower_slab_map(int F, int L, int head, int oW1, int oB1, int oW2, int oB2, int oHW, int oHB, int* map /* host, RS_NET */);
+
+struct ModLossArgs {
+  int nb;
+  const int* idx;
+  int T, E;
+  const float *rb_act, *rb_logp, *rb_adv, *rb_ret, *rb_val;
+  const float* advstats;   // {mean, std} of this minibatch's advantages
+  int L, n_mod, k_mod, nomain;
+  const float* zm;         // [nb][8] main logits
+  const float* zmod;       // [n_mod][nb][8] every module's logits
+  float weight[PH_MOD_MAX];   // multiplicity of module m among the partners / num_partners
+  const float *vm, *vk;    // [nb] main value, trained partner's value
+  float clip, clip_vf, ent_coef, vf_coef, reg_coef;
+  float* dzm;              // [nb][8] out
+  float* dzmod;            // [n_mod][nb][8] out
+  float* dv;               // [nb] out
+  float* statpart;         // [gridDim.x][NSTATP]
+  const int* stop_flag;
+};
+hipError_t launch_modular_loss(const ModLossArgs& a, hipStream_t s);
+struct ModFinalizeArgs {
+  const float* statpart;
+  int nstatpart, nb;
+  int* step;
+  int* mod_first;          // [n_mod] optimizer step count before module m's value side first received a gradient, -1 = never
+  int k_mod;
+  float* kl_sum;           // running sum of this epoch's per-minibatch KLs
+  float* stats_out;        // [PH_NSTAT] or null
+  float ent_coef, vf_coef, reg_coef;
+  const int* stop_flag;
+};
+hipError_t launch_modular_finalize(const ModFinalizeArgs& a, hipStream_t s);
+hipError_t launch_modular_epoch_end(float* kl_sum, int n_mb, float target_kl, int* stop_flag, hipStream_t s);
+struct ModAdamArgs {
+  float *params, *m, *v;
+  const float* grad;
+  const float* blocksq;
+  int nblk, P;
+  const int* step;
+  float lr, beta1, beta2, eps, max_norm;
+  float* stats_out;
+  int n_mod, k_mod, n_seg;
+  int seg_lo[2 * PH_MOD_MAX], seg_hi[2 * PH_MOD_MAX], seg_mod[2 * PH_MOD_MAX];   // value-side parameter ranges of the modules
+  const int* mod_first;
+  const int* stop_flag;
+};
+hipError_t launch_modular_adam(const ModAdamArgs& a, hipStream_t s);
+hipError_t launch_modular_act(const FwdArgs& a, const float* zm, const float* zk, const float* vm, const float* vk, int nomain,
+                              float* logits_main, float* logits_partner, hipStream_t s);
+
 }  // namespace ph

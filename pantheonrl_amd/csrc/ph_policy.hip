@@ -6,166 +6,11 @@
 // Grid: (row tiles of R rows, 2).  blockIdx.y = 0 -> policy net workgroup (logits, sampling, log-prob),
 // 1 -> value net workgroup (values + the observation copy into the rollout buffer).  Each workgroup keeps the
 // 64x64 weight blocks in LDS and runs every layer as 32x32 v_mfma_f32_32x32x2_f32 tiles, one tile per wave.
-#include "ph_launch.h"
+#include "ph_rowtail.h"
 #include "ph_liar.h"
 
 namespace ph {
 
-
-// Row of the rollout buffer that env g's transition goes to, or -1 when it is not recorded.  Rectangular mode: the
-// caller pre-offset the rb_* pointers to row `pos`, so the index is g.  Ragged mode (turn-based games: every env has
-// its own write position, SURVEY.md 8e "per-env pos"): rb_* are the array bases and the row is pos_env[g].
-__device__ __forceinline__ long long rb_row(const FwdArgs& a, int g) {
-  if (!a.pos_env) return g;
-  const int p = a.pos_env[g];
-  if (!a.rec_mask[g] || p >= a.rb_T) return -1;
-  return (long long)p * a.n + g;
-}
-
-// one stamp-in-band word of the fused peer-to-peer exchange: spin (bounded) until it carries the expected step's stamp
-__device__ __forceinline__ int ll_read(const FwdArgs& a, const unsigned long long* word) {
-  const unsigned want = p2p_stamp32(*a.ll_epoch, a.ll_T, a.ll_t);
-  const long long t0 = wall_clock64();
-  while (true) {
-    const unsigned long long v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if ((unsigned)(v >> 32) == want) return (int)(unsigned)v;
-    if ((unsigned long long)(wall_clock64() - t0) > a.ll_timeout) {
-      atomicAdd(a.ll_error, 1ull);
-      return (int)(unsigned)v;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-}
-
-// value-net tail of one row: cache V, write the rollout-buffer row scalars, fold the previous step's late reward in
-__device__ __forceinline__ void value_row_tail(const FwdArgs& a, int g, float v) {
-  const long long ridx = a.rb_val ? rb_row(a, g) : -1;
-  if (a.values && (!a.pos_env || ridx >= 0)) a.values[g] = v;  // ragged: V of the last RECORDED action is cached
-  if (ridx >= 0) {
-    a.rb_val[ridx] = v;
-    a.rb_rew[ridx] = 0.f;
-    a.rb_es[ridx] = a.es_in[g];
-    if (a.pending_reward) {
-      float add = a.pending_reward[g];
-      if (a.joint) {  // shared coordination term of the synthetic SimultaneousEnv transition (joint action)
-        int p = *a.partner_seat;
-        p = p < 0 ? 0 : (p >= a.n_seats ? a.n_seats - 1 : p);
-        if (a.joint_ll) {
-          const int mine = ll_read(a, a.joint_ll + (size_t)a.seat * a.n + g);
-          const int theirs = ll_read(a, a.joint_ll + (size_t)p * a.n + g);
-          add += (mine == theirs) ? a.bonus : 0.f;
-        } else {
-          add += (a.joint[(size_t)a.seat * a.n + g] == a.joint[(size_t)p * a.n + g]) ? a.bonus : 0.f;
-        }
-      }
-      a.prev_rew[g] += add;
-    }
-  }
-}
-
-// RolloutBuffer.add copies the observation (agents.py:172-173): rows [row0, row0 + nrow) by the whole workgroup
-__device__ __forceinline__ void copy_obs_rows(const FwdArgs& a, int row0, int nrow, int D, int tid = -1, int nt = 0) {
-  if (!a.rb_obs) return;
-  if (tid < 0) {
-    tid = threadIdx.x;
-    nt = blockDim.x;
-  }
-  if (!a.pos_env) {
-    const size_t off = (size_t)row0 * D;
-    for (int e = tid; e < nrow * D; e += nt) a.rb_obs[off + e] = a.obs[off + e];
-  } else {
-    for (int e = tid; e < nrow * D; e += nt) {
-      const int r = e / D, d = e - r * D;
-      const long long ridx = rb_row(a, row0 + r);
-      if (ridx >= 0) a.rb_obs[(size_t)ridx * D + d] = a.obs[(size_t)(row0 + r) * D + d];
-    }
-  }
-}
-
-// Philox counter of a forward: the caller's step counter in the low word, the RNG epoch (a device word the iteration graphs
-// advance between replays) in the high one.  A launch that knows the epoch (the persistent Liar's Dice rollout reads it once)
-// folds it into a.counter and passes no pointer, which removes a dependent round trip to L2 from every sampling tail.
-// (Reading the word at the top of the single-step kernels instead measured slower: 6.5 -> 7.0 us per policy_fwd16 launch.)
-__device__ __forceinline__ uint64_t fwd_counter(const FwdArgs& a) {
-  return a.counter + (a.epoch ? (uint64_t)(*a.epoch) << 32 : 0ull);
-}
-
-// Discrete action space with <= 8 logits, one lane per row, the row's logits in registers (z[k >= L] ignored): optional
-// mask offset, logits output, sampling / argmax / given action, log-prob, entropy and the rollout-buffer writes
-__device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDims& nd, int g, float (&zr)[8], uint64_t ctr) {
-  const int nk = nd.L;
-  if (a.mask) {  // modular/policies.py:330-333 : logits - 30*(~mask)
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (k < nk) zr[k] = zr[k] - 30.0f * (1.0f - (float)(a.mask[(size_t)g * nk + k] != 0));
-  }
-  if (a.logits) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (k < nk) a.logits[(size_t)g * nk + k] = zr[k];
-  }
-  float pr[8];
-  float m = -3.0e38f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    zr[k] = (k < nk) ? zr[k] : -3.0e38f;
-    m = fmaxf(m, zr[k]);
-  }
-  float se = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    pr[k] = (k < nk) ? fast_exp(zr[k] - m) : 0.f;
-    se += pr[k];
-  }
-  const float lse = m + fast_log(se), inv = __builtin_amdgcn_rcpf(se);
-  int act = 0;
-  if (a.given_actions) {
-    act = (int)a.given_actions[g];
-    act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
-  } else if (a.deterministic) {
-    float best = zr[0];
-#pragma unroll
-    for (int k = 1; k < 8; ++k)
-      if (k < nk && zr[k] > best) { best = zr[k]; act = k; }
-  } else {
-    const float u = a.uniforms ? a.uniforms[g] : philox_uniform(a.seed, ctr, (uint32_t)g, 0u);
-    float cum = 0.f;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {  // inverse CDF: count prefix sums <= u
-      cum += pr[k] * inv;
-      act += (k < nk - 1 && u >= cum) ? 1 : 0;
-    }
-  }
-  float zact = 0.f, ent = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float lp = zr[k] - lse;
-    ent -= (k < nk) ? pr[k] * inv * lp : 0.f;
-    zact = (k == act) ? zr[k] : zact;
-  }
-  const float logp = zact - lse;
-  // What the ENVIRONMENT consumes: with fix_illegal an illegal sample becomes the first legal index (pettingzoo.py:81-82 does
-  // this inside the env, before base_env.step); the agent is not told, so its buffer row and log-prob keep the sampled action.
-  int env_act = act;
-  if (a.env_mask && a.env_mask[(size_t)g * nk + act] == 0) {
-    env_act = 0;
-#pragma unroll
-    for (int k = 7; k >= 0; --k)
-      if (k < nk && a.env_mask[(size_t)g * nk + k] != 0) env_act = k;
-  }
-  if (a.act_i32) a.act_i32[g] = env_act;
-  if (a.act_f32) a.act_f32[g] = (float)act;
-  if (a.logp) a.logp[g] = logp;
-  if (a.entropy) a.entropy[g] = ent;
-  if (a.rb_act || a.rb_logp) {
-    const long long ridx = rb_row(a, g);
-    if (ridx >= 0) {
-      if (a.rb_act) a.rb_act[ridx] = (float)act;
-      if (a.rb_logp) a.rb_logp[ridx] = logp;
-    }
-  }
-  return env_act;
-}
 
 // General action head of one row, one lane per row, the row's logits z[0..L) in LDS (modified in place): optional mask
 // offset, logits output, then per action component sampling / argmax / given action, log-prob, entropy and the

@@ -3,11 +3,11 @@
     python -m pantheonrl_amd.trainer RPS-v0 PPO PPO --preset 1 --seed 0 -t 10000        (BASELINE config 1)
 
 Same positional arguments and flags as the reference for the part of the surface that sits on the PPO path:
-env in {RPS-v0, LiarsDice-v0}; ego in {PPO, ADAP, LOAD}; each partner in {PPO, ADAP, FIXED, DEFAULT}; JSON configs splatted
+env in {RPS-v0, LiarsDice-v0}; ego in {PPO, ADAP, ModularAlgorithm, LOAD}; each partner in {PPO, ADAP, FIXED, DEFAULT}; JSON configs splatted
 into the constructors; `--framestack`, `--preset 1`, `--ego-save/--alt-save`, `--tensorboard-log/-name`, `--seed`, `--device`,
 `--total-timesteps`, `--share-latent` (ADAP ego + ADAP partners act under the ego's context).  `--record FILE` writes the episode
-transitions in the reference's `.npy` format.  ADAP_MULT / ModularAlgorithm / BC agents belong to components outside the PPO
-rollout+update path and raise EnvException.
+transitions in the reference's `.npy` format.  A ModularAlgorithm ego gets one partner module per partner agent
+(`policy_kwargs = dict(num_partners=len(args.alt))`, trainer.py:131-135).  ADAP_MULT agents (another network) raise EnvException.
 """
 from __future__ import annotations
 
@@ -23,11 +23,12 @@ from .common.wrappers import frame_wrap, recorder_wrap
 from .envs.liar import LiarDefaultAgent, LiarEnv
 from .envs.rps import RPSEnv, RPSWeightedAgent
 from .adap import ADAP, AdapAgent, AdapPolicy
+from .modular import ModularAlgorithm, ModularPolicy
 from .ppo import PPO
 
-EGO_LIST = ["PPO", "ADAP", "LOAD"]
+EGO_LIST = ["PPO", "ADAP", "ModularAlgorithm", "LOAD"]
 PARTNER_LIST = ["PPO", "ADAP", "DEFAULT", "FIXED"]
-OUT_OF_SCOPE = {"ADAP_MULT", "ModularAlgorithm", "BC"}
+OUT_OF_SCOPE = {"ADAP_MULT", "BC"}
 
 
 class EnvException(Exception):
@@ -88,6 +89,8 @@ def gen_load(config: dict, policy_type: str, location: str):
     if policy_type == "BC":         # trainer.py:152-153: BCShell(reconstruct_policy(location)) -- an object with a .policy
         from .bc import reconstruct_policy
         return _bc_shell(reconstruct_policy(location, device=config.get("device", "cuda")))
+    if policy_type == "ModularAlgorithm":     # trainer.py:150-151
+        return ModularAlgorithm.load(location, device=config.get("device", "cuda"))
     if policy_type != "PPO":
         raise EnvException("Not a valid FIXED/LOAD policy")
     return PPO.load(location, device=config.get("device", "cuda"))
@@ -113,9 +116,13 @@ def generate_ego(env, args):
     if args.ego == "LOAD":
         model = gen_load(kwargs, kwargs["type"], kwargs["location"])
         model.set_env(env)
+        if kwargs["type"] == "ModularAlgorithm":     # trainer.py:121-123: fresh partner modules for the partners of THIS run
+            model.set_num_partners(len(args.alt))
         return model
     if args.ego == "ADAP":          # trainer.py:127-128
         return ADAP(policy=AdapPolicy, **kwargs)
+    if args.ego == "ModularAlgorithm":               # trainer.py:131-135
+        return ModularAlgorithm(policy=ModularPolicy, policy_kwargs=dict(num_partners=len(args.alt)), **kwargs)
     return PPO(policy="MlpPolicy", **kwargs)
 
 
