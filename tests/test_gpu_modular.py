@@ -96,7 +96,7 @@ def _filled(orac, name, partner, T, E, seed=0):
 def _device_buffer(pol, name, ob):
     from pantheonrl_amd.ppo import RolloutBuffer
     obs_s, act_s = SHAPES[name]
-    buf = RolloutBuffer(ob.buffer_size, H.to_space(obs_s), H.to_space(act_s), pol.device, pol.ctx, pol.spec, n_envs=ob.n_envs)
+    buf = RolloutBuffer(ob.T, H.to_space(obs_s), H.to_space(act_s), pol.device, pol.ctx, pol.spec, n_envs=ob.E)
     H.upload_buffer(buf, ob)
     return buf
 
