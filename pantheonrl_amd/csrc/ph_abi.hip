@@ -58,6 +58,8 @@ struct ph_ctx {
   size_t advpart_cap = 0;
   int* perm_idx = nullptr;   // (n_epochs, N) minibatch order of the current train() call, written by adv_stats
   size_t perm_idx_cap = 0;
+  int* perm_phys = nullptr;  // the same order as physical buffer rows (t * E + e)
+  size_t perm_phys_cap = 0;
   float* adap_extra = nullptr;   // [workgroups][policy-side parameters] gradient slabs of ADAP's context term
   size_t adap_extra_cap = 0;
   float* adap_loss = nullptr;    // [workgroups] partial sums of the raw term
@@ -190,9 +192,11 @@ int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd) {
       probe.nchunk = (nd->lay.F + PH_HIDDEN - 1) / PH_HIDDEN;
       probe.A = nd->lay.A;
       probe.L = nd->lay.L;
+      probe.F = nd->lay.F;
+      probe.obs_kind = spec->obs.kind;
       if (ph::grad_uses_reg_slabs(probe)) {
         std::vector<int> m(2 * ph::RS_NET);
-        ph::grad_slab_map(nd->lay, m.data());
+        ph::grad_slab_map(nd->lay, m.data(), ph::grad_fast_fold(probe));
         PH_HIP(hipMalloc((void**)&c.slab_map, m.size() * sizeof(int)));
         PH_HIP(hipMemcpy(c.slab_map, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice));
       }
@@ -285,7 +289,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (s.slab_map) (void)hipFree(s.slab_map);
     if (s.act_off) (void)hipFree(s.act_off);
   }
-  void* ptrs[] = {ctx->mw.act, ctx->mw.maps, ctx->mw.kl_sum, ctx->mw.scratch, ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->scalars, ctx->stop_flag,
+  void* ptrs[] = {ctx->mw.act, ctx->mw.maps, ctx->mw.kl_sum, ctx->mw.scratch, ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->perm_phys, ctx->scalars, ctx->stop_flag,
                   ctx->adap_extra, ctx->adap_loss};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1236,12 +1240,14 @@ void fill_grad_args(ph::GradArgs& g, const ph::NetDims& nd, const float* params,
 // floats per gradient slab: the canonical parameter layout, or the register-order layout of ppo_grad_fast_kernel
 int slab_len_of(const ph::NetDims& nd) { return nd.slab_map ? 2 * ph::RS_NET : nd.lay.P; }
 
-int ensure_train_ws(ph_ctx* ctx, int P, int slab_len, int nwg_max, int n_mb_total, size_t n_idx = 0) {
+int ensure_train_ws(ph_ctx* ctx, int P, int slab_len, int nwg_max, int n_mb_total, size_t n_idx = 0, size_t n_phys = 0) {
   if (ctx->capturing) {
-    if ((size_t)nwg_max * slab_len > ctx->slabs_cap || (size_t)n_mb_total * 2 > ctx->advstats_cap || n_idx > ctx->perm_idx_cap)
+    if ((size_t)nwg_max * slab_len > ctx->slabs_cap || (size_t)n_mb_total * 2 > ctx->advstats_cap || n_idx > ctx->perm_idx_cap ||
+        n_phys > ctx->perm_phys_cap)
       return fail("workspace would grow inside graph capture: run the same call once outside capture first");
     return 0;
   }
+  if (n_phys && ensure(ctx->perm_phys, ctx->perm_phys_cap, n_phys)) return 1;
   if (ensure(ctx->slabs, ctx->slabs_cap, (size_t)nwg_max * slab_len)) return 1;
   if (ensure(ctx->statpart, ctx->statpart_cap, (size_t)2 * nwg_max * ph::NSTATP)) return 1;
   if (ensure(ctx->grad, ctx->grad_cap, (size_t)P)) return 1;
@@ -1364,7 +1370,9 @@ int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_s
   t.n_mb = (t.N + batch_size - 1) / batch_size;
   t.P = t.nd.lay.P;
   const MbPlan big = plan_minibatch(ctx, t.nd, batch_size < t.N ? batch_size : t.N);
-  if (ensure_train_ws(ctx, t.P, slab_len_of(t.nd), big.nwg, n_epochs * t.n_mb, perms ? 0 : (size_t)n_epochs * t.N)) return 1;
+  if (ensure_train_ws(ctx, t.P, slab_len_of(t.nd), big.nwg, n_epochs * t.n_mb, perms ? 0 : (size_t)n_epochs * t.N,
+                      (size_t)n_epochs * t.N))
+    return 1;
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
   t.hb = ph::feistel_half_bits((uint32_t)t.N);
@@ -1383,6 +1391,7 @@ int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_s
   aa.out = ctx->advstats;
   aa.partial = ctx->advpart;
   aa.idx_out = perms ? nullptr : ctx->perm_idx;
+  aa.phys_out = ctx->perm_phys;      // the order once more as physical rows: the tile walk then has no index arithmetic
   PH_HIP(ph::launch_adv_stats(aa, n_epochs * t.n_mb, s));
   return 0;
 }
@@ -1398,6 +1407,7 @@ int train_launch_grad(const TrainPlan& t, int mbi, MbPlan* pl_out) {
   std::memset(&g, 0, sizeof(g));
   fill_grad_args(g, t.nd, t.opt->params, t.rb, t.hp, ctx);
   g.idx = (t.perms ? t.perms : ctx->perm_idx) + (size_t)ep * t.N + start;
+  g.idx_phys = ctx->perm_phys + (size_t)ep * t.N + start;
   g.perm_n = (uint32_t)t.N;
   g.perm_hb = t.hb;
   g.perm_seed = t.perm_seed;
@@ -1565,7 +1575,7 @@ int minibatch_grad_run(ph_ctx* ctx, const ph_spec* spec, const float* params, co
   if (resolve(ctx, spec, &nd)) return 1;
   const int P = nd.lay.P;
   const MbPlan pl = plan_minibatch(ctx, nd, nb);
-  if (ensure_train_ws(ctx, P, slab_len_of(nd), pl.nwg, 1)) return 1;
+  if (ensure_train_ws(ctx, P, slab_len_of(nd), pl.nwg, 1, 0, (size_t)nb)) return 1;
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
   ph::AdvStatArgs aa;
@@ -1583,11 +1593,13 @@ int minibatch_grad_run(ph_ctx* ctx, const ph_spec* spec, const float* params, co
   aa.out = ctx->advstats;
   aa.partial = ctx->advpart;
   aa.idx_out = nullptr;
+  aa.phys_out = ctx->perm_phys;
   PH_HIP(ph::launch_adv_stats(aa, 1, s));
   ph::GradArgs g;
   std::memset(&g, 0, sizeof(g));
   fill_grad_args(g, nd, params, rb, hp, ctx);
   g.idx = indices;
+  g.idx_phys = ctx->perm_phys;
   g.nb = nb;
   g.advstats = ctx->advstats;
   g.ntiles = pl.ntiles;
@@ -1630,7 +1642,7 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   const int N = rb->T * rb->E;
   const int nb = batch_size < N ? batch_size : N;
   const MbPlan pl = plan_minibatch(ctx, nd, nb);
-  if (ensure_train_ws(ctx, nd.lay.P, slab_len_of(nd), pl.nwg, 1, (size_t)N)) return 1;
+  if (ensure_train_ws(ctx, nd.lay.P, slab_len_of(nd), pl.nwg, 1, (size_t)N, (size_t)N)) return 1;
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
   ph::AdvStatArgs aa;
@@ -1648,11 +1660,13 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   aa.out = ctx->advstats;
   aa.partial = ctx->advpart;
   aa.idx_out = ctx->perm_idx;   // as in ph_ppo_train: the grad launches read the materialised order
+  aa.phys_out = ctx->perm_phys;
   PH_HIP(ph::launch_adv_stats(aa, 1, s));
   ph::GradArgs g;
   std::memset(&g, 0, sizeof(g));
   fill_grad_args(g, nd, params, rb, hp, ctx);
   g.idx = ctx->perm_idx;
+  g.idx_phys = ctx->perm_phys;
   g.perm_n = aa.perm_n;
   g.perm_hb = aa.perm_hb;
   g.perm_seed = aa.perm_seed;
@@ -2114,6 +2128,7 @@ int ph_modular_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, const ph_modular
   aa.out = ctx->advstats;
   aa.partial = ctx->advpart;
   aa.idx_out = nullptr;
+  aa.phys_out = nullptr;
   PH_HIP(ph::launch_adv_stats(aa, 1, s));
   PH_HIP(hipMemsetAsync(grad_out, 0, (size_t)P_total * sizeof(float), s));
   ModMinibatch mb;
@@ -2198,6 +2213,7 @@ int ph_modular_train(ph_ctx* ctx, const ph_spec* spec, const ph_modular* mod, co
     aa.out = ctx->advstats;
     aa.partial = ctx->advpart;
     aa.idx_out = perms_k ? nullptr : ctx->perm_idx;
+    aa.phys_out = nullptr;
     PH_HIP(ph::launch_adv_stats(aa, n_epochs * n_mb, s));
     for (int ep = 0; ep < n_epochs; ++ep) {
       for (int j = 0; j < n_mb; ++j) {

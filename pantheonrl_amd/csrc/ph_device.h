@@ -313,14 +313,16 @@ template <int NT>
 struct WStage {
   static constexpr int ITERS = HID * HID / 4 / NT;
   float4 v[ITERS];
-  __device__ __forceinline__ void issue(const float* W, int row0, int nrows_total, int tid = -1) {
+  // row63 != null: row 63 of the block comes from that 64-float vector instead (a bias riding as the last weight row)
+  __device__ __forceinline__ void issue(const float* W, int row0, int nrows_total, int tid = -1, const float* row63 = nullptr) {
     if (tid < 0) tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
       const int q = tid + NT * i;  // float4 index inside the 64x64 block
       const int k = row0 + (q >> 4);
-      v[i] = (k < nrows_total) ? *reinterpret_cast<const float4*>(W + (size_t)k * HID + ((q & 15) << 2))
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* src = (k < nrows_total) ? W + (size_t)k * HID + ((q & 15) << 2)
+                                           : ((row63 && (q >> 4) == HID - 1) ? row63 + ((q & 15) << 2) : nullptr);
+      v[i] = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   __device__ __forceinline__ void commit(float* dst, int tid = -1) {

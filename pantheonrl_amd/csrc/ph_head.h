@@ -28,7 +28,8 @@ constexpr int HW_FLOATS = 8 * (HID + HID / 8);
 
 // Calls f(m, w0, w1) for the 16 head-weight rows of lane q, four rows per group, the next group's ds_read_b128s issued
 // before the current group's arithmetic (the scheduler otherwise emits read-wait-use per row: 16 LDS round trips).
-template <class F>
+// NK: logits actually used -- with NK <= 4 the second half of every row is never read.
+template <int NK = 8, class F>
 __device__ __forceinline__ void for_head_rows(const float* hw, int q, F&& f) {
   constexpr int G = 2;  // rows per group
   float4 wa[2][G], wb[2][G];
@@ -36,7 +37,8 @@ __device__ __forceinline__ void for_head_rows(const float* hw, int q, F&& f) {
   for (int i = 0; i < G; ++i) {
     const float4* w = reinterpret_cast<const float4*>(hw + head_row(head_unit(q, i)));
     wa[0][i] = w[0];
-    wb[0][i] = w[1];
+    if constexpr (NK > 4) wb[0][i] = w[1];
+    else wb[0][i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int g = 0; g < 16 / G; ++g) {
@@ -45,7 +47,8 @@ __device__ __forceinline__ void for_head_rows(const float* hw, int q, F&& f) {
       for (int i = 0; i < G; ++i) {
         const float4* w = reinterpret_cast<const float4*>(hw + head_row(head_unit(q, G * (g + 1) + i)));
         wa[(g + 1) & 1][i] = w[0];
-        wb[(g + 1) & 1][i] = w[1];
+        if constexpr (NK > 4) wb[(g + 1) & 1][i] = w[1];
+        else wb[(g + 1) & 1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -111,6 +111,7 @@ struct GradArgs {
   int T, E;
   // minibatch rows: explicit env-major indices, or a Feistel permutation of [0, perm_n) starting at mb_start
   const int* idx;
+  const int* idx_phys;     // the same rows already translated to physical buffer rows (adv_stats_kernel), or null
   uint32_t perm_n, perm_hb;
   uint64_t perm_seed;      // key = epoch_key(perm_seed + *epoch, perm_epoch)
   int perm_epoch;
@@ -163,6 +164,7 @@ struct AdvStatArgs {
   float* out;          // [n_epochs*n_mb][2]
   double* partial;     // [n_epochs*n_mb][ADV_SPLIT][2] per-segment (sum, sum of squares)
   int* idx_out;        // (n_epochs, N) or null: the env-major index of every element, materialised for the grad launches
+  int* phys_out;       // (n_epochs, N) or null: the physical buffer row of every element (t * E + e)
 };
 
 struct ReduceArgs {
@@ -289,7 +291,8 @@ constexpr int RS_NET = 8960;
 constexpr int RS_W2 = 0, RS_W1 = 4096, RS_B1 = 8192, RS_B2 = 8256, RS_HW = 8320, RS_HB = 8832;
 bool grad_fast_eligible(const NetDims& nd);
 bool grad_uses_reg_slabs(const NetDims& nd);
-void grad_slab_map(const ph_layout& lay, int* map /* host, 2 * RS_NET */);
+bool grad_fast_fold(const NetDims& nd);   // the bias of layer 1 rides in row 63 of the staged W1 (Box observations, F < 64)
+void grad_slab_map(const ph_layout& lay, int* map /* host, 2 * RS_NET */, bool fold);
 // tiles (GradArgs.ntiles) and workgroups per net that launch_ppo_grad will use for a minibatch of nb rows
 void grad_plan(const NetDims& nd, int nb, int num_cu, int* ntiles, int* nwg);
 hipError_t launch_ppo_grad_fast(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);

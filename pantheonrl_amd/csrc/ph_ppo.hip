@@ -678,7 +678,9 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
       n = (int)feistel_perm((uint32_t)(start + i), a.perm_n, a.perm_hb, key);
       if (a.idx_out) a.idx_out[(size_t)ep * a.N + start + i] = n;   // each element is visited exactly once
     }
-    return (double)a.rb_adv[env_major_to_phys(n, a.T, a.E)];
+    const int phys = env_major_to_phys(n, a.T, a.E);
+    if (a.phys_out) a.phys_out[(size_t)ep * a.N + start + i] = phys;
+    return (double)a.rb_adv[phys];
   };
   // one pass: sum and sum of squares in fp64 (exact products of f32 values), 4 independent gathers per round
   double s = 0.0, q = 0.0;

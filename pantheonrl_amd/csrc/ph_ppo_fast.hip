@@ -16,6 +16,28 @@
 // LDS: bufA/bufB/bufC/W2 (4 x [64][65] f32) + head weights + per-row scalars = 72.9 KB -> two workgroups per CU.
 #include "ph_head.h"
 
+// Issue-slot cuts of round 3 (f32 MFMA and VALU share the SIMD's lanes, DESIGN.md 3.1: every VALU / LDS instruction removed
+// from the tile walk is time).  Each can be switched off at build time for same-box A/B (scripts/build_variants.sh):
+//   PH_FAST_NK      the policy head's loops run over the L logits that exist (template parameter), not over 8 padded slots
+//   PH_FAST_GHROWS  d act_W accumulated per wave over ITS 16 rows for all logits (48 LDS reads + 6*16 FMAs per tile) instead of
+//                   two logit columns over all 64 rows (128 reads + 128 FMAs), cross-wave sum once in the epilogue
+//   PH_FAST_PHYS    the minibatch order arrives as physical buffer rows (adv_stats_kernel translates once per train()): no
+//                   integer division per row in the tile walk
+//   PH_FAST_FOLDB1  F < 64 Box observations: column 63 of X is 1 and row 63 of the staged W1 is b1, so the MFMA adds the bias
+//                   (bitwise: fmaf(1, b, acc) = acc + b) and d b1 is row 63 of the dW1 accumulators
+#ifndef PH_FAST_NK
+#define PH_FAST_NK 1
+#endif
+#ifndef PH_FAST_GHROWS
+#define PH_FAST_GHROWS 1
+#endif
+#ifndef PH_FAST_PHYS
+#define PH_FAST_PHYS 1
+#endif
+#ifndef PH_FAST_FOLDB1
+#define PH_FAST_FOLDB1 1
+#endif
+
 namespace ph {
 
 struct RowMeta {
@@ -36,17 +58,20 @@ struct XRegs {
       v[i] = __builtin_nontemporal_load(obs + (size_t)(p < 0 ? 0 : p) * nd.D + f);   // read once per epoch and net
     }
   }
+  // FOLD: column 63 of a live row is 1 (the bias row of the staged W1 multiplies it)
+  template <bool FOLD>
   __device__ __forceinline__ void commit(float* dst, int physv, const NetDims& nd, int wave, int lane) const {
     const bool fok = lane < nd.F;
+    const float pad = (FOLD && lane == 63) ? 1.f : 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int p = __builtin_amdgcn_readlane(physv, i);
-      dst[(wave + 4 * i) * LDH + lane] = (p >= 0 && fok) ? v[i] : 0.f;
+      dst[(wave + 4 * i) * LDH + lane] = (p >= 0) ? (fok ? v[i] : pad) : 0.f;
     }
   }
 };
 
-template <bool VALU>
+template <bool VALU, int NK, bool FOLD>
 __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
   if (*a.stop_flag) return;
   PH_STAMP(a.prof, 0);
@@ -74,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
   const int oW2 = net == 0 ? lay.pi_W2 : lay.vf_W2, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
   const float inv_nb = 1.0f / (float)a.nb;
   const int nk = nd.L;
+  const float* row63 = FOLD ? a.params + oB1 : nullptr;   // the staged W1's row 63 (FOLD: b1)
 
   // loop invariants that live in memory are read once here (inside the tile loop each would be a fresh dependent load
   // -- the asm barriers are memory clobbers -- and its wait would also drain the prefetches in flight)
@@ -87,6 +113,9 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
   auto row_index = [&](int tile, int wave, int lane) -> int {
     const int gi = tile * R + wave + 4 * lane;
     if (lane >= 16 || gi >= a.nb) return -1;
+#if PH_FAST_PHYS
+    if (a.idx_phys) return a.idx_phys[gi];     // already a physical row
+#endif
     return a.idx ? a.idx[gi] : (int)feistel_perm((uint32_t)(a.mb_start + gi), a.perm_n, a.perm_hb, perm_key);
   };
   auto row_scalars = [&](int n) -> RowMeta {
@@ -94,7 +123,11 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
     m.phys = -1;
     m.adv = m.old = m.act = 0.f;
     if (n >= 0) {
+#if PH_FAST_PHYS
+      m.phys = a.idx_phys ? n : env_major_to_phys(n, a.T, a.E);
+#else
       m.phys = env_major_to_phys(n, a.T, a.E);
+#endif
       if (net == 0) {
         m.adv = a.rb_adv[m.phys];   // normalised when it is committed to LDS (no wait on the gather here)
         m.old = a.rb_logp[m.phys];
@@ -114,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
   RowMeta meta;
   {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    w1r.issue(a.params + oW1, 0, nd.F);
+    w1r.issue(a.params + oW1, 0, nd.F, -1, row63);
     w2r.issue(a.params + oW2, 0, HID);
     const int n0 = row_index(blockIdx.x, wave, lane);
     float bias1 = 0.f, bias2 = 0.f, hv0 = 0.f, hv1 = 0.f, hb = 0.f;
@@ -153,7 +186,14 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
   }
 
   f32x16 gW1 = {0}, gW2 = {0};
-  float gh0 = 0.f, gh1 = 0.f;   // policy: d act_W[j][2w], [j][2w+1] | value: d val_W[j] partial of this wave (gh0)
+  float gh0 = 0.f;              // value: d val_W[j] partial of this wave
+#if !PH_FAST_GHROWS
+  float gh1 = 0.f;              // policy: gh0 / gh1 = d act_W[j][2w], [j][2w+1] over all rows
+#else
+  float ghr[NK];                // policy: d act_W[lane][k] partial over THIS wave's rows
+#pragma unroll
+  for (int k = 0; k < NK; ++k) ghr[k] = 0.f;
+#endif
   float gb1 = 0.f, gb2 = 0.f;   // bias-gradient partials of this wave's 16 rows (lane = hidden unit)
   float ghb = 0.f;              // policy: d act_b[lane] partial (lane < 8) | value: d val_b partial
   float st[NSTATP];
@@ -179,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
       rold[row] = meta.old;
       ract[row] = meta.act;
     }
-    if (box) xt.commit(bufA, meta.phys, nd, wave, lane);
+    if (box) xt.template commit<FOLD>(bufA, meta.phys, nd, wave, lane);
     lds_barrier();
     if (!box) {
       xs.commit(bufA, rowphys, a.rb_obs, nd, 0, tid);
@@ -192,9 +232,9 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
       f32x16 acc = {0};
       acc = tile_mma<false, false, VALU>(bufA, LDH, bufC, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
       const int col = nt * 32 + li;
-      const float bb = b1s[col];   // once: read inside the loop it is re-fetched, and waited for, behind every store to bufB
+      const float bb = FOLD ? 0.f : b1s[col];   // once: read inside the loop it is re-fetched, and waited for, behind every store to bufB
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bufB[(mt * 32 + drow(r, lh)) * LDH + col] = fast_tanh(acc[r] + bb);
+      for (int r = 0; r < 16; ++r) bufB[(mt * 32 + drow(r, lh)) * LDH + col] = fast_tanh(FOLD ? acc[r] : acc[r] + bb);
     }
     lds_barrier();
     if (first) PH_STAMP(a.prof, 2);
@@ -220,29 +260,24 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
 #pragma unroll
       for (int m = 0; m < 16; ++m) h[m] = bufA[r * LDH + head_unit(q, m)];
       if (net == 0) {
-        float z[8];
+        float z[NK];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) z[k] = 0.f;
-        for_head_rows(hw, q, [&](int m, const float4& w0, const float4& w1) {
-          z[0] = __builtin_fmaf(h[m], w0.x, z[0]);
-          z[1] = __builtin_fmaf(h[m], w0.y, z[1]);
-          z[2] = __builtin_fmaf(h[m], w0.z, z[2]);
-          z[3] = __builtin_fmaf(h[m], w0.w, z[3]);
-          z[4] = __builtin_fmaf(h[m], w1.x, z[4]);
-          z[5] = __builtin_fmaf(h[m], w1.y, z[5]);
-          z[6] = __builtin_fmaf(h[m], w1.z, z[6]);
-          z[7] = __builtin_fmaf(h[m], w1.w, z[7]);
+        for (int k = 0; k < NK; ++k) z[k] = 0.f;
+        for_head_rows<NK>(hw, q, [&](int m, const float4& w0, const float4& w1) {
+          const float wk[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int k = 0; k < NK; ++k) z[k] = __builtin_fmaf(h[m], wk[k], z[k]);
         });
-        float pr[8];
+        float pr[NK];
         float mx = -3.0e38f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          z[k] = quad_sum(z[k]) + hbs[k];
+        for (int k = 0; k < NK; ++k) {
+          z[k] = quad_sum(z[k]) + hbs[k];     // (slots >= L, if NK is the padded 8: bias -3e38, they drop out of everything)
           mx = fmaxf(mx, z[k]);
         }
         float se = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < NK; ++k) {
           pr[k] = fast_exp(z[k] - mx);
           se += pr[k];
         }
@@ -251,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
         act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
         float ent = 0.f, zact = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < NK; ++k) {
           pr[k] *= inv;
           ent -= pr[k] * (z[k] - lse);
           zact = (k == act) ? z[k] : zact;
@@ -277,7 +312,9 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
         }
         float dz[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 8; ++k) dz[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
           const float dlogp = ((k == act) ? 1.f : 0.f) - pr[k];
           const float dent = -pr[k] * ((z[k] - lse) + ent);
           dz[k] = g_lp * dlogp + g_en * dent;
@@ -285,17 +322,13 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
         if (q == 0) {
           float4* o = reinterpret_cast<float4*>(dzs + r * 8);
           o[0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
-          o[1] = make_float4(dz[4], dz[5], dz[6], dz[7]);
+          if constexpr (NK > 4) o[1] = make_float4(dz[4], dz[5], dz[6], dz[7]);
         }
-        for_head_rows(hw, q, [&](int m, const float4& w0, const float4& w1) {
-          float d = dz[0] * w0.x;
-          d = __builtin_fmaf(dz[1], w0.y, d);
-          d = __builtin_fmaf(dz[2], w0.z, d);
-          d = __builtin_fmaf(dz[3], w0.w, d);
-          d = __builtin_fmaf(dz[4], w1.x, d);
-          d = __builtin_fmaf(dz[5], w1.y, d);
-          d = __builtin_fmaf(dz[6], w1.z, d);
-          d = __builtin_fmaf(dz[7], w1.w, d);
+        for_head_rows<NK>(hw, q, [&](int m, const float4& w0, const float4& w1) {
+          const float wk[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          float d = dz[0] * wk[0];
+#pragma unroll
+          for (int k = 1; k < NK; ++k) d = __builtin_fmaf(dz[k], wk[k], d);
           bufC[r * LDH + head_unit(q, m)] = d * (1.0f - h[m] * h[m]);
         });
       } else {
@@ -330,13 +363,40 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
     if (has_next) {
       meta_next = row_scalars(n_next);                        // next tile's row scalars, committed at its T0
       if (first) PH_STAMP(a.prof, 8);
-      w1r.issue(a.params + oW1, 0, nd.F, tid);                // refill of bufC, committed in S6b
+      w1r.issue(a.params + oW1, 0, nd.F, tid, row63);         // refill of bufC, committed in S6b
     }
     if (first) PH_STAMP(a.prof, 9);
     f32x16 dh1 = {0};
     {
       gb2 += lds_sum16(bufC + wave * 16 * LDH + lane, LDH);
       if (net == 0) {
+#if PH_FAST_GHROWS
+        // d act_W[lane][k] += sum over this wave's 16 rows of H2[row][lane] * dz[row][k]: the dz reads are wave-uniform
+        // (LDS broadcasts), four rows of reads in flight, then their FMAs
+        const float* hp = bufA + wave * 16 * LDH + lane;
+        const float* dp = dzs + wave * 16 * 8;
+#pragma unroll 1
+        for (int r0 = 0; r0 < 16; r0 += 4, hp += 4 * LDH, dp += 4 * 8) {
+          float hv[4];
+          float4 da[4], db[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            hv[i] = hp[i * LDH];
+            da[i] = *reinterpret_cast<const float4*>(dp + i * 8);
+            if constexpr (NK > 4) db[i] = *reinterpret_cast<const float4*>(dp + i * 8 + 4);
+            else db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float dk[8] = {da[i].x, da[i].y, da[i].z, da[i].w, db[i].x, db[i].y, db[i].z, db[i].w};
+#pragma unroll
+            for (int k = 0; k < NK; ++k) ghr[k] = __builtin_fmaf(hv[i], dk[k], ghr[k]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (lane < NK) ghb += lds_sum16(dzs + wave * 16 * 8 + lane, 8);
+#else
         const float* hp = bufA + lane;
         const float* dp = dzs + 2 * wave;
 #pragma unroll 1
@@ -357,6 +417,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
         if (lane < 8) ghb += lds_sum16(dzs + wave * 16 * 8 + lane, 8);
+#endif
       } else {
         float hv[16], dv[16];
 #pragma unroll
@@ -388,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) bufB[(mt * 32 + drow(r, lh)) * LDH + nt * 32 + li] = dh1[r] * (1.0f - hv[r] * hv[r]);
     }
-    if (box) xt.commit(bufA, meta.phys, nd, wave, lane);
+    if (box) xt.template commit<FOLD>(bufA, meta.phys, nd, wave, lane);
     else xs.commit(bufA, rowphys, a.rb_obs, nd, 0, tid);
     if (has_next) w1r.commit(bufC, tid);
     lds_barrier();
@@ -397,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
     // ---- S7: dW1 += X^T dZ1 ; d b1.  The next tile's rows are gathered underneath. ----
     meta = meta_next;
     if (has_next && box) xt.issue(meta.phys, a.rb_obs, nd, lane);
-    gb1 += lds_sum16(bufB + wave * 16 * LDH + lane, LDH);
+    if constexpr (!FOLD) gb1 += lds_sum16(bufB + wave * 16 * LDH + lane, LDH);   // FOLD: d b1 is row 63 of gW1
     gW1 = tile_mma<true, false, VALU>(bufA, LDH, bufB, LDH, mt * 32, nt * 32, 0, R, gW1, lane);
     lds_barrier();  // bufA / bufB / row scalars are free for the next tile
     if (first) PH_STAMP(a.prof, 7);
@@ -415,7 +476,9 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
       *reinterpret_cast<float4*>(rslab + RS_W2 + o) = make_float4(gW2[4 * r4], gW2[4 * r4 + 1], gW2[4 * r4 + 2], gW2[4 * r4 + 3]);
       *reinterpret_cast<float4*>(rslab + RS_W1 + o) = make_float4(gW1[4 * r4], gW1[4 * r4 + 1], gW1[4 * r4 + 2], gW1[4 * r4 + 3]);
     }
+#if !PH_FAST_GHROWS
     if (net == 0) *reinterpret_cast<float2*>(rslab + RS_HW + lane * 8 + 2 * wave) = make_float2(gh0, gh1);
+#endif
 #pragma unroll
     for (int k = 0; k < NSTATP; ++k) {
       float v = st[k];
@@ -423,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
       for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
       st[k] = v;
     }
-    float* part = bufA;  // [5][4 waves][64]
+    float* part = bufA;  // [5 + NK][4 waves][64]
     part[(0 * 4 + wave) * 64 + lane] = gb1;
     part[(1 * 4 + wave) * 64 + lane] = gb2;
     part[(2 * 4 + wave) * 64 + lane] = gh0;   // value net: d val_W partials
@@ -432,16 +495,31 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_fast_kernel(GradArgs a) {
 #pragma unroll
       for (int k = 0; k < NSTATP; ++k) part[(4 * 4 + wave) * 64 + k] = st[k];
     }
+#if PH_FAST_GHROWS
+    if (net == 0) {
+#pragma unroll
+      for (int k = 0; k < NK; ++k) part[((5 + k) * 4 + wave) * 64 + lane] = ghr[k];
+    }
+#endif
     lds_barrier();
     auto wsum = [&](int which, int idx) {
       return ((part[(which * 4 + 0) * 64 + idx] + part[(which * 4 + 1) * 64 + idx]) + part[(which * 4 + 2) * 64 + idx]) +
              part[(which * 4 + 3) * 64 + idx];
     };
     if (tid < HID) {
-      rslab[RS_B1 + tid] = wsum(0, tid);
+      if constexpr (!FOLD) rslab[RS_B1 + tid] = wsum(0, tid);
       rslab[RS_B2 + tid] = wsum(1, tid);
       if (net == 1) rslab[RS_HW + tid] = wsum(2, tid);
     }
+#if PH_FAST_GHROWS
+    if (net == 0) {   // d act_W[j][k], j = tid & 63, k = tid >> 6 (+ 4): fixed-order sum of the four waves' row partials
+#pragma unroll
+      for (int k0 = 0; k0 < NK; k0 += 4) {
+        const int k = k0 + (tid >> 6), j = tid & 63;
+        if (k < NK) rslab[RS_HW + j * 8 + k] = wsum(5 + k, j);
+      }
+    }
+#endif
     if (net == 0 && tid < 8) rslab[RS_HB + tid] = wsum(3, tid);
     if (net == 1 && tid == 0) rslab[RS_HB] = wsum(3, 0);
     if (tid < NSTATP) a.statpart[((size_t)net * gridDim.x + blockIdx.x) * NSTATP + tid] = wsum(4, tid);
@@ -462,25 +540,48 @@ bool grad_fast_eligible(const NetDims& nd) {
   return enabled && nd.nchunk == 1 && nd.A == 1 && nd.L <= 8;
 }
 
-template <bool VALU>
-static hipError_t launch_fast_variant(const GradArgs& a, int nwg, hipStream_t s) {
+// FOLD variant: Box observations with a free 64th feature column
+bool grad_fast_fold(const NetDims& nd) { return PH_FAST_FOLDB1 && nd.obs_kind == PH_SPACE_BOX && nd.F < HID; }
+
+template <bool VALU, int NK, bool FOLD>
+static hipError_t launch_fast_inst(const GradArgs& a, int nwg, hipStream_t s) {
   const size_t lds = grad_fast_lds_bytes();
   static bool allowed_dev[64] = {false};  // > 64 KiB of dynamic LDS is opt-in per kernel and device (kept out of graph capture)
   int dev = 0;
   (void)hipGetDevice(&dev);
   bool& allowed = allowed_dev[(dev >= 0 && dev < 64) ? dev : 0];
   if (!allowed) {
-    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_fast_kernel<VALU>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_fast_kernel<VALU, NK, FOLD>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     allowed = true;
   }
-  hipLaunchKernelGGL((ppo_grad_fast_kernel<VALU>), dim3(nwg, 2), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((ppo_grad_fast_kernel<VALU, NK, FOLD>), dim3(nwg, 2), dim3(256), lds, s, a);
   return hipGetLastError();
+}
+template <bool VALU, int NK>
+static hipError_t launch_fast_nk(const GradArgs& a, int nwg, hipStream_t s) {
+  return grad_fast_fold(a.nd) ? launch_fast_inst<VALU, NK, true>(a, nwg, s) : launch_fast_inst<VALU, NK, false>(a, nwg, s);
+}
+template <bool VALU>
+static hipError_t launch_fast_variant(const GradArgs& a, int nwg, hipStream_t s) {
+#if PH_FAST_NK
+  switch (a.nd.L) {     // the head's loops are unrolled over the logits that exist
+    case 1: return launch_fast_nk<VALU, 1>(a, nwg, s);
+    case 2: return launch_fast_nk<VALU, 2>(a, nwg, s);
+    case 3: return launch_fast_nk<VALU, 3>(a, nwg, s);
+    case 4: return launch_fast_nk<VALU, 4>(a, nwg, s);
+    case 5: return launch_fast_nk<VALU, 5>(a, nwg, s);
+    case 6: return launch_fast_nk<VALU, 6>(a, nwg, s);
+    case 7: return launch_fast_nk<VALU, 7>(a, nwg, s);
+    default: break;
+  }
+#endif
+  return launch_fast_nk<VALU, 8>(a, nwg, s);
 }
 
 // slab position -> parameter index (-1 = padding) for both nets of one workgroup's register-order slab: [net][RS_NET]
-void grad_slab_map(const ph_layout& lay, int* map) {
+void grad_slab_map(const ph_layout& lay, int* map, bool fold) {
   const int F = lay.F, L = lay.L;
   for (int net = 0; net < 2; ++net) {
     int* m = map + net * RS_NET;
@@ -493,9 +594,10 @@ void grad_slab_map(const ph_layout& lay, int* map) {
       const int k = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = nt * 32 + (lane & 31);
       m[RS_W2 + s] = oW2 + k * HID + col;
       if (k < F) m[RS_W1 + s] = oW1 + k * HID + col;
+      else if (fold && k == HID - 1) m[RS_W1 + s] = oB1 + col;   // the bias row of the staged W1 (grad_fast_fold)
     }
     for (int i = 0; i < HID; ++i) {
-      m[RS_B1 + i] = oB1 + i;
+      if (!fold) m[RS_B1 + i] = oB1 + i;
       m[RS_B2 + i] = oB2 + i;
     }
     if (net == 0) {
