@@ -202,7 +202,8 @@ def roofline(args, agent):
     flops = 6.0 * macs * nb
     achieved = flops / (ms.value * 1e-3) / 1e12
     small = lay.F <= 64 and lay.A == 1 and lay.L <= 8 and os.environ.get("PH_GRAD_FAST", "1") != "0"
-    kernel = "ppo_grad_fast_kernel<false>" if small else "ppo_grad_kernel<64,LP,false>"
+    kernel = (f"ppo_grad_fast_kernel<false, {lay.L}, {'true' if (lay.F < 64 and type(pol.observation_space).__name__ == 'Box') else 'false'}>"
+              if small else "ppo_grad_kernel<64,LP,false>")
     out = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": 157.3,
            "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None, "launch_ms": ms.value,
            "flops_per_launch": flops}
@@ -241,20 +242,31 @@ def roofline(args, agent):
         del keep
     except Exception as exc:  # noqa: BLE001 -- measurement extra, never fatal
         out["gae_saturating"] = {"error": str(exc)}
-    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc, separate runs), if recorded
+    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc, separate runs).  The digest names the
+    # hash of the kernel's sources at collection time; counters of another kernel are refused, not reported.
     try:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from pmc_digest import kernel_source_sha256
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_ppo_grad.json")))
-        if rec["kernel"].split("::")[-1] == kernel:    # the committed counters belong to this kernel
+        now = kernel_source_sha256(ROOT)
+        if not small or "ppo_grad_fast_kernel" not in rec.get("kernel", ""):
+            out["traffic_source"] = "no committed PMC passes for this workload's kernel"
+        elif rec.get("kernel_source_sha256") != now:
+            out["traffic_source"] = (f"REFUSED: profiles/pmc_ppo_grad.json was collected on kernel sources {str(rec.get('kernel_source_sha256'))[:12]} "
+                                     f"(commit {str(rec.get('git_head'))[:8]}), this tree's hash is {now[:12]}: re-run scripts/profile_round.sh "
+                                     "+ scripts/pmc_digest.py")
+        else:
             out["traffic"] = rec["hbm_bytes_per_launch"]
-            out["traffic_source"] = rec["source"]
+            out["traffic_algorithmic"] = rec["algorithmic_bytes_per_launch"]
+            out["traffic_source"] = rec["source"] + f" @ {str(rec.get('git_head'))[:8]}"
             ig = rec.get("in_graph")
             if ig:   # the same kernel inside the whole-iteration graphs (committed rocprofv3 kernel trace of this command)
                 out["in_graph"] = {"avg_launch_ms": ig["avg_us"] * 1e-3, "achieved": flops / (ig["avg_us"] * 1e-6) / 1e12,
                                    "frac": flops / (ig["avg_us"] * 1e-6) / 1e12 / 157.3, "source": ig["source"]}
             if "sq" in rec:
                 out["mfma_util_percent"] = rec["sq"].get("MfmaUtil_percent")
-    except Exception:  # noqa: BLE001
-        pass
+    except Exception as exc:  # noqa: BLE001
+        out["traffic_source"] = f"unavailable ({exc})"
     return out
 
 
