@@ -73,7 +73,7 @@ def main():
     waves = 2 * 256 * 4
     sq = {k: v["mean"] for k, v in {**m, **g}.items()}
     digest = {
-        "kernel": "ph::" + (row_iso["name"].split("ph::")[-1].split("(")[0] if row_iso else K),
+        "kernel": (re.search(r"ph::ppo_grad_fast_kernel<[^>]*>", row_iso["name"]).group(0) if row_iso else "ph::" + K),
         "round": tag,
         "kernel_source_sha256": kernel_source_sha256(),
         "kernel_sources": list(KERNEL_SOURCES),
