@@ -183,6 +183,42 @@ def cpu_baseline(args):
     return out
 
 
+def gpu_reference_semantics_e1(args, device):
+    """The engine driven exactly as the reference drives a partner (agents.py:111-203 on SB3's defaults): n_envs = 1, one
+    get_action / update pair per environment step with the action copied back to the host every step (the environment is a
+    host program), n_steps rows, batch 64, 10 epochs = 10 * n_steps / 64 dependent Adam steps per rollout.  Same bounded
+    sample as cpu_baseline's reference_semantics_E1 (512 of the 2048 default steps).  This is the launch-latency-bound corner
+    of the engine: printed so that nobody has to guess what E = 1 costs on the GPU next to the CPU figure."""
+    from pantheonrl_amd import PPO, spaces as sp
+    from pantheonrl_amd.common import Observation, OnPolicyAgent
+    wl = WORKLOADS[args.workload]
+    obs_space = sp.Box(-np.inf, np.inf, (wl["obs"][1],)) if wl["obs"][0] == "box" else (
+        sp.Discrete(wl["obs"][1][0]) if len(wl["obs"][1]) == 1 else sp.MultiDiscrete(wl["obs"][1]))
+    act_space = sp.Discrete(wl["act"][0]) if len(wl["act"]) == 1 else sp.MultiDiscrete(wl["act"])
+    env = type("SpacesOnly", (), dict(observation_space=obs_space, action_space=act_space, _is_dummy_space_env=True))()
+    T1 = 512
+    model = PPO("MlpPolicy", env, n_steps=T1, n_envs=1, batch_size=64, n_epochs=10, seed=0, device=device)
+    agent = OnPolicyAgent(model)
+    rng = np.random.default_rng(0)
+    obs = (rng.standard_normal((2 * T1 + 1, wl["obs"][1])).astype(np.float32) if wl["obs"][0] == "box" else
+           (rng.random((2 * T1 + 1, len(wl["obs"][1]))) * np.asarray(wl["obs"][1])).astype(np.int64).astype(np.float32))
+    rew = rng.standard_normal(2 * T1 + 1).astype(np.float32)
+
+    def run(lo, hi):
+        for t in range(lo, hi):
+            agent.get_action(Observation(obs[t]))
+            agent.update(float(rew[t]), False)
+    run(0, T1 + 1)                    # fills the buffer and triggers the first train() (warm-up: workspaces, first launches)
+    th.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    run(T1 + 1, 2 * T1 + 1)           # T1 steps including one whole train() of 80 dependent Adam steps
+    th.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    return {"value": T1 / dt, "unit": "agent-steps/s", "ms_per_env_step_incl_update": 1e3 * dt / T1,
+            "sample": f"n_envs=1, {T1} get_action/update pairs from the host (action read back every step) + one train() "
+                      f"(batch 64, 10 epochs = {10 * T1 // 64} Adam steps)"}
+
+
 def roofline(args, agent):
     """dominant kernel = ppo_grad_kernel (gather + forward + loss + backward of one minibatch); MFMA-bound.
     achieved = algorithmic FLOPs per launch (6*M per row, M = forward MACs) / mean launch duration measured
@@ -338,9 +374,14 @@ def bench_roundrobin(args, device, rank, world, json_fd, tdist):
                   "config": {"workload": wl["name"] + f", ego vs {K} OnPolicy partners, round-robin per environment",
                              "n_envs": args.n_envs, "n_steps": args.n_steps, "batch_size": args.batch_size,
                              "n_epochs": args.n_epochs, "partner_updates": int(upd.item()),
-                             "parallelism": f"one agent per gpu x{world} (ego + {K} partners; per step one broadcast of the "
-                                            "routing block and one all-gather of actions, torch.distributed "
-                                            f"{args.backend})", "launch_mode": "roundrobin"}}
+                             "parallelism": f"one agent per gpu x{world} (ego + {K} partners; per step the routing block to "
+                                            "the partners and their actions back: " + (
+                                                "direct stores into IPC-mapped receive areas + stamps, ONE native call per "
+                                                "iteration and rank" if getattr(side, "native", False) else
+                                                f"one broadcast + one all-gather of torch.distributed {args.backend} per step") + ")",
+                             "carrier": "engine-side" if getattr(side, "native", False) else "torch.distributed",
+                             "p2p_timeouts": side.link.timeouts() if getattr(side, "native", False) else 0,
+                             "launch_mode": "roundrobin"}}
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     tdist.barrier()
     tdist.destroy_process_group()
@@ -548,6 +589,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(args)
             result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+            try:
+                result["gpu_reference_semantics_E1"] = gpu_reference_semantics_e1(args, device)
+            except Exception as exc:  # noqa: BLE001 -- an extra figure, never fatal
+                result["gpu_reference_semantics_E1"] = {"error": str(exc)}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if distributed:

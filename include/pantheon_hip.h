@@ -35,12 +35,14 @@ extern "C" {
 
 #define PH_ABI_VERSION 3   /* 2: + ph_agent_*, ph_bc_*, ph_adap_*, ph_scripted_rollout, ph_liar_selfplay_rollout, ph_roundrobin_env_step,
                                   ph_buffer_compact_columns (additions only: every v1 signature is unchanged)
-                              3: + ph_selfplay_rollout_persistent, PH_STEP_FIX_ILLEGAL / _MASK_ENV_ONLY, ph_modular_* (additions only) */
+                              3: + ph_selfplay_rollout_persistent, PH_STEP_FIX_ILLEGAL / _MASK_ENV_ONLY, ph_modular_*, ph_roundrobin_*_iteration
+                                  (additions only) */
 #define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
 #define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
 #define PH_MAX_LOGITS 64 /* max total policy logits L */
 #define PH_NSTAT 8       /* per-minibatch stats record, see ph_ppo_train */
 #define PH_MOD_MAX 8     /* max partner modules of a ModularPolicy (ph_modular_*) */
+#define PH_MAX_RANKS 16   /* ranks of one node in the peer-to-peer exchange layouts */
 
 #define PH_SPACE_BOX 0      /* gym.spaces.Box, flattened length n                        */
 #define PH_SPACE_DISCRETE 1 /* Discrete(k) (n=1, nvec={k}) or MultiDiscrete(nvec) (n=len) */
@@ -156,6 +158,59 @@ int ph_buffer_add_reward_joint(ph_ctx *ctx, const ph_rollout *rb, int pos, const
 int ph_roundrobin_env_step(ph_ctx *ctx, const int *joint_actions, int *partnerid, const float *base_reward,
                            const float *done, float *reward_out, int *alt_action_out, float *next_block, int block_ld,
                            int n_partners, float bonus, int n);
+/* The same layout with ONE native call per iteration and rank (no host tensor op, collective call or synchronisation per
+ * environment step).  Every rank owns a fine-grained receive area (ph_p2p_alloc) that the others map through HIP IPC
+ * (ph_p2p_open): [64 stamp words | slot 0 | slot 1], ph_rr_area_bytes() long.  Per step t of iteration i (stamp i * T + t + 1):
+ *   rank 0 : ego forward + rollout-buffer row (its actions land in row 0 of its own slot t & 1) -> the routing block of step t
+ *            stored into every partner's slot t & 1, then the partner's block stamp -> wait for the K action stamps -> the
+ *            transition of ph_roundrobin_env_step (writes the header of block t + 1)            multiagentenv.py:149-243
+ *   rank 1+k: wait for the block stamp -> Agent.update of the previous step where it acted, this step's record mask, room and
+ *            episode_start (agents.py:186-203,176) -> ph_policy_forward_ragged -> advance the write rows, store its actions into
+ *            row 1 + k of rank 0's slot, then its action stamp.
+ * A step is ping-pong between rank 0 and each partner, so two slots suffice.  Waits are bounded; a timeout bumps *error.
+ * The caller (roundrobin.py) credits the ego's last reward, runs the learners' updates and decides ONCE per iteration whether a
+ * partner whose columns are full trains (the reference's partner checks before every action, agents.py:126). */
+typedef struct ph_rr_link {
+  int n_partners, rank;                 /* rank 0 = ego, 1 + k = partner k */
+  int n, block_ld;                      /* environments; floats per routing-block row (3 + D) */
+  void *area[PH_MAX_RANKS];             /* [r] rank r's receive area as mapped in this process (own one included) */
+  unsigned long long *error;            /* local device word */
+  unsigned long long timeout_cycles;    /* bound of one wait, wall_clock64() ticks (100 MHz) */
+} ph_rr_link;
+typedef struct ph_rr_ego {
+  const ph_spec *spec;                  /* host */
+  const float *params;
+  const float *obs_seq;                 /* (T, n, D) the ego's observations */
+  const float *base_reward_seq;         /* (T, n) */
+  const float *done_seq;                /* (T, n) */
+  float *blocks;                        /* (T, n, block_ld): observation columns prefilled, headers written step by step */
+  int *partnerid;                       /* (n) in/out */
+  float *rewards;                       /* (T, n) out */
+  int *alt_actions;                     /* (T, n) out */
+  int *partner_trace;                   /* (T, n) out */
+  const float *episode_start0;          /* (n) */
+  unsigned long long seed, counter0;
+  float *values, *log_probs;            /* (n) */
+  const ph_rollout *rb;                 /* host; rows 0 .. T-1 */
+  float bonus;
+} ph_rr_ego;
+typedef struct ph_rr_partner {
+  const ph_spec *spec;                  /* host */
+  const float *params;
+  float *obs_scratch;                   /* (n, D) */
+  float *es_scratch;                    /* (n) */
+  unsigned char *can_scratch;           /* (n) */
+  int *pos;                             /* (n) per-environment write rows, in/out */
+  unsigned char *boundary, *term, *open, *prev_mask;   /* (n) RaggedVecOnPolicyAgent's book-keeping, in/out */
+  unsigned long long seed, counter0;
+  int *actions;                         /* (n) */
+  float *values, *log_probs;            /* (n) */
+  const ph_rollout *rb;                 /* host */
+} ph_rr_partner;
+int ph_rr_area_bytes(int n_partners, int n, int block_ld, size_t *bytes_out /* host */);
+int ph_roundrobin_ego_iteration(ph_ctx *ctx, const ph_rr_link *link, const ph_rr_ego *ego, int T, unsigned long long iteration);
+int ph_roundrobin_partner_iteration(ph_ctx *ctx, const ph_rr_link *link, const ph_rr_partner *partner, int T,
+                                    unsigned long long iteration);
 /* RolloutBuffer.reset() <- agents.py:157 : zero-fills every array */
 int ph_buffer_reset(ph_ctx *ctx, const ph_spec *spec, const ph_rollout *rb);
 
@@ -260,7 +315,6 @@ int ph_selfplay_rollout(ph_ctx *ctx, int n_calls, const ph_step_call *calls /* h
  *      its partner's rank only and can run up to world-1 steps ahead of some other rank: ll_slots must be >= T so that no
  *      slot is reused inside an iteration (the unpack of step T-1 waits for every rank, which bounds the skew per iteration).  After the last step the
  *      words of step T-1 are unpacked into this rank's plain receive slot for ordinary consumers. */
-#define PH_MAX_RANKS 16
 #define PH_IPC_HANDLE_BYTES 64
 typedef struct ph_p2p {
   int world, rank, count, T;

@@ -129,6 +129,27 @@ class PhRolloutCall(C.Structure):
                 ("seat", C.c_int), ("partner_seat", C.c_void_p), ("bonus", C.c_float)]
 
 
+class PhRRLink(C.Structure):
+    """ph_rr_link: the engine-side round-robin layout's peer-mapped receive areas"""
+    _fields_ = [("n_partners", C.c_int), ("rank", C.c_int), ("n", C.c_int), ("block_ld", C.c_int),
+                ("area", C.c_void_p * PH_MAX_RANKS), ("error", C.c_void_p), ("timeout_cycles", C.c_ulonglong)]
+
+
+class PhRREgo(C.Structure):
+    _fields_ = [("spec", C.POINTER(PhSpec)), ("params", C.c_void_p), ("obs_seq", C.c_void_p), ("base_reward_seq", C.c_void_p),
+                ("done_seq", C.c_void_p), ("blocks", C.c_void_p), ("partnerid", C.c_void_p), ("rewards", C.c_void_p),
+                ("alt_actions", C.c_void_p), ("partner_trace", C.c_void_p), ("episode_start0", C.c_void_p),
+                ("seed", C.c_ulonglong), ("counter0", C.c_ulonglong), ("values", C.c_void_p), ("log_probs", C.c_void_p),
+                ("rb", C.POINTER(PhRollout)), ("bonus", C.c_float)]
+
+
+class PhRRPartner(C.Structure):
+    _fields_ = [("spec", C.POINTER(PhSpec)), ("params", C.c_void_p), ("obs_scratch", C.c_void_p), ("es_scratch", C.c_void_p),
+                ("can_scratch", C.c_void_p), ("pos", C.c_void_p), ("boundary", C.c_void_p), ("term", C.c_void_p),
+                ("open", C.c_void_p), ("prev_mask", C.c_void_p), ("seed", C.c_ulonglong), ("counter0", C.c_ulonglong),
+                ("actions", C.c_void_p), ("values", C.c_void_p), ("log_probs", C.c_void_p), ("rb", C.POINTER(PhRollout))]
+
+
 class PhLiarSelfPlay(C.Structure):
     """ph_liar_selfplay: every device pointer of the vectorised Liar's Dice self-play step"""
     _fields_ = [("n", C.c_int), ("spec", C.POINTER(PhSpec)),
@@ -207,6 +228,9 @@ SIGNATURES = {
     "ph_p2p_ll_unpack": [_vp, C.POINTER(PhP2P), _i],
     "ph_selfplay_rollout_p2p": [_vp, _i, C.POINTER(PhStepCall), _i, _vp, C.POINTER(PhP2P)],
     "ph_selfplay_rollout_persistent": [_vp, _i, C.POINTER(PhRolloutCall), _i, C.POINTER(PhP2P), _i],
+    "ph_rr_area_bytes": [_i, _i, _i, C.POINTER(C.c_size_t)],
+    "ph_roundrobin_ego_iteration": [_vp, C.POINTER(PhRRLink), C.POINTER(PhRREgo), _i, _ull],
+    "ph_roundrobin_partner_iteration": [_vp, C.POINTER(PhRRLink), C.POINTER(PhRRPartner), _i, _ull],
     "ph_modular_layout": [C.POINTER(PhSpec), C.POINTER(PhModular), C.POINTER(PhLayout), C.POINTER(PhLayout), C.POINTER(_i)],
     "ph_modular_forward": [_vp, C.POINTER(PhSpec), C.POINTER(PhModular), _vp, _i, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp,
                            _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(PhRollout), _i, _vp, _vp, _i],

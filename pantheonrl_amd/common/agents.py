@@ -73,7 +73,10 @@ class OnPolicyAgent(Agent):
 
     # -- the two callbacks ---------------------------------------------------------------------------------------
     def get_action(self, obs: Observation, record: bool = True) -> np.ndarray:
-        raw_obs, mask = obs.obs, getattr(obs, "action_mask", None)
+        # The reference hands the policy obs.obs alone (agents.py:162: action_from_policy(obs.obs, ...)): a plain SB3 policy never
+        # sees Observation.action_mask, the environment repairs illegal samples (pettingzoo.py:81-82).  `use_action_mask = True`
+        # (an extension, off by default) applies ModularPolicy's -30 logit offset (modular/policies.py:330-333) instead.
+        raw_obs, mask = obs.obs, (getattr(obs, "action_mask", None) if getattr(self, "use_action_mask", False) else None)
         model = self.model
         buf = model.rollout_buffer
 

@@ -453,6 +453,134 @@ int ph_roundrobin_env_step(ph_ctx* ctx, const int* joint_actions, int* partnerid
   return 0;
 }
 
+// ---- engine-side round-robin layout (config 4) -------------------------------------------------------------------------------
+namespace {
+constexpr size_t RR_STAMP_BYTES = 64 * sizeof(unsigned long long);
+size_t rr_slot_bytes(int n_partners, int n, int block_ld) {
+  const size_t blk = (size_t)n * block_ld * sizeof(float), act = (size_t)(n_partners + 1) * n * sizeof(int);
+  return ((blk > act ? blk : act) + 255) / 256 * 256;
+}
+int check_rr_link(const ph_rr_link* l) {
+  if (!l) return fail("null ph_rr_link");
+  if (l->n_partners < 1 || l->n_partners + 1 > PH_MAX_RANKS) return fail("ph_rr_link: n_partners out of range");
+  if (l->rank < 0 || l->rank > l->n_partners || l->n <= 0 || l->block_ld <= 3) return fail("ph_rr_link: bad rank / n / block_ld");
+  if (!l->error) return fail("ph_rr_link: error word required");
+  for (int r = 0; r <= l->n_partners; ++r)
+    if (!l->area[r]) return fail("ph_rr_link: unmapped peer area");
+  return 0;
+}
+unsigned long long* rr_stamps(const ph_rr_link* l, int rank) { return (unsigned long long*)l->area[rank]; }
+char* rr_slot(const ph_rr_link* l, int rank, int parity) {
+  return (char*)l->area[rank] + RR_STAMP_BYTES + (size_t)parity * rr_slot_bytes(l->n_partners, l->n, l->block_ld);
+}
+}  // namespace
+
+int ph_rr_area_bytes(int n_partners, int n, int block_ld, size_t* bytes_out) {
+  if (!bytes_out || n_partners < 1 || n <= 0 || block_ld <= 3) return fail("ph_rr_area_bytes: bad argument");
+  *bytes_out = RR_STAMP_BYTES + 2 * rr_slot_bytes(n_partners, n, block_ld);
+  return 0;
+}
+
+int ph_roundrobin_ego_iteration(ph_ctx* ctx, const ph_rr_link* link, const ph_rr_ego* ego, int T, unsigned long long iteration) {
+  DevGuard dev_guard(ctx);
+  if (!ctx || !ego || T <= 0) return fail("ph_roundrobin_ego_iteration: bad argument");
+  if (check_rr_link(link)) return 1;
+  if (link->rank != 0) return fail("ph_roundrobin_ego_iteration: the ego lives on rank 0");
+  if (!ego->params || !ego->obs_seq || !ego->base_reward_seq || !ego->done_seq || !ego->blocks || !ego->partnerid ||
+      !ego->rewards || !ego->episode_start0 || !ego->rb)
+    return fail("ph_roundrobin_ego_iteration: null argument");
+  if (check_rb(ego->rb)) return 1;
+  if (ego->rb->E != link->n || ego->rb->T < T) return fail("ph_roundrobin_ego_iteration: rollout buffer shape");
+  ph::NetDims nd;
+  if (resolve(ctx, ego->spec, &nd)) return 1;
+  const int n = link->n, K = link->n_partners, ld = link->block_ld;
+  for (int t = 0; t < T; ++t) {
+    const unsigned long long want = iteration * (unsigned long long)T + (unsigned long long)t + 1ull;
+    int* slot = (int*)rr_slot(link, 0, t & 1);   // (1 + K, n): row 0 = the ego's actions of this step
+    if (ph_policy_forward(ctx, ego->spec, ego->params, ego->obs_seq + (size_t)t * n * nd.D, n, nullptr, nullptr, nullptr, ego->seed,
+                          ego->counter0 + (unsigned long long)t, 0, slot, nullptr, ego->values, ego->log_probs, nullptr, nullptr,
+                          ego->rb, t, t == 0 ? ego->episode_start0 : ego->done_seq + (size_t)(t - 1) * n,
+                          t == 0 ? nullptr : ego->rewards + (size_t)(t - 1) * n, 0))
+      return 1;
+    ph::RRSend sd;
+    std::memset(&sd, 0, sizeof(sd));
+    sd.src = ego->blocks + (size_t)t * n * ld;
+    sd.n_floats = n * ld;
+    for (int k = 0; k < K; ++k) {
+      sd.dst[k] = (float*)rr_slot(link, 1 + k, t & 1);
+      sd.stamp[k] = rr_stamps(link, 1 + k);
+    }
+    sd.want = want;
+    PH_HIP(ph::launch_rr_send_block(sd, K, ctx->stream));
+    ph::RREnvStep es;
+    std::memset(&es, 0, sizeof(es));
+    es.stamps = rr_stamps(link, 0);
+    es.want = want;
+    es.timeout = link->timeout_cycles;
+    es.error = link->error;
+    es.joint = slot;
+    es.partnerid = ego->partnerid;
+    es.partner_trace = ego->partner_trace ? ego->partner_trace + (size_t)t * n : nullptr;
+    es.base = ego->base_reward_seq + (size_t)t * n;
+    es.done = ego->done_seq + (size_t)t * n;
+    es.reward_out = ego->rewards + (size_t)t * n;
+    es.alt_action_out = ego->alt_actions ? ego->alt_actions + (size_t)t * n : nullptr;
+    es.next_block = ego->blocks + (size_t)((t + 1) % T) * n * ld;
+    es.block_ld = ld;
+    es.n_partners = K;
+    es.n = n;
+    es.bonus = ego->bonus;
+    PH_HIP(ph::launch_rr_env_step(es, ctx->stream));
+  }
+  return 0;
+}
+
+int ph_roundrobin_partner_iteration(ph_ctx* ctx, const ph_rr_link* link, const ph_rr_partner* pa, int T,
+                                    unsigned long long iteration) {
+  DevGuard dev_guard(ctx);
+  if (!ctx || !pa || T <= 0) return fail("ph_roundrobin_partner_iteration: bad argument");
+  if (check_rr_link(link)) return 1;
+  if (link->rank < 1) return fail("ph_roundrobin_partner_iteration: partners live on ranks 1 .. n_partners");
+  if (!pa->params || !pa->obs_scratch || !pa->es_scratch || !pa->can_scratch || !pa->pos || !pa->boundary || !pa->term ||
+      !pa->open || !pa->prev_mask || !pa->actions || !pa->values || !pa->log_probs || !pa->rb)
+    return fail("ph_roundrobin_partner_iteration: null argument");
+  if (check_rb(pa->rb)) return 1;
+  if (pa->rb->E != link->n) return fail("ph_roundrobin_partner_iteration: the rollout buffer must have one column per environment");
+  const int n = link->n, k = link->rank - 1;
+  for (int t = 0; t < T; ++t) {
+    const unsigned long long want = iteration * (unsigned long long)T + (unsigned long long)t + 1ull;
+    ph::RRPartnerStep st;
+    std::memset(&st, 0, sizeof(st));
+    st.block_stamp = rr_stamps(link, link->rank);
+    st.act_stamp = rr_stamps(link, 0) + 1 + k;
+    st.want = want;
+    st.timeout = link->timeout_cycles;
+    st.error = link->error;
+    st.block = (const float*)rr_slot(link, link->rank, t & 1);
+    st.block_ld = link->block_ld;
+    st.n = n;
+    st.T = pa->rb->T;
+    st.k = k;
+    st.rewards = pa->rb->rewards;
+    st.pos = pa->pos;
+    st.boundary = pa->boundary;
+    st.term = pa->term;
+    st.open = pa->open;
+    st.prev_mask = pa->prev_mask;
+    st.can = pa->can_scratch;
+    st.es = pa->es_scratch;
+    st.obs_out = pa->obs_scratch;
+    st.actions = pa->actions;
+    st.act_dst = (int*)rr_slot(link, 0, t & 1) + (size_t)(1 + k) * n;
+    PH_HIP(ph::launch_rr_partner_pre(st, ctx->stream));
+    if (ph_policy_forward_ragged(ctx, pa->spec, pa->params, pa->obs_scratch, nullptr, pa->seed, pa->counter0 + (unsigned long long)t,
+                                 0, pa->actions, pa->values, pa->log_probs, pa->rb, pa->pos, pa->can_scratch, pa->es_scratch))
+      return 1;
+    PH_HIP(ph::launch_rr_partner_post(st, ctx->stream));
+  }
+  return 0;
+}
+
 int ph_buffer_reset(ph_ctx* ctx, const ph_spec* spec, const ph_rollout* rb) {
   DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");

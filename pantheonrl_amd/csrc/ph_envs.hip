@@ -229,6 +229,131 @@ hipError_t launch_p2p_ll_unpack(const ph_p2p& x, int t, hipStream_t s, int slot)
   return hipGetLastError();
 }
 
+// ---- BASELINE config 4 engine-side (include/pantheon_hip.h: ph_rr_link) -------------------------------------------------------
+// One agent per GPU, ego on rank 0 against K round-robin partners: what crosses ranks per environment step is the routing block
+// (rank 0 -> partners) and every partner's actions (-> rank 0).  Both travel as direct stores into IPC-mapped fine-grained
+// receive areas followed by a monotonic stamp (iteration * T + t + 1); consumers poll the stamp (bounded) inside the kernel
+// that needs the data.  A step is strictly ping-pong between rank 0 and each partner, so two slots (step parity) suffice.
+__device__ __forceinline__ bool rr_wait(const unsigned long long* flag, unsigned long long want, unsigned long long timeout,
+                                        unsigned long long* error) {
+  const long long t0 = wall_clock64();
+  while (true) {
+    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
+    if ((unsigned long long)(wall_clock64() - t0) > timeout) {
+      atomicAdd(error, 1ull);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+// rank 0: routing block of step t -> every partner's slot, then the stamp.  One workgroup per partner (its stores, a
+// system-scope fence, a barrier, then one lane publishes): block k never waits for another block.
+__global__ __launch_bounds__(1024) void rr_send_block_kernel(RRSend a) {
+  const int k = blockIdx.x;
+  float* dst = a.dst[k];
+  const float4* src4 = reinterpret_cast<const float4*>(a.src);
+  float4* dst4 = reinterpret_cast<float4*>(dst);
+  const int n4 = a.n_floats >> 2;
+  for (int i = threadIdx.x; i < n4; i += blockDim.x) dst4[i] = src4[i];
+  for (int i = (n4 << 2) + threadIdx.x; i < a.n_floats; i += blockDim.x) dst[i] = a.src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(a.stamp[k], a.want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+hipError_t launch_rr_send_block(const RRSend& a, int n_partners, hipStream_t s) {
+  hipLaunchKernelGGL(rr_send_block_kernel, dim3(n_partners), dim3(1024), 0, s, a);
+  return hipGetLastError();
+}
+
+// rank 0: wait for every partner's actions of this step, then the transition (roundrobin_env_step_kernel's arithmetic)
+__global__ __launch_bounds__(256) void rr_env_step_kernel(RREnvStep a) {
+  if (threadIdx.x < a.n_partners) (void)rr_wait(a.stamps + 1 + threadIdx.x, a.want, a.timeout, a.error);   // a timeout bumps *error
+  __syncthreads();
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.n) return;
+  int pid = a.partnerid[e];
+  pid = pid < 0 ? 0 : (pid >= a.n_partners ? a.n_partners - 1 : pid);
+  if (a.partner_trace) a.partner_trace[e] = pid;
+  const int a_ego = a.joint[e];
+  const int a_alt = __hip_atomic_load(a.joint + (size_t)(1 + pid) * a.n + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const float r = a.base[e] + ((a_ego == a_alt) ? a.bonus : 0.f);
+  a.reward_out[e] = r;
+  if (a.alt_action_out) a.alt_action_out[e] = a_alt;
+  const float d = a.done[e];
+  const int next = (d != 0.f) ? (pid + 1) % a.n_partners : pid;
+  a.partnerid[e] = next;
+  float* row = a.next_block + (size_t)e * a.block_ld;
+  row[0] = (float)next;
+  row[1] = r;
+  row[2] = d;
+}
+hipError_t launch_rr_env_step(const RREnvStep& a, hipStream_t s) {
+  hipLaunchKernelGGL(rr_env_step_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// partner k, before its forward: wait for the routing block; Agent.update of the previous step where this partner acted
+// (agents.py:186-203: reward into the open row, episode boundary, terminal flag); which environments it acts in now, whether
+// their column has room, the episode_start of the row; the partner-seat observation compacted for the forward kernel
+__global__ __launch_bounds__(256) void rr_partner_pre_kernel(RRPartnerStep a) {
+  if (threadIdx.x == 0) (void)rr_wait(a.block_stamp, a.want, a.timeout, a.error);   // a timeout bumps *error
+  __syncthreads();
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < a.n) {
+    const float* row = a.block + (size_t)e * a.block_ld;
+    const float pid = row[0], r = row[1], d = row[2];
+    const bool m = a.prev_mask[e] != 0, open = a.open[e] != 0;
+    const int p = a.pos[e];
+    if (m && open && p >= 1 && p <= a.T) a.rewards[(size_t)(p - 1) * a.n + e] += r;
+    const bool dd = m && d != 0.f;           // the done flag counts only where this partner acted (blk[:, 2] * mask)
+    bool boundary = (a.boundary[e] != 0) || dd;
+    bool term = (a.term[e] != 0) || (m && open && dd);
+    const bool mask = pid == (float)a.k;
+    const bool room = p < a.T;
+    const bool can = mask && room, blocked = mask && !room;
+    a.es[e] = boundary ? 1.f : 0.f;
+    a.can[e] = can ? 1 : 0;
+    // RaggedVecOnPolicyAgent.get_action's book-keeping after the forward (the forward reads pos / can / es only)
+    a.boundary[e] = can ? 0 : (boundary ? 1 : 0);
+    a.term[e] = can ? 0 : (term ? 1 : 0);
+    a.open[e] = can ? 1 : (blocked ? 0 : (open ? 1 : 0));
+    a.prev_mask[e] = mask ? 1 : 0;
+  }
+  // observation columns of the block -> contiguous (n, D)
+  const int D = a.block_ld - 3;
+  const size_t total = (size_t)a.n * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e2 = i / D, c = i - e2 * D;
+    a.obs_out[i] = a.block[e2 * a.block_ld + 3 + c];
+  }
+}
+hipError_t launch_rr_partner_pre(const RRPartnerStep& a, hipStream_t s) {
+  hipLaunchKernelGGL(rr_partner_pre_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// partner k, after its forward: advance the write rows of the columns that recorded, send the actions to rank 0, stamp
+__global__ __launch_bounds__(1024) void rr_partner_post_kernel(RRPartnerStep a) {
+  for (int e = threadIdx.x; e < a.n; e += blockDim.x) {
+    if (a.can[e] && a.pos[e] < a.T) a.pos[e] += 1;
+    __builtin_nontemporal_store(a.actions[e], a.act_dst + e);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(a.act_stamp, a.want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+hipError_t launch_rr_partner_post(const RRPartnerStep& a, hipStream_t s) {
+  hipLaunchKernelGGL(rr_partner_post_kernel, dim3(1), dim3(1024), 0, s, a);
+  return hipGetLastError();
+}
+
 // HistoryQueue for n envs: one lane per (env, feature) walks its column of frames from the oldest to the newest
 __global__ void framestack_push_kernel(float* __restrict__ stack, const float* __restrict__ obs,
                                        const unsigned char* __restrict__ reset_mask,

@@ -284,6 +284,48 @@ hipError_t launch_p2p_push(const ph_p2p& x, const int* local, int t, hipStream_t
 hipError_t launch_p2p_wait(const ph_p2p& x, int t, hipStream_t s);
 hipError_t launch_p2p_ll_unpack(const ph_p2p& x, int t, hipStream_t s, int slot = -1 /* default: t mod ll_slots */);
 hipError_t launch_p2p_ll_push(const ph_p2p& x, const int* local, int t, hipStream_t s);
+// engine-side round-robin layout (ph_envs.hip)
+struct RRSend {
+  const float* src;                      // this step's routing block (n * block_ld floats)
+  int n_floats;
+  float* dst[PH_MAX_RANKS];              // [k] partner k's slot of this step's parity
+  unsigned long long* stamp[PH_MAX_RANKS];   // [k] partner k's block stamp
+  unsigned long long want;
+};
+struct RREnvStep {
+  const unsigned long long* stamps;      // rank 0's stamp array: [1 + k] = partner k's action stamp
+  unsigned long long want, timeout;
+  unsigned long long* error;
+  const int* joint;                      // (1 + K, n): row 0 the ego's actions, row 1 + k partner k's (this step's slot)
+  int* partnerid;
+  int* partner_trace;                    // (n) or null
+  const float* base;
+  const float* done;
+  float* reward_out;
+  int* alt_action_out;
+  float* next_block;
+  int block_ld, n_partners, n;
+  float bonus;
+};
+struct RRPartnerStep {
+  const unsigned long long* block_stamp;
+  unsigned long long* act_stamp;         // on rank 0
+  unsigned long long want, timeout;
+  unsigned long long* error;
+  const float* block;                    // this step's routing block as received (n, block_ld)
+  int block_ld, n, T, k;
+  float* rewards;                        // the partner's rollout-buffer rewards (T, n)
+  int* pos;
+  unsigned char *boundary, *term, *open, *prev_mask, *can;
+  float* es;
+  float* obs_out;                        // (n, D)
+  const int* actions;                    // (n) this step's sampled actions
+  int* act_dst;                          // rank 0's slot row 1 + k
+};
+hipError_t launch_rr_send_block(const RRSend& a, int n_partners, hipStream_t s);
+hipError_t launch_rr_env_step(const RREnvStep& a, hipStream_t s);
+hipError_t launch_rr_partner_pre(const RRPartnerStep& a, hipStream_t s);
+hipError_t launch_rr_partner_post(const RRPartnerStep& a, hipStream_t s);
 // single-chunk / small-Discrete-head kernel (ph_ppo_fast.hip); eligible() says whether the spec fits it.  Its slabs are in
 // the MFMA accumulators' register order -- [net][RS_NET] floats per workgroup (16-byte stores, 1 KB contiguous per wave
 // instruction) -- and the reduce kernel maps slab positions to parameter indices through the table grad_slab_map fills.

@@ -22,9 +22,16 @@ hosts partner k.  Per environment step:
      where the episode ended) and credits the ego (`update`, folded into its next step's launch).
 
 Partner selection stays a rule over small integers (the kernel applies the reference's `(id + 1) % K`); no gradient or
-parameter ever crosses ranks.  The collectives are torch.distributed's (backend nccl = RCCL over xGMI; gloo with host
-staging when several test ranks share one GPU): a broadcast of E*(3+D)*4 B (266 KB at E = 1024, D = 62) and an all-gather
-of (K+1)*E*4 B per step, both latency-bound.
+parameter ever crosses ranks.
+
+Two carriers for steps 1 and 3.  The ENGINE-SIDE one (default on GPUs, `RoundRobinLink`): every rank owns a fine-grained receive
+area that the others map through HIP IPC; rank 0 stores the routing block straight into the partners' areas and the partners
+store their actions straight into rank 0's, each followed by a monotonic stamp that the consuming kernel polls (bounded) --
+and the T steps of an iteration are enqueued by ONE native call per rank (`ph_roundrobin_ego_iteration` /
+`ph_roundrobin_partner_iteration`): no host tensor op, collective call or synchronisation per environment step.  With it a
+partner decides once per iteration (one host read) whether its full columns are trained on; the reference's partner checks
+before every action (agents.py:126).  The HOST-DRIVEN one (`native=False`, CPU protocol tests): torch.distributed's broadcast
+of E*(3+D)*4 B and all-gather of (K+1)*E*4 B per step, every step's book-keeping as torch ops.
 """
 from __future__ import annotations
 
@@ -36,6 +43,54 @@ import torch.distributed as dist
 from . import _native as nat
 
 HEADER = 3   # routing-block columns before the observation: partner id, previous reward, previous done
+
+
+class RoundRobinLink:
+    """the engine-side carrier: this rank's receive area, every other rank's area mapped through HIP IPC (handles travel
+    through the process group's store), and the ph_rr_link descriptor the native iterations take"""
+
+    _generation = 0
+
+    def __init__(self, ctx, n_partners: int, n_envs: int, obs_dim: int, device, timeout_s: float = 5.0):
+        import ctypes as C
+        self.ctx, self.device = ctx, device
+        rank, world = dist.get_rank(), dist.get_world_size()
+        size = C.c_size_t(0)
+        nat.check(ctx.lib.ph_rr_area_bytes(n_partners, n_envs, HEADER + obs_dim, C.byref(size)))
+        base, handle = C.c_void_p(), (C.c_ubyte * 64)()
+        nat.check(ctx.lib.ph_p2p_alloc(ctx.handle, size.value + 64, C.byref(base), handle))
+        store = dist.distributed_c10d._get_default_store()
+        RoundRobinLink._generation += 1
+        gen = RoundRobinLink._generation
+        store.set(f"pantheonrl_amd/rr/{gen}/{rank}", bytes(handle))
+        link = nat.PhRRLink()
+        link.n_partners, link.rank, link.n, link.block_ld = n_partners, rank, n_envs, HEADER + obs_dim
+        self._mapped = []
+        for r in range(world):
+            if r == rank:
+                link.area[r] = base.value
+                continue
+            peer = (C.c_ubyte * 64).from_buffer_copy(store.get(f"pantheonrl_amd/rr/{gen}/{r}"))
+            mapped = C.c_void_p()
+            nat.check(ctx.lib.ph_p2p_open(ctx.handle, peer, C.byref(mapped)))
+            link.area[r] = mapped.value
+            self._mapped.append(mapped)
+        link.error = base.value + size.value          # the spare 64 bytes behind the area
+        link.timeout_cycles = int(timeout_s * 1e8)
+        self.link, self._base, self._size = link, base, size.value
+
+        class _View:
+            def __init__(self, ptr):
+                self.__cuda_array_interface__ = {"shape": (2,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+        self._error = th.as_tensor(_View(link.error), device=device)
+
+    def timeouts(self) -> int:
+        return int(self._error[0].item())
+
+
+def _native_wanted(device) -> bool:
+    import os
+    return th.device(device).type == "cuda" and os.environ.get("PH_RR_NATIVE", "1") != "0"
 
 
 class _Collectives:
@@ -87,8 +142,46 @@ class RoundRobinEgoRank:
         self.alt_actions = th.zeros((T, E), dtype=th.int32, device=dev)
         self.partner_trace = th.zeros((T, E), dtype=th.int32, device=dev)        # who was partnered where (tests / info)
         self._lib, self._h = (pol.ctx.lib, pol.ctx.handle) if env_step is None else (None, None)
+        self.link: Optional[RoundRobinLink] = None
+        self.iteration = 0
+        self._first_start = th.ones(E, dtype=th.float32, device=dev)
+
+    def attach(self, link: RoundRobinLink) -> None:
+        import ctypes as C
+        self.link = link
+        ego, d = self.ego, self.data
+        pol, rb = ego.model.policy, ego.model.rollout_buffer
+        c = nat.PhRREgo()
+        c.spec, c.params = C.pointer(pol.spec), pol.params.data_ptr()
+        c.obs_seq, c.base_reward_seq, c.done_seq = d.obs.data_ptr(), d.rewards.data_ptr(), d.dones.data_ptr()
+        c.blocks, c.partnerid, c.rewards = self.blocks.data_ptr(), self.partnerid.data_ptr(), self.rewards.data_ptr()
+        c.alt_actions, c.partner_trace = self.alt_actions.data_ptr(), self.partner_trace.data_ptr()
+        c.episode_start0, c.seed = self._first_start.data_ptr(), pol._seed
+        c.values, c.log_probs, c.rb, c.bonus = ego.values.data_ptr(), ego.log_probs.data_ptr(), C.pointer(rb.c_struct()), self.bonus
+        self._c = c
+
+    def _run_iteration_native(self) -> None:
+        """the T steps as ONE native call: forward, routing block into the partners' areas, wait for their actions, transition"""
+        import ctypes as C
+        ego, d, T = self.ego, self.data, self.T
+        pol, rb = ego.model.policy, ego.model.rollout_buffer
+        ego.bind_stream()
+        ego.flush_rewards()
+        self._first_start.copy_(ego._last_episode_starts)
+        self._c.counter0 = pol._counter + 1
+        nat.check(self._lib.ph_roundrobin_ego_iteration(self._h, C.byref(self.link.link), C.byref(self._c), T, self.iteration))
+        pol._counter += T
+        rb.pos, rb.full = T, True
+        ego.n_steps += T
+        ego.num_timesteps += T * self.E
+        ego._pending = self.rewards[T - 1]            # the last step's reward: flushed by compute_returns
+        ego._last_episode_starts = d.dones[T - 1]
+        self.iteration += 1
+        ego.learn_from_buffer()
 
     def run_iteration(self) -> None:
+        if self.link is not None:
+            return self._run_iteration_native()
         ego, d, T = self.ego, self.data, self.T
         ego.bind_stream()
         for t in range(T):
@@ -122,8 +215,41 @@ class RoundRobinPartnerRank:
         self.joint = th.zeros((self.K + 1, self.E), dtype=th.int32, device=dev)
         self.prev_mask: Optional[th.Tensor] = None
         self.updates = 0
+        self.link: Optional[RoundRobinLink] = None
+        self.iteration = 0
+
+    def attach(self, link: RoundRobinLink) -> None:
+        self.link = link
+        dev = self.agent.model.policy.device
+        self._obs = th.zeros((self.E, self.D), dtype=th.float32, device=dev)
+        self._es = th.zeros(self.E, dtype=th.float32, device=dev)
+        self._can = th.zeros(self.E, dtype=th.uint8, device=dev)
+        self._prev = th.zeros(self.E, dtype=th.uint8, device=dev)
+
+    def _run_iteration_native(self) -> None:
+        import ctypes as C
+        agent = self.agent
+        pol, rb = agent.model.policy, agent.model.rollout_buffer
+        pol._bind()
+        if agent.full():                          # once per iteration (one host read): train on the full columns
+            agent.learn_from_buffer()
+            self.updates += 1
+        c = nat.PhRRPartner()
+        c.spec, c.params = C.pointer(pol.spec), pol.params.data_ptr()
+        c.obs_scratch, c.es_scratch, c.can_scratch = self._obs.data_ptr(), self._es.data_ptr(), self._can.data_ptr()
+        c.pos, c.boundary, c.term, c.open = agent.pos.data_ptr(), agent.boundary.data_ptr(), agent.term.data_ptr(), agent.open.data_ptr()
+        c.prev_mask, c.seed, c.counter0 = self._prev.data_ptr(), pol._seed, pol._counter + 1
+        c.actions, c.values, c.log_probs = agent.actions.data_ptr(), agent.values.data_ptr(), agent.log_probs.data_ptr()
+        c.rb = C.pointer(rb.c_struct())
+        pol._bind()
+        nat.check(agent._lib.ph_roundrobin_partner_iteration(agent._h, C.byref(self.link.link), C.byref(c), self.T, self.iteration))
+        pol._counter += self.T
+        agent.num_timesteps += self.T * self.E
+        self.iteration += 1
 
     def run_iteration(self) -> None:
+        if self.link is not None:
+            return self._run_iteration_native()
         agent = self.agent
         for _ in range(self.T):
             self.col.broadcast(self.block, src=0)
@@ -141,10 +267,12 @@ class RoundRobinPartnerRank:
             self.col.all_gather(self.joint, actions.reshape(-1).contiguous())
 
 
-def make_rank(model, n_partners: int, steps_per_iteration: int, data_ego=None, obs_alt=None, bonus: float = 0.01):
+def make_rank(model, n_partners: int, steps_per_iteration: int, data_ego=None, obs_alt=None, bonus: float = 0.01,
+              native: Optional[bool] = None):
     """this rank's half of the layout: rank 0 -> RoundRobinEgoRank (needs the synthetic inputs), rank 1 + k -> partner k.
     `steps_per_iteration` = the ego's n_steps (every rank walks that many environment steps per iteration; a partner's
-    own buffer length may differ)"""
+    own buffer length may differ).  native: None = the engine-side carrier wherever the ranks' receive areas can be mapped
+    into each other (every rank takes the same decision), False = torch.distributed collectives per step."""
     from .envs.vec import RaggedVecOnPolicyAgent
     from .vec import VecOnPolicyAgent
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -152,9 +280,27 @@ def make_rank(model, n_partners: int, steps_per_iteration: int, data_ego=None, o
         raise ValueError(f"round-robin layout: {n_partners} partners need {n_partners + 1} ranks, the group has {world}")
     rb = model.rollout_buffer
     if rank == 0:
-        return RoundRobinEgoRank(VecOnPolicyAgent(model), data_ego, obs_alt, n_partners, bonus)
-    agent = RaggedVecOnPolicyAgent(model)
-    # an environment is with this partner one episode in K: train on the full columns once about half of the columns that can
-    # be active at a time are full, instead of waiting K - 1 episodes for the rest
-    agent.min_full = max(1, rb.n_envs // (2 * n_partners))
-    return RoundRobinPartnerRank(agent, rank - 1, n_partners, rb.n_envs, model.policy.layout.D, steps_per_iteration)
+        side = RoundRobinEgoRank(VecOnPolicyAgent(model), data_ego, obs_alt, n_partners, bonus)
+    else:
+        agent = RaggedVecOnPolicyAgent(model)
+        # an environment is with this partner one episode in K: train on the full columns once about half of the columns that
+        # can be active at a time are full, instead of waiting K - 1 episodes for the rest
+        agent.min_full = max(1, rb.n_envs // (2 * n_partners))
+        side = RoundRobinPartnerRank(agent, rank - 1, n_partners, rb.n_envs, model.policy.layout.D, steps_per_iteration)
+    want = _native_wanted(model.policy.device) if native is None else bool(native)
+    link = None
+    if want:
+        try:
+            link = RoundRobinLink(model.policy.ctx, n_partners, rb.n_envs, model.policy.layout.D, model.policy.device)
+        except Exception as exc:  # noqa: BLE001 -- any failure: every rank falls back together (verdict below)
+            import sys
+            print(f"[pantheonrl_amd.roundrobin] engine-side carrier unavailable ({exc}); using torch.distributed per step",
+                  file=sys.stderr)
+            link = None
+    vdev = model.policy.device if dist.get_backend() == "nccl" else "cpu"
+    verdict = th.tensor([1.0 if link is not None else 0.0], device=vdev)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+    if verdict.item() > 0.5:
+        side.attach(link)
+    side.native = side.link is not None
+    return side

@@ -31,6 +31,9 @@ data_alt = SyntheticRollouts(obs_space, E, T, HORIZON, 1, device)
 model = PPO("MlpPolicy", env, n_steps=T if rank == 0 else T_PARTNER, n_envs=E, batch_size=E * 4, n_epochs=1,
             seed=100 + rank)
 side = rr.make_rank(model, K, T, data_ego=data_ego, obs_alt=data_alt.obs, bonus=BONUS)
+# default: the engine-side carrier (one native call per iteration and rank, IPC-mapped receive areas); PH_RR_NATIVE=0: the
+# host-driven one (torch.distributed collectives and torch book-keeping per step)
+assert side.native == (os.environ.get("PH_RR_NATIVE", "1") != "0"), side.native
 trace = []
 for it in range(ITER):
     dist.barrier()
@@ -131,6 +134,8 @@ if rank == 0 and T_PARTNER >= ITER * T:
     print("RR_REPLAY_OK", flush=True)
 if rank > 0 and T_PARTNER < ITER * T:
     assert side.updates >= 1, "a partner whose columns filled must have trained"
+if side.native:
+    assert side.link.timeouts() == 0, side.link.timeouts()
 dist.barrier()
-print(f"RR_OK rank {rank}/{world}", flush=True)
+print(f"RR_OK rank {rank}/{world} native={side.native}", flush=True)
 dist.destroy_process_group()

@@ -1482,12 +1482,13 @@ def test_round_robin_partners_one_agent_per_rank_replayed_through_multiagentenv(
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # second run: 4-row partner buffers and 5-step episodes: environments change partner at different times, so a partner's
     # columns fill at different rates -- it trains on its full columns (min_full) instead of waiting for all of them
-    for extra, port in (({}, 29561), ({"RR_T_PARTNER": "4"}, 29562)):
+    for extra, port in (({}, 29561), ({"RR_T_PARTNER": "4"}, 29562), ({"PH_RR_NATIVE": "0"}, 29563)):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
                "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "scripts", "roundrobin_ranks.py")]
         out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env={**os.environ, **extra})
         assert out.returncode == 0 and out.stdout.count("RR_OK") == 4, (out.stdout[-1500:], out.stderr[-3000:])
-        assert ("RR_REPLAY_OK" in out.stdout) == (not extra)
+        assert ("RR_REPLAY_OK" in out.stdout) == ("RR_T_PARTNER" not in extra)
+        assert out.stdout.count("native=True") == (0 if "PH_RR_NATIVE" in extra else 4)
 
 
 def test_learn_schedules_and_callback():
