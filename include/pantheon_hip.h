@@ -160,7 +160,8 @@ int ph_roundrobin_env_step(ph_ctx *ctx, const int *joint_actions, int *partnerid
                            int n_partners, float bonus, int n);
 /* The same layout with ONE native call per iteration and rank (no host tensor op, collective call or synchronisation per
  * environment step).  Every rank owns a fine-grained receive area (ph_p2p_alloc) that the others map through HIP IPC
- * (ph_p2p_open): [64 stamp words | slot 0 | slot 1], ph_rr_area_bytes() long.  Per step t of iteration i (stamp i * T + t + 1):
+ * (ph_p2p_open): [64 stamp words | slot 0 | slot 1], ph_rr_area_bytes() long; a partner's slot holds the block's header rows
+ * (n, 4) = [partner id | reward | done | -] followed by the observations (n, D), rank 0's slot the actions (1 + K, n).  Per step t of iteration i (stamp i * T + t + 1):
  *   rank 0 : ego forward + rollout-buffer row (its actions land in row 0 of its own slot t & 1) -> the routing block of step t
  *            stored into every partner's slot t & 1, then the partner's block stamp -> wait for the K action stamps -> the
  *            transition of ph_roundrobin_env_step (writes the header of block t + 1)            multiagentenv.py:149-243
@@ -197,7 +198,7 @@ typedef struct ph_rr_ego {
 typedef struct ph_rr_partner {
   const ph_spec *spec;                  /* host */
   const float *params;
-  float *obs_scratch;                   /* (n, D) */
+  float *obs_scratch;                   /* unused (the forward reads the observations from the receive slot); may be NULL */
   float *es_scratch;                    /* (n) */
   unsigned char *can_scratch;           /* (n) */
   int *pos;                             /* (n) per-environment write rows, in/out */

@@ -457,7 +457,7 @@ int ph_roundrobin_env_step(ph_ctx* ctx, const int* joint_actions, int* partnerid
 namespace {
 constexpr size_t RR_STAMP_BYTES = 64 * sizeof(unsigned long long);
 size_t rr_slot_bytes(int n_partners, int n, int block_ld) {
-  const size_t blk = (size_t)n * block_ld * sizeof(float), act = (size_t)(n_partners + 1) * n * sizeof(int);
+  const size_t blk = (size_t)n * (block_ld + 1) * sizeof(float), act = (size_t)(n_partners + 1) * n * sizeof(int);
   return ((blk > act ? blk : act) + 255) / 256 * 256;
 }
 int check_rr_link(const ph_rr_link* l) {
@@ -470,6 +470,8 @@ int check_rr_link(const ph_rr_link* l) {
   return 0;
 }
 unsigned long long* rr_stamps(const ph_rr_link* l, int rank) { return (unsigned long long*)l->area[rank]; }
+// rank 0's arrival counters of the block send live behind its stamp words (words 32 .. 63 of the stamp area)
+unsigned int* rr_arrive(const ph_rr_link* l) { return (unsigned int*)((unsigned long long*)l->area[0] + 32); }
 char* rr_slot(const ph_rr_link* l, int rank, int parity) {
   return (char*)l->area[rank] + RR_STAMP_BYTES + (size_t)parity * rr_slot_bytes(l->n_partners, l->n, l->block_ld);
 }
@@ -497,21 +499,24 @@ int ph_roundrobin_ego_iteration(ph_ctx* ctx, const ph_rr_link* link, const ph_rr
   for (int t = 0; t < T; ++t) {
     const unsigned long long want = iteration * (unsigned long long)T + (unsigned long long)t + 1ull;
     int* slot = (int*)rr_slot(link, 0, t & 1);   // (1 + K, n): row 0 = the ego's actions of this step
+    // the routing block leaves first: the partners work on step t while the ego's own forward runs
+    ph::RRSend sd;
+    std::memset(&sd, 0, sizeof(sd));
+    sd.src = ego->blocks + (size_t)t * n * ld;
+    sd.n = n;
+    sd.block_ld = ld;
+    for (int k = 0; k < K; ++k) {
+      sd.dst[k] = (float*)rr_slot(link, 1 + k, t & 1);
+      sd.stamp[k] = rr_stamps(link, 1 + k);
+    }
+    sd.arrive = rr_arrive(link);
+    sd.want = want;
+    PH_HIP(ph::launch_rr_send_block(sd, K, ctx->stream));
     if (ph_policy_forward(ctx, ego->spec, ego->params, ego->obs_seq + (size_t)t * n * nd.D, n, nullptr, nullptr, nullptr, ego->seed,
                           ego->counter0 + (unsigned long long)t, 0, slot, nullptr, ego->values, ego->log_probs, nullptr, nullptr,
                           ego->rb, t, t == 0 ? ego->episode_start0 : ego->done_seq + (size_t)(t - 1) * n,
                           t == 0 ? nullptr : ego->rewards + (size_t)(t - 1) * n, 0))
       return 1;
-    ph::RRSend sd;
-    std::memset(&sd, 0, sizeof(sd));
-    sd.src = ego->blocks + (size_t)t * n * ld;
-    sd.n_floats = n * ld;
-    for (int k = 0; k < K; ++k) {
-      sd.dst[k] = (float*)rr_slot(link, 1 + k, t & 1);
-      sd.stamp[k] = rr_stamps(link, 1 + k);
-    }
-    sd.want = want;
-    PH_HIP(ph::launch_rr_send_block(sd, K, ctx->stream));
     ph::RREnvStep es;
     std::memset(&es, 0, sizeof(es));
     es.stamps = rr_stamps(link, 0);
@@ -541,7 +546,7 @@ int ph_roundrobin_partner_iteration(ph_ctx* ctx, const ph_rr_link* link, const p
   if (!ctx || !pa || T <= 0) return fail("ph_roundrobin_partner_iteration: bad argument");
   if (check_rr_link(link)) return 1;
   if (link->rank < 1) return fail("ph_roundrobin_partner_iteration: partners live on ranks 1 .. n_partners");
-  if (!pa->params || !pa->obs_scratch || !pa->es_scratch || !pa->can_scratch || !pa->pos || !pa->boundary || !pa->term ||
+  if (!pa->params || !pa->es_scratch || !pa->can_scratch || !pa->pos || !pa->boundary || !pa->term ||
       !pa->open || !pa->prev_mask || !pa->actions || !pa->values || !pa->log_probs || !pa->rb)
     return fail("ph_roundrobin_partner_iteration: null argument");
   if (check_rb(pa->rb)) return 1;
@@ -569,11 +574,11 @@ int ph_roundrobin_partner_iteration(ph_ctx* ctx, const ph_rr_link* link, const p
     st.prev_mask = pa->prev_mask;
     st.can = pa->can_scratch;
     st.es = pa->es_scratch;
-    st.obs_out = pa->obs_scratch;
     st.actions = pa->actions;
     st.act_dst = (int*)rr_slot(link, 0, t & 1) + (size_t)(1 + k) * n;
     PH_HIP(ph::launch_rr_partner_pre(st, ctx->stream));
-    if (ph_policy_forward_ragged(ctx, pa->spec, pa->params, pa->obs_scratch, nullptr, pa->seed, pa->counter0 + (unsigned long long)t,
+    const float* obs_t = st.block + (size_t)n * 4;    // the observations follow the header rows in the slot
+    if (ph_policy_forward_ragged(ctx, pa->spec, pa->params, obs_t, nullptr, pa->seed, pa->counter0 + (unsigned long long)t,
                                  0, pa->actions, pa->values, pa->log_probs, pa->rb, pa->pos, pa->can_scratch, pa->es_scratch))
       return 1;
     PH_HIP(ph::launch_rr_partner_post(st, ctx->stream));

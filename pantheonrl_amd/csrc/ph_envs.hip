@@ -247,25 +247,34 @@ __device__ __forceinline__ bool rr_wait(const unsigned long long* flag, unsigned
   }
 }
 
-// rank 0: routing block of step t -> every partner's slot, then the stamp.  One workgroup per partner (its stores, a
-// system-scope fence, a barrier, then one lane publishes): block k never waits for another block.
-__global__ __launch_bounds__(1024) void rr_send_block_kernel(RRSend a) {
-  const int k = blockIdx.x;
-  float* dst = a.dst[k];
-  const float4* src4 = reinterpret_cast<const float4*>(a.src);
-  float4* dst4 = reinterpret_cast<float4*>(dst);
-  const int n4 = a.n_floats >> 2;
-  for (int i = threadIdx.x; i < n4; i += blockDim.x) dst4[i] = src4[i];
-  for (int i = (n4 << 2) + threadIdx.x; i < a.n_floats; i += blockDim.x) dst[i] = a.src[i];
+// rank 0: routing block of step t -> every partner's slot, then the stamp.  The interleaved block [id | reward | done | obs] is
+// split on the way: a partner's slot holds the header rows (n, 4) first and the observations (n, D) contiguously behind them,
+// so that the partner's forward kernel reads its observations straight from the slot.  Grid (RR_SEND_SPLIT, K): the
+// workgroups of a partner count themselves in after a system-scope fence; the last one publishes the stamp.
+__global__ __launch_bounds__(256) void rr_send_block_kernel(RRSend a) {
+  const int k = blockIdx.y, D = a.block_ld - 3;
+  float* hdr = a.dst[k];
+  float* obs = hdr + (size_t)a.n * 4;
+  const int rows_per = (a.n + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per, r1 = (r0 + rows_per < a.n) ? r0 + rows_per : a.n;
+  for (int i = r0 * a.block_ld + threadIdx.x; i < r1 * a.block_ld; i += blockDim.x) {
+    const int r = i / a.block_ld, c = i - r * a.block_ld;
+    const float v = a.src[i];
+    if (c < 3) hdr[r * 4 + c] = v;
+    else obs[(size_t)r * D + (c - 3)] = v;
+  }
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence_system();
-    __hip_atomic_store(a.stamp[k], a.want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned int old = atomicAdd(a.arrive + k, 1u);
+    if ((old + 1u) % gridDim.x == 0u) {
+      __threadfence_system();
+      __hip_atomic_store(a.stamp[k], a.want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 hipError_t launch_rr_send_block(const RRSend& a, int n_partners, hipStream_t s) {
-  hipLaunchKernelGGL(rr_send_block_kernel, dim3(n_partners), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(rr_send_block_kernel, dim3(RR_SEND_SPLIT, n_partners), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -304,8 +313,8 @@ __global__ __launch_bounds__(256) void rr_partner_pre_kernel(RRPartnerStep a) {
   __syncthreads();
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < a.n) {
-    const float* row = a.block + (size_t)e * a.block_ld;
-    const float pid = row[0], r = row[1], d = row[2];
+    const float4 h = *reinterpret_cast<const float4*>(a.block + (size_t)e * 4);   // header rows (n, 4) lead the slot
+    const float pid = h.x, r = h.y, d = h.z;
     const bool m = a.prev_mask[e] != 0, open = a.open[e] != 0;
     const int p = a.pos[e];
     if (m && open && p >= 1 && p <= a.T) a.rewards[(size_t)(p - 1) * a.n + e] += r;
@@ -322,13 +331,6 @@ __global__ __launch_bounds__(256) void rr_partner_pre_kernel(RRPartnerStep a) {
     a.term[e] = can ? 0 : (term ? 1 : 0);
     a.open[e] = can ? 1 : (blocked ? 0 : (open ? 1 : 0));
     a.prev_mask[e] = mask ? 1 : 0;
-  }
-  // observation columns of the block -> contiguous (n, D)
-  const int D = a.block_ld - 3;
-  const size_t total = (size_t)a.n * D;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t e2 = i / D, c = i - e2 * D;
-    a.obs_out[i] = a.block[e2 * a.block_ld + 3 + c];
   }
 }
 hipError_t launch_rr_partner_pre(const RRPartnerStep& a, hipStream_t s) {

@@ -285,11 +285,13 @@ hipError_t launch_p2p_wait(const ph_p2p& x, int t, hipStream_t s);
 hipError_t launch_p2p_ll_unpack(const ph_p2p& x, int t, hipStream_t s, int slot = -1 /* default: t mod ll_slots */);
 hipError_t launch_p2p_ll_push(const ph_p2p& x, const int* local, int t, hipStream_t s);
 // engine-side round-robin layout (ph_envs.hip)
+constexpr int RR_SEND_SPLIT = 16;        // workgroups per partner in the block send
 struct RRSend {
-  const float* src;                      // this step's routing block (n * block_ld floats)
-  int n_floats;
-  float* dst[PH_MAX_RANKS];              // [k] partner k's slot of this step's parity
+  const float* src;                      // this step's routing block, interleaved (n, block_ld)
+  int n, block_ld;
+  float* dst[PH_MAX_RANKS];              // [k] partner k's slot of this step's parity: header rows (n, 4), then obs (n, D)
   unsigned long long* stamp[PH_MAX_RANKS];   // [k] partner k's block stamp
+  unsigned int* arrive;                  // [K] local arrival counters (monotonic)
   unsigned long long want;
 };
 struct RREnvStep {
@@ -312,13 +314,12 @@ struct RRPartnerStep {
   unsigned long long* act_stamp;         // on rank 0
   unsigned long long want, timeout;
   unsigned long long* error;
-  const float* block;                    // this step's routing block as received (n, block_ld)
+  const float* block;                    // this step's slot as received: header rows (n, 4), then the observations (n, D)
   int block_ld, n, T, k;
   float* rewards;                        // the partner's rollout-buffer rewards (T, n)
   int* pos;
   unsigned char *boundary, *term, *open, *prev_mask, *can;
   float* es;
-  float* obs_out;                        // (n, D)
   const int* actions;                    // (n) this step's sampled actions
   int* act_dst;                          // rank 0's slot row 1 + k
 };

@@ -88,6 +88,16 @@ class RoundRobinLink:
         return int(self._error[0].item())
 
 
+def _timing() -> bool:
+    import os
+    return os.environ.get("PH_RR_TIMING", "0") == "1"
+
+
+def _now() -> float:
+    import time
+    return time.perf_counter()
+
+
 def _native_wanted(device) -> bool:
     import os
     return th.device(device).type == "cuda" and os.environ.get("PH_RR_NATIVE", "1") != "0"
@@ -169,7 +179,14 @@ class RoundRobinEgoRank:
         ego.flush_rewards()
         self._first_start.copy_(ego._last_episode_starts)
         self._c.counter0 = pol._counter + 1
+        timing = _timing()
+        if timing:
+            th.cuda.synchronize()
+            t0 = _now()
         nat.check(self._lib.ph_roundrobin_ego_iteration(self._h, C.byref(self.link.link), C.byref(self._c), T, self.iteration))
+        if timing:
+            th.cuda.synchronize()
+            t1 = _now()
         pol._counter += T
         rb.pos, rb.full = T, True
         ego.n_steps += T
@@ -178,6 +195,10 @@ class RoundRobinEgoRank:
         ego._last_episode_starts = d.dones[T - 1]
         self.iteration += 1
         ego.learn_from_buffer()
+        if timing:
+            th.cuda.synchronize()
+            print(f"[rr timing] ego iteration {self.iteration}: rollout {1e3 * (t1 - t0):.2f} ms, update {1e3 * (_now() - t1):.2f} ms",
+                  flush=True)
 
     def run_iteration(self) -> None:
         if self.link is not None:
@@ -231,9 +252,16 @@ class RoundRobinPartnerRank:
         agent = self.agent
         pol, rb = agent.model.policy, agent.model.rollout_buffer
         pol._bind()
+        timing = _timing()
+        if timing:
+            th.cuda.synchronize()
+            t0 = _now()
         if agent.full():                          # once per iteration (one host read): train on the full columns
             agent.learn_from_buffer()
             self.updates += 1
+        if timing:
+            th.cuda.synchronize()
+            t1 = _now()
         c = nat.PhRRPartner()
         c.spec, c.params = C.pointer(pol.spec), pol.params.data_ptr()
         c.obs_scratch, c.es_scratch, c.can_scratch = self._obs.data_ptr(), self._es.data_ptr(), self._can.data_ptr()
@@ -246,6 +274,10 @@ class RoundRobinPartnerRank:
         pol._counter += self.T
         agent.num_timesteps += self.T * self.E
         self.iteration += 1
+        if timing:
+            th.cuda.synchronize()
+            print(f"[rr timing] partner {self.k} iteration {self.iteration}: update {1e3 * (t1 - t0):.2f} ms, rollout "
+                  f"{1e3 * (_now() - t1):.2f} ms", flush=True)
 
     def run_iteration(self) -> None:
         if self.link is not None:
