@@ -16,14 +16,22 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ("pantheonrl_amd/csrc/ph_ppo_fast.hip", "pantheonrl_amd/csrc/ph_head.h", "pantheonrl_amd/csrc/ph_device.h",
-                  "pantheonrl_amd/csrc/ph_launch.h")
+                  "pantheonrl_amd/csrc/ph_launch.h:struct GradArgs")
 
 
 def kernel_source_sha256(root: str = ROOT) -> str:
+    """hash of what ppo_grad_fast_kernel is compiled from: its translation unit, the two headers with its device code, and its
+    argument record (the rest of ph_launch.h -- other kernels' records and launcher prototypes -- does not enter)"""
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES:
-        with open(os.path.join(root, rel), "rb") as fh:
-            h.update(rel.encode() + b"\0" + fh.read())
+        path, _, part = rel.partition(":")
+        with open(os.path.join(root, path), "rb") as fh:
+            data = fh.read()
+        if part:
+            text = data.decode()
+            i = text.index(part + " {")
+            data = text[i:text.index("\n};", i) + 3].encode()
+        h.update(rel.encode() + b"\0" + data)
     return h.hexdigest()
 
 
