@@ -55,7 +55,101 @@ __device__ __forceinline__ float lds_coldot(const float* p, int stride, const fl
   return s;
 }
 
-template <int R, int LP, bool VALU, bool OH, bool H16>
+// ---- one-hot first layer without a materialised X (OHR instantiations) ---------------------------------------------------------
+// A one-hot observation row is a set of D hot features.  Per tile the workgroup builds two bit tables from the observations:
+// rowmask[r][w] -- bit b set iff feature 32 w + b of row r is hot -- and colmask[f][w] -- bit b set iff row 32 w + b has feature
+// f hot.  The MFMA A operands of X W1 (lane = row, k = feature) and of X^T dZ1 (lane = feature, k = row) are then one v_bfe +
+// v_cvt on a register: no X chunk in LDS, no zero fill, and the dW1 chunk products need no barrier between them.  (Keeping
+// every chunk of W1 resident as well -- 159 KB for Liar's Dice -- measured slower in situ: the two learners' update launches
+// then cannot share a CU.)
+// Same k order and the same 0.0 / 1.0 operand values as the dense products: bitwise the same accumulators.
+template <bool VALU>
+__device__ __forceinline__ f32x16 tile_mma_onehot_fwd(const unsigned* rowmask, int RW, int c, const float* B, int ldb, int m0, int n0,
+                                                      f32x16 acc, int lane) {
+  const int i = lane & 31, h = lane >> 5;
+  if constexpr (!VALU) {
+    const unsigned w0 = rowmask[(m0 + i) * RW + 2 * c], w1 = rowmask[(m0 + i) * RW + 2 * c + 1];
+    const float* bp = B + h * ldb + n0 + i;
+    float b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b0[u] = bp[2 * u * ldb];
+#pragma unroll
+    for (int s = 0; s < 32; s += 4) {
+      bp += 8 * ldb;
+      if (s + 4 < 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b1[u] = bp[2 * u * ldb];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned w = (s + u) < 16 ? w0 : w1;
+        const float av = (float)((w >> (((2 * (s + u)) & 31) + h)) & 1u);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[u], acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b0[u] = b1[u];
+    }
+  } else {
+    const int col = n0 + i;
+    for (int k = 0; k < HID; ++k) {
+      const float b = B[k * ldb + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + drow(r, h);
+        const float av = (float)((rowmask[row * RW + 2 * c + (k >> 5)] >> (k & 31)) & 1u);
+        acc[r] = __builtin_fmaf(av, b, acc[r]);
+      }
+    }
+  }
+  return acc;
+}
+// acc[f = m0 + .., n] += sum over the 64 rows of X[row][c*64 + f] * B[row][n]
+template <bool VALU>
+__device__ __forceinline__ f32x16 tile_mma_onehot_bwd(const unsigned* colmask, int c, const float* B, int ldb, int m0, int n0,
+                                                      f32x16 acc, int lane) {
+  const int i = lane & 31, h = lane >> 5;
+  if constexpr (!VALU) {
+    const unsigned w0 = colmask[(c * HID + m0 + i) * 2], w1 = colmask[(c * HID + m0 + i) * 2 + 1];
+    const float* bp = B + h * ldb + n0 + i;
+    float b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b0[u] = bp[2 * u * ldb];
+#pragma unroll
+    for (int s = 0; s < 32; s += 4) {
+      bp += 8 * ldb;
+      if (s + 4 < 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b1[u] = bp[2 * u * ldb];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned w = (s + u) < 16 ? w0 : w1;
+        const float av = (float)((w >> (((2 * (s + u)) & 31) + h)) & 1u);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[u], acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b0[u] = b1[u];
+    }
+  } else {
+    const int col = n0 + i;
+    for (int k = 0; k < HID; ++k) {   // k = row
+      const float b = B[k * ldb + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = c * HID + m0 + drow(r, h);
+        const float av = (float)((colmask[f * 2 + (k >> 5)] >> (k & 31)) & 1u);
+        acc[r] = __builtin_fmaf(av, b, acc[r]);
+      }
+    }
+  }
+  return acc;
+}
+
+template <int R, int LP, bool VALU, bool OH, bool H16, bool OHR = false>
 __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   if (*a.stop_flag) return;
   PH_STAMP(a.prof, 0);
@@ -82,6 +176,10 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
   int* feat = rowphys + R;             // [R][D] one-hot positions of the tile (Discrete-family observations only)
   constexpr bool onehot = OH;
   int* fcomp = feat + R * nd.D;        // [nchunk * 64] observation component of every feature (one-hot only)
+  // OHR: no feat / fcomp; bit tables of the tile's hot features and every chunk of W1 resident
+  const int RW = 2 * nd.nchunk;                        // mask words per row
+  unsigned* rowmask = (unsigned*)(rowphys + R);        // [R][RW]
+  unsigned* colmask = rowmask + R * RW;                // [nchunk * 64][2]
   float* wos = regW;
   float* outs = regW + HID * LDO;
 
@@ -131,8 +229,9 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     }
   };
   stage_rows(blockIdx.x);  // overlaps the W2 / bias loads issued above
-  if constexpr (onehot) XStage<R, NT>::build_fcomp(fcomp, nd, tid);
+  if constexpr (onehot && !OHR) XStage<R, NT>::build_fcomp(fcomp, nd, tid);
   w2r.commit(w2s);
+
   if (tid < HID) {
     b1s[tid] = bias1;
     b2s[tid] = bias2;
@@ -157,7 +256,34 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     XStage<R, NT> xr;
     WStage<NT> w1r;
     WoStage<NT, LP> wor;   // sized by the head width of this instantiation
-    if constexpr (onehot) {
+    if constexpr (OHR) {
+      // bit tables of this tile: zero, then one LDS OR per (row, component) -- order-independent, so deterministic
+      for (int e = tid; e < R * RW + nd.nchunk * HID * 2; e += NT) rowmask[e] = 0u;   // rowmask and colmask are contiguous
+      w1r.issue(a.params + oW1, 0, nd.F, tid);
+      if (net == 0) wor.issue(a.params + lay.act_W, nd.L, Lp, tid);   // consumed after the chunk loop
+      __syncthreads();
+      for (int e = tid; e < R * nd.D; e += NT) {
+        const int r = e / nd.D, comp = e - r * nd.D;
+        const int ph_row = rowphys[r];
+        if (ph_row < 0) continue;
+        const int lo = nd.obs_off[comp], n = nd.obs_off[comp + 1] - lo;
+        int x = (int)a.rb_obs[(size_t)ph_row * nd.D + comp];
+        x = x < 0 ? 0 : (x >= n ? n - 1 : x);
+        const int f = lo + x;
+        atomicOr(&rowmask[r * RW + (f >> 5)], 1u << (f & 31));
+        atomicOr(&colmask[f * 2 + (r >> 5)], 1u << (r & 31));
+      }
+      // the W1 chunks stream through the one LDS buffer (two workgroups per CU: the two learners' updates run side by side);
+      // chunk c + 1 is loaded into registers while chunk c's products run
+      for (int c = 0; c < nd.nchunk; ++c) {
+        if (c > 0) __syncthreads();   // previous chunk consumed
+        w1r.commit(regW, tid);
+        __syncthreads();              // (first chunk: the bit tables are complete as well)
+        if (first) PH_STAMP(a.prof, 2);
+        if (c + 1 < nd.nchunk) w1r.issue(a.params + oW1, (c + 1) * HID, nd.F, tid);
+        acc = tile_mma_onehot_fwd<VALU>(rowmask, RW, c, regW, LDH, mt * 32, nt * 32, acc, lane);
+      }
+    } else if constexpr (onehot) {
       // One-hot observations: the hot feature row of every (row, component) once per tile; the chunks of S1 and S7 are then
       // built from LDS (commit_onehot: no zero fill, no scatter).  (Replacing S1 by a gather-sum of W1 rows, as the 16-row
       // forward kernel does, measured no faster at 64 rows per workgroup: 491 KB of gathered rows per workgroup against 69 KB
@@ -513,7 +639,7 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
     // S7 needs X chunk 0 again: with one feature chunk the staged registers of S1 are still live (no second
     // gather); otherwise it is re-issued here and lands during the MFMAs.
     f32x16 dh1 = {0};
-    if (nd.nchunk > 1) xr.issue(rowphys, a.rb_obs, nd, 0, tid);
+    if (!OHR && nd.nchunk > 1) xr.issue(rowphys, a.rb_obs, nd, 0, tid);
     {
       f32x16 g = {0};
       if (!first) {
@@ -541,7 +667,8 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) bufB[(mt * 32 + drow(r, lh)) * LDH + nt * 32 + li] = dh1[r] * (1.0f - hv[r] * hv[r]);
     }
-    if constexpr (onehot) xr.commit_onehot(bufA, fcomp, nd, 0, tid);
+    if constexpr (OHR) {
+    } else if constexpr (onehot) xr.commit_onehot(bufA, fcomp, nd, 0, tid);
     else xr.commit(bufA, rowphys, a.rb_obs, nd, 0, tid);
     __syncthreads();
     if (first) PH_STAMP(a.prof, 11);
@@ -552,6 +679,23 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
       slab[oB1 + tid] = s;
     }
     for (int c = 0; c < nd.nchunk; ++c) {
+      if constexpr (OHR) {     // dW1 chunk c straight from the bit table: no X in LDS, no barrier between chunks
+        f32x16 g = {0};
+        if (!first) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = c * HID + mt * 32 + drow(r, lh);
+            if (k < nd.F) g[r] = slab[oW1 + (size_t)k * HID + nt * 32 + li];
+          }
+        }
+        g = tile_mma_onehot_bwd<VALU>(colmask, c, bufB, LDH, mt * 32, nt * 32, g, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = c * HID + mt * 32 + drow(r, lh);
+          if (k < nd.F) slab[oW1 + (size_t)k * HID + nt * 32 + li] = g[r];
+        }
+        continue;
+      }
       if (c > 0) {
         __syncthreads();  // previous chunk consumed
         if constexpr (onehot) {
@@ -613,24 +757,48 @@ size_t grad_lds_bytes(int R, int Lp, int onehot_D, int nchunk) {
   return sizeof(float) * (size_t)(2 * R * LDH + regW_sz + HID * LDH + 3 * 64 + 3 * R + NSTATP * 4 + 8 * R + R + R * onehot_D +
                                   (onehot_D ? nchunk * HID : 0));
 }
+// OHR instantiations: bit tables instead of the hot-position / feature-component tables
+static size_t grad_lds_bytes_ohr(int R, int Lp, int nchunk) {
+  const int LDO = Lp + 1;
+  const int regW_sz = (HID * LDH > (HID + R) * LDO) ? HID * LDH : (HID + R) * LDO;
+  return sizeof(float) * (size_t)(2 * R * LDH + regW_sz + HID * LDH + 3 * 64 + 3 * R + NSTATP * 4 + 8 * R + R + R * 2 * nchunk +
+                                  nchunk * HID * 2);
+}
+static bool grad_ohr_enabled() {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("PH_GRAD_OHR");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  return enabled != 0;
+}
 
-template <int LP, bool VALU, bool OH, bool H16>
-static hipError_t launch_grad_variant(const GradArgs& a, int nwg, hipStream_t s) {
+template <int LP, bool VALU, bool OH, bool H16, bool OHR>
+static hipError_t launch_grad_inst(const GradArgs& a, int nwg, size_t lds, hipStream_t s) {
   constexpr int R = 64;
-  const size_t lds = grad_lds_bytes(R, LP, OH ? a.nd.D : 0, a.nd.nchunk);
   dim3 grid(nwg, 2), block(R * 4);
   static size_t allowed[64] = {0};  // > 64 KiB of dynamic LDS is opt-in per kernel and device (kept out of graph capture)
   int dev = 0;
   (void)hipGetDevice(&dev);
   dev = (dev >= 0 && dev < 64) ? dev : 0;
   if (lds > allowed[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<R, LP, VALU, OH, H16>,
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<R, LP, VALU, OH, H16, OHR>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     allowed[dev] = lds;
   }
-  hipLaunchKernelGGL((ppo_grad_kernel<R, LP, VALU, OH, H16>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((ppo_grad_kernel<R, LP, VALU, OH, H16, OHR>), grid, block, lds, s, a);
   return hipGetLastError();
+}
+template <int LP, bool VALU, bool OH, bool H16>
+static hipError_t launch_grad_variant(const GradArgs& a, int nwg, hipStream_t s) {
+  constexpr int R = 64;
+  if constexpr (OH) {
+    // one-hot observations: the first layer's products take their X operands from bit tables, no materialised X
+    const size_t ohr = grad_lds_bytes_ohr(R, LP, a.nd.nchunk);
+    if (grad_ohr_enabled() && ohr <= 80 * 1024) return launch_grad_inst<LP, VALU, true, H16, true>(a, nwg, ohr, s);
+  }
+  return launch_grad_inst<LP, VALU, OH, H16, false>(a, nwg, grad_lds_bytes(R, LP, OH ? a.nd.D : 0, a.nd.nchunk), s);
 }
 template <int LP, bool VALU>
 static hipError_t launch_grad_shape(const GradArgs& a, int nwg, hipStream_t s) {
