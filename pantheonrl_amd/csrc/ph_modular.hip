@@ -17,53 +17,67 @@
 // The tower kernel below is ppo_grad_fast_kernel's tile walk (same 32x32 MFMA tiles on LDS operands, same register-order
 // gradient slabs, same register-resident four-lanes-per-row head phase) with the loss taken out and two things added: the head
 // gradient comes from HBM (written by the loss kernel) plus up to two external dL/dH2 terms, and dL/dX = dZ1 W1^T is one more
-// product.  It keeps X, H1, H2 in separate LDS buffers and stages W1 per tile (88 KB: one workgroup per CU) -- this path is a
-// correctness-first "next" row, not the headline kernel.
+// product.  LDS budget and buffer rotation are the fast kernel's (72.6 KB, two workgroups per CU; X and W1 are fetched a second
+// time per backward tile under the tile's products); it has no cross-tile prefetch.
 #include "ph_head.h"
 #include "ph_rowtail.h"
 
 namespace ph {
 
 // X tile of a tower: rows of the rollout buffer gathered through the minibatch order (main towers; Box or one-hot
-// observations of at most 64 features) or rows gi of a dense [nb][64] matrix (module towers reading the main policy latent)
-__device__ __forceinline__ void tower_stage_x(float* bufX, const int* rowphys, const TowerArgs& a, int tid) {
-  if (a.obs_off == nullptr) {
+// observations of at most 64 features) or rows gi of a dense [nb][64] matrix (module towers reading the main policy latent).
+// Box rows: issue (16 loads per thread, no waits) and commit (LDS stores) are separate so that the second staging of a
+// backward tile (X returns to the buffer H2 occupied) rides under the tile's MFMA products.
+struct TowerX {
+  float v[16];
+  __device__ __forceinline__ void issue(const int* rowphys, const TowerArgs& a, int tid) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int e = tid + 256 * i, r = e >> 6, c = e & 63;
       const int p = rowphys[r];
-      bufX[r * LDH + c] = (p >= 0 && c < a.F) ? a.x[(size_t)p * a.x_ld + c] : 0.f;
+      v[i] = (p >= 0 && c < a.F) ? a.x[(size_t)p * a.x_ld + c] : 0.f;
     }
-  } else {   // Discrete / MultiDiscrete observations: one-hot features (SB3 preprocess_obs), out-of-range values clamped
+  }
+  __device__ __forceinline__ void commit(float* bufX, int tid) const {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int e = tid + 256 * i;
-      bufX[(e >> 6) * LDH + (e & 63)] = 0.f;
+      bufX[(e >> 6) * LDH + (e & 63)] = v[i];
     }
-    __syncthreads();
-    for (int e = tid; e < 64 * a.x_ld; e += 256) {
-      const int r = e / a.x_ld, comp = e - r * a.x_ld;
-      const int p = rowphys[r];
-      if (p < 0) continue;
-      const int lo = a.obs_off[comp], n = a.obs_off[comp + 1] - lo;
-      int v = (int)a.x[(size_t)p * a.x_ld + comp];
-      v = v < 0 ? 0 : (v >= n ? n - 1 : v);
-      if (lo + v < 64) bufX[r * LDH + lo + v] = 1.f;
-    }
+  }
+};
+// Discrete / MultiDiscrete observations: one-hot features (SB3 preprocess_obs), out-of-range values clamped.  All threads call
+// it (one workgroup barrier inside); the caller barriers afterwards.
+__device__ __forceinline__ void tower_stage_onehot(float* bufX, const int* rowphys, const TowerArgs& a, int tid) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = tid + 256 * i;
+    bufX[(e >> 6) * LDH + (e & 63)] = 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * a.x_ld; e += 256) {
+    const int r = e / a.x_ld, comp = e - r * a.x_ld;
+    const int p = rowphys[r];
+    if (p < 0) continue;
+    const int lo = a.obs_off[comp], n = a.obs_off[comp + 1] - lo;
+    int v = (int)a.x[(size_t)p * a.x_ld + comp];
+    v = v < 0 ? 0 : (v >= n ? n - 1 : v);
+    if (lo + v < 64) bufX[r * LDH + lo + v] = 1.f;
   }
 }
 
-template <bool VALU>
-__global__ __launch_bounds__(256) void tower_kernel(TowerLaunch L) {
+// LDS: bufA / bufB / bufC / W2 (4 x [64][65] f32) + head weights + per-row head gradients = 72.6 KB -> two workgroups per CU,
+// the fast gradient kernel's budget: X -> H2 -> X share bufA, H1 -> dZ1 bufB, W1 -> dZ2 -> W1 bufC.
+template <bool VALU, bool BWD>
+__global__ __launch_bounds__(256, 2) void tower_kernel(TowerLaunch L) {
   if (L.stop_flag && *L.stop_flag) return;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 64;
   const TowerArgs& a = L.t[blockIdx.y];
-  const bool bwd = L.mode != 0;
-  float* bufX = smem;                 // [R][LDH]   X (kept for dW1)
-  float* bufH1 = bufX + R * LDH;      // [R][LDH]   H1 -> dZ1
-  float* bufH2 = bufH1 + R * LDH;     // [R][LDH]   H2
-  float* bufC = bufH2 + R * LDH;      // [64][LDH]  W1 -> dZ2 -> W1
+  constexpr bool bwd = BWD;
+  float* bufA = smem;                 // [R][LDH]   X -> H2 -> X
+  float* bufB = bufA + R * LDH;       // [R][LDH]   H1 -> dZ1
+  float* bufC = bufB + R * LDH;       // [64][LDH]  W1 -> dZ2 -> W1
   float* w2s = bufC + HID * LDH;      // [64][LDH]
   float* hw = w2s + HID * LDH;        // policy: head weights as [64][8] (skewed rows, columns >= L zero) | value: [64]
   float* dzs = hw + HW_FLOATS;        // policy: dL/dlogits [R][8] | value: dL/dv [R]
@@ -73,15 +87,16 @@ __global__ __launch_bounds__(256) void tower_kernel(TowerLaunch L) {
   int* rowphys = (int*)(hbs + 16);    // [R] source row of X, -1 = padding
   int* rowgi = rowphys + R;           // [R] minibatch row, -1 = padding
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mt = wave >> 1, nt = wave & 1, li = lane & 31, lh = lane >> 5;
   const bool pol = a.head == 1;
+  const bool onehot = a.obs_off != nullptr;
   const int nk = a.L;
 
-  // ---- weights that stay for the whole launch ----
+  // ---- weights that stay for the whole launch (W1 too in forward mode: nothing overwrites bufC there) ----
   {
-    WStage<256> w2r;
+    const int tid = threadIdx.x;
+    WStage<256> w2r, w1r;
     w2r.issue(a.W2, 0, HID);
+    if (!bwd) w1r.issue(a.W1, 0, a.F);
     float bias1 = 0.f, bias2 = 0.f, hv0 = 0.f, hv1 = 0.f, hb = 0.f;
     if (tid < HID) {
       bias1 = a.b1[tid];
@@ -99,6 +114,7 @@ __global__ __launch_bounds__(256) void tower_kernel(TowerLaunch L) {
       if (tid == 0) hb = a.hb[0];
     }
     w2r.commit(w2s);
+    if (!bwd) w1r.commit(bufC);
     if (tid < HID) {
       b1s[tid] = bias1;
       b2s[tid] = bias2;
@@ -117,6 +133,13 @@ __global__ __launch_bounds__(256) void tower_kernel(TowerLaunch L) {
   float gh0 = 0.f, gh1 = 0.f, gb1 = 0.f, gb2 = 0.f, ghb = 0.f;
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    // thread coordinates re-derived per tile from an opaque copy of threadIdx.x (keeps the compiler from pinning hundreds of
+    // loop-invariant LDS addresses in VGPRs across the tile loop: 509 -> < 256 registers)
+    int tidv = threadIdx.x;
+    asm volatile("" : "+v"(tidv));
+    const int tid = tidv, lane = tid & 63, wave = tid >> 6;
+    const int mt = wave >> 1, nt = wave & 1, li = lane & 31, lh = lane >> 5;
+
     // ---- rows of this tile, X, W1 (bufC is overwritten by dZ2 in every backward tile), the head gradient ----
     __syncthreads();   // the previous tile is done with every buffer
     if (tid < R) {
@@ -127,9 +150,15 @@ __global__ __launch_bounds__(256) void tower_kernel(TowerLaunch L) {
       rowgi[tid] = gi < a.nb ? gi : -1;
     }
     WStage<256> w1r;
-    w1r.issue(a.W1, 0, a.F);
+    if (bwd) w1r.issue(a.W1, 0, a.F, tid);
     __syncthreads();
-    tower_stage_x(bufX, rowphys, a, tid);
+    TowerX xr;
+    if (onehot) {
+      tower_stage_onehot(bufA, rowphys, a, tid);
+    } else {
+      xr.issue(rowphys, a, tid);
+      xr.commit(bufA, tid);
+    }
     if (bwd) {
       if (pol) {
 #pragma unroll
@@ -140,38 +169,38 @@ __global__ __launch_bounds__(256) void tower_kernel(TowerLaunch L) {
       } else if (tid < R) {
         dzs[tid] = rowgi[tid] >= 0 ? a.dhead[rowgi[tid]] : 0.f;
       }
+      w1r.commit(bufC, tid);
     }
-    w1r.commit(bufC);
-    __syncthreads();
+    lds_barrier();
 
-    // ---- S1: H1 = tanh(X W1 + b1) ----
+    // ---- S1: H1 = tanh(X W1 + b1) -> bufB ----
     {
       f32x16 acc = {0};
-      acc = tile_mma<false, false, VALU>(bufX, LDH, bufC, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
+      acc = tile_mma<false, false, VALU>(bufA, LDH, bufC, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
       const int col = nt * 32 + li;
       const float bb = b1s[col];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bufH1[(mt * 32 + drow(r, lh)) * LDH + col] = fast_tanh(acc[r] + bb);
+      for (int r = 0; r < 16; ++r) bufB[(mt * 32 + drow(r, lh)) * LDH + col] = fast_tanh(acc[r] + bb);
     }
-    __syncthreads();
-    // ---- S2: H2 = tanh(H1 W2 + b2) ----
+    lds_barrier();
+    // ---- S2: H2 = tanh(H1 W2 + b2) -> bufA (X is dead) ----
     {
       f32x16 acc = {0};
-      acc = tile_mma<false, false, VALU>(bufH1, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
+      acc = tile_mma<false, false, VALU>(bufB, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, acc, lane);
       const int col = nt * 32 + li;
       const float bb = b2s[col];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bufH2[(mt * 32 + drow(r, lh)) * LDH + col] = fast_tanh(acc[r] + bb);
+      for (int r = 0; r < 16; ++r) bufA[(mt * 32 + drow(r, lh)) * LDH + col] = fast_tanh(acc[r] + bb);
     }
-    __syncthreads();
+    lds_barrier();
 
     const int r = tid >> 2, q = tid & 3;
     const int gi = rowgi[r];
     float h[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) h[m] = bufH2[r * LDH + head_unit(q, m)];
+    for (int m = 0; m < 16; ++m) h[m] = bufA[r * LDH + head_unit(q, m)];
 
-    if (!bwd) {
+    if constexpr (!bwd) {
       // ---- forward: head output (logits incl. bias / value incl. bias), latent ----
       if (pol) {
         float z[8];
@@ -205,13 +234,13 @@ __global__ __launch_bounds__(256) void tower_kernel(TowerLaunch L) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int e = tid + 256 * i, rr = e >> 6, c = e & 63;
-          if (rowgi[rr] >= 0) a.h2_out[(size_t)rowgi[rr] * 64 + c] = bufH2[rr * LDH + c];
+          if (rowgi[rr] >= 0) a.h2_out[(size_t)rowgi[rr] * 64 + c] = bufA[rr * LDH + c];
         }
       }
       continue;
-    }
+    } else {
 
-    // ---- SH': dH2 = dhead . headW^T (+ external terms) ; dZ2 = dH2 * (1 - H2^2) -> bufC ----
+    // ---- SH': dH2 = dhead . headW^T (+ external terms) ; dZ2 = dH2 * (1 - H2^2) -> bufC (W1 is dead) ----
     {
       float ext[16];
 #pragma unroll
@@ -248,73 +277,91 @@ __global__ __launch_bounds__(256) void tower_kernel(TowerLaunch L) {
           bufC[r * LDH + head_unit(q, m)] = (dv * hw[head_unit(q, m)] + ext[m]) * (1.0f - h[m] * h[m]);
       }
     }
-    __syncthreads();
+    lds_barrier();
 
-    // ---- S6a: d b2, head gradients, dW2 += H1^T dZ2, dH1 = dZ2 W2^T ----
+    // ---- S6a: d b2, head gradients, dW2 += H1^T dZ2, dH1 = dZ2 W2^T; X and W1 are fetched again underneath ----
     f32x16 dh1 = {0};
+    if (!onehot) xr.issue(rowphys, a, tid);      // back into bufA for dW1 (committed once H2 is consumed)
+    w1r.issue(a.W1, 0, a.F, tid);                 // back into bufC for dL/dX (committed once dZ2 is consumed)
     {
       gb2 += lds_sum16(bufC + wave * 16 * LDH + lane, LDH);
       if (pol) {
-        for (int r0 = 0; r0 < R; r0 += 8) {
+        const float* hp = bufA + lane;
+        const float* dp = dzs + 2 * wave;
+#pragma unroll 1
+        for (int r0 = 0; r0 < R; r0 += 8, hp += 8 * LDH, dp += 8 * 8) {   // a real loop: 8 rows of reads, then their FMAs
           float hv[8];
           float2 d[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            hv[i] = bufH2[(r0 + i) * LDH + lane];
-            d[i] = *reinterpret_cast<const float2*>(dzs + (r0 + i) * 8 + 2 * wave);
+            hv[i] = hp[i * LDH];
+            d[i] = *reinterpret_cast<const float2*>(dp + i * 8);
           }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             gh0 = __builtin_fmaf(hv[i], d[i].x, gh0);
             gh1 = __builtin_fmaf(hv[i], d[i].y, gh1);
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
         if (lane < 8) ghb += lds_sum16(dzs + wave * 16 * 8 + lane, 8);
       } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float dv = dzs[wave * 16 + i];
-          gh0 = __builtin_fmaf(bufH2[(wave * 16 + i) * LDH + lane], dv, gh0);
+          gh0 = __builtin_fmaf(bufA[(wave * 16 + i) * LDH + lane], dv, gh0);
           ghb += dv;
         }
       }
-      gW2 = tile_mma<true, false, VALU>(bufH1, LDH, bufC, LDH, mt * 32, nt * 32, 0, R, gW2, lane);
+      gW2 = tile_mma<true, false, VALU>(bufB, LDH, bufC, LDH, mt * 32, nt * 32, 0, R, gW2, lane);
       dh1 = tile_mma<false, true, VALU>(bufC, LDH, w2s, LDH, mt * 32, nt * 32, 0, HID, dh1, lane);
     }
-    w1r.issue(a.W1, 0, a.F);   // back into bufC for the dL/dX product (committed once dZ2 is consumed)
-    __syncthreads();
-    // ---- S6b: dZ1 = dH1 * (1 - H1^2) in place; W1 back ----
+    lds_barrier();
+    // ---- S6b: dZ1 = dH1 * (1 - H1^2) in place; X back into bufA; W1 back into bufC ----
     {
       float hv[16];
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) hv[rr] = bufH1[(mt * 32 + drow(rr, lh)) * LDH + nt * 32 + li];
+      for (int rr = 0; rr < 16; ++rr) hv[rr] = bufB[(mt * 32 + drow(rr, lh)) * LDH + nt * 32 + li];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) bufH1[(mt * 32 + drow(rr, lh)) * LDH + nt * 32 + li] = dh1[rr] * (1.0f - hv[rr] * hv[rr]);
+      for (int rr = 0; rr < 16; ++rr) bufB[(mt * 32 + drow(rr, lh)) * LDH + nt * 32 + li] = dh1[rr] * (1.0f - hv[rr] * hv[rr]);
     }
-    w1r.commit(bufC);
-    __syncthreads();
+    if (onehot) tower_stage_onehot(bufA, rowphys, a, tid);
+    else xr.commit(bufA, tid);
+    w1r.commit(bufC, tid);
+    lds_barrier();
     // ---- S7: d b1, dW1 += X^T dZ1, dL/dX = dZ1 W1^T ----
-    gb1 += lds_sum16(bufH1 + wave * 16 * LDH + lane, LDH);
-    gW1 = tile_mma<true, false, VALU>(bufX, LDH, bufH1, LDH, mt * 32, nt * 32, 0, R, gW1, lane);
+    gb1 += lds_sum16(bufB + wave * 16 * LDH + lane, LDH);
+    gW1 = tile_mma<true, false, VALU>(bufA, LDH, bufB, LDH, mt * 32, nt * 32, 0, R, gW1, lane);
     if (a.dx_out) {
       f32x16 dx = {0};
-      dx = tile_mma<false, true, VALU>(bufH1, LDH, bufC, LDH, mt * 32, nt * 32, 0, HID, dx, lane);
+      dx = tile_mma<false, true, VALU>(bufB, LDH, bufC, LDH, mt * 32, nt * 32, 0, HID, dx, lane);
+      // rows of a tile are consecutive minibatch rows (tile * 64 + row): one base pointer, constant row offsets
+      float* p0 = a.dx_out + ((size_t)tile * R + mt * 32 + 4 * lh) * 64 + nt * 32 + li;
+      const int row_lim = a.nb - (tile * R + mt * 32 + 4 * lh);    // rows below this offset exist
+      if (a.dx_accumulate) {
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const int g2 = rowgi[mt * 32 + drow(rr, lh)];
-        if (g2 >= 0) {
-          float* p = a.dx_out + (size_t)g2 * 64 + nt * 32 + li;
-          *p = a.dx_accumulate ? *p + dx[rr] : dx[rr];
+        for (int rr = 0; rr < 16; ++rr) {
+          const int ro = (rr & 3) + 8 * (rr >> 2);
+          if (ro < row_lim) p0[ro * 64] += dx[rr];
+        }
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int ro = (rr & 3) + 8 * (rr >> 2);
+          if (ro < row_lim) p0[ro * 64] = dx[rr];
         }
       }
     }
+    }
   }
-  if (!bwd) return;
+  if constexpr (!bwd) return;
 
   // ---- epilogue: accumulators -> this tower's slab (the fast gradient kernel's register order), fixed-order cross-wave sums ----
   __syncthreads();
   {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* rslab = a.slab + (size_t)blockIdx.x * a.slab_stride;
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
@@ -323,7 +370,7 @@ __global__ __launch_bounds__(256) void tower_kernel(TowerLaunch L) {
       *reinterpret_cast<float4*>(rslab + RS_W1 + o) = make_float4(gW1[4 * r4], gW1[4 * r4 + 1], gW1[4 * r4 + 2], gW1[4 * r4 + 3]);
     }
     if (pol) *reinterpret_cast<float2*>(rslab + RS_HW + lane * 8 + 2 * wave) = make_float2(gh0, gh1);
-    float* part = bufX;  // [4][4 waves][64]
+    float* part = bufA;  // [4][4 waves][64]
     part[(0 * 4 + wave) * 64 + lane] = gb1;
     part[(1 * 4 + wave) * 64 + lane] = gb2;
     part[(2 * 4 + wave) * 64 + lane] = gh0;
@@ -343,24 +390,27 @@ __global__ __launch_bounds__(256) void tower_kernel(TowerLaunch L) {
   }
 }
 
-size_t tower_lds_bytes() { return sizeof(float) * (size_t)(5 * 64 * LDH + HW_FLOATS + 64 * 8 + 2 * HID + 16 + 2 * 64); }
+size_t tower_lds_bytes() { return sizeof(float) * (size_t)(4 * 64 * LDH + HW_FLOATS + 64 * 8 + 2 * HID + 16 + 2 * 64); }
 
-hipError_t launch_tower(const TowerLaunch& L, int nwg, int n_towers, int gemm_mode, hipStream_t s) {
+template <bool VALU, bool BWD>
+static hipError_t launch_tower_inst(const TowerLaunch& L, int nwg, int n_towers, hipStream_t s) {
   const size_t lds = tower_lds_bytes();
-  static bool allowed[2][64] = {{false}};
+  static bool allowed[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   dev = (dev >= 0 && dev < 64) ? dev : 0;
-  const int v = gemm_mode != 0 ? 1 : 0;
-  if (!allowed[v][dev]) {
-    hipError_t e = v ? hipFuncSetAttribute((const void*)tower_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                     : hipFuncSetAttribute((const void*)tower_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (!allowed[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)tower_kernel<VALU, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    allowed[v][dev] = true;
+    allowed[dev] = true;
   }
-  if (v) hipLaunchKernelGGL((tower_kernel<true>), dim3(nwg, n_towers), dim3(256), lds, s, L);
-  else hipLaunchKernelGGL((tower_kernel<false>), dim3(nwg, n_towers), dim3(256), lds, s, L);
+  hipLaunchKernelGGL((tower_kernel<VALU, BWD>), dim3(nwg, n_towers), dim3(256), lds, s, L);
   return hipGetLastError();
+}
+hipError_t launch_tower(const TowerLaunch& L, int nwg, int n_towers, int gemm_mode, hipStream_t s) {
+  if (L.mode != 0)
+    return gemm_mode != 0 ? launch_tower_inst<true, true>(L, nwg, n_towers, s) : launch_tower_inst<false, true>(L, nwg, n_towers, s);
+  return gemm_mode != 0 ? launch_tower_inst<true, false>(L, nwg, n_towers, s) : launch_tower_inst<false, false>(L, nwg, n_towers, s);
 }
 
 // slab position -> parameter index (-1 = padding) of ONE tower's register-order slab (RS_NET floats): the single-net form of
