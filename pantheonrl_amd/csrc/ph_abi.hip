@@ -36,6 +36,7 @@ struct SpecCache {
   int* obs_off = nullptr;  // device prefix sums
   int* act_off = nullptr;
   int* slab_map = nullptr; // device: slab position -> parameter index for register-order gradient slabs, or null
+  int* slab_map_split = nullptr;  // device: the same table for the split-bf16 gradient kernel, or null
 };
 
 }  // namespace
@@ -199,12 +200,19 @@ int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd) {
         ph::grad_slab_map(nd->lay, m.data(), ph::grad_fast_fold(probe));
         PH_HIP(hipMalloc((void**)&c.slab_map, m.size() * sizeof(int)));
         PH_HIP(hipMemcpy(c.slab_map, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (ph::grad_split_eligible(probe)) {
+          ph::grad_slab_map_split(nd->lay, m.data(), ph::grad_fast_fold(probe));
+          PH_HIP(hipMalloc((void**)&c.slab_map_split, m.size() * sizeof(int)));
+          PH_HIP(hipMemcpy(c.slab_map_split, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
       }
     }
     ctx->specs.push_back(c);
     hit = &ctx->specs.back();
   }
   nd->slab_map = hit->slab_map;
+  nd->slab_map_split = hit->slab_map_split;
+  nd->split = 0;
   nd->obs_kind = spec->obs.kind;
   nd->D = nd->lay.D;
   nd->F = nd->lay.F;
@@ -287,6 +295,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
   for (auto& s : ctx->specs) {
     if (s.obs_off) (void)hipFree(s.obs_off);
     if (s.slab_map) (void)hipFree(s.slab_map);
+    if (s.slab_map_split) (void)hipFree(s.slab_map_split);
     if (s.act_off) (void)hipFree(s.act_off);
   }
   void* ptrs[] = {ctx->mw.act, ctx->mw.maps, ctx->mw.kl_sum, ctx->mw.scratch, ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->perm_phys, ctx->scalars, ctx->stop_flag,
@@ -1370,6 +1379,13 @@ void fill_grad_args(ph::GradArgs& g, const ph::NetDims& nd, const float* params,
   g.prof = ctx->prof;
 }
 
+// gemm_mode 2 (products as six bf16 MFMA terms over three-plane operands, float32 accuracy) applies to the gradient launches
+// of specs ppo_grad_split_kernel takes; everywhere else it means 0.  The split kernel's slabs have their own order.
+void select_gemm(ph::NetDims& nd, int gemm_mode) {
+  nd.split = (gemm_mode == 2 && nd.slab_map_split != nullptr) ? 1 : 0;
+  if (nd.split) nd.slab_map = nd.slab_map_split;
+}
+
 // floats per gradient slab: the canonical parameter layout, or the register-order layout of ppo_grad_fast_kernel
 int slab_len_of(const ph::NetDims& nd) { return nd.slab_map ? 2 * ph::RS_NET : nd.lay.P; }
 
@@ -1489,6 +1505,7 @@ int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_s
   if (check_rb(rb)) return 1;
   if (n_epochs <= 0 || batch_size <= 0) return fail("ph_ppo_train: n_epochs and batch_size must be positive");
   if (resolve(ctx, spec, &t.nd)) return 1;
+  select_gemm(t.nd, gemm_mode);
   t.ctx = ctx;
   t.opt = opt;
   t.rb = rb;
@@ -1706,6 +1723,7 @@ int minibatch_grad_run(ph_ctx* ctx, const ph_spec* spec, const float* params, co
   if (nb <= 0) return fail("ph_ppo_minibatch_grad: nb must be positive");
   ph::NetDims nd;
   if (resolve(ctx, spec, &nd)) return 1;
+  select_gemm(nd, gemm_mode);
   const int P = nd.lay.P;
   const MbPlan pl = plan_minibatch(ctx, nd, nb);
   if (ensure_train_ws(ctx, P, slab_len_of(nd), pl.nwg, 1, 0, (size_t)nb)) return 1;
@@ -1772,6 +1790,7 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   if (batch_size <= 0 || reps <= 0) return fail("ph_bench_ppo_grad: bad sizes");
   ph::NetDims nd;
   if (resolve(ctx, spec, &nd)) return 1;
+  select_gemm(nd, gemm_mode);
   const int N = rb->T * rb->E;
   const int nb = batch_size < N ? batch_size : N;
   const MbPlan pl = plan_minibatch(ctx, nd, nb);

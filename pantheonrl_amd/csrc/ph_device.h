@@ -196,6 +196,8 @@ struct NetDims {
   const int* obs_off;  // device: prefix sums of obs nvec (D+1) for the one-hot path, else nullptr
   const int* act_off;  // device: prefix sums of act nvec (A+1)
   const int* slab_map; // device: slab position -> parameter index when the spec runs on register-order slabs, else nullptr
+  const int* slab_map_split;  // device: the same for ppo_grad_split_kernel's accumulator order, or nullptr (spec not eligible)
+  int split;           // 1: this call runs the split-bf16 gradient kernel (gemm_mode 2 on an eligible spec); slab_map then IS slab_map_split
   ph_layout lay;
 };
 

@@ -339,6 +339,11 @@ void grad_slab_map(const ph_layout& lay, int* map /* host, 2 * RS_NET */, bool f
 // tiles (GradArgs.ntiles) and workgroups per net that launch_ppo_grad will use for a minibatch of nb rows
 void grad_plan(const NetDims& nd, int nb, int num_cu, int* ntiles, int* nwg);
 hipError_t launch_ppo_grad_fast(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s);
+// the same gradient with every product as six bf16 MFMA terms over three-plane operands (ph_ppo_split.hip): gemm_mode 2.
+// Its slabs are in ITS accumulators' order (grad_slab_map_split); NetDims.split says the spec runs on it.
+bool grad_split_eligible(const NetDims& nd);
+void grad_slab_map_split(const ph_layout& lay, int* map /* host, 2 * RS_NET */, bool fold);
+hipError_t launch_ppo_grad_split(const GradArgs& a, int nwg, hipStream_t s);
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s);
 int reduce_blocks(int slab_len);

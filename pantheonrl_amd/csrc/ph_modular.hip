@@ -409,8 +409,8 @@ static hipError_t launch_tower_inst(const TowerLaunch& L, int nwg, int n_towers,
 }
 hipError_t launch_tower(const TowerLaunch& L, int nwg, int n_towers, int gemm_mode, hipStream_t s) {
   if (L.mode != 0)
-    return gemm_mode != 0 ? launch_tower_inst<true, true>(L, nwg, n_towers, s) : launch_tower_inst<false, true>(L, nwg, n_towers, s);
-  return gemm_mode != 0 ? launch_tower_inst<true, false>(L, nwg, n_towers, s) : launch_tower_inst<false, false>(L, nwg, n_towers, s);
+    return gemm_mode == 1 ? launch_tower_inst<true, true>(L, nwg, n_towers, s) : launch_tower_inst<false, true>(L, nwg, n_towers, s);
+  return gemm_mode == 1 ? launch_tower_inst<true, false>(L, nwg, n_towers, s) : launch_tower_inst<false, false>(L, nwg, n_towers, s);
 }
 
 // slab position -> parameter index (-1 = padding) of ONE tower's register-order slab (RS_NET floats): the single-net form of

@@ -498,7 +498,7 @@ static hipError_t launch_fwd16_variant(const FwdArgs& a, hipStream_t s) {
 hipError_t launch_policy_fwd16_rollout(const FwdArgs& a, const ScriptedSteps& sc, int gemm_mode, hipStream_t s) {
   const size_t lds = fwd16_lds_bytes();
   dim3 grid((a.n + 15) / 16, 2), block(256);
-  if (gemm_mode != 0) hipLaunchKernelGGL((policy_fwd16_rollout_kernel<true>), grid, block, lds, s, a, sc);
+  if (gemm_mode == 1) hipLaunchKernelGGL((policy_fwd16_rollout_kernel<true>), grid, block, lds, s, a, sc);
   else hipLaunchKernelGGL((policy_fwd16_rollout_kernel<false>), grid, block, lds, s, a, sc);
   return hipGetLastError();
 }
@@ -1184,12 +1184,12 @@ hipError_t launch_policy_fwd_multi(const FwdMulti& m, int n_agents, hipStream_t 
 
 hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s) {
   // R = 32 rows per workgroup keeps >= 2*n/32 workgroups in flight for the small-E rollout step
-  const bool big = (gemm_mode == 0 && a.n >= 16384);
+  const bool big = (gemm_mode != 1 && a.n >= 16384);
   const bool lp64 = a.nd.Lp == 64;
   if (a.nd.Lp != 32 && a.nd.Lp != 64) return hipErrorInvalidValue;
-  if (fwd16_eligible(a.nd, a.n)) return gemm_mode != 0 ? launch_fwd16_variant<true>(a, s) : launch_fwd16_variant<false>(a, s);
-  if (fwd16h_eligible(a.nd, a.n)) return gemm_mode != 0 ? launch_fwd16h_variant<true>(a, s) : launch_fwd16h_variant<false>(a, s);
-  if (gemm_mode != 0) return lp64 ? launch_fwd_variant<32, 64, true>(a, s) : launch_fwd_variant<32, 32, true>(a, s);
+  if (fwd16_eligible(a.nd, a.n)) return gemm_mode == 1 ? launch_fwd16_variant<true>(a, s) : launch_fwd16_variant<false>(a, s);
+  if (fwd16h_eligible(a.nd, a.n)) return gemm_mode == 1 ? launch_fwd16h_variant<true>(a, s) : launch_fwd16h_variant<false>(a, s);
+  if (gemm_mode == 1) return lp64 ? launch_fwd_variant<32, 64, true>(a, s) : launch_fwd_variant<32, 32, true>(a, s);
   if (big) return lp64 ? launch_fwd_variant<64, 64, false>(a, s) : launch_fwd_variant<64, 32, false>(a, s);
   return lp64 ? launch_fwd_variant<32, 64, false>(a, s) : launch_fwd_variant<32, 32, false>(a, s);
 }

@@ -819,10 +819,11 @@ void grad_plan(const NetDims& nd, int nb, int num_cu, int* ntiles, int* nwg) {
 }
 
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s) {
+  if (a.nd.split) return launch_ppo_grad_split(a, nwg, s);   // gemm_mode 2 on a spec the split kernel takes (ph_abi.hip: select_gemm)
   if (grad_fast_eligible(a.nd)) return launch_ppo_grad_fast(a, nwg, gemm_mode, s);
   if (a.nd.Lp != 32 && a.nd.Lp != 64) return hipErrorInvalidValue;
   const bool lp64 = a.nd.Lp == 64;
-  if (gemm_mode != 0) return lp64 ? launch_grad_shape<64, true>(a, nwg, s) : launch_grad_shape<32, true>(a, nwg, s);
+  if (gemm_mode == 1) return lp64 ? launch_grad_shape<64, true>(a, nwg, s) : launch_grad_shape<32, true>(a, nwg, s);
   return lp64 ? launch_grad_shape<64, false>(a, nwg, s) : launch_grad_shape<32, false>(a, nwg, s);
 }
 

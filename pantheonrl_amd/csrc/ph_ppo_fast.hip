@@ -612,7 +612,7 @@ void grad_slab_map(const ph_layout& lay, int* map, bool fold) {
 }
 
 hipError_t launch_ppo_grad_fast(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s) {
-  return gemm_mode != 0 ? launch_fast_variant<true>(a, nwg, s) : launch_fast_variant<false>(a, nwg, s);
+  return gemm_mode == 1 ? launch_fast_variant<true>(a, nwg, s) : launch_fast_variant<false>(a, nwg, s);
 }
 
 }  // namespace ph

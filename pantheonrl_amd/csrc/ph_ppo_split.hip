@@ -1,0 +1,752 @@
+// ppo_grad_split_kernel: the PPO minibatch gradient of ppo_grad_fast_kernel (same shape class, same loss arithmetic, same
+// slab / reduce / Adam pipeline; SB3 PPO.train() inner loop, pantheonrl/common/agents.py:155, arithmetic SURVEY.md A.3) with
+// every 64x64x64 product on the bf16 matrix pipe at float32 accuracy.
+//
+// gfx950 has no fast f32 matrix instruction: v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate (1/16 of bf16) and occupies the
+// SIMD's vector lanes, so in ppo_grad_fast_kernel the MFMA, VALU and LDS issue cycles add up.  Here every f32
+// operand x is carried as three bf16 planes  x = h + m + l  (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 3 x 8 = 24
+// significand bits, the subtraction residues are exact) and a product is six v_mfma_f32_16x16x32_bf16 terms accumulated in
+// f32: hh + hm + mh + mm + hl + lh (the dropped ml / lm / ll terms are <= 2^-24 relative, the size of one f32 rounding).
+// Measured against float64 (scripts/ubench/split_bf16_probe.hip, 64x64x64, profiles/r03_split_bf16_probe.txt) the six-term
+// product has a LOWER rms error than the exact-f32 fmaf chain (7.6e-7 vs 1.2e-6 on N(0,1) operands) because the matrix pipe sums
+// the 32 products of an instruction before it rounds.  Six bf16 MFMAs cost 6/16 of the f32 MFMA they replace AND run on the
+// matrix pipe beside the vector ALU instead of on it.
+//
+// Decomposition: grid (nWG, 2 nets), 64-row tiles, four waves; wave w owns hidden units / output columns [16w, 16w+16) of
+// every product (N side) and all 64 rows or inputs (M side: four 16x16 blocks).  Its three weight operands (W1, W2 for the
+// forward pass, W2 by rows for dH1) are split once per workgroup and stay in registers as MFMA B fragments (72 VGPRs): no
+// weight ever sits in LDS.  Activations live in LDS only as bf16 planes, each in ONE layout; the product that contracts over
+// the plane's row index reads it with ds_read_b64_tr_b16 (the hardware 4x4 transpose), the one that contracts over the
+// contiguous index with ds_read_b128:
+//     XT   [feature][row]   written from the gathered rows      S1 (tr)      dW1 (plain)
+//     H1T  [unit][row]      S1 epilogue (4 rows = one b64)      S2 (tr)      dW2 (plain)       -> DZ1T [unit][row] (dW1, plain)
+//     DZ2  [row][unit]      head phase (8 units = one b128)     dH1 (plain)  dW2 (tr)          overlays H2 (f32, head only)
+// Bias gradients are MFMAs with an all-ones A operand on the B fragments already in registers; layer 1's bias rides as
+// feature 63 (FOLD) as in the f32 kernel.  3 x 24 KB of planes + 5.8 KB of head state = 79.7 KB -> two workgroups per CU.
+#include "ph_head.h"
+
+namespace ph {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 tr_bf16x4;
+#define PH_LDS_AS __attribute__((address_space(3)))
+
+constexpr int PL_ROW = 128;             // bytes of one plane row: 64 bf16 = 8 granules of 16 bytes
+constexpr int PL_BYTES = 64 * PL_ROW;   // one plane
+constexpr int PB_BYTES = 3 * PL_BYTES;  // a plane buffer: planes h, m, l
+
+// 16-byte granule g of plane row a sits at granule g ^ pl_swz(a): sixteen consecutive rows reading the same logical granule
+// (the ds_read_b128 operand pattern) cover all 64 banks once, and the four rows of a transposing read land on different
+// bank groups (rows a and a + 2 differ in bit 2 of the granule index)
+__device__ __forceinline__ int pl_swz(int a) { return (((a >> 1) & 1) << 2) | (((a >> 2) & 1) << 1) | ((a >> 3) & 1); }
+
+struct Frag3 {
+  bf16x8 p[3];
+};
+
+__device__ __forceinline__ void split1(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  const float r1 = x - (float)h;   // exact
+  m = (__bf16)r1;
+  const float r2 = r1 - (float)m;  // exact
+  l = (__bf16)r2;
+}
+__device__ __forceinline__ void split8(const float* x, Frag3& f) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    __bf16 h, m, l;
+    split1(x[e], h, m, l);
+    f.p[0][e] = h;
+    f.p[1][e] = m;
+    f.p[2][e] = l;
+  }
+}
+__device__ __forceinline__ void split4(const float* x, bf16x4 (&p)[3]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    __bf16 h, m, l;
+    split1(x[e], h, m, l);
+    p[0][e] = h;
+    p[1][e] = m;
+    p[2][e] = l;
+  }
+}
+
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// acc += (ah + am + al)(bh + bm + bl) without the three smallest cross terms, small terms first
+__device__ __forceinline__ f32x4 mma6(const Frag3& a, const Frag3& b, f32x4 acc) {
+  acc = mfma16(a.p[0], b.p[2], acc);
+  acc = mfma16(a.p[2], b.p[0], acc);
+  acc = mfma16(a.p[1], b.p[1], acc);
+  acc = mfma16(a.p[0], b.p[1], acc);
+  acc = mfma16(a.p[1], b.p[0], acc);
+  acc = mfma16(a.p[0], b.p[0], acc);
+  return acc;
+}
+// column sums: every row of the 16x16 result is sum_k b[k][col]
+__device__ __forceinline__ f32x4 mma_ones(const Frag3& b, f32x4 acc) {
+  bf16x8 one;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) one[e] = (__bf16)1.0f;
+  acc = mfma16(one, b.p[2], acc);
+  acc = mfma16(one, b.p[1], acc);
+  acc = mfma16(one, b.p[0], acc);
+  return acc;
+}
+
+// eight k-contiguous elements of plane row `a`: one ds_read_b128 per plane.  base = byte offset of (row, logical granule) with
+// the swizzle applied (see plain_base); `imm` = compile-time displacement (16-row block, buffer)
+__device__ __forceinline__ Frag3 ld_plain(const char* smem, int base, int imm) {
+  Frag3 f;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) f.p[p] = *reinterpret_cast<const bf16x8*>(smem + base + imm + p * PL_BYTES);
+  return f;
+}
+__device__ __forceinline__ bf16x4 ld_tr4(const char* smem, int off) {
+  const tr_bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((PH_LDS_AS tr_bf16x4*)(smem + off));
+  return __builtin_bit_cast(bf16x4, v);
+}
+// eight elements along the plane-ROW index (rows k0 .. k0+7) of one column per lane: two transposing reads per plane.
+// lo / hi = byte offsets of the lane's 8-byte piece in rows k0 + (t>>2) and k0 + 4 + (t>>2) (see tr_base)
+__device__ __forceinline__ Frag3 ld_tr(const char* smem, int lo, int hi, int imm) {
+  Frag3 f;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const bf16x4 a = ld_tr4(smem, lo + imm + p * PL_BYTES), b = ld_tr4(smem, hi + imm + p * PL_BYTES);
+    f.p[p] = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  return f;
+}
+
+// lane (i = lane & 15, kg = lane >> 4) of an MFMA operand read with ld_plain: plane row 16*blk + i (blk through imm), elements
+// 32*c + 8*kg .. +7  ->  logical granule 4c + kg
+__device__ __forceinline__ int plain_base(int i, int kg, int c) { return i * PL_ROW + (((4 * c + kg) ^ pl_swz(i)) << 4); }
+// lane (t = lane & 15, kg) of an operand read with ld_tr: column 16*mblk + t, plane rows 32*c + 8*kg + 4*half + 0..3.  The lane
+// addresses the 8-byte piece (row +(t>>2), columns 16*mblk + 4*(t&3) .. +3) and receives column t of the 4 x 16 block.
+__device__ __forceinline__ int tr_base(int t, int kg, int c, int half, int mblk) {
+  const int a = 32 * c + 8 * kg + 4 * half + (t >> 2);
+  const int g = 2 * mblk + ((t & 3) >> 1);
+  return a * PL_ROW + ((g ^ pl_swz(a)) << 4) + 8 * (t & 1);
+}
+// b64 store of rows 16*blk + 4*kg .. +3 of plane row a (the C layout of a 16x16 tile: lane column, four consecutive rows)
+__device__ __forceinline__ int cstore_off(int a, int blk, int kg) {
+  return a * PL_ROW + (((2 * blk + (kg >> 1)) ^ pl_swz(a)) << 4) + 8 * (kg & 1);
+}
+__device__ __forceinline__ void st_planes4(char* smem, int off, const bf16x4 (&p)[3]) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(smem + off + q * PL_BYTES) = p[q];
+}
+__device__ __forceinline__ void st_planes8(char* smem, int off, const Frag3& f) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(smem + off + q * PL_BYTES) = f.p[q];
+}
+
+struct SplitRowMeta {
+  int phys;
+  float adv, old, act;
+};
+
+// Box observation rows in registers: lane = feature, register i = row 16*wave + i (sixteen consecutive rows per lane: two
+// 16-byte plane stores per plane at commit)
+struct XRows {
+  float v[16];
+  __device__ __forceinline__ void issue(int physv, const float* obs, const NetDims& nd, int lane) {
+    const int f = lane < nd.F ? lane : 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = __builtin_amdgcn_readlane(physv, i);
+      v[i] = __builtin_nontemporal_load(obs + (size_t)(p < 0 ? 0 : p) * nd.D + f);
+    }
+  }
+  template <bool FOLD>
+  __device__ __forceinline__ void commit(char* xt, int physv, const NetDims& nd, int wave, int lane) const {
+    const bool fok = lane < nd.F;
+    const float pad = (FOLD && lane == 63) ? 1.f : 0.f;
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = __builtin_amdgcn_readlane(physv, i);
+      x[i] = (p >= 0) ? (fok ? v[i] : pad) : 0.f;
+    }
+    const int sw = pl_swz(lane);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      Frag3 f;
+      split8(x + 8 * g, f);
+      st_planes8(xt, lane * PL_ROW + (((2 * wave + g) ^ sw) << 4), f);
+    }
+  }
+};
+
+template <int NK, bool FOLD>
+__global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
+  if (*a.stop_flag) return;
+  PH_STAMP(a.prof, 0);
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  char* smem = reinterpret_cast<char*>(smem_f);
+  constexpr int R = 64;
+  constexpr int XT = 0, H1T = PB_BYTES, DZ2 = 2 * PB_BYTES;   // byte offsets of the plane buffers
+  const NetDims& nd = a.nd;
+  const ph_layout& lay = nd.lay;
+  float* h2 = smem_f + DZ2 / 4;                 // [R][LDH] f32, overlaid by the DZ2 planes once the head phase has read it
+  float* hw = smem_f + 3 * PB_BYTES / 4;        // policy: act_W as [64][8] skewed (head_row) | value: val_W [64]
+  float* dzs = hw + HW_FLOATS;                  // policy: dL/dlogits [R][8] | value: dL/dv [R]
+  float* b1s = dzs + R * 8;                     // [64]
+  float* b2s = b1s + HID;                       // [64]
+  float* hbs = b2s + HID;                       // act_b [8] | val_b
+  float* radv = hbs + 16;                       // [R]
+  float* rold = radv + R;                       // [R]
+  float* ract = rold + R;                       // [R]
+  int* rowphys = (int*)(ract + R);              // [R]
+
+  const int net = blockIdx.y;
+  const int oW1 = net == 0 ? lay.pi_W1 : lay.vf_W1, oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1;
+  const int oW2 = net == 0 ? lay.pi_W2 : lay.vf_W2, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
+  const float inv_nb = 1.0f / (float)a.nb;
+  const int nk = nd.L;
+
+  const uint64_t perm_key = a.idx ? 0ull : epoch_key(a.perm_seed + (a.epoch ? *a.epoch : 0ull), a.perm_epoch);
+  const bool norm = net == 0 && a.norm_adv && a.nb > 1;
+  const float adv_mean = norm ? a.advstats[0] : 0.f;
+  const float adv_den = norm ? a.advstats[1] + 1e-8f : 1.f;
+
+  // lane i < 16 of wave w serves row 16*w + i
+  auto row_index = [&](int tile, int wave, int lane) -> int {
+    const int gi = tile * R + wave * 16 + lane;
+    if (lane >= 16 || gi >= a.nb) return -1;
+    if (a.idx_phys) return a.idx_phys[gi];
+    return a.idx ? a.idx[gi] : (int)feistel_perm((uint32_t)(a.mb_start + gi), a.perm_n, a.perm_hb, perm_key);
+  };
+  auto row_scalars = [&](int n) -> SplitRowMeta {
+    SplitRowMeta m;
+    m.phys = -1;
+    m.adv = m.old = m.act = 0.f;
+    if (n >= 0) {
+      m.phys = a.idx_phys ? n : env_major_to_phys(n, a.T, a.E);
+      if (net == 0) {
+        m.adv = a.rb_adv[m.phys];
+        m.old = a.rb_logp[m.phys];
+        m.act = a.rb_act[m.phys];
+      } else {
+        m.adv = a.rb_ret[m.phys];
+        m.old = a.rb_val[m.phys];
+      }
+    }
+    return m;
+  };
+
+  // ---- prologue: this wave's weight fragments (split once), head weights, the first tile's rows ----
+  Frag3 W1f[2], W2f[2], W2b[2];
+  XRows xt;
+  SplitRowMeta meta;
+  {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 15, kg = lane >> 4, n = 16 * wave + j;
+    const int n0 = row_index(blockIdx.x, wave, lane);
+    float bias1 = 0.f, bias2 = 0.f, hv0 = 0.f, hv1 = 0.f, hb = 0.f;
+    if (tid < HID) {
+      bias1 = a.params[oB1 + tid];
+      bias2 = a.params[oB2 + tid];
+    }
+    if (net == 0) {
+      const int j0 = tid >> 3, k = tid & 7;
+      if (k < nk) {
+        hv0 = a.params[lay.act_W + j0 * nk + k];
+        hv1 = a.params[lay.act_W + (j0 + 32) * nk + k];
+      }
+      if (tid < 8) hb = (tid < nk) ? a.params[lay.act_b + tid] : -3.0e38f;
+    } else {
+      if (tid < HID) hv0 = a.params[lay.val_W + tid];
+      if (tid == 0) hb = a.params[lay.val_b];
+    }
+    meta = row_scalars(n0);
+    xt.issue(meta.phys, a.rb_obs, nd, lane);
+    float w1[2][8], w2[2][8], wb[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 32 * c + 8 * kg + e;
+        // feature k of the first layer: rows >= F are zero; FOLD: row 63 is b1 (X carries a 1 there)
+        w1[c][e] = (k < nd.F) ? a.params[oW1 + k * HID + n] : ((FOLD && k == HID - 1) ? a.params[oB1 + n] : 0.f);
+        w2[c][e] = a.params[oW2 + k * HID + n];
+      }
+      const float4* src = reinterpret_cast<const float4*>(a.params + oW2 + n * HID + 32 * c + 8 * kg);   // W2[n][k..k+7]
+      const float4 s0 = src[0], s1 = src[1];
+      wb[c][0] = s0.x; wb[c][1] = s0.y; wb[c][2] = s0.z; wb[c][3] = s0.w;
+      wb[c][4] = s1.x; wb[c][5] = s1.y; wb[c][6] = s1.z; wb[c][7] = s1.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      split8(w1[c], W1f[c]);
+      split8(w2[c], W2f[c]);
+      split8(wb[c], W2b[c]);
+    }
+    if (tid < HID) {
+      b1s[tid] = bias1;
+      b2s[tid] = bias2;
+    }
+    if (net == 0) {
+      hw[head_row(tid >> 3) + (tid & 7)] = hv0;
+      hw[head_row((tid >> 3) + 32) + (tid & 7)] = hv1;
+      if (tid < 8) hbs[tid] = hb;
+    } else {
+      if (tid < HID) hw[tid] = hv0;
+      if (tid == 0) hbs[0] = hb;
+    }
+  }
+
+  f32x4 gW1[4], gW2[4];
+  f32x4 gB1 = {0.f, 0.f, 0.f, 0.f}, gB2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    gW1[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gW2[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float gh0 = 0.f;              // value: d val_W[lane] partial over this wave's rows
+  float ghr[NK];                // policy: d act_W[lane][k] partial over this wave's rows
+#pragma unroll
+  for (int k = 0; k < NK; ++k) ghr[k] = 0.f;
+  float ghb = 0.f;
+  float st[NSTATP];
+#pragma unroll
+  for (int k = 0; k < NSTATP; ++k) st[k] = 0.f;
+
+  bool first = true;
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, first = false) {
+    int tidv = threadIdx.x;
+    asm volatile("" : "+v"(tidv));
+    const int tid = tidv, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kg = lane >> 4;
+    const bool has_next = tile + (int)gridDim.x < a.ntiles;
+    const int unit = 16 * wave + j;   // this lane's column of every 16x16 result
+
+    // ---- T0: this tile's rows land in LDS as planes ----
+    if (lane < 16) {
+      const int row = wave * 16 + lane;
+      rowphys[row] = meta.phys;
+      radv[row] = (norm && meta.phys >= 0) ? (meta.adv - adv_mean) / adv_den : meta.adv;
+      rold[row] = meta.old;
+      ract[row] = meta.act;
+    }
+    xt.template commit<FOLD>(smem + XT, meta.phys, nd, wave, lane);
+    lds_barrier();
+    if (first) PH_STAMP(a.prof, 1);
+
+    // per-lane operand offsets of this tile walk
+    const int pb0 = plain_base(j, kg, 0), pb1 = plain_base(j, kg, 1);
+
+    f32x4 d1[4];   // 1 - H1^2 of this lane's 16 elements (rows 16*blk + 4*kg + r, column `unit`): kept for dZ1
+    // ---- S1: H1 = tanh(X W1 (+ b1)) -> H1T planes ----
+    {
+      f32x4 acc[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const Frag3 x = ld_tr(smem, tr_base(j, kg, c, 0, b), tr_base(j, kg, c, 1, b), XT);
+          acc[b] = mma6(x, W1f[c], acc[b]);
+        }
+      }
+      const float bb = FOLD ? 0.f : b1s[unit];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = fast_tanh(FOLD ? acc[b][r] : acc[b][r] + bb);
+          d1[b][r] = 1.0f - v[r] * v[r];
+        }
+        bf16x4 p[3];
+        split4(v, p);
+        st_planes4(smem, H1T + cstore_off(unit, b, kg), p);
+      }
+    }
+    lds_barrier();
+    if (first) PH_STAMP(a.prof, 2);
+
+    // ---- S2: H2 = tanh(H1 W2 + b2) -> h2 (f32, [row][unit]) ----
+    const int n_next = has_next ? row_index(tile + gridDim.x, wave, lane) : -1;
+    {
+      f32x4 acc[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const Frag3 x = ld_tr(smem, tr_base(j, kg, c, 0, b), tr_base(j, kg, c, 1, b), H1T);
+          acc[b] = mma6(x, W2f[c], acc[b]);
+        }
+      }
+      const float bb = b2s[unit];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2[(16 * b + 4 * kg + r) * LDH + unit] = fast_tanh(acc[b][r] + bb);
+      }
+    }
+    lds_barrier();
+    if (first) PH_STAMP(a.prof, 3);
+
+    // ---- SH-a: head forward, loss, dL/dhead; dZ2 = dH2 * (1 - H2^2) stays in registers; four lanes per row ----
+    float dzv[16];
+    const int hr = tid >> 2, hq = tid & 3;
+    {
+      const int r = hr, q = hq;
+      const bool valid = rowphys[r] >= 0;
+      float h[16];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) h[m] = h2[r * LDH + head_unit(q, m)];
+      if (net == 0) {
+        float z[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) z[k] = 0.f;
+        for_head_rows<NK>(hw, q, [&](int m, const float4& w0, const float4& w1) {
+          const float wk[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int k = 0; k < NK; ++k) z[k] = __builtin_fmaf(h[m], wk[k], z[k]);
+        });
+        float pr[NK];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          z[k] = quad_sum(z[k]) + hbs[k];
+          mx = fmaxf(mx, z[k]);
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          pr[k] = fast_exp(z[k] - mx);
+          se += pr[k];
+        }
+        const float lse = mx + fast_log(se), inv = __builtin_amdgcn_rcpf(se);
+        int act = (int)ract[r];
+        act = act < 0 ? 0 : (act >= nk ? nk - 1 : act);
+        float ent = 0.f, zact = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          pr[k] *= inv;
+          ent -= pr[k] * (z[k] - lse);
+          zact = (k == act) ? z[k] : zact;
+        }
+        const float logp = zact - lse;
+        const float adv = radv[r];
+        const float lr = logp - rold[r];
+        const float ratio = fast_exp(lr);
+        const float lo_c = 1.0f - a.clip, hi_c = 1.0f + a.clip;
+        const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
+        const float pl1 = adv * ratio, pl2 = adv * rc;
+        const float inr = (ratio >= lo_c && ratio <= hi_c) ? 1.f : 0.f;
+        const float gate = (pl1 < pl2) ? 1.f : ((pl1 > pl2) ? inr : 0.5f + 0.5f * inr);
+        const float live = valid ? 1.f : 0.f;
+        const float g_lp = -inv_nb * adv * ratio * gate * live;
+        const float g_en = -a.ent_coef * inv_nb * live;
+        if (valid && q == 0) {
+          st[0] += -fminf(pl1, pl2);
+          st[2] += -ent;
+          st[3] += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
+          st[4] += (ratio - 1.0f) - lr;
+        }
+        float dz[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dz[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const float dlogp = ((k == act) ? 1.f : 0.f) - pr[k];
+          const float dent = -pr[k] * ((z[k] - lse) + ent);
+          dz[k] = g_lp * dlogp + g_en * dent;
+        }
+        if (q == 0) {
+          float4* o = reinterpret_cast<float4*>(dzs + r * 8);
+          o[0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+          if constexpr (NK > 4) o[1] = make_float4(dz[4], dz[5], dz[6], dz[7]);
+        }
+        for_head_rows<NK>(hw, q, [&](int m, const float4& w0, const float4& w1) {
+          const float wk[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          float d = dz[0] * wk[0];
+#pragma unroll
+          for (int k = 1; k < NK; ++k) d = __builtin_fmaf(dz[k], wk[k], d);
+          dzv[m] = d * (1.0f - h[m] * h[m]);
+        });
+      } else {
+        float wv[16];
+        float v = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          wv[m] = hw[head_unit(q, m)];
+          v = __builtin_fmaf(h[m], wv[m], v);
+        }
+        v = quad_sum(v) + hbs[0];
+        const float retn = radv[r], oldv = rold[r];
+        float vp = v, pass = 1.f;
+        if (a.clip_vf >= 0.f) {
+          const float dlt = v - oldv;
+          pass = (dlt >= -a.clip_vf && dlt <= a.clip_vf) ? 1.f : 0.f;
+          vp = oldv + fminf(fmaxf(dlt, -a.clip_vf), a.clip_vf);
+        }
+        const float err = vp - retn;
+        const float dv = valid ? a.vf_coef * 2.0f * err * inv_nb * pass : 0.f;
+        if (valid && q == 0) st[1] += err * err;
+        if (q == 0) dzs[r] = dv;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) dzv[m] = dv * wv[m] * (1.0f - h[m] * h[m]);
+      }
+    }
+    lds_barrier();
+    if (first) PH_STAMP(a.prof, 4);
+
+    // ---- SH-b: d head weights / d head bias over this wave's 16 rows (H2 is still in LDS) ----
+    SplitRowMeta meta_next = meta;
+    if (has_next) meta_next = row_scalars(n_next);   // next tile's row scalars, committed at its T0
+    if (net == 0) {
+      const float* hp = h2 + wave * 16 * LDH + lane;
+      const float* dp = dzs + wave * 16 * 8;
+#pragma unroll 1
+      for (int r0 = 0; r0 < 16; r0 += 4, hp += 4 * LDH, dp += 4 * 8) {
+        float hv[4];
+        float4 da[4], db[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          hv[i] = hp[i * LDH];
+          da[i] = *reinterpret_cast<const float4*>(dp + i * 8);
+          if constexpr (NK > 4) db[i] = *reinterpret_cast<const float4*>(dp + i * 8 + 4);
+          else db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float dk[8] = {da[i].x, da[i].y, da[i].z, da[i].w, db[i].x, db[i].y, db[i].z, db[i].w};
+#pragma unroll
+          for (int k = 0; k < NK; ++k) ghr[k] = __builtin_fmaf(hv[i], dk[k], ghr[k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (lane < NK) ghb += lds_sum16(dzs + wave * 16 * 8 + lane, 8);
+    } else {
+      float hv[16], dv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        hv[i] = h2[(wave * 16 + i) * LDH + lane];
+        dv[i] = dzs[wave * 16 + i];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        gh0 = __builtin_fmaf(hv[i], dv[i], gh0);
+        ghb += dv[i];
+      }
+    }
+    lds_barrier();
+
+    // ---- SH-c: dZ2 -> planes [row][unit] over H2 ----
+    {
+      const int sw = pl_swz(hr);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {   // units 8q .. 8q+7 (granule q) and 32 + 8q .. (granule 4 + q)
+        Frag3 f;
+        split8(dzv + 8 * g, f);
+        st_planes8(smem, DZ2 + hr * PL_ROW + (((4 * g + hq) ^ sw) << 4), f);
+      }
+    }
+    lds_barrier();
+    if (first) PH_STAMP(a.prof, 5);
+
+    // ---- S6a: dW2 += H1^T dZ2, d b2 ; dH1 = dZ2 W2^T ----
+    f32x4 dh1[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dh1[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        // B: dZ2 columns 16w .. +15 (this wave's units), contraction over rows 32c + 8kg ..: transposing reads
+        const Frag3 dz = ld_tr(smem, tr_base(j, kg, c, 0, wave), tr_base(j, kg, c, 1, wave), DZ2);
+        gB2 = mma_ones(dz, gB2);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const Frag3 h1 = ld_plain(smem, c == 0 ? pb0 : pb1, H1T + b * 16 * PL_ROW);   // A: H1T rows (input units) 16b + i
+          gW2[b] = mma6(h1, dz, gW2[b]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const Frag3 dz = ld_plain(smem, c == 0 ? pb0 : pb1, DZ2 + b * 16 * PL_ROW);    // A: dZ2 rows 16b + i, units 32c + 8kg ..
+          dh1[b] = mma6(dz, W2b[c], dh1[b]);
+        }
+      }
+    }
+    lds_barrier();
+    if (first) PH_STAMP(a.prof, 6);
+
+    // ---- S6b: dZ1 = dH1 * (1 - H1^2) -> DZ1T planes over H1T ----
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = dh1[b][r] * d1[b][r];
+      bf16x4 p[3];
+      split4(v, p);
+      st_planes4(smem, H1T + cstore_off(unit, b, kg), p);
+    }
+    lds_barrier();
+
+    // ---- S7: dW1 += X^T dZ1 (d b1 rides as feature 63, or as a ones product).  The next tile's rows are gathered underneath. ----
+    meta = meta_next;
+    if (has_next) xt.issue(meta.phys, a.rb_obs, nd, lane);
+    {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const Frag3 dz = ld_plain(smem, c == 0 ? pb0 : pb1, H1T + wave * 16 * PL_ROW);   // B: DZ1T row (unit) 16w + j, rows 32c + 8kg ..
+        if constexpr (!FOLD) gB1 = mma_ones(dz, gB1);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const Frag3 x = ld_plain(smem, c == 0 ? pb0 : pb1, XT + b * 16 * PL_ROW);     // A: XT rows (features) 16b + i
+          gW1[b] = mma6(x, dz, gW1[b]);
+        }
+      }
+    }
+    lds_barrier();  // XT / H1T / row scalars are free for the next tile
+    if (first) PH_STAMP(a.prof, 7);
+  }
+  PH_STAMP(a.prof, 12);
+
+  // ---- epilogue: accumulators -> slab (once), cross-wave sums in a fixed order ----
+  {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* rslab = a.slabs + ((size_t)blockIdx.x * 2 + net) * RS_NET;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int o = ((wave * 4 + b) * 64 + lane) * 4;
+      *reinterpret_cast<float4*>(rslab + RS_W2 + o) = make_float4(gW2[b][0], gW2[b][1], gW2[b][2], gW2[b][3]);
+      *reinterpret_cast<float4*>(rslab + RS_W1 + o) = make_float4(gW1[b][0], gW1[b][1], gW1[b][2], gW1[b][3]);
+    }
+    if (lane < 16) {   // every row of the ones products is the column sum
+      rslab[RS_B2 + 16 * wave + lane] = gB2[0];
+      if constexpr (!FOLD) rslab[RS_B1 + 16 * wave + lane] = gB1[0];
+    }
+#pragma unroll
+    for (int k = 0; k < NSTATP; ++k) {
+      float v = st[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      st[k] = v;
+    }
+    float* part = smem_f;  // [3 + NK][4 waves][64] over XT
+    part[(0 * 4 + wave) * 64 + lane] = gh0;
+    part[(1 * 4 + wave) * 64 + lane] = ghb;
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < NSTATP; ++k) part[(2 * 4 + wave) * 64 + k] = st[k];
+    }
+    if (net == 0) {
+#pragma unroll
+      for (int k = 0; k < NK; ++k) part[((3 + k) * 4 + wave) * 64 + lane] = ghr[k];
+    }
+    lds_barrier();
+    auto wsum = [&](int which, int idx) {
+      return ((part[(which * 4 + 0) * 64 + idx] + part[(which * 4 + 1) * 64 + idx]) + part[(which * 4 + 2) * 64 + idx]) +
+             part[(which * 4 + 3) * 64 + idx];
+    };
+    if (net == 1 && tid < HID) rslab[RS_HW + tid] = wsum(0, tid);
+    if (net == 0) {
+#pragma unroll
+      for (int k0 = 0; k0 < NK; k0 += 4) {
+        const int k = k0 + (tid >> 6), jj = tid & 63;
+        if (k < NK) rslab[RS_HW + jj * 8 + k] = wsum(3 + k, jj);
+      }
+    }
+    if (net == 0 && tid < 8) rslab[RS_HB + tid] = wsum(1, tid);
+    if (net == 1 && tid == 0) rslab[RS_HB] = wsum(1, 0);
+    if (tid < NSTATP) a.statpart[((size_t)net * gridDim.x + blockIdx.x) * NSTATP + tid] = wsum(2, tid);
+  }
+  PH_STAMP(a.prof, 13);
+}
+
+static size_t grad_split_lds_bytes() {
+  return (size_t)3 * PB_BYTES + sizeof(float) * (size_t)(HW_FLOATS + 64 * 8 + 2 * HID + 16 + 3 * 64 + 64);
+}
+
+// the split kernel takes Box observations of the fast kernel's shape class (PH_GRAD_SPLIT=0 switches it off)
+bool grad_split_eligible(const NetDims& nd) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("PH_GRAD_SPLIT");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  return enabled && grad_fast_eligible(nd) && nd.obs_kind == PH_SPACE_BOX;
+}
+
+template <int NK, bool FOLD>
+static hipError_t launch_split_inst(const GradArgs& a, int nwg, hipStream_t s) {
+  const size_t lds = grad_split_lds_bytes();
+  static bool allowed_dev[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  bool& allowed = allowed_dev[(dev >= 0 && dev < 64) ? dev : 0];
+  if (!allowed) {
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_split_kernel<NK, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    allowed = true;
+  }
+  hipLaunchKernelGGL((ppo_grad_split_kernel<NK, FOLD>), dim3(nwg, 2), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+template <int NK>
+static hipError_t launch_split_nk(const GradArgs& a, int nwg, hipStream_t s) {
+  return grad_fast_fold(a.nd) ? launch_split_inst<NK, true>(a, nwg, s) : launch_split_inst<NK, false>(a, nwg, s);
+}
+
+hipError_t launch_ppo_grad_split(const GradArgs& a, int nwg, hipStream_t s) {
+  switch (a.nd.L) {
+    case 1: return launch_split_nk<1>(a, nwg, s);
+    case 2: return launch_split_nk<2>(a, nwg, s);
+    case 3: return launch_split_nk<3>(a, nwg, s);
+    case 4: return launch_split_nk<4>(a, nwg, s);
+    case 5: return launch_split_nk<5>(a, nwg, s);
+    case 6: return launch_split_nk<6>(a, nwg, s);
+    case 7: return launch_split_nk<7>(a, nwg, s);
+    default: break;
+  }
+  return launch_split_nk<8>(a, nwg, s);
+}
+
+// slab position -> parameter index for the split kernel's accumulator order: position ((wave*4 + blk)*64 + lane)*4 + r holds
+// element (k = 16*blk + 4*(lane>>4) + r, col = 16*wave + (lane & 15)) of dW2 / dW1
+void grad_slab_map_split(const ph_layout& lay, int* map, bool fold) {
+  const int F = lay.F, L = lay.L;
+  for (int net = 0; net < 2; ++net) {
+    int* m = map + net * RS_NET;
+    for (int i = 0; i < RS_NET; ++i) m[i] = -1;
+    const int oW1 = net == 0 ? lay.pi_W1 : lay.vf_W1, oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1;
+    const int oW2 = net == 0 ? lay.pi_W2 : lay.vf_W2, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
+    for (int s = 0; s < HID * HID; ++s) {
+      const int wave = s >> 10, blk = (s >> 8) & 3, lane = (s >> 2) & 63, r = s & 3;
+      const int k = 16 * blk + 4 * (lane >> 4) + r, col = 16 * wave + (lane & 15);
+      m[RS_W2 + s] = oW2 + k * HID + col;
+      if (k < F) m[RS_W1 + s] = oW1 + k * HID + col;
+      else if (fold && k == HID - 1) m[RS_W1 + s] = oB1 + col;
+    }
+    for (int i = 0; i < HID; ++i) {
+      if (!fold) m[RS_B1 + i] = oB1 + i;
+      m[RS_B2 + i] = oB2 + i;
+    }
+    if (net == 0) {
+      for (int j = 0; j < HID; ++j)
+        for (int k = 0; k < L && k < 8; ++k) m[RS_HW + j * 8 + k] = lay.act_W + j * L + k;
+      for (int k = 0; k < L && k < 8; ++k) m[RS_HB + k] = lay.act_b + k;
+    } else {
+      for (int j = 0; j < HID; ++j) m[RS_HW + j] = lay.val_W + j;
+      m[RS_HB] = lay.val_b;
+    }
+  }
+}
+
+}  // namespace ph

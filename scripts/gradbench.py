@@ -16,7 +16,8 @@ run_iteration_eager(agent, data)
 th.cuda.synchronize()
 pol, rb = model.policy, model.rollout_buffer
 hp = model.hyper(); ms = C.c_float(0); rb.pos = T
-for rep in range(3):
-    nat.check(pol.ctx.lib.ph_bench_ppo_grad(pol.ctx.handle, C.byref(pol.spec), pol.params.data_ptr(), C.byref(rb.c_struct()),
-                                            C.byref(hp), int(model.batch_size), 200, 0, C.byref(ms)))
-print(os.environ.get("PANTHEON_HIP_LIB", "default").split("/")[-1], "us/launch %.2f" % (ms.value * 1e3))
+for mode in (int(m) for m in os.environ.get("GRADBENCH_MODES", "0,2").split(",")):   # 0 = f32 MFMA kernel, 2 = split-bf16 kernel
+    for rep in range(3):
+        nat.check(pol.ctx.lib.ph_bench_ppo_grad(pol.ctx.handle, C.byref(pol.spec), pol.params.data_ptr(), C.byref(rb.c_struct()),
+                                                C.byref(hp), int(model.batch_size), 200, mode, C.byref(ms)))
+    print(os.environ.get("PANTHEON_HIP_LIB", "default").split("/")[-1], "gemm_mode", mode, "us/launch %.2f" % (ms.value * 1e3))

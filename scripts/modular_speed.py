@@ -53,7 +53,8 @@ def step_plain():
 
 dt = timed(step_plain)
 print(f"MlpPolicy forward + add, {E} environments: {dt / 32 * 1e6:.1f} us per step (host call included)")
-for K in (1, 2, 3):
+KS = tuple(int(k) for k in os.environ.get("MOD_K", "1,2,3").split(","))
+for K in KS:
     m = ModularAlgorithm("ModularPolicy", env, n_steps=T, n_envs=E, batch_size=E * T // 4, n_epochs=10, seed=0,
                          marginal_reg_coef=0.5, policy_kwargs=dict(num_partners=K))
     m.device_permutations = True

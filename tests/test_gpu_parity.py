@@ -7,6 +7,8 @@ Tolerances (float32 path, stated per test):
   * gradients: atol 1e-6 + rtol 2e-4 ;  post-Adam weights: atol 2e-6 per optimizer step taken.
   * everything integer (actions under a mask, illegal-action fix-up, permutation indices): bit-exact.
 """
+import copy
+
 import numpy as np
 import pytest
 import torch as th
@@ -265,7 +267,9 @@ def test_buffer_add_reward_reset_and_fused_step():
 # ----------------------------------------------------------------------------------------------------------------
 # K3/K5/K6 PPO update
 # ----------------------------------------------------------------------------------------------------------------
-def _grad_pair(name, T, E, idx, hp: orc.PPOHyper, seed=11, gemm_mode=0):
+def _grad_pair(name, T, E, idx, hp: orc.PPOHyper, seed=11, gemm_mode=0, f64=False):
+    """device minibatch gradient, the oracle's autograd gradient (float32 as the reference computes it; f64: the same graph in
+    float64 -- the yardstick for "which float32 path is closer to the true gradient")"""
     import ctypes as C
     from pantheonrl_amd import _native as nat
     from pantheonrl_amd.ppo import PPO
@@ -282,6 +286,36 @@ def _grad_pair(name, T, E, idx, hp: orc.PPOHyper, seed=11, gemm_mode=0):
     loss, stats_ref = orc.ppo_minibatch_loss(orac, mb, hp)
     loss.backward()
     g_ref = orac.flat_grads()
+    if f64:
+        o64 = copy.deepcopy(orac).double()
+        mb64 = {k: (v.double() if v.is_floating_point() else v) for k, v in mb.items()}
+        o64.optimizer = None
+        for q in o64.parameters():
+            q.grad = None
+        # the loss of orc.ppo_minibatch_loss written out on the float64 modules (Box observations, one Discrete head; the
+        # oracle's own entry point casts observations to float32)
+        lat_pi, lat_vf = o64.policy_net(mb64["observations"]), o64.value_net_mlp(mb64["observations"])
+        logp_all = th.log_softmax(o64.action_net(lat_pi), dim=-1)
+        act64 = mb64["actions"].long().flatten()
+        log_prob = logp_all.gather(1, act64[:, None])[:, 0]
+        entropy = -(logp_all.exp() * logp_all).sum(-1)
+        values = o64.value_net(lat_vf).flatten()
+        adv = mb64["advantages"]
+        if hp.normalize_advantage and len(adv) > 1:
+            adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        ratio = th.exp(log_prob - mb64["old_log_prob"])
+        pl = -th.min(adv * ratio, adv * th.clamp(ratio, 1 - hp.clip_range, 1 + hp.clip_range)).mean()
+        vp = values if hp.clip_range_vf is None else mb64["old_values"] + th.clamp(values - mb64["old_values"], -hp.clip_range_vf,
+                                                                                  hp.clip_range_vf)
+        loss64 = pl + hp.ent_coef * (-entropy.mean()) + hp.vf_coef * ((mb64["returns"] - vp) ** 2).mean()
+        loss64.backward()
+        parts = []
+        for seq in (o64.policy_net, o64.value_net_mlp):       # the flat parameter order of MlpPolicyOracle.flat_grads, kept in float64
+            for li in (0, 2):
+                parts += [seq[li].weight.grad.t().contiguous().reshape(-1), seq[li].bias.grad]
+        parts += [o64.action_net.weight.grad.t().contiguous().reshape(-1), o64.action_net.bias.grad,
+                  o64.value_net.weight.grad.reshape(-1), o64.value_net.bias.grad]
+        g_ref = th.cat(parts).numpy().copy()
     # device gradient
     model = PPO.__new__(PPO)
     for k in ("learning_rate", "clip_range", "clip_range_vf", "ent_coef", "vf_coef", "max_grad_norm", "target_kl",
@@ -326,6 +360,40 @@ def test_minibatch_gradient_options_and_valu_cross_check():
     assert np.array_equal(g, g1), np.abs(g - g1).max()   # MFMA == fmaf chain, bitwise
     g2, g2_ref, _, _, lay2 = _grad_pair("liar", 16, 6, idx[idx < 96][:70], hp)
     _assert_grads(g2, g2_ref, lay2)
+
+
+@pytest.mark.parametrize("name,T,E,nb", [("overcooked", 16, 8, 64), ("overcooked", 32, 16, 200), ("mpe8", 8, 8, 37),
+                                          ("overcooked", 64, 64, 4096)])
+def test_split_bf16_gradient_matches_autograd(name, T, E, nb):
+    """gemm_mode 2 (ppo_grad_split_kernel: every product as six bf16 MFMA terms over three-plane operands) against the same
+    autograd gradient and at the same tolerance as the exact-float32 kernel"""
+    rng = np.random.default_rng(nb)
+    idx = rng.permutation(T * E)[:nb]
+    g, g_ref, st, st_ref, lay = _grad_pair(name, T, E, idx, orc.PPOHyper(), gemm_mode=2)
+    _assert_grads(g, g_ref, lay)
+    for i, k in enumerate(("policy_loss", "value_loss", "entropy_loss", "clip_fraction", "approx_kl", "loss")):
+        assert abs(st[i] - st_ref[k]) <= 1e-5 + 1e-4 * abs(st_ref[k]), (k, st[i], st_ref[k])
+    hp = orc.PPOHyper(clip_range=0.1, clip_range_vf=0.3, ent_coef=0.01, vf_coef=0.7, normalize_advantage=False)
+    g, g_ref, _, _, lay = _grad_pair(name, T, E, idx, hp, gemm_mode=2)
+    _assert_grads(g, g_ref, lay)
+
+
+def test_split_bf16_gradient_is_as_close_to_float64_as_the_float32_kernel():
+    """The accuracy claim behind gemm_mode 2, measured: against the float64 gradient of the same minibatch the split kernel's
+    error is no larger than 1.5x the exact-float32 MFMA kernel's (in practice it is smaller: the matrix pipe adds the 32
+    products of an instruction before it rounds) -- and both are at float32 rounding level."""
+    T, E, nb = 64, 64, 4096
+    idx = np.random.default_rng(3).permutation(T * E)[:nb]
+    hp = orc.PPOHyper()
+    g0, g64, _, _, _ = _grad_pair("overcooked", T, E, idx, hp, gemm_mode=0, f64=True)
+    g2 = _grad_pair("overcooked", T, E, idx, hp, gemm_mode=2)[0]
+    assert not np.array_equal(g0, g2)                      # it IS the other kernel
+    scale = np.abs(g64).max()
+    e0, e2 = np.abs(g0 - g64), np.abs(g2 - g64)
+    rms0, rms2 = float(np.sqrt((e0 ** 2).mean())), float(np.sqrt((e2 ** 2).mean()))
+    print(f"vs float64: f32 kernel max {e0.max():.3e} rms {rms0:.3e} | split kernel max {e2.max():.3e} rms {rms2:.3e} | scale {scale:.3e}")
+    assert e2.max() <= 1.5 * e0.max() + 1e-9 and rms2 <= 1.5 * rms0 + 1e-10, (e0.max(), e2.max(), rms0, rms2)
+    assert e2.max() <= 2e-6 * scale + 1e-9, (e2.max(), scale)
 
 
 def _train_pair(name, T, E, hp: orc.PPOHyper, seed=21, device_perms=False):
