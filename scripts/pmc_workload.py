@@ -29,8 +29,9 @@ lib, h = pol.ctx.lib, pol.ctx.handle
 ms = C.c_float(0)
 hp = model.hyper()
 pol._bind()
-nat.check(lib.ph_bench_ppo_grad(h, C.byref(pol.spec), pol.params.data_ptr(), C.byref(rb.c_struct()), C.byref(hp),
-                                int(model.batch_size), 5, 0, C.byref(ms)))
+for gm in (int(m) for m in os.environ.get("PMC_GEMM_MODES", "0,2").split(",")):   # 0: ppo_grad_fast_kernel, 2: ppo_grad_split_kernel
+    nat.check(lib.ph_bench_ppo_grad(h, C.byref(pol.spec), pol.params.data_ptr(), C.byref(rb.c_struct()), C.byref(hp),
+                                    int(model.batch_size), 5, gm, C.byref(ms)))
 Tb, Eb = 2048, 16384
 big = nat.PhRollout()
 big.T, big.E = Tb, Eb
