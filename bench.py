@@ -230,19 +230,35 @@ def roofline(args, agent):
     hp = model.hyper()
     ms = C.c_float(0)
     pol._bind()
+    gm = int(getattr(pol, "gemm_mode", 0))
     nat.check(pol.ctx.lib.ph_bench_ppo_grad(pol.ctx.handle, C.byref(pol.spec), pol.params.data_ptr(),
-                                            C.byref(rb.c_struct()), C.byref(hp), int(model.batch_size), 20, 0,
+                                            C.byref(rb.c_struct()), C.byref(hp), int(model.batch_size), 20, gm,
                                             C.byref(ms)))
     macs = 2 * (lay.F * 64 + 64 * 64) + 64 * lay.L + 64
     nb = min(model.batch_size, rb.buffer_size * rb.n_envs)
     flops = 6.0 * macs * nb
     achieved = flops / (ms.value * 1e-3) / 1e12
     small = lay.F <= 64 and lay.A == 1 and lay.L <= 8 and os.environ.get("PH_GRAD_FAST", "1") != "0"
-    kernel = (f"ppo_grad_fast_kernel<false, {lay.L}, {'true' if (lay.F < 64 and type(pol.observation_space).__name__ == 'Box') else 'false'}>"
-              if small else "ppo_grad_kernel<64,LP,false>")
+    box = type(pol.observation_space).__name__ == "Box"
+    fold = "true" if (lay.F < 64 and box) else "false"
+    split = small and box and gm == 2 and os.environ.get("PH_GRAD_SPLIT", "1") != "0"
+    kernel = (f"ppo_grad_split_kernel<{lay.L}, {fold}>" if split else
+              f"ppo_grad_fast_kernel<false, {lay.L}, {fold}>" if small else "ppo_grad_kernel<64,LP,false>")
     out = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": 157.3,
            "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None, "launch_ms": ms.value,
-           "flops_per_launch": flops}
+           "flops_per_launch": flops, "gemm_mode": gm,
+           "peak_basis": "dense f32 MFMA peak of gfx950 (v_mfma_f32_32x32x2_f32: 157.3 TFLOP/s = the f32 vector rate)"}
+    if split:
+        # what the matrix pipe actually executes: five 64x64x64 products per tile and net, six bf16 terms each, plus the
+        # ones-products of the bias gradients -- against the dense bf16 peak
+        tiles = (nb + 63) // 64
+        executed = 2.0 * tiles * 4 * 246 * (16 * 16 * 32 * 2)
+        out["matrix_pipe"] = {"executed_flops_per_launch": executed, "achieved": executed / (ms.value * 1e-3) / 1e12,
+                              "peak": 2500.0, "unit": "TFLOP/s (bf16 dense)",
+                              "frac": executed / (ms.value * 1e-3) / 1e12 / 2500.0,
+                              "note": "float32 operands as three bf16 planes, six v_mfma_f32_16x16x32_bf16 terms per product, f32 "
+                                      "accumulate; error vs a float64 gradient <= the exact-f32 kernel's (tests/test_gpu_parity.py); the "
+                                      "kernel is bound by its VALU work (tanh, plane splits, head), not by the matrix pipe"}
     # secondary, HBM-bound: the GAE pass (20 algorithmic bytes per transition) at the bench size (launch-latency bound:
     # 2.6 MB) and at a saturating size (E=16384, T=2048: 671 MB), serial (bit-exact) and scan kernels
     lv = th.zeros(rb.n_envs, device=pol.device)
@@ -285,7 +301,7 @@ def roofline(args, agent):
         from pmc_digest import kernel_source_sha256
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_ppo_grad.json")))
         now = kernel_source_sha256(ROOT)
-        if not small or "ppo_grad_fast_kernel" not in rec.get("kernel", ""):
+        if kernel.split("<")[0] not in rec.get("kernel", ""):
             out["traffic_source"] = "no committed PMC passes for this workload's kernel"
         elif rec.get("kernel_source_sha256") != now:
             out["traffic_source"] = (f"REFUSED: profiles/pmc_ppo_grad.json was collected on kernel sources {str(rec.get('kernel_source_sha256'))[:12]} "
@@ -548,6 +564,10 @@ def main():
                    "exchange": ({"route": exchange.route, **exchange.route_log, "p2p_timeouts": exchange.p2p_timeouts()}
                                 if exchange is not None and hasattr(exchange, "route") else None),
                    "launch_mode": mode,
+                   # arithmetic of the update's 64x64 products: see include/pantheon_hip.h (gemm_mode) -- 2 = float32 operands as three
+                   # bf16 planes, six matrix-pipe terms per product, f32 accumulate (float32 accuracy, measured against float64 in
+                   # tests/test_gpu_parity.py); 0 = exact-f32 MFMA (PH_GEMM_MODE=0 python bench.py reproduces that line)
+                   "gemm_mode": int(getattr(agents[0].model.policy, "gemm_mode", 0)),
                    "action_masks": args.action_masks if mode == "fusedstep" else "none",
                    # how the n_steps steps of a rollout are launched: "scripted" / "persistent" = ONE launch per rollout (N = 1
                    # graph mode; the exchange layouts with the per-step action hand-off done in-kernel), "stepwise" / "p2p" = one

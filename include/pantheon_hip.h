@@ -511,7 +511,14 @@ int ph_framestack_push(ph_ctx *ctx, float *stack, const float *obs, const unsign
  *              Feistel permutation of [0,T*E) per epoch generated in-kernel from perm_seed.
  *   stats      (n_epochs * ceil(T*E/batch_size), PH_NSTAT) f32 or NULL: per minibatch
  *              {policy_loss, value_loss, entropy_loss, clip_fraction, approx_kl, loss, grad_norm, applied}.
- *   gemm_mode  0 = MFMA v_mfma_f32_32x32x2_f32 (product path), 1 = VALU fmaf chain with the same tile order (debug).
+ *   gemm_mode  how the 64x64x64 products are computed:
+ *              0 = v_mfma_f32_32x32x2_f32, exact float32 (bit-for-bit the k-ordered fmaf chain);
+ *              1 = VALU fmaf chain with the same tile order (debug cross-check of 0, bitwise equal to it);
+ *              2 = float32 operands carried as three bf16 planes (x = h + m + l, 24 significand bits), each product six
+ *                  v_mfma_f32_16x16x32_bf16 terms accumulated in float32 (ppo_grad_split_kernel): float32 accuracy -- against a
+ *                  float64 gradient its error is not larger than mode 0's (tests/test_gpu_parity.py) -- at 6/16 of the matrix
+ *                  cycles, beside the vector ALU instead of on it.  Applies to the gradient launches of specs that kernel
+ *                  takes (Box observations, <= 64 features, one Discrete head of <= 8 logits); everywhere else 2 means 0.
  * target_kl early stop is evaluated on the device; later minibatches become no-ops (applied = 0). */
 int ph_ppo_train(ph_ctx *ctx, const ph_spec *spec, const ph_opt_state *opt, const ph_rollout *rb,
                  const ph_ppo_hyper *hyper /* host */, int n_epochs, int batch_size, const int *perms,

@@ -15,6 +15,7 @@ writes, GAE, forward, PPO update) runs in the hand-written HIP kernels.  There i
 from __future__ import annotations
 
 import ctypes as C
+import os
 import io
 import json
 import time
@@ -152,7 +153,10 @@ class ActorCriticPolicy:
         self.spec = sp.make_spec(observation_space, action_space)
         self.layout = nat.layout_of(self.spec)
         self.ctx = nat.Context(self.device.index)
-        self.gemm_mode = 0
+        # how the 64x64 products of the gradient kernels are computed (include/pantheon_hip.h, gemm_mode): 2 = three bf16 planes per
+        # float32 operand, six matrix-pipe terms per product (float32 accuracy, the fast path; specs the split kernel does not
+        # take run mode 0), 0 = exact float32 MFMA, 1 = VALU fmaf chain (debug cross-check of mode 0).  PH_GEMM_MODE overrides.
+        self.gemm_mode = int(os.environ.get("PH_GEMM_MODE", "2"))
         lay = self.layout
         self.params = th.zeros(lay.P, dtype=th.float32, device=self.device)
         self.adam_m = th.zeros_like(self.params)
