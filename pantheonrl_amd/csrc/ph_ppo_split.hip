@@ -106,10 +106,11 @@ __device__ __forceinline__ f32x4 mma_ones(const Frag3& b, f32x4 acc) {
 
 // eight k-contiguous elements of plane row `a`: one ds_read_b128 per plane.  base = byte offset of (row, logical granule) with
 // the swizzle applied (see plain_base); `imm` = compile-time displacement (16-row block, buffer)
+template <int PS = PL_BYTES>   // PS: byte distance between the planes of a buffer
 __device__ __forceinline__ Frag3 ld_plain(const char* smem, int base, int imm) {
   Frag3 f;
 #pragma unroll
-  for (int p = 0; p < 3; ++p) f.p[p] = *reinterpret_cast<const bf16x8*>(smem + base + imm + p * PL_BYTES);
+  for (int p = 0; p < 3; ++p) f.p[p] = *reinterpret_cast<const bf16x8*>(smem + base + imm + p * PS);
   return f;
 }
 __device__ __forceinline__ bf16x4 ld_tr4(const char* smem, int off) {
@@ -118,11 +119,12 @@ __device__ __forceinline__ bf16x4 ld_tr4(const char* smem, int off) {
 }
 // eight elements along the plane-ROW index (rows k0 .. k0+7) of one column per lane: two transposing reads per plane.
 // lo / hi = byte offsets of the lane's 8-byte piece in rows k0 + (t>>2) and k0 + 4 + (t>>2) (see tr_base)
+template <int PS = PL_BYTES>
 __device__ __forceinline__ Frag3 ld_tr(const char* smem, int lo, int hi, int imm_lo, int imm_hi) {
   Frag3 f;
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
-    const bf16x4 a = ld_tr4(smem, lo + imm_lo + p * PL_BYTES), b = ld_tr4(smem, hi + imm_hi + p * PL_BYTES);
+    const bf16x4 a = ld_tr4(smem, lo + imm_lo + p * PS), b = ld_tr4(smem, hi + imm_hi + p * PS);
     f.p[p] = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
   }
   return f;
@@ -146,9 +148,17 @@ __device__ __forceinline__ void st_planes4(char* smem, int off, const bf16x4 (&p
 #pragma unroll
   for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(smem + off + q * PL_BYTES) = p[q];
 }
+template <int PS = PL_BYTES>
 __device__ __forceinline__ void st_planes8(char* smem, int off, const Frag3& f) {
 #pragma unroll
-  for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(smem + off + q * PL_BYTES) = f.p[q];
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(smem + off + q * PS) = f.p[q];
+}
+// order this wave's LDS accesses around a hand-off between its own lanes (LDS instructions of one wave execute in order; this
+// keeps the compiler from moving accesses across the point and drains the queue)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 }
 
 struct SplitRowMeta {
@@ -197,11 +207,18 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   char* smem = reinterpret_cast<char*>(smem_f);
   constexpr int R = 64;
-  constexpr int LH2 = 68;   // leading dimension of H2: 16-byte aligned rows (the epilogue of S2 and the head phase move four units per access)
+  // The dZ2 buffer is ROW-interleaved -- row r holds its three planes back to back (384 bytes) -- and H2 (f32, 256 bytes a row)
+  // lives in the same row slots: a wave's dZ2 rows then overlay exactly the H2 rows that only this wave still reads, and the
+  // head phase (forward/loss, d head weights, dZ2 commit) runs without a workgroup barrier inside.
+  constexpr int DZ_ROW = 3 * PL_ROW, DZ_PL = PL_ROW;
   constexpr int XT = 0, H1T = PB_BYTES, DZ2 = 2 * PB_BYTES;   // byte offsets of the plane buffers
   const NetDims& nd = a.nd;
   const ph_layout& lay = nd.lay;
-  float* h2 = smem_f + DZ2 / 4;                 // [R][LH2] f32, overlaid by the DZ2 planes once the head phase has read it
+  // H2[row][unit] (f32): 16-byte granule u/4 of row r at granule (u/4) ^ h2_swz(r) of the row slot -- the S2 epilogue's and the
+  // head phase's 16-byte accesses are then (nearly) conflict-free (scripts/lds_swizzle_search.py); the swizzle depends on row
+  // bits 0..1 only, which are compile-time constants where the d act_W loop walks rows
+  auto h2_swz = [](int r) -> int { return (r & 1) | ((r & 2) ? 12 : 0); };
+  auto h2_at = [&](int r, int gran) -> float* { return reinterpret_cast<float*>(smem + DZ2 + r * DZ_ROW + ((gran ^ h2_swz(r)) << 4)); };
   float* hw = smem_f + 3 * PB_BYTES / 4;        // policy: act_W as [64][8] skewed (head_row) | value: val_W [64]
   float* dzs = hw + HW_FLOATS;                  // policy: dL/dlogits [R][8] | value: dL/dv [R]
   float* b1s = dzs + R * 8;                     // [64]
@@ -262,20 +279,35 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     // indices are back -- the row scalars and the observation rows; the weights are split while those are in flight
     const int n0 = row_index(blockIdx.x, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
+    // One per-lane pointer per matrix and compile-time displacements; every load is unconditional (W1 rows >= F read the
+    // parameters that follow W1 in the vector -- in bounds -- and are replaced afterwards): no 64-bit arithmetic and no
+    // exec-mask branch per element
     float w1[2][8], w2[2][8], wb[2][8];
+    {
+      const int wofs = 8 * kg * HID + n;
+      const float* pW1 = a.params + oW1 + wofs;
+      const float* pW2 = a.params + oW2 + wofs;
+      const float4* pWb = reinterpret_cast<const float4*>(a.params + oW2 + n * HID + 8 * kg);   // W2[n][8kg ..]
+      const float b1n = FOLD ? a.params[oB1 + n] : 0.f;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < 2; ++c) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = 32 * c + 8 * kg + e;
-        // feature k of the first layer: rows >= F are zero; FOLD: row 63 is b1 (X carries a 1 there)
-        w1[c][e] = (k < nd.F) ? a.params[oW1 + k * HID + n] : ((FOLD && k == HID - 1) ? a.params[oB1 + n] : 0.f);
-        w2[c][e] = a.params[oW2 + k * HID + n];
+        for (int e = 0; e < 8; ++e) {
+          w1[c][e] = pW1[(32 * c + e) * HID];
+          w2[c][e] = pW2[(32 * c + e) * HID];
+        }
+        const float4 s0 = pWb[8 * c], s1 = pWb[8 * c + 1];
+        wb[c][0] = s0.x; wb[c][1] = s0.y; wb[c][2] = s0.z; wb[c][3] = s0.w;
+        wb[c][4] = s1.x; wb[c][5] = s1.y; wb[c][6] = s1.z; wb[c][7] = s1.w;
       }
-      const float4* src = reinterpret_cast<const float4*>(a.params + oW2 + n * HID + 32 * c + 8 * kg);   // W2[n][k..k+7]
-      const float4 s0 = src[0], s1 = src[1];
-      wb[c][0] = s0.x; wb[c][1] = s0.y; wb[c][2] = s0.z; wb[c][3] = s0.w;
-      wb[c][4] = s1.x; wb[c][5] = s1.y; wb[c][6] = s1.z; wb[c][7] = s1.w;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 32 * c + 8 * kg + e;   // feature k: rows >= F are zero; FOLD: row 63 is b1 (X carries a 1 there)
+          w1[c][e] = (k < nd.F) ? w1[c][e] : ((FOLD && k == HID - 1) ? b1n : 0.f);
+        }
+      }
     }
     float bias1 = 0.f, bias2 = 0.f, hv0 = 0.f, hv1 = 0.f, hb = 0.f;
     if (tid < HID) {
@@ -383,26 +415,18 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     };
 
     f32x4 d1[4];   // 1 - H1^2 of this lane's 16 elements (rows 16*blk + 4*kg + r, column `unit`): kept for dZ1
-    // ---- S1: H1 = tanh(X W1 (+ b1)) -> H1T planes ----
+    // ---- S1: H1 = tanh(X W1 (+ b1)) -> H1T planes.  Block-outer: the epilogue of block b (VALU) runs under the MFMAs of b + 1 ----
     {
-      f32x4 acc[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const Frag3 x = ld_trf(XT, c, b);
-          acc[b] = mma6(x, W1f[c], acc[b]);
-        }
-      }
       const float bb = FOLD ? 0.f : b1s[unit];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc = mma6(ld_trf(XT, c, b), W1f[c], acc);
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = fast_tanh(FOLD ? acc[b][r] : acc[b][r] + bb);
+          v[r] = fast_tanh(FOLD ? acc[r] : acc[r] + bb);
           d1[b][r] = 1.0f - v[r] * v[r];
         }
         bf16x4 p[3];
@@ -413,26 +437,18 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     lds_barrier();
     if (first) PH_STAMP(a.prof, 2);
 
-    // ---- S2: H2 = tanh(H1 W2 + b2) -> h2 (f32, [row][unit]).  Operand roles swapped (A = W2 fragments): the result tile is
-    //      H2^T, i.e. lane = row 16*blk + j, registers = units 16*wave + 4*kg + r -> one 16-byte store per block ----
+    // ---- S2: H2 = tanh(H1 W2 + b2) -> H2 (f32).  Operand roles swapped (A = W2 fragments): the result tile is H2^T, i.e.
+    //      lane = row 16*blk + j, registers = units 16*wave + 4*kg + r -> one 16-byte store per block ----
     const int n_next = has_next ? row_index(tile + gridDim.x, wave, lane) : -1;
     {
-      f32x4 acc[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const Frag3 x = ld_trf(H1T, c, b);
-          acc[b] = mma6(W2f[c], x, acc[b]);
-        }
-      }
       const float4 bb = *reinterpret_cast<const float4*>(b2s + 16 * wave + 4 * kg);
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        *reinterpret_cast<float4*>(h2 + (16 * b + j) * LH2 + 16 * wave + 4 * kg) =
-            make_float4(fast_tanh(acc[b][0] + bb.x), fast_tanh(acc[b][1] + bb.y), fast_tanh(acc[b][2] + bb.z), fast_tanh(acc[b][3] + bb.w));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc = mma6(W2f[c], ld_trf(H1T, c, b), acc);
+        *reinterpret_cast<float4*>(h2_at(16 * b + j, 4 * wave + kg)) =
+            make_float4(fast_tanh(acc[0] + bb.x), fast_tanh(acc[1] + bb.y), fast_tanh(acc[2] + bb.z), fast_tanh(acc[3] + bb.w));
       }
     }
     lds_barrier();
@@ -447,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
       float h[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {   // head_unit(q, m) = 8q + (m & 7) + 32 (m >> 3): two runs of eight units
-        const float4 v = *reinterpret_cast<const float4*>(h2 + r * LH2 + 8 * q + 4 * (g & 1) + 32 * (g >> 1));
+        const float4 v = *reinterpret_cast<const float4*>(h2_at(r, 2 * q + (g & 1) + 8 * (g >> 1)));
         h[4 * g] = v.x; h[4 * g + 1] = v.y; h[4 * g + 2] = v.z; h[4 * g + 3] = v.w;
       }
       if (net == 0) {
@@ -545,22 +561,26 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
         for (int m = 0; m < 16; ++m) dzv[m] = dv * wv[m] * (1.0f - h[m] * h[m]);
       }
     }
-    lds_barrier();
+    wave_lds_sync();   // dzs rows of this wave are written and read by this wave only
     if (first) PH_STAMP(a.prof, 4);
 
-    // ---- SH-b: d head weights / d head bias over this wave's 16 rows (H2 is still in LDS) ----
+    // ---- SH-b: d head weights / d head bias over this wave's 16 rows (H2 rows of this wave, still in LDS) ----
     SplitRowMeta meta_next = meta;
     if (has_next) meta_next = row_scalars(n_next);   // next tile's row scalars, committed at its T0
     if (net == 0) {
-      const float* hp = h2 + wave * 16 * LH2 + lane;
+      // unit `lane` of row r sits at dword ((lane >> 2) ^ h2_swz(r)) * 4 + (lane & 3) of the row slot; h2_swz(r) only depends on r & 3
+      int lofs[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lofs[i] = (((lane >> 2) ^ h2_swz(i)) << 2) | (lane & 3);
+      const float* hp = reinterpret_cast<const float*>(smem + DZ2 + wave * 16 * DZ_ROW);
       const float* dp = dzs + wave * 16 * 8;
 #pragma unroll 1
-      for (int r0 = 0; r0 < 16; r0 += 4, hp += 4 * LH2, dp += 4 * 8) {
+      for (int r0 = 0; r0 < 16; r0 += 4, hp += 4 * (DZ_ROW / 4), dp += 4 * 8) {
         float hv[4];
         float4 da[4], db[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          hv[i] = hp[i * LH2];
+          hv[i] = hp[i * (DZ_ROW / 4) + lofs[i]];
           da[i] = *reinterpret_cast<const float4*>(dp + i * 8);
           if constexpr (NK > 4) db[i] = *reinterpret_cast<const float4*>(dp + i * 8 + 4);
           else db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -579,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
       float hv[16], dv[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        hv[i] = h2[(wave * 16 + i) * LH2 + lane];
+        hv[i] = *(reinterpret_cast<const float*>(smem + DZ2 + (wave * 16 + i) * DZ_ROW) + ((((lane >> 2) ^ h2_swz(i)) << 2) | (lane & 3)));
         dv[i] = dzs[wave * 16 + i];
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -589,16 +609,16 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
         ghb += dv[i];
       }
     }
-    lds_barrier();
+    wave_lds_sync();   // this wave's H2 rows are consumed; its dZ2 rows go on top of them
 
-    // ---- SH-c: dZ2 -> planes [row][unit] over H2 ----
+    // ---- SH-c: dZ2 -> planes, row-interleaved [row][plane][unit], over this wave's H2 rows ----
     {
       const int sw = pl_swz(hr);
 #pragma unroll
       for (int g = 0; g < 2; ++g) {   // units 8q .. 8q+7 (granule q) and 32 + 8q .. (granule 4 + q)
         Frag3 f;
         split8(dzv + 8 * g, f);
-        st_planes8(smem, DZ2 + hr * PL_ROW + (((4 * g + hq) ^ sw) << 4), f);
+        st_planes8<DZ_PL>(smem, DZ2 + hr * DZ_ROW + (((4 * g + hq) ^ sw) << 4), f);
       }
     }
     lds_barrier();
@@ -606,14 +626,15 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
 
     // ---- S6a: dW2 += H1^T dZ2, d b2 ; dH1 = dZ2 W2^T ----
     f32x4 dh1[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) dh1[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
+      // B of dW2: dZ2 columns 16w .. +15 (this wave's units), contraction over rows 32c + 8kg ..: transposing reads of the
+      // row-interleaved buffer (row stride DZ_ROW, planes DZ_PL apart)
+      const int a0 = 8 * kg + (j >> 2), g0 = ((j & 3) >> 1) ^ pl_swz(a0), row0 = a0 * DZ_ROW + 8 * (j & 1);
+      const int tlo = row0 + ((g0 ^ (2 * wave)) << 4), thi = row0 + ((g0 ^ (2 * (wave ^ 1))) << 4);
+      const int db0 = j * DZ_ROW + ((kg ^ pl_swz(j)) << 4), db1 = j * DZ_ROW + (((4 + kg) ^ pl_swz(j)) << 4);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        // B: dZ2 columns 16w .. +15 (this wave's units), contraction over rows 32c + 8kg ..: transposing reads
-        const Frag3 dz = ld_tr(smem, tr_base(j, kg, 0, 0, wave), tr_base(j, kg, 0, 1, wave) - 4 * PL_ROW, DZ2 + 32 * c * PL_ROW,
-                               DZ2 + (32 * c + 4) * PL_ROW);
+        const Frag3 dz = ld_tr<DZ_PL>(smem, tlo, thi, DZ2 + 32 * c * DZ_ROW, DZ2 + (32 * c + 4) * DZ_ROW);
         gB2 = mma_ones(dz, gB2);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -622,28 +643,27 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
         }
       }
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int b = 0; b < 4; ++b) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const Frag3 dz = ld_plain(smem, c == 0 ? pb0 : pb1, DZ2 + b * 16 * PL_ROW);    // A: dZ2 rows 16b + i, units 32c + 8kg ..
-          dh1[b] = mma6(dz, W2b[c], dh1[b]);
-        }
+        for (int c = 0; c < 2; ++c)   // A: dZ2 rows 16b + i, units 32c + 8kg ..
+          acc = mma6(ld_plain<DZ_PL>(smem, c == 0 ? db0 : db1, DZ2 + b * 16 * DZ_ROW), W2b[c], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh1[b][r] = acc[r] * d1[b][r];   // dZ1 (registers; stored after the barrier)
       }
     }
     lds_barrier();
     if (first) PH_STAMP(a.prof, 6);
 
-    // ---- S6b: dZ1 = dH1 * (1 - H1^2) -> DZ1T planes over H1T ----
+    // ---- S6b: dZ1 -> DZ1T planes over H1T (this wave's 16 units = the only rows its dW1 product reads) ----
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = dh1[b][r] * d1[b][r];
+      float v[4] = {dh1[b][0], dh1[b][1], dh1[b][2], dh1[b][3]};
       bf16x4 p[3];
       split4(v, p);
       st_planes4(smem, H1T + csb[b], p);
     }
-    lds_barrier();
+    wave_lds_sync();
 
     // ---- S7: dW1 += X^T dZ1 (d b1 rides as feature 63, or as a ones product).  The next tile's rows are gathered underneath. ----
     meta = meta_next;

@@ -90,3 +90,32 @@ for LH2 in (65,68,72,76,80,84):
             for g in range(4):
                 t7+=cycles(lambda l: ((16*w+(l>>2))*LH2+8*(l&3)+4*(g&1)+32*(g>>1))*4, B128_GROUPS, 64, 16)
     print("LH2",LH2,"P6 h2 b128 write x16:",t6,"P7 head b128 read x16:",t7)
+
+# ---- H2 (f32) inside the row-interleaved dZ2 buffer: row stride 384 B, unit granule (4 floats) g at (g ^ f(row)) ----
+def h2_total(M):
+    def f(r):
+        v = 0
+        for b in range(4):
+            v |= (bin(r & M[b]).count("1") & 1) << b
+        return v
+    t6 = 0
+    for w in range(4):
+        for b in range(4):
+            t6 += cycles(lambda l: (16*b+(l&15))*384 + ((((4*w+(l>>4))) ^ f(16*b+(l&15))) << 4), G8, 32, 16)
+    t7 = 0
+    for w in range(4):
+        for g in range(4):
+            t7 += cycles(lambda l: (16*w+(l>>2))*384 + (((2*(l&3)+(g&1)+8*(g>>1)) ^ f(16*w+(l>>2))) << 4), B128_GROUPS, 64, 16)
+    return t6, t7
+bestf = None
+for M in itertools.product(range(16), repeat=4):
+    t6, t7 = h2_total(M)
+    if bestf is None or t6 + t7 < bestf[0]:
+        bestf = (t6 + t7, M, t6, t7)
+print("H2 swizzle best", bestf)
+bestf = None
+for M in itertools.product(range(4), repeat=4):     # f depends on row bits 0..1 only (compile-time in the d act_W loop)
+    t6, t7 = h2_total(M)
+    if bestf is None or t6 + 4 * t7 < bestf[0]:
+        bestf = (t6 + 4 * t7, M, t6, t7)
+print("H2 swizzle, row bits 0-1 only: best", bestf)

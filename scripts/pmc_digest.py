@@ -15,12 +15,12 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ("pantheonrl_amd/csrc/ph_ppo_fast.hip", "pantheonrl_amd/csrc/ph_head.h", "pantheonrl_amd/csrc/ph_device.h",
+KERNEL_SOURCES = ("pantheonrl_amd/csrc/ph_ppo_split.hip", "pantheonrl_amd/csrc/ph_head.h", "pantheonrl_amd/csrc/ph_device.h",
                   "pantheonrl_amd/csrc/ph_launch.h:struct GradArgs")
 
 
 def kernel_source_sha256(root: str = ROOT) -> str:
-    """hash of what ppo_grad_fast_kernel is compiled from: its translation unit, the two headers with its device code, and its
+    """hash of what ppo_grad_split_kernel (the default gradient kernel of the bench workload, gemm_mode 2) is compiled from: its translation unit, the two headers with its device code, and its
     argument record (the rest of ph_launch.h -- other kernels' records and launcher prototypes -- does not enter)"""
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES:
@@ -66,7 +66,7 @@ def _kernel_row(path, kernel_substr):
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
-    K = "ppo_grad_fast_kernel"
+    K = "ppo_grad_split_kernel"
     f, w = _counters(os.path.join(src, "pmc_f.txt"), K), _counters(os.path.join(src, "pmc_w.txt"), K)
     m, g = _counters(os.path.join(src, "pmc_m.txt"), K), _counters(os.path.join(src, "pmc_g.txt"), K)
     cal_f = _counters(os.path.join(src, "pmc_f.txt"), "gae_serial_kernel")
@@ -81,7 +81,7 @@ def main():
     waves = 2 * 256 * 4
     sq = {k: v["mean"] for k, v in {**m, **g}.items()}
     digest = {
-        "kernel": (re.search(r"ph::ppo_grad_fast_kernel<[^>]*>", row_iso["name"]).group(0) if row_iso else "ph::" + K),
+        "kernel": (re.search(r"ph::" + K + r"<[^>]*>", row_iso["name"]).group(0) if row_iso else "ph::" + K),
         "round": tag,
         "kernel_source_sha256": kernel_source_sha256(),
         "kernel_sources": list(KERNEL_SOURCES),

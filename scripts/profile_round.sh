@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python bench.py --no-cpu-ba
 python scripts/rocprof_summary.py $(find $OUT/kt -name "*_results.db" | head -1) > $OUT/bench_graph_kernel_stats.txt 2>&1
 for pass in "f:FETCH_SIZE" "w:WRITE_SIZE" "m:SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" "g:GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
   name=${pass%%:*}; ctrs=${pass#*:}
-  rocprofv3 --kernel-trace --pmc $ctrs -d $OUT/pmc_$name -o p -- python scripts/pmc_workload.py > $OUT/pmc_$name.log 2>&1
+  PMC_GEMM_MODES=2 rocprofv3 --kernel-trace --pmc $ctrs -d $OUT/pmc_$name -o p -- python scripts/pmc_workload.py > $OUT/pmc_$name.log 2>&1
   python scripts/rocprof_summary.py $(find $OUT/pmc_$name -name "*_results.db" | head -1) > $OUT/pmc_$name.txt 2>&1
 done
 rm -rf $OUT/kt $OUT/pmc_f $OUT/pmc_w $OUT/pmc_m $OUT/pmc_g
