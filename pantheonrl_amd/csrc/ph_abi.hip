@@ -37,6 +37,7 @@ struct SpecCache {
   int* act_off = nullptr;
   int* slab_map = nullptr; // device: slab position -> parameter index for register-order gradient slabs, or null
   int* slab_map_split = nullptr;  // device: the same table for the split-bf16 gradient kernel, or null
+  int* wimage_map = nullptr;      // device: parameter -> weight fragment image elements of the split kernel (ph_split.h), or null
 };
 
 }  // namespace
@@ -55,6 +56,7 @@ struct ph_ctx {
   size_t blocksq_cap = 0;
   float* advstats = nullptr;
   size_t advstats_cap = 0;
+  unsigned short* wimage = nullptr;   // split gradient kernel: pre-split weight fragments of the policy being trained (ph_split.h)
   double* advpart = nullptr;     // per-segment partial sums of the advantage statistics
   size_t advpart_cap = 0;
   int* perm_idx = nullptr;   // (n_epochs, N) minibatch order of the current train() call, written by adv_stats
@@ -204,6 +206,10 @@ int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd) {
           ph::grad_slab_map_split(nd->lay, m.data(), ph::grad_fast_fold(probe));
           PH_HIP(hipMalloc((void**)&c.slab_map_split, m.size() * sizeof(int)));
           PH_HIP(hipMemcpy(c.slab_map_split, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice));
+          std::vector<int> wm(2 * (size_t)nd->lay.P);
+          ph::grad_weight_image_map(nd->lay, ph::grad_fast_fold(probe), wm.data());
+          PH_HIP(hipMalloc((void**)&c.wimage_map, wm.size() * sizeof(int)));
+          PH_HIP(hipMemcpy(c.wimage_map, wm.data(), wm.size() * sizeof(int), hipMemcpyHostToDevice));
         }
       }
     }
@@ -212,6 +218,7 @@ int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd) {
   }
   nd->slab_map = hit->slab_map;
   nd->slab_map_split = hit->slab_map_split;
+  nd->wimage_map = hit->wimage_map;
   nd->split = 0;
   nd->obs_kind = spec->obs.kind;
   nd->D = nd->lay.D;
@@ -296,9 +303,10 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (s.obs_off) (void)hipFree(s.obs_off);
     if (s.slab_map) (void)hipFree(s.slab_map);
     if (s.slab_map_split) (void)hipFree(s.slab_map_split);
+    if (s.wimage_map) (void)hipFree(s.wimage_map);
     if (s.act_off) (void)hipFree(s.act_off);
   }
-  void* ptrs[] = {ctx->mw.act, ctx->mw.maps, ctx->mw.kl_sum, ctx->mw.scratch, ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->perm_phys, ctx->scalars, ctx->stop_flag,
+  void* ptrs[] = {ctx->wimage, ctx->mw.act, ctx->mw.maps, ctx->mw.kl_sum, ctx->mw.scratch, ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->perm_phys, ctx->scalars, ctx->stop_flag,
                   ctx->adap_extra, ctx->adap_loss};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1377,6 +1385,20 @@ void fill_grad_args(ph::GradArgs& g, const ph::NetDims& nd, const float* params,
   g.statpart = ctx->statpart;
   g.stop_flag = ctx->stop_flag;
   g.prof = ctx->prof;
+  g.wimage = ctx->wimage;
+}
+
+// the split kernel's weight fragment image of `params`, rebuilt from scratch (entries no parameter backs are zero): at the start
+// of every train() / gradient call, whatever happened to the parameters in between; ppo_adam_kernel keeps it current afterwards
+int rebuild_weight_image(ph_ctx* ctx, const ph::NetDims& nd, const float* params) {
+  if (!nd.split) return 0;
+  if (!ctx->wimage) {
+    if (ctx->capturing) return fail("first split-kernel use inside graph capture: call it once outside capture first");
+    PH_HIP(hipMalloc((void**)&ctx->wimage, (size_t)ph::WIMG_ELEMS * sizeof(unsigned short)));
+  }
+  PH_HIP(hipMemsetAsync(ctx->wimage, 0, (size_t)ph::WIMG_ELEMS * sizeof(unsigned short), ctx->stream));
+  PH_HIP(ph::launch_weight_image(params, ctx->wimage, nd.wimage_map, nd.lay.P, ctx->stream));
+  return 0;
 }
 
 // gemm_mode 2 (products as six bf16 MFMA terms over three-plane operands, float32 accuracy) applies to the gradient launches
@@ -1525,6 +1547,7 @@ int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_s
     return 1;
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
+  if (rebuild_weight_image(ctx, t.nd, opt->params)) return 1;
   t.hb = ph::feistel_half_bits((uint32_t)t.N);
   ph::AdvStatArgs aa;
   aa.rb_adv = rb->advantages;
@@ -1618,6 +1641,8 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
   ad.eps = t.hp->adam_eps;
   ad.max_norm = t.hp->max_grad_norm;
   ad.stats_out = r.stats_out;
+  ad.wimage = t.nd.split ? ctx->wimage : nullptr;
+  ad.wimage_map = t.nd.wimage_map;
   PH_HIP(ph::launch_ppo_adam(ad, s));
   return 0;
 }
@@ -1729,6 +1754,7 @@ int minibatch_grad_run(ph_ctx* ctx, const ph_spec* spec, const float* params, co
   if (ensure_train_ws(ctx, P, slab_len_of(nd), pl.nwg, 1, 0, (size_t)nb)) return 1;
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
+  if (rebuild_weight_image(ctx, nd, params)) return 1;
   ph::AdvStatArgs aa;
   aa.rb_adv = rb->advantages;
   aa.T = rb->T;
@@ -1797,6 +1823,7 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   if (ensure_train_ws(ctx, nd.lay.P, slab_len_of(nd), pl.nwg, 1, (size_t)N, (size_t)N)) return 1;
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
+  if (rebuild_weight_image(ctx, nd, params)) return 1;
   ph::AdvStatArgs aa;
   aa.rb_adv = rb->advantages;
   aa.T = rb->T;

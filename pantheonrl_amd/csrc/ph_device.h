@@ -197,6 +197,7 @@ struct NetDims {
   const int* act_off;  // device: prefix sums of act nvec (A+1)
   const int* slab_map; // device: slab position -> parameter index when the spec runs on register-order slabs, else nullptr
   const int* slab_map_split;  // device: the same for ppo_grad_split_kernel's accumulator order, or nullptr (spec not eligible)
+  const int* wimage_map;      // device: parameter -> weight-image elements of the split kernel (ph_split.h), or nullptr
   int split;           // 1: this call runs the split-bf16 gradient kernel (gemm_mode 2 on an eligible spec); slab_map then IS slab_map_split
   ph_layout lay;
 };

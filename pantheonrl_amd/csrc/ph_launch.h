@@ -126,6 +126,7 @@ struct GradArgs {
   const int* stop_flag;    // device flag set by the KL early stop
   long long* prof;         // debug: per-workgroup phase timestamps (clock64), or null
   int ntiles;
+  const unsigned short* wimage;   // split kernel: the pre-split weight fragment image of `params` (ph_split.h)
 };
 
 __device__ __host__ inline uint64_t epoch_key(uint64_t seed, int epoch) {
@@ -205,6 +206,8 @@ struct AdamArgs {
   int* stop_flag;
   float lr, beta1, beta2, eps, max_norm;
   float* stats_out;       // [PH_NSTAT] or null: writes grad_norm at [6]
+  unsigned short* wimage; // the split gradient kernel's weight fragment image (ph_split.h) kept in step with params, or null
+  const int* wimage_map;  // [P][2]
 };
 
 size_t fwd_lds_bytes(int R, int Lp);
@@ -342,6 +345,12 @@ hipError_t launch_ppo_grad_fast(const GradArgs& a, int nwg, int gemm_mode, hipSt
 // the same gradient with every product as six bf16 MFMA terms over three-plane operands (ph_ppo_split.hip): gemm_mode 2.
 // Its slabs are in ITS accumulators' order (grad_slab_map_split); NetDims.split says the spec runs on it.
 bool grad_split_eligible(const NetDims& nd);
+// weight fragment image of the split kernel (ph_split.h): elements (bf16), distance between the planes of one fragment
+constexpr int WIMG_PLANE = 64 * 8;
+constexpr int WIMG_ELEMS = 2 * 4 * 3 * 2 * 3 * WIMG_PLANE;
+void grad_weight_image_map(const ph_layout& lay, bool fold, int* map /* host, P x 2 */);
+// image <- split(params) through the map (the image must have been zeroed by the caller)
+hipError_t launch_weight_image(const float* params, unsigned short* image, const int* map, int P, hipStream_t s);
 void grad_slab_map_split(const ph_layout& lay, int* map /* host, 2 * RS_NET */, bool fold);
 hipError_t launch_ppo_grad_split(const GradArgs& a, int nwg, hipStream_t s);
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);

@@ -12,6 +12,7 @@
 // is initialised from the slab, so the add is free); a second kernel sums the slabs in a fixed order
 // (deterministic), a third applies clip_grad_norm_ + Adam.
 #include "ph_launch.h"
+#include "ph_split.h"
 
 namespace ph {
 
@@ -1053,6 +1054,16 @@ __global__ __launch_bounds__(256) void ppo_adam_kernel(AdamArgs a) {
   a.v[p] = v;
   const float pn = a.params[p] - ss_s * (m / denom);                   // param.addcdiv_(exp_avg, denom, -step_size)
   a.params[p] = pn;
+  if (a.wimage) wimage_put(a.wimage, a.wimage_map, p, pn);             // the split gradient kernel's pre-split weight fragments
+}
+
+__global__ __launch_bounds__(256) void weight_image_kernel(const float* params, unsigned short* image, const int* map, int P) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < P) wimage_put(image, map, p, params[p]);
+}
+hipError_t launch_weight_image(const float* params, unsigned short* image, const int* map, int P, hipStream_t s) {
+  hipLaunchKernelGGL(weight_image_kernel, dim3((P + 255) / 256), dim3(256), 0, s, params, image, map, P);
+  return hipGetLastError();
 }
 hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(ppo_adam_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);

@@ -24,6 +24,7 @@
 // Bias gradients are MFMAs with an all-ones A operand on the B fragments already in registers; layer 1's bias rides as
 // feature 63 (FOLD) as in the f32 kernel.  3 x 24 KB of planes + 5.8 KB of head state = 79.7 KB -> two workgroups per CU.
 #include "ph_head.h"
+#include "ph_split.h"
 
 namespace ph {
 
@@ -52,13 +53,6 @@ struct Frag3 {
   bf16x8 p[3];
 };
 
-__device__ __forceinline__ void split1(float x, __bf16& h, __bf16& m, __bf16& l) {
-  h = (__bf16)x;
-  const float r1 = x - (float)h;   // exact
-  m = (__bf16)r1;
-  const float r2 = r1 - (float)m;  // exact
-  l = (__bf16)r2;
-}
 __device__ __forceinline__ void split8(const float* x, Frag3& f) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -279,33 +273,16 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     // indices are back -- the row scalars and the observation rows; the weights are split while those are in flight
     const int n0 = row_index(blockIdx.x, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
-    // One per-lane pointer per matrix and compile-time displacements; every load is unconditional (W1 rows >= F read the
-    // parameters that follow W1 in the vector -- in bounds -- and are replaced afterwards): no 64-bit arithmetic and no
-    // exec-mask branch per element
-    float w1[2][8], w2[2][8], wb[2][8];
+    // this wave's eighteen weight fragments, already split (ph_split.h: ppo_adam_kernel keeps the image in step with params)
     {
-      const int wofs = 8 * kg * HID + n;
-      const float* pW1 = a.params + oW1 + wofs;
-      const float* pW2 = a.params + oW2 + wofs;
-      const float4* pWb = reinterpret_cast<const float4*>(a.params + oW2 + n * HID + 8 * kg);   // W2[n][8kg ..]
-      const float b1n = FOLD ? a.params[oB1 + n] : 0.f;
+      const uint4* img = reinterpret_cast<const uint4*>(a.wimage) + (size_t)((net * 4 + wave) * 18) * 64 + lane;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          w1[c][e] = pW1[(32 * c + e) * HID];
-          w2[c][e] = pW2[(32 * c + e) * HID];
-        }
-        const float4 s0 = pWb[8 * c], s1 = pWb[8 * c + 1];
-        wb[c][0] = s0.x; wb[c][1] = s0.y; wb[c][2] = s0.z; wb[c][3] = s0.w;
-        wb[c][4] = s1.x; wb[c][5] = s1.y; wb[c][6] = s1.z; wb[c][7] = s1.w;
-      }
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int k = 32 * c + 8 * kg + e;   // feature k: rows >= F are zero; FOLD: row 63 is b1 (X carries a 1 there)
-          w1[c][e] = (k < nd.F) ? w1[c][e] : ((FOLD && k == HID - 1) ? b1n : 0.f);
+        for (int p = 0; p < 3; ++p) {
+          W1f[c].p[p] = __builtin_bit_cast(bf16x8, img[((0 * 2 + c) * 3 + p) * 64]);
+          W2f[c].p[p] = __builtin_bit_cast(bf16x8, img[((1 * 2 + c) * 3 + p) * 64]);
+          W2b[c].p[p] = __builtin_bit_cast(bf16x8, img[((2 * 2 + c) * 3 + p) * 64]);
         }
       }
     }
@@ -333,12 +310,6 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     PH_STAMP(a.prof, 10);
     if (stop_now) return;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      split8(w1[c], W1f[c]);
-      split8(w2[c], W2f[c]);
-      split8(wb[c], W2b[c]);
-    }
     PH_STAMP(a.prof, 11);
     if (tid < HID) {
       b1s[tid] = bias1;
@@ -784,6 +755,33 @@ hipError_t launch_ppo_grad_split(const GradArgs& a, int nwg, hipStream_t s) {
     default: break;
   }
   return launch_split_nk<8>(a, nwg, s);
+}
+
+// parameter -> weight-image elements (plane 0) of the fragments ppo_grad_split_kernel loads: [P][2], -1 = none
+void grad_weight_image_map(const ph_layout& lay, bool fold, int* map) {
+  for (int i = 0; i < 2 * lay.P; ++i) map[i] = -1;
+  auto elem = [](int net, int wave, int set, int c, int lane, int e) {
+    return (((((net * 4 + wave) * 3 + set) * 2 + c) * 3 + 0) * 64 + lane) * 8 + e;
+  };
+  auto put = [&](int p, int idx) {
+    if (map[2 * p] < 0) map[2 * p] = idx;
+    else map[2 * p + 1] = idx;
+  };
+  for (int net = 0; net < 2; ++net) {
+    const int oW1 = net == 0 ? lay.pi_W1 : lay.vf_W1, oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1;
+    const int oW2 = net == 0 ? lay.pi_W2 : lay.vf_W2;
+    for (int k = 0; k < HID; ++k) {
+      for (int n = 0; n < HID; ++n) {
+        // B fragment element of (contraction index k, column n): wave n/16, lane (k/8 % 4) * 16 + n % 16, chunk k/32, slot k % 8
+        const int by_col = elem(net, n >> 4, 0, k >> 5, ((k >> 3) & 3) * 16 + (n & 15), k & 7);
+        if (k < lay.F) put(oW1 + k * HID + n, by_col);
+        else if (fold && k == HID - 1) put(oB1 + n, by_col);                               // W1f: feature 63 is b1
+        put(oW2 + k * HID + n, by_col + (elem(0, 0, 1, 0, 0, 0) - elem(0, 0, 0, 0, 0, 0))); // W2f: W2[k][n], contraction over inputs k
+        // W2b: W2[row k][out n] as (column = input unit k, contraction over outputs n)
+        put(oW2 + k * HID + n, elem(net, k >> 4, 2, n >> 5, ((n >> 3) & 3) * 16 + (k & 15), n & 7));
+      }
+    }
+  }
 }
 
 // slab position -> parameter index for the split kernel's accumulator order: position ((wave*4 + blk)*64 + lane)*4 + r holds
