@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
   };
 
   // ---- prologue: this wave's weight fragments (split once), head weights, the first tile's rows ----
-  Frag3 W1f[2], W2f[2], W2b[2];
+  Frag3 W1f[2];   // (W2 for the forward pass is fetched inside S1 for S2; the third set, W2 by rows for dH1, is fetched from the image inside S6a: 24 registers less across the tile)
   XRows xt;
   SplitRowMeta meta;
   {
@@ -281,8 +281,6 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           W1f[c].p[p] = __builtin_bit_cast(bf16x8, img[((0 * 2 + c) * 3 + p) * 64]);
-          W2f[c].p[p] = __builtin_bit_cast(bf16x8, img[((1 * 2 + c) * 3 + p) * 64]);
-          W2b[c].p[p] = __builtin_bit_cast(bf16x8, img[((2 * 2 + c) * 3 + p) * 64]);
         }
       }
     }
@@ -387,6 +385,14 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
 
     f32x4 d1[4];   // 1 - H1^2 of this lane's 16 elements (rows 16*blk + 4*kg + r, column `unit`): kept for dZ1
     // ---- S1: H1 = tanh(X W1 (+ b1)) -> H1T planes.  Block-outer: the epilogue of block b (VALU) runs under the MFMAs of b + 1 ----
+    Frag3 W2f[2];   // W2 by (input, unit): B of S2, fetched under S1's products (L2-resident image)
+    {
+      const uint4* img = reinterpret_cast<const uint4*>(a.wimage) + (size_t)((net * 4 + wave) * 18 + 6) * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) W2f[c].p[p] = __builtin_bit_cast(bf16x8, img[(c * 3 + p) * 64]);
+    }
     {
       const float bb = FOLD ? 0.f : b1s[unit];
 #pragma unroll
@@ -603,6 +609,15 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
       const int a0 = 8 * kg + (j >> 2), g0 = ((j & 3) >> 1) ^ pl_swz(a0), row0 = a0 * DZ_ROW + 8 * (j & 1);
       const int tlo = row0 + ((g0 ^ (2 * wave)) << 4), thi = row0 + ((g0 ^ (2 * (wave ^ 1))) << 4);
       const int db0 = j * DZ_ROW + ((kg ^ pl_swz(j)) << 4), db1 = j * DZ_ROW + (((4 + kg) ^ pl_swz(j)) << 4);
+      // W2 by rows (B of dH1): six L2-resident 16-byte loads per lane, issued here and consumed after the dW2 product
+      Frag3 W2b[2];
+      {
+        const uint4* img = reinterpret_cast<const uint4*>(a.wimage) + (size_t)((net * 4 + wave) * 18 + 12) * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) W2b[c].p[p] = __builtin_bit_cast(bf16x8, img[(c * 3 + p) * 64]);
+      }
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const Frag3 dz = ld_tr<DZ_PL>(smem, tlo, thi, DZ2 + 32 * c * DZ_ROW, DZ2 + (32 * c + 4) * DZ_ROW);
