@@ -860,6 +860,7 @@ __global__ __launch_bounds__(64) void bc_forward_kernel(BcFwdArgs a) {
   const ph_bc_layout& lay = a.lay;
   const int F = nd.F, L = nd.L, P = lay.P;
   float* ps = smem;
+  float* zs = smem + ((P + 3) & ~3) + threadIdx.x;   // this lane's logits of one action component: zs[c * 64] (LDS, not scratch)
   for (int p = threadIdx.x; p < P; p += 64) ps[p] = a.params[p];
   __syncthreads();
   const int row = blockIdx.x * 64 + threadIdx.x;
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(64) void bc_forward_kernel(BcFwdArgs a) {
   float lp_sum = 0.f, ent_sum = 0.f;
   for (int comp = 0; comp < nd.A; ++comp) {
     const int lo = nd.act_off[comp], n = nd.act_off[comp + 1] - lo;
-    float z[PH_MAX_LOGITS];
+    auto z = [&](int c) -> float& { return zs[c * 64]; };
     float mx = -3.0e38f;
     int arg = 0;
     for (int c = 0; c < n; ++c) {
@@ -910,14 +911,14 @@ __global__ __launch_bounds__(64) void bc_forward_kernel(BcFwdArgs a) {
       for (int k = 0; k < BH; ++k) s = __builtin_fmaf(h2[k], ps[lay.act_W + k * L + lo + c], s);
       if (a.mask && a.mask[(size_t)row * L + lo + c] == 0) s -= 30.0f;   // modular/policies.py:330-333
       if (a.logits) a.logits[(size_t)row * L + lo + c] = s;
-      z[c] = s;
+      z(c) = s;
       if (s > mx) {
         mx = s;
         arg = c;
       }
     }
     float se = 0.f;
-    for (int c = 0; c < n; ++c) se += __expf(z[c] - mx);
+    for (int c = 0; c < n; ++c) se += __expf(z(c) - mx);
     const float lse = mx + __logf(se);
     int act = arg;
     if (a.given) {
@@ -928,7 +929,7 @@ __global__ __launch_bounds__(64) void bc_forward_kernel(BcFwdArgs a) {
       float cdf = 0.f;
       act = n - 1;
       for (int c = 0; c < n; ++c) {
-        cdf += __expf(z[c] - lse);
+        cdf += __expf(z(c) - lse);
         if (u < cdf) {
           act = c;
           break;
@@ -937,10 +938,10 @@ __global__ __launch_bounds__(64) void bc_forward_kernel(BcFwdArgs a) {
     }
     float h = 0.f;
     for (int c = 0; c < n; ++c) {
-      const float lq = z[c] - lse;
+      const float lq = z(c) - lse;
       h -= __expf(lq) * lq;
     }
-    lp_sum += z[act] - lse;
+    lp_sum += z(act) - lse;
     ent_sum += h;
     if (a.act_i32) a.act_i32[(size_t)row * nd.A + comp] = act;
   }
@@ -969,7 +970,7 @@ hipError_t launch_bc_forward(const NetDims& nd, const ph_bc_layout& lay, const f
   a.logp = logp;
   a.entropy = entropy;
   a.logits = logits;
-  const size_t lds = sizeof(float) * (size_t)lay.P;
+  const size_t lds = sizeof(float) * ((((size_t)lay.P + 3) & ~(size_t)3) + 64 * (size_t)PH_MAX_LOGITS);
   static size_t allowed[64] = {0};
   int dev = 0;
   (void)hipGetDevice(&dev);

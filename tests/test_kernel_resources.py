@@ -1,0 +1,72 @@
+"""Register hygiene of the bench path's kernels, checked where they are compiled (no GPU): hipcc's own resource-usage remarks for
+gfx950.  The gradient kernels must not touch scratch, and the split gradient kernel's register count is part of the iteration's
+schedule: two of its waves plus one wave of the OTHER learner's reduce / Adam kernels have to fit into the 512
+registers of a SIMD lane, or every reduce block displaces a gradient workgroup for its whole life (measured: -13 % on the bench)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pantheonrl_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+
+
+def _usage(source, tmp_path_factory):
+    out = tmp_path_factory.mktemp("res") / "x.o"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c",
+                        os.path.join(CSRC, source), "-o", str(out), "-Rpass-analysis=kernel-resource-usage"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"remark:\s+Function Name:\s+(\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill|LDS Size \[bytes/block\]):\s+(\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" [")[0]] = int(m.group(2))
+    return kernels
+
+
+@pytest.fixture(scope="module")
+def split(tmp_path_factory):
+    return _usage("ph_ppo_split.hip", tmp_path_factory)
+
+
+@pytest.fixture(scope="module")
+def ppo(tmp_path_factory):
+    return _usage("ph_ppo.hip", tmp_path_factory)
+
+
+def _alloc(k):     # registers a wave of the kernel occupies: VGPRs + AGPRs in the unified file, in granules of 8
+    return (k["VGPRs"] + k.get("AGPRs", 0) + 7) // 8 * 8
+
+
+def test_split_gradient_kernel_has_no_scratch_and_leaves_room_for_the_update_kernels(split, ppo):
+    inst = {n: k for n, k in split.items() if "ppo_grad_split_kernel" in n}
+    assert len(inst) == 16, sorted(inst)                      # NK = 1..8 x FOLD
+    for n, k in inst.items():
+        assert k["ScratchSize"] == 0 and k["VGPRs Spill"] == 0, (n, k)
+        assert _alloc(k) <= 240, (n, k)
+    bench = inst["_ZN2ph21ppo_grad_split_kernelILi6ELb1EEEvNS_8GradArgsE"]    # Overcooked: 6 logits, bias folded
+    reduce_k = ppo["_ZN2ph17ppo_reduce_kernelENS_10ReduceArgsE"]
+    adam_k = ppo["_ZN2ph15ppo_adam_kernelENS_8AdamArgsE"]
+    for other in (reduce_k, adam_k):
+        assert other["ScratchSize"] == 0
+        assert 2 * _alloc(bench) + _alloc(other) <= 512, (bench, other)
+
+
+def test_general_and_fast_gradient_kernels_have_no_scratch(ppo, tmp_path_factory):
+    fast = _usage("ph_ppo_fast.hip", tmp_path_factory)
+    for n, k in list(fast.items()) + [(n, k) for n, k in ppo.items() if "ppo_grad_kernel" in n]:
+        if "ppo_grad" not in n:
+            continue
+        # some general-kernel instantiations reserve an SGPR-scavenging slot (<= 24 bytes of private segment) without a single
+        # scratch instruction; a spilled VGPR is what this guards against
+        assert k["VGPRs Spill"] == 0 and k["ScratchSize"] <= 24, (n, k)
