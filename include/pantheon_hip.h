@@ -572,6 +572,7 @@ int ph_ppo_minibatch_grad(ph_ctx *ctx, const ph_spec *spec, const float *params,
 #define PH_CTX_UNIT_SQUARE 1     /* "unit_square": uniform in [-1,1)^n                   util.py:54-59 */
 #define PH_CTX_POSITIVE_SQUARE 2 /* "positive_square": uniform in [0,1)^n                util.py:62-67 */
 #define PH_CTX_CATEGORICAL 3     /* "categorical": one-hot                               util.py:70-77 */
+#define PH_CTX_NATURAL_NUMBERS 4 /* "natural_numbers": ONE integer in [0, ctx_size); ctx_size must be 1   util.py:80-89 */
 typedef struct ph_adap_loss {     /* defaults: ADAP.__init__ adap_learn.py:111-116 */
   int context_size;               /* 3    */
   int num_context_samples;        /* 5    */

@@ -390,6 +390,8 @@ def adap_sample_contexts(sampler: str, ctx_size: int, num: int, uniforms: np.nda
     elif sampler == "categorical":
         c = th.zeros(num, ctx_size)
         c[th.arange(num), th.clamp((u[:, 0] * ctx_size).long(), max=ctx_size - 1)] = 1
+    elif sampler == "natural_numbers":   # util.py:80-89: (num, 1) integers in [0, ctx_size), th.randint teacher-forced by u[:, 0]
+        c = th.clamp((u[:, :1] * ctx_size).long(), max=ctx_size - 1).float()
     else:
         raise ValueError(sampler)
     return c.numpy()

@@ -71,7 +71,7 @@ class PhAdapLoss(C.Structure):
                 ("used_contexts", C.c_void_p)]
 
 
-CONTEXT_SAMPLERS = {"l2": 0, "unit_square": 1, "positive_square": 2, "categorical": 3}
+CONTEXT_SAMPLERS = {"l2": 0, "unit_square": 1, "positive_square": 2, "categorical": 3, "natural_numbers": 4}
 BC_STAT_NAMES = ("neglogp", "entropy", "ent_loss", "prob_true_act", "l2_norm", "l2_loss", "loss", "rows")
 
 

@@ -37,11 +37,14 @@ def _categorical(ctx_size, num, rng):
     return c
 
 
-# adap/util.py:42-95; "natural_numbers" yields a (num, 1) vector whatever context_size is, which no AdapPolicy accepts
+# adap/util.py:42-95.  "natural_numbers" (util.py:80-89) yields a (num, 1) vector of integers in [0, ctx_size) whatever
+# context_size is: AdapPolicy.set_context only takes it when context_size == 1 (and the only integer is then 0), which is the
+# one configuration the engine accepts it in.
 SAMPLERS = {"l2": _l2,
             "unit_square": lambda n, num, rng: rng.random((num, n)).astype(np.float32) * 2 - 1,
             "positive_square": lambda n, num, rng: rng.random((num, n)).astype(np.float32),
-            "categorical": _categorical}
+            "categorical": _categorical,
+            "natural_numbers": lambda n, num, rng: rng.integers(0, n, size=(num, 1)).astype(np.float32)}
 
 
 class AdapPolicy(ActorCriticPolicy):
@@ -110,6 +113,8 @@ class ADAP(PPO):
             raise ValueError("the engine implements AdapPolicy (concatenated context); AdapPolicyMult is not built")
         if context_sampler not in SAMPLERS:
             raise ValueError(f"unknown context sampler {context_sampler!r} (one of {sorted(SAMPLERS)})")
+        if context_sampler == "natural_numbers" and int(context_size) != 1:
+            raise ValueError("context_sampler='natural_numbers' draws (num, 1) contexts (adap/util.py:80-89): it needs context_size=1")
         self.context_loss_coeff, self.context_size = float(context_loss_coeff), int(context_size)
         self.num_context_samples, self.num_state_samples = int(num_context_samples), int(num_state_samples)
         self.context_sampler = context_sampler

@@ -1456,7 +1456,9 @@ int adap_check(ph_ctx* ctx, const ph::NetDims& nd, const ph_adap_loss* ad, const
   if (ad->num_context_samples < 2 || ad->num_context_samples > ph::ADAP_ROWS)
     return fail(w + ": num_context_samples must be in [2, 16]");
   if (ad->num_state_samples <= 0) return fail(w + ": num_state_samples must be positive");
-  if (ad->sampler < PH_CTX_L2 || ad->sampler > PH_CTX_CATEGORICAL) return fail(w + ": unknown context sampler");
+  if (ad->sampler < PH_CTX_L2 || ad->sampler > PH_CTX_NATURAL_NUMBERS) return fail(w + ": unknown context sampler");
+  if (ad->sampler == PH_CTX_NATURAL_NUMBERS && ad->context_size != 1)
+    return fail(w + ": the natural_numbers sampler draws (num, 1) contexts: context_size must be 1");
   if (ph::adap_lds_bytes(nd, ad->num_context_samples, ad->context_size) > 160 * 1024)
     return fail(w + ": observation / action space too large for the context kernel's LDS tile");
   const size_t nwg = (size_t)ph::adap_workgroups(ad->num_context_samples, ad->num_state_samples);

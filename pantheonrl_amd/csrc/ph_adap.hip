@@ -142,6 +142,10 @@ __global__ __launch_bounds__(256) void adap_context_kernel(AdapArgs a) {
       float* c = cxs + ln * cs;
       if (a.contexts) {
         for (int k = 0; k < cs; ++k) c[k] = a.contexts[ln * cs + k];
+      } else if (a.sampler == PH_CTX_NATURAL_NUMBERS) {    // util.py:80-89: (num, 1) integers in [0, ctx_size); ctx_size == 1 here
+        int v = (int)(philox_uniform(key, 1ull, (uint32_t)ln, 0u) * (float)cs);
+        v = v >= cs ? cs - 1 : v;
+        for (int k = 0; k < cs; ++k) c[k] = k == 0 ? (float)v : 0.f;
       } else if (a.sampler == PH_CTX_CATEGORICAL) {        // util.py:70-77
         int hot = (int)(philox_uniform(key, 1ull, (uint32_t)ln, 0u) * (float)cs);
         hot = hot >= cs ? cs - 1 : hot;

@@ -320,7 +320,9 @@ def test_adap_refuses_what_it_does_not_implement():
     with pytest.raises(ValueError):
         ADAP("AdapPolicyMult", box)
     with pytest.raises(ValueError):
-        ADAP("AdapPolicy", box, context_sampler="natural_numbers")
+        ADAP("AdapPolicy", box, context_sampler="natural_numbers")          # (num, 1) contexts need context_size = 1 ...
+    nn_model = ADAP("AdapPolicy", box, context_sampler="natural_numbers", context_size=1, n_steps=8, batch_size=8, n_epochs=1)
+    assert np.array_equal(nn_model.sample_context(4), np.zeros((4, 1), np.float32))   # ... and the only integer in [0, 1) is 0
     with pytest.raises(ValueError):
         ADAP("AdapPolicy", disc)
     m = ADAP("AdapPolicy", box, n_steps=8, batch_size=8, n_epochs=1, num_context_samples=1)
