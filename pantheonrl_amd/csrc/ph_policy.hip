@@ -247,6 +247,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   float* b2s = b1s + HID;           // [64]
   float* hbs = b2s + HID;           // act_b [8] | val_b
   int* rowphys = (int*)(hbs + 8);   // [16]
+  float* upre = (float*)(rowphys + 16);   // [2][16] sampling uniforms of the rows, drawn a step ahead (scripted rollouts)
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -311,6 +312,15 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
     a.counter = a0.counter + epoch_hi;
   }
   const unsigned long long px_epoch = (px && px_persistent) ? *px->epoch : 0ull;   // constant for the launch as well
+  // (scripted rollouts) the sampling uniform of step t + 1 is a function of (seed, counter + t + 1, row) alone: wave 1, idle
+  // during the head phase of the policy workgroup, draws it a step ahead, so the ten Philox rounds leave the one lane per row
+  // that walks softmax -> inverse CDF -> log-prob.  Same call, same value: the rollout stays bitwise the launch-by-launch walk.
+  const bool draw_ahead = sc && net == 0 && !a0.uniforms && !a0.deterministic && !a0.given_actions;
+  auto draw_uniforms = [&](int t1) {
+    if (lane < R && row0 + lane < a0.n)
+      upre[(t1 & 1) * R + lane] = philox_uniform(a0.seed, a0.counter + (unsigned long long)t1 + epoch_hi, (uint32_t)(row0 + lane), 0u);
+  };
+  if (draw_ahead && wave == 1) draw_uniforms(0);   // visible to wave 0 after the barriers of step 0's layers
   for (int t = 0; t < n_steps; ++t) {
   if (t > 0) {   // (scripted rollout) the next step's argument record and observation rows; the weights stay where they are
     const size_t row = (size_t)t * a0.n;
@@ -401,7 +411,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
 #pragma unroll
       for (int k = 0; k < 8; ++k) z[k] = quad_sum_f(z[k]) + ((k < nk) ? hbs[k] : 0.f);
       if (q == 0 && grow < a.n) {
-        const int act = discrete8_row_tail(a, nd, grow, z, fwd_counter(a));
+        const int act = discrete8_row_tail(a, nd, grow, z, fwd_counter(a), draw_ahead ? upre + (t & 1) * R + r : nullptr);
         if (px) {  // push: (stamp << 32 | action) as one 8-byte store into every rank's receive area, slot t mod ll_slots
           const int pt = px_t + t;
           const int slot = px_persistent ? p2p_persistent_slot(px_epoch, px->T, pt) : pt % px->ll_slots;
@@ -437,6 +447,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
       }
     }
   }
+  if (draw_ahead && wave == 1 && t + 1 < n_steps) draw_uniforms(t + 1);
   if (net == 1) copy_obs_rows(a, row0, (a.n - row0 < R) ? a.n - row0 : R, nd.D);
   PH_STAMP(a.prof, 7);
   }
@@ -469,7 +480,7 @@ static int current_device_slot() {
   return (dev >= 0 && dev < 64) ? dev : 0;
 }
 
-static size_t fwd16_lds_bytes() { return sizeof(float) * (size_t)(2 * 16 * LDH + 2 * HID * LDH + HID * 8 + 2 * HID + 8 + 16); }
+static size_t fwd16_lds_bytes() { return sizeof(float) * (size_t)(2 * 16 * LDH + 2 * HID * LDH + HID * 8 + 2 * HID + 8 + 16 + 32); }
 
 bool fwd16_eligible(const NetDims& nd, int n) {
   static int enabled = -1;

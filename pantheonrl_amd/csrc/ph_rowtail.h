@@ -86,7 +86,9 @@ __device__ __forceinline__ uint64_t fwd_counter(const FwdArgs& a) {
 
 // Discrete action space with <= 8 logits, one lane per row, the row's logits in registers (z[k >= L] ignored): optional
 // mask offset, logits output, sampling / argmax / given action, log-prob, entropy and the rollout-buffer writes
-__device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDims& nd, int g, float (&zr)[8], uint64_t ctr) {
+// u_pre: this row's sampling uniform when the caller drew it ahead of time (the same Philox call, off the critical lane)
+__device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDims& nd, int g, float (&zr)[8], uint64_t ctr,
+                                                  const float* u_pre = nullptr) {
   const int nk = nd.L;
   if (a.mask) {  // modular/policies.py:330-333 : logits - 30*(~mask)
 #pragma unroll
@@ -122,7 +124,7 @@ __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDim
     for (int k = 1; k < 8; ++k)
       if (k < nk && zr[k] > best) { best = zr[k]; act = k; }
   } else {
-    const float u = a.uniforms ? a.uniforms[g] : philox_uniform(a.seed, ctr, (uint32_t)g, 0u);
+    const float u = a.uniforms ? a.uniforms[g] : (u_pre ? *u_pre : philox_uniform(a.seed, ctr, (uint32_t)g, 0u));
     float cum = 0.f;
 #pragma unroll
     for (int k = 0; k < 7; ++k) {  // inverse CDF: count prefix sums <= u
