@@ -58,11 +58,16 @@ class ActionExchange:
         self._p2p_keep = []
 
     # -- peer-to-peer route ---------------------------------------------------------------------------------------------
-    def attach_p2p(self, ctx, epoch_word: th.Tensor, n_steps: int, timeout_s: float = 2.0) -> bool:
+    def attach_p2p(self, ctx, epoch_word: th.Tensor, n_steps: int, timeout_s: Optional[float] = None) -> bool:
         """Map every rank's fine-grained receive area through HIP IPC (handles travel through the process group's store)
         and build the ph_p2p descriptor.  `epoch_word` is the device word the engine advances once per iteration
-        (ph_rng_epoch_advance); stamps are epoch * n_steps + t + 1.  Returns False if anything fails."""
+        (ph_rng_epoch_advance); stamps are epoch * n_steps + t + 1.  Returns False if anything fails.
+        `timeout_s` bounds ONE in-kernel wait for a peer's word (default PH_P2P_TIMEOUT_S or 10 s: a bound for lost peers, far
+        above any healthy hand-off -- ranks that time-slice one GPU, or a rank still instantiating its graphs, can be seconds
+        late to a step)."""
         import ctypes as C
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("PH_P2P_TIMEOUT_S", "10"))
 
         from . import _native as nat
         if not self.local.is_cuda or self.world > nat.PH_MAX_RANKS:

@@ -277,7 +277,10 @@ def test_adap_context_samplers_have_the_reference_shapes():
     rng = np.random.default_rng(0)
     for name, fn in SAMPLERS.items():
         c = fn(3, 16, rng)
-        assert c.shape == (16, 3) and c.dtype == np.float32
+        # util.py:80-89: "natural_numbers" is (num, 1) integers in [0, ctx_size) whatever ctx_size is
+        assert c.shape == ((16, 1) if name == "natural_numbers" else (16, 3)) and c.dtype == np.float32
+    nat_num = orc.adap_sample_contexts("natural_numbers", 3, 64, u)
+    assert nat_num.shape == (64, 1) and np.array_equal(nat_num[:, 0], np.floor(u[:, 0] * 3))
     assert np.abs(np.linalg.norm(SAMPLERS["l2"](3, 16, rng), axis=1) - 1).max() < 1e-6
 
 
