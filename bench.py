@@ -120,6 +120,10 @@ def build_agents(args, device):
         model = PPO("MlpPolicy", env, n_steps=args.n_steps, n_envs=args.n_envs, batch_size=args.batch_size,
                     n_epochs=args.n_epochs, seed=seed, device=device)
         model.device_permutations = True
+        if args.agents_per_gpu == 1 and os.environ.get("PH_EXCLUSIVE_DEVICE", "1") != "0":
+            # one learner per GPU (north_star's layout, config 5): its update launches have the device to themselves, so the slab
+            # reduction may use the wide blocks (same summation tree, same results: include/pantheon_hip.h)
+            model.policy.ctx.set_exclusive_device(True)
         agents.append(VecOnPolicyAgent(model))
         datas.append(SyntheticRollouts(obs_space, args.n_envs, args.n_steps, wl["horizon"], seed % 3, device))
     return agents, datas

@@ -121,6 +121,11 @@ int ph_rng_epoch_advance(ph_ctx *ctx);
 /* Debug: while a buffer is attached, workgroup (bx,by) of policy_fwd / ppo_grad writes the shader clock at up to 16
  * phase boundaries to stamps[((by*gridDim.x)+bx)*16 + phase] (caller sizes it: 16 * workgroups int64).  NULL detaches. */
 int ph_debug_set_profile_buffer(ph_ctx *ctx, long long *stamps_dev);
+/* Scheduling hint: nothing else runs on this context's device while its training launches do (one learner per GPU --
+ * north_star's "one agent per GPU", BASELINE config 5).  The slab reduction between two gradient launches then uses 1024-lane
+ * blocks (it sits on the critical path) instead of the 256-lane blocks sized to run BESIDE another learner's gradient launch;
+ * both walk the same summation tree, so results do not depend on the hint.  Default 0. */
+int ph_set_exclusive_device(ph_ctx *ctx, int exclusive);
 /* HIP-event timing on the ctx stream (bench.py roofline: events must sit on the stream the kernels run on) */
 int ph_timer_start(ph_ctx *ctx);
 int ph_timer_stop(ph_ctx *ctx, float *ms_out /* host */); /* synchronises */

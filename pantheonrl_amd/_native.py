@@ -184,6 +184,7 @@ SIGNATURES = {
     "ph_ctx_set_rng_epoch": [_vp, _vp],
     "ph_rng_epoch_advance": [_vp],
     "ph_debug_set_profile_buffer": [_vp, _vp],
+    "ph_set_exclusive_device": [_vp, _i],
     "ph_timer_start": [_vp],
     "ph_timer_stop": [_vp, C.POINTER(C.c_float)],
     "ph_layout_of": [C.POINTER(PhSpec), C.POINTER(PhLayout)],
@@ -344,6 +345,10 @@ class Context:
 
     def sync(self) -> None:
         check(self.lib.ph_ctx_sync(self.handle))
+
+    def set_exclusive_device(self, exclusive: bool) -> None:
+        """scheduling hint (ph_set_exclusive_device): this context's training launches have the device to themselves"""
+        check(self.lib.ph_set_exclusive_device(self.handle, int(bool(exclusive))))
 
     def close(self) -> None:
         if getattr(self, "handle", None):

@@ -56,6 +56,7 @@ struct ph_ctx {
   size_t blocksq_cap = 0;
   float* advstats = nullptr;
   size_t advstats_cap = 0;
+  bool exclusive = false;             // ph_set_exclusive_device: nothing else runs on the device beside this context's launches
   unsigned short* wimage = nullptr;   // split gradient kernel: pre-split weight fragments of the policy being trained (ph_split.h)
   double* advpart = nullptr;     // per-segment partial sums of the advantage statistics
   size_t advpart_cap = 0;
@@ -384,6 +385,12 @@ int ph_debug_set_profile_buffer(ph_ctx* ctx, long long* stamps_dev) {
   DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
   ctx->prof = stamps_dev;
+  return 0;
+}
+
+int ph_set_exclusive_device(ph_ctx* ctx, int exclusive) {
+  if (!ctx) return fail("null ctx");
+  ctx->exclusive = exclusive != 0;
   return 0;
 }
 
@@ -1435,6 +1442,7 @@ namespace {
 
 // one PPO.train() call resolved into launch parameters
 struct TrainPlan {
+  int alone = 1;          // not part of a joint call (ph_ppo_train_multi chains several learners' launches)
   ph_ctx* ctx;
   ph::NetDims nd;
   const ph_opt_state* opt;
@@ -1619,6 +1627,7 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
   r.stop_flag = ctx->stop_flag;
   r.step = t.opt->step;
   r.scalars = ctx->scalars;
+  r.wide = t.alone && ctx->exclusive;
   if (t.adap) {
     const int ep = mbi / t.n_mb, start = (mbi - ep * t.n_mb) * t.batch_size;
     const int* idx = (t.perms ? t.perms : ctx->perm_idx) + (size_t)ep * t.N + start;
@@ -1693,6 +1702,7 @@ int ph_ppo_train_multi(const ph_train_call* calls, int n_calls) {
     if (train_prepare(t[k], c.ctx, c.spec, c.opt, c.rb, c.hyper, c.n_epochs, c.batch_size, c.perms, c.perm_seed, c.stats,
                       c.gemm_mode))
       return 1;
+    t[k].alone = n_calls == 1;
     if (!t[k].ctx->ev_grad) PH_HIP(hipEventCreateWithFlags(&t[k].ctx->ev_grad, hipEventDisableTiming));
     total[k] = c.n_epochs * t[k].n_mb;
     longest = total[k] > longest ? total[k] : longest;

@@ -192,6 +192,7 @@ struct ReduceArgs {
   float extra_norm = 0.f;             // raw term = extra_norm * sum(extra_loss)
   float extra_coef = 0.f;             // loss statistic += extra_coef * raw term
   float* extra_loss_out = nullptr;    // [1] raw term of this minibatch, or null
+  int wide = 0;                       // 1: 1024-lane blocks (the learner has the device to itself); same summation tree either way
 };
 
 struct AdamArgs {

@@ -906,18 +906,21 @@ hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s) {
 // grad[p] = sum_g slab[g][p] in a fixed order, per-block sum of squares, minibatch statistics, KL decision.
 // Every lane sums its group's slabs with 8 loads in flight, the group sums are folded through LDS in a fixed order; the
 // result is bit-reproducible run to run.
-// Block = 64 parameters x 4 slab groups = 256 lanes.  The block is deliberately SMALL: one wave per SIMD at 42 VGPRs fits
-// into the registers two resident gradient workgroups leave free (2 x 224 of 512 per lane), so the reduce blocks of one
-// learner run beside the other learner's gradient launch instead of waiting for a whole CU to drain.  With 1024-lane
-// blocks (64 x 16: faster in isolation, 9.5 us vs ~14 us) they could not, and the two learners' updates serialised:
-// 4.74 -> 4.10 ms per bench iteration on the same box.  (-DPH_RED_WIDE restores the wide block.)
-#if defined(PH_RED_WIDE)
-constexpr int RED_PARAMS = 64, RED_GROUPS = 16, RED_SHIFT = 6;
-#else
-constexpr int RED_PARAMS = 64, RED_GROUPS = 4, RED_SHIFT = 6;
-#endif
-__global__ __launch_bounds__(RED_PARAMS * RED_GROUPS) void ppo_reduce_kernel(ReduceArgs a) {
-  __shared__ float gsum[RED_GROUPS][RED_PARAMS];
+// The slabs are summed in a FIXED tree that does not depend on the block shape: RED_SUB = 16 consecutive ranges of slabs, each
+// with eight interleaved accumulators folded pairwise; four consecutive range sums chained into a quarter sum A_g; the total is
+// (A_0 + A_1) + (A_2 + A_3).  Two block shapes walk that tree (the 256-lane one keeps its quarter sums in registers: its LDS
+// footprint must stay within the 4.4 KB two resident gradient workgroups leave free on a CU):
+//   GROUPS = 4  (64 parameters x 4 lanes-groups = 256 lanes, each group takes four ranges in turn): one wave per SIMD at 42 VGPRs
+//               fits into the registers two resident gradient workgroups leave free, so the reduce blocks of one learner run
+//               beside the OTHER learner's gradient launch instead of waiting for a whole CU to drain (ph_ppo_train_multi:
+//               4.74 -> 4.10 ms per bench iteration when this was introduced);
+//   GROUPS = 16 (1024 lanes, one range per group): four times the loads in flight -- for a learner that has the device to itself
+//               (ph_ppo_train, one agent per GPU), where the reduce sits on the critical path between two gradient launches.
+// Both give bitwise the same gradient (same tree), so ph_ppo_train and ph_ppo_train_multi keep producing identical results.
+constexpr int RED_PARAMS = 64, RED_SUB = 16, RED_SHIFT = 6;
+template <int GROUPS>
+__global__ __launch_bounds__(RED_PARAMS * GROUPS) void ppo_reduce_kernel(ReduceArgs a) {
+  __shared__ float gsum[GROUPS][RED_PARAMS];
   __shared__ float part[32][NSTATP];
   __shared__ float means[NSTATP];
   const int tid = threadIdx.x;
@@ -929,30 +932,53 @@ __global__ __launch_bounds__(RED_PARAMS * RED_GROUPS) void ppo_reduce_kernel(Red
     }
     return;
   }
-  const int pl = tid & (RED_PARAMS - 1), grp = tid >> RED_SHIFT;
+  // grp is wave-uniform (64 lanes = 64 parameters per group): as a scalar, the slab offsets are SALU work and the loads take an
+  // SGPR base + one 32-bit lane offset -- no 64-bit address per load in flight
+  const int pl = tid & (RED_PARAMS - 1), grp = __builtin_amdgcn_readfirstlane(tid >> RED_SHIFT);
   const int p = blockIdx.x * RED_PARAMS + pl;   // slab position
   {
-    const int per = (a.nslab + RED_GROUPS - 1) / RED_GROUPS;
-    const int k0 = grp * per, k1 = (k0 + per < a.nslab) ? k0 + per : a.nslab;
-    float acc[8];
+    const int per = (a.nslab + RED_SUB - 1) / RED_SUB;
+    float quarter = 0.f;
+#pragma unroll 1
+    for (int sub = grp * (RED_SUB / GROUPS); sub < (grp + 1) * (RED_SUB / GROUPS); ++sub) {
+      const int k0 = sub * per, k1 = (k0 + per < a.nslab) ? k0 + per : a.nslab;
+      float acc[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-    if (p < a.slab_len) {
-      int k = k0;
-      for (; k + 7 < k1; k += 8) {
+      for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+      if (p < a.slab_len) {
+        int k = k0;
+        for (; k + 15 < k1; k += 16) {   // two rounds of loads in flight; the adds keep the one-round-at-a-time order
+          float x0[8], x1[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] += a.slabs[(size_t)(k + u) * a.slab_len + p];
+          for (int u = 0; u < 8; ++u) x0[u] = a.slabs[(size_t)(k + u) * a.slab_len + p];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x1[u] = a.slabs[(size_t)(k + 8 + u) * a.slab_len + p];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc[u] = (acc[u] + x0[u]) + x1[u];
+        }
+        for (; k + 7 < k1; k += 8) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc[u] += a.slabs[(size_t)(k + u) * a.slab_len + p];
+        }
+        for (; k < k1; ++k) acc[0] += a.slabs[(size_t)k * a.slab_len + p];
       }
-      for (; k < k1; ++k) acc[0] += a.slabs[(size_t)k * a.slab_len + p];
+      const float range = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+      quarter = (sub & 3) == 0 ? range : quarter + range;   // A_g = ((s_4g + s_4g+1) + s_4g+2) + s_4g+3
     }
-    gsum[grp][pl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    gsum[grp][pl] = quarter;   // GROUPS = 4: A_grp; GROUPS = 16: one range sum
   }
   __syncthreads();
   if (tid < 64) {  // wave 0: fold the group sums, square, wave-reduce
     float g = 0.f;
     if (tid < RED_PARAMS) {
+      if constexpr (GROUPS == 4) {
+        g = (gsum[0][tid] + gsum[1][tid]) + (gsum[2][tid] + gsum[3][tid]);
+      } else {
+        float q4[4];
 #pragma unroll
-      for (int j = 0; j < RED_GROUPS; ++j) g += gsum[j][tid];
+        for (int j = 0; j < 4; ++j) q4[j] = ((gsum[4 * j][tid] + gsum[4 * j + 1][tid]) + gsum[4 * j + 2][tid]) + gsum[4 * j + 3][tid];
+        g = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+      }
       // canonical slabs: position = parameter index; register-order slabs (ppo_grad_fast_kernel): through the table
       const int dst = p < a.slab_len ? (a.map ? a.map[p] : p) : -1;
       if (dst >= 0) {
@@ -1014,7 +1040,8 @@ __global__ __launch_bounds__(RED_PARAMS * RED_GROUPS) void ppo_reduce_kernel(Red
 }
 int reduce_blocks(int slab_len) { return (slab_len + RED_PARAMS - 1) / RED_PARAMS; }
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(ppo_reduce_kernel, dim3(reduce_blocks(a.slab_len)), dim3(RED_PARAMS * RED_GROUPS), 0, s, a);
+  if (a.wide) hipLaunchKernelGGL(ppo_reduce_kernel<16>, dim3(reduce_blocks(a.slab_len)), dim3(RED_PARAMS * 16), 0, s, a);
+  else hipLaunchKernelGGL(ppo_reduce_kernel<4>, dim3(reduce_blocks(a.slab_len)), dim3(RED_PARAMS * 4), 0, s, a);
   return hipGetLastError();
 }
 

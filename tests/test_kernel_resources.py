@@ -55,11 +55,14 @@ def test_split_gradient_kernel_has_no_scratch_and_leaves_room_for_the_update_ker
         assert k["ScratchSize"] == 0 and k["VGPRs Spill"] == 0, (n, k)
         assert _alloc(k) <= 240, (n, k)
     bench = inst["_ZN2ph21ppo_grad_split_kernelILi6ELb1EEEvNS_8GradArgsE"]    # Overcooked: 6 logits, bias folded
-    reduce_k = ppo["_ZN2ph17ppo_reduce_kernelENS_10ReduceArgsE"]
+    reduce_k = ppo["_ZN2ph17ppo_reduce_kernelILi4EEEvNS_10ReduceArgsE"]     # the 256-lane shape ph_ppo_train_multi launches
     adam_k = ppo["_ZN2ph15ppo_adam_kernelENS_8AdamArgsE"]
+    grad_lds = 3 * 3 * 64 * 128 + 4 * (8 * (64 + 8) + 64 * 8 + 2 * 64 + 16 + 3 * 64 + 64)   # grad_split_lds_bytes(): 79 680 B, dynamic
     for other in (reduce_k, adam_k):
         assert other["ScratchSize"] == 0
         assert 2 * _alloc(bench) + _alloc(other) <= 512, (bench, other)
+        # ... and its static LDS into what two gradient workgroups leave of the CU's 160 KB (a 5 KB reduce block once cost 13 %)
+        assert 2 * grad_lds + other["LDS Size"] <= 160 * 1024, (grad_lds, other)
 
 
 def test_general_and_fast_gradient_kernels_have_no_scratch(ppo, tmp_path_factory):
