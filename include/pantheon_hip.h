@@ -121,6 +121,10 @@ int ph_rng_epoch_advance(ph_ctx *ctx);
 /* Debug: while a buffer is attached, workgroup (bx,by) of policy_fwd / ppo_grad writes the shader clock at up to 16
  * phase boundaries to stamps[((by*gridDim.x)+bx)*16 + phase] (caller sizes it: 16 * workgroups int64).  NULL detaches. */
 int ph_debug_set_profile_buffer(ph_ctx *ctx, long long *stamps_dev);
+/* debug: how many elements of the context's pre-split weight image (the fragments gemm_mode 2's gradient kernel loads; kept in
+ * step with the parameters by the optimizer kernel) differ from what `params` (device, P floats) split to right now.
+ * *mismatches (host) = -1 when the context holds no image.  Synchronises the context's stream. */
+int ph_debug_weight_image_mismatches(ph_ctx *ctx, const ph_spec *spec, const float *params, int *mismatches);
 /* Scheduling hint: nothing else runs on this context's device while its training launches do (one learner per GPU --
  * north_star's "one agent per GPU", BASELINE config 5).  The slab reduction between two gradient launches then uses 1024-lane
  * blocks (it sits on the critical path) instead of the 256-lane blocks sized to run BESIDE another learner's gradient launch;

@@ -185,6 +185,7 @@ SIGNATURES = {
     "ph_rng_epoch_advance": [_vp],
     "ph_debug_set_profile_buffer": [_vp, _vp],
     "ph_set_exclusive_device": [_vp, _i],
+    "ph_debug_weight_image_mismatches": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(C.c_int)],
     "ph_timer_start": [_vp],
     "ph_timer_stop": [_vp, C.POINTER(C.c_float)],
     "ph_layout_of": [C.POINTER(PhSpec), C.POINTER(PhLayout)],

@@ -388,6 +388,23 @@ int ph_debug_set_profile_buffer(ph_ctx* ctx, long long* stamps_dev) {
   return 0;
 }
 
+int ph_debug_weight_image_mismatches(ph_ctx* ctx, const ph_spec* spec, const float* params, int* mismatches_host) {
+  DevGuard dev_guard(ctx);
+  if (!ctx || !params || !mismatches_host) return fail("ph_debug_weight_image_mismatches: null argument");
+  ph::NetDims nd;
+  if (resolve(ctx, spec, &nd)) return 1;
+  *mismatches_host = -1;                       // -1: this context holds no image (the split kernel never ran for it)
+  if (!ctx->wimage || !nd.wimage_map) return 0;
+  int* d = nullptr;
+  PH_HIP(hipMalloc((void**)&d, sizeof(int)));
+  PH_HIP(hipMemsetAsync(d, 0, sizeof(int), ctx->stream));
+  PH_HIP(ph::launch_weight_image_check(params, ctx->wimage, nd.wimage_map, nd.lay.P, d, ctx->stream));
+  PH_HIP(hipMemcpyAsync(mismatches_host, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d);
+  return 0;
+}
+
 int ph_set_exclusive_device(ph_ctx* ctx, int exclusive) {
   if (!ctx) return fail("null ctx");
   ctx->exclusive = exclusive != 0;

@@ -352,6 +352,8 @@ constexpr int WIMG_ELEMS = 2 * 4 * 3 * 2 * 3 * WIMG_PLANE;
 void grad_weight_image_map(const ph_layout& lay, bool fold, int* map /* host, P x 2 */);
 // image <- split(params) through the map (the image must have been zeroed by the caller)
 hipError_t launch_weight_image(const float* params, unsigned short* image, const int* map, int P, hipStream_t s);
+hipError_t launch_weight_image_check(const float* params, const unsigned short* image, const int* map, int P, int* mismatches,
+                                     hipStream_t s);
 void grad_slab_map_split(const ph_layout& lay, int* map /* host, 2 * RS_NET */, bool fold);
 hipError_t launch_ppo_grad_split(const GradArgs& a, int nwg, hipStream_t s);
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);

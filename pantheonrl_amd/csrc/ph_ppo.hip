@@ -1088,6 +1088,28 @@ __global__ __launch_bounds__(256) void weight_image_kernel(const float* params, 
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < P) wimage_put(image, map, p, params[p]);
 }
+// debug: number of image elements (all three planes) that differ from what `params` split to
+__global__ __launch_bounds__(256) void weight_image_check_kernel(const float* params, const unsigned short* image, const int* map, int P,
+                                                                 int* mismatches) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  __bf16 h, m, l;
+  split1(params[p], h, m, l);
+  const unsigned short want[3] = {__builtin_bit_cast(unsigned short, h), __builtin_bit_cast(unsigned short, m),
+                                  __builtin_bit_cast(unsigned short, l)};
+  int bad = 0;
+  for (int k = 0; k < 2; ++k) {
+    const int pos = map[2 * p + k];
+    if (pos < 0) continue;
+    for (int q = 0; q < 3; ++q) bad += image[pos + q * WIMG_PLANE] != want[q];
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+hipError_t launch_weight_image_check(const float* params, const unsigned short* image, const int* map, int P, int* mismatches,
+                                     hipStream_t s) {
+  hipLaunchKernelGGL(weight_image_check_kernel, dim3((P + 255) / 256), dim3(256), 0, s, params, image, map, P, mismatches);
+  return hipGetLastError();
+}
 hipError_t launch_weight_image(const float* params, unsigned short* image, const int* map, int P, hipStream_t s) {
   hipLaunchKernelGGL(weight_image_kernel, dim3((P + 255) / 256), dim3(256), 0, s, params, image, map, P);
   return hipGetLastError();

@@ -396,6 +396,44 @@ def test_split_bf16_gradient_is_as_close_to_float64_as_the_float32_kernel():
     assert e2.max() <= 2e-6 * scale + 1e-9, (e2.max(), scale)
 
 
+def test_split_kernel_weight_image_tracks_the_parameters_through_adam_steps_and_early_stops():
+    """The fragments ppo_grad_split_kernel loads come from an image the Adam kernel updates in place.  After a train() of many
+    minibatches -- and after one that the KL test cuts short -- the image must equal what the CURRENT parameters split to,
+    element for element; overwriting the parameters from outside must be picked up by the next gradient call."""
+    import ctypes as C
+    from pantheonrl_amd import _native as nat
+    from pantheonrl_amd.ppo import PPO
+    name, T, E = "overcooked", 16, 8
+    orac = H.oracle_policy(name, seed=4)
+    ob = H.filled_oracle_buffer(name, orac, T, E, seed=4)
+    obs_s, act_s = H.CONFIGS[name]
+    env = type("E", (), dict(observation_space=H.to_space(obs_s), action_space=H.to_space(act_s), _is_dummy_space_env=True))()
+
+    def mismatches(model):
+        n = C.c_int(-2)
+        pol = model.policy
+        nat.check(pol.ctx.lib.ph_debug_weight_image_mismatches(pol.ctx.handle, C.byref(pol.spec), pol.params.data_ptr(), C.byref(n)))
+        return n.value
+
+    for target_kl in (None, 1e-6):
+        model = PPO("MlpPolicy", env, n_steps=T, n_envs=E, batch_size=32, n_epochs=5, learning_rate=3e-3, target_kl=target_kl, seed=0)
+        assert model.policy.gemm_mode == 2
+        model.policy.set_flat_params(orac.flat_params())
+        H.upload_buffer(model.rollout_buffer, ob)
+        assert mismatches(model) == -1                     # no image before the first update
+        before = model.policy.params.clone()
+        model.train()
+        th.cuda.synchronize()
+        assert not th.equal(before, model.policy.params)
+        assert mismatches(model) == 0, (target_kl, mismatches(model))
+        model.policy.set_flat_params(orac.flat_params() * 1.01)      # from outside: the image is now stale ...
+        assert mismatches(model) > 0
+        H.upload_buffer(model.rollout_buffer, ob)
+        model.train()                                                 # ... and rebuilt at the start of the next call
+        th.cuda.synchronize()
+        assert mismatches(model) == 0
+
+
 def _train_pair(name, T, E, hp: orc.PPOHyper, seed=21, device_perms=False):
     from pantheonrl_amd import _native as nat
     from pantheonrl_amd.ppo import PPO
