@@ -27,6 +27,11 @@ CONFIGS = {
     "adap_oc": (SpaceSpec("box", dim=62 + 3), SpaceSpec("discrete", nvec=(6,))),            # two feature chunks
     "adap_small": (SpaceSpec("box", dim=35 + 3), SpaceSpec("discrete", nvec=(5,))),         # the 64-row fast gradient kernel
     "adap_multi": (SpaceSpec("box", dim=20 + 4), SpaceSpec("multidiscrete", nvec=(3, 9, 4))),
+    # corners of the split gradient kernel's shape class: one feature; all 64 features (no free column for the folded bias) with
+    # all 8 logits; 63 features (the bias column is the last free one) with a 2-logit head
+    "box1": (SpaceSpec("box", dim=1), SpaceSpec("discrete", nvec=(2,))),
+    "box64": (SpaceSpec("box", dim=64), SpaceSpec("discrete", nvec=(8,))),
+    "box63": (SpaceSpec("box", dim=63), SpaceSpec("discrete", nvec=(2,))),
 }
 
 

@@ -378,6 +378,23 @@ def test_split_bf16_gradient_matches_autograd(name, T, E, nb):
     _assert_grads(g, g_ref, lay)
 
 
+@pytest.mark.parametrize("name,T,E,nb", [("box1", 8, 8, 64), ("box64", 16, 8, 128), ("box64", 8, 8, 1), ("box63", 16, 8, 65),
+                                          ("box63", 8, 4, 31), ("mpe8", 64, 8, 257)])
+def test_split_bf16_gradient_corner_shapes(name, T, E, nb):
+    """feature counts 1 / 63 / 64 (folded and unfolded first-layer bias), 2 and 8 logits, minibatches of 1, 31, 65, 257 rows
+    (partial tiles, a tile with a single live row, workgroups with and without a second tile): against autograd, and against the
+    exact-f32 kernel at float32 rounding level"""
+    rng = np.random.default_rng(nb)
+    idx = rng.permutation(T * E)[:nb]
+    hp = orc.PPOHyper(clip_range_vf=0.2, ent_coef=0.01)
+    g2, g_ref, st, st_ref, lay = _grad_pair(name, T, E, idx, hp, gemm_mode=2)
+    _assert_grads(g2, g_ref, lay)
+    g0 = _grad_pair(name, T, E, idx, hp, gemm_mode=0)[0]
+    assert np.abs(g2 - g0).max() <= 2e-6 * max(np.abs(g0).max(), 1e-3), (np.abs(g2 - g0).max(), np.abs(g0).max())
+    for i, k in enumerate(("policy_loss", "value_loss", "entropy_loss", "clip_fraction", "approx_kl", "loss")):
+        assert abs(st[i] - st_ref[k]) <= 1e-5 + 1e-4 * abs(st_ref[k]), (k, st[i], st_ref[k])
+
+
 def test_split_bf16_gradient_is_as_close_to_float64_as_the_float32_kernel():
     """The accuracy claim behind gemm_mode 2, measured: against the float64 gradient of the same minibatch the split kernel's
     error is no larger than 1.5x the exact-float32 MFMA kernel's (in practice it is smaller: the matrix pipe adds the 32
