@@ -26,6 +26,10 @@
 #include "ph_head.h"
 #include "ph_split.h"
 
+#ifndef PH_SPLIT_HEAD_PAIRS
+#define PH_SPLIT_HEAD_PAIRS 1
+#endif
+
 namespace ph {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -521,6 +525,21 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
           o[0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
           if constexpr (NK > 4) o[1] = make_float4(dz[4], dz[5], dz[6], dz[7]);
         }
+#if PH_SPLIT_HEAD_PAIRS
+        // dH2[m] = sum_k dz[k] act_W[m][k] as packed FMAs over ADJACENT logits of one weight row (the register pairs a 16-byte
+        // LDS read delivers): left to itself the vectoriser pairs two ROWS instead and pays a v_mov per packed operand
+        typedef float hp2 __attribute__((ext_vector_type(2)));
+        hp2 dzp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dzp[k] = (hp2){dz[2 * k], dz[2 * k + 1]};      // dz[k >= NK] = 0
+        for_head_rows<NK>(hw, q, [&](int m, const float4& w0, const float4& w1) {
+          hp2 acc = (hp2){w0.x, w0.y} * dzp[0];
+          if constexpr (NK > 2) acc = __builtin_elementwise_fma((hp2){w0.z, w0.w}, dzp[1], acc);
+          if constexpr (NK > 4) acc = __builtin_elementwise_fma((hp2){w1.x, w1.y}, dzp[2], acc);
+          if constexpr (NK > 6) acc = __builtin_elementwise_fma((hp2){w1.z, w1.w}, dzp[3], acc);
+          dzv[m] = (acc.x + acc.y) * (1.0f - h[m] * h[m]);
+        });
+#else
         for_head_rows<NK>(hw, q, [&](int m, const float4& w0, const float4& w1) {
           const float wk[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
           float d = dz[0] * wk[0];
@@ -528,6 +547,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
           for (int k = 1; k < NK; ++k) d = __builtin_fmaf(dz[k], wk[k], d);
           dzv[m] = d * (1.0f - h[m] * h[m]);
         });
+#endif
       } else {
         float wv[16];
         float v = 0.f;
