@@ -136,6 +136,11 @@ int ph_timer_stop(ph_ctx *ctx, float *ms_out /* host */); /* synchronises */
 
 /* ---- shapes --------------------------------------------------------------------------------------------- */
 int ph_layout_of(const ph_spec *spec /* host */, ph_layout *out /* host */);
+/* debug, host only (no device touched): the tables of gemm_mode 2's gradient kernel for `spec` -- slab_map[net * 8960 + position]
+ * = parameter index held at that position of a workgroup's gradient slab (-1 = padding), image_map[2 * p + {0, 1}] = element
+ * index (plane 0) of the weight-fragment image backed by parameter p (-1 = none).  *eligible = 0 (tables untouched) for specs
+ * the kernel does not take. */
+int ph_debug_split_tables(const ph_spec *spec, int *slab_map, int *image_map, int *eligible);
 
 /* ---- K1: rollout buffer writes --------------------------------------------------------------------------- */
 /* RolloutBuffer.add(obs, action, reward=0, episode_start, value, log_prob) at row `pos` <- agents.py:172-179.

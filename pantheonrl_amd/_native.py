@@ -189,6 +189,7 @@ SIGNATURES = {
     "ph_timer_start": [_vp],
     "ph_timer_stop": [_vp, C.POINTER(C.c_float)],
     "ph_layout_of": [C.POINTER(PhSpec), C.POINTER(PhLayout)],
+    "ph_debug_split_tables": [C.POINTER(PhSpec), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "ph_buffer_add": [_vp, C.POINTER(PhSpec), C.POINTER(PhRollout), _i, _vp, _vp, _vp, _vp, _vp],
     "ph_buffer_add_reward": [_vp, C.POINTER(PhRollout), _i, _vp, _vp],
     "ph_buffer_add_reward_joint": [_vp, C.POINTER(PhRollout), _i, _vp, _vp, _i, _i, _vp, C.c_float],

@@ -428,6 +428,28 @@ int ph_timer_stop(ph_ctx* ctx, float* ms_out) {
 
 int ph_layout_of(const ph_spec* spec, ph_layout* out) { return layout_of(spec, out); }
 
+// Host-only: the two tables that tie ppo_grad_split_kernel's register and fragment orders to parameter indices, for inspection
+// (tests/test_host_logic.py checks them against the layout without a GPU).  Returns 0 and *eligible = 0 for specs the kernel
+// does not take (the tables are then untouched).
+int ph_debug_split_tables(const ph_spec* spec, int* slab_map /* 2 * 8960 */, int* image_map /* 2 * P */, int* eligible) {
+  if (!spec || !slab_map || !image_map || !eligible) return fail("ph_debug_split_tables: null argument");
+  ph_layout lay;
+  if (layout_of(spec, &lay)) return 1;
+  ph::NetDims probe;
+  std::memset(&probe, 0, sizeof(probe));
+  probe.lay = lay;
+  probe.nchunk = (lay.F + PH_HIDDEN - 1) / PH_HIDDEN;
+  probe.A = lay.A;
+  probe.L = lay.L;
+  probe.F = lay.F;
+  probe.obs_kind = spec->obs.kind;
+  *eligible = ph::grad_split_eligible(probe) ? 1 : 0;
+  if (!*eligible) return 0;
+  ph::grad_slab_map_split(lay, slab_map, ph::grad_fast_fold(probe));
+  ph::grad_weight_image_map(lay, ph::grad_fast_fold(probe), image_map);
+  return 0;
+}
+
 // ---- K1 ----
 int ph_buffer_add(ph_ctx* ctx, const ph_spec* spec, const ph_rollout* rb, int pos, const float* obs,
                   const float* actions, const float* episode_start, const float* values, const float* log_probs) {
