@@ -14,13 +14,16 @@
 //
 // Decomposition: grid (nWG, 2 nets), 64-row tiles, four waves; wave w owns hidden units / output columns [16w, 16w+16) of
 // every product (N side) and all 64 rows or inputs (M side: four 16x16 blocks).  Its three weight operands (W1, W2 for the
-// forward pass, W2 by rows for dH1) are split once per workgroup and stay in registers as MFMA B fragments (72 VGPRs): no
-// weight ever sits in LDS.  Activations live in LDS only as bf16 planes, each in ONE layout; the product that contracts over
+// forward pass, W2 by rows for dH1) arrive as ready-made MFMA B fragments from an image of the parameters that the optimizer
+// kernel keeps split (ph_split.h): no weight ever sits in LDS and none is split here.  W1's fragments stay in registers
+// (24 VGPRs); W2's two sets are fetched (L2) inside the phase before the one that uses them, which keeps the kernel at 219
+// VGPRs -- two of its waves and one wave of another learner's reduce / Adam kernel share a SIMD.
+// Activations live in LDS only as bf16 planes, each in ONE layout; the product that contracts over
 // the plane's row index reads it with ds_read_b64_tr_b16 (the hardware 4x4 transpose), the one that contracts over the
 // contiguous index with ds_read_b128:
 //     XT   [feature][row]   written from the gathered rows      S1 (tr)      dW1 (plain)
 //     H1T  [unit][row]      S1 epilogue (4 rows = one b64)      S2 (tr)      dW2 (plain)       -> DZ1T [unit][row] (dW1, plain)
-//     DZ2  [row][unit]      head phase (8 units = one b128)     dH1 (plain)  dW2 (tr)          overlays H2 (f32, head only)
+//     DZ2  [row][plane][unit]  head phase (8 units = one b128)  dH1 (plain)  dW2 (tr)          row r overlays H2's row r (f32, head only)
 // Bias gradients are MFMAs with an all-ones A operand on the B fragments already in registers; layer 1's bias rides as
 // feature 63 (FOLD) as in the f32 kernel.  3 x 24 KB of planes + 5.8 KB of head state = 79.7 KB -> two workgroups per CU.
 #include "ph_head.h"
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     return m;
   };
 
-  // ---- prologue: this wave's weight fragments (split once), head weights, the first tile's rows ----
+  // ---- prologue: this wave's W1 fragments (from the image), head weights, the first tile's rows ----
   Frag3 W1f[2];   // (W2 for the forward pass is fetched inside S1 for S2; the third set, W2 by rows for dH1, is fetched from the image inside S6a: 24 registers less across the tile)
   XRows xt;
   SplitRowMeta meta;

@@ -89,10 +89,10 @@ if not LIAR:
                                     int(model.batch_size), 1, 2, C.byref(ms)))
     th.cuda.synchronize()
     print(f"ppo_grad_split launch {ms.value * 1e3:.1f} us")
-    report("ppo_grad_split prologue", nwg, 2, ["issue idx + weight loads", "row scalars issued (idx arrived)", "X loads issued", "weights split (weights arrived)",
+    report("ppo_grad_split prologue", nwg, 2, ["issue idx + weight loads", "row scalars issued (idx arrived)", "X loads issued", "weight fragments arrived",
                                                "head state to LDS, T0 scalars", "X commit (rows arrived, split, stores)", "barrier"],
            slots=[0, 8, 9, 10, 11, 14, 15, 1])
-    report("ppo_grad_split", nwg, 2, ["prologue (weights split) + T0", "S1 mma+tanh+split", "S2 mma+tanh", "SH-a head (VALU)",
+    report("ppo_grad_split", nwg, 2, ["prologue + T0", "S1 mma+tanh+split", "S2 mma+tanh", "SH-a head (VALU)",
                                       "SH-b d head W + SH-c dZ2 split", "S6a dW2, dH1 mma", "S6b dZ1 split + S7 dW1", "remaining tiles",
                                       "epilogue"], slots=[0, 1, 2, 3, 4, 5, 6, 7, 12, 13])
 nat.check(lib.ph_debug_set_profile_buffer(h, None))
