@@ -303,6 +303,62 @@ class MlpPolicyOracle(nn.Module):
         return th.cat(out).numpy().astype(np.float32).copy()
 
 
+class AdapMultPolicyOracle(MlpPolicyOracle):
+    """``AdapPolicyMult`` = ``AdapPolicy`` with ``MultModel`` as its extractor (adap/policies.py:136-283), SB3's default
+    ``net_arch=[dict(pi=[64, 64], vf=[64, 64])]``, tanh.  ORACLE ONLY: the engine has no device path for this network yet
+    (DESIGN.md 6); the restatement and its known-answer tests are the yardstick the device path will be built against.
+
+    The stored observation is ``features ++ context`` (adap_learn.py:448-452) as for ``AdapPolicy``; ``MultModel.forward``
+    splits it again (policies.py:268-272) and, per net (policies.py:239-264):
+        x      = tanh(W1 o + b1)                      branch_1 on the observation WITHOUT the context
+        x_a    = tanh(Ws x + bs)    (64 -> 64 * C)     scaling, viewed as (64, C): element [j][c] is output row j * C + c
+        latent = tanh(W2 (x + x_a @ ctx) + b2)        branch_2
+    Orthogonal init with gain sqrt(2) reaches every Linear of the extractor, the scaling layers included (SB3 applies
+    ``init_weights`` to ``mlp_extractor`` as a whole: modular/policies.py:229-241 is the same loop)."""
+
+    def __init__(self, obs_space: SpaceSpec, act_space: SpaceSpec, context_size: int = 3, lr: float = 3e-4,
+                 ortho_init: bool = True):
+        nn.Module.__init__(self)
+        assert obs_space.kind == "box", "features ++ context rows are Box rows (adap.py turns Discrete features into one-hots)"
+        assert act_space.kind in ("discrete", "multidiscrete")
+        self.obs_space, self.act_space, self.context_size = obs_space, act_space, int(context_size)
+        Fdim, L, C = obs_space.flat_len - self.context_size, act_space.flat_len, self.context_size
+        assert Fdim > 0
+
+        def net():
+            return (nn.Sequential(nn.Linear(Fdim, HIDDEN), nn.Tanh()), nn.Sequential(nn.Linear(HIDDEN, HIDDEN * C), nn.Tanh()),
+                    nn.Sequential(nn.Linear(HIDDEN, HIDDEN), nn.Tanh()))
+        self.agent_branch_1, self.agent_scaling, self.agent_branch_2 = net()
+        self.value_branch_1, self.value_scaling, self.value_branch_2 = net()
+        self.action_net = nn.Linear(HIDDEN, L)
+        self.value_net = nn.Linear(HIDDEN, 1)
+        if ortho_init:
+            extractor = (self.agent_branch_1, self.agent_scaling, self.agent_branch_2, self.value_branch_1, self.value_scaling,
+                         self.value_branch_2)
+            for mod, gain in [(m, np.sqrt(2)) for m in extractor] + [(self.action_net, 0.01), (self.value_net, 1.0)]:
+                for m in mod.modules():
+                    if isinstance(m, nn.Linear):
+                        nn.init.orthogonal_(m.weight, gain=gain)
+                        m.bias.data.fill_(0.0)
+        self.optimizer = th.optim.Adam(self.parameters(), lr=lr, eps=1e-5)
+
+    def _branch(self, b1, scaling, b2, o: th.Tensor, ctx: th.Tensor) -> th.Tensor:
+        x = b1(o)
+        x_a = scaling(x).view(o.shape[0], HIDDEN, self.context_size)          # policies.py:245 / 258
+        return b2(x + th.matmul(x_a, ctx.unsqueeze(-1)).squeeze(-1))          # policies.py:246-247 / 259-260
+
+    def _latents(self, obs: th.Tensor):
+        feats = preprocess_obs(obs, self.obs_space)
+        o, ctx = feats[:, :-self.context_size], feats[:, -self.context_size:]  # policies.py:270-271
+        return (self._branch(self.agent_branch_1, self.agent_scaling, self.agent_branch_2, o, ctx),
+                self._branch(self.value_branch_1, self.value_scaling, self.value_branch_2, o, ctx))
+
+    def flat_params(self):   # the engine's flat layout (include/pantheon_hip.h) has no slot for the scaling layers
+        raise NotImplementedError("AdapPolicyMult has no device layout yet")
+
+    flat_grads = load_flat = flat_params
+
+
 def inverse_cdf_sample(probs: th.Tensor, u: th.Tensor) -> th.Tensor:
     """action = number of prefix sums (float32, left to right) that are <= u, clamped to n-1."""
     n = probs.shape[1]

@@ -413,3 +413,103 @@ def test_modular_train_walks_partner_by_partner_with_one_buffer_each():
     b3 = pol3.flat_params()
     orc.modular_train(pol3, bufs[:1], hp, 0.3)
     assert not np.array_equal(pol3.flat_params()[n_main + per:], b3[n_main + per:])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# AdapPolicyMult (adap/policies.py:136-283) -- oracle only: the restatement the device path will be built against
+# ----------------------------------------------------------------------------------------------------------------
+def _mult(F=7, C=3, L=4, seed=2):
+    th.manual_seed(seed)
+    return orc.AdapMultPolicyOracle(orc.SpaceSpec("box", dim=F + C), orc.SpaceSpec("discrete", nvec=(L,)), context_size=C)
+
+
+def test_adap_mult_forward_is_the_written_out_arithmetic():
+    """x = tanh(W1 o + b1); x_a = tanh(Ws x + bs) viewed (64, C) ROW-major (output row j * C + c pairs hidden unit j with context
+    component c: policies.py:245 `.view(batch, hidden, context)`); latent = tanh(W2 (x + x_a ctx) + b2) -- in float64 numpy"""
+    F, C, L = 7, 3, 4
+    pol = _mult(F, C, L)
+    with th.no_grad():                      # biases off zero so that a dropped bias would show
+        for prm in pol.parameters():
+            if prm.ndim == 1:
+                prm.add_(0.1 * th.randn_like(prm))
+    rng = np.random.default_rng(0)
+    obs = rng.standard_normal((9, F + C)).astype(np.float32)
+    o, ctx = obs[:, :F].astype(np.float64), obs[:, F:].astype(np.float64)
+
+    def lin(seq, x):
+        return x @ seq[0].weight.detach().numpy().astype(np.float64).T + seq[0].bias.detach().numpy().astype(np.float64)
+
+    def branch(b1, sc, b2):
+        x = np.tanh(lin(b1, o))
+        s = np.tanh(lin(sc, x))                                             # (n, 64 * C)
+        xa = np.stack([sum(s[:, j * C + c] * ctx[:, c] for c in range(C)) for j in range(64)], axis=1)
+        return np.tanh(lin(b2, x + xa))
+    lat_pi = branch(pol.agent_branch_1, pol.agent_scaling, pol.agent_branch_2)
+    lat_vf = branch(pol.value_branch_1, pol.value_scaling, pol.value_branch_2)
+    got_pi, got_vf = pol._latents(th.as_tensor(obs))
+    assert np.abs(got_pi.detach().numpy() - lat_pi).max() < 2e-6 and np.abs(got_vf.detach().numpy() - lat_vf).max() < 2e-6
+    z = lat_pi @ pol.action_net.weight.detach().numpy().astype(np.float64).T + pol.action_net.bias.detach().numpy()
+    assert np.abs(pol.logits(th.as_tensor(obs)).detach().numpy() - z).max() < 2e-6
+    v = lat_vf @ pol.value_net.weight.detach().numpy().astype(np.float64).T + pol.value_net.bias.detach().numpy()
+    assert np.abs(pol.predict_values(th.as_tensor(obs)).detach().numpy() - v).max() < 2e-6
+
+
+def test_adap_mult_known_answers():
+    F, C, L = 7, 3, 4
+    pol = _mult(F, C, L)
+    obs = th.as_tensor(np.random.default_rng(1).standard_normal((6, F + C)).astype(np.float32))
+    # (1) scaling layers at zero: x_a = tanh(0) = 0 and the network is the plain 64-64 MLP on the observation WITHOUT its context
+    plain = orc.MlpPolicyOracle(orc.SpaceSpec("box", dim=F), orc.SpaceSpec("discrete", nvec=(L,)))
+    with th.no_grad():
+        for sc in (pol.agent_scaling, pol.value_scaling):
+            sc[0].weight.zero_()
+            sc[0].bias.zero_()
+        for dst, src in ((plain.policy_net[0], pol.agent_branch_1[0]), (plain.policy_net[2], pol.agent_branch_2[0]),
+                         (plain.value_net_mlp[0], pol.value_branch_1[0]), (plain.value_net_mlp[2], pol.value_branch_2[0]),
+                         (plain.action_net, pol.action_net), (plain.value_net, pol.value_net)):
+            dst.weight.copy_(src.weight)
+            dst.bias.copy_(src.bias)
+    assert th.equal(pol.logits(obs), plain.logits(obs[:, :F])) and th.equal(pol.predict_values(obs), plain.predict_values(obs[:, :F]))
+    # (2) zero context: the scaling output is multiplied away whatever its weights are
+    pol2 = _mult(F, C, L, seed=5)
+    obs0 = obs.clone()
+    obs0[:, F:] = 0
+    x = pol2.agent_branch_1(obs0[:, :F])
+    assert th.allclose(pol2._latents(obs0)[0], pol2.agent_branch_2(x), atol=0, rtol=0)
+    # (3) the pre-activation of branch_2 is LINEAR in the context: latent(c1 + c2) - latent(c1) - latent(c2) + latent(0) = 0 there
+    def pre(c):
+        o = obs[:, :F]
+        xx = pol2.agent_branch_1(o)
+        xa = pol2.agent_scaling(xx).view(o.shape[0], 64, C)
+        return pol2.agent_branch_2[0](xx + th.matmul(xa, c.unsqueeze(-1)).squeeze(-1))
+    c1, c2 = th.randn(6, C), th.randn(6, C)
+    assert th.allclose(pre(c1 + c2) - pre(c1) - pre(c2) + pre(th.zeros(6, C)), th.zeros(6, 64), atol=2e-5)
+    # (4) one hot context e_c picks column c of the (64, C) view: output rows j * C + c of the scaling layer
+    e1 = th.zeros(6, C)
+    e1[:, 1] = 1
+    o = obs[:, :F]
+    xx = pol2.agent_branch_1(o)
+    want = pol2.agent_branch_2(xx + pol2.agent_scaling(xx)[:, 1::C])
+    assert th.allclose(pol2._latents(th.cat([o, e1], dim=1))[0], want, atol=1e-6)
+    # (5) orthogonal init reaches the scaling layers (gain sqrt 2: rows of the 192 x 64 weight are not orthonormal, columns are)
+    w = _mult(F, C, L, seed=7).agent_scaling[0].weight.detach()
+    assert th.allclose(w.t() @ w, 2.0 * th.eye(64), atol=1e-4)
+    # (6) the PPO minibatch loss runs and reaches every parameter of both scaling layers
+    pol3 = _mult(F, C, L, seed=9)
+    mb = dict(observations=obs, actions=th.randint(0, L, (6, 1)).float(), old_values=th.randn(6), old_log_prob=-th.rand(6),
+              advantages=th.randn(6), returns=th.randn(6))
+    loss, stats = orc.ppo_minibatch_loss(pol3, mb, orc.PPOHyper())
+    loss.backward()
+    for sc in (pol3.agent_scaling, pol3.value_scaling):
+        assert sc[0].weight.grad is not None and float(sc[0].weight.grad.abs().sum()) > 0
+    with pytest.raises(NotImplementedError):
+        pol3.flat_params()
+    # (7) ADAP's context term (util.py:97-131) on this network: with the scaling layers at zero the policy ignores its context, every
+    # pairwise KL is 0 and the term is exactly 1; with them live it is below 1 and differentiable through the scaling weights
+    ctxs = np.random.default_rng(3).standard_normal((4, C)).astype(np.float32)
+    assert float(orc.adap_context_loss(pol, obs, C, np.arange(6), ctxs).detach()) == 1.0
+    term = orc.adap_context_loss(pol3, obs, C, np.arange(6), ctxs)
+    assert 0.0 < float(term.detach()) < 1.0
+    pol3.optimizer.zero_grad()
+    term.backward()
+    assert float(pol3.agent_scaling[0].weight.grad.abs().sum()) > 0 and pol3.value_scaling[0].weight.grad is None
