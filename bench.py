@@ -605,7 +605,8 @@ def main():
         dt2 = time.perf_counter() - t1
         result["stepwise_rollout"] = {"value": steps_per_iter * k2 / dt2, "unit": "agent-steps/s", "ms_per_step": 1e3 * dt2 / k2,
                                       "steps": k2, "note": "one launch per environment step inside the iteration graphs "
-                                      "(--rollout stepwise); the N>1 layouts exchange actions every step and run this way"}
+                                      "(--rollout stepwise): what an environment that lives on the host or on another node forces; the N>1 layouts of this bench "
+                                              "hand actions over in-kernel and launch a rollout once, like the default"}
     if rank == 0:
         if not args.no_roofline:
             result["roofline"] = roofline(args, agents[0])
