@@ -1,121 +1,127 @@
-import itertools, collections
-B128_GROUPS=[[0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27],[4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31]]
-B128_GROUPS+= [[l+32 for l in g] for g in B128_GROUPS]
-G32=[list(range(0,32)),list(range(32,64))]
-G16=[list(range(16*i,16*i+16)) for i in range(4)]
-G8=[list(range(8*i,8*i+8)) for i in range(8)]
-def cycles(addr_fn, groups, nbanks, width):
-    """extra cycles: per group, max over banks of distinct (addr/4) values hitting that bank... model: each lane touches width/4 dwords"""
-    extra=0
+#!/usr/bin/env python
+"""LDS bank-conflict model of ppo_grad_split_kernel's plane buffers (pantheonrl_amd/csrc/ph_ppo_split.hip) and the exhaustive
+search that chose its granule swizzles.
+
+Model (MI355X_MICROARCH.md, LDS table): a wave64 access is serviced in fixed lane groups, one LDS cycle per group; within a
+group every additional distinct dword on a busy bank costs one more cycle (SQ_LDS_BANK_CONFLICT counts those).  Groups and
+bank moduli per instruction:
+    ds_read_b128         four NON-contiguous 16-lane groups, bank = (addr / 4) % 64
+    ds_read_b64_tr_b16   two 32-lane groups,                 bank = (addr / 4) % 64
+    ds_write_b64         four contiguous 16-lane groups,     bank = (addr / 4) % 32
+    ds_write_b128        eight contiguous 8-lane groups,     bank = (addr / 4) % 32
+The model reproduced the measured counter of the kernel's first layout to 4 % (2.05 M predicted, 2.13 M measured per launch) and of
+the chosen one to 13 % (0.40 M vs 0.46 M).
+
+A plane row is 128 bytes = 8 granules of 16 bytes; granule g of row a is stored at granule g ^ swz(a), swz linear over the low four
+row bits (a 3 x 4 bit matrix M: bit r of swz = parity(a & M[r])).  `python scripts/lds_swizzle_search.py` runs the search over all
+4096 matrices and the corresponding search for the float32 H2 rows that share the dZ2 buffer's 384-byte row slots;
+tests/test_host_logic.py pins the chosen maps against this model."""
+import collections
+import itertools
+
+B128_GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+B128_GROUPS += [[lane + 32 for lane in g] for g in B128_GROUPS]
+G32 = [list(range(0, 32)), list(range(32, 64))]
+G16 = [list(range(16 * i, 16 * i + 16)) for i in range(4)]
+G8 = [list(range(8 * i, 8 * i + 8)) for i in range(8)]
+
+PLANE_SWZ = (0b0010, 0b0110, 0b1011)      # the kernel's pl_swz: bit0 = a1, bit1 = a1 ^ a2, bit2 = a0 ^ a1 ^ a3
+H2_SWZ = (0b01, 0b00, 0b10, 0b10)         # the kernel's h2_swz: (r & 1) | ((r & 2) ? 12 : 0)
+
+
+def extra_cycles(addr_fn, groups, nbanks, width):
+    """conflict cycles of one wave instruction: per lane group, (max distinct dwords on one bank) - 1"""
+    extra = 0
     for g in groups:
-        per=collections.defaultdict(set)
-        for l in g:
-            a=addr_fn(l)
-            for d in range(width//4):
-                dw=a//4+d
-                per[dw%nbanks].add(dw)
-        extra+=max(len(v) for v in per.values())-1
+        per = collections.defaultdict(set)
+        for lane in g:
+            a = addr_fn(lane)
+            for d in range(width // 4):
+                per[(a // 4 + d) % nbanks].add(a // 4 + d)
+        extra += max(len(v) for v in per.values()) - 1
     return extra
-def mk_s(M):
-    # M: 3 rows of 4-bit masks; s bit r = parity(a & M[r])
-    def s(a):
-        v=0
-        for r in range(3):
-            v|= (bin(a&M[r]).count("1")&1)<<r
+
+
+def linear_map(M):
+    def f(a):
+        v = 0
+        for r, mask in enumerate(M):
+            v |= (bin(a & mask).count("1") & 1) << r
         return v
-    return s
-def total(M, verbose=False):
-    s=mk_s(M)
-    res={}
-    # P1 plain b128 read
-    t=0
+    return f
+
+
+def plane_conflicts(M):
+    """conflict cycles of the kernel's access patterns to a plane buffer (row stride 128 B) under granule swizzle M"""
+    s = linear_map(M)
+    res = {}
+    # operand fragments read with ds_read_b128: lane (i = lane & 15 -> row 16 blk + i, kg = lane >> 4 -> granule 4c + kg)
+    res["plain b128 read (x2)"] = sum(
+        extra_cycles(lambda l: (l & 15) * 128 + (((4 * c + (l >> 4)) ^ s(l & 15)) << 4), B128_GROUPS, 64, 16) for c in range(2))
+    # operand fragments read with ds_read_b64_tr_b16: lane (t, kg) addresses row 32c + 8kg + 4half + t/4, 8-byte piece t % 4 of
+    # the granule pair 2 mblk, 2 mblk + 1
+    t = 0
     for c in range(2):
-        for blk in range(1):
-            t+=cycles(lambda l: (16*blk+(l&15))*128 + (((4*c+(l>>4))^s((l&15)))<<4), B128_GROUPS, 64, 16)
-    res["P1 plain b128 (x2 c)"]=t
-    t=0
-    for c in range(2):
-      for half in range(2):
-        for mblk in range(4):
-            def f(l):
-                tt=l&15; kg=l>>4
-                a=32*c+8*kg+4*half+(tt>>2); G=2*mblk+((tt&3)>>1)
-                return a*128+(((G^s(a&15)))<<4)+8*(tt&1)
-            t+=cycles(f, G32, 64, 8)
-    res["P2 tr b64 (x16)"]=t
-    t=0
+        for half in range(2):
+            for mblk in range(4):
+                def f(l):
+                    tt, kg = l & 15, l >> 4
+                    a = 32 * c + 8 * kg + 4 * half + (tt >> 2)
+                    return a * 128 + (((2 * mblk + ((tt & 3) >> 1)) ^ s(a & 15)) << 4) + 8 * (tt & 1)
+                t += extra_cycles(f, G32, 64, 8)
+    res["transposing b64 read (x16)"] = t
+    # C-layout ds_write_b64: lane (j, kg) writes rows 16 blk + 4 kg .. +3 of plane row 16 w + j
+    t = 0
     for w in range(4):
         for blk in range(4):
             def f(l):
-                j=l&15; kg=l>>4; a=16*w+j; G=2*blk+(kg>>1)
-                return a*128+((G^s(a&15))<<4)+8*(kg&1)
-            t+=cycles(f, G16, 32, 8)
-    res["P3 C b64 write (x16)"]=t
-    t=0
-    for w in range(4):
-        for g in range(2):
-            t+=cycles(lambda l: l*128+(((2*w+g)^s(l&15))<<4), G8, 32, 16)
-    res["P4 X b128 write (x8)"]=t
-    t=0
+                j, kg = l & 15, l >> 4
+                a = 16 * w + j
+                return a * 128 + (((2 * blk + (kg >> 1)) ^ s(a & 15)) << 4) + 8 * (kg & 1)
+            t += extra_cycles(f, G16, 32, 8)
+    res["C-layout b64 write (x16)"] = t
+    # X commit: lane = plane row (feature), granule 2w + g
+    res["X commit b128 write (x8)"] = sum(
+        extra_cycles(lambda l: l * 128 + (((2 * w + g) ^ s(l & 15)) << 4), G8, 32, 16) for w in range(4) for g in range(2))
+    # dZ2 commit: lane (row 16w + lane/4, q = lane % 4) writes granule 4g + q
+    t = 0
     for w in range(4):
         for g in range(2):
             def f(l):
-                hr=16*w+(l>>2); hq=l&3
-                return hr*128+(((4*g+hq)^s(hr&15))<<4)
-            t+=cycles(f, G8, 32, 16)
-    res["P5 dZ2 b128 write (x8)"]=t
+                hr, hq = 16 * w + (l >> 2), l & 3
+                return hr * 128 + (((4 * g + hq) ^ s(hr & 15)) << 4)
+            t += extra_cycles(f, G8, 32, 16)
+    res["dZ2 commit b128 write (x8)"] = t
     return res
-def score(res):
-    return res["P1 plain b128 (x2 c)"]*39/2 + res["P2 tr b64 (x16)"]*108/16 + res["P3 C b64 write (x16)"]*24/16 + res["P4 X b128 write (x8)"]*6/8+res["P5 dZ2 b128 write (x8)"]*6/8
-cur=[0b0100,0b1000,0b0010]   # bit0 = a bit2, bit1 = a bit3, bit2 = a bit1
-print("current", total(cur), score(total(cur)))
-old=[0b1000,0b0100,0b0010]
-print("old", total(old), score(total(old)))
-best=None
-for M in itertools.product(range(16), repeat=3):
-    r=total(M); sc=score(r)
-    if best is None or sc<best[0]:
-        best=(sc,M,r)
-print("best", best)
-# h2 accesses
-for LH2 in (65,68,72,76,80,84):
-    t6=0
-    if LH2%4==0:
-        for w in range(4):
-            for b in range(4):
-                t6+=cycles(lambda l: ((16*b+(l&15))*LH2+16*w+4*(l>>4))*4, G8, 32, 16)
-    t7=0
-    if LH2%4==0:
-        for w in range(4):
-            for g in range(4):
-                t7+=cycles(lambda l: ((16*w+(l>>2))*LH2+8*(l&3)+4*(g&1)+32*(g>>1))*4, B128_GROUPS, 64, 16)
-    print("LH2",LH2,"P6 h2 b128 write x16:",t6,"P7 head b128 read x16:",t7)
 
-# ---- H2 (f32) inside the row-interleaved dZ2 buffer: row stride 384 B, unit granule (4 floats) g at (g ^ f(row)) ----
-def h2_total(M):
-    def f(r):
-        v = 0
-        for b in range(4):
-            v |= (bin(r & M[b]).count("1") & 1) << b
-        return v
-    t6 = 0
-    for w in range(4):
-        for b in range(4):
-            t6 += cycles(lambda l: (16*b+(l&15))*384 + ((((4*w+(l>>4))) ^ f(16*b+(l&15))) << 4), G8, 32, 16)
-    t7 = 0
-    for w in range(4):
-        for g in range(4):
-            t7 += cycles(lambda l: (16*w+(l>>2))*384 + (((2*(l&3)+(g&1)+8*(g>>1)) ^ f(16*w+(l>>2))) << 4), B128_GROUPS, 64, 16)
-    return t6, t7
-bestf = None
-for M in itertools.product(range(16), repeat=4):
-    t6, t7 = h2_total(M)
-    if bestf is None or t6 + t7 < bestf[0]:
-        bestf = (t6 + t7, M, t6, t7)
-print("H2 swizzle best", bestf)
-bestf = None
-for M in itertools.product(range(4), repeat=4):     # f depends on row bits 0..1 only (compile-time in the d act_W loop)
-    t6, t7 = h2_total(M)
-    if bestf is None or t6 + 4 * t7 < bestf[0]:
-        bestf = (t6 + 4 * t7, M, t6, t7)
-print("H2 swizzle, row bits 0-1 only: best", bestf)
+
+def plane_score(res):
+    """conflict cycles per tile and wave: the kernel's instruction counts per pattern"""
+    return (res["plain b128 read (x2)"] * 78 / 2 + res["transposing b64 read (x16)"] * 108 / 16 + res["C-layout b64 write (x16)"] * 24 / 16 +
+            res["X commit b128 write (x8)"] * 6 / 8 + res["dZ2 commit b128 write (x8)"] * 6 / 8)
+
+
+def h2_conflicts(M):
+    """H2 (f32) inside the row-interleaved dZ2 buffer: row stride 384 B, unit granule (4 floats) g at g ^ f(row).
+    Returns (S2 epilogue's 16-byte stores, head phase's 16-byte reads), 16 instructions each."""
+    f = linear_map(M)
+    writes = sum(extra_cycles(lambda l: (16 * b + (l & 15)) * 384 + (((4 * w + (l >> 4)) ^ f(16 * b + (l & 15))) << 4), G8, 32, 16)
+                 for w in range(4) for b in range(4))
+    reads = sum(extra_cycles(lambda l: (16 * w + (l >> 2)) * 384 + (((2 * (l & 3) + (g & 1) + 8 * (g >> 1)) ^ f(16 * w + (l >> 2))) << 4),
+                             B128_GROUPS, 64, 16) for w in range(4) for g in range(4))
+    return writes, reads
+
+
+def main():
+    first = (0b1000, 0b0100, 0b0010)
+    print("first layout      ", plane_conflicts(first), "-> %.0f conflict cycles per tile and wave" % plane_score(plane_conflicts(first)))
+    print("chosen (PLANE_SWZ)", plane_conflicts(PLANE_SWZ), "-> %.0f" % plane_score(plane_conflicts(PLANE_SWZ)))
+    best = min(((plane_score(plane_conflicts(M)), M) for M in itertools.product(range(16), repeat=3)))
+    print("best of 4096 linear maps:", best, plane_conflicts(best[1]))
+    print("H2 chosen (H2_SWZ): stores / reads", h2_conflicts(H2_SWZ))
+    best_h2 = min(((w + 4 * r, M) for M in itertools.product(range(4), repeat=4) for w, r in [h2_conflicts(M)]))
+    print("H2, maps of row bits 0..1 only (compile-time constants in the d act_W loop): best", best_h2, h2_conflicts(best_h2[1]))
+
+
+if __name__ == "__main__":
+    main()

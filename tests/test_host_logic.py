@@ -520,3 +520,29 @@ def test_tester_and_bctrainer_cli_surface():
     b = bctrainer.build_parser().parse_args(["LiarsDice-v0", "demo.npy", "--choose-alt", "-t", "4", "--l2", "0.01", "--save", "c.pt"])
     assert (b.env, b.trajectory, b.choose_alt, b.total_epochs, b.l2, b.save, b.framestack) == ("LiarsDice-v0", "demo.npy", True, 4,
                                                                                              0.01, "c.pt", 1)
+
+
+def test_lds_swizzles_of_the_split_gradient_kernel_are_conflict_free_under_the_lane_group_model():
+    """pl_swz / h2_swz of ph_ppo_split.hip restated as linear maps (scripts/lds_swizzle_search.py) and run through the LDS lane-group
+    model that predicted the kernel's measured SQ_LDS_BANK_CONFLICT: operand reads (plain and transposing), the X commit and the
+    dZ2 commit are conflict-free, the 8-byte C-layout stores keep their inherent 2-way conflict, H2's head reads are conflict-free."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "lds_swizzle_search.py")
+    spec = importlib.util.spec_from_file_location("lds_swizzle_search", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.plane_conflicts(mod.PLANE_SWZ)
+    assert res["plain b128 read (x2)"] == 0 and res["transposing b64 read (x16)"] == 0
+    assert res["X commit b128 write (x8)"] == 0 and res["dZ2 commit b128 write (x8)"] == 0
+    assert res["C-layout b64 write (x16)"] == 64                      # one extra cycle per 16-lane group
+    first = mod.plane_conflicts((0b1000, 0b0100, 0b0010))             # the layout the kernel started with
+    assert mod.plane_score(first) > 5 * mod.plane_score(res)
+    writes, reads = mod.h2_conflicts(mod.H2_SWZ)
+    assert reads == 0 and writes == 128
+    # the device function, restated: pl_swz(a) = a1 | (a1 ^ a2) << 1 | (a0 ^ a1 ^ a3) << 2 ; h2_swz(r) = (r & 1) | ((r & 2) ? 12 : 0)
+    s, f = mod.linear_map(mod.PLANE_SWZ), mod.linear_map(mod.H2_SWZ)
+    for a in range(16):
+        a0, a1, a2, a3 = a & 1, (a >> 1) & 1, (a >> 2) & 1, (a >> 3) & 1
+        assert s(a) == (a1 | ((a1 ^ a2) << 1) | ((a0 ^ a1 ^ a3) << 2))
+        assert f(a) == ((a & 1) | (12 if a & 2 else 0))
