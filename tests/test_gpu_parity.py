@@ -6,6 +6,10 @@ Tolerances (float32 path, stated per test):
   * logits / values / log-probs / entropy: atol 2e-5 (tanh/exp/log differ by <= 2 ulp between ocml and torch-CPU).
   * gradients: atol 1e-6 + rtol 2e-4 ;  post-Adam weights: atol 2e-6 per optimizer step taken.
   * everything integer (actions under a mask, illegal-action fix-up, permutation indices): bit-exact.
+The update runs with the engine's default product arithmetic (gemm_mode 2: float32 operands as three bf16 planes, six matrix-pipe
+terms per product, float32 accumulation) wherever the split gradient kernel takes the shape; the tolerances above were stated for
+the exact-float32 kernels and none was changed for it.  Tests that pin a mode pass gemm_mode explicitly (0 = exact-f32 MFMA, 1 = its
+bitwise VALU restatement, 2 = split).
 """
 import copy
 
