@@ -385,6 +385,14 @@ def bench_roundrobin(args, device, rank, world, json_fd, tdist):
     dt = float(tmax.item())
     upd = th.tensor([float(getattr(side, "updates", 0))], dtype=th.float64, device=device if args.backend == "nccl" else "cpu")
     tdist.all_reduce(upd)
+    # in-kernel waits that timed out anywhere invalidate the run on every rank (a partner's last iteration is only checked at
+    # the start of its next one: roundrobin.RoundRobinLink.check)
+    tmo = th.tensor([float(side.link.timeouts()) if getattr(side, "native", False) else 0.0], dtype=th.float64,
+                    device=device if args.backend == "nccl" else "cpu")
+    tdist.all_reduce(tmo)
+    if tmo.item() != 0:
+        raise SystemExit(f"bench.py: rank {rank}: {int(tmo.item())} round-robin waits timed out across the ranks -- the run is "
+                         f"invalid; here: {side.link.timeout_record() if getattr(side, 'native', False) else None}")
     if rank == 0:
         value = 2.0 * args.n_envs * args.n_steps * args.steps / dt
         result = {"metric": f"env-steps/sec (all agents) {args.workload} shapes, ego vs {K} round-robin partners",
@@ -400,7 +408,7 @@ def bench_roundrobin(args, device, rank, world, json_fd, tdist):
                                                 "iteration and rank" if getattr(side, "native", False) else
                                                 f"one broadcast + one all-gather of torch.distributed {args.backend} per step") + ")",
                              "carrier": "engine-side" if getattr(side, "native", False) else "torch.distributed",
-                             "p2p_timeouts": side.link.timeouts() if getattr(side, "native", False) else 0,
+                             "p2p_timeouts": int(tmo.item()),
                              "launch_mode": "roundrobin"}}
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     tdist.barrier()
@@ -585,7 +593,8 @@ def main():
                                       "(agents_per_gpu learners x n_envs x n_steps per iteration)"},
     }
     if exchange is not None and hasattr(exchange, "route") and exchange.p2p_timeouts() != 0:
-        raise SystemExit(f"bench.py: rank {rank}: {exchange.p2p_timeouts()} peer-to-peer polls timed out -- the run is invalid")
+        raise SystemExit(f"bench.py: rank {rank}: {exchange.p2p_timeouts()} peer-to-peer polls timed out -- the run is invalid; "
+                         f"first: {exchange.p2p_timeout_record()}")
     if distributed and ranks_seen != args.gpus:
         raise SystemExit(f"bench.py: the collective saw {ranks_seen} ranks, --gpus is {args.gpus}")
     if mode == "graph" and args.rollout == "scripted":

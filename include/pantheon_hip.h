@@ -33,10 +33,11 @@
 extern "C" {
 #endif
 
-#define PH_ABI_VERSION 3   /* 2: + ph_agent_*, ph_bc_*, ph_adap_*, ph_scripted_rollout, ph_liar_selfplay_rollout, ph_roundrobin_env_step,
+#define PH_ABI_VERSION 4   /* 2: + ph_agent_*, ph_bc_*, ph_adap_*, ph_scripted_rollout, ph_liar_selfplay_rollout, ph_roundrobin_env_step,
                                   ph_buffer_compact_columns (additions only: every v1 signature is unchanged)
                               3: + ph_selfplay_rollout_persistent, PH_STEP_FIX_ILLEGAL / _MASK_ENV_ONLY, ph_modular_*, ph_roundrobin_*_iteration
-                                  (additions only) */
+                                  (additions only)
+                              4: + ph_selfplay_rollout_persistent_capacity, ph_ppo_train's gradient pack (no signature changed) */
 #define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
 #define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
 #define PH_MAX_LOGITS 64 /* max total policy logits L */
@@ -371,7 +372,9 @@ int ph_selfplay_rollout_p2p(ph_ctx *ctx, int n_calls, const ph_step_call *calls 
  *   receive slot of parity (T - 1) & 1, which also makes this rank wait for every peer once per iteration.
  *   Every workgroup of the launch must be resident at once (value workgroups poll; policy workgroups never wait):
  *   n_calls * 2 * ceil(n / 16) workgroups, times `ranks_on_device` when several ranks share one GPU, must not exceed
- *   2 * #CUs -- otherwise the call refuses (use ph_selfplay_rollout_p2p).  Shapes of the 16-row forward only. */
+ *   what ph_selfplay_rollout_persistent_capacity reports -- the runtime's occupancy answer for the rollout kernel on this
+ *   device (workgroups per CU x CUs, one workgroup per CU held back where the answer is not bounded by LDS: the occupancy API
+ *   can be one high there) -- otherwise the call refuses (use ph_selfplay_rollout_p2p).  Shapes of the 16-row forward only. */
 typedef struct ph_rollout_call {
   const ph_spec *spec;               /* host */
   const float *params;
@@ -394,6 +397,10 @@ typedef struct ph_rollout_call {
 } ph_rollout_call;
 int ph_selfplay_rollout_persistent(ph_ctx *ctx, int n_calls, const ph_rollout_call *calls /* host */, int T,
                                    const ph_p2p *x, int ranks_on_device);
+/* workgroups of the exchange rollout kernel the device keeps resident at once (hipOccupancyMaxActiveBlocksPerMultiprocessor,
+ * not a formula): the bound ph_selfplay_rollout_persistent checks its grid against.  Callers that must agree across ranks
+ * (vec.FusedSelfPlayRollout) read it, decide, and all-reduce the decision. */
+int ph_selfplay_rollout_persistent_capacity(ph_ctx *ctx, int *workgroups_out);
 
 /* Ragged rollout buffers for vectorised TURN-BASED games ("per-env pos"): a partner does not act in
  * every env at every step, so each env e has its own write row pos_env[e] (device int32, caller-owned).

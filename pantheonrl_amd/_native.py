@@ -231,6 +231,7 @@ SIGNATURES = {
     "ph_p2p_ll_unpack": [_vp, C.POINTER(PhP2P), _i],
     "ph_selfplay_rollout_p2p": [_vp, _i, C.POINTER(PhStepCall), _i, _vp, C.POINTER(PhP2P)],
     "ph_selfplay_rollout_persistent": [_vp, _i, C.POINTER(PhRolloutCall), _i, C.POINTER(PhP2P), _i],
+    "ph_selfplay_rollout_persistent_capacity": [_vp, C.POINTER(_i)],
     "ph_rr_area_bytes": [_i, _i, _i, C.POINTER(C.c_size_t)],
     "ph_roundrobin_ego_iteration": [_vp, C.POINTER(PhRRLink), C.POINTER(PhRREgo), _i, _ull],
     "ph_roundrobin_partner_iteration": [_vp, C.POINTER(PhRRLink), C.POINTER(PhRRPartner), _i, _ull],
@@ -297,7 +298,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.argtypes = argtypes
         fn.restype = C.c_char_p if name in ("ph_last_error", "ph_agent_last_error") else C.c_int
-    if lib.ph_abi_version() != 3:
+    if lib.ph_abi_version() != 4:
         raise NativeError("libpantheon_hip.so ABI version mismatch")
     _lib = lib
     return lib

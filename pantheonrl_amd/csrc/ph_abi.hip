@@ -81,6 +81,7 @@ struct ph_ctx {
   int comm_world = 1, comm_rank = 0;
   hipEvent_t ev_grad = nullptr;   // ph_ppo_train_multi: "this learner's latest gradient launch"
   int num_cu = 256;
+  int exchange_blocks_per_cu = 0;           // occupancy answer for the exchange rollout kernel (0 = not asked yet)
   unsigned long long* rng_epoch = nullptr;  // caller-owned device word
   long long* prof = nullptr;                // caller-owned debug stamp buffer
   // ModularAlgorithm workspace (ph_modular_*): activations and head gradients in minibatch order, the towers' slab maps
@@ -1092,6 +1093,14 @@ int ensure_p2p_dev(ph_ctx* ctx, const ph_p2p* x) {
 }
 }  // namespace
 
+int ph_selfplay_rollout_persistent_capacity(ph_ctx* ctx, int* workgroups_out) {
+  DevGuard dev_guard(ctx);
+  if (!ctx || !workgroups_out) return fail("ph_selfplay_rollout_persistent_capacity: null argument");
+  if (ctx->exchange_blocks_per_cu <= 0) PH_HIP(ph::exchange_rollout_blocks_per_cu(&ctx->exchange_blocks_per_cu));
+  *workgroups_out = ctx->exchange_blocks_per_cu * ctx->num_cu;
+  return 0;
+}
+
 int ph_selfplay_rollout_persistent(ph_ctx* ctx, int n_calls, const ph_rollout_call* calls, int T, const ph_p2p* x,
                                    int ranks_on_device) {
   DevGuard dev_guard(ctx);
@@ -1103,7 +1112,9 @@ int ph_selfplay_rollout_persistent(ph_ctx* ctx, int n_calls, const ph_rollout_ca
   if (x->count != n_calls * calls[0].n) return fail("ph_p2p.count must be local agents x n");
   if (ranks_on_device < 1) ranks_on_device = 1;
   const long long wgs = (long long)n_calls * 2 * ((calls[0].n + 15) / 16) * ranks_on_device;
-  if (wgs > 2ll * ctx->num_cu)
+  int capacity = 0;
+  if (ph_selfplay_rollout_persistent_capacity(ctx, &capacity)) return 1;
+  if (wgs > (long long)capacity)
     return fail("ph_selfplay_rollout_persistent: the launch's workgroups would not all be resident (value workgroups poll): use "
                 "ph_selfplay_rollout_p2p");
   ph::FwdMulti m;

@@ -176,12 +176,14 @@ __global__ __launch_bounds__(64) void p2p_wait_kernel(ph_p2p x, int t) {
   const unsigned long long* flag = x.flags[x.rank] + src;
   const long long t0 = wall_clock64();
   bool ok = false;
+  unsigned long long seen = 0ull;
   while (true) {
-    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) { ok = true; break; }
+    seen = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (seen >= want) { ok = true; break; }
     if ((unsigned long long)(wall_clock64() - t0) > x.timeout_cycles) break;
     __builtin_amdgcn_s_sleep(8);
   }
-  if (!ok) atomicAdd(x.error, 1ull);
+  if (!ok) p2p_note_timeout(x.error, 3, t, (unsigned long long)src, want, seen);
   __threadfence_system();
 }
 hipError_t launch_p2p_wait(const ph_p2p& x, int t, hipStream_t s) {
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void p2p_ll_unpack_kernel(ph_p2p x, int t, int
     v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((unsigned)(v >> 32) == want) break;
     if ((unsigned long long)(wall_clock64() - t0) > x.timeout_cycles) {
-      atomicAdd(x.error, 1ull);
+      p2p_note_timeout(x.error, 2, t, (unsigned long long)i, want, v);
       break;
     }
     __builtin_amdgcn_s_sleep(2);
@@ -238,9 +240,10 @@ __device__ __forceinline__ bool rr_wait(const unsigned long long* flag, unsigned
                                         unsigned long long* error) {
   const long long t0 = wall_clock64();
   while (true) {
-    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
+    const unsigned long long seen = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (seen >= want) return true;
     if ((unsigned long long)(wall_clock64() - t0) > timeout) {
-      atomicAdd(error, 1ull);
+      p2p_note_timeout(error, 4, 0, 0ull, want, seen);
       return false;
     }
     __builtin_amdgcn_s_sleep(8);

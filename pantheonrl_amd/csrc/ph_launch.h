@@ -9,6 +9,20 @@ __host__ __device__ inline unsigned p2p_stamp32(unsigned long long epoch, int T,
   return (unsigned)(epoch * (unsigned long long)T + (unsigned long long)t + 1ull);
 }
 
+// A bounded in-kernel wait that expired: count it in error[0]; the FIRST one of the area's lifetime also leaves a record of what
+// was waited for -- error[1] = kind | step << 8 | index << 32 (kind: 1 stamp-in-band word polled by a forward's value tail,
+// 2 the same word polled by the unpack kernel, 3 a stamp flag of the push / wait pair, 4 a round-robin block or action stamp;
+// index: word offset inside the step's slot = seat * n + row, or the source rank), error[2] = the stamp wanted, error[3] = the
+// word seen last.  The areas reserve 64 bytes (eight words) for this.
+__device__ __forceinline__ void p2p_note_timeout(unsigned long long* error, int kind, int t, unsigned long long index,
+                                                 unsigned long long want, unsigned long long seen) {
+  if (atomicAdd(error, 1ull) == 0ull) {
+    error[1] = (unsigned long long)(unsigned)kind | ((unsigned long long)(unsigned)(t & 0xffffff) << 8) | (index << 32);
+    error[2] = want;
+    error[3] = seen;
+  }
+}
+
 struct FwdArgs {
   NetDims nd;
   const float* params;
@@ -97,6 +111,9 @@ hipError_t launch_policy_fwd16_rollout(const FwdArgs& a, const ScriptedSteps& sc
 // all T steps of every local agent of the symmetric agent-per-GPU layout in ONE launch, the per-step action hand-off done
 // in-kernel over the stamp-in-band words (m.px.persistent = 1)
 hipError_t launch_policy_fwd16_exchange_rollout(const FwdMulti& m, const ScriptedMulti& sm, int n_agents, hipStream_t s);
+// workgroups of that kernel one CU keeps resident, as the runtime's occupancy query answers for this device (with a margin of one
+// where the answer is not LDS-bound: MI355X_MICROARCH.md, "Residency and cooperative launch")
+hipError_t exchange_rollout_blocks_per_cu(int* blocks_out);
 
 struct GradArgs {
   NetDims nd;

@@ -514,6 +514,21 @@ hipError_t launch_policy_fwd16_rollout(const FwdArgs& a, const ScriptedSteps& sc
   return hipGetLastError();
 }
 
+hipError_t exchange_rollout_blocks_per_cu(int* blocks_out) {
+  const size_t lds = fwd16_lds_bytes();
+  int api = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, (const void*)policy_fwd16_exchange_rollout_kernel, 256, lds);
+  if (e != hipSuccess) return e;
+  const int by_lds = (int)((size_t)160 * 1024 / lds);
+  int blocks = api < 8 ? api : 8;
+  // The API's answer is exact where LDS bounds it; where registers bound it the hardware can admit one block fewer per CU than
+  // the API says (SGPR allocation granule), and a polling grid sized by the optimistic figure never completes: hold one back.
+  if (blocks > by_lds) blocks = by_lds;
+  else if (blocks < by_lds && blocks > 1) blocks -= 1;
+  *blocks_out = blocks < 1 ? 1 : blocks;
+  return hipSuccess;
+}
+
 hipError_t launch_policy_fwd16_exchange_rollout(const FwdMulti& m, const ScriptedMulti& sm, int n_agents, hipStream_t s) {
   hipLaunchKernelGGL(policy_fwd16_exchange_rollout_kernel, dim3((m.a[0].n + 15) / 16, 2, n_agents), dim3(256), fwd16_lds_bytes(),
                      s, m, sm);

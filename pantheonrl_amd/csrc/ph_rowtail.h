@@ -24,7 +24,7 @@ __device__ __forceinline__ int ll_read(const FwdArgs& a, const unsigned long lon
     const unsigned long long v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((unsigned)(v >> 32) == want) return (int)(unsigned)v;
     if ((unsigned long long)(wall_clock64() - t0) > a.ll_timeout) {
-      atomicAdd(a.ll_error, 1ull);
+      p2p_note_timeout(a.ll_error, 1, a.ll_t, a.joint_ll ? (unsigned long long)(word - a.joint_ll) : 0ull, want, v);
       return (int)(unsigned)v;
     }
     __builtin_amdgcn_s_sleep(2);

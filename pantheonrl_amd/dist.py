@@ -115,7 +115,7 @@ class ActionExchange:
                     self.__cuda_array_interface__ = {"shape": shape, "typestr": "<i4", "data": (ptr, False), "version": 2}
             self._p2p_slots = [th.as_tensor(_View(own + par * slot, (self.n_seats, self.n_envs)), device=self.local.device)
                                for par in (0, 1)]
-            self._p2p_error = th.as_tensor(_View(x.error, (2,)), device=self.local.device)   # u64 as two i32
+            self._p2p_error = th.as_tensor(_View(x.error, (8,)), device=self.local.device)   # four u64 as eight i32
             self._p2p_keep = [epoch_word, bases]
             self.p2p, self.native_ctx = x, ctx
             return True
@@ -225,14 +225,16 @@ class ActionExchange:
         device, as the one-GPU test boxes do) -- the persistent rollout's residency bound needs it"""
         if self.world == 1 or not self.local.is_cuda:
             return 1
-        try:
+        try:                                      # local work only: the collective below is reached by every rank
             props = th.cuda.get_device_properties(self.local.device)
             me = f"{os.uname().nodename}:{getattr(props, 'uuid', self.local.device.index)}"
-            ids = [None] * self.world
-            dist.all_gather_object(ids, me, group=self.group)
-            return max(1, sum(1 for v in ids if v == me))
         except Exception:  # noqa: BLE001
-            return self.world
+            me = None                             # "unknown": counted as sharing with everybody, on every rank alike
+        ids = [None] * self.world
+        dist.all_gather_object(ids, me, group=self.group)
+        if any(v is None for v in ids):
+            return self.world                     # the same (pessimistic) answer everywhere
+        return max(1, sum(1 for v in ids if v == me))
 
     def _torch_gather(self) -> th.Tensor:
         """all-gather of `self.local` through torch.distributed alone (the route of last resort and the yardstick the native
@@ -293,6 +295,25 @@ class ActionExchange:
 
     def p2p_timeouts(self) -> int:
         return int(self._p2p_error[0].item()) if self.p2p is not None else 0
+
+    def p2p_timeout_record(self) -> Optional[dict]:
+        """what the FIRST timed-out wait of this rank was waiting for (csrc/ph_launch.h: p2p_note_timeout), or None"""
+        if self.p2p is None or self.p2p_timeouts() == 0:
+            return None
+        w = [int(v) & 0xFFFFFFFF for v in self._p2p_error.cpu().tolist()]
+        kinds = {1: "stamp-in-band word polled by a value tail", 2: "stamp-in-band word polled by the unpack kernel",
+                 3: "stamp flag of the push / wait pair", 4: "round-robin stamp"}
+        index = w[3]
+        rec = {"rank": self.rank, "kind": kinds.get(w[2] & 0xFF, w[2] & 0xFF), "step": w[2] >> 8,
+               "want_stamp": w[4], "seen_stamp": w[7], "seen_value": w[6], "timeouts": self.p2p_timeouts()}
+        if (w[2] & 0xFF) in (1, 2):
+            rec["seat"], rec["row"] = index // max(self.n_envs, 1), index % max(self.n_envs, 1)
+            T = int(self.p2p.T)
+            rec["seen_is"] = ("nothing yet" if w[7] == 0 else
+                              f"iteration {(w[7] - 1) // T} step {(w[7] - 1) % T}") + f"; wanted iteration {(w[4] - 1) // T} step {(w[4] - 1) % T}"
+        else:                                   # 64-bit stamps: the low words
+            rec["source_rank"], rec["seen_stamp"], rec["seen_value"] = index, w[6], None
+        return rec
 
     def p2p_step(self, t: int, in_band: bool = False) -> th.Tensor:
         """one exchange of step t outside the fused rollout loop (tests, self-test): push + wait with stamp flags, or -- the

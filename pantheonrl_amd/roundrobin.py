@@ -51,41 +51,90 @@ class RoundRobinLink:
 
     _generation = 0
 
-    def __init__(self, ctx, n_partners: int, n_envs: int, obs_dim: int, device, timeout_s: float = 5.0):
+    def __init__(self, ctx, n_partners: int, n_envs: int, obs_dim: int, device, timeout_s: Optional[float] = None):
         import ctypes as C
+        import os
+        if timeout_s is None:      # one bound for every in-kernel wait of the package (dist.ActionExchange.attach_p2p)
+            timeout_s = float(os.environ.get("PH_P2P_TIMEOUT_S", "10"))
         self.ctx, self.device = ctx, device
         rank, world = dist.get_rank(), dist.get_world_size()
-        size = C.c_size_t(0)
-        nat.check(ctx.lib.ph_rr_area_bytes(n_partners, n_envs, HEADER + obs_dim, C.byref(size)))
-        base, handle = C.c_void_p(), (C.c_ubyte * 64)()
-        nat.check(ctx.lib.ph_p2p_alloc(ctx.handle, size.value + 64, C.byref(base), handle))
         store = dist.distributed_c10d._get_default_store()
+        # the generation advances BEFORE anything can fail, and a rank that fails says so under its key: the n-th attempt of
+        # every rank meets under the same keys whatever happened to earlier attempts, and nobody waits out the store's timeout
+        # for a handle that will never come
         RoundRobinLink._generation += 1
         gen = RoundRobinLink._generation
-        store.set(f"pantheonrl_amd/rr/{gen}/{rank}", bytes(handle))
+        key = f"pantheonrl_amd/rr/{gen}/{rank}"
+        self._mapped, self._base = [], None
+        try:
+            size = C.c_size_t(0)
+            nat.check(ctx.lib.ph_rr_area_bytes(n_partners, n_envs, HEADER + obs_dim, C.byref(size)))
+            base, handle = C.c_void_p(), (C.c_ubyte * 64)()
+            nat.check(ctx.lib.ph_p2p_alloc(ctx.handle, size.value + 64, C.byref(base), handle))
+            self._base = base
+        except Exception:
+            store.set(key, b"failed")
+            raise
+        store.set(key, bytes(handle))
         link = nat.PhRRLink()
         link.n_partners, link.rank, link.n, link.block_ld = n_partners, rank, n_envs, HEADER + obs_dim
-        self._mapped = []
-        for r in range(world):
-            if r == rank:
-                link.area[r] = base.value
-                continue
-            peer = (C.c_ubyte * 64).from_buffer_copy(store.get(f"pantheonrl_amd/rr/{gen}/{r}"))
-            mapped = C.c_void_p()
-            nat.check(ctx.lib.ph_p2p_open(ctx.handle, peer, C.byref(mapped)))
-            link.area[r] = mapped.value
-            self._mapped.append(mapped)
+        try:
+            for r in range(world):
+                if r == rank:
+                    link.area[r] = base.value
+                    continue
+                raw = store.get(f"pantheonrl_amd/rr/{gen}/{r}")
+                if len(raw) != 64:
+                    raise RuntimeError(f"rank {r} could not allocate its receive area")
+                peer = (C.c_ubyte * 64).from_buffer_copy(raw)
+                mapped = C.c_void_p()
+                nat.check(ctx.lib.ph_p2p_open(ctx.handle, peer, C.byref(mapped)))
+                link.area[r] = mapped.value
+                self._mapped.append(mapped)
+        except Exception:
+            self.close()
+            raise
         link.error = base.value + size.value          # the spare 64 bytes behind the area
         link.timeout_cycles = int(timeout_s * 1e8)
-        self.link, self._base, self._size = link, base, size.value
+        self.link, self._size = link, size.value
 
         class _View:
             def __init__(self, ptr):
-                self.__cuda_array_interface__ = {"shape": (2,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+                self.__cuda_array_interface__ = {"shape": (8,), "typestr": "<i4", "data": (ptr, False), "version": 2}
         self._error = th.as_tensor(_View(link.error), device=device)
 
     def timeouts(self) -> int:
         return int(self._error[0].item())
+
+    def timeout_record(self) -> Optional[dict]:
+        """what the first timed-out wait was waiting for (csrc/ph_launch.h: p2p_note_timeout), or None"""
+        if self.timeouts() == 0:
+            return None
+        w = [int(v) & 0xFFFFFFFF for v in self._error.cpu().tolist()]
+        return {"rank": int(self.link.rank), "timeouts": w[0], "want_stamp": w[4], "seen_stamp": w[6]}
+
+    def check(self, where: str) -> None:
+        """a wait that timed out means the iteration went on with stale slots (the kernels never hang the device): the buffers it
+        filled must not be trained on"""
+        n = self.timeouts()
+        if n:
+            raise nat.NativeError(f"round-robin carrier: {n} in-kernel wait(s) timed out {where} ({self.timeout_record()}); "
+                                  "a peer is lost or more than PH_P2P_TIMEOUT_S late -- the rollout buffers hold stale rows")
+
+    def close(self) -> None:
+        """unmap the peers' areas and free this rank's (idempotent)"""
+        for m in self._mapped:
+            try:
+                self.ctx.lib.ph_p2p_close(self.ctx.handle, m)
+            except Exception:  # noqa: BLE001
+                pass
+        self._mapped = []
+        if self._base is not None:
+            try:
+                self.ctx.lib.ph_p2p_free(self.ctx.handle, self._base)
+            except Exception:  # noqa: BLE001
+                pass
+            self._base = None
 
 
 def _timing() -> bool:
@@ -194,6 +243,7 @@ class RoundRobinEgoRank:
         ego._pending = self.rewards[T - 1]            # the last step's reward: flushed by compute_returns
         ego._last_episode_starts = d.dones[T - 1]
         self.iteration += 1
+        self.link.check(f"in the ego's iteration {self.iteration - 1}")   # one host read: never train on stale joint actions
         ego.learn_from_buffer()
         if timing:
             th.cuda.synchronize()
@@ -256,6 +306,8 @@ class RoundRobinPartnerRank:
         if timing:
             th.cuda.synchronize()
             t0 = _now()
+        if self.iteration > 0:                    # the previous iteration's waits, before its rows are trained on or extended
+            self.link.check(f"in partner {self.k}'s iteration {self.iteration - 1}")
         if agent.full():                          # once per iteration (one host read): train on the full columns
             agent.learn_from_buffer()
             self.updates += 1

@@ -371,20 +371,30 @@ class FusedSelfPlayRollout:
             c.n_seats, c.seat, c.partner_seat, c.bonus = exchange.n_seats, exchange.seat(i), self.partner[i].data_ptr(), bonus
 
     def persistent_ok(self) -> bool:
-        """can this iteration's rollout run as the one-launch exchange rollout?  Needs the peer-to-peer words, the 16-row
-        forward's shapes, 2 T word slots, and every workgroup of the launch resident at once (value workgroups poll)."""
+        """can the rollouts run as the one-launch exchange rollout?  Needs the peer-to-peer words, the 16-row forward's shapes,
+        2 T word slots, and every workgroup of the launch resident at once (value workgroups poll): the grid of all ranks sharing
+        this device against what the runtime's occupancy query reports for the kernel.  The two rollout forms use different word
+        slots, so the verdict is taken ONCE per exchange route and is the same on every rank (all-reduced): a rank whose local
+        inputs differ (an environment variable, uneven ranks per GPU) takes the others to the per-step form with it."""
         import os
         ex = self.exchange
-        if self.want_persistent is False or os.environ.get("PH_EXCHANGE_PERSISTENT", "1") == "0" or ex.p2p is None:
-            return False
-        lay = self.agents[0].model.policy.layout
-        E = self.agents[0].E
-        if not (lay.F <= 64 and lay.A == 1 and lay.L <= 8 and E < 16384):
-            return False
-        if ex.p2p.T < self.T or ex.p2p.ll_slots < 2 * ex.p2p.T:
-            return False
-        n_cu = th.cuda.get_device_properties(self.agents[0].model.policy.device).multi_processor_count
-        return len(self.agents) * 2 * ((E + 15) // 16) * max(getattr(ex, "ranks_on_device", 1), 1) <= 2 * n_cu
+        key = (id(ex.p2p), getattr(ex, "route", None))
+        if getattr(self, "_persistent_verdict", None) is not None and self._persistent_verdict[0] == key:
+            return self._persistent_verdict[1]
+        ok = not (self.want_persistent is False or os.environ.get("PH_EXCHANGE_PERSISTENT", "1") == "0" or ex.p2p is None)
+        if ok:
+            lay = self.agents[0].model.policy.layout
+            E = self.agents[0].E
+            ok = lay.F <= 64 and lay.A == 1 and lay.L <= 8 and E < 16384
+            ok = ok and not (ex.p2p.T < self.T or ex.p2p.ll_slots < 2 * ex.p2p.T)
+            if ok:
+                cap = C.c_int(0)
+                nat.check(self._lib.ph_selfplay_rollout_persistent_capacity(self._h, C.byref(cap)))
+                ok = len(self.agents) * 2 * ((E + 15) // 16) * max(getattr(ex, "ranks_on_device", 1), 1) <= cap.value
+        if getattr(ex, "world", 1) > 1 and hasattr(ex, "_everyone"):
+            ok = ex._everyone(bool(ok))
+        self._persistent_verdict = (key, bool(ok))
+        return bool(ok)
 
     def set_pairing(self, pairing_round: int) -> None:
         ex = self.exchange

@@ -73,8 +73,9 @@ def device_policy(name: str, oracle: MlpPolicyOracle):
 
 
 def filled_oracle_buffer(name: str, oracle: MlpPolicyOracle, T: int, E: int, seed: int = 0,
-                         p_done: float = 0.05) -> RolloutBufferOracle:
-    """a full rollout buffer produced by the oracle policy on synthetic inputs (SURVEY.md 8d generators)."""
+                         p_done: float = 0.05, obs_fn=None) -> RolloutBufferOracle:
+    """a full rollout buffer produced by the oracle policy on synthetic inputs (SURVEY.md 8d generators).
+    obs_fn(obs, rng) -> obs replaces the N(0, 1) Box observations (integer-valued / rescaled features)."""
     rng = np.random.default_rng(seed)
     obs_s, act_s = CONFIGS[name]
     buf = RolloutBufferOracle(T, E, obs_s.stored_len, act_s.stored_len)
@@ -82,6 +83,8 @@ def filled_oracle_buffer(name: str, oracle: MlpPolicyOracle, T: int, E: int, see
     values = None
     for _ in range(T):
         obs = sample_obs(obs_s, E, rng)
+        if obs_fn is not None:
+            obs = np.ascontiguousarray(obs_fn(obs, rng), dtype=np.float32)
         with th.no_grad():
             actions, values, logp = oracle.forward(th.as_tensor(obs))
         buf.add(obs, actions.numpy(), rng.standard_normal(E).astype(np.float32), starts, values, logp)

@@ -271,14 +271,20 @@ def test_buffer_add_reward_reset_and_fused_step():
 # ----------------------------------------------------------------------------------------------------------------
 # K3/K5/K6 PPO update
 # ----------------------------------------------------------------------------------------------------------------
-def _grad_pair(name, T, E, idx, hp: orc.PPOHyper, seed=11, gemm_mode=0, f64=False):
+def _grad_pair(name, T, E, idx, hp: orc.PPOHyper, seed=11, gemm_mode=0, f64=False, obs_fn=None, w1_scale=1.0):
     """device minibatch gradient, the oracle's autograd gradient (float32 as the reference computes it; f64: the same graph in
-    float64 -- the yardstick for "which float32 path is closer to the true gradient")"""
+    float64 -- the yardstick for "which float32 path is closer to the true gradient").  obs_fn: other observation
+    distributions than N(0, 1); w1_scale multiplies both first-layer weight matrices (keeps pre-activations in tanh's live range
+    when the observations are rescaled)"""
     import ctypes as C
     from pantheonrl_amd import _native as nat
     from pantheonrl_amd.ppo import PPO
     orac = H.oracle_policy(name, seed=seed)
-    ob = H.filled_oracle_buffer(name, orac, T, E, seed=seed)
+    if w1_scale != 1.0:
+        with th.no_grad():
+            orac.policy_net[0].weight.mul_(w1_scale)
+            orac.value_net_mlp[0].weight.mul_(w1_scale)
+    ob = H.filled_oracle_buffer(name, orac, T, E, seed=seed, obs_fn=obs_fn)
     pol = H.device_policy(name, orac)
     pol.gemm_mode = gemm_mode
     buf = H.make_device_buffer(name, pol, T, E)
@@ -399,11 +405,12 @@ def test_split_bf16_gradient_corner_shapes(name, T, E, nb):
         assert abs(st[i] - st_ref[k]) <= 1e-5 + 1e-4 * abs(st_ref[k]), (k, st[i], st_ref[k])
 
 
-def test_split_bf16_gradient_is_as_close_to_float64_as_the_float32_kernel():
+@pytest.mark.parametrize("T,E,nb", [(64, 64, 4096), (128, 1024, 32768)])
+def test_split_bf16_gradient_is_as_close_to_float64_as_the_float32_kernel(T, E, nb):
     """The accuracy claim behind gemm_mode 2, measured: against the float64 gradient of the same minibatch the split kernel's
     error is no larger than 1.5x the exact-float32 MFMA kernel's (in practice it is smaller: the matrix pipe adds the 32
-    products of an instruction before it rounds) -- and both are at float32 rounding level."""
-    T, E, nb = 64, 64, 4096
+    products of an instruction before it rounds) -- and both are at float32 rounding level.  At 4 096 rows and at the bench's
+    32 768-row minibatch (every workgroup walks two tiles, 512 gradient slabs are reduced)."""
     idx = np.random.default_rng(3).permutation(T * E)[:nb]
     hp = orc.PPOHyper()
     g0, g64, _, _, _ = _grad_pair("overcooked", T, E, idx, hp, gemm_mode=0, f64=True)
@@ -415,6 +422,35 @@ def test_split_bf16_gradient_is_as_close_to_float64_as_the_float32_kernel():
     print(f"vs float64: f32 kernel max {e0.max():.3e} rms {rms0:.3e} | split kernel max {e2.max():.3e} rms {rms2:.3e} | scale {scale:.3e}")
     assert e2.max() <= 1.5 * e0.max() + 1e-9 and rms2 <= 1.5 * rms0 + 1e-10, (e0.max(), e2.max(), rms0, rms2)
     assert e2.max() <= 2e-6 * scale + 1e-9, (e2.max(), scale)
+
+
+@pytest.mark.parametrize("kind", ["counts_0_400", "counts_0_400_rescaled_w1", "x1e4", "x1e4_rescaled_w1", "x1e-4",
+                                  "x1e-4_rescaled_w1"])
+def test_split_bf16_gradient_on_integer_valued_large_and_tiny_observations(kind):
+    """Overcooked's real features are counts and distances, not N(0, 1): the split kernel (three bf16 planes per float32 operand)
+    on integer-valued observations in [0, 400] and on observations scaled by 1e4 / 1e-4, against the exact-f32 kernel at
+    <= 2e-6 of the largest gradient entry and against autograd at the usual tolerance.  Raw, such inputs drive SB3's
+    orthogonal first layer deep into tanh's flat region (most first-layer gradients vanish); the `_rescaled_w1` variants divide
+    the first-layer weights by the input scale so that every layer's gradient is live while the X planes still carry the
+    large / tiny magnitudes."""
+    T, E, nb = 64, 64, 4096
+    idx = np.random.default_rng(5).permutation(T * E)[:nb]
+    scale = {"counts": 400.0, "x1e4": 1e4, "x1e-4": 1e-4}[kind.split("_")[0]]
+    if kind.startswith("counts"):
+        obs_fn = lambda obs, rng: rng.integers(0, 401, size=obs.shape).astype(np.float32)   # noqa: E731
+    else:
+        obs_fn = lambda obs, rng: obs * np.float32(scale)                                   # noqa: E731
+    w1 = 1.0 / scale if kind.endswith("rescaled_w1") else 1.0
+    hp = orc.PPOHyper(ent_coef=0.01)
+    g2, g_ref, st, st_ref, lay = _grad_pair("overcooked", T, E, idx, hp, gemm_mode=2, obs_fn=obs_fn, w1_scale=w1)
+    g0 = _grad_pair("overcooked", T, E, idx, hp, gemm_mode=0, obs_fn=obs_fn, w1_scale=w1)[0]
+    top = max(np.abs(g0).max(), 1e-6)
+    assert np.isfinite(g2).all() and np.abs(g2 - g0).max() <= 2e-6 * top, (kind, np.abs(g2 - g0).max(), top)
+    _assert_grads(g2, g_ref, lay)
+    if kind.endswith("rescaled_w1"):     # the first-layer gradient is really there (not a comparison of zeros)
+        assert np.abs(g_ref[lay.pi_W1:lay.pi_b1]).max() > 1e-4 * top * min(scale, 1.0)
+    for i, k in enumerate(("policy_loss", "value_loss", "entropy_loss", "clip_fraction", "approx_kl", "loss")):
+        assert abs(st[i] - st_ref[k]) <= 1e-5 + 1e-4 * abs(st_ref[k]), (k, st[i], st_ref[k])
 
 
 def test_split_kernel_weight_image_tracks_the_parameters_through_adam_steps_and_early_stops():
@@ -1436,16 +1472,18 @@ def test_peer_to_peer_exchange_between_processes(world):
 # ----------------------------------------------------------------------------------------------------------------
 # round 2: sizes and chains the round-1 suite only property-tested, reference-semantics run, truncation bootstrap
 # ----------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name,T,E,nb", [("overcooked", 128, 1024, 32768), ("liar", 128, 256, 8192),
-                                          ("adap_oc", 128, 256, 32768), ("liar", 128, 256, 32768)])
-def test_full_size_minibatch_gradient_matches_autograd(name, T, E, nb):
+@pytest.mark.parametrize("name,T,E,nb,gemm_mode", [("overcooked", 128, 1024, 32768, 0), ("overcooked", 128, 1024, 32768, 2),
+                                                    ("liar", 128, 256, 8192, 0), ("adap_oc", 128, 256, 32768, 0),
+                                                    ("liar", 128, 256, 32768, 0)])
+def test_full_size_minibatch_gradient_matches_autograd(name, T, E, nb, gemm_mode):
     """One whole minibatch of BASELINE configs 3 and 2 at their real sizes (32 768 rows of Overcooked-simple; 8 192 rows of
     Liar's Dice with F = 270 one-hot features and two action components) against autograd on the oracle.  A sum over nb
     rows in another order: tolerance 2e-4 of the largest gradient entry, as for the small shapes.  The 32 768-row cases of
     the 65-feature Box shape (Overcooked + ADAP context) and of Liar's Dice make every workgroup of the general kernel walk
-    two tiles (slab read-modify-write, row metadata of the next tile staged behind the current one)."""
+    two tiles (slab read-modify-write, row metadata of the next tile staged behind the current one).  The Overcooked case runs on
+    both arithmetics: the exact-f32 kernels (gemm_mode 0) and the split-bf16 kernel PPO.train() and bench.py use by default (2)."""
     idx = np.random.default_rng(nb).permutation(T * E)[:nb]
-    g, g_ref, st, st_ref, lay = _grad_pair(name, T, E, idx, orc.PPOHyper())
+    g, g_ref, st, st_ref, lay = _grad_pair(name, T, E, idx, orc.PPOHyper(), gemm_mode=gemm_mode)
     _assert_grads(g, g_ref, lay)
     for i, k in enumerate(("policy_loss", "value_loss", "entropy_loss", "clip_fraction", "approx_kl", "loss")):
         assert abs(st[i] - st_ref[k]) <= 1e-5 + 1e-4 * abs(st_ref[k]), (k, st[i], st_ref[k])
