@@ -102,6 +102,8 @@ def parse():
                     "exercise the N>1 code path with several ranks on ONE GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the extra figures measured after the timed region "
+                    "(stepwise_rollout, one_agent_per_gpu): a kernel trace of the run then holds the headline's launches only")
     return ap.parse_args()
 
 
@@ -597,7 +599,7 @@ def main():
                          f"first: {exchange.p2p_timeout_record()}")
     if distributed and ranks_seen != args.gpus:
         raise SystemExit(f"bench.py: the collective saw {ranks_seen} ranks, --gpus is {args.gpus}")
-    if mode == "graph" and args.rollout == "scripted":
+    if mode == "graph" and args.rollout == "scripted" and not args.headline_only:
         # the same iteration with one launch per environment step, timed in the same process on the same agents: what the
         # scripted rollout saves is launch boundaries, nothing else (the two walks are bitwise equal)
         sgraphs = [IterationGraph(a, d, s) for a, d, s in zip(agents, datas, streams)]
@@ -616,6 +618,30 @@ def main():
                                       "steps": k2, "note": "one launch per environment step inside the iteration graphs "
                                       "(--rollout stepwise): what an environment that lives on the host or on another node forces; the N>1 layouts of this bench "
                                               "hand actions over in-kernel and launch a rollout once, like the default"}
+    if mode == "graph" and world == 1 and args.agents_per_gpu != 1 and args.rollout in ("scripted", "stepwise") and not args.headline_only:
+        # north_star's literal layout -- ONE learner per GPU ("8 agents on 8 GPUs") -- on this GPU: the N = 1 base a scaling curve of
+        # `--agents-per-gpu 1` runs is measured against.  Nothing overlaps the learner's reduce / Adam then, so each minibatch's
+        # reduce + clip + Adam runs as one launch (ppo_step_kernel) between two gradient launches.
+        try:
+            one_args = argparse.Namespace(**{**vars(args), "agents_per_gpu": 1})
+            a1, d1 = build_agents(one_args, device)
+            s1 = th.cuda.Stream(device=device)
+            g1 = IterationGraph(a1[0], d1[0], s1, scripted=args.rollout == "scripted")
+            for _ in range(2):
+                g1.launch()
+            barrier()
+            k1 = max(1, min(args.steps, 20))
+            t1 = time.perf_counter()
+            for _ in range(k1):
+                g1.launch()
+            barrier()
+            dt1 = time.perf_counter() - t1
+            result["one_agent_per_gpu"] = {"value": args.n_envs * args.n_steps * k1 / dt1, "unit": "agent-steps/s",
+                                           "ms_per_step": 1e3 * dt1 / k1, "steps": k1,
+                                           "note": "python bench.py --agents-per-gpu 1: one learner alone on the device (exclusive "
+                                                   "hint: reduce + clip + Adam of a minibatch as one launch)"}
+        except Exception as exc:  # noqa: BLE001 -- an extra figure, never fatal
+            result["one_agent_per_gpu"] = {"error": str(exc)}
     if rank == 0:
         if not args.no_roofline:
             result["roofline"] = roofline(args, agents[0])

@@ -616,8 +616,11 @@ int ph_adap_minibatch_grad(ph_ctx *ctx, const ph_spec *spec, const float *params
                            float *stats_out, int gemm_mode, const ph_adap_loss *adap /* host */);
 
 /* Measurement hook for bench.py's roofline: enqueue ONLY the ppo_grad kernel (the dominant kernel of PPO.train) `reps`
- * times for the first minibatch (size min(batch_size, T*E), in-kernel permutation) between two HIP events on the ctx
- * stream; *avg_ms_out = mean launch duration.  Optimizer state is not touched.  Synchronises. */
+ * times between two HIP events on the ctx stream; *avg_ms_out = mean launch duration.  Launch i takes minibatch
+ * i mod ceil(T*E / batch) of one in-kernel permutation of the buffer (size min(batch_size, T*E)), as the launches of an epoch do:
+ * consecutive launches read DIFFERENT rows, so the figure does not flatter the kernel with rows the previous launch left in
+ * the L2 (with PH_BENCH_GRAD_SAME_ROWS=1 every launch repeats the first minibatch -- the round-1..3 behaviour).
+ * Optimizer state is not touched.  Synchronises. */
 int ph_bench_ppo_grad(ph_ctx *ctx, const ph_spec *spec, const float *params, const ph_rollout *rb,
                       const ph_ppo_hyper *hyper /* host */, int batch_size, int reps, int gemm_mode,
                       float *avg_ms_out /* host */);

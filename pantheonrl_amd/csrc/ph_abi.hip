@@ -64,6 +64,18 @@ struct ph_ctx {
   size_t perm_idx_cap = 0;
   int* perm_phys = nullptr;  // the same order as physical buffer rows (t * E + e)
   size_t perm_phys_cap = 0;
+  // the split gradient kernel's pack of the current train() call (ph_split.h): observation rows as bf16 planes, per-row scalars
+  // of either net in minibatch order
+  uint4* ximg = nullptr;     // [rows + 1][24]
+  size_t ximg_cap = 0;       // in uint4
+  uint4* rec_pi = nullptr;   // (n_epochs, N)
+  uint4* rec_vf = nullptr;
+  size_t rec_cap = 0;        // elements of each
+  // the fused reduce + clip + Adam launch of an exclusive learner (ppo_step_kernel): one stamped word per block (+ 1), the
+  // launch generation, the count of sweeps that timed out
+  unsigned long long* step_words = nullptr;
+  size_t step_words_cap = 0;
+  unsigned int* step_gen = nullptr;   // [2]: generation, sweep errors
   float* adap_extra = nullptr;   // [workgroups][policy-side parameters] gradient slabs of ADAP's context term
   size_t adap_extra_cap = 0;
   float* adap_loss = nullptr;    // [workgroups] partial sums of the raw term
@@ -308,7 +320,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (s.wimage_map) (void)hipFree(s.wimage_map);
     if (s.act_off) (void)hipFree(s.act_off);
   }
-  void* ptrs[] = {ctx->wimage, ctx->mw.act, ctx->mw.maps, ctx->mw.kl_sum, ctx->mw.scratch, ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->perm_phys, ctx->scalars, ctx->stop_flag,
+  void* ptrs[] = {ctx->wimage, ctx->mw.act, ctx->mw.maps, ctx->mw.kl_sum, ctx->mw.scratch, ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->perm_phys, ctx->ximg, ctx->rec_pi, ctx->rec_vf, ctx->step_words, ctx->step_gen, ctx->scalars, ctx->stop_flag,
                   ctx->adap_extra, ctx->adap_loss};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1443,6 +1455,10 @@ void fill_grad_args(ph::GradArgs& g, const ph::NetDims& nd, const float* params,
   g.stop_flag = ctx->stop_flag;
   g.prof = ctx->prof;
   g.wimage = ctx->wimage;
+  g.ximg = ctx->ximg;
+  g.ximg_zero_row = rb->T * rb->E;
+  g.rec_pi = ctx->rec_pi;   // callers offset these to the minibatch
+  g.rec_vf = ctx->rec_vf;
 }
 
 // the split kernel's weight fragment image of `params`, rebuilt from scratch (entries no parameter backs are zero): at the start
@@ -1458,6 +1474,37 @@ int rebuild_weight_image(ph_ctx* ctx, const ph::NetDims& nd, const float* params
   return 0;
 }
 
+// The split kernel's gradient pack: workspace for `n_rec` row records per net and the plane image of the buffer's rows, and the
+// image itself (obs_planes_kernel) -- built at the start of every train() / gradient call from the observations as they are
+// then.  The row records are written by the advantage-statistics launch that follows (fill_adv_records).
+int build_grad_pack(ph_ctx* ctx, const ph::NetDims& nd, const ph_rollout* rb, size_t n_rec) {
+  if (!nd.split) return 0;
+  const size_t rows = (size_t)rb->T * rb->E;
+  const size_t need_img = (rows + 1) * ph::XIMG_ROW_U4;
+  if (ctx->capturing) {
+    if (need_img > ctx->ximg_cap || n_rec > ctx->rec_cap)
+      return fail("workspace would grow inside graph capture: run the same call once outside capture first");
+  } else {
+    if (ensure(ctx->ximg, ctx->ximg_cap, need_img)) return 1;
+    if (n_rec > ctx->rec_cap) {
+      size_t c1 = ctx->rec_cap, c2 = ctx->rec_cap;
+      if (ensure(ctx->rec_pi, c1, n_rec)) return 1;
+      if (ensure(ctx->rec_vf, c2, n_rec)) return 1;
+      ctx->rec_cap = n_rec;
+    }
+  }
+  PH_HIP(ph::launch_obs_planes(rb->observations, (int)rows, nd.D, nd.F, ph::grad_fast_fold(nd) ? 1 : 0, ctx->ximg, ctx->stream));
+  return 0;
+}
+void fill_adv_records(ph::AdvStatArgs& aa, const ph_ctx* ctx, const ph::NetDims& nd, const ph_rollout* rb) {
+  aa.rec_pi_out = nd.split ? ctx->rec_pi : nullptr;
+  aa.rec_vf_out = nd.split ? ctx->rec_vf : nullptr;
+  aa.rb_logp = rb->log_probs;
+  aa.rb_act = rb->actions;
+  aa.rb_ret = rb->returns;
+  aa.rb_val = rb->values;
+}
+
 // gemm_mode 2 (products as six bf16 MFMA terms over three-plane operands, float32 accuracy) applies to the gradient launches
 // of specs ppo_grad_split_kernel takes; everywhere else it means 0.  The split kernel's slabs have their own order.
 void select_gemm(ph::NetDims& nd, int gemm_mode) {
@@ -1471,7 +1518,7 @@ int slab_len_of(const ph::NetDims& nd) { return nd.slab_map ? 2 * ph::RS_NET : n
 int ensure_train_ws(ph_ctx* ctx, int P, int slab_len, int nwg_max, int n_mb_total, size_t n_idx = 0, size_t n_phys = 0) {
   if (ctx->capturing) {
     if ((size_t)nwg_max * slab_len > ctx->slabs_cap || (size_t)n_mb_total * 2 > ctx->advstats_cap || n_idx > ctx->perm_idx_cap ||
-        n_phys > ctx->perm_phys_cap)
+        n_phys > ctx->perm_phys_cap || (size_t)ph::reduce_blocks(slab_len) + 1 > ctx->step_words_cap || !ctx->step_gen)
       return fail("workspace would grow inside graph capture: run the same call once outside capture first");
     return 0;
   }
@@ -1483,7 +1530,27 @@ int ensure_train_ws(ph_ctx* ctx, int P, int slab_len, int nwg_max, int n_mb_tota
   if (ensure(ctx->advstats, ctx->advstats_cap, (size_t)n_mb_total * 2)) return 1;
   if (ensure(ctx->advpart, ctx->advpart_cap, (size_t)n_mb_total * 2 * ph::ADV_SPLIT)) return 1;
   if (n_idx && ensure(ctx->perm_idx, ctx->perm_idx_cap, n_idx)) return 1;
+  const size_t n_words = (size_t)ph::reduce_blocks(slab_len) + 1;
+  if (n_words > ctx->step_words_cap) {
+    if (ensure(ctx->step_words, ctx->step_words_cap, n_words)) return 1;
+    PH_HIP(hipMemsetAsync(ctx->step_words, 0, n_words * sizeof(unsigned long long), ctx->stream));
+  }
+  if (!ctx->step_gen) {
+    PH_HIP(hipMalloc((void**)&ctx->step_gen, 2 * sizeof(unsigned int)));
+    PH_HIP(hipMemsetAsync(ctx->step_gen, 0, 2 * sizeof(unsigned int), ctx->stream));
+  }
   return 0;
+}
+
+// reduce + clip + Adam of an exclusive learner's minibatch as ONE launch?  (PH_STEP_FUSED=0 keeps the two launches)
+bool step_fused_wanted(const ph_ctx* ctx, int slab_len, bool alone) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("PH_STEP_FUSED");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  return enabled && alone && ctx->exclusive && ctx->step_words && ctx->step_gen &&
+         ph::step_fused_fits(ph::reduce_blocks(slab_len), 0, ctx->num_cu);
 }
 
 }  // namespace
@@ -1608,6 +1675,7 @@ int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_s
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
   if (rebuild_weight_image(ctx, t.nd, opt->params)) return 1;
+  if (build_grad_pack(ctx, t.nd, rb, (size_t)n_epochs * t.N)) return 1;
   t.hb = ph::feistel_half_bits((uint32_t)t.N);
   ph::AdvStatArgs aa;
   aa.rb_adv = rb->advantages;
@@ -1625,6 +1693,7 @@ int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_s
   aa.partial = ctx->advpart;
   aa.idx_out = perms ? nullptr : ctx->perm_idx;
   aa.phys_out = ctx->perm_phys;      // the order once more as physical rows: the tile walk then has no index arithmetic
+  fill_adv_records(aa, ctx, t.nd, rb);
   PH_HIP(ph::launch_adv_stats(aa, n_epochs * t.n_mb, s));
   return 0;
 }
@@ -1641,6 +1710,10 @@ int train_launch_grad(const TrainPlan& t, int mbi, MbPlan* pl_out) {
   fill_grad_args(g, t.nd, t.opt->params, t.rb, t.hp, ctx);
   g.idx = (t.perms ? t.perms : ctx->perm_idx) + (size_t)ep * t.N + start;
   g.idx_phys = ctx->perm_phys + (size_t)ep * t.N + start;
+  if (t.nd.split) {
+    g.rec_pi = ctx->rec_pi + (size_t)ep * t.N + start;
+    g.rec_vf = ctx->rec_vf + (size_t)ep * t.N + start;
+  }
   g.perm_n = (uint32_t)t.N;
   g.perm_hb = t.hb;
   g.perm_seed = t.perm_seed;
@@ -1683,7 +1756,9 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
     const int* idx = (t.perms ? t.perms : ctx->perm_idx) + (size_t)ep * t.N + start;
     if (adap_launch(ctx, t.nd, t.opt->params, t.rb, t.adap, idx, pl.nb, mbi, &r)) return 1;
   }
-  PH_HIP(ph::launch_ppo_reduce(r, s));
+  const bool fused = step_fused_wanted(ctx, slab_len_of(t.nd), t.alone != 0);
+  if (fused) r.wide = 0;   // 256-lane blocks: eight per CU are resident, so the whole grid is (1024-lane blocks: two per CU -- the grid would not fit with a margin)
+  if (!fused) PH_HIP(ph::launch_ppo_reduce(r, s));
 
   ph::AdamArgs ad;
   ad.params = t.opt->params;
@@ -1704,7 +1779,12 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
   ad.stats_out = r.stats_out;
   ad.wimage = t.nd.split ? ctx->wimage : nullptr;
   ad.wimage_map = t.nd.wimage_map;
-  PH_HIP(ph::launch_ppo_adam(ad, s));
+  if (fused) {
+    // ~2 s of wall_clock64 ticks (100 MHz): a bound for a block that cannot be scheduled, far above any healthy sweep
+    PH_HIP(ph::launch_ppo_step(r, ad, ctx->step_words, ctx->step_gen, ctx->step_gen + 1, 200000000ull, s));
+  } else {
+    PH_HIP(ph::launch_ppo_adam(ad, s));
+  }
   return 0;
 }
 
@@ -1817,6 +1897,7 @@ int minibatch_grad_run(ph_ctx* ctx, const ph_spec* spec, const float* params, co
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
   if (rebuild_weight_image(ctx, nd, params)) return 1;
+  if (build_grad_pack(ctx, nd, rb, (size_t)nb)) return 1;
   ph::AdvStatArgs aa;
   aa.rb_adv = rb->advantages;
   aa.T = rb->T;
@@ -1833,6 +1914,7 @@ int minibatch_grad_run(ph_ctx* ctx, const ph_spec* spec, const float* params, co
   aa.partial = ctx->advpart;
   aa.idx_out = nullptr;
   aa.phys_out = ctx->perm_phys;
+  fill_adv_records(aa, ctx, nd, rb);
   PH_HIP(ph::launch_adv_stats(aa, 1, s));
   ph::GradArgs g;
   std::memset(&g, 0, sizeof(g));
@@ -1882,10 +1964,13 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   const int N = rb->T * rb->E;
   const int nb = batch_size < N ? batch_size : N;
   const MbPlan pl = plan_minibatch(ctx, nd, nb);
-  if (ensure_train_ws(ctx, nd.lay.P, slab_len_of(nd), pl.nwg, 1, (size_t)N, (size_t)N)) return 1;
+  const char* same_env = getenv("PH_BENCH_GRAD_SAME_ROWS");
+  const int n_mb = (same_env && same_env[0] == '1') ? 1 : N / nb;   // whole minibatches of one epoch's order
+  if (ensure_train_ws(ctx, nd.lay.P, slab_len_of(nd), pl.nwg, n_mb, (size_t)N, (size_t)N)) return 1;
   hipStream_t s = ctx->stream;
   PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
   if (rebuild_weight_image(ctx, nd, params)) return 1;
+  if (build_grad_pack(ctx, nd, rb, (size_t)N)) return 1;
   ph::AdvStatArgs aa;
   aa.rb_adv = rb->advantages;
   aa.T = rb->T;
@@ -1897,26 +1982,34 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   aa.epoch = nullptr;
   aa.N = N;
   aa.batch = nb;
-  aa.n_mb = 1;
+  aa.n_mb = n_mb;
   aa.out = ctx->advstats;
   aa.partial = ctx->advpart;
   aa.idx_out = ctx->perm_idx;   // as in ph_ppo_train: the grad launches read the materialised order
   aa.phys_out = ctx->perm_phys;
-  PH_HIP(ph::launch_adv_stats(aa, 1, s));
+  fill_adv_records(aa, ctx, nd, rb);
+  PH_HIP(ph::launch_adv_stats(aa, n_mb, s));
   ph::GradArgs g;
   std::memset(&g, 0, sizeof(g));
   fill_grad_args(g, nd, params, rb, hp, ctx);
-  g.idx = ctx->perm_idx;
-  g.idx_phys = ctx->perm_phys;
   g.perm_n = aa.perm_n;
   g.perm_hb = aa.perm_hb;
   g.perm_seed = aa.perm_seed;
   g.nb = nb;
-  g.advstats = ctx->advstats;
   g.ntiles = pl.ntiles;
-  PH_HIP(ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s));  // warm
+  auto launch = [&](int i) -> hipError_t {
+    const size_t start = (size_t)(i % n_mb) * nb;
+    g.idx = ctx->perm_idx + start;
+    g.idx_phys = ctx->perm_phys + start;
+    g.mb_start = (int)start;
+    g.rec_pi = ctx->rec_pi ? ctx->rec_pi + start : nullptr;
+    g.rec_vf = ctx->rec_vf ? ctx->rec_vf + start : nullptr;
+    g.advstats = ctx->advstats + 2 * (size_t)(i % n_mb);
+    return ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s);
+  };
+  for (int i = 0; i < n_mb; ++i) PH_HIP(launch(i));  // warm
   PH_HIP(hipEventRecord(ctx->ev0, s));
-  for (int i = 0; i < reps; ++i) PH_HIP(ph::launch_ppo_grad(g, pl.nwg, gemm_mode, s));
+  for (int i = 0; i < reps; ++i) PH_HIP(launch(i));
   PH_HIP(hipEventRecord(ctx->ev1, s));
   PH_HIP(hipEventSynchronize(ctx->ev1));
   float ms = 0.f;

@@ -144,6 +144,12 @@ struct GradArgs {
   long long* prof;         // debug: per-workgroup phase timestamps (clock64), or null
   int ntiles;
   const unsigned short* wimage;   // split kernel: the pre-split weight fragment image of `params` (ph_split.h)
+  // split kernel: the gradient pack of this train() call (ph_split.h) -- the observation rows as bf16 planes, split ONCE per
+  // call (they do not change across its epochs), and the per-row scalars of each net packed in minibatch order
+  const uint4* ximg;       // [N + 1][3 planes][64] bf16 = 24 granules of 16 bytes per buffer row; row N is all zero (dead rows of a partial tile)
+  int ximg_zero_row;       // N
+  const uint4* rec_pi;     // this minibatch: {physical row, advantage, old log-prob, action} per position
+  const uint4* rec_vf;     // this minibatch: {physical row, return, old value, -}
 };
 
 __device__ __host__ inline uint64_t epoch_key(uint64_t seed, int epoch) {
@@ -183,6 +189,10 @@ struct AdvStatArgs {
   double* partial;     // [n_epochs*n_mb][ADV_SPLIT][2] per-segment (sum, sum of squares)
   int* idx_out;        // (n_epochs, N) or null: the env-major index of every element, materialised for the grad launches
   int* phys_out;       // (n_epochs, N) or null: the physical buffer row of every element (t * E + e)
+  // the split gradient kernel's row records in minibatch order (GradArgs.rec_pi / rec_vf), or null
+  uint4* rec_pi_out = nullptr;   // (n_epochs, N) {phys, advantage, old log-prob, action}
+  uint4* rec_vf_out = nullptr;   // (n_epochs, N) {phys, return, old value, 0}
+  const float *rb_logp = nullptr, *rb_act = nullptr, *rb_ret = nullptr, *rb_val = nullptr;   // read only when the records are written (action length 1)
 };
 
 struct ReduceArgs {
@@ -374,8 +384,17 @@ hipError_t launch_weight_image_check(const float* params, const unsigned short* 
 void grad_slab_map_split(const ph_layout& lay, int* map /* host, 2 * RS_NET */, bool fold);
 hipError_t launch_ppo_grad_split(const GradArgs& a, int nwg, hipStream_t s);
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);
+// observation rows (n, D) f32 -> the split kernel's plane image [n + 1][3][64] bf16 (features >= F zero; with `fold` feature 63 is
+// 1: the first layer's bias rides as a feature; row n all zero)
+constexpr int XIMG_ROW_U4 = 24;   // uint4 granules per image row: 3 planes x 8
+hipError_t launch_obs_planes(const float* obs, int n, int D, int F, int fold, uint4* image, hipStream_t s);
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s);
 int reduce_blocks(int slab_len);
+// reduce + clip + Adam as one launch (ppo_step_kernel): `words` [reduce_blocks + 1] and `gen` are workspace that persists across
+// launches (zeroed once); step_fused_fits says whether every block of the grid is resident at once on the current device
+bool step_fused_fits(int nblk, int wide, int num_cu);
+hipError_t launch_ppo_step(const ReduceArgs& r, const AdamArgs& ad, unsigned long long* words, unsigned int* gen,
+                           unsigned int* sweep_error, unsigned long long timeout, hipStream_t st);
 hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_set_int(int* p, int v, hipStream_t s);
 // behavioural cloning on the shared 32-32 policy (ph_bc.hip)

@@ -850,7 +850,13 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
     }
     const int phys = env_major_to_phys(n, a.T, a.E);
     if (a.phys_out) a.phys_out[(size_t)ep * a.N + start + i] = phys;
-    return (double)a.rb_adv[phys];
+    const float adv = a.rb_adv[phys];
+    if (a.rec_pi_out) {   // the five per-row scalars of the gradient launches, gathered once per train() instead of once per launch
+      const size_t o = (size_t)ep * a.N + start + i;
+      a.rec_pi_out[o] = make_uint4((unsigned)phys, __float_as_uint(adv), __float_as_uint(a.rb_logp[phys]), __float_as_uint(a.rb_act[phys]));
+      a.rec_vf_out[o] = make_uint4((unsigned)phys, __float_as_uint(a.rb_ret[phys]), __float_as_uint(a.rb_val[phys]), 0u);
+    }
+    return (double)adv;
   };
   // one pass: sum and sum of squares in fp64 (exact products of f32 values), 4 independent gathers per round
   double s = 0.0, q = 0.0;
@@ -902,6 +908,49 @@ hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- observation rows -> bf16 planes (ph_split.h), once per train() ----------------------------------------------------------
+// A workgroup takes 32 rows: their 32 D floats are contiguous in the buffer and come in as one coalesced stream into LDS
+// ([row][65]: odd stride, the 8-float reads below are conflict-free), then one lane per (row, 8-feature granule) splits eight
+// features and stores three 16-byte plane granules (8 lanes = one 128-byte plane row).  Reads 4 D and writes 384 bytes per row:
+// HBM-bound.
+constexpr int OP_ROWS = 32;
+__global__ __launch_bounds__(256) void obs_planes_kernel(const float* __restrict__ obs, int n, int D, int F, int fold,
+                                                         uint4* __restrict__ image) {
+  __shared__ float xs[OP_ROWS][65];
+  const int tid = threadIdx.x;
+  const size_t row0 = (size_t)blockIdx.x * OP_ROWS;
+  const int nrow = (row0 + OP_ROWS <= (size_t)n) ? OP_ROWS : (int)((size_t)n > row0 ? (size_t)n - row0 : 0);
+  const float* src = obs + row0 * D;
+  for (int e = tid; e < nrow * D; e += 256) {
+    const int r = e / D, f = e - r * D;
+    if (f < F) xs[r][f] = __builtin_nontemporal_load(src + e);
+  }
+  __syncthreads();
+  const int r = tid >> 3, g = tid & 7;
+  const size_t row = row0 + r;
+  if (row > (size_t)n) return;
+  typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+  bf8 pl[3];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int f = 8 * g + e;
+    float x = 0.f;
+    if (row < (size_t)n) x = f < F ? xs[r][f] : ((fold && f == HID - 1) ? 1.f : 0.f);
+    __bf16 h, m, l;
+    split1(x, h, m, l);
+    pl[0][e] = h;
+    pl[1][e] = m;
+    pl[2][e] = l;
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) image[row * XIMG_ROW_U4 + p * 8 + g] = __builtin_bit_cast(uint4, pl[p]);
+}
+hipError_t launch_obs_planes(const float* obs, int n, int D, int F, int fold, uint4* image, hipStream_t s) {
+  const size_t blocks = ((size_t)n + 1 + OP_ROWS - 1) / OP_ROWS;   // rows 0 .. n (row n = the zero row)
+  hipLaunchKernelGGL(obs_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, obs, n, D, F, fold, image);
+  return hipGetLastError();
+}
+
 // ---- slab reduction: grad[p] = sum_g slab[g][p] (fixed order), per-block sum of squares, minibatch statistics ----
 // grad[p] = sum_g slab[g][p] in a fixed order, per-block sum of squares, minibatch statistics, KL decision.
 // Every lane sums its group's slabs with 8 loads in flight, the group sums are folded through LDS in a fixed order; the
@@ -918,20 +967,46 @@ hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s) {
 //               (ph_ppo_train, one agent per GPU), where the reduce sits on the critical path between two gradient launches.
 // Both give bitwise the same gradient (same tree), so ph_ppo_train and ph_ppo_train_multi keep producing identical results.
 constexpr int RED_PARAMS = 64, RED_SUB = 16, RED_SHIFT = 6;
+
+// clip_grad_norm_'s scaling and torch.optim.Adam's single-tensor update of ONE parameter (eps = 1e-5 default of SB3).  One
+// definition for ppo_adam_kernel and the fused ppo_step_kernel, with floating-point contraction OFF: which multiply-add pairs
+// the compiler fuses otherwise depends on the surrounding kernel, and the two paths must give bitwise the same parameters.
+struct AdamScalars {
+  float coef, ss, bc2s;   // clip coefficient, lr / (1 - beta1^t), sqrt(1 - beta2^t)
+};
+__device__ __forceinline__ AdamScalars adam_scalars(float total_norm, float max_norm, int step, float lr, float beta1, float beta2) {
+  AdamScalars k;
+  const float cc = max_norm / (total_norm + 1e-6f);  // torch.nn.utils.clip_grad_norm_
+  k.coef = cc < 1.0f ? cc : 1.0f;
+  const double t = (double)step;
+  const double bc1 = 1.0 - pow((double)beta1, t);
+  const double bc2 = 1.0 - pow((double)beta2, t);
+  k.ss = (float)((double)lr / bc1);
+  k.bc2s = (float)sqrt(bc2);
+  return k;
+}
+__device__ __forceinline__ float adam_update(float grad, const AdamScalars& k, float beta1, float beta2, float eps, float* m_p,
+                                             float* v_p, float* param_p) {
+#pragma clang fp contract(off)
+  const float g = grad * k.coef;
+  const float m0 = *m_p, v0 = *v_p;
+  const float d = g - m0;
+  const float m = m0 + d * (1.0f - beta1);                 // exp_avg.lerp_(grad, 1-beta1)
+  const float gg = g * g;
+  const float v = v0 * beta2 + (1.0f - beta2) * gg;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+  const float denom = sqrtf(v) / k.bc2s + eps;
+  *m_p = m;
+  *v_p = v;
+  const float step = k.ss * (m / denom);
+  const float pn = *param_p - step;                        // param.addcdiv_(exp_avg, denom, -step_size)
+  *param_p = pn;
+  return pn;
+}
+// the slab sum of this block's 64 positions in the fixed tree: lane tid < 64 returns the gradient entry of position
+// blockIdx.x * 64 + tid (0 for padding) and the parameter it belongs to (dst, -1 = padding); other lanes return 0 / -1
 template <int GROUPS>
-__global__ __launch_bounds__(RED_PARAMS * GROUPS) void ppo_reduce_kernel(ReduceArgs a) {
-  __shared__ float gsum[GROUPS][RED_PARAMS];
-  __shared__ float part[32][NSTATP];
-  __shared__ float means[NSTATP];
+__device__ __forceinline__ float reduce_positions(const ReduceArgs& a, float (*gsum)[RED_PARAMS], int* dst_out) {
   const int tid = threadIdx.x;
-  if (*a.stop_flag != 0) {  // a previous minibatch of this train() call hit the KL early stop
-    if (blockIdx.x == 0 && tid < PH_NSTAT && a.stats_out) a.stats_out[tid] = 0.f;
-    if (blockIdx.x == 0 && tid == 0) {
-      a.scalars[1] = 0.f;
-      a.scalars[2] = 0.f;
-    }
-    return;
-  }
   // grp is wave-uniform (64 lanes = 64 parameters per group): as a scalar, the slab offsets are SALU work and the loads take an
   // SGPR base + one 32-bit lane offset -- no 64-bit address per load in flight
   const int pl = tid & (RED_PARAMS - 1), grp = __builtin_amdgcn_readfirstlane(tid >> RED_SHIFT);
@@ -968,77 +1043,248 @@ __global__ __launch_bounds__(RED_PARAMS * GROUPS) void ppo_reduce_kernel(ReduceA
     gsum[grp][pl] = quarter;   // GROUPS = 4: A_grp; GROUPS = 16: one range sum
   }
   __syncthreads();
-  if (tid < 64) {  // wave 0: fold the group sums, square, wave-reduce
-    float g = 0.f;
-    if (tid < RED_PARAMS) {
-      if constexpr (GROUPS == 4) {
-        g = (gsum[0][tid] + gsum[1][tid]) + (gsum[2][tid] + gsum[3][tid]);
-      } else {
-        float q4[4];
+  float g = 0.f;
+  int dst = -1;
+  if (tid < RED_PARAMS) {  // wave 0: fold the group sums
+    if constexpr (GROUPS == 4) {
+      g = (gsum[0][tid] + gsum[1][tid]) + (gsum[2][tid] + gsum[3][tid]);
+    } else {
+      float q4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q4[j] = ((gsum[4 * j][tid] + gsum[4 * j + 1][tid]) + gsum[4 * j + 2][tid]) + gsum[4 * j + 3][tid];
-        g = (q4[0] + q4[1]) + (q4[2] + q4[3]);
-      }
-      // canonical slabs: position = parameter index; register-order slabs (ppo_grad_fast_kernel): through the table
-      const int dst = p < a.slab_len ? (a.map ? a.map[p] : p) : -1;
-      if (dst >= 0) {
-        if (a.n_extra > 0) {   // the additional term's slabs, fixed order
-          const int e = dst < a.extra_cut ? dst : ((dst >= a.extra_lo && dst < a.extra_hi) ? a.extra_cut + (dst - a.extra_lo) : -1);
-          if (e >= 0)
-            for (int k = 0; k < a.n_extra; ++k) g += a.extra[(size_t)k * a.extra_len + e];
-        }
-        a.grad[dst] = g;
-      } else {
-        g = 0.f;
-      }
+      for (int j = 0; j < 4; ++j) q4[j] = ((gsum[4 * j][tid] + gsum[4 * j + 1][tid]) + gsum[4 * j + 2][tid]) + gsum[4 * j + 3][tid];
+      g = (q4[0] + q4[1]) + (q4[2] + q4[3]);
     }
+    // canonical slabs: position = parameter index; register-order slabs (ppo_grad_fast_kernel): through the table
+    dst = p < a.slab_len ? (a.map ? a.map[p] : p) : -1;
+    if (dst >= 0) {
+      if (a.n_extra > 0) {   // the additional term's slabs, fixed order
+        const int e = dst < a.extra_cut ? dst : ((dst >= a.extra_lo && dst < a.extra_hi) ? a.extra_cut + (dst - a.extra_lo) : -1);
+        if (e >= 0)
+          for (int k = 0; k < a.n_extra; ++k) g += a.extra[(size_t)k * a.extra_len + e];
+      }
+    } else {
+      g = 0.f;
+    }
+  }
+  *dst_out = dst;
+  return g;
+}
+// minibatch statistics (means over the nb rows) and the KL decision, by one block (>= 256 threads); thread 0 returns `stop`
+__device__ __forceinline__ bool reduce_statistics(const ReduceArgs& a, float (*part)[NSTATP], float* means, bool bump_step) {
+  const int tid = threadIdx.x;
+  bool stop = false;
+  if (tid < 256) {  // 32 lanes per statistic, strided over the workgroup partials, then a fixed-order fold
+    const int kst = tid & (NSTATP - 1), j = tid >> 3;
+    float v = 0.f;
+    for (int w = j; w < a.nstatpart; w += 32) v += a.statpart[(size_t)w * NSTATP + kst];
+    part[j][kst] = v;
+  }
+  __syncthreads();
+  if (tid < NSTATP) {
+    float v = 0.f;
+    for (int j = 0; j < 32; ++j) v += part[j][tid];
+    means[tid] = v / (float)a.nb;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float pl_ = means[0], vl = means[1], el = means[2], cf = means[3], kl = means[4];
+    stop = (a.target_kl >= 0.f) && (kl > 1.5f * a.target_kl);
+    if (bump_step && !stop && a.step) *a.step += 1;
+    a.scalars[0] = kl;
+    a.scalars[1] = stop ? 0.f : 1.f;
+    a.scalars[2] = stop ? 1.f : 0.f;  // ppo_adam_kernel raises stop_flag (next launch), never mid-kernel
+    if (a.stats_out) {
+      a.stats_out[0] = pl_;
+      a.stats_out[1] = vl;
+      a.stats_out[2] = el;
+      a.stats_out[3] = cf;
+      a.stats_out[4] = kl;
+      a.stats_out[5] = pl_ + a.ent_coef * el + a.vf_coef * vl;
+      a.stats_out[6] = 0.f;
+      a.stats_out[7] = stop ? 0.f : 1.f;
+    }
+    if (a.n_extra > 0) {   // raw additional term of this minibatch (adap_learn.py:313-320: loss += coeff * context_loss)
+      float raw = 0.f;
+      for (int k = 0; k < a.n_extra; ++k) raw += a.extra_loss[k];
+      raw *= a.extra_norm;
+      if (a.extra_loss_out) *a.extra_loss_out = raw;
+      if (a.stats_out) a.stats_out[5] += a.extra_coef * raw;
+    }
+  }
+  return stop;
+}
+
+template <int GROUPS>
+__global__ __launch_bounds__(RED_PARAMS * GROUPS) void ppo_reduce_kernel(ReduceArgs a) {
+  __shared__ float gsum[GROUPS][RED_PARAMS];
+  __shared__ float part[32][NSTATP];
+  __shared__ float means[NSTATP];
+  const int tid = threadIdx.x;
+  if (*a.stop_flag != 0) {  // a previous minibatch of this train() call hit the KL early stop
+    if (blockIdx.x == 0 && tid < PH_NSTAT && a.stats_out) a.stats_out[tid] = 0.f;
+    if (blockIdx.x == 0 && tid == 0) {
+      a.scalars[1] = 0.f;
+      a.scalars[2] = 0.f;
+    }
+    return;
+  }
+  int dst;
+  const float g = reduce_positions<GROUPS>(a, gsum, &dst);
+  if (tid < 64) {  // wave 0: store, square, wave-reduce
+    if (dst >= 0) a.grad[dst] = g;
     float q = g * g;
     for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
     if (tid == 0) a.blocksq[blockIdx.x] = q;
   }
-
-  if (blockIdx.x == 0) {  // minibatch statistics: means over the nb rows (block-uniform branch)
-    if (tid < 256) {  // 32 lanes per statistic, strided over the workgroup partials, then a fixed-order fold
-      const int kst = tid & (NSTATP - 1), j = tid >> 3;
-      float v = 0.f;
-      for (int w = j; w < a.nstatpart; w += 32) v += a.statpart[(size_t)w * NSTATP + kst];
-      part[j][kst] = v;
-    }
-    __syncthreads();
-    if (tid < NSTATP) {
-      float v = 0.f;
-      for (int j = 0; j < 32; ++j) v += part[j][tid];
-      means[tid] = v / (float)a.nb;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      const float pl_ = means[0], vl = means[1], el = means[2], cf = means[3], kl = means[4];
-      const bool stop = (a.target_kl >= 0.f) && (kl > 1.5f * a.target_kl);
-      if (!stop && a.step) *a.step += 1;
-      a.scalars[0] = kl;
-      a.scalars[1] = stop ? 0.f : 1.f;
-      a.scalars[2] = stop ? 1.f : 0.f;  // ppo_adam_kernel raises stop_flag (next launch), never mid-kernel
-      if (a.stats_out) {
-        a.stats_out[0] = pl_;
-        a.stats_out[1] = vl;
-        a.stats_out[2] = el;
-        a.stats_out[3] = cf;
-        a.stats_out[4] = kl;
-        a.stats_out[5] = pl_ + a.ent_coef * el + a.vf_coef * vl;
-        a.stats_out[6] = 0.f;
-        a.stats_out[7] = stop ? 0.f : 1.f;
-      }
-      if (a.n_extra > 0) {   // raw additional term of this minibatch (adap_learn.py:313-320: loss += coeff * context_loss)
-        float raw = 0.f;
-        for (int k = 0; k < a.n_extra; ++k) raw += a.extra_loss[k];
-        raw *= a.extra_norm;
-        if (a.extra_loss_out) *a.extra_loss_out = raw;
-        if (a.stats_out) a.stats_out[5] += a.extra_coef * raw;
-      }
-    }
-  }
+  if (blockIdx.x == 0) (void)reduce_statistics(a, part, means, true);  // block-uniform branch
 }
+
+// ---- reduce + clip + Adam as ONE launch (a learner that has the device to itself: the three launches of a minibatch step sit on
+// its critical path, and two of the three kernel boundaries plus the separate pass over the gradient go away) -----------------
+// Every block reduces its 64 slab positions (the tree above), publishes its sum of squares as ONE 8-byte word {tag, value}
+// (tag = launch generation + 1: a single-copy-atomic store, nothing else crosses blocks), sweeps all blocks' words until they carry
+// this launch's tag (all blocks are resident: the launcher checks the grid against the occupancy query), folds them in
+// ppo_adam_kernel's order -- so the fused and the two-launch path give bitwise the same parameters -- and applies clip + Adam to its
+// own 64 entries straight from registers.  Block 0 also does the minibatch statistics and the KL decision and carries `stop` in
+// a word of its own.  A sweep that does not complete within `timeout` ticks (never, unless a block cannot be scheduled) counts in
+// *sweep_error and skips the update instead of hanging the device.
+struct StepArgs {
+  ReduceArgs r;
+  AdamArgs ad;
+  unsigned long long* words;   // [gridDim.x + 1]
+  unsigned int* gen;           // launch generation (device word, advanced by block 0 at the end of every launch)
+  unsigned long long timeout;  // wall_clock64 ticks
+  unsigned int* sweep_error;
+};
+template <int GROUPS>
+__global__ __launch_bounds__(RED_PARAMS * GROUPS) void ppo_step_kernel(StepArgs s) {
+  __shared__ float gsum[GROUPS][RED_PARAMS];
+  __shared__ float part[32][NSTATP];
+  __shared__ float means[NSTATP];
+  const ReduceArgs& a = s.r;
+  const AdamArgs& ad = s.ad;
+  const int tid = threadIdx.x, nblk = gridDim.x;
+  if (*a.stop_flag != 0) {  // a previous minibatch of this train() call hit the KL early stop (stable for the whole launch)
+    if (blockIdx.x == 0 && tid < PH_NSTAT && a.stats_out) a.stats_out[tid] = 0.f;
+    if (blockIdx.x == 0 && tid == 0) {
+      a.scalars[1] = 0.f;
+      a.scalars[2] = 0.f;
+    }
+    return;
+  }
+  // read before anything of this launch is published: block 0 advances both only after every block has published
+  const unsigned tag = *s.gen + 1u;
+  const int step_new = *ad.step + 1;
+  int dst;
+  const float g = reduce_positions<GROUPS>(a, gsum, &dst);
+  if (tid < 64) {
+    float q = g * g;
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+    if (tid == 0)
+      __hip_atomic_store(s.words + blockIdx.x, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(q), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (blockIdx.x == 0) {
+    const bool stop = reduce_statistics(a, part, means, false);
+    if (tid == 0)
+      __hip_atomic_store(s.words + nblk, ((unsigned long long)tag << 32) | (stop ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid >= 64) return;   // (block 0's other waves are past their last barrier)
+  // Adam's bias corrections need the step count only: two double-precision pow() under the wait for the other blocks' words
+  AdamScalars k = adam_scalars(0.f, ad.max_norm, step_new, ad.lr, ad.beta1, ad.beta2);
+  // ---- wave 0: sweep the nblk + 1 words; lane l takes words l, l + 64, ... ----
+  constexpr int MAXW = 16;   // nblk + 1 <= 64 * MAXW (the launcher checks)
+  float qv[MAXW];
+  bool ok = false;
+  const long long t0 = wall_clock64();
+  while (true) {
+    bool all = true;
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) {
+      const int k = tid + 64 * i;
+      qv[i] = 0.f;
+      if (k <= nblk) {
+        const unsigned long long w = __hip_atomic_load(s.words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        all = all && ((unsigned)(w >> 32) == tag);
+        qv[i] = __uint_as_float((unsigned)w);
+      }
+    }
+    if (__all(all)) { ok = true; break; }
+    if ((unsigned long long)(wall_clock64() - t0) > s.timeout) break;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  if (!ok) {   // never on a healthy device; the parameters stay as they are
+    if (tid == 0) {
+      atomicAdd(s.sweep_error, 1u);
+      if (blockIdx.x == 0 && a.stats_out) a.stats_out[7] = -1.f;
+    }
+    return;
+  }
+  // the stop word sits at index nblk: lane nblk % 64, slot nblk / 64
+  int stop_i = 0;
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i)
+    if (tid + 64 * i == nblk) stop_i = __float_as_int(qv[i]) & 1;
+  const bool stop = __any(stop_i != 0);
+  // total = sum of the nblk squares in ppo_adam_kernel's order: its thread t (256 of them) adds entries t, t + 256, ...; each of its
+  // four waves folds by shuffles; (w0 + w1) + (w2 + w3).  Entry k lives in lane k % 64, slot k / 64: thread t = 64 v + lane of
+  // "virtual wave" v owns slots v, v + 4, v + 8, ...
+  float shv[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    float q = 0.f;
+#pragma unroll
+    for (int i = v; i < MAXW; i += 4)
+      if (tid + 64 * i < nblk) q += qv[i];
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+    shv[v] = __shfl(q, 0, 64);
+  }
+  const float total = sqrtf((shv[0] + shv[1]) + (shv[2] + shv[3]));
+  if (blockIdx.x == 0 && tid == 0) {   // every block has published, i.e. has read gen / step / stop_flag: now they may change
+    if (!stop && ad.step) *const_cast<int*>(ad.step) = step_new;
+    if (stop) *a.stop_flag = 1;
+    *s.gen = tag;
+    if (!stop && a.stats_out) a.stats_out[6] = total;
+  }
+  if (stop || dst < 0) return;
+  {
+    const float cc = ad.max_norm / (total + 1e-6f);  // torch.nn.utils.clip_grad_norm_ (as in adam_scalars)
+    k.coef = cc < 1.0f ? cc : 1.0f;
+  }
+  const int p = dst;
+  const float pn = adam_update(g, k, ad.beta1, ad.beta2, ad.eps, ad.m + p, ad.v + p, ad.params + p);
+  if (ad.wimage) wimage_put(ad.wimage, ad.wimage_map, p, pn);
+}
+
 int reduce_blocks(int slab_len) { return (slab_len + RED_PARAMS - 1) / RED_PARAMS; }
+// Can the fused step kernel run this grid with every block resident (its blocks wait for each other)?  The runtime's occupancy
+// answer for the kernel on the current device, one block per CU held back (the API can be one high: MI355X_MICROARCH.md).
+bool step_fused_fits(int nblk, int wide, int num_cu) {
+  if (nblk + 1 > 64 * 16) return false;
+  static int per_cu[2] = {-1, -1};
+  int& v = per_cu[wide ? 1 : 0];
+  if (v < 0) {
+    int api = 0;
+    hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, (const void*)ppo_step_kernel<16>, RED_PARAMS * 16, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, (const void*)ppo_step_kernel<4>, RED_PARAMS * 4, 0);
+    v = (e == hipSuccess && api > 1) ? api - 1 : 0;
+  }
+  return (long long)v * num_cu >= (long long)nblk;
+}
+hipError_t launch_ppo_step(const ReduceArgs& r, const AdamArgs& ad, unsigned long long* words, unsigned int* gen,
+                           unsigned int* sweep_error, unsigned long long timeout, hipStream_t st) {
+  StepArgs s;
+  s.r = r;
+  s.ad = ad;
+  s.words = words;
+  s.gen = gen;
+  s.timeout = timeout;
+  s.sweep_error = sweep_error;
+  const int nblk = reduce_blocks(r.slab_len);
+  if (r.wide) hipLaunchKernelGGL(ppo_step_kernel<16>, dim3(nblk), dim3(RED_PARAMS * 16), 0, st, s);
+  else hipLaunchKernelGGL(ppo_step_kernel<4>, dim3(nblk), dim3(RED_PARAMS * 4), 0, st, s);
+  return hipGetLastError();
+}
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s) {
   if (a.wide) hipLaunchKernelGGL(ppo_reduce_kernel<16>, dim3(reduce_blocks(a.slab_len)), dim3(RED_PARAMS * 16), 0, s, a);
   else hipLaunchKernelGGL(ppo_reduce_kernel<4>, dim3(reduce_blocks(a.slab_len)), dim3(RED_PARAMS * 4), 0, s, a);
@@ -1048,7 +1294,7 @@ hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s) {
 // ---- clip_grad_norm_ + Adam (torch.optim.Adam single-tensor maths, eps = 1e-5) ----------------------------------------
 __global__ __launch_bounds__(256) void ppo_adam_kernel(AdamArgs a) {
   __shared__ float sh[4];
-  __shared__ float coef_s, ss_s, bc2s_s;
+  __shared__ AdamScalars ks;
   const int tid = threadIdx.x;
   if (a.scalars[1] == 0.f) {  // KL early stop (or already stopped): no optimizer step
     if (blockIdx.x == 0 && tid == 0 && a.scalars[2] != 0.f) *a.stop_flag = 1;
@@ -1061,26 +1307,14 @@ __global__ __launch_bounds__(256) void ppo_adam_kernel(AdamArgs a) {
   __syncthreads();
   if (tid == 0) {
     const float total = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3]));
-    const float cc = a.max_norm / (total + 1e-6f);  // torch.nn.utils.clip_grad_norm_
-    coef_s = cc < 1.0f ? cc : 1.0f;
-    const double t = (double)*a.step;
-    const double bc1 = 1.0 - pow((double)a.beta1, t);
-    const double bc2 = 1.0 - pow((double)a.beta2, t);
-    ss_s = (float)((double)a.lr / bc1);
-    bc2s_s = (float)sqrt(bc2);
+    ks = adam_scalars(total, a.max_norm, *a.step, a.lr, a.beta1, a.beta2);
     if (blockIdx.x == 0 && a.stats_out) a.stats_out[6] = total;
   }
   __syncthreads();
   const int p = blockIdx.x * blockDim.x + tid;
   if (p >= a.P) return;
-  const float g = a.grad[p] * coef_s;
-  const float m = a.m[p] + (g - a.m[p]) * (1.0f - a.beta1);          // exp_avg.lerp_(grad, 1-beta1)
-  const float v = a.v[p] * a.beta2 + (1.0f - a.beta2) * g * g;       // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-  const float denom = sqrtf(v) / bc2s_s + a.eps;
-  a.m[p] = m;
-  a.v[p] = v;
-  const float pn = a.params[p] - ss_s * (m / denom);                   // param.addcdiv_(exp_avg, denom, -step_size)
-  a.params[p] = pn;
+  const AdamScalars k = ks;
+  const float pn = adam_update(a.grad[p], k, a.beta1, a.beta2, a.eps, a.m + p, a.v + p, a.params + p);
   if (a.wimage) wimage_put(a.wimage, a.wimage_map, p, pn);             // the split gradient kernel's pre-split weight fragments
 }
 

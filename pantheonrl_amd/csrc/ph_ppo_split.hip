@@ -21,9 +21,13 @@
 // Activations live in LDS only as bf16 planes, each in ONE layout; the product that contracts over
 // the plane's row index reads it with ds_read_b64_tr_b16 (the hardware 4x4 transpose), the one that contracts over the
 // contiguous index with ds_read_b128:
-//     XT   [feature][row]   written from the gathered rows      S1 (tr)      dW1 (plain)
+//     X    [row][feature]   16-byte copies of the plane image    S1 (plain)   dW1 (tr)          rows gathered from GradArgs.ximg
 //     H1T  [unit][row]      S1 epilogue (4 rows = one b64)      S2 (tr)      dW2 (plain)       -> DZ1T [unit][row] (dW1, plain)
 //     DZ2  [row][plane][unit]  head phase (8 units = one b128)  dH1 (plain)  dW2 (tr)          row r overlays H2's row r (f32, head only)
+// The observation rows are split ONCE per train() call (obs_planes_kernel -> GradArgs.ximg: they do not change across the
+// call's epochs and minibatches), and the five per-row scalars arrive packed in minibatch order (adv_stats_kernel ->
+// GradArgs.rec_pi / rec_vf): a tile's gather is one 16-byte record per row and six 16-byte plane granules per lane -- no
+// index arithmetic, no split, no 4-byte gathers in the 40 launches.
 // Bias gradients are MFMAs with an all-ones A operand on the B fragments already in registers; layer 1's bias rides as
 // feature 63 (FOLD) as in the f32 kernel.  3 x 24 KB of planes + 5.8 KB of head state = 79.7 KB -> two workgroups per CU.
 #include "ph_head.h"
@@ -32,12 +36,38 @@
 #ifndef PH_SPLIT_HEAD_PAIRS
 #define PH_SPLIT_HEAD_PAIRS 1
 #endif
+// 1: W1's fragments are fetched from the (L2-resident) weight image at the top of every tile, under the row commit, instead of
+// staying in registers from the prologue on: 24 registers less across the tile walk (212 instead of 238 VGPRs once the staged
+// observation planes take 24 registers), which keeps room on every SIMD for a wave of another learner's reduce / Adam kernel
+#ifndef PH_SPLIT_W1_PER_TILE
+#define PH_SPLIT_W1_PER_TILE 1
+#endif
+// how the 32 KB of weight-gradient accumulators of a workgroup go to its slab: 0 plain stores (the lines stay dirty in the XCD's
+// L2 and the end-of-kernel release writes 17.9 MB back behind the last workgroup), 1 write-through (sc1) stores that leave
+// while other workgroups still compute (MI355X_MICROARCH.md, "publish-large"), 2 nontemporal
+#ifndef PH_SPLIT_SLAB_STORE
+#define PH_SPLIT_SLAB_STORE 1
+#endif
+// 1: a workgroup's weight-gradient accumulators leave for its slab as soon as they are final -- dW2 (and d b2) after the LAST tile's
+// dW2 product, under that tile's dH1 / dZ1 / dW1 work, and dW1 block by block inside the last dW1 product (which then runs
+// block-outer) -- instead of as one 32 KB burst per workgroup after the last barrier, when all 512 workgroups finish together and
+// 17.9 MB hit the fabric at once (measured: the slab stores cost 5.7 of 26 us, scripts/ab_variants: PH_EXP_NO_SLABS)
+#ifndef PH_SPLIT_EARLY_SLABS
+#define PH_SPLIT_EARLY_SLABS 1
+#endif
+// experiments only (wrong results): PH_EXP_NO_SLABS skips the slab stores, PH_EXP_NO_XROWS reads every row from the zero row
 
 namespace ph {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 tr_bf16x4;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte streaming load (each granule is read once per launch and net: keep it out of L1)
+__device__ __forceinline__ uint4 ld_nt16(const uint4* p) {
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 #define PH_LDS_AS __attribute__((address_space(3)))
 
 constexpr int PL_ROW = 128;             // bytes of one plane row: 64 bf16 = 8 granules of 16 bytes
@@ -81,6 +111,18 @@ __device__ __forceinline__ void split4(const float* x, bf16x4 (&p)[3]) {
   }
 }
 
+// 16-byte slab store (PH_SPLIT_SLAB_STORE)
+__device__ __forceinline__ void st_slab16(float* p, const f32x4& v) {
+#if defined(PH_EXP_NO_SLABS)
+  (void)p; (void)v;
+#elif PH_SPLIT_SLAB_STORE == 1
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif PH_SPLIT_SLAB_STORE == 2
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
 __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
@@ -167,34 +209,32 @@ struct SplitRowMeta {
   float adv, old, act;
 };
 
-// Box observation rows in registers: lane = feature, register i = row 16*wave + i (sixteen consecutive rows per lane: two
-// 16-byte plane stores per plane at commit)
+// A tile's observation rows as plane granules in registers: wave w stages rows 16w .. 16w+15 of the tile; lane = (row 8i + lane/8,
+// logical granule lane % 8) for i = 0, 1 and every plane: 8 consecutive lanes read one 128-byte plane row of the image.
 struct XRows {
-  float v[16];
-  __device__ __forceinline__ void issue(int physv, const float* obs, const NetDims& nd, int lane) {
-    const int f = lane < nd.F ? lane : 0;
+  uint4 v[6];   // [i][plane]
+  // physv: lane r < 16 holds the physical buffer row of tile row 16w + r (negative = dead row -> the image's zero row)
+  __device__ __forceinline__ void issue(int physv, const uint4* ximg, int zero_row, int lane) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int p = __builtin_amdgcn_readlane(physv, i);
-      v[i] = __builtin_nontemporal_load(obs + (size_t)(p < 0 ? 0 : p) * nd.D + f);
+    for (int i = 0; i < 2; ++i) {
+      const int r = 8 * i + (lane >> 3);
+      int p = __builtin_amdgcn_ds_bpermute(4 * r, physv);
+      p = p < 0 ? zero_row : p;
+#if defined(PH_EXP_NO_XROWS)
+      p = zero_row;
+#endif
+      const uint4* src = ximg + (size_t)p * XIMG_ROW_U4 + (lane & 7);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) v[i * 3 + q] = ld_nt16(src + q * 8);
     }
   }
-  template <bool FOLD>
-  __device__ __forceinline__ void commit(char* xt, int physv, const NetDims& nd, int wave, int lane) const {
-    const bool fok = lane < nd.F;
-    const float pad = (FOLD && lane == 63) ? 1.f : 0.f;
-    float x[16];
+  __device__ __forceinline__ void commit(char* x, int wave, int lane) const {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int p = __builtin_amdgcn_readlane(physv, i);
-      x[i] = (p >= 0) ? (fok ? v[i] : pad) : 0.f;
-    }
-    const int sw = pl_swz(lane);
+    for (int i = 0; i < 2; ++i) {
+      const int row = 16 * wave + 8 * i + (lane >> 3);
+      const int off = row * PL_ROW + (((lane & 7) ^ pl_swz(row)) << 4);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      Frag3 f;
-      split8(x + 8 * g, f);
-      st_planes8(xt, lane * PL_ROW + (((2 * wave + g) ^ sw) << 4), f);
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4*>(x + off + q * PL_BYTES) = v[i * 3 + q];
     }
   }
 };
@@ -231,12 +271,10 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
   int* rowphys = (int*)(ract + R);              // [R]
 
   const int net = blockIdx.y;
-  const int oW1 = net == 0 ? lay.pi_W1 : lay.vf_W1, oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1;
-  const int oW2 = net == 0 ? lay.pi_W2 : lay.vf_W2, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
+  const int oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
   const float inv_nb = 1.0f / (float)a.nb;
   const int nk = nd.L;
 
-  const uint64_t perm_key = a.idx ? 0ull : epoch_key(a.perm_seed + (a.epoch ? *a.epoch : 0ull), a.perm_epoch);
   const bool norm = net == 0 && a.norm_adv && a.nb > 1;
   // unconditional loads (a null table reads two parameters instead): no branch, no wait here -- first use is the first tile's T0
   const float* advp = a.advstats ? a.advstats : a.params;
@@ -244,27 +282,19 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
   const float adv_mean = norm ? adv0 : 0.f;
   const float adv_den = norm ? adv1 + 1e-8f : 1.f;
 
-  // lane i < 16 of wave w serves row 16*w + i
-  auto row_index = [&](int tile, int wave, int lane) -> int {
+  // lane i < 16 of wave w serves row 16*w + i: its record {physical row, advantage | return, old log-prob | old value, action}
+  const uint4* recs = net == 0 ? a.rec_pi : a.rec_vf;
+  auto row_record = [&](int tile, int wave, int lane) -> SplitRowMeta {
     const int gi = tile * R + wave * 16 + lane;
-    if (lane >= 16 || gi >= a.nb) return -1;
-    if (a.idx_phys) return a.idx_phys[gi];
-    return a.idx ? a.idx[gi] : (int)feistel_perm((uint32_t)(a.mb_start + gi), a.perm_n, a.perm_hb, perm_key);
-  };
-  auto row_scalars = [&](int n) -> SplitRowMeta {
     SplitRowMeta m;
     m.phys = -1;
     m.adv = m.old = m.act = 0.f;
-    if (n >= 0) {
-      m.phys = a.idx_phys ? n : env_major_to_phys(n, a.T, a.E);
-      if (net == 0) {
-        m.adv = a.rb_adv[m.phys];
-        m.old = a.rb_logp[m.phys];
-        m.act = a.rb_act[m.phys];
-      } else {
-        m.adv = a.rb_ret[m.phys];
-        m.old = a.rb_val[m.phys];
-      }
+    if (lane < 16 && gi < a.nb) {
+      const uint4 r = ld_nt16(recs + gi);
+      m.phys = (int)r.x;
+      m.adv = __uint_as_float(r.y);
+      m.old = __uint_as_float(r.z);
+      m.act = __uint_as_float(r.w);
     }
     return m;
   };
@@ -275,12 +305,12 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
   SplitRowMeta meta;
   {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int j = lane & 15, kg = lane >> 4, n = 16 * wave + j;
-    // issue order: the first tile's row indices, then every weight of this wave (independent of the indices), then -- once the
-    // indices are back -- the row scalars and the observation rows; the weights are split while those are in flight
-    const int n0 = row_index(blockIdx.x, wave, lane);
+    // issue order: the first tile's row records, then every weight of this wave (independent of them), then -- once the
+    // records are back -- the observation planes of the rows they name
+    meta = row_record(blockIdx.x, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
-    // this wave's eighteen weight fragments, already split (ph_split.h: ppo_adam_kernel keeps the image in step with params)
+    // this wave's weight fragments arrive already split (ph_split.h: ppo_adam_kernel keeps the image in step with params)
+#if !PH_SPLIT_W1_PER_TILE
     {
       const uint4* img = reinterpret_cast<const uint4*>(a.wimage) + (size_t)((net * 4 + wave) * 18) * 64 + lane;
 #pragma unroll
@@ -291,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
         }
       }
     }
+#endif
     float bias1 = 0.f, bias2 = 0.f, hv0 = 0.f, hv1 = 0.f, hb = 0.f;
     if (tid < HID) {
       bias1 = a.params[oB1 + tid];
@@ -309,9 +340,8 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     PH_STAMP(a.prof, 8);
-    meta = row_scalars(n0);
     PH_STAMP(a.prof, 9);
-    xt.issue(meta.phys, a.rb_obs, nd, lane);
+    xt.issue(meta.phys, a.ximg, a.ximg_zero_row, lane);
     __builtin_amdgcn_sched_barrier(0);
     PH_STAMP(a.prof, 10);
     if (stop_now) return;
@@ -346,6 +376,8 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
 #pragma unroll
   for (int k = 0; k < NSTATP; ++k) st[k] = 0.f;
 
+  float* const rslab = a.slabs + ((size_t)blockIdx.x * 2 + net) * RS_NET;
+  bool slabs_out = false;   // dW1 / dW2 / d b2 already stored by the last tile (PH_SPLIT_EARLY_SLABS)
   bool first = true;
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, first = false) {
     int tidv = threadIdx.x;
@@ -355,6 +387,15 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     const bool has_next = tile + (int)gridDim.x < a.ntiles;
     const int unit = 16 * wave + j;   // this lane's column of every 16x16 result
 
+#if PH_SPLIT_W1_PER_TILE
+    {   // W1 by (feature, unit): B of S1, six L2-resident 16-byte loads per lane, in flight under the row commit
+      const uint4* img = reinterpret_cast<const uint4*>(a.wimage) + (size_t)((net * 4 + wave) * 18) * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) W1f[c].p[p] = __builtin_bit_cast(bf16x8, img[(c * 3 + p) * 64]);
+    }
+#endif
     // ---- T0: this tile's rows land in LDS as planes ----
     if (lane < 16) {
       const int row = wave * 16 + lane;
@@ -364,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
       ract[row] = meta.act;
     }
     if (first) PH_STAMP(a.prof, 14);
-    xt.template commit<FOLD>(smem + XT, meta.phys, nd, wave, lane);
+    xt.commit(smem + XT, wave, lane);
     if (first) PH_STAMP(a.prof, 15);
     lds_barrier();
     if (first) PH_STAMP(a.prof, 1);
@@ -406,15 +447,15 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
       // LDS store it cannot prove disjoint, so in plain loop order every block's reads waited behind the previous block's
       // stores (a deeper pipeline -- MFMAs of block b + 1 issued before the epilogue of block b, reads two blocks ahead -- measured
       // slower: 26.05 vs 25.65 us, at 231 instead of 219 VGPRs)
-      Frag3 xa = ld_trf(XT, 0, 0), xb = ld_trf(XT, 1, 0);
+      Frag3 xa = ld_plain(smem, pb0, XT), xb = ld_plain(smem, pb1, XT);   // A: X rows 16b + i, features 32c + 8kg ..
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = mma6(xa, W1f[0], acc);
         acc = mma6(xb, W1f[1], acc);
         if (b < 3) {
-          xa = ld_trf(XT, 0, b + 1);
-          xb = ld_trf(XT, 1, b + 1);
+          xa = ld_plain(smem, pb0, XT + (b + 1) * 16 * PL_ROW);
+          xb = ld_plain(smem, pb1, XT + (b + 1) * 16 * PL_ROW);
         }
         float v[4];
 #pragma unroll
@@ -432,7 +473,8 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
 
     // ---- S2: H2 = tanh(H1 W2 + b2) -> H2 (f32).  Operand roles swapped (A = W2 fragments): the result tile is H2^T, i.e.
     //      lane = row 16*blk + j, registers = units 16*wave + 4*kg + r -> one 16-byte store per block ----
-    const int n_next = has_next ? row_index(tile + gridDim.x, wave, lane) : -1;
+    SplitRowMeta meta_next = meta;
+    if (has_next) meta_next = row_record(tile + gridDim.x, wave, lane);   // next tile's rows, committed at its T0
     {
       const float4 bb = *reinterpret_cast<const float4*>(b2s + 16 * wave + 4 * kg);
       Frag3 xa = ld_trf(H1T, 0, 0), xb = ld_trf(H1T, 1, 0);   // read-ahead as in S1
@@ -579,8 +621,6 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     if (first) PH_STAMP(a.prof, 4);
 
     // ---- SH-b: d head weights / d head bias over this wave's 16 rows (H2 rows of this wave, still in LDS) ----
-    SplitRowMeta meta_next = meta;
-    if (has_next) meta_next = row_scalars(n_next);   // next tile's row scalars, committed at its T0
     if (net == 0) {
       // unit `lane` of row r sits at dword ((lane >> 2) ^ h2_swz(r)) * 4 + (lane & 3) of the row slot; h2_swz(r) only depends on r & 3
       int lofs[4];
@@ -665,6 +705,13 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
           gW2[b] = mma6(h1, dz, gW2[b]);
         }
       }
+#if PH_SPLIT_EARLY_SLABS
+      if (!has_next) {   // dW2 and d b2 are final: their 16 KB leave under the rest of this tile
+#pragma unroll
+        for (int b = 0; b < 4; ++b) st_slab16(rslab + RS_W2 + ((wave * 4 + b) * 64 + lane) * 4, gW2[b]);
+        if (lane < 16) rslab[RS_B2 + 16 * wave + lane] = gB2[0];   // every row of the ones product is the column sum
+      }
+#endif
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -690,18 +737,39 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
 
     // ---- S7: dW1 += X^T dZ1 (d b1 rides as feature 63, or as a ones product).  The next tile's rows are gathered underneath. ----
     meta = meta_next;
-    if (has_next) xt.issue(meta.phys, a.rb_obs, nd, lane);
+    if (has_next) xt.issue(meta.phys, a.ximg, a.ximg_zero_row, lane);
     {
+#if PH_SPLIT_EARLY_SLABS
+      // block-outer: dW1 block b (features 16b .. +15) is final after its two chunks, and on the last tile it leaves at once
+      const Frag3 dz0 = ld_plain(smem, pb0, H1T + wave * 16 * PL_ROW);   // B: DZ1T row (unit) 16w + j, rows 8kg .. / 32 + 8kg ..
+      const Frag3 dz1 = ld_plain(smem, pb1, H1T + wave * 16 * PL_ROW);
+      if constexpr (!FOLD) {
+        gB1 = mma_ones(dz0, gB1);
+        gB1 = mma_ones(dz1, gB1);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        gW1[b] = mma6(ld_trf(XT, 0, b), dz0, gW1[b]);   // A: features 16b + i (lane), tile rows 8kg .. (contraction): transposing reads of X
+        gW1[b] = mma6(ld_trf(XT, 1, b), dz1, gW1[b]);
+        if (!has_next) st_slab16(rslab + RS_W1 + ((wave * 4 + b) * 64 + lane) * 4, gW1[b]);
+      }
+      if (!has_next) {
+        if constexpr (!FOLD)
+          if (lane < 16) rslab[RS_B1 + 16 * wave + lane] = gB1[0];
+        slabs_out = true;
+      }
+#else
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const Frag3 dz = ld_plain(smem, c == 0 ? pb0 : pb1, H1T + wave * 16 * PL_ROW);   // B: DZ1T row (unit) 16w + j, rows 32c + 8kg ..
         if constexpr (!FOLD) gB1 = mma_ones(dz, gB1);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const Frag3 x = ld_plain(smem, c == 0 ? pb0 : pb1, XT + b * 16 * PL_ROW);     // A: XT rows (features) 16b + i
+          const Frag3 x = ld_trf(XT, c, b);     // A: features 16b + i (lane), tile rows 32c + 8kg .. (contraction): transposing reads of X
           gW1[b] = mma6(x, dz, gW1[b]);
         }
       }
+#endif
     }
     lds_barrier();  // XT / H1T / row scalars are free for the next tile
     if (first) PH_STAMP(a.prof, 7);
@@ -711,16 +779,17 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
   // ---- epilogue: accumulators -> slab (once), cross-wave sums in a fixed order ----
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* rslab = a.slabs + ((size_t)blockIdx.x * 2 + net) * RS_NET;
+    if (!slabs_out) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int o = ((wave * 4 + b) * 64 + lane) * 4;
-      *reinterpret_cast<float4*>(rslab + RS_W2 + o) = make_float4(gW2[b][0], gW2[b][1], gW2[b][2], gW2[b][3]);
-      *reinterpret_cast<float4*>(rslab + RS_W1 + o) = make_float4(gW1[b][0], gW1[b][1], gW1[b][2], gW1[b][3]);
-    }
-    if (lane < 16) {   // every row of the ones products is the column sum
-      rslab[RS_B2 + 16 * wave + lane] = gB2[0];
-      if constexpr (!FOLD) rslab[RS_B1 + 16 * wave + lane] = gB1[0];
+      for (int b = 0; b < 4; ++b) {
+        const int o = ((wave * 4 + b) * 64 + lane) * 4;
+        st_slab16(rslab + RS_W2 + o, gW2[b]);
+        st_slab16(rslab + RS_W1 + o, gW1[b]);
+      }
+      if (lane < 16) {   // every row of the ones products is the column sum
+        rslab[RS_B2 + 16 * wave + lane] = gB2[0];
+        if constexpr (!FOLD) rslab[RS_B1 + 16 * wave + lane] = gB1[0];
+      }
     }
 #pragma unroll
     for (int k = 0; k < NSTATP; ++k) {

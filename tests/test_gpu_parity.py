@@ -443,10 +443,27 @@ def test_split_bf16_gradient_on_integer_valued_large_and_tiny_observations(kind)
     w1 = 1.0 / scale if kind.endswith("rescaled_w1") else 1.0
     hp = orc.PPOHyper(ent_coef=0.01)
     g2, g_ref, st, st_ref, lay = _grad_pair("overcooked", T, E, idx, hp, gemm_mode=2, obs_fn=obs_fn, w1_scale=w1)
-    g0 = _grad_pair("overcooked", T, E, idx, hp, gemm_mode=0, obs_fn=obs_fn, w1_scale=w1)[0]
-    top = max(np.abs(g0).max(), 1e-6)
-    assert np.isfinite(g2).all() and np.abs(g2 - g0).max() <= 2e-6 * top, (kind, np.abs(g2 - g0).max(), top)
-    _assert_grads(g2, g_ref, lay)
+    g0, g64, _, _, _ = _grad_pair("overcooked", T, E, idx, hp, gemm_mode=0, obs_fn=obs_fn, w1_scale=w1, f64=True)
+    top = max(np.abs(g64).max(), 1e-6)
+    e0, e2, d20 = np.abs(g0 - g64).max(), np.abs(g2 - g64).max(), np.abs(g2 - g0).max()
+    print(f"{kind}: |g|max {top:.3e}; vs float64: exact-f32 kernel {e0:.3e}, split kernel {e2:.3e}; split vs exact-f32 {d20:.3e}")
+    assert np.isfinite(g2).all()
+    if kind.endswith("rescaled_w1") or kind == "x1e-4":
+        assert d20 <= 2e-6 * top, (kind, d20, top)
+    # Raw counts / 1e4-scaled inputs put most hidden units deep in tanh's flat region, where 1 - H^2 turns the float32 rounding of
+    # a pre-activation of magnitude ~1e2..1e5 into a RELATIVE change of the gradient: the problem is ill-conditioned for any
+    # float32 kernel, so the yardstick is the float64 gradient -- the split kernel must not be farther from it than the exact-f32
+    # kernel is (the claim of test_split_bf16_gradient_is_as_close_to_float64_as_the_float32_kernel, on these inputs)
+    assert e2 <= 1.5 * e0 + 2e-6 * top, (kind, e0, e2, top)
+    if kind != "x1e4":
+        _assert_grads(g2, g_ref, lay)
+    else:
+        # pre-activations of magnitude 1e4..1e5: the float32 AUTOGRAD gradient is itself only good to ~1e-3 here (it differs from
+        # the float64 one by that much), so "2e-4 of the largest entry against float32 autograd" is not a statement about the
+        # kernel; what is asserted is the float64 comparison above and that both kernels sit as close to the float32 autograd
+        # gradient as that one sits to float64
+        ref_err = np.abs(g_ref - g64).max()
+        assert np.abs(g2 - g_ref).max() <= 2.0 * ref_err + e0 + 2e-6 * top, (np.abs(g2 - g_ref).max(), ref_err, e0)
     if kind.endswith("rescaled_w1"):     # the first-layer gradient is really there (not a comparison of zeros)
         assert np.abs(g_ref[lay.pi_W1:lay.pi_b1]).max() > 1e-4 * top * min(scale, 1.0)
     for i, k in enumerate(("policy_loss", "value_loss", "entropy_loss", "clip_fraction", "approx_kl", "loss")):
@@ -579,8 +596,9 @@ def test_train_full_size_properties():
     env = type("E", (), dict(observation_space=H.to_space(obs_s), action_space=H.to_space(act_s),
                              _is_dummy_space_env=True))()
 
-    def run():
+    def run(exclusive=False):
         model = PPO("MlpPolicy", env, n_steps=T, n_envs=E, batch_size=T * E // 4, n_epochs=2, seed=0)
+        model.policy.ctx.set_exclusive_device(exclusive)
         model.policy.set_flat_params(orac.flat_params())
         rng = np.random.default_rng(0)
         rb, pol = model.rollout_buffer, model.policy
@@ -601,6 +619,38 @@ def test_train_full_size_properties():
     assert np.isfinite(st).all() and np.isfinite(m1.policy.get_flat_params()).all()
     assert np.array_equal(m1.policy.get_flat_params(), m2.policy.get_flat_params())  # fixed-order reductions
     assert not np.array_equal(m1.policy.get_flat_params(), orac.flat_params())
+    # a learner that has the device to itself runs reduce + clip + Adam as ONE launch (ppo_step_kernel: every block publishes its
+    # sum of squares as a stamped word, sweeps all words, updates its own 64 entries): bitwise the two-launch path -- parameters,
+    # Adam moments, step counter, weight image, per-minibatch statistics
+    m3 = run(exclusive=True)
+    assert np.array_equal(m1.policy.get_flat_params(), m3.policy.get_flat_params())
+    assert th.equal(m1.policy.adam_m, m3.policy.adam_m) and th.equal(m1.policy.adam_v, m3.policy.adam_v)
+    assert int(m3.policy.opt_step.item()) == int(m1.policy.opt_step.item()) == 8
+    assert np.array_equal(m1.last_train_stats, m3.last_train_stats)
+
+
+def test_fused_step_launch_is_bitwise_the_two_launches_through_a_kl_early_stop():
+    """the one-launch minibatch step (exclusive device) on the early-stop path: the KL test stops the update before its step, the
+    later minibatches of the call do nothing, statistics rows and optimizer step count equal the two-launch path's"""
+    from pantheonrl_amd.ppo import PPO
+    name, T, E = "overcooked", 32, 8
+    orac = H.oracle_policy(name, seed=5)
+    ob = H.filled_oracle_buffer(name, orac, T, E, seed=5)
+    obs_s, act_s = H.CONFIGS[name]
+    env = type("E", (), dict(observation_space=H.to_space(obs_s), action_space=H.to_space(act_s), _is_dummy_space_env=True))()
+    out = []
+    for exclusive in (False, True):
+        model = PPO("MlpPolicy", env, n_steps=T, n_envs=E, batch_size=32, n_epochs=6, learning_rate=3e-2, target_kl=0.01, seed=0)
+        model.policy.ctx.set_exclusive_device(exclusive)
+        model.policy.set_flat_params(orac.flat_params())
+        H.upload_buffer(model.rollout_buffer, ob)
+        model.device_permutations = True
+        model.train()
+        th.cuda.synchronize()
+        out.append((model.policy.get_flat_params(), model.last_train_stats.copy(), int(model.policy.opt_step.item())))
+    (p0, st0, n0), (p1, st1, n1) = out
+    assert 0 < n0 < 6 * 8, n0                                   # the test exercises the early stop
+    assert n0 == n1 and np.array_equal(p0, p1) and np.array_equal(st0, st1)
 
 
 # ----------------------------------------------------------------------------------------------------------------
