@@ -150,6 +150,7 @@ struct GradArgs {
   int ximg_zero_row;       // N
   const uint4* rec_pi;     // this minibatch: {physical row, advantage, old log-prob, action} per position
   const uint4* rec_vf;     // this minibatch: {physical row, return, old value, -}
+  int net_base;            // 0; experiments launch the two nets separately (net = blockIdx.y + net_base)
 };
 
 __device__ __host__ inline uint64_t epoch_key(uint64_t seed, int epoch) {

@@ -226,11 +226,18 @@ __device__ __forceinline__ float quad_sum_f(float v) {
   return v;
 }
 
-// sc != nullptr: the scripted rollout -- the weights are staged once and the step below runs sc->n_steps times, each time on
+// sc != nullptr: the scripted rollout -- the weights are fetched once and the step below runs sc->n_steps times, each time on
 // the next rows of the observation / reward / done sequences and of the rollout buffer (see ScriptedSteps)
 // px_persistent (with px and sc): the exchange rollout -- step t pushes its actions as stamp-in-band words of step t and the
 // value workgroups consume the words of step t - 1 (t >= 1), all inside the loop; the last step's reward, which the
 // launch-by-launch walk credits after the rollout from the unpacked joint action, is credited at the end of the loop.
+//
+// Round 4: no weight ever sits in LDS.  A lane's B operands of the three products of a step -- W1[g + 4s][16 wave + c],
+// W2[g + 4s][16 wave + c] and, in wave 0, the head's weights [g + 4s][c] -- do not depend on the step: they are fetched from the
+// parameters once per launch into 48 registers (the scripted rollouts keep them for all n_steps steps: 32 LDS reads per layer and
+// step gone; the single-step launch loses the 33 KB weight staging that was 40 % of its time).  The head is a third 16x16x4 MFMA
+// product (wave 0: z = H2 act_W, or H2 val_W in column 0) instead of 128 FMAs per lane over LDS-resident weights; its 16 x 8
+// result goes through 512 bytes of LDS so that lane r < 16 owns row r for the distribution tail.
 template <bool VALU>
 __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2p* px = nullptr, int px_t = 0, int px_a_local = 0,
                                                   int agent = 0, const ScriptedSteps* sc = nullptr, int px_persistent = 0) {
@@ -240,13 +247,8 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   FwdArgs a = a0;
   float* xs = smem;                 // [16][LDH]  X, later H2
   float* hs = xs + R * LDH;         // [16][LDH]  H1
-  float* w1s = hs + R * LDH;        // [64][LDH]
-  float* w2s = w1s + HID * LDH;     // [64][LDH]
-  float* hw = w2s + HID * LDH;      // policy: act_W [64][8] | value: val_W [64]
-  float* b1s = hw + HID * 8;        // [64]
-  float* b2s = b1s + HID;           // [64]
-  float* hbs = b2s + HID;           // act_b [8] | val_b
-  int* rowphys = (int*)(hbs + 8);   // [16]
+  float* zs = hs + R * LDH;         // [16][8]    head output incl. bias: policy logits | value in column 0
+  int* rowphys = (int*)(zs + R * 8);      // [16]
   float* upre = (float*)(rowphys + 16);   // [2][16] sampling uniforms of the rows, drawn a step ahead (scripted rollouts)
 
   const int tid = threadIdx.x;
@@ -263,43 +265,32 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   PH_STAMP(a.prof, 0);
   // every global load of the kernel is issued here; row indices are trivial (row0 + r), so X needs no metadata pass
   if (tid < R) rowphys[tid] = (row0 + tid < a.n) ? row0 + tid : -1;
-  WStage<NT> w1r, w2r;
-  w1r.issue(W1, 0, nd.F);
-  w2r.issue(W2, 0, HID);
-  float bias1 = 0.f, bias2 = 0.f, hv0 = 0.f, hv1 = 0.f, hb = 0.f;
-  if (tid < HID) {
-    bias1 = B1[tid];
-    bias2 = B2[tid];
-  }
-  if (net == 0) {
-    const int j0 = tid >> 3, k = tid & 7;  // elements tid and tid + 256 of the [64][8] block
-    if (k < nk) {
-      hv0 = a.params[lay.act_W + j0 * nk + k];
-      hv1 = a.params[lay.act_W + (j0 + 32) * nk + k];
+  float bw1[16], bw2[16], bwh[16];   // B operands: element [g + 4s][this lane's column] of W1, W2 and the head
+  const int col = 16 * wave + c;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int k = g + 4 * s;
+    bw1[s] = (k < nd.F) ? W1[k * HID + col] : 0.f;
+    bw2[s] = W2[k * HID + col];
+    bwh[s] = 0.f;
+    if (wave == 0) {
+      if (net == 0) {
+        if (c < nk) bwh[s] = a.params[lay.act_W + k * nk + c];
+      } else if (c == 0) {
+        bwh[s] = a.params[lay.val_W + k];
+      }
     }
-    if (tid < 8 && tid < nk) hb = a.params[lay.act_b + tid];
-  } else {
-    if (tid < HID) hv0 = a.params[lay.val_W + tid];
-    if (tid == 0) hb = a.params[lay.val_b];
+  }
+  const float bias1 = B1[col], bias2 = B2[col];
+  float hbias = 0.f;
+  if (wave == 0) {
+    if (net == 0) hbias = (c < nk) ? a.params[lay.act_b + c] : 0.f;
+    else hbias = (c == 0) ? a.params[lay.val_b] : 0.f;
   }
   XStage<R, NT> xr;
   lds_only_barrier();  // rowphys visible
   if (sc) a.obs = sc->obs_seq;
   xr.issue(rowphys, a.obs, nd, 0);
-  w1r.commit(w1s);
-  w2r.commit(w2s);
-  if (tid < HID) {
-    b1s[tid] = bias1;
-    b2s[tid] = bias2;
-  }
-  if (net == 0) {
-    hw[tid] = hv0;
-    hw[tid + 256] = hv1;
-    if (tid < 8) hbs[tid] = hb;
-  } else {
-    if (tid < HID) hw[tid] = hv0;
-    if (tid == 0) hbs[0] = hb;
-  }
   xr.commit(xs, rowphys, a.obs, nd, 0);
   lds_only_barrier();
   PH_STAMP(a.prof, 1);
@@ -321,7 +312,26 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
       upre[(t1 & 1) * R + lane] = philox_uniform(a0.seed, a0.counter + (unsigned long long)t1 + epoch_hi, (uint32_t)(row0 + lane), 0u);
   };
   if (draw_ahead && wave == 1) draw_uniforms(0);   // visible to wave 0 after the barriers of step 0's layers
+
+  // one 16x16 output tile per wave: D[row 4g+r][this lane's column] = sum_k A[row][k] B[k][column]; two accumulator chains
+  auto product = [&](const float* A, const float (&bw)[16]) -> f32x4 {
+    f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = A + c * LDH + g;
+    float av[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) av[s] = ap[4 * s];
+#pragma unroll
+    for (int s = 0; s < 16; s += 2) {
+      e = mma16<VALU>(av[s], bw[s], e, lane);
+      o = mma16<VALU>(av[s + 1], bw[s + 1], o, lane);
+    }
+    return e + o;
+  };
+
   for (int t = 0; t < n_steps; ++t) {
+  // debug stamps of ONE step in the middle of a scripted rollout (slots 8..15: scripts/rollout_phase.py)
+  long long* const pstep = (sc && t == 8) ? a0.prof : nullptr;
+  PH_STAMP(pstep, 8);
   if (t > 0) {   // (scripted rollout) the next step's argument record and observation rows; the weights stay where they are
     const size_t row = (size_t)t * a0.n;
     a.obs = sc->obs_seq + row * nd.D;
@@ -348,70 +358,62 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
     xr.commit(xs, rowphys, a.obs, nd, 0);
     lds_only_barrier();
   }
+  PH_STAMP(pstep, 9);
 
-  // one 16x16 output tile per wave: D[row 4g+r][col 16*wave + c] = sum_k A[row][k] W[k][col]; two accumulator chains
-  auto layer = [&](const float* A, const float* W) -> f32x4 {
-    f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
-    const float* ap = A + c * LDH + g;
-    const float* bp = W + g * LDH + 16 * wave + c;
-    float av[16], bv[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      av[s] = ap[4 * s];
-      bv[s] = bp[4 * s * LDH];
-    }
-#pragma unroll
-    for (int s = 0; s < 16; s += 2) {
-      e = mma16<VALU>(av[s], bv[s], e, lane);
-      o = mma16<VALU>(av[s + 1], bv[s + 1], o, lane);
-    }
-    return e + o;
-  };
+  // value workgroup, rectangular rollout: what the row tail reads (previous done, pending reward, the reward row it adds to) is
+  // fetched here, under the layers; RolloutBuffer.add's observation copy of Box rows goes out straight from the staged registers
+  // (the row was read once: no second trip to the observation)
+  const bool pre_ok = net == 1 && wave == 0 && lane < R && row0 + lane < a.n && !a.pos_env && a.rb_val;
+  ValuePre vpre = {0.f, 0.f, 0.f};
+  if (pre_ok) vpre = value_row_preload(a, row0 + lane);
+  const bool copy_from_regs = net == 1 && a.rb_obs && !a.pos_env && nd.obs_kind == PH_SPACE_BOX;
   {
-    const f32x4 z1 = layer(xs, w1s);
-    const float b = b1s[16 * wave + c];
+    const f32x4 z1 = product(xs, bw1);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hs[(4 * g + r) * LDH + 16 * wave + c] = fast_tanh(z1[r] + b);
+    for (int r = 0; r < 4; ++r) hs[(4 * g + r) * LDH + col] = fast_tanh(z1[r] + bias1);
   }
   lds_only_barrier();
   PH_STAMP(a.prof, 3);
+  PH_STAMP(pstep, 10);
   {
-    const f32x4 z2 = layer(hs, w2s);
-    const float b = b2s[16 * wave + c];
+    const f32x4 z2 = product(hs, bw2);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xs[(4 * g + r) * LDH + 16 * wave + c] = fast_tanh(z2[r] + b);   // X is dead: H2 over it
+    for (int r = 0; r < 4; ++r) xs[(4 * g + r) * LDH + col] = fast_tanh(z2[r] + bias2);   // X is dead: H2 over it
   }
   lds_only_barrier();
   PH_STAMP(a.prof, 5);
+  PH_STAMP(pstep, 11);
 
-  // ---- head: wave 0, four lanes per row (16 hidden units each), quad-DPP reduction; the other waves copy observations ----
+  // ---- head: wave 0, a third product (columns = logits, or the value in column 0); the other waves copy observations ----
   if (wave == 0) {
-    const int r = lane >> 2, q = lane & 3;
-    const int grow = row0 + r;
-    float h[16];
+    const f32x4 zh = product(xs, bwh);
+    PH_STAMP(pstep, 12);
+    if (c < 8) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) h[m] = xs[r * LDH + 8 * q + (m & 7) + 32 * (m >> 3)];
-    if (net == 0) {
-      float z[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) z[k] = 0.f;
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const float4* w = reinterpret_cast<const float4*>(hw + (8 * q + (m & 7) + 32 * (m >> 3)) * 8);
-        const float4 w0 = w[0], w1 = w[1];
-        z[0] = __builtin_fmaf(h[m], w0.x, z[0]);
-        z[1] = __builtin_fmaf(h[m], w0.y, z[1]);
-        z[2] = __builtin_fmaf(h[m], w0.z, z[2]);
-        z[3] = __builtin_fmaf(h[m], w0.w, z[3]);
-        z[4] = __builtin_fmaf(h[m], w1.x, z[4]);
-        z[5] = __builtin_fmaf(h[m], w1.y, z[5]);
-        z[6] = __builtin_fmaf(h[m], w1.z, z[6]);
-        z[7] = __builtin_fmaf(h[m], w1.w, z[7]);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) z[k] = quad_sum_f(z[k]) + ((k < nk) ? hbs[k] : 0.f);
-      if (q == 0 && grow < a.n) {
-        const int act = discrete8_row_tail(a, nd, grow, z, fwd_counter(a), draw_ahead ? upre + (t & 1) * R + r : nullptr);
+      for (int r = 0; r < 4; ++r) zs[(4 * g + r) * 8 + c] = zh[r] + hbias;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // zs is written and read by this wave only
+    __builtin_amdgcn_wave_barrier();
+    PH_STAMP(pstep, 13);
+    const int r = lane, grow = row0 + lane;   // lane r < 16 owns row r
+    if (r < R && grow < a.n) {
+      if (net == 0) {
+        const float4 z0 = *reinterpret_cast<const float4*>(zs + r * 8), z1 = *reinterpret_cast<const float4*>(zs + r * 8 + 4);
+        float z[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+        const float* up = draw_ahead ? upre + (t & 1) * R + r : nullptr;
+        const uint64_t ctr = fwd_counter(a);
+        int act;
+        switch (nk) {   // the logit count as a compile-time constant: the tail's loops shrink to the logits that exist
+          case 1: act = discrete8_row_tail<1>(a, nd, grow, z, ctr, up); break;
+          case 2: act = discrete8_row_tail<2>(a, nd, grow, z, ctr, up); break;
+          case 3: act = discrete8_row_tail<3>(a, nd, grow, z, ctr, up); break;
+          case 4: act = discrete8_row_tail<4>(a, nd, grow, z, ctr, up); break;
+          case 5: act = discrete8_row_tail<5>(a, nd, grow, z, ctr, up); break;
+          case 6: act = discrete8_row_tail<6>(a, nd, grow, z, ctr, up); break;
+          case 7: act = discrete8_row_tail<7>(a, nd, grow, z, ctr, up); break;
+          default: act = discrete8_row_tail<8>(a, nd, grow, z, ctr, up); break;
+        }
         if (px) {  // push: (stamp << 32 | action) as one 8-byte store into every rank's receive area, slot t mod ll_slots
           const int pt = px_t + t;
           const int slot = px_persistent ? p2p_persistent_slot(px_epoch, px->T, pt) : pt % px->ll_slots;
@@ -421,14 +423,9 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
           for (int p = 0; p < px->world; ++p)
             __hip_atomic_store(px->ll[p] + off, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-      }
-    } else {
-      float v = 0.f;
-#pragma unroll
-      for (int m = 0; m < 16; ++m) v = __builtin_fmaf(h[m], hw[8 * q + (m & 7) + 32 * (m >> 3)], v);
-      v = quad_sum_f(v) + hbs[0];
-      if (q == 0 && grow < a.n) {
-        value_row_tail(a, grow, v);
+      } else {
+        const float v = zs[r * 8];
+        value_row_tail(a, grow, v, pre_ok, vpre);
         // (scripted rollout) the last step's own reward: the flush that precedes GAE on the launch-by-launch path
         if (sc && t == n_steps - 1) {
           float add = sc->rew_seq[(size_t)t * a0.n + grow];
@@ -447,9 +444,20 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
       }
     }
   }
+  PH_STAMP(pstep, 14);
   if (draw_ahead && wave == 1 && t + 1 < n_steps) draw_uniforms(t + 1);
-  if (net == 1) copy_obs_rows(a, row0, (a.n - row0 < R) ? a.n - row0 : R, nd.D);
+  if (copy_from_regs) {   // stores only, at the end of the step: nothing of this step waits behind them
+    const int kk = tid & 63;
+#pragma unroll
+    for (int i = 0; i < XStage<R, NT>::ITERS; ++i) {
+      const int rr = (tid + NT * i) >> 6;
+      if (kk < nd.D && row0 + rr < a.n) a.rb_obs[(size_t)(row0 + rr) * nd.D + kk] = xr.v[i];
+    }
+  } else if (net == 1) {
+    copy_obs_rows(a, row0, (a.n - row0 < R) ? a.n - row0 : R, nd.D);
+  }
   PH_STAMP(a.prof, 7);
+  PH_STAMP(pstep, 15);
   }
 }
 
@@ -480,7 +488,7 @@ static int current_device_slot() {
   return (dev >= 0 && dev < 64) ? dev : 0;
 }
 
-static size_t fwd16_lds_bytes() { return sizeof(float) * (size_t)(2 * 16 * LDH + 2 * HID * LDH + HID * 8 + 2 * HID + 8 + 16 + 32); }
+static size_t fwd16_lds_bytes() { return sizeof(float) * (size_t)(2 * 16 * LDH + 16 * 8 + 16 + 32); }
 
 bool fwd16_eligible(const NetDims& nd, int n) {
   static int enabled = -1;

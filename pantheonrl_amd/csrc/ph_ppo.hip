@@ -1012,7 +1012,11 @@ __device__ __forceinline__ float reduce_positions(const ReduceArgs& a, float (*g
   const int pl = tid & (RED_PARAMS - 1), grp = __builtin_amdgcn_readfirstlane(tid >> RED_SHIFT);
   const int p = blockIdx.x * RED_PARAMS + pl;   // slab position
   {
+#if defined(PH_EXP_REDUCE_NO_LOADS)
+    const int per = 0;
+#else
     const int per = (a.nslab + RED_SUB - 1) / RED_SUB;
+#endif
     float quarter = 0.f;
 #pragma unroll 1
     for (int sub = grp * (RED_SUB / GROUPS); sub < (grp + 1) * (RED_SUB / GROUPS); ++sub) {

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
   float* ract = rold + R;                       // [R]
   int* rowphys = (int*)(ract + R);              // [R]
 
-  const int net = blockIdx.y;
+  const int net = blockIdx.y + a.net_base;
   const int oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
   const float inv_nb = 1.0f / (float)a.nb;
   const int nk = nd.L;
@@ -376,7 +376,11 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
 #pragma unroll
   for (int k = 0; k < NSTATP; ++k) st[k] = 0.f;
 
+#if defined(PH_EXP_NET_ONLY)
+  float* const rslab = a.slabs + ((size_t)(blockIdx.x % 128) * 2 + net) * RS_NET;   // timing experiment: keep the small stores inside the workspace
+#else
   float* const rslab = a.slabs + ((size_t)blockIdx.x * 2 + net) * RS_NET;
+#endif
   bool slabs_out = false;   // dW1 / dW2 / d b2 already stored by the last tile (PH_SPLIT_EARLY_SLABS)
   bool first = true;
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, first = false) {
@@ -824,7 +828,9 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     }
     if (net == 0 && tid < 8) rslab[RS_HB + tid] = wsum(1, tid);
     if (net == 1 && tid == 0) rslab[RS_HB] = wsum(1, 0);
+#if !defined(PH_EXP_NET_ONLY)
     if (tid < NSTATP) a.statpart[((size_t)net * gridDim.x + blockIdx.x) * NSTATP + tid] = wsum(2, tid);
+#endif
   }
   PH_STAMP(a.prof, 13);
 }
@@ -856,6 +862,17 @@ static hipError_t launch_split_inst(const GradArgs& a, int nwg, hipStream_t s) {
     if (e != hipSuccess) return e;
     allowed = true;
   }
+#if defined(PH_EXP_NET_ONLY)   // experiment: ONE net per launch (PH_EXP_NET_ONLY = 0 | 1 | 2 = both, one after the other)
+  {
+    GradArgs b = a;
+    for (int net = 0; net < 2; ++net) {
+      if (PH_EXP_NET_ONLY != 2 && PH_EXP_NET_ONLY != net) continue;
+      b.net_base = net;
+      hipLaunchKernelGGL((ppo_grad_split_kernel<NK, FOLD>), dim3(a.ntiles, 1), dim3(256), lds, s, b);   // one tile per workgroup, two resident per CU: a CU works on ONE net (timing only: build with PH_EXP_NO_SLABS)
+    }
+    return hipGetLastError();
+  }
+#endif
   hipLaunchKernelGGL((ppo_grad_split_kernel<NK, FOLD>), dim3(nwg, 2), dim3(256), lds, s, a);
   return hipGetLastError();
 }

@@ -31,16 +31,30 @@ __device__ __forceinline__ int ll_read(const FwdArgs& a, const unsigned long lon
   }
 }
 
+// What the value-net tail of row g READS from global memory (rectangular rollouts): fetched at the top of a step, under the
+// layers, so that the tail is stores only -- three dependent round trips less at the end of every step of a rollout
+struct ValuePre {
+  float es, pend, prev;
+};
+__device__ __forceinline__ ValuePre value_row_preload(const FwdArgs& a, int g) {
+  ValuePre p;
+  p.es = a.es_in ? a.es_in[g] : 0.f;
+  p.pend = a.pending_reward ? a.pending_reward[g] : 0.f;
+  p.prev = (a.pending_reward && a.prev_rew) ? a.prev_rew[g] : 0.f;
+  return p;
+}
+
 // value-net tail of one row: cache V, write the rollout-buffer row scalars, fold the previous step's late reward in
-__device__ __forceinline__ void value_row_tail(const FwdArgs& a, int g, float v) {
+// (has_pre: `pre` holds the row's inputs, fetched ahead by value_row_preload -- rectangular rollouts only)
+__device__ __forceinline__ void value_row_tail(const FwdArgs& a, int g, float v, bool has_pre = false, ValuePre pre = ValuePre{0.f, 0.f, 0.f}) {
   const long long ridx = a.rb_val ? rb_row(a, g) : -1;
   if (a.values && (!a.pos_env || ridx >= 0)) a.values[g] = v;  // ragged: V of the last RECORDED action is cached
   if (ridx >= 0) {
     a.rb_val[ridx] = v;
     a.rb_rew[ridx] = 0.f;
-    a.rb_es[ridx] = a.es_in[g];
+    a.rb_es[ridx] = has_pre ? pre.es : a.es_in[g];
     if (a.pending_reward) {
-      float add = a.pending_reward[g];
+      float add = has_pre ? pre.pend : a.pending_reward[g];
       if (a.joint) {  // shared coordination term of the synthetic SimultaneousEnv transition (joint action)
         int p = *a.partner_seat;
         p = p < 0 ? 0 : (p >= a.n_seats ? a.n_seats - 1 : p);
@@ -52,7 +66,8 @@ __device__ __forceinline__ void value_row_tail(const FwdArgs& a, int g, float v)
           add += (a.joint[(size_t)a.seat * a.n + g] == a.joint[(size_t)p * a.n + g]) ? a.bonus : 0.f;
         }
       }
-      a.prev_rew[g] += add;
+      if (has_pre) a.prev_rew[g] = pre.prev + add;
+      else a.prev_rew[g] += add;
     }
   }
 }
@@ -87,9 +102,13 @@ __device__ __forceinline__ uint64_t fwd_counter(const FwdArgs& a) {
 // Discrete action space with <= 8 logits, one lane per row, the row's logits in registers (z[k >= L] ignored): optional
 // mask offset, logits output, sampling / argmax / given action, log-prob, entropy and the rollout-buffer writes
 // u_pre: this row's sampling uniform when the caller drew it ahead of time (the same Philox call, off the critical lane)
+// NK: 8 = the logit count is a run-time value (nd.L, padding logits carry -3e38 and add exact zeros); 1..7 = it is NK, known at
+// compile time -- the loops shrink to the logits that exist.  Bitwise the same results: the generic form only ever adds +0.0 and
+// never selects a padding logit.
+template <int NK = 8>
 __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDims& nd, int g, float (&zr)[8], uint64_t ctr,
                                                   const float* u_pre = nullptr) {
-  const int nk = nd.L;
+  const int nk = NK < 8 ? NK : nd.L;
   if (a.mask) {  // modular/policies.py:330-333 : logits - 30*(~mask)
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -104,12 +123,15 @@ __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDim
   float m = -3.0e38f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
+    if (NK < 8 && k >= NK) continue;   // (compile-time: the loop is unrolled)
     zr[k] = (k < nk) ? zr[k] : -3.0e38f;
     m = fmaxf(m, zr[k]);
   }
   float se = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
+    pr[k] = 0.f;
+    if (NK < 8 && k >= NK) continue;
     pr[k] = (k < nk) ? fast_exp(zr[k] - m) : 0.f;
     se += pr[k];
   }
@@ -128,6 +150,7 @@ __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDim
     float cum = 0.f;
 #pragma unroll
     for (int k = 0; k < 7; ++k) {  // inverse CDF: count prefix sums <= u
+      if (NK < 8 && k >= NK - 1) continue;
       cum += pr[k] * inv;
       act += (k < nk - 1 && u >= cum) ? 1 : 0;
     }
@@ -135,6 +158,7 @@ __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDim
   float zact = 0.f, ent = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
+    if (NK < 8 && k >= NK) continue;
     const float lp = zr[k] - lse;
     ent -= (k < nk) ? pr[k] * inv * lp : 0.f;
     zact = (k == act) ? zr[k] : zact;
