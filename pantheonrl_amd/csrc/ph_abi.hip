@@ -1840,6 +1840,10 @@ int ph_ppo_train_multi(const ph_train_call* calls, int n_calls) {
   // Round-robin over the learners, minibatch by minibatch.  Gradient launches fill the whole device, so two of them side by
   // side only slow each other down; chaining them (each waits for the previous learner's gradient launch) lets one
   // learner's small reduce / Adam launches run in the shadow of the next learner's gradient launch.
+  // (Round 4 measured the alternatives on MI355X, 2 learners, whole iterations as hipGraphs: this chaining 3.62 ms; every gradient
+  // launch on ONE queue with each learner's reduce / Adam on a side stream tied in by two events per minibatch 3.87 ms; NO
+  // chaining at all -- one linear graph per learner, free-running, bench.py's default -- 2.74 ms.  Cross-stream edges inside a
+  // graph cost far more than the overlap they arrange; the hardware's own interleaving of two independent queues wins.)
   hipEvent_t prev = nullptr;
   hipStream_t prev_stream = nullptr;
   for (int mbi = 0; mbi < longest; ++mbi) {

@@ -1,7 +1,10 @@
 """BASELINE config 4 on K + 1 ranks (here sharing one GPU over gloo): ego on rank 0, partner k on rank 1 + k, per-environment
 round-robin partner ids, partner observations routed from the ego's rank.  After the run every rank's buffers travel to
-rank 0, which replays EVERY environment through the Python MultiAgentEnv step loop (the reference's own control flow,
-pantheonrl/common/multiagentenv.py:149-243) with replay agents and compares buffers row by row."""
+rank 0, which replays the environments (all of them, or RR_SAMPLE of them spread over the vector) through the reference's control
+flow (pantheonrl/common/multiagentenv.py:149-243) with replay agents and compares buffers row by row.  RR_ENV_IMPL picks whose
+statement of that control flow does the replay: "product" = pantheonrl_amd.common.SimultaneousEnv (itself tested against
+hand-derived expectations), "oracle" = oracle/multiagent_oracle.py (an independent restatement that shares no code with the
+product).  RR_E / RR_T / RR_ITER / RR_SAMPLE size the run: BASELINE config 4 as written is RR_E=1024, four ranks."""
 import os
 import sys
 
@@ -21,7 +24,9 @@ dev_index = int(os.environ.get("LOCAL_RANK", "0")) % th.cuda.device_count()
 th.cuda.set_device(dev_index)
 dist.init_process_group(os.environ.get("RR_BACKEND", "gloo"))
 device = th.device("cuda", dev_index)
-E, T, D, ITER, BONUS = 24, 8, 62, 3, 0.25
+E, T, D, ITER, BONUS = int(os.environ.get("RR_E", "24")), int(os.environ.get("RR_T", "8")), 62, int(os.environ.get("RR_ITER", "3")), 0.25
+SAMPLE = int(os.environ.get("RR_SAMPLE", "0")) or E
+ENV_IMPL = os.environ.get("RR_ENV_IMPL", "product")
 HORIZON = int(os.environ.get("RR_HORIZON", "5"))
 T_PARTNER = int(os.environ.get("RR_T_PARTNER", "64"))      # long enough that no partner trains during the replayed run
 obs_space, act_space = sp.Box(-np.inf, np.inf, (D,)), sp.Discrete(6)
@@ -74,12 +79,15 @@ if rank == 0 and T_PARTNER >= ITER * T:
             self.rows[-1]["reward"] = np.float32(self.rows[-1]["reward"] + np.float32(reward))
             self.last_start = bool(done)
 
-    class Scripted(SimultaneousEnv):
-        observation_space, action_space = obs_space, act_space
+    class ScriptedGame:
+        """the scripted 2-player game itself (multi_reset / multi_step); `wrapper` = whoever drives it"""
 
         def __init__(self, e):
-            super().__init__()
-            self.e, self.g = e, 0
+            self.e, self.g, self.wrapper = e, 0, None
+
+        def _active_partner(self):
+            w = self.wrapper
+            return w.partners[0][w.partnerids[0]] if ENV_IMPL == "product" else w.partners[w.partnerid]
 
         def multi_reset(self):
             t = self.g % T
@@ -88,18 +96,35 @@ if rank == 0 and T_PARTNER >= ITER * T:
         def multi_step(self, ego_action, alt_action):
             it, t = divmod(self.g, T)
             a1 = int(trace[it]["alt_actions"][t, self.e])        # what the active partner's device forward sampled
-            self.partners[0][self.partnerids[0]].rows[-1]["action"] = a1
+            self._active_partner().rows[-1]["action"] = a1
             r = np.float32(base[t, self.e] + (np.float32(BONUS) if int(ego_action) == a1 else np.float32(0)))
             d = bool(done[t, self.e])
             self.g += 1
             tn = self.g % T
             return (obs0[tn, self.e], obs1[tn, self.e]), (r, r), d, {}
 
-    for e in range(E):
-        game = Scripted(e)
+    if ENV_IMPL == "product":
+        class Scripted(ScriptedGame, SimultaneousEnv):
+            observation_space, action_space = obs_space, act_space
+
+            def __init__(self, e):
+                SimultaneousEnv.__init__(self)
+                ScriptedGame.__init__(self, e)
+                self.wrapper = self
+    else:
+        from oracle.multiagent_oracle import RoundRobinSimultaneousOracle
+
+    sample = sorted({int(round(i * (E - 1) / max(SAMPLE - 1, 1))) for i in range(SAMPLE)})
+    for e in sample:
         partners = [Replay() for _ in range(K)]
-        for p in partners:
-            game.add_partner_agent(p)
+        if ENV_IMPL == "product":
+            game = Scripted(e)
+            for p in partners:
+                game.add_partner_agent(p)
+        else:
+            inner = ScriptedGame(e)
+            game = RoundRobinSimultaneousOracle(inner, partners)
+            inner.wrapper = game
         ego_rows = []
         ob = game.reset()
         start = True

@@ -906,6 +906,24 @@ def test_trainer_preset_object_graph_end_to_end(tmp_path, monkeypatch):
     assert os.path.isdir("logs") and any(n.startswith("RPS-v0-PPOPPO-0") for n in os.listdir("logs"))
 
 
+def test_trainer_rps_preset_1_exactly_as_baseline_config_1_states_it(tmp_path, monkeypatch):
+    """BASELINE config 1 AS WRITTEN: `trainer.py RPS-v0 PPO PPO --preset 1 -t 10000` on SB3's defaults (n_envs 1, n_steps 2048,
+    batch 64, 10 epochs; trainer.py:231-256,404-413).  SURVEY.md 8(c): the ego collects 5 x 2048 = 10 240 steps (learn() stops at
+    the first rollout boundary past 10 000) and updates after each; the partner trains at the NEXT get_action after its buffer
+    fills (agents.py:126), so its fifth full buffer is never trained on: 4 updates.  Every update is 10 epochs x 32 minibatches."""
+    from pantheonrl_amd import trainer
+    monkeypatch.chdir(tmp_path)
+    ego, partners, env = trainer.run(["RPS-v0", "PPO", "PPO", "--preset", "1", "--seed", "0", "-t", "10000"])
+    assert ego.n_steps == 2048 and ego.batch_size == 64 and ego.n_epochs == 10 and ego.n_envs == 1
+    assert ego.num_timesteps == 10240
+    assert int(ego.policy.opt_step.item()) == 5 * 320
+    partner = partners[0]
+    assert partner.model.n_steps == 2048 and partner.num_timesteps == 10240
+    assert partner.iteration == 4 and int(partner.model.policy.opt_step.item()) == 4 * 320
+    assert len(ego.ep_info_buffer) == 100 and all(e["l"] == 1 for e in ego.ep_info_buffer)    # one-step episodes (rps.py:45)
+    assert np.isfinite(ego.policy.get_flat_params()).all() and np.isfinite(partner.model.policy.get_flat_params()).all()
+
+
 def test_fused_multi_agent_step_matches_per_agent_calls():
     """ph_policy_step_multi (all local agents in one launch, previous step's joint-action reward folded in) leaves the
     same rollout buffers as the per-agent forward + ph_buffer_add_reward_joint sequence."""
@@ -1697,7 +1715,12 @@ def test_round_robin_partners_one_agent_per_rank_replayed_through_multiagentenv(
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # second run: 4-row partner buffers and 5-step episodes: environments change partner at different times, so a partner's
     # columns fill at different rates -- it trains on its full columns (min_full) instead of waiting for all of them
-    for extra, port in (({}, 29561), ({"RR_T_PARTNER": "4"}, 29562), ({"PH_RR_NATIVE": "0"}, 29563)):
+    # fourth run: the replay through oracle/multiagent_oracle.py -- an independent restatement of the reference's step / reset control
+    # flow that shares no code with the product's SimultaneousEnv; fifth: BASELINE config 4 at its written size (1 024 environments,
+    # 62 features, 3 partners, 4 ranks), a 64-environment sample spread over the vector replayed through that oracle
+    for extra, port in (({}, 29561), ({"RR_T_PARTNER": "4"}, 29562), ({"PH_RR_NATIVE": "0"}, 29563),
+                        ({"RR_ENV_IMPL": "oracle"}, 29564),
+                        ({"RR_ENV_IMPL": "oracle", "RR_E": "1024", "RR_T": "32", "RR_ITER": "2", "RR_SAMPLE": "64"}, 29565)):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
                "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "scripts", "roundrobin_ranks.py")]
         out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env={**os.environ, **extra})
