@@ -1550,7 +1550,7 @@ bool step_fused_wanted(const ph_ctx* ctx, int slab_len, bool alone) {
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
   return enabled && alone && ctx->exclusive && ctx->step_words && ctx->step_gen &&
-         ph::step_fused_fits(ph::reduce_blocks(slab_len), 0, ctx->num_cu);
+         ph::step_fused_fits(ph::reduce_blocks(slab_len), slab_len, ctx->num_cu);
 }
 
 }  // namespace
@@ -1757,7 +1757,6 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
     if (adap_launch(ctx, t.nd, t.opt->params, t.rb, t.adap, idx, pl.nb, mbi, &r)) return 1;
   }
   const bool fused = step_fused_wanted(ctx, slab_len_of(t.nd), t.alone != 0);
-  if (fused) r.wide = 0;   // 256-lane blocks: eight per CU are resident, so the whole grid is (1024-lane blocks: two per CU -- the grid would not fit with a margin)
   if (!fused) PH_HIP(ph::launch_ppo_reduce(r, s));
 
   ph::AdamArgs ad;

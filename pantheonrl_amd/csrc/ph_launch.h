@@ -220,7 +220,7 @@ struct ReduceArgs {
   float extra_norm = 0.f;             // raw term = extra_norm * sum(extra_loss)
   float extra_coef = 0.f;             // loss statistic += extra_coef * raw term
   float* extra_loss_out = nullptr;    // [1] raw term of this minibatch, or null
-  int wide = 0;                       // 1: 1024-lane blocks (the learner has the device to itself); same summation tree either way
+  int wide = 0;                       // 1: the learner has the device to itself -- 16-byte loads (more registers); same summation tree either way
 };
 
 struct AdamArgs {
@@ -393,7 +393,7 @@ hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s);
 int reduce_blocks(int slab_len);
 // reduce + clip + Adam as one launch (ppo_step_kernel): `words` [reduce_blocks + 1] and `gen` are workspace that persists across
 // launches (zeroed once); step_fused_fits says whether every block of the grid is resident at once on the current device
-bool step_fused_fits(int nblk, int wide, int num_cu);
+bool step_fused_fits(int nblk, int slab_len, int num_cu);
 hipError_t launch_ppo_step(const ReduceArgs& r, const AdamArgs& ad, unsigned long long* words, unsigned int* gen,
                            unsigned int* sweep_error, unsigned long long timeout, hipStream_t st);
 hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s);

@@ -952,20 +952,22 @@ hipError_t launch_obs_planes(const float* obs, int n, int D, int F, int fold, ui
 }
 
 // ---- slab reduction: grad[p] = sum_g slab[g][p] (fixed order), per-block sum of squares, minibatch statistics ----
-// grad[p] = sum_g slab[g][p] in a fixed order, per-block sum of squares, minibatch statistics, KL decision.
-// Every lane sums its group's slabs with 8 loads in flight, the group sums are folded through LDS in a fixed order; the
-// result is bit-reproducible run to run.
-// The slabs are summed in a FIXED tree that does not depend on the block shape: RED_SUB = 16 consecutive ranges of slabs, each
-// with eight interleaved accumulators folded pairwise; four consecutive range sums chained into a quarter sum A_g; the total is
-// (A_0 + A_1) + (A_2 + A_3).  Two block shapes walk that tree (the 256-lane one keeps its quarter sums in registers: its LDS
-// footprint must stay within the 4.4 KB two resident gradient workgroups leave free on a CU):
-//   GROUPS = 4  (64 parameters x 4 lanes-groups = 256 lanes, each group takes four ranges in turn): one wave per SIMD at 42 VGPRs
-//               fits into the registers two resident gradient workgroups leave free, so the reduce blocks of one learner run
-//               beside the OTHER learner's gradient launch instead of waiting for a whole CU to drain (ph_ppo_train_multi:
-//               4.74 -> 4.10 ms per bench iteration when this was introduced);
-//   GROUPS = 16 (1024 lanes, one range per group): four times the loads in flight -- for a learner that has the device to itself
-//               (ph_ppo_train, one agent per GPU), where the reduce sits on the critical path between two gradient launches.
-// Both give bitwise the same gradient (same tree), so ph_ppo_train and ph_ppo_train_multi keep producing identical results.
+// The slabs are summed in ONE FIXED tree per slab position, whatever lane layout walks it (bit-reproducible run to run, and
+// ph_ppo_train / ph_ppo_train_multi / the fused step launch give identical parameters):
+//   * RED_SUB = 16 consecutive ranges of per = ceil(nslab / 16) slabs;
+//   * inside a range, slab j goes to accumulator j % 8, every accumulator adds its slabs in increasing j (a slab past the end of a
+//     ragged range adds 0.0f); range sum = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+//   * four consecutive range sums chained into a quarter, A_g = ((s_4g + s_4g+1) + s_4g+2) + s_4g+3;  total (A_0 + A_1) + (A_2 + A_3).
+// A block is 256 lanes for 64 slab positions; wave w always holds the four ranges of quarter w.  What differs is how many ADJACENT
+// positions a lane carries (VEC), i.e. how wide its loads are and how many ranges of the quarter it walks in turn (4 / VEC):
+//   VEC = 1: 4-byte loads, four ranges in turn                              (slab lengths that are odd: canonical slabs of some specs);
+//   VEC = 2: 8-byte loads, two ranges in turn, 16 loads = 128 B in flight per lane -- 58 VGPRs: one wave of it still fits into the
+//            registers two resident gradient waves leave on a SIMD, so one learner's reduce blocks run beside the OTHER learner's
+//            gradient launch instead of waiting for a CU to drain (tests/test_kernel_resources.py);
+//   VEC = 4: 16-byte loads, one range per lane, 16 loads = 256 B in flight -- a learner that has the device to itself
+//            (ph_set_exclusive_device; the fused step launch), where the reduction sits on the critical path.
+// Round 3's layout (one position per lane, 64 B in flight) read the 17 MB of a bench minibatch in eight dependent rounds of
+// 256-byte wave accesses: latency, not bandwidth (9.5 us = 1.8 TB/s).
 constexpr int RED_PARAMS = 64, RED_SUB = 16, RED_SHIFT = 6;
 
 // clip_grad_norm_'s scaling and torch.optim.Adam's single-tensor update of ONE parameter (eps = 1e-5 default of SB3).  One
@@ -1004,60 +1006,118 @@ __device__ __forceinline__ float adam_update(float grad, const AdamScalars& k, f
 }
 // the slab sum of this block's 64 positions in the fixed tree: lane tid < 64 returns the gradient entry of position
 // blockIdx.x * 64 + tid (0 for padding) and the parameter it belongs to (dst, -1 = padding); other lanes return 0 / -1
-template <int GROUPS>
+template <int VEC>
+struct RedVec;
+template <>
+struct RedVec<1> { using T = float; };
+template <>
+struct RedVec<2> { using T = float2; };
+template <>
+struct RedVec<4> { using T = float4; };
+template <int VEC>
 __device__ __forceinline__ float reduce_positions(const ReduceArgs& a, float (*gsum)[RED_PARAMS], int* dst_out) {
-  const int tid = threadIdx.x;
-  // grp is wave-uniform (64 lanes = 64 parameters per group): as a scalar, the slab offsets are SALU work and the loads take an
-  // SGPR base + one 32-bit lane offset -- no 64-bit address per load in flight
-  const int pl = tid & (RED_PARAMS - 1), grp = __builtin_amdgcn_readfirstlane(tid >> RED_SHIFT);
-  const int p = blockIdx.x * RED_PARAMS + pl;   // slab position
-  {
+  static_assert(VEC == 1 || VEC == 2 || VEC == 4, "positions per lane");
+  using VT = typename RedVec<VEC>::T;
+  constexpr int LP = RED_PARAMS / VEC;   // lanes that cover the block's 64 positions
+  constexpr int TURNS = 4 / VEC;         // ranges of the wave's quarter a lane walks in turn
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> RED_SHIFT);
+  const int lp = lane % LP, gw = lane / LP;
+  const int p0 = blockIdx.x * RED_PARAMS + lp * VEC;   // first of this lane's VEC positions (slab_len % VEC == 0: all in or all out)
 #if defined(PH_EXP_REDUCE_NO_LOADS)
-    const int per = 0;
+  const int per = 0;
 #else
-    const int per = (a.nslab + RED_SUB - 1) / RED_SUB;
+  const int per = (a.nslab + RED_SUB - 1) / RED_SUB;
 #endif
-    float quarter = 0.f;
-#pragma unroll 1
-    for (int sub = grp * (RED_SUB / GROUPS); sub < (grp + 1) * (RED_SUB / GROUPS); ++sub) {
-      const int k0 = sub * per, k1 = (k0 + per < a.nslab) ? k0 + per : a.nslab;
-      float acc[8];
+  const bool full = per * RED_SUB == a.nslab;          // no ragged range (every bench shape): no predicates
+  const unsigned stride = (unsigned)a.slab_len * (unsigned)sizeof(float);   // nslab * stride < 4 GB (the launcher checks)
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.slabs), 0, (int)((unsigned)a.nslab * stride), 0x00020000);
+  float rs[TURNS][VEC];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-      if (p < a.slab_len) {
-        int k = k0;
-        for (; k + 15 < k1; k += 16) {   // two rounds of loads in flight; the adds keep the one-round-at-a-time order
-          float x0[8], x1[8];
+  for (int t = 0; t < TURNS; ++t)
 #pragma unroll
-          for (int u = 0; u < 8; ++u) x0[u] = a.slabs[(size_t)(k + u) * a.slab_len + p];
+    for (int c = 0; c < VEC; ++c) rs[t][c] = 0.f;
+#pragma unroll 1   // one copy of the range walk: its registers are the kernel's (the 8-byte shape has 64 to stay within)
+  for (int turn = 0; turn < TURNS; ++turn) {
+    const int sub = wave * 4 + gw * TURNS + turn;
+    const int k0 = sub * per;
+    const int n = (k0 + per <= a.nslab ? per : a.nslab - k0);   // slabs of this lane's range (<= 0: none)
+    float acc[8][VEC];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) x1[u] = a.slabs[(size_t)(k + 8 + u) * a.slab_len + p];
+    for (int u = 0; u < 8; ++u)
 #pragma unroll
-          for (int u = 0; u < 8; ++u) acc[u] = (acc[u] + x0[u]) + x1[u];
+      for (int c = 0; c < VEC; ++c) acc[u][c] = 0.f;
+    if (p0 < a.slab_len) {
+      // buffer loads: descriptor + one 32-bit lane offset (range start + position) + a scalar offset (slab j of the range) --
+      // no 64-bit address per load in flight (flat loads cost the 8-byte shape 32 VGPRs of addresses)
+      const unsigned lane_off = (unsigned)k0 * stride + (unsigned)p0 * (unsigned)sizeof(float);
+      auto ld = [&](int j) -> VT {
+        if constexpr (VEC == 4) return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, (unsigned)j * stride, 0));
+        else if constexpr (VEC == 2) return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_off, (unsigned)j * stride, 0));
+        else return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off, (unsigned)j * stride, 0));
+      };
+      auto add = [&](float (&dst)[VEC], const VT& x) {
+        const float* xv = reinterpret_cast<const float*>(&x);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) dst[c] += xv[c];
+      };
+      int j = 0;
+      if (full) {
+        for (; j + 15 < per; j += 16) {   // two rounds of loads in flight; the adds keep the one-round-at-a-time order
+          VT x0[8], x1[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x0[u] = ld(j + u);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x1[u] = ld(j + 8 + u);
+          if constexpr (VEC == 4) __builtin_amdgcn_sched_barrier(0);   // all sixteen in flight (the scheduler otherwise rolls a window of eight)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) add(acc[u], x0[u]);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) add(acc[u], x1[u]);
         }
-        for (; k + 7 < k1; k += 8) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) acc[u] += a.slabs[(size_t)(k + u) * a.slab_len + p];
-        }
-        for (; k < k1; ++k) acc[0] += a.slabs[(size_t)k * a.slab_len + p];
       }
-      const float range = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-      quarter = (sub & 3) == 0 ? range : quarter + range;   // A_g = ((s_4g + s_4g+1) + s_4g+2) + s_4g+3
+      for (; j < per; j += 8) {           // ragged ranges, and the tail of a full one: a slab past the range's end adds 0
+        VT x0[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          x0[u] = VT{};
+          if (j + u < n) x0[u] = ld(j + u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) add(acc[u], x0[u]);
+      }
     }
-    gsum[grp][pl] = quarter;   // GROUPS = 4: A_grp; GROUPS = 16: one range sum
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      const float range = ((acc[0][c] + acc[1][c]) + (acc[2][c] + acc[3][c])) + ((acc[4][c] + acc[5][c]) + (acc[6][c] + acc[7][c]));
+#pragma unroll
+      for (int t = 0; t < TURNS; ++t) rs[t][c] = (turn == t) ? range : rs[t][c];   // turn is uniform: a scalar select
+    }
+  }
+  // quarter of this wave: the chain over its four ranges -- range 4 w + g * TURNS + turn sits in lane group g, slot turn
+  {
+    float q[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) q[c] = rs[0][c];
+#pragma unroll
+    for (int g = 0; g < VEC; ++g)
+#pragma unroll
+      for (int turn = 0; turn < TURNS; ++turn) {
+        if (g == 0 && turn == 0) continue;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) q[c] += (g == 0) ? rs[turn][c] : __shfl(rs[turn][c], lp + g * LP, 64);
+      }
+    if (gw == 0) {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) gsum[wave][lp * VEC + c] = q[c];
+    }
   }
   __syncthreads();
   float g = 0.f;
   int dst = -1;
-  if (tid < RED_PARAMS) {  // wave 0: fold the group sums
-    if constexpr (GROUPS == 4) {
-      g = (gsum[0][tid] + gsum[1][tid]) + (gsum[2][tid] + gsum[3][tid]);
-    } else {
-      float q4[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) q4[j] = ((gsum[4 * j][tid] + gsum[4 * j + 1][tid]) + gsum[4 * j + 2][tid]) + gsum[4 * j + 3][tid];
-      g = (q4[0] + q4[1]) + (q4[2] + q4[3]);
-    }
+  if (tid < RED_PARAMS) {  // wave 0: fold the quarters
+    const int p = blockIdx.x * RED_PARAMS + tid;
+    g = (gsum[0][tid] + gsum[1][tid]) + (gsum[2][tid] + gsum[3][tid]);
     // canonical slabs: position = parameter index; register-order slabs (ppo_grad_fast_kernel): through the table
     dst = p < a.slab_len ? (a.map ? a.map[p] : p) : -1;
     if (dst >= 0) {
@@ -1118,9 +1178,9 @@ __device__ __forceinline__ bool reduce_statistics(const ReduceArgs& a, float (*p
   return stop;
 }
 
-template <int GROUPS>
-__global__ __launch_bounds__(RED_PARAMS * GROUPS) void ppo_reduce_kernel(ReduceArgs a) {
-  __shared__ float gsum[GROUPS][RED_PARAMS];
+template <int VEC>
+__global__ __launch_bounds__(RED_PARAMS * 4) void ppo_reduce_kernel(ReduceArgs a) {
+  __shared__ float gsum[4][RED_PARAMS];
   __shared__ float part[32][NSTATP];
   __shared__ float means[NSTATP];
   const int tid = threadIdx.x;
@@ -1133,7 +1193,7 @@ __global__ __launch_bounds__(RED_PARAMS * GROUPS) void ppo_reduce_kernel(ReduceA
     return;
   }
   int dst;
-  const float g = reduce_positions<GROUPS>(a, gsum, &dst);
+  const float g = reduce_positions<VEC>(a, gsum, &dst);
   if (tid < 64) {  // wave 0: store, square, wave-reduce
     if (dst >= 0) a.grad[dst] = g;
     float q = g * g;
@@ -1160,9 +1220,9 @@ struct StepArgs {
   unsigned long long timeout;  // wall_clock64 ticks
   unsigned int* sweep_error;
 };
-template <int GROUPS>
-__global__ __launch_bounds__(RED_PARAMS * GROUPS) void ppo_step_kernel(StepArgs s) {
-  __shared__ float gsum[GROUPS][RED_PARAMS];
+template <int VEC>
+__global__ __launch_bounds__(RED_PARAMS * 4) void ppo_step_kernel(StepArgs s) {
+  __shared__ float gsum[4][RED_PARAMS];
   __shared__ float part[32][NSTATP];
   __shared__ float means[NSTATP];
   const ReduceArgs& a = s.r;
@@ -1180,7 +1240,7 @@ __global__ __launch_bounds__(RED_PARAMS * GROUPS) void ppo_step_kernel(StepArgs 
   const unsigned tag = *s.gen + 1u;
   const int step_new = *ad.step + 1;
   int dst;
-  const float g = reduce_positions<GROUPS>(a, gsum, &dst);
+  const float g = reduce_positions<VEC>(a, gsum, &dst);
   if (tid < 64) {
     float q = g * g;
     for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
@@ -1261,16 +1321,20 @@ __global__ __launch_bounds__(RED_PARAMS * GROUPS) void ppo_step_kernel(StepArgs 
 }
 
 int reduce_blocks(int slab_len) { return (slab_len + RED_PARAMS - 1) / RED_PARAMS; }
+// positions per lane of the reduction (see reduce_positions): the widest load the slab length allows, 16 bytes only for a learner
+// that has the device to itself (beside another learner's gradient launch the 8-byte shape's register count is what fits)
+static int reduce_vec(int slab_len, int exclusive) { return (slab_len % 4 == 0 && exclusive) ? 4 : (slab_len % 2 == 0 ? 2 : 1); }
 // Can the fused step kernel run this grid with every block resident (its blocks wait for each other)?  The runtime's occupancy
 // answer for the kernel on the current device, one block per CU held back (the API can be one high: MI355X_MICROARCH.md).
-bool step_fused_fits(int nblk, int wide, int num_cu) {
+bool step_fused_fits(int nblk, int slab_len, int num_cu) {
   if (nblk + 1 > 64 * 16) return false;
-  static int per_cu[2] = {-1, -1};
-  int& v = per_cu[wide ? 1 : 0];
+  static int per_cu[3] = {-1, -1, -1};
+  const int vec = reduce_vec(slab_len, 1);
+  int& v = per_cu[vec == 4 ? 2 : vec - 1];
   if (v < 0) {
     int api = 0;
-    hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, (const void*)ppo_step_kernel<16>, RED_PARAMS * 16, 0)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, (const void*)ppo_step_kernel<4>, RED_PARAMS * 4, 0);
+    const void* fn = vec == 4 ? (const void*)ppo_step_kernel<4> : vec == 2 ? (const void*)ppo_step_kernel<2> : (const void*)ppo_step_kernel<1>;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, fn, RED_PARAMS * 4, 0);
     v = (e == hipSuccess && api > 1) ? api - 1 : 0;
   }
   return (long long)v * num_cu >= (long long)nblk;
@@ -1285,13 +1349,23 @@ hipError_t launch_ppo_step(const ReduceArgs& r, const AdamArgs& ad, unsigned lon
   s.timeout = timeout;
   s.sweep_error = sweep_error;
   const int nblk = reduce_blocks(r.slab_len);
-  if (r.wide) hipLaunchKernelGGL(ppo_step_kernel<16>, dim3(nblk), dim3(RED_PARAMS * 16), 0, st, s);
-  else hipLaunchKernelGGL(ppo_step_kernel<4>, dim3(nblk), dim3(RED_PARAMS * 4), 0, st, s);
+  if ((unsigned long long)r.nslab * (unsigned long long)r.slab_len * sizeof(float) >= (1ull << 32)) return hipErrorInvalidValue;
+  switch (reduce_vec(r.slab_len, 1)) {
+    case 4: hipLaunchKernelGGL(ppo_step_kernel<4>, dim3(nblk), dim3(RED_PARAMS * 4), 0, st, s); break;
+    case 2: hipLaunchKernelGGL(ppo_step_kernel<2>, dim3(nblk), dim3(RED_PARAMS * 4), 0, st, s); break;
+    default: hipLaunchKernelGGL(ppo_step_kernel<1>, dim3(nblk), dim3(RED_PARAMS * 4), 0, st, s); break;
+  }
   return hipGetLastError();
 }
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s) {
-  if (a.wide) hipLaunchKernelGGL(ppo_reduce_kernel<16>, dim3(reduce_blocks(a.slab_len)), dim3(RED_PARAMS * 16), 0, s, a);
-  else hipLaunchKernelGGL(ppo_reduce_kernel<4>, dim3(reduce_blocks(a.slab_len)), dim3(RED_PARAMS * 4), 0, s, a);
+  const dim3 grid(reduce_blocks(a.slab_len)), block(RED_PARAMS * 4);
+  // 32-bit buffer offsets (the largest slab area of any shape in use: 512 x 177 KB = 90 MB)
+  if ((unsigned long long)a.nslab * (unsigned long long)a.slab_len * sizeof(float) >= (1ull << 32)) return hipErrorInvalidValue;
+  switch (reduce_vec(a.slab_len, a.wide)) {
+    case 4: hipLaunchKernelGGL(ppo_reduce_kernel<4>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(ppo_reduce_kernel<2>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(ppo_reduce_kernel<1>, grid, block, 0, s, a); break;
+  }
   return hipGetLastError();
 }
 

@@ -55,7 +55,7 @@ def test_split_gradient_kernel_has_no_scratch_and_leaves_room_for_the_update_ker
         assert k["ScratchSize"] == 0 and k["VGPRs Spill"] == 0, (n, k)
         assert _alloc(k) <= 240, (n, k)
     bench = inst["_ZN2ph21ppo_grad_split_kernelILi6ELb1EEEvNS_8GradArgsE"]    # Overcooked: 6 logits, bias folded
-    reduce_k = ppo["_ZN2ph17ppo_reduce_kernelILi4EEEvNS_10ReduceArgsE"]     # the 256-lane shape ph_ppo_train_multi launches
+    reduce_k = ppo["_ZN2ph17ppo_reduce_kernelILi2EEEvNS_10ReduceArgsE"]     # the 8-byte-load shape learners that share a device launch
     adam_k = ppo["_ZN2ph15ppo_adam_kernelENS_8AdamArgsE"]
     grad_lds = 3 * 3 * 64 * 128 + 4 * (8 * (64 + 8) + 64 * 8 + 2 * 64 + 16 + 3 * 64 + 64)   # grad_split_lds_bytes(): 79 680 B, dynamic
     for other in (reduce_k, adam_k):
