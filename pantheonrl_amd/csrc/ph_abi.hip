@@ -56,6 +56,7 @@ struct ph_ctx {
   size_t blocksq_cap = 0;
   float* advstats = nullptr;
   size_t advstats_cap = 0;
+  const int* wimage_zeroed_for = nullptr;   // the map (= spec) the weight image's unbacked elements were last zeroed for
   bool exclusive = false;             // ph_set_exclusive_device: nothing else runs on the device beside this context's launches
   unsigned short* wimage = nullptr;   // split gradient kernel: pre-split weight fragments of the policy being trained (ph_split.h)
   double* advpart = nullptr;     // per-segment partial sums of the advantage statistics
@@ -71,6 +72,8 @@ struct ph_ctx {
   uint4* rec_pi = nullptr;   // (n_epochs, N)
   uint4* rec_vf = nullptr;
   size_t rec_cap = 0;        // elements of each
+  uint4* rowrec = nullptr;   // [rows][2] the per-row scalars packed by physical row (input of the record pass)
+  size_t rowrec_cap = 0;
   // the fused reduce + clip + Adam launch of an exclusive learner (ppo_step_kernel): one stamped word per block (+ 1), the
   // launch generation, the count of sweeps that timed out
   unsigned long long* step_words = nullptr;
@@ -320,7 +323,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (s.wimage_map) (void)hipFree(s.wimage_map);
     if (s.act_off) (void)hipFree(s.act_off);
   }
-  void* ptrs[] = {ctx->wimage, ctx->mw.act, ctx->mw.maps, ctx->mw.kl_sum, ctx->mw.scratch, ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->perm_phys, ctx->ximg, ctx->rec_pi, ctx->rec_vf, ctx->step_words, ctx->step_gen, ctx->scalars, ctx->stop_flag,
+  void* ptrs[] = {ctx->wimage, ctx->mw.act, ctx->mw.maps, ctx->mw.kl_sum, ctx->mw.scratch, ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->perm_phys, ctx->ximg, ctx->rec_pi, ctx->rec_vf, ctx->rowrec, ctx->step_words, ctx->step_gen, ctx->scalars, ctx->stop_flag,
                   ctx->adap_extra, ctx->adap_loss};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1469,7 +1472,13 @@ int rebuild_weight_image(ph_ctx* ctx, const ph::NetDims& nd, const float* params
     if (ctx->capturing) return fail("first split-kernel use inside graph capture: call it once outside capture first");
     PH_HIP(hipMalloc((void**)&ctx->wimage, (size_t)ph::WIMG_ELEMS * sizeof(unsigned short)));
   }
-  PH_HIP(hipMemsetAsync(ctx->wimage, 0, (size_t)ph::WIMG_ELEMS * sizeof(unsigned short), ctx->stream));
+  // Elements no parameter backs are written by nobody (weight_image_kernel / ppo_adam_kernel go through the map), so they are
+  // zeroed when the image starts serving a spec, i.e. a map, not before every call (a 4.5 us fill node in every iteration graph)
+  if (ctx->wimage_zeroed_for != nd.wimage_map) {
+    if (ctx->capturing) return fail("the weight image changes its spec inside graph capture: run the same call once outside capture first");
+    PH_HIP(hipMemsetAsync(ctx->wimage, 0, (size_t)ph::WIMG_ELEMS * sizeof(unsigned short), ctx->stream));
+    ctx->wimage_zeroed_for = nd.wimage_map;
+  }
   PH_HIP(ph::launch_weight_image(params, ctx->wimage, nd.wimage_map, nd.lay.P, ctx->stream));
   return 0;
 }
@@ -1482,10 +1491,11 @@ int build_grad_pack(ph_ctx* ctx, const ph::NetDims& nd, const ph_rollout* rb, si
   const size_t rows = (size_t)rb->T * rb->E;
   const size_t need_img = (rows + 1) * ph::XIMG_ROW_U4;
   if (ctx->capturing) {
-    if (need_img > ctx->ximg_cap || n_rec > ctx->rec_cap)
+    if (need_img > ctx->ximg_cap || n_rec > ctx->rec_cap || 2 * rows > ctx->rowrec_cap)
       return fail("workspace would grow inside graph capture: run the same call once outside capture first");
   } else {
     if (ensure(ctx->ximg, ctx->ximg_cap, need_img)) return 1;
+    if (ensure(ctx->rowrec, ctx->rowrec_cap, 2 * rows)) return 1;
     if (n_rec > ctx->rec_cap) {
       size_t c1 = ctx->rec_cap, c2 = ctx->rec_cap;
       if (ensure(ctx->rec_pi, c1, n_rec)) return 1;
@@ -1493,12 +1503,14 @@ int build_grad_pack(ph_ctx* ctx, const ph::NetDims& nd, const ph_rollout* rb, si
       ctx->rec_cap = n_rec;
     }
   }
-  PH_HIP(ph::launch_obs_planes(rb->observations, (int)rows, nd.D, nd.F, ph::grad_fast_fold(nd) ? 1 : 0, ctx->ximg, ctx->stream));
+  PH_HIP(ph::launch_obs_planes(rb->observations, (int)rows, nd.D, nd.F, ph::grad_fast_fold(nd) ? 1 : 0, ctx->ximg, rb->advantages,
+                               rb->log_probs, rb->actions, rb->returns, rb->values, ctx->rowrec, ctx->stream));
   return 0;
 }
 void fill_adv_records(ph::AdvStatArgs& aa, const ph_ctx* ctx, const ph::NetDims& nd, const ph_rollout* rb) {
   aa.rec_pi_out = nd.split ? ctx->rec_pi : nullptr;
   aa.rec_vf_out = nd.split ? ctx->rec_vf : nullptr;
+  aa.rowrec = (nd.split && rb->advantages && rb->log_probs && rb->actions && rb->returns && rb->values) ? ctx->rowrec : nullptr;
   aa.rb_logp = rb->log_probs;
   aa.rb_act = rb->actions;
   aa.rb_ret = rb->returns;
@@ -1673,11 +1685,11 @@ int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_s
                       (size_t)n_epochs * t.N))
     return 1;
   hipStream_t s = ctx->stream;
-  PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
   if (rebuild_weight_image(ctx, t.nd, opt->params)) return 1;
   if (build_grad_pack(ctx, t.nd, rb, (size_t)n_epochs * t.N)) return 1;
   t.hb = ph::feistel_half_bits((uint32_t)t.N);
   ph::AdvStatArgs aa;
+  aa.clear_flag = ctx->stop_flag;    // the call's KL stop flag starts at 0 (no launch of its own: nothing reads it before the first gradient launch)
   aa.rb_adv = rb->advantages;
   aa.T = rb->T;
   aa.E = rb->E;

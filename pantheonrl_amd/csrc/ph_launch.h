@@ -194,6 +194,8 @@ struct AdvStatArgs {
   uint4* rec_pi_out = nullptr;   // (n_epochs, N) {phys, advantage, old log-prob, action}
   uint4* rec_vf_out = nullptr;   // (n_epochs, N) {phys, return, old value, 0}
   const float *rb_logp = nullptr, *rb_act = nullptr, *rb_ret = nullptr, *rb_val = nullptr;   // read only when the records are written (action length 1)
+  const uint4* rowrec = nullptr; // [T*E][2] the same scalars packed by physical row (obs_planes_kernel), or null: gather from the arrays
+  int* clear_flag = nullptr;     // set to 0 by the launch (the train() call's KL stop flag), or null
 };
 
 struct ReduceArgs {
@@ -388,7 +390,8 @@ hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);
 // observation rows (n, D) f32 -> the split kernel's plane image [n + 1][3][64] bf16 (features >= F zero; with `fold` feature 63 is
 // 1: the first layer's bias rides as a feature; row n all zero)
 constexpr int XIMG_ROW_U4 = 24;   // uint4 granules per image row: 3 planes x 8
-hipError_t launch_obs_planes(const float* obs, int n, int D, int F, int fold, uint4* image, hipStream_t s);
+hipError_t launch_obs_planes(const float* obs, int n, int D, int F, int fold, uint4* image, const float* adv, const float* logp,
+                             const float* act, const float* ret, const float* val, uint4* rowrec, hipStream_t s);
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s);
 int reduce_blocks(int slab_len);
 // reduce + clip + Adam as one launch (ppo_step_kernel): `words` [reduce_blocks + 1] and `gen` are workspace that persists across

@@ -837,6 +837,7 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
   const int nb = (a.N - start < a.batch) ? a.N - start : a.batch;
   const uint64_t key = epoch_key(a.perm_seed + (a.epoch ? *a.epoch : 0ull), ep);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (a.clear_flag && blockIdx.x == 0 && tid == 0) *a.clear_flag = 0;
   const int chunk = (nb + ADV_SPLIT - 1) / ADV_SPLIT;
   const int lo = seg * chunk, hi = (lo + chunk < nb) ? lo + chunk : nb;
   auto value = [&](int i) -> double {
@@ -850,11 +851,20 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
     }
     const int phys = env_major_to_phys(n, a.T, a.E);
     if (a.phys_out) a.phys_out[(size_t)ep * a.N + start + i] = phys;
-    const float adv = a.rb_adv[phys];
-    if (a.rec_pi_out) {   // the five per-row scalars of the gradient launches, gathered once per train() instead of once per launch
+    float adv;
+    if (a.rec_pi_out && a.rowrec) {   // the row's scalars from the packed table obs_planes_kernel wrote (same bits as the arrays)
+      const uint4 rp = a.rowrec[2 * (size_t)phys], rv = a.rowrec[2 * (size_t)phys + 1];
       const size_t o = (size_t)ep * a.N + start + i;
-      a.rec_pi_out[o] = make_uint4((unsigned)phys, __float_as_uint(adv), __float_as_uint(a.rb_logp[phys]), __float_as_uint(a.rb_act[phys]));
-      a.rec_vf_out[o] = make_uint4((unsigned)phys, __float_as_uint(a.rb_ret[phys]), __float_as_uint(a.rb_val[phys]), 0u);
+      adv = __uint_as_float(rp.x);
+      a.rec_pi_out[o] = make_uint4((unsigned)phys, rp.x, rp.y, rp.z);
+      a.rec_vf_out[o] = make_uint4((unsigned)phys, rv.x, rv.y, 0u);
+    } else {
+      adv = a.rb_adv[phys];
+      if (a.rec_pi_out) {   // the five per-row scalars of the gradient launches, gathered once per train() instead of once per launch
+        const size_t o = (size_t)ep * a.N + start + i;
+        a.rec_pi_out[o] = make_uint4((unsigned)phys, __float_as_uint(adv), __float_as_uint(a.rb_logp[phys]), __float_as_uint(a.rb_act[phys]));
+        a.rec_vf_out[o] = make_uint4((unsigned)phys, __float_as_uint(a.rb_ret[phys]), __float_as_uint(a.rb_val[phys]), 0u);
+      }
     }
     return (double)adv;
   };
@@ -914,8 +924,12 @@ hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s) {
 // features and stores three 16-byte plane granules (8 lanes = one 128-byte plane row).  Reads 4 D and writes 384 bytes per row:
 // HBM-bound.
 constexpr int OP_ROWS = 32;
+struct RowScalars {   // the rollout buffer's per-row scalars (action length 1), or all null
+  const float *adv, *logp, *act, *ret, *val;
+  uint4* rowrec;      // [n][2]: {advantage, old log-prob, action, 0} {return, old value, 0, 0} by physical row
+};
 __global__ __launch_bounds__(256) void obs_planes_kernel(const float* __restrict__ obs, int n, int D, int F, int fold,
-                                                         uint4* __restrict__ image) {
+                                                         uint4* __restrict__ image, RowScalars rs) {
   __shared__ float xs[OP_ROWS][65];
   const int tid = threadIdx.x;
   const size_t row0 = (size_t)blockIdx.x * OP_ROWS;
@@ -929,6 +943,14 @@ __global__ __launch_bounds__(256) void obs_planes_kernel(const float* __restrict
   const int r = tid >> 3, g = tid & 7;
   const size_t row = row0 + r;
   if (row > (size_t)n) return;
+  // the row's five scalars side by side (32 bytes): adv_stats_kernel then builds a minibatch-order record from ONE random 32-byte
+  // read of this L2-sized table instead of five random 4-byte reads that each pull a line
+  if (rs.rowrec && row < (size_t)n && g < 2) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (g == 0) v = make_uint4(__float_as_uint(rs.adv[row]), __float_as_uint(rs.logp[row]), __float_as_uint(rs.act[row]), 0u);
+    else v = make_uint4(__float_as_uint(rs.ret[row]), __float_as_uint(rs.val[row]), 0u, 0u);
+    rs.rowrec[2 * row + g] = v;
+  }
   typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
   bf8 pl[3];
 #pragma unroll
@@ -945,9 +967,11 @@ __global__ __launch_bounds__(256) void obs_planes_kernel(const float* __restrict
 #pragma unroll
   for (int p = 0; p < 3; ++p) image[row * XIMG_ROW_U4 + p * 8 + g] = __builtin_bit_cast(uint4, pl[p]);
 }
-hipError_t launch_obs_planes(const float* obs, int n, int D, int F, int fold, uint4* image, hipStream_t s) {
+hipError_t launch_obs_planes(const float* obs, int n, int D, int F, int fold, uint4* image, const float* adv, const float* logp,
+                             const float* act, const float* ret, const float* val, uint4* rowrec, hipStream_t s) {
   const size_t blocks = ((size_t)n + 1 + OP_ROWS - 1) / OP_ROWS;   // rows 0 .. n (row n = the zero row)
-  hipLaunchKernelGGL(obs_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, obs, n, D, F, fold, image);
+  RowScalars rs{adv, logp, act, ret, val, (adv && logp && act && ret && val) ? rowrec : nullptr};
+  hipLaunchKernelGGL(obs_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, obs, n, D, F, fold, image, rs);
   return hipGetLastError();
 }
 
@@ -987,20 +1011,27 @@ __device__ __forceinline__ AdamScalars adam_scalars(float total_norm, float max_
   k.bc2s = (float)sqrt(bc2);
   return k;
 }
-__device__ __forceinline__ float adam_update(float grad, const AdamScalars& k, float beta1, float beta2, float eps, float* m_p,
-                                             float* v_p, float* param_p) {
+// value form: the caller fetched m0 / v0 / p0 (possibly long before the clip coefficient is known) and stores the results
+__device__ __forceinline__ float adam_apply(float grad, const AdamScalars& k, float beta1, float beta2, float eps, float m0, float v0,
+                                            float p0, float* m_out, float* v_out) {
 #pragma clang fp contract(off)
   const float g = grad * k.coef;
-  const float m0 = *m_p, v0 = *v_p;
   const float d = g - m0;
   const float m = m0 + d * (1.0f - beta1);                 // exp_avg.lerp_(grad, 1-beta1)
   const float gg = g * g;
   const float v = v0 * beta2 + (1.0f - beta2) * gg;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
   const float denom = sqrtf(v) / k.bc2s + eps;
+  *m_out = m;
+  *v_out = v;
+  const float step = k.ss * (m / denom);
+  return p0 - step;                                        // param.addcdiv_(exp_avg, denom, -step_size)
+}
+__device__ __forceinline__ float adam_update(float grad, const AdamScalars& k, float beta1, float beta2, float eps, float* m_p,
+                                             float* v_p, float* param_p) {
+  float m, v;
+  const float pn = adam_apply(grad, k, beta1, beta2, eps, *m_p, *v_p, *param_p, &m, &v);
   *m_p = m;
   *v_p = v;
-  const float step = k.ss * (m / denom);
-  const float pn = *param_p - step;                        // param.addcdiv_(exp_avg, denom, -step_size)
   *param_p = pn;
   return pn;
 }
@@ -1123,8 +1154,16 @@ __device__ __forceinline__ float reduce_positions(const ReduceArgs& a, float (*g
     if (dst >= 0) {
       if (a.n_extra > 0) {   // the additional term's slabs, fixed order
         const int e = dst < a.extra_cut ? dst : ((dst >= a.extra_lo && dst < a.extra_hi) ? a.extra_cut + (dst - a.extra_lo) : -1);
-        if (e >= 0)
-          for (int k = 0; k < a.n_extra; ++k) g += a.extra[(size_t)k * a.extra_len + e];
+        if (e >= 0) {
+          for (int k0 = 0; k0 < a.n_extra; k0 += 8) {   // loads batched, adds in slab order
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = (k0 + u < a.n_extra) ? a.extra[(size_t)(k0 + u) * a.extra_len + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (k0 + u < a.n_extra) g += x[u];
+          }
+        }
       }
     } else {
       g = 0.f;
@@ -1140,7 +1179,19 @@ __device__ __forceinline__ bool reduce_statistics(const ReduceArgs& a, float (*p
   if (tid < 256) {  // 32 lanes per statistic, strided over the workgroup partials, then a fixed-order fold
     const int kst = tid & (NSTATP - 1), j = tid >> 3;
     float v = 0.f;
-    for (int w = j; w < a.nstatpart; w += 32) v += a.statpart[(size_t)w * NSTATP + kst];
+    // sixteen loads in flight per lane (the bench shape's 512 partial records: ONE round trip; written as `v += load` the compiler
+    // waits for every load before it issues the next -- 16 dependent round trips, which made this block the long pole of the launch)
+    for (int w0 = j; w0 < a.nstatpart; w0 += 32 * 16) {
+      float x[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int w = w0 + 32 * u;
+        x[u] = (w < a.nstatpart) ? a.statpart[(size_t)w * NSTATP + kst] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (w0 + 32 * u < a.nstatpart) v += x[u];
+    }
     part[j][kst] = v;
   }
   __syncthreads();
@@ -1169,7 +1220,14 @@ __device__ __forceinline__ bool reduce_statistics(const ReduceArgs& a, float (*p
     }
     if (a.n_extra > 0) {   // raw additional term of this minibatch (adap_learn.py:313-320: loss += coeff * context_loss)
       float raw = 0.f;
-      for (int k = 0; k < a.n_extra; ++k) raw += a.extra_loss[k];
+      for (int k0 = 0; k0 < a.n_extra; k0 += 16) {   // loads batched, adds in index order
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = (k0 + u < a.n_extra) ? a.extra_loss[k0 + u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (k0 + u < a.n_extra) raw += x[u];
+      }
       raw *= a.extra_norm;
       if (a.extra_loss_out) *a.extra_loss_out = raw;
       if (a.stats_out) a.stats_out[5] += a.extra_coef * raw;
@@ -1192,6 +1250,10 @@ __global__ __launch_bounds__(RED_PARAMS * 4) void ppo_reduce_kernel(ReduceArgs a
     }
     return;
   }
+  if (blockIdx.x == gridDim.x - 1) {   // the extra block: minibatch statistics and the KL decision, beside the slab blocks
+    (void)reduce_statistics(a, part, means, true);
+    return;
+  }
   int dst;
   const float g = reduce_positions<VEC>(a, gsum, &dst);
   if (tid < 64) {  // wave 0: store, square, wave-reduce
@@ -1200,7 +1262,6 @@ __global__ __launch_bounds__(RED_PARAMS * 4) void ppo_reduce_kernel(ReduceArgs a
     for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
     if (tid == 0) a.blocksq[blockIdx.x] = q;
   }
-  if (blockIdx.x == 0) (void)reduce_statistics(a, part, means, true);  // block-uniform branch
 }
 
 // ---- reduce + clip + Adam as ONE launch (a learner that has the device to itself: the three launches of a minibatch step sit on
@@ -1227,7 +1288,7 @@ __global__ __launch_bounds__(RED_PARAMS * 4) void ppo_step_kernel(StepArgs s) {
   __shared__ float means[NSTATP];
   const ReduceArgs& a = s.r;
   const AdamArgs& ad = s.ad;
-  const int tid = threadIdx.x, nblk = gridDim.x;
+  const int tid = threadIdx.x, nblk = gridDim.x - 1;   // slab blocks; block nblk does the statistics
   if (*a.stop_flag != 0) {  // a previous minibatch of this train() call hit the KL early stop (stable for the whole launch)
     if (blockIdx.x == 0 && tid < PH_NSTAT && a.stats_out) a.stats_out[tid] = 0.f;
     if (blockIdx.x == 0 && tid == 0) {
@@ -1239,6 +1300,12 @@ __global__ __launch_bounds__(RED_PARAMS * 4) void ppo_step_kernel(StepArgs s) {
   // read before anything of this launch is published: block 0 advances both only after every block has published
   const unsigned tag = *s.gen + 1u;
   const int step_new = *ad.step + 1;
+  if (blockIdx.x == nblk) {   // the extra block: statistics + KL decision while the slab blocks reduce; its word carries `stop`
+    const bool stop = reduce_statistics(a, part, means, false);
+    if (tid == 0)
+      __hip_atomic_store(s.words + nblk, ((unsigned long long)tag << 32) | (stop ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   int dst;
   const float g = reduce_positions<VEC>(a, gsum, &dst);
   if (tid < 64) {
@@ -1248,12 +1315,19 @@ __global__ __launch_bounds__(RED_PARAMS * 4) void ppo_step_kernel(StepArgs s) {
       __hip_atomic_store(s.words + blockIdx.x, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(q), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (blockIdx.x == 0) {
-    const bool stop = reduce_statistics(a, part, means, false);
-    if (tid == 0)
-      __hip_atomic_store(s.words + nblk, ((unsigned long long)tag << 32) | (stop ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid >= 64) return;
+  // this lane's moments, parameter and image positions: fetched under the wait for the other blocks' words
+  float m0 = 0.f, v0 = 0.f, p0 = 0.f;
+  int i0 = -1, i1 = -1;
+  if (dst >= 0) {
+    m0 = ad.m[dst];
+    v0 = ad.v[dst];
+    p0 = ad.params[dst];
+    if (ad.wimage) {
+      i0 = ad.wimage_map[2 * dst];
+      i1 = ad.wimage_map[2 * dst + 1];
+    }
   }
-  if (tid >= 64) return;   // (block 0's other waves are past their last barrier)
   // Adam's bias corrections need the step count only: two double-precision pow() under the wait for the other blocks' words
   AdamScalars k = adam_scalars(0.f, ad.max_norm, step_new, ad.lr, ad.beta1, ad.beta2);
   // ---- wave 0: sweep the nblk + 1 words; lane l takes words l, l + 64, ... ----
@@ -1316,8 +1390,12 @@ __global__ __launch_bounds__(RED_PARAMS * 4) void ppo_step_kernel(StepArgs s) {
     k.coef = cc < 1.0f ? cc : 1.0f;
   }
   const int p = dst;
-  const float pn = adam_update(g, k, ad.beta1, ad.beta2, ad.eps, ad.m + p, ad.v + p, ad.params + p);
-  if (ad.wimage) wimage_put(ad.wimage, ad.wimage_map, p, pn);
+  float m, v;
+  const float pn = adam_apply(g, k, ad.beta1, ad.beta2, ad.eps, m0, v0, p0, &m, &v);
+  ad.m[p] = m;
+  ad.v[p] = v;
+  ad.params[p] = pn;
+  if (ad.wimage) wimage_put_at(ad.wimage, i0, i1, pn);
 }
 
 int reduce_blocks(int slab_len) { return (slab_len + RED_PARAMS - 1) / RED_PARAMS; }
@@ -1337,7 +1415,7 @@ bool step_fused_fits(int nblk, int slab_len, int num_cu) {
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, fn, RED_PARAMS * 4, 0);
     v = (e == hipSuccess && api > 1) ? api - 1 : 0;
   }
-  return (long long)v * num_cu >= (long long)nblk;
+  return (long long)v * num_cu >= (long long)nblk + 1;   // + the statistics block
 }
 hipError_t launch_ppo_step(const ReduceArgs& r, const AdamArgs& ad, unsigned long long* words, unsigned int* gen,
                            unsigned int* sweep_error, unsigned long long timeout, hipStream_t st) {
@@ -1351,14 +1429,14 @@ hipError_t launch_ppo_step(const ReduceArgs& r, const AdamArgs& ad, unsigned lon
   const int nblk = reduce_blocks(r.slab_len);
   if ((unsigned long long)r.nslab * (unsigned long long)r.slab_len * sizeof(float) >= (1ull << 32)) return hipErrorInvalidValue;
   switch (reduce_vec(r.slab_len, 1)) {
-    case 4: hipLaunchKernelGGL(ppo_step_kernel<4>, dim3(nblk), dim3(RED_PARAMS * 4), 0, st, s); break;
-    case 2: hipLaunchKernelGGL(ppo_step_kernel<2>, dim3(nblk), dim3(RED_PARAMS * 4), 0, st, s); break;
-    default: hipLaunchKernelGGL(ppo_step_kernel<1>, dim3(nblk), dim3(RED_PARAMS * 4), 0, st, s); break;
+    case 4: hipLaunchKernelGGL(ppo_step_kernel<4>, dim3(nblk + 1), dim3(RED_PARAMS * 4), 0, st, s); break;
+    case 2: hipLaunchKernelGGL(ppo_step_kernel<2>, dim3(nblk + 1), dim3(RED_PARAMS * 4), 0, st, s); break;
+    default: hipLaunchKernelGGL(ppo_step_kernel<1>, dim3(nblk + 1), dim3(RED_PARAMS * 4), 0, st, s); break;
   }
   return hipGetLastError();
 }
 hipError_t launch_ppo_reduce(const ReduceArgs& a, hipStream_t s) {
-  const dim3 grid(reduce_blocks(a.slab_len)), block(RED_PARAMS * 4);
+  const dim3 grid(reduce_blocks(a.slab_len) + 1), block(RED_PARAMS * 4);   // + the statistics block
   // 32-bit buffer offsets (the largest slab area of any shape in use: 512 x 177 KB = 90 MB)
   if ((unsigned long long)a.nslab * (unsigned long long)a.slab_len * sizeof(float) >= (1ull << 32)) return hipErrorInvalidValue;
   switch (reduce_vec(a.slab_len, a.wide)) {
@@ -1374,26 +1452,55 @@ __global__ __launch_bounds__(256) void ppo_adam_kernel(AdamArgs a) {
   __shared__ float sh[4];
   __shared__ AdamScalars ks;
   const int tid = threadIdx.x;
+  // everything this thread's entry needs goes out first: the gradient, the moments, the parameter and its image positions do not
+  // depend on the norm, so they travel under the sum of squares, the two pow() of the bias corrections and the barriers
+  const int p = blockIdx.x * blockDim.x + tid;
+  const bool live = p < a.P;
+  float gr = 0.f, m0 = 0.f, v0 = 0.f, p0 = 0.f;
+  int i0 = -1, i1 = -1;
+  if (live) {
+    gr = a.grad[p];
+    m0 = a.m[p];
+    v0 = a.v[p];
+    p0 = a.params[p];
+    if (a.wimage) {
+      i0 = a.wimage_map[2 * p];
+      i1 = a.wimage_map[2 * p + 1];
+    }
+  }
   if (a.scalars[1] == 0.f) {  // KL early stop (or already stopped): no optimizer step
     if (blockIdx.x == 0 && tid == 0 && a.scalars[2] != 0.f) *a.stop_flag = 1;
     return;
   }
+  const int step = (tid == 0) ? *a.step : 0;
   float q = 0.f;
-  for (int k = tid; k < a.nblk; k += blockDim.x) q += a.blocksq[k];
+  {   // this thread's entries of the per-block squares (k = tid, tid + 256, ...), loads batched, adds in index order
+    float x[4];
+    for (int k0 = tid; k0 < a.nblk; k0 += 4 * 256) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = (k0 + 256 * u < a.nblk) ? a.blocksq[k0 + 256 * u] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k0 + 256 * u < a.nblk) q += x[u];
+    }
+  }
   for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
   if ((tid & 63) == 0) sh[tid >> 6] = q;
   __syncthreads();
   if (tid == 0) {
     const float total = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3]));
-    ks = adam_scalars(total, a.max_norm, *a.step, a.lr, a.beta1, a.beta2);
+    ks = adam_scalars(total, a.max_norm, step, a.lr, a.beta1, a.beta2);
     if (blockIdx.x == 0 && a.stats_out) a.stats_out[6] = total;
   }
   __syncthreads();
-  const int p = blockIdx.x * blockDim.x + tid;
-  if (p >= a.P) return;
+  if (!live) return;
   const AdamScalars k = ks;
-  const float pn = adam_update(a.grad[p], k, a.beta1, a.beta2, a.eps, a.m + p, a.v + p, a.params + p);
-  if (a.wimage) wimage_put(a.wimage, a.wimage_map, p, pn);             // the split gradient kernel's pre-split weight fragments
+  float m, v;
+  const float pn = adam_apply(gr, k, a.beta1, a.beta2, a.eps, m0, v0, p0, &m, &v);
+  a.m[p] = m;
+  a.v[p] = v;
+  a.params[p] = pn;
+  if (a.wimage) wimage_put_at(a.wimage, i0, i1, pn);                    // the split gradient kernel's pre-split weight fragments
 }
 
 __global__ __launch_bounds__(256) void weight_image_kernel(const float* params, unsigned short* image, const int* map, int P) {

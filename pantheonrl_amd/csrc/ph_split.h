@@ -21,8 +21,8 @@ __device__ __forceinline__ void split1(float x, __bf16& h, __bf16& m, __bf16& l)
 // (W2 sits in two sets); `map` (P x 2 ints, -1 = none) holds the element index in plane 0, planes are WIMG_PLANE apart.
 // Elements no parameter backs (features >= F of W1) stay zero.  Maintained by ppo_adam_kernel after every step; rebuilt from the
 // parameters at the start of every train() / gradient call (weight_image_kernel).
-__device__ __forceinline__ void wimage_put(unsigned short* image, const int* map, int p, float x) {
-  const int p0 = map[2 * p], p1 = map[2 * p + 1];
+// the image positions (p0, p1 -- either may be -1) of a parameter already in hand
+__device__ __forceinline__ void wimage_put_at(unsigned short* image, int p0, int p1, float x) {
   if (p0 < 0 && p1 < 0) return;
   __bf16 h, m, l;
   split1(x, h, m, l);
@@ -38,6 +38,9 @@ __device__ __forceinline__ void wimage_put(unsigned short* image, const int* map
     image[p1 + WIMG_PLANE] = mb;
     image[p1 + 2 * WIMG_PLANE] = lb;
   }
+}
+__device__ __forceinline__ void wimage_put(unsigned short* image, const int* map, int p, float x) {
+  wimage_put_at(image, map[2 * p], map[2 * p + 1], x);
 }
 
 }  // namespace ph
