@@ -514,9 +514,43 @@ static hipError_t launch_fwd16_variant(const FwdArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_policy_fwd16_rollout(const FwdArgs& a, const ScriptedSteps& sc, int gemm_mode, hipStream_t s) {
+// A scripted rollout is a latency chain per workgroup, and a launch of E / 16 x 2 workgroups (128 at the bench size) covers half
+// the chip: when two learners' rollouts run side by side the dispatcher is free to put a workgroup of each on the SAME CU while
+// other CUs stay empty, and the two chains then share SIMDs for the whole launch (measured: 390 us alone, 440-470 us side by side).
+// Asking for more than half a CU's LDS makes a CU take ONE rollout workgroup, whoever launched it (same-box A/B 107.6 -> 109.7 M
+// agent-steps/s, profiles/r04_g_ab_hoist_spread.txt; PH_ROLLOUT_SPREAD=0 switches it off; only
+// for launches of at most #CUs / 2 workgroups, so that two of them still fit on the chip at once).
+static size_t rollout_lds_bytes(int nwg_total) {
+  static int spread = -1, num_cu[64] = {0};
+  if (spread < 0) {
+    const char* e = getenv("PH_ROLLOUT_SPREAD");
+    spread = (e && e[0] == '0') ? 0 : 1;
+  }
   const size_t lds = fwd16_lds_bytes();
+  if (!spread) return lds;
+  int& cu = num_cu[current_device_slot()];
+  if (cu == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = -1;
+  }
+  return (cu > 0 && 2 * nwg_total <= cu) ? (size_t)81 * 1024 + 512 : lds;
+}
+hipError_t launch_policy_fwd16_rollout(const FwdArgs& a, const ScriptedSteps& sc, int gemm_mode, hipStream_t s) {
   dim3 grid((a.n + 15) / 16, 2), block(256);
+  const size_t lds = rollout_lds_bytes((int)(grid.x * grid.y));
+  if (lds > 64 * 1024) {   // dynamic LDS above 64 KiB is opt-in, per kernel and device
+    static bool allowed_dev[2][64] = {{false}};
+    bool& allowed = allowed_dev[gemm_mode == 1 ? 1 : 0][current_device_slot()];
+    if (!allowed) {
+      hipError_t e = gemm_mode == 1 ? hipFuncSetAttribute((const void*)policy_fwd16_rollout_kernel<true>,
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                    : hipFuncSetAttribute((const void*)policy_fwd16_rollout_kernel<false>,
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      allowed = true;
+    }
+  }
   if (gemm_mode == 1) hipLaunchKernelGGL((policy_fwd16_rollout_kernel<true>), grid, block, lds, s, a, sc);
   else hipLaunchKernelGGL((policy_fwd16_rollout_kernel<false>), grid, block, lds, s, a, sc);
   return hipGetLastError();

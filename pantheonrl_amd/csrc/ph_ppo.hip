@@ -1045,8 +1045,16 @@ template <>
 struct RedVec<2> { using T = float2; };
 template <>
 struct RedVec<4> { using T = float4; };
+// the parameter slab position blockIdx.x * 64 + tid belongs to (wave 0; -1 = padding / other waves): fetched by the callers BEFORE
+// the slab walk -- the table lookup is a memory round trip of its own and nothing in it depends on the slabs
+__device__ __forceinline__ int reduce_dst(const ReduceArgs& a) {
+  const int tid = threadIdx.x;
+  if (tid >= RED_PARAMS) return -1;
+  const int p = blockIdx.x * RED_PARAMS + tid;
+  return p < a.slab_len ? (a.map ? a.map[p] : p) : -1;
+}
 template <int VEC>
-__device__ __forceinline__ float reduce_positions(const ReduceArgs& a, float (*gsum)[RED_PARAMS], int* dst_out) {
+__device__ __forceinline__ float reduce_positions(const ReduceArgs& a, float (*gsum)[RED_PARAMS], int dst) {
   static_assert(VEC == 1 || VEC == 2 || VEC == 4, "positions per lane");
   using VT = typename RedVec<VEC>::T;
   constexpr int LP = RED_PARAMS / VEC;   // lanes that cover the block's 64 positions
@@ -1145,12 +1153,9 @@ __device__ __forceinline__ float reduce_positions(const ReduceArgs& a, float (*g
   }
   __syncthreads();
   float g = 0.f;
-  int dst = -1;
   if (tid < RED_PARAMS) {  // wave 0: fold the quarters
-    const int p = blockIdx.x * RED_PARAMS + tid;
     g = (gsum[0][tid] + gsum[1][tid]) + (gsum[2][tid] + gsum[3][tid]);
-    // canonical slabs: position = parameter index; register-order slabs (ppo_grad_fast_kernel): through the table
-    dst = p < a.slab_len ? (a.map ? a.map[p] : p) : -1;
+    // (dst: canonical slabs: position = parameter index; register-order slabs (ppo_grad_fast_kernel): through the table)
     if (dst >= 0) {
       if (a.n_extra > 0) {   // the additional term's slabs, fixed order
         const int e = dst < a.extra_cut ? dst : ((dst >= a.extra_lo && dst < a.extra_hi) ? a.extra_cut + (dst - a.extra_lo) : -1);
@@ -1169,7 +1174,6 @@ __device__ __forceinline__ float reduce_positions(const ReduceArgs& a, float (*g
       g = 0.f;
     }
   }
-  *dst_out = dst;
   return g;
 }
 // minibatch statistics (means over the nb rows) and the KL decision, by one block (>= 256 threads); thread 0 returns `stop`
@@ -1254,8 +1258,8 @@ __global__ __launch_bounds__(RED_PARAMS * 4) void ppo_reduce_kernel(ReduceArgs a
     (void)reduce_statistics(a, part, means, true);
     return;
   }
-  int dst;
-  const float g = reduce_positions<VEC>(a, gsum, &dst);
+  const int dst = reduce_dst(a);
+  const float g = reduce_positions<VEC>(a, gsum, dst);
   if (tid < 64) {  // wave 0: store, square, wave-reduce
     if (dst >= 0) a.grad[dst] = g;
     float q = g * g;
@@ -1289,7 +1293,12 @@ __global__ __launch_bounds__(RED_PARAMS * 4) void ppo_step_kernel(StepArgs s) {
   const ReduceArgs& a = s.r;
   const AdamArgs& ad = s.ad;
   const int tid = threadIdx.x, nblk = gridDim.x - 1;   // slab blocks; block nblk does the statistics
-  if (*a.stop_flag != 0) {  // a previous minibatch of this train() call hit the KL early stop (stable for the whole launch)
+  // the three device words every block starts from, as one batch of scalar loads.  gen / step are read before anything of this
+  // launch is published: block 0 advances both only after every block has published
+  const int stopped = *a.stop_flag;
+  const unsigned tag = *s.gen + 1u;
+  const int step_new = *ad.step + 1;
+  if (stopped != 0) {  // a previous minibatch of this train() call hit the KL early stop (stable for the whole launch)
     if (blockIdx.x == 0 && tid < PH_NSTAT && a.stats_out) a.stats_out[tid] = 0.f;
     if (blockIdx.x == 0 && tid == 0) {
       a.scalars[1] = 0.f;
@@ -1297,26 +1306,15 @@ __global__ __launch_bounds__(RED_PARAMS * 4) void ppo_step_kernel(StepArgs s) {
     }
     return;
   }
-  // read before anything of this launch is published: block 0 advances both only after every block has published
-  const unsigned tag = *s.gen + 1u;
-  const int step_new = *ad.step + 1;
   if (blockIdx.x == nblk) {   // the extra block: statistics + KL decision while the slab blocks reduce; its word carries `stop`
     const bool stop = reduce_statistics(a, part, means, false);
     if (tid == 0)
       __hip_atomic_store(s.words + nblk, ((unsigned long long)tag << 32) | (stop ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  int dst;
-  const float g = reduce_positions<VEC>(a, gsum, &dst);
-  if (tid < 64) {
-    float q = g * g;
-    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
-    if (tid == 0)
-      __hip_atomic_store(s.words + blockIdx.x, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(q), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (tid >= 64) return;
-  // this lane's moments, parameter and image positions: fetched under the wait for the other blocks' words
+  // wave 0's lanes: the parameter behind their slab position, then its moments, value and image positions -- two dependent round
+  // trips that complete under the slab walk
+  const int dst = reduce_dst(a);
   float m0 = 0.f, v0 = 0.f, p0 = 0.f;
   int i0 = -1, i1 = -1;
   if (dst >= 0) {
@@ -1328,6 +1326,15 @@ __global__ __launch_bounds__(RED_PARAMS * 4) void ppo_step_kernel(StepArgs s) {
       i1 = ad.wimage_map[2 * dst + 1];
     }
   }
+  const float g = reduce_positions<VEC>(a, gsum, dst);
+  if (tid < 64) {
+    float q = g * g;
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+    if (tid == 0)
+      __hip_atomic_store(s.words + blockIdx.x, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(q), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid >= 64) return;
   // Adam's bias corrections need the step count only: two double-precision pow() under the wait for the other blocks' words
   AdamScalars k = adam_scalars(0.f, ad.max_norm, step_new, ad.lr, ad.beta1, ad.beta2);
   // ---- wave 0: sweep the nblk + 1 words; lane l takes words l, l + 64, ... ----
