@@ -1548,8 +1548,8 @@ int ensure_train_ws(ph_ctx* ctx, int P, int slab_len, int nwg_max, int n_mb_tota
     PH_HIP(hipMemsetAsync(ctx->step_words, 0, n_words * sizeof(unsigned long long), ctx->stream));
   }
   if (!ctx->step_gen) {
-    PH_HIP(hipMalloc((void**)&ctx->step_gen, 2 * sizeof(unsigned int)));
-    PH_HIP(hipMemsetAsync(ctx->step_gen, 0, 2 * sizeof(unsigned int), ctx->stream));
+    PH_HIP(hipMalloc((void**)&ctx->step_gen, 4 * sizeof(unsigned int)));   // generation, timed-out waits, -, -
+    PH_HIP(hipMemsetAsync(ctx->step_gen, 0, 4 * sizeof(unsigned int), ctx->stream));
   }
   return 0;
 }
@@ -1710,6 +1710,10 @@ int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_s
   return 0;
 }
 
+void fill_step_args(const TrainPlan& t, int mbi, const MbPlan& pl, ph::ReduceArgs& r, ph::AdamArgs& ad);
+// ~2 s of wall_clock64 ticks (100 MHz): the bound of a wait for a workgroup that cannot be scheduled, far above any healthy one
+constexpr unsigned long long STEP_WAIT_TICKS = 200000000ull;
+
 // gradient launch of minibatch mbi = ep * n_mb + k
 int train_launch_grad(const TrainPlan& t, int mbi, MbPlan* pl_out) {
   ph_ctx* ctx = t.ctx;
@@ -1735,16 +1739,14 @@ int train_launch_grad(const TrainPlan& t, int mbi, MbPlan* pl_out) {
   g.nb = nb;
   g.advstats = ctx->advstats + 2 * (size_t)mbi;
   g.ntiles = pl.ntiles;
-  PH_HIP(ph::launch_ppo_grad(g, pl.nwg, t.gemm_mode, ctx->stream));
   *pl_out = pl;
+  PH_HIP(ph::launch_ppo_grad(g, pl.nwg, t.gemm_mode, ctx->stream));
   return 0;
 }
 
-// slab reduction + statistics + KL decision, then clip + Adam, of the minibatch whose gradient launch returned `pl`
-int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
+// the argument records of minibatch mbi's reduce (+ statistics, KL decision) and clip + Adam
+void fill_step_args(const TrainPlan& t, int mbi, const MbPlan& pl, ph::ReduceArgs& r, ph::AdamArgs& ad) {
   ph_ctx* ctx = t.ctx;
-  hipStream_t s = ctx->stream;
-  ph::ReduceArgs r;
   r.slabs = ctx->slabs;
   r.nslab = pl.nwg;
   r.nstatpart = 2 * pl.nwg;
@@ -1763,15 +1765,6 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
   r.step = t.opt->step;
   r.scalars = ctx->scalars;
   r.wide = t.alone && ctx->exclusive;
-  if (t.adap) {
-    const int ep = mbi / t.n_mb, start = (mbi - ep * t.n_mb) * t.batch_size;
-    const int* idx = (t.perms ? t.perms : ctx->perm_idx) + (size_t)ep * t.N + start;
-    if (adap_launch(ctx, t.nd, t.opt->params, t.rb, t.adap, idx, pl.nb, mbi, &r)) return 1;
-  }
-  const bool fused = step_fused_wanted(ctx, slab_len_of(t.nd), t.alone != 0);
-  if (!fused) PH_HIP(ph::launch_ppo_reduce(r, s));
-
-  ph::AdamArgs ad;
   ad.params = t.opt->params;
   ad.m = t.opt->adam_m;
   ad.v = t.opt->adam_v;
@@ -1790,10 +1783,25 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
   ad.stats_out = r.stats_out;
   ad.wimage = t.nd.split ? ctx->wimage : nullptr;
   ad.wimage_map = t.nd.wimage_map;
+}
+
+// slab reduction + statistics + KL decision, then clip + Adam, of the minibatch whose gradient launch returned `pl`
+int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
+  ph_ctx* ctx = t.ctx;
+  hipStream_t s = ctx->stream;
+  ph::ReduceArgs r;
+  ph::AdamArgs ad;
+  fill_step_args(t, mbi, pl, r, ad);
+  if (t.adap) {
+    const int ep = mbi / t.n_mb, start = (mbi - ep * t.n_mb) * t.batch_size;
+    const int* idx = (t.perms ? t.perms : ctx->perm_idx) + (size_t)ep * t.N + start;
+    if (adap_launch(ctx, t.nd, t.opt->params, t.rb, t.adap, idx, pl.nb, mbi, &r)) return 1;
+  }
+  const bool fused = step_fused_wanted(ctx, slab_len_of(t.nd), t.alone != 0);
   if (fused) {
-    // ~2 s of wall_clock64 ticks (100 MHz): a bound for a block that cannot be scheduled, far above any healthy sweep
-    PH_HIP(ph::launch_ppo_step(r, ad, ctx->step_words, ctx->step_gen, ctx->step_gen + 1, 200000000ull, s));
+    PH_HIP(ph::launch_ppo_step(r, ad, ctx->step_words, ctx->step_gen, ctx->step_gen + 1, STEP_WAIT_TICKS, s));
   } else {
+    PH_HIP(ph::launch_ppo_reduce(r, s));
     PH_HIP(ph::launch_ppo_adam(ad, s));
   }
   return 0;

@@ -241,6 +241,17 @@ struct AdamArgs {
   const int* wimage_map;  // [P][2]
 };
 
+// reduce + clip + Adam of one minibatch as ONE launch (ph_step.h: step_body; ppo_step_kernel) for a learner that has its device
+// to itself
+struct StepArgs {
+  ReduceArgs r;
+  AdamArgs ad;
+  unsigned long long* words = nullptr;   // [slab blocks + 1] stamped {tag, value} words
+  unsigned int* gen = nullptr;           // launch generation (device word, advanced by block 0 at the end of every step)
+  unsigned long long timeout = 0;        // wall_clock64 ticks: bound of every wait
+  unsigned int* sweep_error = nullptr;   // count of waits that ran into the bound
+};
+
 size_t fwd_lds_bytes(int R, int Lp);
 size_t grad_lds_bytes(int R, int Lp, int onehot_D, int nchunk);
 hipError_t launch_policy_fwd(const FwdArgs& a, int gemm_mode, hipStream_t s);
