@@ -97,7 +97,7 @@ def main():
         "in_graph": None if not row_graph else {"avg_us": row_graph["avg_us"], "min_us": row_graph["min_us"],
                                                 "max_us": row_graph["max_us"], "calls": row_graph["calls"],
                                                 "source": f"{tag}_bench_graph_kernel_stats.txt (rocprofv3 --kernel-trace --stats -- "
-                                                          "python bench.py --no-cpu-baseline)"},
+                                                          "python bench.py --no-cpu-baseline --no-roofline --headline-only: the launches of the two-learner headline only; the profiler serialises the two learners' kernels)"},
         "isolated_under_pmc": row_iso,
         "sq": {**sq, "waves_per_launch": waves},
         "flops_per_launch_6M_convention": 6.0 * M * nb,
