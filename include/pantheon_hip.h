@@ -33,11 +33,12 @@
 extern "C" {
 #endif
 
-#define PH_ABI_VERSION 4   /* 2: + ph_agent_*, ph_bc_*, ph_adap_*, ph_scripted_rollout, ph_liar_selfplay_rollout, ph_roundrobin_env_step,
+#define PH_ABI_VERSION 5   /* 2: + ph_agent_*, ph_bc_*, ph_adap_*, ph_scripted_rollout, ph_liar_selfplay_rollout, ph_roundrobin_env_step,
                                   ph_buffer_compact_columns (additions only: every v1 signature is unchanged)
                               3: + ph_selfplay_rollout_persistent, PH_STEP_FIX_ILLEGAL / _MASK_ENV_ONLY, ph_modular_*, ph_roundrobin_*_iteration
                                   (additions only)
-                              4: + ph_selfplay_rollout_persistent_capacity, ph_ppo_train's gradient pack (no signature changed) */
+                              4: + ph_selfplay_rollout_persistent_capacity, ph_ppo_train's gradient pack (no signature changed)
+                              5: + ph_policy_act_host, ph_buffer_add_reward_const (additions only) */
 #define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
 #define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
 #define PH_MAX_LOGITS 64 /* max total policy logits L */
@@ -152,6 +153,9 @@ int ph_buffer_add(ph_ctx *ctx, const ph_spec *spec, const ph_rollout *rb, int po
 /* buf.rewards[pos][e] += reward[e] for e with env_mask[e] != 0 (NULL = all) <- Agent.update, agents.py:198 */
 int ph_buffer_add_reward(ph_ctx *ctx, const ph_rollout *rb, int pos, const float *reward /* (E) */,
                          const unsigned char *env_mask /* (E) or NULL */);
+/* Agent.update(reward, done) with a SCALAR reward (agents.py:198: buf.rewards[pos - 1][0] += reward; every environment of the
+ * row receives it): the value travels as a kernel argument -- no host array, no copy, nothing to wait for. */
+int ph_buffer_add_reward_const(ph_ctx *ctx, const ph_rollout *rb, int pos, float reward);
 /* Agent-per-GPU SimultaneousEnv step (multiagentenv.py:149-170 with the actions all-gathered over RCCL): seat `seat`
  * receives rewards[pos][e] += base_reward[e] + bonus * (joint[seat][e] == joint[*partner_seat][e]) -- the shared
  * coordination term of the synthetic transition, consuming the JOINT action.  joint_actions is (n_seats, E) int32;
@@ -256,6 +260,19 @@ int ph_policy_forward(ph_ctx *ctx, const ph_spec *spec, const float *params, con
                       float *actions_f32, float *values, float *log_probs, float *entropy, float *logits,
                       const ph_rollout *rb, int pos, const float *episode_start_in, const float *pending_reward,
                       int gemm_mode);
+
+/* The same call for an environment that lives on the HOST (the reference's own situation: one get_action per environment step,
+ * the action needed back before the environment can move -- agents.py:111-184, util.py:63-81): observations, episode starts and
+ * the three results are HOST arrays; the call stages them through pinned memory of the context, runs the forward (with the fused
+ * rollout-buffer write when rb != NULL, as above), copies the results back and returns when they are there.  One call and one
+ * synchronisation per environment step instead of several tensor operations; the sampled actions are bitwise those of
+ * ph_policy_forward with the same (seed, counter).
+ *   obs_host (n, D) f32; episode_start_host (n) f32 or NULL (required with rb); actions_host (n, A) i32; values_host (n);
+ *   log_probs_host (n) -- any output may be NULL. */
+int ph_policy_act_host(ph_ctx *ctx, const ph_spec *spec, const float *params, const float *obs_host, int n,
+                       const float *episode_start_host, unsigned long long seed, unsigned long long counter,
+                       int deterministic, int *actions_host, float *values_host, float *log_probs_host,
+                       const ph_rollout *rb, int pos, int gemm_mode);
 
 /* One environment step of SEVERAL local agents in one launch (agent-per-GPU self-play hosts two learners per GPU).
  * Each record is one agent's ph_policy_forward call with the fused rollout-buffer write; optionally the PREVIOUS step's

@@ -197,6 +197,8 @@ SIGNATURES = {
     "ph_gae": [_vp, C.POINTER(PhRollout), _vp, _vp, _d, _d, _i],
     "ph_policy_forward": [_vp, C.POINTER(PhSpec), _vp, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, _vp, _vp,
                           _vp, C.POINTER(PhRollout), _i, _vp, _vp, _i],
+    "ph_policy_act_host": [_vp, C.POINTER(PhSpec), _vp, _vp, _i, _vp, _ull, _ull, _i, _vp, _vp, _vp, C.POINTER(PhRollout), _i, _i],
+    "ph_buffer_add_reward_const": [_vp, C.POINTER(PhRollout), _i, C.c_float],
     "ph_policy_step_multi": [_vp, _i, C.POINTER(PhStepCall)],
     "ph_policy_forward_ragged": [_vp, C.POINTER(PhSpec), _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, C.POINTER(PhRollout),
                                  _vp, _vp, _vp],
@@ -298,7 +300,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.argtypes = argtypes
         fn.restype = C.c_char_p if name in ("ph_last_error", "ph_agent_last_error") else C.c_int
-    if lib.ph_abi_version() != 4:
+    if lib.ph_abi_version() != 5:
         raise NativeError("libpantheon_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -53,6 +53,8 @@ class AdapPolicy(ActorCriticPolicy):
     Discrete / MultiDiscrete environment the features are the one-hot encoding SB3's preprocess_obs builds: the rows this
     policy hands to the engine (and that the rollout buffer therefore stores) are the features, not the raw integers."""
 
+    host_step_path = False   # the rows are built on the device (features ++ context, _obs)
+
     def __init__(self, observation_space, action_space, context_size: int = 3, **kw):
         kind = sp._kind(observation_space)
         if kind == "Box":

@@ -92,7 +92,13 @@ class OnPolicyAgent(Agent):
         resample_noise(model, self.n_steps)
 
         fused = record and hasattr(model.policy, "forward_and_store")
-        if fused:  # forward + RolloutBuffer.add(reward=0) in one launch
+        if (fused and mask is None and getattr(model.policy, "host_step_path", False) and not isinstance(raw_obs, th.Tensor)
+                and isinstance(self._last_episode_starts, (list, tuple, np.ndarray))):
+            # the environment lives on the host (the reference's situation): one native call per step -- stage in, forward + row
+            # write, results out (ActorCriticPolicy.forward_and_store_host); same kernel and RNG stream as the general path
+            actions, values, log_probs = model.policy.forward_and_store_host(self._shape_obs(raw_obs, buf), buf,
+                                                                             self._last_episode_starts)
+        elif fused:  # forward + RolloutBuffer.add(reward=0) in one launch
             shaped = self._shape_obs(raw_obs, buf)
             act_t, values, log_probs = model.policy.forward_and_store(
                 shaped, buf, self._last_episode_starts,

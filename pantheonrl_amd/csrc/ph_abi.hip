@@ -56,6 +56,10 @@ struct ph_ctx {
   size_t blocksq_cap = 0;
   float* advstats = nullptr;
   size_t advstats_cap = 0;
+  // ph_policy_act_host: pinned host staging + its device mirror (observations in, actions / values / log-probs out)
+  float* act_stage_host = nullptr;
+  float* act_stage_dev = nullptr;
+  size_t act_stage_cap = 0;   // floats
   const int* wimage_zeroed_for = nullptr;   // the map (= spec) the weight image's unbacked elements were last zeroed for
   bool exclusive = false;             // ph_set_exclusive_device: nothing else runs on the device beside this context's launches
   unsigned short* wimage = nullptr;   // split gradient kernel: pre-split weight fragments of the policy being trained (ph_split.h)
@@ -327,6 +331,8 @@ int ph_ctx_destroy(ph_ctx* ctx) {
                   ctx->adap_extra, ctx->adap_loss};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (ctx->act_stage_dev) (void)hipFree(ctx->act_stage_dev);
+  if (ctx->act_stage_host) (void)hipHostFree(ctx->act_stage_host);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev_grad) (void)hipEventDestroy(ctx->ev_grad);
@@ -502,6 +508,15 @@ int ph_buffer_add_reward(ph_ctx* ctx, const ph_rollout* rb, int pos, const float
   if (pos < 0 || pos >= rb->T) return fail("ph_buffer_add_reward: pos out of range");
   if (!reward) return fail("ph_buffer_add_reward: null reward");
   PH_HIP(ph::launch_reward_add(rb->rewards + (size_t)pos * rb->E, reward, env_mask, rb->E, ctx->stream));
+  return 0;
+}
+
+int ph_buffer_add_reward_const(ph_ctx* ctx, const ph_rollout* rb, int pos, float reward) {
+  DevGuard dev_guard(ctx);
+  if (!ctx) return fail("null ctx");
+  if (check_rb(rb)) return 1;
+  if (pos < 0 || pos >= rb->T) return fail("ph_buffer_add_reward_const: pos out of range");
+  PH_HIP(ph::launch_reward_add_const(rb->rewards + (size_t)pos * rb->E, reward, rb->E, ctx->stream));
   return 0;
 }
 
@@ -745,6 +760,50 @@ int ph_policy_forward(ph_ctx* ctx, const ph_spec* spec, const float* params, con
     return fail("ph_policy_forward: pending_reward needs the fused rollout-buffer write");
   }
   PH_HIP(ph::launch_policy_fwd(a, gemm_mode, ctx->stream));
+  return 0;
+}
+
+int ph_policy_act_host(ph_ctx* ctx, const ph_spec* spec, const float* params, const float* obs_host, int n,
+                       const float* episode_start_host, unsigned long long seed, unsigned long long counter, int deterministic,
+                       int* actions_host, float* values_host, float* log_probs_host, const ph_rollout* rb, int pos, int gemm_mode) {
+  DevGuard dev_guard(ctx);
+  if (!ctx) return fail("null ctx");
+  if (!params || !obs_host) return fail("ph_policy_act_host: null params/obs");
+  if (n <= 0) return fail("ph_policy_act_host: n must be positive");
+  if (rb && !episode_start_host) return fail("ph_policy_act_host: the fused rollout-buffer write needs episode_start_host");
+  if (ctx->capturing) return fail("ph_policy_act_host synchronises: not inside graph capture");
+  ph::NetDims nd;
+  if (resolve(ctx, spec, &nd)) return 1;
+  // staging layout (floats): obs n*D | episode_start n || actions n*A (as int32) | values n | log_probs n
+  const size_t n_in = (size_t)n * nd.D + (size_t)n, n_out = (size_t)n * nd.A + 2 * (size_t)n, need = n_in + n_out;
+  if (need > ctx->act_stage_cap) {
+    if (ctx->act_stage_host) (void)hipHostFree(ctx->act_stage_host);
+    if (ctx->act_stage_dev) (void)hipFree(ctx->act_stage_dev);
+    ctx->act_stage_host = nullptr;
+    ctx->act_stage_dev = nullptr;
+    ctx->act_stage_cap = 0;
+    const size_t cap = need < 4096 ? 4096 : need;
+    PH_HIP(hipHostMalloc((void**)&ctx->act_stage_host, cap * sizeof(float), hipHostMallocDefault));
+    PH_HIP(hipMalloc((void**)&ctx->act_stage_dev, cap * sizeof(float)));
+    ctx->act_stage_cap = cap;
+  }
+  float *h = ctx->act_stage_host, *d = ctx->act_stage_dev;
+  std::memcpy(h, obs_host, (size_t)n * nd.D * sizeof(float));
+  if (episode_start_host) std::memcpy(h + (size_t)n * nd.D, episode_start_host, (size_t)n * sizeof(float));
+  else std::memset(h + (size_t)n * nd.D, 0, (size_t)n * sizeof(float));
+  PH_HIP(hipMemcpyAsync(d, h, n_in * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  float* d_out = d + n_in;
+  int* d_act = reinterpret_cast<int*>(d_out);
+  float *d_val = d_out + (size_t)n * nd.A, *d_lp = d_val + n;
+  if (ph_policy_forward(ctx, spec, params, d, n, nullptr, nullptr, nullptr, seed, counter, deterministic, d_act, nullptr, d_val,
+                        d_lp, nullptr, nullptr, rb, pos, rb ? d + (size_t)n * nd.D : nullptr, nullptr, gemm_mode))
+    return 1;
+  float* h_out = h + n_in;
+  PH_HIP(hipMemcpyAsync(h_out, d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  if (actions_host) std::memcpy(actions_host, h_out, (size_t)n * nd.A * sizeof(int));
+  if (values_host) std::memcpy(values_host, h_out + (size_t)n * nd.A, (size_t)n * sizeof(float));
+  if (log_probs_host) std::memcpy(log_probs_host, h_out + (size_t)n * nd.A + n, (size_t)n * sizeof(float));
   return 0;
 }
 

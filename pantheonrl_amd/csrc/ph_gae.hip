@@ -279,6 +279,15 @@ hipError_t launch_reward_add(float* rew_row, const float* reward, const unsigned
   return hipGetLastError();
 }
 
+__global__ void reward_add_const_kernel(float* __restrict__ rew_row, float reward, int E) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < E) rew_row[e] += reward;
+}
+hipError_t launch_reward_add_const(float* rew_row, float reward, int E, hipStream_t s) {
+  hipLaunchKernelGGL(reward_add_const_kernel, dim3((E + 255) / 256), dim3(256), 0, s, rew_row, reward, E);
+  return hipGetLastError();
+}
+
 // ragged (per-env write position) forms of Agent.update and of the position advance after a recorded action
 __global__ void reward_add_ragged_kernel(float* __restrict__ rewards, const int* __restrict__ pos_env,
                                          const float* __restrict__ reward, const unsigned char* __restrict__ mask, int T,

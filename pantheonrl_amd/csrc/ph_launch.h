@@ -273,6 +273,7 @@ hipError_t launch_liar_reset(int* hands, int* history, int* nmoves, const unsign
                              unsigned char* ego_first, unsigned long long seed, unsigned long long counter,
                              const unsigned long long* epoch, float probegostart, int n, hipStream_t s);
 hipError_t launch_reward_add(float* rew_row, const float* reward, const unsigned char* env_mask, int E, hipStream_t s);
+hipError_t launch_reward_add_const(float* rew_row, float reward, int E, hipStream_t s);
 hipError_t launch_reward_add_joint(float* rew_row, const float* base, const int* joint, int E, int n_seats, int seat,
                                    const int* partner_seat, float bonus, hipStream_t s);
 hipError_t launch_framestack_push(float* stack, const float* obs, const unsigned char* reset_mask,

@@ -41,6 +41,8 @@ class ModularPolicy(ActorCriticPolicy):
     [dict(pi=[64, 64], vf=[64, 64])], tanh).  Parameters: the main network in ph_layout order, then every module's block in the
     ph_layout order of a (Box(64), same action space) network; `state_dict()` uses the reference's module names."""
 
+    host_step_path = False   # the composed forward (main + partner towers) has its own launches
+
     def __init__(self, observation_space, action_space, lr: float = 3e-4, device="cuda", ortho_init: bool = True,
                  seed: Optional[int] = None, sampling_stream: int = 0, num_partners: int = 1, baseline: bool = False,
                  nomain: bool = False):

@@ -105,6 +105,13 @@ class RolloutBuffer:
     def add_reward(self, reward, env_mask=None, pos: Optional[int] = None) -> None:
         """buf.rewards[pos-1][e] += reward[e] <- Agent.update, agents.py:198 (vectorised over envs)."""
         row = self.pos - 1 if pos is None else pos
+        if (env_mask is None and self.n_envs == 1 and isinstance(reward, np.ndarray) and reward.size == 1):
+            reward = float(reward.reshape(-1)[0])
+        if env_mask is None and isinstance(reward, (int, float, np.floating, np.integer)):
+            # a scalar for every environment of the row (Agent.update's own signature): it travels as a kernel argument
+            self._bind()
+            nat.check(self.ctx.lib.ph_buffer_add_reward_const(self.ctx.handle, C.byref(self._c), row, float(reward)))
+            return
         r = _f32_dev(np.broadcast_to(np.asarray(reward, np.float32), (self.n_envs,))
                      if not isinstance(reward, th.Tensor) else reward, self.device, (self.n_envs,))
         m = None
@@ -146,6 +153,10 @@ class ActorCriticPolicy:
     """SB3 MlpPolicy (FlattenExtractor + MlpExtractor pi=[64,64], vf=[64,64], tanh) with parameters resident in HBM
     as one flat input-major vector (layout in include/pantheon_hip.h)."""
 
+    # OnPolicyAgent.get_action may use forward_and_store_host (one native call per environment step) for host observations;
+    # subclasses that build their rows on the device (AdapPolicy appends the context there) switch it off
+    host_step_path = True
+
     def __init__(self, observation_space, action_space, lr: float = 3e-4, device="cuda",
                  ortho_init: bool = True, seed: Optional[int] = None, sampling_stream: int = 0):
         self.device = _require_cuda(device)
@@ -174,6 +185,7 @@ class ActorCriticPolicy:
             z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
             self._seed = int((z ^ (z >> 31)) & 0x7FFFFFFFFFFFFFFF)
         self._counter = 0
+        self._host_out: Dict[int, tuple] = {}   # forward_and_store_host's result arrays, per row count
         self._init_weights(ortho_init)
 
     # -- parameters -------------------------------------------------------------------------------------------
@@ -278,6 +290,32 @@ class ActorCriticPolicy:
         rb.pos += 1
         rb.full = rb.pos == rb.buffer_size
         return self._shape_actions(acts), values, logp
+
+    def forward_and_store_host(self, obs_rows: np.ndarray, rb: RolloutBuffer, episode_start, deterministic: bool = False):
+        """forward_and_store for an environment that lives on the host: host rows in, host results out, ONE native call and one
+        synchronisation (ph_policy_act_host) instead of the tensor operations of the general path.  Same kernel, same
+        (seed, counter): bitwise the same samples.  -> (actions np.int64 shaped like SB3's, values (n,1) CPU tensor, log_prob (n,))"""
+        if rb.pos >= rb.buffer_size:
+            raise nat.NativeError("RolloutBuffer.add on a full buffer")
+        lay = self.layout
+        rows = np.ascontiguousarray(obs_rows, dtype=np.float32).reshape(-1, lay.D)
+        n = rows.shape[0]
+        out = self._host_out.get(n)
+        if out is None:
+            out = self._host_out[n] = (np.empty((n, lay.A), np.int32), np.empty((n, 1), np.float32), np.empty((n,), np.float32),
+                                       np.empty((n,), np.float32))
+        acts, values, logp, es = out
+        es[:] = episode_start
+        self._bind()
+        self._counter += 1
+        nat.check(self.ctx.lib.ph_policy_act_host(
+            self.ctx.handle, C.byref(self.spec), self.params.data_ptr(), rows.ctypes.data, n, es.ctypes.data, self._seed,
+            self._counter, int(bool(deterministic)), acts.ctypes.data, values.ctypes.data, logp.ctypes.data,
+            C.byref(rb.c_struct()), int(rb.pos), int(self.gemm_mode)))
+        rb.pos += 1
+        rb.full = rb.pos == rb.buffer_size
+        shaped = acts.astype(np.int64).reshape((-1,) + tuple(self.action_space.shape))
+        return shaped, th.from_numpy(values.copy()), th.from_numpy(logp.copy())
 
     def evaluate_actions(self, obs, actions, action_mask=None):
         """-> (values (n,1), log_prob (n,), entropy (n,))  (modular/policies.py:364-383)."""
@@ -527,9 +565,14 @@ class PPO:
         if callback is not None and hasattr(callback, "on_rollout_start"):
             callback.on_rollout_start()
         for t in range(self.n_steps):
-            actions, _, _ = pol.forward_and_store(self._last_obs, rb, self._last_episode_starts,
-                                                  uniforms=None if forced_uniforms is None else forced_uniforms[t])
-            act_np = actions.cpu().numpy()
+            if forced_uniforms is None and getattr(pol, "host_step_path", False) and isinstance(self._last_obs, np.ndarray):
+                # host environment: one native call per step (stage in, forward + row write, results out)
+                act_np, _, _ = pol.forward_and_store_host(self._last_obs, rb, self._last_episode_starts)
+                actions = act_np
+            else:
+                actions, _, _ = pol.forward_and_store(self._last_obs, rb, self._last_episode_starts,
+                                                      uniforms=None if forced_uniforms is None else forced_uniforms[t])
+                act_np = actions.cpu().numpy()
             new_obs, rewards, dones, infos = env.step(act_np)
             self.num_timesteps += self.n_envs
             if callback is not None and hasattr(callback, "on_step"):

@@ -653,6 +653,39 @@ def test_fused_step_launch_is_bitwise_the_two_launches_through_a_kl_early_stop()
     assert n0 == n1 and np.array_equal(p0, p1) and np.array_equal(st0, st1)
 
 
+def test_host_step_path_is_bitwise_the_general_path():
+    """OnPolicyAgent.get_action for a host environment goes through ph_policy_act_host (stage in, forward + row write, results
+    out: ONE native call and one synchronisation per environment step, agents.py:111-184) and Agent.update's scalar reward
+    through ph_buffer_add_reward_const; the tensor path it replaces gives the same actions, the same buffer, the same values and,
+    after two train() calls on those buffers, the same parameters -- bit for bit (same kernel, same (seed, counter))."""
+    from pantheonrl_amd import OnPolicyAgent, PPO
+    from pantheonrl_amd.common import Observation
+    obs_s, act_s = H.CONFIGS["overcooked"]
+    env = type("E", (), dict(observation_space=H.to_space(obs_s), action_space=H.to_space(act_s), _is_dummy_space_env=True))()
+    rng = np.random.default_rng(3)
+    obs = rng.standard_normal((40, 62)).astype(np.float32)
+    rew = rng.standard_normal(40).astype(np.float32)
+    done = rng.random(40) < 0.2
+    outs = []
+    for host in (True, False):
+        model = PPO("MlpPolicy", env, n_steps=16, n_envs=1, batch_size=8, n_epochs=2, seed=7)
+        model.policy.host_step_path = host          # the instance attribute shadows the class flag
+        agent = OnPolicyAgent(model)
+        acts = []
+        for t in range(40):
+            acts.append(np.asarray(agent.get_action(Observation(obs[t]))).copy())
+            agent.update(float(rew[t]), bool(done[t]))
+        th.cuda.synchronize()
+        outs.append((np.array(acts), model.rollout_buffer.host(), model.policy.get_flat_params(), agent.n_steps, agent.iteration))
+    (a0, b0, p0, n0, i0), (a1, b1, p1, n1, i1) = outs
+    assert i0 == i1 == 2 and n0 == n1                      # two updates happened in both runs
+    assert np.array_equal(a0, a1)
+    for k in b0:
+        assert np.array_equal(b0[k], b1[k]), k
+    assert np.array_equal(p0, p1)
+    assert len(set(a0.reshape(-1).tolist())) > 1           # the policy did sample
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # the drop-in surface end to end: trainer.py preset-1 object graph on RPS (BASELINE config 1)
 # ----------------------------------------------------------------------------------------------------------------
