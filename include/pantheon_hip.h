@@ -263,8 +263,9 @@ int ph_policy_forward(ph_ctx *ctx, const ph_spec *spec, const float *params, con
 
 /* The same call for an environment that lives on the HOST (the reference's own situation: one get_action per environment step,
  * the action needed back before the environment can move -- agents.py:111-184, util.py:63-81): observations, episode starts and
- * the three results are HOST arrays; the call stages them through pinned memory of the context, runs the forward (with the fused
- * rollout-buffer write when rb != NULL, as above), copies the results back and returns when they are there.  One call and one
+ * the three results are HOST arrays; the call stages them through pinned, device-visible memory of the context that the forward
+ * kernel reads and writes directly (with the fused rollout-buffer write when rb != NULL, as above) and returns when the kernel
+ * has finished.  One call, one launch and one
  * synchronisation per environment step instead of several tensor operations; the sampled actions are bitwise those of
  * ph_policy_forward with the same (seed, counter).
  *   obs_host (n, D) f32; episode_start_host (n) f32 or NULL (required with rb); actions_host (n, A) i32; values_host (n);

@@ -56,7 +56,7 @@ struct ph_ctx {
   size_t blocksq_cap = 0;
   float* advstats = nullptr;
   size_t advstats_cap = 0;
-  // ph_policy_act_host: pinned host staging + its device mirror (observations in, actions / values / log-probs out)
+  // ph_policy_act_host: pinned, coherent host staging the kernel accesses directly (host view, device view of the same memory)
   float* act_stage_host = nullptr;
   float* act_stage_dev = nullptr;
   size_t act_stage_cap = 0;   // floats
@@ -331,7 +331,6 @@ int ph_ctx_destroy(ph_ctx* ctx) {
                   ctx->adap_extra, ctx->adap_loss};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  if (ctx->act_stage_dev) (void)hipFree(ctx->act_stage_dev);
   if (ctx->act_stage_host) (void)hipHostFree(ctx->act_stage_host);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -774,33 +773,31 @@ int ph_policy_act_host(ph_ctx* ctx, const ph_spec* spec, const float* params, co
   if (ctx->capturing) return fail("ph_policy_act_host synchronises: not inside graph capture");
   ph::NetDims nd;
   if (resolve(ctx, spec, &nd)) return 1;
-  // staging layout (floats): obs n*D | episode_start n || actions n*A (as int32) | values n | log_probs n
+  // staging layout (floats): obs n*D | episode_start n || actions n*A (as int32) | values n | log_probs n -- pinned, coherent host
+  // memory the kernel reads and writes DIRECTLY (a few hundred bytes over the host link): no copy launches, one kernel, one wait
   const size_t n_in = (size_t)n * nd.D + (size_t)n, n_out = (size_t)n * nd.A + 2 * (size_t)n, need = n_in + n_out;
   if (need > ctx->act_stage_cap) {
     if (ctx->act_stage_host) (void)hipHostFree(ctx->act_stage_host);
-    if (ctx->act_stage_dev) (void)hipFree(ctx->act_stage_dev);
     ctx->act_stage_host = nullptr;
     ctx->act_stage_dev = nullptr;
     ctx->act_stage_cap = 0;
     const size_t cap = need < 4096 ? 4096 : need;
-    PH_HIP(hipHostMalloc((void**)&ctx->act_stage_host, cap * sizeof(float), hipHostMallocDefault));
-    PH_HIP(hipMalloc((void**)&ctx->act_stage_dev, cap * sizeof(float)));
+    PH_HIP(hipHostMalloc((void**)&ctx->act_stage_host, cap * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+    PH_HIP(hipHostGetDevicePointer((void**)&ctx->act_stage_dev, ctx->act_stage_host, 0));
     ctx->act_stage_cap = cap;
   }
-  float *h = ctx->act_stage_host, *d = ctx->act_stage_dev;
+  float *h = ctx->act_stage_host, *d = ctx->act_stage_dev;   // the same memory, host and device view
   std::memcpy(h, obs_host, (size_t)n * nd.D * sizeof(float));
   if (episode_start_host) std::memcpy(h + (size_t)n * nd.D, episode_start_host, (size_t)n * sizeof(float));
   else std::memset(h + (size_t)n * nd.D, 0, (size_t)n * sizeof(float));
-  PH_HIP(hipMemcpyAsync(d, h, n_in * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   float* d_out = d + n_in;
   int* d_act = reinterpret_cast<int*>(d_out);
   float *d_val = d_out + (size_t)n * nd.A, *d_lp = d_val + n;
   if (ph_policy_forward(ctx, spec, params, d, n, nullptr, nullptr, nullptr, seed, counter, deterministic, d_act, nullptr, d_val,
                         d_lp, nullptr, nullptr, rb, pos, rb ? d + (size_t)n * nd.D : nullptr, nullptr, gemm_mode))
     return 1;
-  float* h_out = h + n_in;
-  PH_HIP(hipMemcpyAsync(h_out, d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   PH_HIP(hipStreamSynchronize(ctx->stream));
+  const float* h_out = h + n_in;
   if (actions_host) std::memcpy(actions_host, h_out, (size_t)n * nd.A * sizeof(int));
   if (values_host) std::memcpy(values_host, h_out + (size_t)n * nd.A, (size_t)n * sizeof(float));
   if (log_probs_host) std::memcpy(log_probs_host, h_out + (size_t)n * nd.A + n, (size_t)n * sizeof(float));
