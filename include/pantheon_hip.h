@@ -38,7 +38,7 @@ extern "C" {
                               3: + ph_selfplay_rollout_persistent, PH_STEP_FIX_ILLEGAL / _MASK_ENV_ONLY, ph_modular_*, ph_roundrobin_*_iteration
                                   (additions only)
                               4: + ph_selfplay_rollout_persistent_capacity, ph_ppo_train's gradient pack (no signature changed)
-                              5: + ph_policy_act_host, ph_buffer_add_reward_const (additions only) */
+                              5: + ph_policy_act_host, ph_buffer_add_reward_const, ph_adapmult_* (additions only) */
 #define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
 #define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
 #define PH_MAX_LOGITS 64 /* max total policy logits L */
@@ -632,6 +632,34 @@ int ph_adap_train(ph_ctx *ctx, const ph_spec *spec, const ph_opt_state *opt, con
 int ph_adap_minibatch_grad(ph_ctx *ctx, const ph_spec *spec, const float *params, const ph_rollout *rb,
                            const ph_ppo_hyper *hyper /* host */, const int *indices, int nb, float *grad_out,
                            float *stats_out, int gemm_mode, const ph_adap_loss *adap /* host */);
+
+/* ---- AdapPolicyMult (pantheonrl/algos/adap/policies.py:136-283): AdapPolicy with MultModel as its extractor -----------------
+ * Rows are features ++ context like AdapPolicy's (adap_learn.py:448-452); per net (policies.py:239-264)
+ *   x = tanh(W1 o + b1)  (o = the row without its context),  x_a = tanh(Ws x + bs) viewed as (64, C),
+ *   latent = tanh(W2 (x + x_a @ ctx) + b2),  then action_net / value_net.
+ * spec: obs = Box(features + context_size) with features <= 64, context_size <= 4; act = Discrete(<= 8).
+ * Parameter vector (input-major, like ph_layout): pi {W1 [Fo][64], b1, Ws [64][64 C] (column j C + c), bs, W2 [64][64], b2},
+ * vf {the same}, act_W [64][L], act_b, val_W [64], val_b.  The entry points mirror ph_policy_forward / ph_ppo_minibatch_grad /
+ * ph_adap_train (same argument meaning; `adap` may be NULL in the gradient call = PPO loss only); the network runs as a chain of
+ * small launches over dense intermediates (csrc/ph_adapmult.hip), exact float32. */
+typedef struct ph_adapmult_layout {
+  int Fo, C, L, P;
+  int pi_W1, pi_b1, pi_Ws, pi_bs, pi_W2, pi_b2;
+  int vf_W1, vf_b1, vf_Ws, vf_bs, vf_W2, vf_b2;
+  int act_W, act_b, val_W, val_b;
+} ph_adapmult_layout;
+int ph_adapmult_layout_of(const ph_spec *spec, int context_size, ph_adapmult_layout *out /* host */);
+int ph_adapmult_forward(ph_ctx *ctx, const ph_spec *spec, int context_size, const float *params, const float *obs, int n,
+                        const unsigned char *action_mask, const float *uniforms, const float *given_actions,
+                        unsigned long long seed, unsigned long long counter, int deterministic, int *actions_i32,
+                        float *actions_f32, float *values, float *log_probs, float *entropy, float *logits,
+                        const ph_rollout *rb, int pos, const float *episode_start_in);
+int ph_adapmult_minibatch_grad(ph_ctx *ctx, const ph_spec *spec, int context_size, const float *params, const ph_rollout *rb,
+                               const ph_ppo_hyper *hyper /* host */, const int *indices, int nb, float *grad_out,
+                               float *stats_out, const ph_adap_loss *adap /* host, or NULL */);
+int ph_adapmult_train(ph_ctx *ctx, const ph_spec *spec, int context_size, const ph_opt_state *opt, const ph_rollout *rb,
+                      const ph_ppo_hyper *hyper /* host */, int n_epochs, int batch_size, const int *perms,
+                      unsigned long long perm_seed, float *stats, const ph_adap_loss *adap /* host */);
 
 /* Measurement hook for bench.py's roofline: enqueue ONLY the ppo_grad kernel (the dominant kernel of PPO.train) `reps`
  * times between two HIP events on the ctx stream; *avg_ms_out = mean launch duration.  Launch i takes minibatch

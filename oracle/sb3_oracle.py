@@ -305,8 +305,7 @@ class MlpPolicyOracle(nn.Module):
 
 class AdapMultPolicyOracle(MlpPolicyOracle):
     """``AdapPolicyMult`` = ``AdapPolicy`` with ``MultModel`` as its extractor (adap/policies.py:136-283), SB3's default
-    ``net_arch=[dict(pi=[64, 64], vf=[64, 64])]``, tanh.  ORACLE ONLY: the engine has no device path for this network yet
-    (DESIGN.md 6); the restatement and its known-answer tests are the yardstick the device path will be built against.
+    ``net_arch=[dict(pi=[64, 64], vf=[64, 64])]``, tanh: the yardstick of the device path (csrc/ph_adapmult.hip).
 
     The stored observation is ``features ++ context`` (adap_learn.py:448-452) as for ``AdapPolicy``; ``MultModel.forward``
     splits it again (policies.py:268-272) and, per net (policies.py:239-264):
@@ -353,10 +352,41 @@ class AdapMultPolicyOracle(MlpPolicyOracle):
         return (self._branch(self.agent_branch_1, self.agent_scaling, self.agent_branch_2, o, ctx),
                 self._branch(self.value_branch_1, self.value_scaling, self.value_branch_2, o, ctx))
 
-    def flat_params(self):   # the engine's flat layout (include/pantheon_hip.h) has no slot for the scaling layers
-        raise NotImplementedError("AdapPolicyMult has no device layout yet")
+    # -- flat vector in ph_adapmult_layout's order (include/pantheon_hip.h): per net W1 b1 Ws bs W2 b2 (pi, then vf), then the heads;
+    #    weights input-major, i.e. the scaling layer as [64][64 C] with column j C + c = torch's output row j C + c
+    def _linears(self):
+        return [self.agent_branch_1[0], self.agent_scaling[0], self.agent_branch_2[0], self.value_branch_1[0],
+                self.value_scaling[0], self.value_branch_2[0], self.action_net]
 
-    flat_grads = load_flat = flat_params
+    def flat_params(self) -> np.ndarray:
+        out = []
+        for lin in self._linears():
+            out += [lin.weight.detach().t().contiguous().reshape(-1), lin.bias.detach()]
+        out += [self.value_net.weight.detach().reshape(-1), self.value_net.bias.detach()]
+        return th.cat(out).numpy().astype(np.float32).copy()
+
+    def load_flat_params(self, flat: np.ndarray) -> None:
+        flat = th.as_tensor(np.asarray(flat, np.float32))
+        o = 0
+        with th.no_grad():
+            for lin in self._linears():
+                n = lin.weight.numel()
+                lin.weight.copy_(flat[o:o + n].reshape(lin.in_features, lin.out_features).t())
+                o += n
+                lin.bias.copy_(flat[o:o + lin.bias.numel()])
+                o += lin.bias.numel()
+            self.value_net.weight.copy_(flat[o:o + HIDDEN].reshape(1, HIDDEN))
+            self.value_net.bias.copy_(flat[o + HIDDEN:o + HIDDEN + 1])
+            o += HIDDEN + 1
+        assert o == flat.numel()
+
+    def flat_grads(self) -> np.ndarray:
+        zero = lambda t: th.zeros_like(t) if t.grad is None else t.grad   # noqa: E731
+        out = []
+        for lin in self._linears():
+            out += [zero(lin.weight).t().contiguous().reshape(-1), zero(lin.bias)]
+        out += [zero(self.value_net.weight).reshape(-1), zero(self.value_net.bias)]
+        return th.cat(out).numpy().astype(np.float32).copy()
 
 
 def inverse_cdf_sample(probs: th.Tensor, u: th.Tensor) -> th.Tensor:

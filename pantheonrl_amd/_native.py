@@ -38,6 +38,11 @@ class PhLayout(C.Structure):
                                         "vf_W2", "vf_b2", "act_W", "act_b", "val_W", "val_b")]
 
 
+class PhAdapMultLayout(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("Fo", "C", "L", "P", "pi_W1", "pi_b1", "pi_Ws", "pi_bs", "pi_W2", "pi_b2", "vf_W1", "vf_b1",
+                                        "vf_Ws", "vf_bs", "vf_W2", "vf_b2", "act_W", "act_b", "val_W", "val_b")]
+
+
 class PhRollout(C.Structure):
     _fields_ = [("T", C.c_int), ("E", C.c_int)] + [(k, C.c_void_p) for k in (
         "observations", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns")]
@@ -197,6 +202,13 @@ SIGNATURES = {
     "ph_gae": [_vp, C.POINTER(PhRollout), _vp, _vp, _d, _d, _i],
     "ph_policy_forward": [_vp, C.POINTER(PhSpec), _vp, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, _vp, _vp,
                           _vp, C.POINTER(PhRollout), _i, _vp, _vp, _i],
+    "ph_adapmult_layout_of": [C.POINTER(PhSpec), _i, _vp],
+    "ph_adapmult_forward": [_vp, C.POINTER(PhSpec), _i, _vp, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, _vp, _vp,
+                            _vp, C.POINTER(PhRollout), _i, _vp],
+    "ph_adapmult_minibatch_grad": [_vp, C.POINTER(PhSpec), _i, _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _vp, _i, _vp, _vp,
+                                   _vp],
+    "ph_adapmult_train": [_vp, C.POINTER(PhSpec), _i, C.POINTER(PhOptState), C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i,
+                          _vp, _ull, _vp, _vp],
     "ph_policy_act_host": [_vp, C.POINTER(PhSpec), _vp, _vp, _i, _vp, _ull, _ull, _i, _vp, _vp, _vp, C.POINTER(PhRollout), _i, _i],
     "ph_buffer_add_reward_const": [_vp, C.POINTER(PhRollout), _i, C.c_float],
     "ph_policy_step_multi": [_vp, _i, C.POINTER(PhStepCall)],
@@ -325,6 +337,12 @@ def make_space(kind: int, n: int, nvec: Sequence[int] = ()) -> PhSpace:
 def layout_of(spec: PhSpec) -> PhLayout:
     lay = PhLayout()
     check(load().ph_layout_of(C.byref(spec), C.byref(lay)))
+    return lay
+
+
+def adapmult_layout_of(spec: PhSpec, context_size: int) -> PhAdapMultLayout:
+    lay = PhAdapMultLayout()
+    check(load().ph_adapmult_layout_of(C.byref(spec), int(context_size), C.byref(lay)))
     return lay
 
 

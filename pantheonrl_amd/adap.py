@@ -10,7 +10,8 @@ ADAP (adap_learn.py:30-227) is PPO over a policy that also reads a latent contex
   ``ph_adap_train`` -- one small launch per minibatch next to the PPO gradient launch, folded into the same gradient reduction,
   clip and Adam step (include/pantheon_hip.h).
 
-Not built: ``AdapPolicyMult`` (policies.py:149-283, the multiplicative-latent extractor is a different network).
+``AdapPolicyMult`` (policies.py:136-283: the multiplicative-latent extractor, a different network) has its own parameter layout and
+launch chain (csrc/ph_adapmult.hip) behind the same classes: ``ADAP("AdapPolicyMult", ...)``.
 """
 from __future__ import annotations
 
@@ -106,13 +107,104 @@ class AdapPolicy(ActorCriticPolicy):
         return th.cat((t, c), dim=1).contiguous()
 
 
+class AdapPolicyMult(AdapPolicy):
+    """adap/policies.py:136-283: AdapPolicy whose extractor is MultModel -- per net  x = tanh(W1 o + b1),
+    x_a = tanh(Ws x + bs) viewed as (64, C),  latent = tanh(W2 (x + x_a @ ctx) + b2)  on rows features ++ context.  Same rows, same
+    rollout buffer and same surface as AdapPolicy; the parameters follow ph_adapmult_layout (include/pantheon_hip.h) and the
+    network runs as a chain of small launches (csrc/ph_adapmult.hip)."""
+
+    # reference module names (policies.py:207-236) -> (weight offset, bias offset, fan in, fan out); gains: SB3's init_weights loop
+    # reaches every Linear of mlp_extractor with sqrt(2) (modular/policies.py:229-241 is the same loop)
+    _MODS = (("mlp_extractor.agent_branch_1.0", "pi_W1", "pi_b1"), ("mlp_extractor.agent_scaling.0", "pi_Ws", "pi_bs"),
+             ("mlp_extractor.agent_branch_2.0", "pi_W2", "pi_b2"), ("mlp_extractor.value_branch_1.0", "vf_W1", "vf_b1"),
+             ("mlp_extractor.value_scaling.0", "vf_Ws", "vf_bs"), ("mlp_extractor.value_branch_2.0", "vf_W2", "vf_b2"),
+             ("action_net", "act_W", "act_b"), ("value_net", "val_W", "val_b"))
+
+    def __init__(self, observation_space, action_space, context_size: int = 3, **kw):
+        ortho = kw.get("ortho_init", True)
+        super().__init__(observation_space, action_space, context_size=context_size, **kw)
+        self.mlayout = nat.adapmult_layout_of(self.spec, self.context_size)      # raises for shapes the device path does not take
+        P = self.mlayout.P
+        self.params = th.zeros(P, dtype=th.float32, device=self.device)
+        self.adam_m = th.zeros_like(self.params)
+        self.adam_v = th.zeros_like(self.params)
+        self._init_weights(ortho)
+
+    def _mshapes(self):
+        m, H, C = self.mlayout, 64, self.context_size
+        return {"pi_W1": (m.Fo, H), "pi_Ws": (H, H * C), "pi_W2": (H, H), "vf_W1": (m.Fo, H), "vf_Ws": (H, H * C), "vf_W2": (H, H),
+                "act_W": (H, m.L), "val_W": (H, 1)}
+
+    def _init_weights(self, ortho_init: bool) -> None:
+        if not hasattr(self, "mlayout"):      # the base constructor's call: its MlpPolicy-sized vector is replaced right after
+            return super()._init_weights(ortho_init)
+        flat = th.zeros(self.mlayout.P, dtype=th.float32)
+        for name, (fin, fout) in self._mshapes().items():
+            w = th.empty(fout, fin)
+            gain = 0.01 if name == "act_W" else (1.0 if name == "val_W" else float(np.sqrt(2)))
+            if ortho_init:
+                th.nn.init.orthogonal_(w, gain=gain)
+            else:
+                th.nn.init.kaiming_uniform_(w, a=np.sqrt(5))
+            off = getattr(self.mlayout, name)
+            flat[off:off + fin * fout] = w.t().contiguous().reshape(-1)
+        self.params.copy_(flat)
+
+    def state_dict(self):
+        flat, m, shapes, out = self.params.detach().cpu(), self.mlayout, self._mshapes(), {}
+        for mod, wname, bname in self._MODS:
+            fin, fout = shapes[wname]
+            woff, boff = getattr(m, wname), getattr(m, bname)
+            out[mod + ".weight"] = flat[woff:woff + fin * fout].reshape(fin, fout).t().contiguous()
+            out[mod + ".bias"] = flat[boff:boff + fout].clone()
+        return out
+
+    def load_state_dict(self, sd) -> None:
+        flat, m, shapes = th.zeros(self.mlayout.P), self.mlayout, self._mshapes()
+        for mod, wname, bname in self._MODS:
+            fin, fout = shapes[wname]
+            woff, boff = getattr(m, wname), getattr(m, bname)
+            flat[woff:woff + fin * fout] = th.as_tensor(sd[mod + ".weight"]).float().reshape(fout, fin).t().reshape(-1)
+            flat[boff:boff + fout] = th.as_tensor(sd[mod + ".bias"]).float().reshape(-1)
+        self.params.copy_(flat)
+
+    def _launch(self, obs_t, *, mask=None, uniforms=None, given=None, deterministic=False, want_logits=False,
+                want_entropy=False, rb: Optional[RolloutBuffer] = None, pos: int = 0, episode_start=None):
+        from .ppo import _f32_dev
+        n, lay, dev = obs_t.shape[0], self.layout, self.device
+        acts = th.empty((n, lay.A), dtype=th.int32, device=dev)
+        values = th.empty((n, 1), dtype=th.float32, device=dev)
+        logp = th.empty((n,), dtype=th.float32, device=dev)
+        logits = th.empty((n, lay.L), dtype=th.float32, device=dev) if want_logits else None
+        ent = th.empty((n,), dtype=th.float32, device=dev) if want_entropy else None
+        m = None if mask is None else th.as_tensor(mask).to(device=dev, dtype=th.uint8).reshape(n, lay.L).contiguous()
+        u = None if uniforms is None else _f32_dev(uniforms, dev, (n, lay.A))
+        g = None if given is None else _f32_dev(given, dev, (n, lay.A))
+        es = None if episode_start is None else _f32_dev(episode_start, dev, (n,))
+        self._bind()
+        self._counter += 1
+        nat.check(self.ctx.lib.ph_adapmult_forward(
+            self.ctx.handle, C.byref(self.spec), int(self.context_size), self.params.data_ptr(), obs_t.data_ptr(), n, nat.ptr(m),
+            nat.ptr(u), nat.ptr(g), self._seed, self._counter, int(bool(deterministic)), acts.data_ptr(), None, values.data_ptr(),
+            logp.data_ptr(), nat.ptr(ent), nat.ptr(logits), C.byref(rb.c_struct()) if rb is not None else None, int(pos),
+            nat.ptr(es)))
+        return acts, values, logp, ent, logits
+
+
 class ADAP(PPO):
     """pantheonrl.algos.adap.adap_learn.ADAP: same constructor surface (adap_learn.py:86-117) on top of `PPO`."""
 
     def __init__(self, policy=AdapPolicy, env=None, *args, context_loss_coeff: float = 0.1, context_size: int = 3,
-                 num_context_samples: int = 5, context_sampler: str = "l2", num_state_samples: int = 32, **kwargs):
-        if policy not in ("AdapPolicy", AdapPolicy):
-            raise ValueError("the engine implements AdapPolicy (concatenated context); AdapPolicyMult is not built")
+                 num_context_samples: int = 5, context_sampler: str = "l2", num_state_samples: int = 32,
+                 policy_kind: Optional[str] = None, **kwargs):
+        policy = policy_kind or policy          # (checkpoints name the policy class: ADAP.load passes policy_kind)
+        if policy in ("AdapPolicy", AdapPolicy):
+            self._policy_cls = AdapPolicy
+        elif policy in ("AdapPolicyMult", AdapPolicyMult):
+            self._policy_cls = AdapPolicyMult
+        else:
+            raise ValueError(f"ADAP policies: 'AdapPolicy' (concatenated context) or 'AdapPolicyMult' (multiplicative), not {policy!r}")
+        self.policy_kind = self._policy_cls.__name__
         if context_sampler not in SAMPLERS:
             raise ValueError(f"unknown context sampler {context_sampler!r} (one of {sorted(SAMPLERS)})")
         if context_sampler == "natural_numbers" and int(context_size) != 1:
@@ -128,7 +220,8 @@ class ADAP(PPO):
         self.last_context_losses: Optional[np.ndarray] = None
         super().__init__("MlpPolicy", env, *args, **kwargs)
 
-    _HP = PPO._HP + ("context_loss_coeff", "context_size", "num_context_samples", "context_sampler", "num_state_samples")
+    _HP = PPO._HP + ("context_loss_coeff", "context_size", "num_context_samples", "context_sampler", "num_state_samples",
+                     "policy_kind")
 
     def sample_context(self, num: int = 1) -> np.ndarray:
         return SAMPLERS[self.context_sampler](self.context_size, num, self.context_rng)
@@ -145,9 +238,9 @@ class ADAP(PPO):
             self.policy.set_context(np.asarray(extra["context"], np.float32))
 
     def _setup_model(self) -> None:                 # adap_learn.py:208-215
-        self.policy = AdapPolicy(self.observation_space, self.action_space, context_size=self.context_size,
-                                 lr=self.learning_rate, device=self.device, seed=self.seed,
-                                 sampling_stream=self.sampling_stream)
+        self.policy = self._policy_cls(self.observation_space, self.action_space, context_size=self.context_size,
+                                       lr=self.learning_rate, device=self.device, seed=self.seed,
+                                       sampling_stream=self.sampling_stream)
         self.rollout_buffer = RolloutBuffer(self.n_steps, self.policy.full_observation_space, self.action_space, self.device,
                                             self.policy.ctx, self.policy.spec, gae_lambda=self.gae_lambda, gamma=self.gamma,
                                             n_envs=self.n_envs)
@@ -185,6 +278,11 @@ class ADAP(PPO):
         n_mb = (N + self.batch_size - 1) // self.batch_size
         forced = getattr(self, "_forced_samples", None) or (None, None)
         ad = self.adap_struct(self.n_epochs * n_mb, forced[0], forced[1])
+        if isinstance(pol, AdapPolicyMult):
+            nat.check(pol.ctx.lib.ph_adapmult_train(pol.ctx.handle, C.byref(pol.spec), int(pol.context_size), C.byref(opt),
+                                                    C.byref(rb.c_struct()), C.byref(hp), int(self.n_epochs), int(self.batch_size),
+                                                    nat.ptr(perm_t), int(self.permutation_seed), stats.data_ptr(), C.byref(ad)))
+            return
         nat.check(pol.ctx.lib.ph_adap_train(pol.ctx.handle, C.byref(pol.spec), C.byref(opt), C.byref(rb.c_struct()),
                                             C.byref(hp), int(self.n_epochs), int(self.batch_size), nat.ptr(perm_t),
                                             int(self.permutation_seed), stats.data_ptr(), int(pol.gemm_mode), C.byref(ad)))

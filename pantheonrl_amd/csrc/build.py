@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["ph_abi.hip", "ph_policy.hip", "ph_gae.hip", "ph_ppo.hip", "ph_ppo_fast.hip", "ph_ppo_split.hip", "ph_envs.hip", "ph_agent.hip", "ph_bc.hip", "ph_adap.hip", "ph_modular.hip"]
+SOURCES = ["ph_abi.hip", "ph_policy.hip", "ph_gae.hip", "ph_ppo.hip", "ph_ppo_fast.hip", "ph_ppo_split.hip", "ph_envs.hip", "ph_agent.hip", "ph_bc.hip", "ph_adap.hip", "ph_modular.hip", "ph_adapmult.hip"]
 HEADERS = ["ph_device.h", "ph_launch.h", "ph_liar.h", "ph_head.h", "ph_split.h", "ph_rowtail.h", os.path.join(ROOT, "include", "pantheon_hip.h")]
 LIB = os.path.join(HERE, "libpantheon_hip.so")
 

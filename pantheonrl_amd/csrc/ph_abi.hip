@@ -83,6 +83,8 @@ struct ph_ctx {
   unsigned long long* step_words = nullptr;
   size_t step_words_cap = 0;
   unsigned int* step_gen = nullptr;   // [2]: generation, sweep errors
+  float* am_buf = nullptr;       // AdapPolicyMult: the dense intermediates of one net (ph_adapmult.hip), one block
+  size_t am_buf_cap = 0;         // floats
   float* adap_extra = nullptr;   // [workgroups][policy-side parameters] gradient slabs of ADAP's context term
   size_t adap_extra_cap = 0;
   float* adap_loss = nullptr;    // [workgroups] partial sums of the raw term
@@ -328,7 +330,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
     if (s.act_off) (void)hipFree(s.act_off);
   }
   void* ptrs[] = {ctx->wimage, ctx->mw.act, ctx->mw.maps, ctx->mw.kl_sum, ctx->mw.scratch, ctx->advpart, ctx->p2p_dev, ctx->slabs, ctx->statpart, ctx->grad, ctx->blocksq, ctx->advstats, ctx->perm_idx, ctx->perm_phys, ctx->ximg, ctx->rec_pi, ctx->rec_vf, ctx->rowrec, ctx->step_words, ctx->step_gen, ctx->scalars, ctx->stop_flag,
-                  ctx->adap_extra, ctx->adap_loss};
+                  ctx->adap_extra, ctx->adap_loss, ctx->am_buf};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->act_stage_host) (void)hipHostFree(ctx->act_stage_host);
@@ -2030,6 +2032,347 @@ int minibatch_grad_run(ph_ctx* ctx, const ph_spec* spec, const float* params, co
   return 0;
 }
 }  // namespace
+
+// ---- AdapPolicyMult (adap/policies.py:136-283; kernels: ph_adapmult.hip) ------------------------------------------------------
+int ph_adapmult_layout_of(const ph_spec* spec, int C, ph_adapmult_layout* o) {
+  if (!o) return fail("ph_adapmult_layout_of: null layout");
+  ph_layout big;
+  if (layout_of(spec, &big)) return 1;
+  if (spec->obs.kind != PH_SPACE_BOX) return fail("AdapPolicyMult: rows are Box rows (features ++ context)");
+  if (big.A != 1 || big.L > 8) return fail("AdapPolicyMult: one Discrete head of at most 8 logits");
+  if (C < 1 || C > 4) return fail("AdapPolicyMult: context_size must be in [1, 4]");
+  if (big.F - C < 1 || big.F - C > 64) return fail("AdapPolicyMult: 1 .. 64 features besides the context");
+  const int H = PH_HIDDEN;
+  o->Fo = big.F - C;
+  o->C = C;
+  o->L = big.L;
+  int off = 0;
+  o->pi_W1 = off; off += o->Fo * H;
+  o->pi_b1 = off; off += H;
+  o->pi_Ws = off; off += H * H * C;
+  o->pi_bs = off; off += H * C;
+  o->pi_W2 = off; off += H * H;
+  o->pi_b2 = off; off += H;
+  o->vf_W1 = off; off += o->Fo * H;
+  o->vf_b1 = off; off += H;
+  o->vf_Ws = off; off += H * H * C;
+  o->vf_bs = off; off += H * C;
+  o->vf_W2 = off; off += H * H;
+  o->vf_b2 = off; off += H;
+  o->act_W = off; off += H * o->L;
+  o->act_b = off; off += o->L;
+  o->val_W = off; off += H;
+  o->val_b = off; off += 1;
+  o->P = off;
+  return 0;
+}
+
+namespace {
+// the dense intermediates for `rows` rows of width D, carved out of one block (every array starts on a 64-float boundary)
+int am_work(ph_ctx* ctx, const ph_adapmult_layout& L, int D, int rows, ph::AmWork* w) {
+  const size_t H = PH_HIDDEN, C = (size_t)L.C, R = (size_t)rows;
+  auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
+  const size_t sizes[] = {R * H, R * H * C, R * H, R * H, R * 8, R, R * 8, R, R * H, R * H, R * H * C, R * (size_t)D,
+                          R, R, R, R, R};
+  size_t total = 0;
+  for (size_t n : sizes) total += up(n);
+  if (total > ctx->am_buf_cap) {
+    if (ctx->capturing) return fail("workspace would grow inside graph capture: run the same call once outside capture first");
+    if (ensure(ctx->am_buf, ctx->am_buf_cap, total)) return 1;
+  }
+  float* p = ctx->am_buf;
+  float** fields[] = {&w->x, &w->xa, &w->y, &w->h, &w->z, &w->v, &w->dz, &w->dv, &w->dzh, &w->dy, &w->dza, &w->xg,
+                      &w->act, &w->oldlp, &w->adv, &w->ret, &w->oldv};
+  for (size_t i = 0; i < sizeof(sizes) / sizeof(sizes[0]); ++i) {
+    *fields[i] = p;
+    p += up(sizes[i]);
+  }
+  return 0;
+}
+int am_nslab(int nb) {
+  const int n = (nb + 15) / 16;
+  return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+// PPO loss gradient of rows indices[0..nb) into ctx->slabs (nslab slabs of P floats, canonical order) + statistics partials; with
+// `adap` the context term's slabs and loss shares as well (fields of *r).  advstats: {mean, std} of the minibatch's advantages.
+int am_minibatch(ph_ctx* ctx, const ph_adapmult_layout& L, int D, const float* params, const ph_rollout* rb, const ph_ppo_hyper* hp,
+                 const int* indices, int nb, const float* advstats, const ph_adap_loss* adap, int mbi, ph::ReduceArgs* r) {
+  hipStream_t s = ctx->stream;
+  const int S = adap ? adap->num_state_samples : 0, Cs = adap ? adap->num_context_samples : 0;
+  const int n_states = adap ? (S < nb ? S : nb) : 0;
+  const int rows_max = nb > n_states * Cs ? nb : n_states * Cs;
+  ph::AmWork w;
+  if (am_work(ctx, L, D, rows_max, &w)) return 1;
+  const int nslab = am_nslab(nb);
+  ph::AmGather g;
+  g.rb_obs = rb->observations;
+  g.rb_act = rb->actions;
+  g.rb_logp = rb->log_probs;
+  g.rb_adv = rb->advantages;
+  g.rb_ret = rb->returns;
+  g.rb_val = rb->values;
+  g.idx = indices;
+  g.nb = nb;
+  g.T = rb->T;
+  g.E = rb->E;
+  g.D = D;
+  g.norm_adv = hp->normalize_advantage;
+  g.advstats = advstats;
+  g.xg = w.xg;
+  g.act = w.act;
+  g.oldlp = w.oldlp;
+  g.adv = w.adv;
+  g.ret = w.ret;
+  g.oldv = w.oldv;
+  PH_HIP(ph::launch_am_gather(g, s));
+  for (int net = 0; net < 2; ++net) {
+    PH_HIP(ph::am_forward_net(L, params, net, w.xg, D, nb, w, s));
+    PH_HIP(ph::launch_am_loss(w, L.L, nb, *hp, ctx->statpart, nslab, net, s));
+    PH_HIP(ph::am_backward_net(L, params, net, w.xg, D, nb, w, ctx->slabs, nslab, L.P, net == 0 ? L.act_W : L.val_W,
+                               net == 0 ? L.act_b : L.val_b, s));
+  }
+  r->slabs = ctx->slabs;
+  r->nslab = nslab;
+  r->nstatpart = 2 * nslab;
+  r->P = L.P;
+  r->slab_len = L.P;
+  r->map = nullptr;
+  if (adap) {   // adap/util.py:97-131: n_states sampled states under Cs sampled contexts, policy net only
+    const int cs = adap->context_size, extra_len = L.vf_W1 + (L.val_W - L.act_W);
+    if (ensure(ctx->adap_extra, ctx->adap_extra_cap, (size_t)n_states * extra_len)) return 1;
+    if (ensure(ctx->adap_loss, ctx->adap_loss_cap, (size_t)n_states)) return 1;
+    ph::AmCtx a;
+    std::memset(&a, 0, sizeof(a));
+    a.rb_obs = rb->observations;
+    a.idx = indices;
+    a.nb = nb;
+    a.T = rb->T;
+    a.E = rb->E;
+    a.D = D;
+    a.ctx_size = cs;
+    a.n_ctx = Cs;
+    a.n_states = n_states;
+    a.sampler = adap->sampler;
+    a.state_idx = adap->state_idx ? adap->state_idx + (size_t)mbi * S : nullptr;
+    a.contexts = adap->contexts ? adap->contexts + (size_t)mbi * Cs * cs : nullptr;
+    a.seed = adap->seed;
+    a.epoch = ctx->rng_epoch;
+    a.mbi = (uint32_t)mbi;
+    a.nb_hb = ph::feistel_half_bits((uint32_t)nb);
+    a.rows = w.xg;
+    a.used_state_idx = adap->used_state_idx ? adap->used_state_idx + (size_t)mbi * S : nullptr;
+    a.used_contexts = adap->used_contexts ? adap->used_contexts + (size_t)mbi * Cs * cs : nullptr;
+    PH_HIP(ph::launch_am_ctx_rows(a, s));
+    const int R = n_states * Cs, npairs = Cs * (Cs - 1) / 2;
+    PH_HIP(ph::am_forward_net(L, params, 0, w.xg, D, R, w, s));
+    PH_HIP(ph::launch_am_ctx_loss(w.z, L.L, n_states, Cs, adap->context_loss_coeff / (float)(npairs * n_states), w.dz,
+                                  ctx->adap_loss, s));
+    // one slab per state (its Cs rows): policy-side parameters at their own offsets, the action head behind them
+    PH_HIP(ph::am_backward_net(L, params, 0, w.xg, D, R, w, ctx->adap_extra, n_states, extra_len, L.vf_W1,
+                               L.vf_W1 + (L.act_b - L.act_W), s));
+    r->extra = ctx->adap_extra;
+    r->n_extra = n_states;
+    r->extra_len = extra_len;
+    r->extra_cut = L.vf_W1;
+    r->extra_lo = L.act_W;
+    r->extra_hi = L.val_W;
+    r->extra_loss = ctx->adap_loss;
+    r->extra_norm = 1.0f / (float)(npairs * n_states);
+    r->extra_coef = adap->context_loss_coeff;
+    r->extra_loss_out = adap->context_loss ? adap->context_loss + mbi : nullptr;
+  }
+  return 0;
+}
+int am_adap_ok(const ph_adapmult_layout& L, const ph_adap_loss* ad, const char* who) {
+  const std::string w(who);
+  if (ad->context_size != L.C) return fail(w + ": the context term's context_size differs from the policy's");
+  if (ad->num_context_samples < 2 || ad->num_context_samples > ph::ADAP_ROWS) return fail(w + ": num_context_samples must be in [2, 16]");
+  if (ad->num_state_samples <= 0 || ad->num_state_samples > 256) return fail(w + ": num_state_samples must be in [1, 256]");
+  if (ad->sampler < PH_CTX_L2 || ad->sampler > PH_CTX_NATURAL_NUMBERS) return fail(w + ": unknown context sampler");
+  if (ad->sampler == PH_CTX_NATURAL_NUMBERS && ad->context_size != 1)
+    return fail(w + ": the natural_numbers sampler draws (num, 1) contexts: context_size must be 1");
+  return 0;
+}
+}  // namespace
+
+int ph_adapmult_forward(ph_ctx* ctx, const ph_spec* spec, int context_size, const float* params, const float* obs, int n,
+                        const unsigned char* action_mask, const float* uniforms, const float* given_actions,
+                        unsigned long long seed, unsigned long long counter, int deterministic, int* actions_i32,
+                        float* actions_f32, float* values, float* log_probs, float* entropy, float* logits, const ph_rollout* rb,
+                        int pos, const float* episode_start_in) {
+  DevGuard dev_guard(ctx);
+  if (!ctx) return fail("null ctx");
+  if (!params || !obs) return fail("ph_adapmult_forward: null params/obs");
+  if (n <= 0) return fail("ph_adapmult_forward: n must be positive");
+  ph_adapmult_layout L;
+  if (ph_adapmult_layout_of(spec, context_size, &L)) return 1;
+  ph::FwdArgs a;
+  std::memset(&a, 0, sizeof(a));
+  if (resolve(ctx, spec, &a.nd)) return 1;
+  a.params = params;
+  a.obs = obs;
+  a.n = n;
+  a.mask = action_mask;
+  a.uniforms = uniforms;
+  a.given_actions = given_actions;
+  a.seed = seed;
+  a.counter = counter;
+  a.epoch = ctx->rng_epoch;
+  a.deterministic = deterministic;
+  a.act_i32 = actions_i32;
+  a.act_f32 = actions_f32;
+  a.values = values;
+  a.logp = log_probs;
+  a.entropy = entropy;
+  a.logits = logits;
+  if (rb) {
+    if (check_rb(rb)) return 1;
+    if (n != rb->E) return fail("ph_adapmult_forward: fused add needs n == rollout E");
+    if (pos < 0 || pos >= rb->T) return fail("ph_adapmult_forward: pos out of range (buffer full?)");
+    if (!episode_start_in) return fail("ph_adapmult_forward: fused add needs episode_start_in");
+    const size_t row = (size_t)pos * rb->E;
+    a.rb_obs = rb->observations + row * a.nd.D;
+    a.rb_act = rb->actions + row * a.nd.A;
+    a.rb_rew = rb->rewards + row;
+    a.rb_es = rb->episode_starts + row;
+    a.rb_val = rb->values + row;
+    a.rb_logp = rb->log_probs + row;
+    a.es_in = episode_start_in;
+  }
+  ph::AmWork w;
+  if (am_work(ctx, L, a.nd.D, n, &w)) return 1;
+  PH_HIP(ph::am_forward_net(L, params, 0, obs, a.nd.D, n, w, ctx->stream));
+  PH_HIP(ph::am_forward_net(L, params, 1, obs, a.nd.D, n, w, ctx->stream));
+  PH_HIP(ph::launch_am_act(a, w.z, w.v, ctx->stream));
+  return 0;
+}
+
+int ph_adapmult_minibatch_grad(ph_ctx* ctx, const ph_spec* spec, int context_size, const float* params, const ph_rollout* rb,
+                               const ph_ppo_hyper* hp, const int* indices, int nb, float* grad_out, float* stats_out,
+                               const ph_adap_loss* adap) {
+  DevGuard dev_guard(ctx);
+  if (!ctx) return fail("null ctx");
+  if (!params || !hp || !indices || !grad_out) return fail("ph_adapmult_minibatch_grad: null argument");
+  if (check_rb(rb)) return 1;
+  if (nb <= 0) return fail("ph_adapmult_minibatch_grad: nb must be positive");
+  ph_adapmult_layout L;
+  if (ph_adapmult_layout_of(spec, context_size, &L)) return 1;
+  if (adap && am_adap_ok(L, adap, "ph_adapmult_minibatch_grad")) return 1;
+  const int nslab = am_nslab(nb);
+  if (ensure_train_ws(ctx, L.P, L.P, nslab, 1, 0, (size_t)nb)) return 1;
+  hipStream_t s = ctx->stream;
+  PH_HIP(ph::launch_set_int(ctx->stop_flag, 0, s));
+  ph::AdvStatArgs aa;
+  aa.rb_adv = rb->advantages;
+  aa.T = rb->T;
+  aa.E = rb->E;
+  aa.perms = indices;  // one "epoch" whose first nb entries are the minibatch
+  aa.perm_n = 0;
+  aa.perm_hb = 1;
+  aa.perm_seed = 0;
+  aa.epoch = nullptr;
+  aa.N = nb;
+  aa.batch = nb;
+  aa.n_mb = 1;
+  aa.out = ctx->advstats;
+  aa.partial = ctx->advpart;
+  aa.idx_out = nullptr;
+  aa.phys_out = ctx->perm_phys;
+  PH_HIP(ph::launch_adv_stats(aa, 1, s));
+  ph::ReduceArgs r;
+  if (am_minibatch(ctx, L, spec->obs.n, params, rb, hp, indices, nb, ctx->advstats, adap, 0, &r)) return 1;
+  r.grad = grad_out;
+  r.blocksq = ctx->blocksq;
+  r.statpart = ctx->statpart;
+  r.stats_out = stats_out;
+  r.nb = nb;
+  r.ent_coef = hp->ent_coef;
+  r.vf_coef = hp->vf_coef;
+  r.target_kl = -1.f;
+  r.stop_flag = ctx->stop_flag;
+  r.step = nullptr;
+  r.scalars = ctx->scalars;
+  PH_HIP(ph::launch_ppo_reduce(r, s));
+  return 0;
+}
+
+int ph_adapmult_train(ph_ctx* ctx, const ph_spec* spec, int context_size, const ph_opt_state* opt, const ph_rollout* rb,
+                      const ph_ppo_hyper* hp, int n_epochs, int batch_size, const int* perms, unsigned long long perm_seed,
+                      float* stats, const ph_adap_loss* adap) {
+  DevGuard dev_guard(ctx);
+  if (!ctx) return fail("null ctx");
+  if (!opt || !opt->params || !opt->adam_m || !opt->adam_v || !opt->step) return fail("ph_adapmult_train: null optimizer state");
+  if (!hp || !adap) return fail("ph_adapmult_train: null hyper-parameters / context-term description");
+  if (check_rb(rb)) return 1;
+  if (n_epochs <= 0 || batch_size <= 0) return fail("ph_adapmult_train: n_epochs and batch_size must be positive");
+  ph_adapmult_layout L;
+  if (ph_adapmult_layout_of(spec, context_size, &L)) return 1;
+  if (am_adap_ok(L, adap, "ph_adapmult_train")) return 1;
+  const int N = rb->T * rb->E, n_mb = (N + batch_size - 1) / batch_size;
+  const int nb_max = batch_size < N ? batch_size : N;
+  if (ensure_train_ws(ctx, L.P, L.P, am_nslab(nb_max), n_epochs * n_mb, perms ? 0 : (size_t)n_epochs * N, (size_t)n_epochs * N))
+    return 1;
+  hipStream_t s = ctx->stream;
+  const uint32_t hb = ph::feistel_half_bits((uint32_t)N);
+  ph::AdvStatArgs aa;
+  aa.rb_adv = rb->advantages;
+  aa.T = rb->T;
+  aa.E = rb->E;
+  aa.perms = perms;
+  aa.perm_n = (uint32_t)N;
+  aa.perm_hb = hb;
+  aa.perm_seed = perm_seed;
+  aa.epoch = ctx->rng_epoch;
+  aa.N = N;
+  aa.batch = batch_size;
+  aa.n_mb = n_mb;
+  aa.out = ctx->advstats;
+  aa.partial = ctx->advpart;
+  aa.idx_out = perms ? nullptr : ctx->perm_idx;
+  aa.phys_out = ctx->perm_phys;
+  aa.clear_flag = ctx->stop_flag;
+  PH_HIP(ph::launch_adv_stats(aa, n_epochs * n_mb, s));
+  for (int mbi = 0; mbi < n_epochs * n_mb; ++mbi) {
+    const int ep = mbi / n_mb, k = mbi - ep * n_mb, start = k * batch_size;
+    const int nb = (N - start < batch_size) ? N - start : batch_size;
+    const int* idx = (perms ? perms : ctx->perm_idx) + (size_t)ep * N + start;
+    ph::ReduceArgs r;
+    if (am_minibatch(ctx, L, spec->obs.n, opt->params, rb, hp, idx, nb, ctx->advstats + 2 * (size_t)mbi, adap, mbi, &r)) return 1;
+    r.grad = ctx->grad;
+    r.blocksq = ctx->blocksq;
+    r.statpart = ctx->statpart;
+    r.stats_out = stats ? stats + (size_t)mbi * PH_NSTAT : nullptr;
+    r.nb = nb;
+    r.ent_coef = hp->ent_coef;
+    r.vf_coef = hp->vf_coef;
+    r.target_kl = hp->target_kl;
+    r.stop_flag = ctx->stop_flag;
+    r.step = opt->step;
+    r.scalars = ctx->scalars;
+    PH_HIP(ph::launch_ppo_reduce(r, s));
+    ph::AdamArgs ad;
+    ad.params = opt->params;
+    ad.m = opt->adam_m;
+    ad.v = opt->adam_v;
+    ad.grad = ctx->grad;
+    ad.blocksq = ctx->blocksq;
+    ad.nblk = ph::reduce_blocks(L.P);
+    ad.P = L.P;
+    ad.step = opt->step;
+    ad.scalars = ctx->scalars;
+    ad.stop_flag = ctx->stop_flag;
+    ad.lr = hp->learning_rate;
+    ad.beta1 = hp->adam_beta1;
+    ad.beta2 = hp->adam_beta2;
+    ad.eps = hp->adam_eps;
+    ad.max_norm = hp->max_grad_norm;
+    ad.stats_out = r.stats_out;
+    ad.wimage = nullptr;
+    ad.wimage_map = nullptr;
+    PH_HIP(ph::launch_ppo_adam(ad, s));
+  }
+  return 0;
+}
 
 int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, const ph_rollout* rb,
                       const ph_ppo_hyper* hp, int batch_size, int reps, int gemm_mode, float* avg_ms_out) {

@@ -318,6 +318,46 @@ struct AdapArgs {
   const int* stop_flag;
   long long* prof;         // debug: per-workgroup phase timestamps (clock64), or null
 };
+// ---- AdapPolicyMult (ph_adapmult.hip): dense [rows][width] intermediates of ONE net at a time, sized for the largest row count ----
+struct AmWork {
+  float *x, *xa, *y, *h;        // [rows][64], [rows][64 C], [rows][64], [rows][64]
+  float *z, *v;                 // logits [rows][L], value [rows]
+  float *dz, *dv;               // dL/dlogits, dL/dvalue
+  float *dzh, *dy, *dza;        // backward: [rows][64], [rows][64], [rows][64 C]
+  float *xg;                    // the minibatch's rows [rows][D]
+  float *act, *oldlp, *adv, *ret, *oldv;   // its per-row scalars
+};
+struct AmGather {
+  const float *rb_obs, *rb_act, *rb_logp, *rb_adv, *rb_ret, *rb_val;
+  const int* idx;
+  int nb, T, E, D, norm_adv;
+  const float* advstats;
+  float *xg, *act, *oldlp, *adv, *ret, *oldv;
+};
+struct AmCtx {
+  const float* rb_obs;
+  const int* idx;
+  int nb, T, E, D;
+  int ctx_size, n_ctx, n_states, sampler;
+  const int* state_idx;
+  const float* contexts;
+  uint64_t seed;
+  const unsigned long long* epoch;
+  uint32_t mbi, nb_hb;
+  float* rows;                  // [n_states * n_ctx][D] out
+  int* used_state_idx;
+  float* used_contexts;
+};
+hipError_t am_forward_net(const ph_adapmult_layout& L, const float* params, int net, const float* X, int ldx, int rows,
+                          const AmWork& w, hipStream_t s);
+hipError_t am_backward_net(const ph_adapmult_layout& L, const float* params, int net, const float* X, int ldx, int rows,
+                           const AmWork& w, float* slabs, int nslab, int slab_len, int head_w_off, int head_b_off, hipStream_t s);
+hipError_t launch_am_act(const FwdArgs& a, const float* z, const float* v, hipStream_t s);
+hipError_t launch_am_gather(const AmGather& g, hipStream_t s);
+hipError_t launch_am_loss(const AmWork& w, int L, int nb, const ph_ppo_hyper& hp, float* statpart, int nslab, int net,
+                          hipStream_t s);
+hipError_t launch_am_ctx_rows(const AmCtx& a, hipStream_t s);
+hipError_t launch_am_ctx_loss(const float* z, int L, int n_states, int Cs, float wgt, float* dz, float* loss_part, hipStream_t s);
 int adap_workgroups(int n_ctx, int n_states);
 int adap_slab_floats(const ph_layout& lay);
 size_t adap_lds_bytes(const NetDims& nd, int n_ctx, int ctx_size);

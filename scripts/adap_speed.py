@@ -54,6 +54,19 @@ def main():
         a, b = timed(ppo), timed(adap)
         print(f"obs {d_env}+3: PPO.train {a:.3f} ms ({a / n_mb * 1e3:.1f} us / minibatch)   ADAP.train {b:.3f} ms "
               f"({b / n_mb * 1e3:.1f} us / minibatch)   context term +{(b - a) / n_mb * 1e3:.1f} us / minibatch", flush=True)
+        # AdapPolicyMult: another network (x, x_a = tanh(Ws x + bs) as (64, C), latent = tanh(W2 (x + x_a ctx) + b2)), run as a chain
+        # of small launches over dense intermediates (csrc/ph_adapmult.hip), at the bench-size minibatch and at the reference's own
+        mult = ADAP("AdapPolicyMult", env, **kw)
+        fill(mult, rng)
+        c = timed(mult, reps=2)
+        print(f"obs {d_env}+3: ADAP(AdapPolicyMult).train {c:.3f} ms ({c / n_mb * 1e3:.1f} us / 32768-row minibatch)", flush=True)
+    env = type("E", (), dict(observation_space=sp.Box(-np.inf, np.inf, (62,)), action_space=sp.Discrete(6), _is_dummy_space_env=True))()
+    for pol in ("AdapPolicy", "AdapPolicyMult"):     # the reference's sizes: n_envs 1, n_steps 2048, batch 64, 10 epochs = 320 steps
+        m = ADAP(pol, env, n_steps=2048, n_envs=1, batch_size=64, n_epochs=10, seed=0)
+        fill(m, np.random.default_rng(1))
+        t = timed(m, reps=2)
+        print(f"reference sizes (2048 rows, batch 64, 10 epochs): ADAP({pol}).train {t:.2f} ms = {t / 320 * 1e3:.1f} us per Adam step",
+              flush=True)
 
 
 if __name__ == "__main__":

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../pantheonrl_amd/csrc"
 mkdir -p variants
-SRCS="ph_abi.hip ph_policy.hip ph_gae.hip ph_ppo.hip ph_ppo_fast.hip ph_ppo_split.hip ph_envs.hip ph_agent.hip ph_bc.hip ph_adap.hip ph_modular.hip"
+SRCS="ph_abi.hip ph_policy.hip ph_gae.hip ph_ppo.hip ph_ppo_fast.hip ph_ppo_split.hip ph_envs.hip ph_agent.hip ph_bc.hip ph_adap.hip ph_modular.hip ph_adapmult.hip"
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I ../../include -I . -Wall -Wno-unused-function $flags \

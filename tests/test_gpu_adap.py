@@ -318,7 +318,9 @@ def test_adap_refuses_what_it_does_not_implement():
     box = type("E", (), dict(observation_space=sp.Box(-1, 1, (5,)), action_space=sp.Discrete(4), _is_dummy_space_env=True))()
     disc = type("E", (), dict(observation_space=sp.MultiBinary(5), action_space=sp.Discrete(4), _is_dummy_space_env=True))()
     with pytest.raises(ValueError):
-        ADAP("AdapPolicyMult", box)
+        ADAP("AdapPolicyTimes", box)                                        # (AdapPolicyMult: tests/test_gpu_adapmult.py)
+    with pytest.raises(Exception):
+        ADAP("AdapPolicyMult", box, context_size=5, n_steps=8, batch_size=8, n_epochs=1)   # the device path takes 1 .. 4 components
     with pytest.raises(ValueError):
         ADAP("AdapPolicy", box, context_sampler="natural_numbers")          # (num, 1) contexts need context_size = 1 ...
     nn_model = ADAP("AdapPolicy", box, context_sampler="natural_numbers", context_size=1, n_steps=8, batch_size=8, n_epochs=1)

@@ -285,7 +285,8 @@ def test_trainer_cli_surface_and_presets():
     args = trainer.preset(args, 1)
     assert args.tensorboard_log == "logs" and args.tensorboard_name == "RPS-v0-PPOPPO-7"
     assert args.ego_save == "models/RPS-v0-PPO-ego-7" and args.alt_save == "models/RPS-v0-PPO-alt-7"
-    for bad in (["RPS-v0", "ADAP_MULT", "PPO"], ["RPS-v0", "PPO", "BC"], ["OvercookedMultiEnv-v0", "PPO", "PPO"],
+    trainer.input_check(p.parse_args(["RPS-v0", "ADAP_MULT", "ADAP", "--share-latent", "--alt-config", "{}"]))   # trainer.py:32-34,67-71
+    for bad in (["RPS-v0", "ADAP_MULT", "PPO", "--share-latent"], ["RPS-v0", "PPO", "BC"], ["OvercookedMultiEnv-v0", "PPO", "PPO"],
                 ["RPS-v0", "PPO", "PPO", "--share-latent"], ["RPS-v0", "ADAP", "PPO", "--share-latent"],
                 ["RPS-v0", "SAC", "PPO"]):
         a = p.parse_args(bad)

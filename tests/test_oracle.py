@@ -416,7 +416,7 @@ def test_modular_train_walks_partner_by_partner_with_one_buffer_each():
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# AdapPolicyMult (adap/policies.py:136-283) -- oracle only: the restatement the device path will be built against
+# AdapPolicyMult (adap/policies.py:136-283): the restatement the device path (csrc/ph_adapmult.hip) is tested against
 # ----------------------------------------------------------------------------------------------------------------
 def _mult(F=7, C=3, L=4, seed=2):
     th.manual_seed(seed)
@@ -502,8 +502,7 @@ def test_adap_mult_known_answers():
     loss.backward()
     for sc in (pol3.agent_scaling, pol3.value_scaling):
         assert sc[0].weight.grad is not None and float(sc[0].weight.grad.abs().sum()) > 0
-    with pytest.raises(NotImplementedError):
-        pol3.flat_params()
+    assert pol3.flat_params().size == sum(prm.numel() for prm in pol3.parameters())     # the device layout holds every parameter
     # (7) ADAP's context term (util.py:97-131) on this network: with the scaling layers at zero the policy ignores its context, every
     # pairwise KL is 0 and the term is exactly 1; with them live it is below 1 and differentiable through the scaling weights
     ctxs = np.random.default_rng(3).standard_normal((4, C)).astype(np.float32)
@@ -513,3 +512,71 @@ def test_adap_mult_known_answers():
     pol3.optimizer.zero_grad()
     term.backward()
     assert float(pol3.agent_scaling[0].weight.grad.abs().sum()) > 0 and pol3.value_scaling[0].weight.grad is None
+
+
+def test_adap_mult_flat_layout_round_trip_and_the_launch_chain_of_its_gradient():
+    """(1) the flat vector of ph_adapmult_layout (per net W1 b1 Ws bs W2 b2, heads last; weights input-major) round-trips through the
+    oracle; (2) the backward chain csrc/ph_adapmult.hip runs launch by launch -- dh = dz Wo^T, dzh = dh (1 - h^2), dW2 = y^T dzh,
+    dy = dzh W2^T, dza = dy ctx (1 - xa^2), dWs = x^T dza, dx = dy + dza Ws^T, dz1 = dx (1 - x^2), dW1 = o^T dz1 -- restated in
+    float64 numpy on the flat vector, is autograd's gradient of an arbitrary function of the logits and the value"""
+    F, C, L = 7, 3, 4
+    pol = _mult(F, C, L, seed=4)
+    with th.no_grad():
+        for prm in pol.parameters():
+            if prm.ndim == 1:
+                prm.add_(0.2 * th.randn_like(prm))
+    flat = pol.flat_params()
+    H_ = 64
+    per_net = F * H_ + H_ + H_ * H_ * C + H_ * C + H_ * H_ + H_
+    assert flat.size == 2 * per_net + H_ * L + L + H_ + 1
+    other = _mult(F, C, L, seed=9)
+    other.load_flat_params(flat)
+    assert np.array_equal(other.flat_params(), flat)
+    rng = np.random.default_rng(0)
+    obs = rng.standard_normal((11, F + C)).astype(np.float32)
+    assert th.equal(other.logits(th.as_tensor(obs)), pol.logits(th.as_tensor(obs)))
+    # an arbitrary scalar of the outputs: autograd ...
+    wz, wv = rng.standard_normal((11, L)), rng.standard_normal((11, 1))
+    pol.optimizer.zero_grad()
+    z = pol.logits(th.as_tensor(obs))
+    v = pol.predict_values(th.as_tensor(obs))
+    ((z * th.as_tensor(wz, dtype=th.float32)).sum() + (v * th.as_tensor(wv, dtype=th.float32)).sum()).backward()
+    g_ref = pol.flat_grads().astype(np.float64)
+    # ... and the chain, net by net, on the flat vector
+    p = flat.astype(np.float64)
+    o, ctx = obs[:, :F].astype(np.float64), obs[:, F:].astype(np.float64)
+    g = np.zeros_like(p)
+    off = 0
+    offs = {}
+    for net in ("pi", "vf"):
+        for nm, n in (("W1", F * H_), ("b1", H_), ("Ws", H_ * H_ * C), ("bs", H_ * C), ("W2", H_ * H_), ("b2", H_)):
+            offs[net + nm] = (off, n)
+            off += n
+    for nm, n in (("act_W", H_ * L), ("act_b", L), ("val_W", H_), ("val_b", 1)):
+        offs[nm] = (off, n)
+        off += n
+    take = lambda k: p[offs[k][0]:offs[k][0] + offs[k][1]]      # noqa: E731
+
+    def put(k, val):
+        g[offs[k][0]:offs[k][0] + offs[k][1]] = np.asarray(val).reshape(-1)
+    for net, Wo, bo, dout in (("pi", "act_W", "act_b", wz), ("vf", "val_W", "val_b", wv)):
+        W1, Ws, W2 = take(net + "W1").reshape(F, H_), take(net + "Ws").reshape(H_, H_ * C), take(net + "W2").reshape(H_, H_)
+        x = np.tanh(o @ W1 + take(net + "b1"))
+        xa = np.tanh(x @ Ws + take(net + "bs"))                                     # column j * C + c
+        y = x + (xa.reshape(-1, H_, C) * ctx[:, None, :]).sum(-1)
+        h = np.tanh(y @ W2 + take(net + "b2"))
+        No = dout.shape[1]
+        Wout = take(Wo).reshape(H_, No)
+        put(Wo, h.T @ dout)
+        put(bo, dout.sum(0))
+        dzh = (dout @ Wout.T) * (1 - h * h)
+        put(net + "W2", y.T @ dzh)
+        put(net + "b2", dzh.sum(0))
+        dy = dzh @ W2.T
+        dza = (dy[:, :, None] * ctx[:, None, :]).reshape(-1, H_ * C) * (1 - xa * xa)
+        put(net + "Ws", x.T @ dza)
+        put(net + "bs", dza.sum(0))
+        dz1 = (dy + dza @ Ws.T) * (1 - x * x)
+        put(net + "W1", o.T @ dz1)
+        put(net + "b1", dz1.sum(0))
+    assert np.abs(g - g_ref).max() <= 2e-5 * max(1.0, np.abs(g_ref).max()), np.abs(g - g_ref).max()
