@@ -17,35 +17,50 @@
 namespace ph {
 
 // ---- primitives -----------------------------------------------------------------------------------------------------------------
-// Y[r][n] = act(b[n] + sum_k X[r * ldx + k] W[k * N + n]), r < rows, n < N; act: 0 none, 1 tanh.  16 rows x 64 columns per block.
+// Y[r][n] = act(b[n] + sum_k X[r * ldx + k] W[k * N + n]), r < rows, n < N, K <= 64; act: 0 none, 1 tanh.  A block owns 64 rows x
+// 64 columns, a thread 4 x 4 of them; X (transposed to [k][row]) and W's columns pass through LDS once; k ascending per entry.
 __global__ __launch_bounds__(256) void am_dense_kernel(const float* __restrict__ X, int ldx, int K, const float* __restrict__ W,
                                                        const float* __restrict__ b, int N, float* __restrict__ Y, int rows, int act) {
-  __shared__ float xs[16][65];
-  const int tid = threadIdx.x, rr = tid >> 4, cq = tid & 15;
-  const int r0 = blockIdx.x * 16, n0 = blockIdx.y * 64 + cq * 4;
-  for (int e = tid; e < 16 * K; e += 256) {
-    const int r = e / K, k = e - r * K;
-    xs[r][k] = (r0 + r < rows) ? X[(size_t)(r0 + r) * ldx + k] : 0.f;
+  __shared__ __attribute__((aligned(16))) float xt[64][68], ws[64][68];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int r0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int rl = e >> 6, k = e & 63;   // consecutive lanes read consecutive k of one row of X
+    xt[k][rl] = (r0 + rl < rows && k < K) ? X[(size_t)(r0 + rl) * ldx + k] : 0.f;
+    const int kk = e >> 6, c = e & 63;   // ... and consecutive columns of one row of W
+    ws[kk][c] = (kk < K && n0 + c < N) ? W[(size_t)kk * N + n0 + c] : 0.f;
   }
   __syncthreads();
-  const int r = r0 + rr;
-  if (r >= rows) return;
-  float acc[4];
+  float acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = (n0 + i < N) ? b[n0 + i] : 0.f;
+  for (int j = 0; j < 4; ++j) {
+    const float bv = (n0 + 4 * tx + j < N) ? b[n0 + 4 * tx + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][j] = bv;
+  }
   for (int k = 0; k < K; ++k) {
-    const float xv = xs[rr][k];
+    const float4 a4 = *reinterpret_cast<const float4*>(&xt[k][4 * ty]);
+    const float4 b4 = *reinterpret_cast<const float4*>(&ws[k][4 * tx]);
+    const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bw[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (n0 + i < N) acc[i] = fmaf(xv, W[(size_t)k * N + n0 + i], acc[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bw[j], acc[i][j]);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (n0 + i < N) Y[(size_t)r * N + n0 + i] = act ? fast_tanh(acc[i]) : acc[i];
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + 4 * ty + i;
+    if (r >= rows) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 4 * tx + j;
+      if (n < N) Y[(size_t)r * N + n] = act ? fast_tanh(acc[i][j]) : acc[i][j];
+    }
+  }
 }
 static hipError_t dense(const float* X, int ldx, int K, const float* W, const float* b, int N, float* Y, int rows, int act,
                         hipStream_t s) {
-  hipLaunchKernelGGL(am_dense_kernel, dim3((rows + 15) / 16, (N + 63) / 64), dim3(256), 0, s, X, ldx, K, W, b, N, Y, rows, act);
+  hipLaunchKernelGGL(am_dense_kernel, dim3((rows + 63) / 64, (N + 63) / 64), dim3(256), 0, s, X, ldx, K, W, b, N, Y, rows, act);
   return hipGetLastError();
 }
 
@@ -61,18 +76,45 @@ __global__ void am_contract_kernel(const float* __restrict__ x, const float* __r
   y[e] = v;
 }
 
-// dX[r][k] (+)= sum_n dY[r][n] W[k * N + n]   (dX = dY W^T), k < K
+// dX[r][k] (+)= sum_n dY[r][n] W[k * N + n]   (dX = dY W^T), K = 64.  16 rows per block; dY and W pass through LDS in chunks of
+// 64 columns (W's chunk transposed to [n][k]: a lane's four k are contiguous), n in ascending order per entry.
 __global__ __launch_bounds__(256) void am_dense_dx_kernel(const float* __restrict__ dY, const float* __restrict__ W, int N, int K,
                                                           float* __restrict__ dX, int rows, int accumulate) {
-  const int tid = threadIdx.x, k = tid & 63;
-  const int r = blockIdx.x * 4 + (tid >> 6);
-  if (r >= rows || k >= K) return;
-  float v = accumulate ? dX[(size_t)r * K + k] : 0.f;
-  for (int n = 0; n < N; ++n) v = fmaf(dY[(size_t)r * N + n], W[(size_t)k * N + n], v);
-  dX[(size_t)r * K + k] = v;
+  __shared__ float ds[16][65];
+  __shared__ __attribute__((aligned(16))) float wt[64][68];   // [n][k]
+  const int tid = threadIdx.x, rr = tid >> 4, kq = tid & 15;
+  const int r0 = blockIdx.x * 16, r = r0 + rr;
+  float acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (accumulate && r < rows) ? dX[(size_t)r * K + 4 * kq + i] : 0.f;
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    const int nn = (N - n0 < 64) ? N - n0 : 64;
+    __syncthreads();
+    for (int e = tid; e < 16 * 64; e += 256) {
+      const int rl = e >> 6, n = e & 63;
+      ds[rl][n] = (r0 + rl < rows && n < nn) ? dY[(size_t)(r0 + rl) * N + n0 + n] : 0.f;
+    }
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int k = e >> 6, n = e & 63;      // consecutive lanes read consecutive n of one row k of W
+      wt[n][k] = (n < nn) ? W[(size_t)k * N + n0 + n] : 0.f;
+    }
+    __syncthreads();
+    for (int n = 0; n < nn; ++n) {
+      const float d = ds[rr][n];
+      const float4 w4 = *reinterpret_cast<const float4*>(&wt[n][4 * kq]);
+      acc[0] = fmaf(d, w4.x, acc[0]);
+      acc[1] = fmaf(d, w4.y, acc[1]);
+      acc[2] = fmaf(d, w4.z, acc[2]);
+      acc[3] = fmaf(d, w4.w, acc[3]);
+    }
+  }
+  if (r < rows) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dX[(size_t)r * K + 4 * kq + i] = acc[i];
+  }
 }
 static hipError_t dense_dx(const float* dY, const float* W, int N, int K, float* dX, int rows, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(am_dense_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dY, W, N, K, dX, rows, accumulate);
+  hipLaunchKernelGGL(am_dense_dx_kernel, dim3((rows + 15) / 16), dim3(256), 0, s, dY, W, N, K, dX, rows, accumulate);
   return hipGetLastError();
 }
 
@@ -94,29 +136,69 @@ __global__ void am_contract_bwd_kernel(const float* __restrict__ dy, const float
 }
 
 // slab k (rows [k * per, (k + 1) * per) of the minibatch): slab[woff + kk * N + n] = sum_r X[r * ldx + kk] dY[r * N + n] and
-// slab[boff + n] = sum_r dY[r * N + n] -- one thread per entry, rows in order (a fixed summation order per entry)
+// slab[boff + n] = sum_r dY[r * N + n].  A block owns a 64 (kk) x 64 (n) tile of the product for its slab, a thread 4 x 4 entries;
+// X and dY pass through LDS 16 rows at a time; every entry adds its rows in ascending order (a fixed summation order).
 __global__ __launch_bounds__(256) void am_dense_dw_kernel(const float* __restrict__ X, int ldx, int K, const float* __restrict__ dY,
                                                           int N, float* __restrict__ slabs, int slab_len, int woff, int boff, int rows,
                                                           int per) {
-  const int e = blockIdx.y * 256 + threadIdx.x;
-  if (e >= (K + 1) * N) return;
+  __shared__ __attribute__((aligned(16))) float xs[16][68], ds[16][68];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int n0 = blockIdx.y * 64;
   const int r0 = blockIdx.x * per, r1 = (r0 + per < rows) ? r0 + per : rows;
-  float acc = 0.f;
-  if (e < K * N) {
-    const int kk = e / N, n = e - kk * N;
-    for (int r = r0; r < r1; ++r) acc = fmaf(X[(size_t)r * ldx + kk], dY[(size_t)r * N + n], acc);
-    slabs[(size_t)blockIdx.x * slab_len + woff + e] = acc;
-  } else {
-    const int n = e - K * N;
-    for (int r = r0; r < r1; ++r) acc += dY[(size_t)r * N + n];
-    slabs[(size_t)blockIdx.x * slab_len + boff + n] = acc;
+  float acc[4][4], bsum[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bsum[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  }
+  for (int rb = r0; rb < r1; rb += 16) {
+    __syncthreads();
+    for (int e = tid; e < 16 * 64; e += 256) {
+      const int rl = e >> 6, c = e & 63;
+      const bool live = rb + rl < r1;
+      xs[rl][c] = (live && c < K) ? X[(size_t)(rb + rl) * ldx + c] : 0.f;
+      ds[rl][c] = (live && n0 + c < N) ? dY[(size_t)(rb + rl) * N + n0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int rl = 0; rl < 16; ++rl) {
+      const float4 a4 = *reinterpret_cast<const float4*>(&xs[rl][4 * ty]);
+      const float4 b4 = *reinterpret_cast<const float4*>(&ds[rl][4 * tx]);
+      const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+      if (ty == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bsum[j] += b[j];
+      }
+    }
+  }
+  float* slab = slabs + (size_t)blockIdx.x * slab_len;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kk = 4 * ty + i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 4 * tx + j;
+      if (kk < K && n < N) slab[woff + kk * N + n] = acc[i][j];
+    }
+  }
+  if (ty == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 4 * tx + j;
+      if (n < N) slab[boff + n] = bsum[j];
+    }
   }
 }
 static hipError_t dense_dw(const float* X, int ldx, int K, const float* dY, int N, float* slabs, int nslab, int slab_len, int woff,
                            int boff, int rows, hipStream_t s) {
   const int per = (rows + nslab - 1) / nslab;
-  hipLaunchKernelGGL(am_dense_dw_kernel, dim3(nslab, ((K + 1) * N + 255) / 256), dim3(256), 0, s, X, ldx, K, dY, N, slabs,
-                     slab_len, woff, boff, rows, per);
+  hipLaunchKernelGGL(am_dense_dw_kernel, dim3(nslab, (N + 63) / 64), dim3(256), 0, s, X, ldx, K, dY, N, slabs, slab_len, woff, boff,
+                     rows, per);
   return hipGetLastError();
 }
 
