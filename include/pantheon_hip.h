@@ -38,7 +38,7 @@ extern "C" {
                               3: + ph_selfplay_rollout_persistent, PH_STEP_FIX_ILLEGAL / _MASK_ENV_ONLY, ph_modular_*, ph_roundrobin_*_iteration
                                   (additions only)
                               4: + ph_selfplay_rollout_persistent_capacity, ph_ppo_train's gradient pack (no signature changed)
-                              5: + ph_policy_act_host, ph_buffer_add_reward_const, ph_adapmult_* (additions only) */
+                              5: + ph_policy_act_host, ph_buffer_add_reward_const, ph_adapmult_*, ph_ctx_set_joint_reward_rule (additions only) */
 #define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
 #define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
 #define PH_MAX_LOGITS 64 /* max total policy logits L */
@@ -156,6 +156,17 @@ int ph_buffer_add_reward(ph_ctx *ctx, const ph_rollout *rb, int pos, const float
 /* Agent.update(reward, done) with a SCALAR reward (agents.py:198: buf.rewards[pos - 1][0] += reward; every environment of the
  * row receives it): the value travels as a kernel argument -- no host array, no copy, nothing to wait for. */
 int ph_buffer_add_reward_const(ph_ctx *ctx, const ph_rollout *rb, int pos, float reward);
+/* How the joint action of a SimultaneousEnv step enters every agent's reward in ph_buffer_add_reward_joint, ph_policy_step_multi,
+ * ph_selfplay_rollout_* (multiagentenv.py:395-409 hands each agent ITS reward of the step).  A setting of the context:
+ *   PH_JOINT_MATCH_BONUS (default): + bonus * [own action == partner's]   -- the synthetic driver's shared coordination term
+ *   PH_JOINT_RPS:                   + bonus * rock-paper-scissors payoff of (own, partner's): (own - partner's + 3) % 3 == 1 wins,
+ *                                     == 2 loses, 0 draws (rps.py:41-45; zero-sum: the partner's reward is the negative) -- a
+ *                                     device-resident RPS self-play is the exchange rollout under this rule (bonus = 1, base reward 0,
+ *                                     every step ends its episode) */
+#define PH_JOINT_MATCH_BONUS 0
+#define PH_JOINT_RPS 1
+int ph_ctx_set_joint_reward_rule(ph_ctx *ctx, int rule);
+
 /* Agent-per-GPU SimultaneousEnv step (multiagentenv.py:149-170 with the actions all-gathered over RCCL): seat `seat`
  * receives rewards[pos][e] += base_reward[e] + bonus * (joint[seat][e] == joint[*partner_seat][e]) -- the shared
  * coordination term of the synthetic transition, consuming the JOINT action.  joint_actions is (n_seats, E) int32;

@@ -202,6 +202,7 @@ SIGNATURES = {
     "ph_gae": [_vp, C.POINTER(PhRollout), _vp, _vp, _d, _d, _i],
     "ph_policy_forward": [_vp, C.POINTER(PhSpec), _vp, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, _vp, _vp,
                           _vp, C.POINTER(PhRollout), _i, _vp, _vp, _i],
+    "ph_ctx_set_joint_reward_rule": [_vp, _i],
     "ph_adapmult_layout_of": [C.POINTER(PhSpec), _i, _vp],
     "ph_adapmult_forward": [_vp, C.POINTER(PhSpec), _i, _vp, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, _vp, _vp,
                             _vp, C.POINTER(PhRollout), _i, _vp],
@@ -368,6 +369,11 @@ class Context:
 
     def sync(self) -> None:
         check(self.lib.ph_ctx_sync(self.handle))
+
+    def set_joint_reward_rule(self, rule: str) -> None:
+        """how a step's joint action enters the agents' rewards (ph_ctx_set_joint_reward_rule): "match" = bonus * [own == partner's]
+        (the synthetic driver), "rps" = bonus * rock-paper-scissors payoff (rps.py:41-45)"""
+        check(self.lib.ph_ctx_set_joint_reward_rule(self.handle, {"match": 0, "rps": 1}[rule]))
 
     def set_exclusive_device(self, exclusive: bool) -> None:
         """scheduling hint (ph_set_exclusive_device): this context's training launches have the device to themselves"""

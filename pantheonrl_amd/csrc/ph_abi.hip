@@ -60,6 +60,7 @@ struct ph_ctx {
   float* act_stage_host = nullptr;
   float* act_stage_dev = nullptr;
   size_t act_stage_cap = 0;   // floats
+  int joint_reward_rule = 0;     // ph_ctx_set_joint_reward_rule: how a step's joint action enters the agents' rewards
   const int* wimage_zeroed_for = nullptr;   // the map (= spec) the weight image's unbacked elements were last zeroed for
   bool exclusive = false;             // ph_set_exclusive_device: nothing else runs on the device beside this context's launches
   unsigned short* wimage = nullptr;   // split gradient kernel: pre-split weight fragments of the policy being trained (ph_split.h)
@@ -342,6 +343,13 @@ int ph_ctx_destroy(ph_ctx* ctx) {
   return 0;
 }
 
+int ph_ctx_set_joint_reward_rule(ph_ctx* ctx, int rule) {
+  if (!ctx) return fail("null ctx");
+  if (rule != PH_JOINT_MATCH_BONUS && rule != PH_JOINT_RPS) return fail("ph_ctx_set_joint_reward_rule: unknown rule");
+  ctx->joint_reward_rule = rule;
+  return 0;
+}
+
 int ph_ctx_set_stream(ph_ctx* ctx, void* hip_stream) {
   DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");
@@ -530,7 +538,7 @@ int ph_buffer_add_reward_joint(ph_ctx* ctx, const ph_rollout* rb, int pos, const
   if (!base_reward || !joint_actions || !partner_seat) return fail("ph_buffer_add_reward_joint: null argument");
   if (n_seats <= 0 || seat < 0 || seat >= n_seats) return fail("ph_buffer_add_reward_joint: bad seat");
   PH_HIP(ph::launch_reward_add_joint(rb->rewards + (size_t)pos * rb->E, base_reward, joint_actions, rb->E, n_seats, seat,
-                                     partner_seat, bonus, ctx->stream));
+                                     partner_seat, bonus, ctx->joint_reward_rule, ctx->stream));
   return 0;
 }
 
@@ -916,6 +924,7 @@ int step_multi_impl(ph_ctx* ctx, int n_calls, const ph_step_call* calls, const p
         a.seat = c.seat;
         a.partner_seat = c.partner_seat;
         a.bonus = c.bonus;
+        a.reward_rule = ctx->joint_reward_rule;
       }
     }
   }
@@ -1234,6 +1243,7 @@ int ph_selfplay_rollout_persistent(ph_ctx* ctx, int n_calls, const ph_rollout_ca
     a.seat = c.seat;
     a.partner_seat = c.partner_seat;
     a.bonus = c.bonus;
+    a.reward_rule = ctx->joint_reward_rule;
     a.ll_epoch = x->epoch;
     a.ll_T = x->T;
     a.ll_timeout = x->timeout_cycles;

@@ -316,18 +316,18 @@ hipError_t launch_ragged_advance(int* pos_env, const unsigned char* mask, int T,
 
 __global__ void reward_add_joint_kernel(float* __restrict__ rew_row, const float* __restrict__ base,
                                         const int* __restrict__ joint, int E, int n_seats, int seat,
-                                        const int* __restrict__ partner_seat, float bonus) {
+                                        const int* __restrict__ partner_seat, float bonus, int rule) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   int p = *partner_seat;
   p = p < 0 ? 0 : (p >= n_seats ? n_seats - 1 : p);
-  const float b = (joint[(size_t)seat * E + e] == joint[(size_t)p * E + e]) ? bonus : 0.f;
+  const float b = joint_reward(joint[(size_t)seat * E + e], joint[(size_t)p * E + e], bonus, rule);
   rew_row[e] += base[e] + b;
 }
 hipError_t launch_reward_add_joint(float* rew_row, const float* base, const int* joint, int E, int n_seats, int seat,
-                                   const int* partner_seat, float bonus, hipStream_t s) {
+                                   const int* partner_seat, float bonus, int rule, hipStream_t s) {
   hipLaunchKernelGGL(reward_add_joint_kernel, dim3((E + 255) / 256), dim3(256), 0, s, rew_row, base, joint, E, n_seats,
-                     seat, partner_seat, bonus);
+                     seat, partner_seat, bonus, rule);
   return hipGetLastError();
 }
 

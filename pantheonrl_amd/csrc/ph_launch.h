@@ -63,6 +63,7 @@ struct FwdArgs {
   int n_seats, seat;
   const int* partner_seat;      // device int
   float bonus;
+  int reward_rule;              // how the joint action enters the reward (ph_rowtail.h joint_reward): 0 match bonus, 1 rock-paper-scissors
   const unsigned char* env_mask;  // (n, L) or null: act_i32 (what the environment / the exchange consumes) receives the
                                   // ENV-side fix-up of an illegal sample -- the first legal index, pettingzoo.py:81-82 -- while
                                   // the rollout buffer keeps the sampled action, as the reference's agent does.  Independent of
@@ -152,6 +153,17 @@ struct GradArgs {
   const uint4* rec_vf;     // this minibatch: {physical row, return, old value, -}
   int net_base;            // 0; experiments launch the two nets separately (net = blockIdx.y + net_base)
 };
+
+// What the joint action of a SimultaneousEnv step adds to an agent's reward (multiagentenv.py:395-409 hands every agent ITS reward):
+// rule 0 = the synthetic driver's shared coordination term, bonus * [own action == partner's]; rule 1 = rock-paper-scissors,
+// bonus * payoff with (own - partner's + 3) % 3 == 1 a win, == 2 a loss (rps.py:41-45: the ego's gain, the partner gets its negative)
+__device__ __host__ inline float joint_reward(int mine, int theirs, float bonus, int rule) {
+  if (rule == 1) {
+    const int d = (mine - theirs + 3) % 3;
+    return d == 1 ? bonus : (d == 2 ? -bonus : 0.f);
+  }
+  return mine == theirs ? bonus : 0.f;
+}
 
 __device__ __host__ inline uint64_t epoch_key(uint64_t seed, int epoch) {
   uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(epoch + 1);
@@ -275,7 +287,7 @@ hipError_t launch_liar_reset(int* hands, int* history, int* nmoves, const unsign
 hipError_t launch_reward_add(float* rew_row, const float* reward, const unsigned char* env_mask, int E, hipStream_t s);
 hipError_t launch_reward_add_const(float* rew_row, float reward, int E, hipStream_t s);
 hipError_t launch_reward_add_joint(float* rew_row, const float* base, const int* joint, int E, int n_seats, int seat,
-                                   const int* partner_seat, float bonus, hipStream_t s);
+                                   const int* partner_seat, float bonus, int rule, hipStream_t s);
 hipError_t launch_framestack_push(float* stack, const float* obs, const unsigned char* reset_mask,
                                   const float* default_obs, int n, int D, int nf, hipStream_t s);
 hipError_t launch_roundrobin_env_step(const int* joint, int* partnerid, const float* base, const float* done, float* reward_out,

@@ -437,7 +437,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
             p = p < 0 ? 0 : (p >= a0.n_seats ? a0.n_seats - 1 : p);
             const int mine = ll_read(b, b.joint_ll + (size_t)a0.seat * a0.n + grow);
             const int theirs = ll_read(b, b.joint_ll + (size_t)p * a0.n + grow);
-            add += (mine == theirs) ? a0.bonus : 0.f;
+            add += joint_reward(mine, theirs, a0.bonus, a0.reward_rule);
           }
           a.rb_rew[grow] += add;
         }

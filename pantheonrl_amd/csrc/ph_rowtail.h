@@ -61,9 +61,9 @@ __device__ __forceinline__ void value_row_tail(const FwdArgs& a, int g, float v,
         if (a.joint_ll) {
           const int mine = ll_read(a, a.joint_ll + (size_t)a.seat * a.n + g);
           const int theirs = ll_read(a, a.joint_ll + (size_t)p * a.n + g);
-          add += (mine == theirs) ? a.bonus : 0.f;
+          add += joint_reward(mine, theirs, a.bonus, a.reward_rule);
         } else {
-          add += (a.joint[(size_t)a.seat * a.n + g] == a.joint[(size_t)p * a.n + g]) ? a.bonus : 0.f;
+          add += joint_reward(a.joint[(size_t)a.seat * a.n + g], a.joint[(size_t)p * a.n + g], a.bonus, a.reward_rule);
         }
       }
       if (has_pre) a.prev_rew[g] = pre.prev + add;

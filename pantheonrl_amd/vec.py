@@ -182,6 +182,19 @@ class SyntheticRollouts:
         self.T, self.E = T, E
 
 
+class RPSTables:
+    """What RPSEnv (envs/rps.py; reference rpsgym/rps.py:8-48) hands two agents over n_steps rounds of n_envs tables, as the
+    exchange rollouts' inputs: the constant observation [0], base reward 0 (the whole reward is the joint action's payoff:
+    FusedSelfPlayRollout(..., reward_rule="rps", bonus=1.0)) and every round ends its episode."""
+
+    def __init__(self, n_envs: int, n_steps: int, device):
+        T, E = n_steps, n_envs
+        self.obs = th.zeros((T, E, 1), dtype=th.float32, device=device)
+        self.rewards = th.zeros((T, E), dtype=th.float32, device=device)
+        self.dones = th.ones((T, E), dtype=th.float32, device=device)
+        self.T, self.E = T, E
+
+
 def run_iteration_eager(agent: VecOnPolicyAgent, data: SyntheticRollouts, scripted: bool = False) -> None:
     """one PPO iteration: T x (get_action, update), then GAE + train at the head of the next get_action -- here
     invoked explicitly so an iteration is self-contained.  scripted: the T steps as one launch (rollout_scripted)."""
@@ -304,7 +317,7 @@ class FusedSelfPlayRollout:
     PPO update of the local agents then run concurrently on separate streams."""
 
     def __init__(self, agents, datas, exchange, stream: th.cuda.Stream, bonus: float = 0.01, update_graphs: bool = True,
-                 masks=None, mask_mode: int = 2, persistent: Optional[bool] = None):
+                 masks=None, mask_mode: int = 2, persistent: Optional[bool] = None, reward_rule: str = "match"):
         """masks[i]: (T, E, L) uint8 action masks of local agent i's steps (SURVEY.md 8d, config 5 variant) or None.
         mask_mode 2 (default) is the reference's plain PPO partner: the policy never sees the mask (agents.py:162 hands it
         obs.obs), the environment replaces an illegal sample by the first legal index (pettingzoo.py:81-82) and the buffer row
@@ -312,6 +325,10 @@ class FusedSelfPlayRollout:
         persistent: None = use the one-launch exchange rollout (ph_selfplay_rollout_persistent) whenever the peer-to-peer
         route is up and the launch fits the chip."""
         self.agents, self.datas, self.exchange, self.stream, self.bonus = agents, datas, exchange, stream, bonus
+        # reward_rule "rps": the joint action pays rock-paper-scissors (bonus * payoff of (own, partner's), rps.py:41-45) instead of
+        # the synthetic driver's match bonus -- with zero base rewards and every step a terminal one this IS RPSEnv for E tables
+        for a in agents:
+            a.model.policy.ctx.set_joint_reward_rule(reward_rule)
         self.masks, self.mask_mode, self.want_persistent = masks, int(mask_mode), persistent
         self.update_graphs, self._update_gid, self._iterations_run = update_graphs, None, 0
         dev = agents[0].model.policy.device

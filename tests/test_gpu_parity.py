@@ -1555,6 +1555,54 @@ def test_persistent_exchange_rollout_is_bitwise_the_per_step_walk(E, T, n_agents
         assert (n_illegal > T * E * n_agents // 20) if mask_mode == 2 else (n_illegal == 0)
 
 
+@pytest.mark.parametrize("E,T", [(64, 8), (1024, 128)])
+def test_device_resident_rps_self_play_is_one_launch_and_pays_the_reference_payoff(E, T):
+    """BASELINE config 1's game as a device-resident self-play (rpsgym/rps.py:41-45; multiagentenv.py:395-409): two PPO learners on
+    E tables, the exchange rollout under PH_JOINT_RPS -- every round's reward is the payoff of the joint action, +1 / 0 / -1 for the
+    one and its negative for the other, every round ends its episode.  The one-launch rollout (ph_selfplay_rollout_persistent) is
+    bitwise the launch-per-step walk; the rewards are envs/rps.py's PAYOFF of the recorded actions, exactly."""
+    from pantheonrl_amd import PPO, spaces as sp
+    from pantheonrl_amd import dist as pdist
+    from pantheonrl_amd.envs.rps import rps_payoff
+    from pantheonrl_amd.vec import FusedSelfPlayRollout, RPSTables, VecOnPolicyAgent
+    env = type("S", (), dict(observation_space=sp.Discrete(1), action_space=sp.Discrete(3), _is_dummy_space_env=True))()
+
+    def run(persistent):
+        agents, datas = [], []
+        for seed in (5, 6):
+            m = PPO("MlpPolicy", env, n_steps=T, n_envs=E, batch_size=E * T // 2, n_epochs=2, seed=seed)
+            agents.append(VecOnPolicyAgent(m))
+            datas.append(RPSTables(E, T, m.device))
+        ex = pdist.ActionExchange(len(agents), E, agents[0].model.device)
+        ex.want_p2p = True
+        stream = th.cuda.Stream()
+        snaps = []
+        with th.cuda.stream(stream):
+            steps = FusedSelfPlayRollout(agents, datas, ex, stream, bonus=1.0, persistent=persistent, reward_rule="rps")
+            for it in range(2):
+                steps.run_iteration(it)
+                assert steps.last_rollout_mode == ("persistent" if persistent else "p2p")
+                th.cuda.synchronize()
+                snaps.append({f"rb{i}_{k}": v.copy() for i, a in enumerate(agents) for k, v in a.model.rollout_buffer.host().items()})
+        assert ex.p2p_timeouts() == 0
+        return snaps, [a.model.policy.get_flat_params() for a in agents]
+
+    walk, w_params = run(False)
+    one, o_params = run(True)
+    for x, y in zip(walk, one):
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k
+    for x, y in zip(w_params, o_params):
+        assert np.array_equal(x, y)
+    for snap in one:
+        a0, a1 = snap["rb0_actions"][..., 0].astype(np.int64), snap["rb1_actions"][..., 0].astype(np.int64)
+        assert set(np.unique(a0)) <= {0, 1, 2} and len(np.unique(a0)) == 3
+        assert np.array_equal(snap["rb0_rewards"], rps_payoff(a0, a1).astype(np.float32))          # the ego's gain ...
+        assert np.array_equal(snap["rb1_rewards"], -snap["rb0_rewards"])                             # ... and its negative
+        assert np.array_equal(snap["rb0_episode_starts"], np.ones((T, E), np.float32))               # one-step episodes
+    assert not np.array_equal(o_params[0], o_params[1])
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_peer_to_peer_exchange_between_processes(world):
     """ranks (sharing this GPU) map each other's receive areas through HIP IPC and exchange 3 x 8 steps, then drive the fused
