@@ -633,6 +633,38 @@ def main():
                          f"first: {exchange.p2p_timeout_record()}")
     if distributed and ranks_seen != args.gpus:
         raise SystemExit(f"bench.py: the collective saw {ranks_seen} ranks, --gpus is {args.gpus}")
+    if mode == "graph" and args.rollout == "scripted" and not distributed:
+        # How the iteration divides, measured without a profiler: the learners' one-launch rollouts alone (side by side, as in the
+        # iteration), timed over 10 repetitions; the rest of the iteration is the update -- GAE, the gradient pack and n_epochs x
+        # minibatches of (gradient launch, reduce, Adam) per learner -- whose gradient launches take turns on the device, so
+        # update time / gradient launches is what ONE gradient launch costs the iteration, everything else of the update included.
+        try:
+            for a, d, st in zip(agents, datas, streams):
+                with th.cuda.stream(st):
+                    a.bind_stream()
+                    a.rollout_scripted(d)
+                    a.finish_update()
+            barrier()
+            kr = 10
+            tr = time.perf_counter()
+            for _ in range(kr):
+                for a, d, st in zip(agents, datas, streams):
+                    with th.cuda.stream(st):
+                        a.bind_stream()
+                        a.rollout_scripted(d)
+                        a.finish_update()
+            barrier()
+            rollout_ms = 1e3 * (time.perf_counter() - tr) / kr
+            n_mb = args.n_epochs * ((args.n_envs * args.n_steps + args.batch_size - 1) // args.batch_size) * len(agents)
+            upd_ms = 1e3 * dt / args.steps - rollout_ms
+            result["iteration_split"] = {
+                "rollout_ms": rollout_ms, "update_ms": upd_ms, "gradient_launches_per_iteration": n_mb,
+                "us_per_gradient_launch_in_iteration": 1e3 * upd_ms / n_mb,
+                "note": "rollouts of all learners side by side, timed alone (10 repetitions); update = iteration - rollouts (GAE, gradient "
+                        "pack, every minibatch's gradient launch + reduce + Adam); no profiler involved -- compare with roofline.isolated "
+                        "(the gradient kernel alone) and roofline.in_graph (the same kernel under rocprofv3, which serialises the learners)"}
+        except Exception as exc:  # noqa: BLE001 -- an extra figure, never fatal
+            result["iteration_split"] = {"error": str(exc)}
     if mode == "graph" and args.rollout == "scripted" and not args.headline_only:
         # the same iteration with one launch per environment step, timed in the same process on the same agents: what the
         # scripted rollout saves is launch boundaries, nothing else (the two walks are bitwise equal)
