@@ -73,3 +73,22 @@ def test_general_and_fast_gradient_kernels_have_no_scratch(ppo, tmp_path_factory
         # some general-kernel instantiations reserve an SGPR-scavenging slot (<= 24 bytes of private segment) without a single
         # scratch instruction; a spilled VGPR is what this guards against
         assert k["VGPRs Spill"] == 0 and k["ScratchSize"] <= 24, (n, k)
+
+
+def test_update_step_kernels_have_no_one_load_per_iteration_loops(tmp_path_factory):
+    """Round 4's lesson as a guard: `for (...) v += p[i]` compiles to load, s_waitcnt vmcnt(0), add, branch -- one memory round trip
+    per iteration -- and sixteen of those made block 0 of ppo_reduce_kernel the long pole of its launch (CHANGELOG.md).  The reduce,
+    step and Adam kernels of the update must not contain an inner loop that waits for ALL of at most two loads before it branches
+    back (scripts/serial_load_loops.py reads hipcc's assembly)."""
+    import sys
+    out = tmp_path_factory.mktemp("asm") / "ppo.s"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-S",
+                        "--cuda-device-only", os.path.join(CSRC, "ph_ppo.hip"), "-o", str(out)], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    scan = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "serial_load_loops.py"), str(out), "2"], capture_output=True,
+                          text=True, timeout=300)
+    assert scan.returncode == 0, scan.stderr[-2000:]
+    hits = [l for l in scan.stdout.splitlines() if any(k in l for k in ("ppo_reduce_kernel", "ppo_step_kernel", "ppo_adam_kernel",
+                                                                         "adv_stats_kernel", "obs_planes_kernel"))]
+    assert not hits, "\n".join(hits)
