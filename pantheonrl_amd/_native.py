@@ -365,7 +365,11 @@ class Context:
         self.device_index = int(device_index)
 
     def set_stream(self, raw_stream: int) -> None:
-        check(self.lib.ph_ctx_set_stream(self.handle, C.c_void_p(raw_stream)))
+        # every engine call binds the caller's current stream first; the native call is skipped while the stream stays the same
+        # (a per-step host loop otherwise pays it twice per environment step)
+        if raw_stream != getattr(self, "_bound_stream", None):
+            check(self.lib.ph_ctx_set_stream(self.handle, C.c_void_p(raw_stream)))
+            self._bound_stream = raw_stream
 
     def sync(self) -> None:
         check(self.lib.ph_ctx_sync(self.handle))
