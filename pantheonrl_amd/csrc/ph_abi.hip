@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdint>
@@ -60,6 +61,12 @@ struct ph_ctx {
   float* act_stage_host = nullptr;
   float* act_stage_dev = nullptr;
   size_t act_stage_cap = 0;   // floats
+  // the two completion words of a one-tile ph_policy_act_host launch (coherent host memory, both views), the sequence number
+  // the next launch stores, and -- while ph_policy_act_host is inside ph_policy_forward -- the words that launch should signal
+  unsigned int* act_done_host = nullptr;
+  unsigned int* act_done_dev = nullptr;
+  unsigned int act_seq = 0;
+  unsigned int* fwd_host_done = nullptr;
   int joint_reward_rule = 0;     // ph_ctx_set_joint_reward_rule: how a step's joint action enters the agents' rewards
   const int* wimage_zeroed_for = nullptr;   // the map (= spec) the weight image's unbacked elements were last zeroed for
   bool exclusive = false;             // ph_set_exclusive_device: nothing else runs on the device beside this context's launches
@@ -335,6 +342,7 @@ int ph_ctx_destroy(ph_ctx* ctx) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->act_stage_host) (void)hipHostFree(ctx->act_stage_host);
+  if (ctx->act_done_host) (void)hipHostFree(ctx->act_done_host);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev_grad) (void)hipEventDestroy(ctx->ev_grad);
@@ -768,8 +776,21 @@ int ph_policy_forward(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   } else if (pending_reward) {
     return fail("ph_policy_forward: pending_reward needs the fused rollout-buffer write");
   }
+  a.host_done = ctx->fwd_host_done;
+  a.host_seq = ctx->act_seq;
   PH_HIP(ph::launch_policy_fwd(a, gemm_mode, ctx->stream));
   return 0;
+}
+
+// How ph_policy_act_host waits for a one-tile launch: 1 = on the launch's two completion words in host memory, 0 = on the stream.
+// PH_ACT_HOST_WAIT=stream selects the latter (the A/B switch of the measurement in DESIGN.md section 3.1).
+static bool act_host_waits_on_words() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PH_ACT_HOST_WAIT");
+    v = (e && std::strcmp(e, "stream") == 0) ? 0 : 1;
+  }
+  return v == 1;
 }
 
 int ph_policy_act_host(ph_ctx* ctx, const ph_spec* spec, const float* params, const float* obs_host, int n,
@@ -803,10 +824,40 @@ int ph_policy_act_host(ph_ctx* ctx, const ph_spec* spec, const float* params, co
   float* d_out = d + n_in;
   int* d_act = reinterpret_cast<int*>(d_out);
   float *d_val = d_out + (size_t)n * nd.A, *d_lp = d_val + n;
-  if (ph_policy_forward(ctx, spec, params, d, n, nullptr, nullptr, nullptr, seed, counter, deterministic, d_act, nullptr, d_val,
-                        d_lp, nullptr, nullptr, rb, pos, rb ? d + (size_t)n * nd.D : nullptr, nullptr, gemm_mode))
-    return 1;
-  PH_HIP(hipStreamSynchronize(ctx->stream));
+  // One tile of the 16-row forward = one policy and one value workgroup: each stores the launch's sequence number into its word
+  // after its last output, and the host polls the two words (the outputs are in the same coherent memory, ordered before them).
+  const bool words = act_host_waits_on_words() && n <= 16 && ph::fwd16_eligible(nd, n);
+  if (words && !ctx->act_done_host) {
+    PH_HIP(hipHostMalloc((void**)&ctx->act_done_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    PH_HIP(hipHostGetDevicePointer((void**)&ctx->act_done_dev, ctx->act_done_host, 0));
+    ctx->act_done_host[0] = ctx->act_done_host[1] = 0;
+  }
+  if (words) {
+    if (++ctx->act_seq == 0) ctx->act_seq = 1;
+    ctx->fwd_host_done = ctx->act_done_dev;
+  }
+  const int frc = ph_policy_forward(ctx, spec, params, d, n, nullptr, nullptr, nullptr, seed, counter, deterministic, d_act,
+                                    nullptr, d_val, d_lp, nullptr, nullptr, rb, pos, rb ? d + (size_t)n * nd.D : nullptr, nullptr,
+                                    gemm_mode);
+  ctx->fwd_host_done = nullptr;
+  if (frc) return 1;
+  bool arrived = false;
+  if (words) {
+    // a launch takes ~10 us end to end; a launch that has not signalled within 50 ms is waited for on the stream, which also
+    // surfaces whatever error kept it from running
+    const unsigned int seq = ctx->act_seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+      if (__atomic_load_n(ctx->act_done_host, __ATOMIC_ACQUIRE) == seq &&
+          __atomic_load_n(ctx->act_done_host + 1, __ATOMIC_ACQUIRE) == seq) {
+        arrived = true;
+        break;
+      }
+      if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+      __builtin_ia32_pause();
+    }
+  }
+  if (!arrived) PH_HIP(hipStreamSynchronize(ctx->stream));
   const float* h_out = h + n_in;
   if (actions_host) std::memcpy(actions_host, h_out, (size_t)n * nd.A * sizeof(int));
   if (values_host) std::memcpy(values_host, h_out + (size_t)n * nd.A, (size_t)n * sizeof(float));

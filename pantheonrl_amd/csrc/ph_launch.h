@@ -69,6 +69,8 @@ struct FwdArgs {
                                   // the rollout buffer keeps the sampled action, as the reference's agent does.  Independent of
                                   // `mask` (the policy-side logit offset of ModularPolicy): OnPolicyAgent hands a plain PPO
                                   // policy obs.obs only (agents.py:162), so its samples are unmasked and the env repairs them
+  unsigned int* host_done;      // ph_policy_act_host: [2] words in coherent host memory, or null; the policy / value workgroup of a
+  unsigned int host_seq;        // ONE-tile launch stores host_seq into word blockIdx.y after its last output (system scope)
 };
 
 // T steps of the 16-row forward against a scripted environment inside one launch (policy_fwd16_rollout_kernel): the per-step

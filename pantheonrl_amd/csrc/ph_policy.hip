@@ -464,6 +464,14 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
 template <bool VALU>
 __global__ __launch_bounds__(256) void policy_fwd16_kernel(FwdArgs a) {
   policy_fwd16_body<VALU>(a);
+  // ph_policy_act_host waits on two host words instead of on the stream: a stream wait goes through the runtime's completion
+  // signal (interrupt or a polled signal, then its bookkeeping), the words arrive with the outputs.  Every lane's stores are
+  // ordered before the word by its own system-scope fence; the barrier orders all lanes' fences before lane 0's store.
+  if (a.host_done) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(a.host_done + blockIdx.y, a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 template <bool VALU>
 __global__ __launch_bounds__(256) void policy_fwd16_rollout_kernel(FwdArgs a, ScriptedSteps sc) {
