@@ -1098,9 +1098,13 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
     }
     PH_STAMP(prof, 9 + 2 * f);
     if (keeper) {
-      if (f == 0) liar_sp_after_ego_lane(s, e, r.alt_rewards, r.alt_T);
-      else if (f == 1) liar_sp_after_reply_lane(s, e, r.alt_rewards, r.alt_T, r.ego_rew_row0 + row, counter + epoch_hi, nullptr, 0);
-      else liar_sp_after_opening_lane(s, e);
+      // the table number is made opaque per pass: otherwise the per-lane addresses of the book-keeping (64-bit pairs into the
+      // mirror) are hoisted out of the rollout loop and held -- spilled -- across the forwards
+      int ek = e;
+      asm volatile("" : "+v"(ek));
+      if (f == 0) liar_sp_after_ego_lane(s, ek, r.alt_rewards, r.alt_T);
+      else if (f == 1) liar_sp_after_reply_lane(s, ek, r.alt_rewards, r.alt_T, r.ego_rew_row0 + row, counter + epoch_hi, nullptr, 0);
+      else liar_sp_after_opening_lane(s, ek);
     }
     __syncthreads();
     PH_STAMP(prof, 10 + 2 * f);
@@ -1123,9 +1127,13 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
   copy_out(g.rew2, m.rew2, 2);
   copy_out(g.es_alt, m.es_alt, 1);
   copy_out(g.ego_episode_start, m.es_ego, 1);
+  // (the lane's index is made opaque so that the twelve flag addresses of the mirror-in are recomputed here, not kept across
+  // the rollout)
+  int lane_row = row0 + tid512;
+  asm volatile("" : "+v"(lane_row));
 #pragma unroll
   for (int k = 0; k < 12; ++k)
-    if (tid512 < nrow) gu8[k][row0 + tid512] = m.u8[16 * k + tid512];
+    if (tid512 < nrow) gu8[k][lane_row] = m.u8[16 * k + tid512];
 }
 
 static bool fwd16h_eligible(const NetDims& nd, int n);

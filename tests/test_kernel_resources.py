@@ -92,3 +92,16 @@ def test_update_step_kernels_have_no_one_load_per_iteration_loops(tmp_path_facto
     hits = [l for l in scan.stdout.splitlines() if any(k in l for k in ("ppo_reduce_kernel", "ppo_step_kernel", "ppo_adam_kernel",
                                                                          "adv_stats_kernel", "obs_planes_kernel"))]
     assert not hits, "\n".join(hits)
+
+
+def test_rollout_kernels_have_no_scratch(tmp_path_factory):
+    """The persistent rollout kernels hold their state for thousands of dependent steps: a spilled register is a scratch round trip
+    per step.  (The Liar's Dice rollout once kept 31 spilled registers: per-lane mirror addresses hoisted out of its loop.)"""
+    pol = _usage("ph_policy.hip", tmp_path_factory)
+    want = ["liar_rollout_kernel", "policy_fwd16_rollout_kernelILb0E", "policy_fwd16_exchange_rollout_kernel",
+            "policy_fwd16_multi_kernel", "policy_fwd16_kernelILb0E", "policy_fwd16h_kernelILb0E"]
+    for w in want:
+        hit = {n: k for n, k in pol.items() if w in n}
+        assert hit, (w, sorted(pol))
+        for n, k in hit.items():
+            assert k["ScratchSize"] == 0 and k["VGPRs Spill"] == 0, (n, k)
