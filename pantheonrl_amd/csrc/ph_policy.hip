@@ -428,14 +428,14 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
         const uint64_t ctr = fwd_counter(a);
         int act;
         switch (nk) {   // the logit count as a compile-time constant: the tail's loops shrink to the logits that exist
-          case 1: act = discrete8_row_tail<1>(a, nd, grow, z, ctr, up, sc != nullptr); break;
-          case 2: act = discrete8_row_tail<2>(a, nd, grow, z, ctr, up, sc != nullptr); break;
-          case 3: act = discrete8_row_tail<3>(a, nd, grow, z, ctr, up, sc != nullptr); break;
-          case 4: act = discrete8_row_tail<4>(a, nd, grow, z, ctr, up, sc != nullptr); break;
-          case 5: act = discrete8_row_tail<5>(a, nd, grow, z, ctr, up, sc != nullptr); break;
-          case 6: act = discrete8_row_tail<6>(a, nd, grow, z, ctr, up, sc != nullptr); break;
-          case 7: act = discrete8_row_tail<7>(a, nd, grow, z, ctr, up, sc != nullptr); break;
-          default: act = discrete8_row_tail<8>(a, nd, grow, z, ctr, up, sc != nullptr); break;
+          case 1: act = discrete8_row_tail<1>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
+          case 2: act = discrete8_row_tail<2>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
+          case 3: act = discrete8_row_tail<3>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
+          case 4: act = discrete8_row_tail<4>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
+          case 5: act = discrete8_row_tail<5>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
+          case 6: act = discrete8_row_tail<6>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
+          case 7: act = discrete8_row_tail<7>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
+          default: act = discrete8_row_tail<8>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
         }
         if (px) {  // push: (stamp << 32 | action) as one 8-byte store into every rank's receive area, slot t mod ll_slots
           const int pt = px_t + t;

@@ -105,9 +105,17 @@ __device__ __forceinline__ uint64_t fwd_counter(const FwdArgs& a) {
 // NK: 8 = the logit count is a run-time value (nd.L, padding logits carry -3e38 and add exact zeros); 1..7 = it is NK, known at
 // compile time -- the loops shrink to the logits that exist.  Bitwise the same results: the generic form only ever adds +0.0 and
 // never selects a padding logit.
+// -DPH_TAIL_STAMPS (scripts/rollout_phase.py's finer view): shader clock at three points inside the tail, slots 2 / 4 / 6 of
+// the workgroup's stamp record, for the step the caller passes a buffer for
+#if defined(PH_TAIL_STAMPS)
+#define PH_TAIL_STAMP(slot) PH_STAMP(tail_dbg, slot)
+#else
+#define PH_TAIL_STAMP(slot) do { } while (0)
+#endif
 template <int NK = 8>
 __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDims& nd, int g, float (&zr)[8], uint64_t ctr,
-                                                  const float* u_pre = nullptr, bool settle = false) {
+                                                  const float* u_pre = nullptr, bool settle = false,
+                                                  long long* tail_dbg = nullptr) {
   const int nk = NK < 8 ? NK : nd.L;
   if (a.mask) {  // modular/policies.py:330-333 : logits - 30*(~mask)
 #pragma unroll
@@ -136,6 +144,7 @@ __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDim
     se += pr[k];
   }
   const float lse = m + fast_log(se), inv = __builtin_amdgcn_rcpf(se);
+  PH_TAIL_STAMP(2);
   int act = 0;
   if (a.given_actions) {
     act = (int)a.given_actions[g];
@@ -155,6 +164,7 @@ __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDim
       act += (k < nk - 1 && u >= cum) ? 1 : 0;
     }
   }
+  PH_TAIL_STAMP(4);
   float zact = 0.f, ent = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -177,6 +187,7 @@ __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDim
   // saying so with a wait the compiler's wait insertion sees keeps "a load into this register may be in flight" from reaching
   // the top of the next step, where it would put a full memory wait in front of every reuse of these registers
   if (settle) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): free here, the stores below are not issued yet
+  PH_TAIL_STAMP(6);
   if (a.act_i32) a.act_i32[g] = env_act;
   if (a.act_f32) a.act_f32[g] = (float)act;
   if (a.logp) a.logp[g] = logp;

@@ -43,3 +43,10 @@ for net in range(2):
     print(f"net {net}: step 8 of {len(blk)} workgroups, {np.median(blk[:, -1] - blk[:, 0]):.0f} cycles (median)")
     for lab, colv in zip(labels, d.T):
         print(f"    {lab:<58} median {np.median(colv):>7.0f}   max {colv.max():>7.0f}")
+    if net == 0 and os.environ.get("TAIL_STAMPS"):   # library built with -DPH_TAIL_STAMPS: slots 2 / 4 / 6 inside the row tail
+        raw = st[:nwg].astype(np.float64)
+        raw = raw[raw[:, 8] > 0]
+        pts = [raw[:, 13], raw[:, 2], raw[:, 4], raw[:, 6], raw[:, 14]]
+        for lab, a0, a1 in zip(["tail: mask / max / exp / sum / log", "tail: uniform + inverse CDF", "tail: log-prob, entropy, env fix-up",
+                                "tail: stores (+ exchange push)"], pts[:-1], pts[1:]):
+            print(f"        {lab:<54} median {np.median(a1 - a0):>7.0f}   max {(a1 - a0).max():>7.0f}")
