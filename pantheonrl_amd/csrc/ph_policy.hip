@@ -296,8 +296,6 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   PH_STAMP(a.prof, 1);
 
   const int n_steps = sc ? sc->n_steps : 1;
-  const bool x_ahead = sc && nd.obs_kind == PH_SPACE_BOX;
-  XStage<R, NT> xn;   // the next step's rows, in flight
   unsigned long long epoch_hi = 0ull;
   if (sc) {   // the RNG epoch word is constant for the launch: one read instead of one per sampling tail
     epoch_hi = a0.epoch ? (unsigned long long)(*a0.epoch) << 32 : 0ull;
@@ -330,10 +328,6 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
     return e + o;
   };
 
-  // every load of the prologue (the weights above all) has landed before the first step: said in a form the compiler's wait
-  // insertion sees, or each step's products carry the prologue's countdown (vmcnt(18) ... vmcnt(1)) and with it a wait for
-  // whatever the step itself has in flight
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   for (int t = 0; t < n_steps; ++t) {
   // debug stamps of ONE step in the middle of a scripted rollout (slots 8..15: scripts/rollout_phase.py)
   long long* const pstep = (sc && t == 8) ? a0.prof : nullptr;
@@ -360,18 +354,10 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
     }
     a.prof = nullptr;
     lds_only_barrier();   // the previous step's head is done with xs (H2)
-    if (x_ahead) {
-#pragma unroll
-      for (int i = 0; i < XStage<R, NT>::ITERS; ++i) xr.v[i] = xn.v[i];
-    } else {
-      xr.issue(rowphys, a.obs, nd, 0);
-    }
+    xr.issue(rowphys, a.obs, nd, 0);
     xr.commit(xs, rowphys, a.obs, nd, 0);
     lds_only_barrier();
   }
-  // (scripted rollout, Box rows) the observation rows of step t + 1 do not depend on this step's actions -- the scripted sequence
-  // stands for an environment whose next observation is on the chip when the action is, as the device-resident games' is -- so
-  // their fetch is issued here and lands under the layers instead of in front of the next step (1 500 of ~8 100 cycles per step)
   PH_STAMP(pstep, 9);
 
   // value workgroup, rectangular rollout: what the row tail reads (previous done, pending reward, the reward row it adds to) is
@@ -381,7 +367,6 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   ValuePre vpre = {0.f, 0.f, 0.f};
   if (pre_ok) vpre = value_row_preload(a, row0 + lane);
   const bool copy_from_regs = net == 1 && a.rb_obs && !a.pos_env && nd.obs_kind == PH_SPACE_BOX;
-  if (x_ahead && t + 1 < n_steps) xn.issue(rowphys, sc->obs_seq + (size_t)(t + 1) * a0.n * nd.D, nd, 0);
   {
     const f32x4 z1 = product(xs, bw1);
 #pragma unroll
@@ -396,14 +381,6 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
     for (int r = 0; r < 4; ++r) xs[(4 * g + r) * LDH + col] = fast_tanh(z2[r] + bias2);   // X is dead: H2 over it
   }
   lds_only_barrier();
-  // the rows fetched ahead are claimed HERE, two layers after their loads were issued: the memory counter is in order and counts
-  // stores too, so a first use at the top of the next step would wait for the acknowledgement of every store of this step's tail
-  if (x_ahead) {
-#pragma unroll
-    for (int i = 0; i < XStage<R, NT>::ITERS; ++i) asm volatile("" : "+v"(xn.v[i]));
-  }
-  asm volatile("" : "+v"(vpre.es), "+v"(vpre.pend), "+v"(vpre.prev));   // (the same for what the value tail preloaded)
-  if (sc) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), in the form the compiler's wait insertion sees (see the tail's note)
   PH_STAMP(a.prof, 5);
   PH_STAMP(pstep, 11);
 
@@ -428,14 +405,14 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
         const uint64_t ctr = fwd_counter(a);
         int act;
         switch (nk) {   // the logit count as a compile-time constant: the tail's loops shrink to the logits that exist
-          case 1: act = discrete8_row_tail<1>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
-          case 2: act = discrete8_row_tail<2>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
-          case 3: act = discrete8_row_tail<3>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
-          case 4: act = discrete8_row_tail<4>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
-          case 5: act = discrete8_row_tail<5>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
-          case 6: act = discrete8_row_tail<6>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
-          case 7: act = discrete8_row_tail<7>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
-          default: act = discrete8_row_tail<8>(a, nd, grow, z, ctr, up, sc != nullptr, pstep); break;
+          case 1: act = discrete8_row_tail<1>(a, nd, grow, z, ctr, up, pstep); break;
+          case 2: act = discrete8_row_tail<2>(a, nd, grow, z, ctr, up, pstep); break;
+          case 3: act = discrete8_row_tail<3>(a, nd, grow, z, ctr, up, pstep); break;
+          case 4: act = discrete8_row_tail<4>(a, nd, grow, z, ctr, up, pstep); break;
+          case 5: act = discrete8_row_tail<5>(a, nd, grow, z, ctr, up, pstep); break;
+          case 6: act = discrete8_row_tail<6>(a, nd, grow, z, ctr, up, pstep); break;
+          case 7: act = discrete8_row_tail<7>(a, nd, grow, z, ctr, up, pstep); break;
+          default: act = discrete8_row_tail<8>(a, nd, grow, z, ctr, up, pstep); break;
         }
         if (px) {  // push: (stamp << 32 | action) as one 8-byte store into every rank's receive area, slot t mod ll_slots
           const int pt = px_t + t;
@@ -478,7 +455,6 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
     }
   } else if (net == 1) {
     copy_obs_rows(a, row0, (a.n - row0 < R) ? a.n - row0 : R, nd.D);
-    if (sc) __builtin_amdgcn_s_waitcnt(0x0F70);   // (one-hot observation rows: the copy's loads are settled before the next step)
   }
   PH_STAMP(a.prof, 7);
   PH_STAMP(pstep, 15);

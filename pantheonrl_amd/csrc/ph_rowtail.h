@@ -114,8 +114,7 @@ __device__ __forceinline__ uint64_t fwd_counter(const FwdArgs& a) {
 #endif
 template <int NK = 8>
 __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDims& nd, int g, float (&zr)[8], uint64_t ctr,
-                                                  const float* u_pre = nullptr, bool settle = false,
-                                                  long long* tail_dbg = nullptr) {
+                                                  const float* u_pre = nullptr, long long* tail_dbg = nullptr) {
   const int nk = NK < 8 ? NK : nd.L;
   if (a.mask) {  // modular/policies.py:330-333 : logits - 30*(~mask)
 #pragma unroll
@@ -183,10 +182,6 @@ __device__ __forceinline__ int discrete8_row_tail(const FwdArgs& a, const NetDim
     for (int k = 7; k >= 0; --k)
       if (k < nk && a.env_mask[(size_t)g * nk + k] != 0) env_act = k;
   }
-  // settle (the rollout kernels' step loop): every load of this tail has been consumed by now and nothing but stores follows;
-  // saying so with a wait the compiler's wait insertion sees keeps "a load into this register may be in flight" from reaching
-  // the top of the next step, where it would put a full memory wait in front of every reuse of these registers
-  if (settle) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): free here, the stores below are not issued yet
   PH_TAIL_STAMP(6);
   if (a.act_i32) a.act_i32[g] = env_act;
   if (a.act_f32) a.act_f32[g] = (float)act;

@@ -106,28 +106,3 @@ def test_rollout_kernels_have_no_scratch(tmp_path_factory):
         for n, k in hit.items():
             assert k["ScratchSize"] == 0 and k["VGPRs Spill"] == 0, (n, k)
 
-
-def test_scripted_rollout_step_issues_its_loads_without_a_full_memory_wait(tmp_path_factory):
-    """The step loop of policy_fwd16_rollout_kernel fetches the next step's observation rows (and the value tail's inputs) at the
-    top of a step and claims them two layers later.  hipcc's wait insertion once put `s_waitcnt vmcnt(0)` in front of every one of
-    those loads -- registers of the previous step's tail counted as "possibly in flight" at the back edge -- which serialised
-    them behind the acknowledgement of the tail's stores.  Guard: from the loop header to the barrier that ends layer 1 (the
-    third barrier of the step) there is no full memory wait."""
-    out = tmp_path_factory.mktemp("asm") / "policy.s"
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-S",
-                        "--cuda-device-only", os.path.join(CSRC, "ph_policy.hip"), "-o", str(out)], capture_output=True, text=True,
-                       timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    txt = out.read_text()
-    start = txt.index("_ZN2ph27policy_fwd16_rollout_kernelILb0EEEvNS_7FwdArgsENS_13ScriptedStepsE:")
-    body = txt[start:txt.index("s_endpgm", start)].splitlines()
-    headers = [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l]
-    assert headers, "no loop found in the rollout kernel"
-    step = body[headers[-1]:]                       # the step loop is the last top-level loop of the kernel
-    barriers = [i for i, l in enumerate(step) if l.strip().startswith("s_barrier")]
-    assert len(barriers) >= 3, barriers
-    head = step[:barriers[2]]
-    loads = [l for l in head if "global_load_dword" in l]
-    assert len(loads) >= 4, loads                   # the four row fragments fetched ahead (+ the value tail's three inputs)
-    waits = [l for l in head if re.search(r"s_waitcnt\s+vmcnt\(0\)", l)]
-    assert not waits, "\n".join(waits)
