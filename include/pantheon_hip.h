@@ -276,9 +276,12 @@ int ph_policy_forward(ph_ctx *ctx, const ph_spec *spec, const float *params, con
  * the action needed back before the environment can move -- agents.py:111-184, util.py:63-81): observations, episode starts and
  * the three results are HOST arrays; the call stages them through pinned, device-visible memory of the context that the forward
  * kernel reads and writes directly (with the fused rollout-buffer write when rb != NULL, as above) and returns when the kernel
- * has finished.  One call, one launch and one
- * synchronisation per environment step instead of several tensor operations; the sampled actions are bitwise those of
- * ph_policy_forward with the same (seed, counter).
+ * has finished.  One call, one launch and one wait per environment step instead of several tensor operations; the sampled
+ * actions are bitwise those of ph_policy_forward with the same (seed, counter).  A launch of one 16-row tile (n <= 16, the
+ * 16-row forward's shape class) signals its end through two words in the same pinned memory, stored by the policy and the value
+ * workgroup after their last output, and the call polls those (bounded: 50 ms, then the stream wait) instead of synchronising
+ * the stream; PH_ACT_HOST_WAIT=stream in the environment selects the stream wait for every launch.  Either way every write of the
+ * launch, the rollout-buffer row included, is complete when the call returns.
  *   obs_host (n, D) f32; episode_start_host (n) f32 or NULL (required with rb); actions_host (n, A) i32; values_host (n);
  *   log_probs_host (n) -- any output may be NULL. */
 int ph_policy_act_host(ph_ctx *ctx, const ph_spec *spec, const float *params, const float *obs_host, int n,
