@@ -97,7 +97,7 @@ class OnPolicyAgent(Agent):
             # the environment lives on the host (the reference's situation): one native call per step -- stage in, forward + row
             # write, results out (ActorCriticPolicy.forward_and_store_host); same kernel and RNG stream as the general path
             actions, values, log_probs = model.policy.forward_and_store_host(self._shape_obs(raw_obs, buf), buf,
-                                                                             self._last_episode_starts)
+                                                                             self._last_episode_starts, as_numpy=True)
         elif fused:  # forward + RolloutBuffer.add(reward=0) in one launch
             shaped = self._shape_obs(raw_obs, buf)
             act_t, values, log_probs = model.policy.forward_and_store(
@@ -127,8 +127,10 @@ class OnPolicyAgent(Agent):
     def update(self, reward: float, done: bool) -> None:
         buf = self.model.rollout_buffer
         self._last_episode_starts = [done]
-        if hasattr(buf, "add_reward"):
-            buf.add_reward(reward)              # rewards[pos-1] += reward on the device (agents.py:198)
+        if type(reward) is float and hasattr(buf, "add_reward_scalar"):
+            buf.add_reward_scalar(reward)       # rewards[pos-1] += reward on the device (agents.py:198), the scalar as an argument
+        elif hasattr(buf, "add_reward"):
+            buf.add_reward(reward)
         else:
             buf.rewards[buf.pos - 1][0] += reward
         self._bump_episode(reward=reward)
@@ -142,10 +144,9 @@ class OnPolicyAgent(Agent):
 
     # -- bookkeeping ------------------------------------------------------------------------------------------------
     def _bump_episode(self, reward: float = 0, length: int = 0) -> None:
-        info = self.model.ep_info_buffer.pop()
+        info = self.model.ep_info_buffer[-1]     # the running episode's record, updated in place
         info["r"] += reward
         info["l"] += length
-        self.model.ep_info_buffer.append(info)
 
     def _log_rollout(self) -> None:
         model, lg = self.model, self.model.logger

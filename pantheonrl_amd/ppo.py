@@ -55,6 +55,17 @@ def _f32_dev(x, dev: th.device, shape: Tuple[int, ...]) -> th.Tensor:
     return t.to(device=dev, dtype=th.float32).reshape(shape).contiguous()
 
 
+_RAW_STREAM = getattr(th._C, "_cuda_getCurrentRawStream", None)
+
+
+def _raw_stream(device) -> int:
+    """the caller's current stream on `device` as the raw handle (what ph_ctx_set_stream takes); the private getter costs a third
+    of torch.cuda.current_stream(...).cuda_stream, and this runs in front of every engine call"""
+    if _RAW_STREAM is not None and device.index is not None:
+        return _RAW_STREAM(device.index)
+    return th.cuda.current_stream(device).cuda_stream
+
+
 class RolloutBuffer:
     """Device-resident SB3 RolloutBuffer.  Arrays are torch views of HBM, time-major (T, E, ...)."""
 
@@ -132,10 +143,24 @@ class RolloutBuffer:
 
     # -- helpers ---------------------------------------------------------------------------------------------
     def _bind(self) -> None:
-        self.ctx.set_stream(th.cuda.current_stream(self.device).cuda_stream)
+        self.ctx.set_stream(_raw_stream(self.device))
 
     def c_struct(self) -> nat.PhRollout:
         return self._c
+
+    def c_ref(self):
+        """byref(c_struct()), made once (the per-step host path passes it every environment step)"""
+        ref = self.__dict__.get("_c_byref")
+        if ref is None:
+            ref = self._c_byref = C.byref(self._c)
+        return ref
+
+    def add_reward_scalar(self, reward: float) -> None:
+        """add_reward for Agent.update's own signature -- one float for the last row written -- without the dispatch around it"""
+        self._bind()
+        rc = self.ctx.lib.ph_buffer_add_reward_const(self.ctx.handle, self.c_ref(), self.pos - 1, reward)
+        if rc:
+            nat.check(rc)
 
     def host(self) -> Dict[str, np.ndarray]:
         """copy of every array on the host (tests, save/export)."""
@@ -147,6 +172,26 @@ class RolloutBuffer:
 _SD = (("mlp_extractor.policy_net.0", "pi_W1", "pi_b1"), ("mlp_extractor.policy_net.2", "pi_W2", "pi_b2"),
        ("mlp_extractor.value_net.0", "vf_W1", "vf_b1"), ("mlp_extractor.value_net.2", "vf_W2", "vf_b2"),
        ("action_net", "act_W", "act_b"), ("value_net", "val_W", "val_b"))
+
+
+class _HostStep:
+    """forward_and_store_host's staging for one (row count, observation shape): arrays, their addresses, argument references"""
+
+    def __init__(self, pol, obs_shape):
+        lay = pol.layout
+        n = int(np.prod(obs_shape)) // lay.D
+        if n * lay.D != int(np.prod(obs_shape)) or n <= 0:
+            raise ValueError(f"observation rows of shape {tuple(obs_shape)} do not hold whole rows of {lay.D} values")
+        self.n = n
+        self.rows = np.empty((n, lay.D), np.float32)
+        self.rows_nd = self.rows.reshape(obs_shape)          # assignment converts dtype and layout in one copy
+        self.acts = np.empty((n, lay.A), np.int32)
+        self.acts_shaped = self.acts.reshape((-1,) + tuple(pol.action_space.shape))
+        self.vals, self.logp, self.es = np.empty((n, 1), np.float32), np.empty((n,), np.float32), np.empty((n,), np.float32)
+        self.rows_ptr, self.acts_ptr = self.rows.ctypes.data, self.acts.ctypes.data
+        self.vals_ptr, self.logp_ptr, self.es_ptr = self.vals.ctypes.data, self.logp.ctypes.data, self.es.ctypes.data
+        self.spec_ref = C.byref(pol.spec)
+        self.params, self.params_ptr = pol.params, pol.params.data_ptr()
 
 
 class ActorCriticPolicy:
@@ -185,7 +230,7 @@ class ActorCriticPolicy:
             z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
             self._seed = int((z ^ (z >> 31)) & 0x7FFFFFFFFFFFFFFF)
         self._counter = 0
-        self._host_out: Dict[int, tuple] = {}   # forward_and_store_host's result arrays, per row count
+        self._host_out: Dict[tuple, "_HostStep"] = {}   # forward_and_store_host's staging, per observation-rows shape
         self._init_weights(ortho_init)
 
     # -- parameters -------------------------------------------------------------------------------------------
@@ -244,7 +289,7 @@ class ActorCriticPolicy:
         return t.to(device=self.device, dtype=th.float32).reshape(-1, D).contiguous()
 
     def _bind(self) -> None:
-        self.ctx.set_stream(th.cuda.current_stream(self.device).cuda_stream)
+        self.ctx.set_stream(_raw_stream(self.device))
 
     def _launch(self, obs_t, *, mask=None, uniforms=None, given=None, deterministic=False, want_logits=False,
                 want_entropy=False, rb: Optional[RolloutBuffer] = None, pos: int = 0, episode_start=None):
@@ -291,31 +336,40 @@ class ActorCriticPolicy:
         rb.full = rb.pos == rb.buffer_size
         return self._shape_actions(acts), values, logp
 
-    def forward_and_store_host(self, obs_rows: np.ndarray, rb: RolloutBuffer, episode_start, deterministic: bool = False):
+    def forward_and_store_host(self, obs_rows: np.ndarray, rb: RolloutBuffer, episode_start, deterministic: bool = False,
+                               as_numpy: bool = False):
         """forward_and_store for an environment that lives on the host: host rows in, host results out, ONE native call and one
-        synchronisation (ph_policy_act_host) instead of the tensor operations of the general path.  Same kernel, same
-        (seed, counter): bitwise the same samples.  -> (actions np.int64 shaped like SB3's, values (n,1) CPU tensor, log_prob (n,))"""
-        if rb.pos >= rb.buffer_size:
+        wait (ph_policy_act_host) instead of the tensor operations of the general path.  Same kernel, same (seed, counter):
+        bitwise the same samples.  -> (actions np.int64 shaped like SB3's, values (n,1), log_prob (n,)); the last two as CPU
+        tensors, or -- as_numpy, what OnPolicyAgent asks for: it only keeps the values for the next GAE -- as numpy copies.
+
+        This runs once per environment step of an n_envs = 1 loop, where the Python around the launch is most of the step
+        (scripts/host_step_overhead.py): the staging arrays, their addresses and the argument references are made once per
+        (row count, observation shape) and reused."""
+        pos = rb.pos
+        if pos >= rb.buffer_size:
             raise nat.NativeError("RolloutBuffer.add on a full buffer")
-        lay = self.layout
-        rows = np.ascontiguousarray(obs_rows, dtype=np.float32).reshape(-1, lay.D)
-        n = rows.shape[0]
-        out = self._host_out.get(n)
-        if out is None:
-            out = self._host_out[n] = (np.empty((n, lay.A), np.int32), np.empty((n, 1), np.float32), np.empty((n,), np.float32),
-                                       np.empty((n,), np.float32))
-        acts, values, logp, es = out
-        es[:] = episode_start
+        obs_rows = np.asarray(obs_rows)
+        hs = self._host_out.get(obs_rows.shape)
+        if hs is None:
+            hs = self._host_out[obs_rows.shape] = _HostStep(self, obs_rows.shape)
+        hs.rows_nd[...] = obs_rows
+        hs.es[:] = episode_start
+        if self.params is not hs.params:          # (load_state_dict / set_flat_params may have replaced the tensor)
+            hs.params, hs.params_ptr = self.params, self.params.data_ptr()
         self._bind()
         self._counter += 1
-        nat.check(self.ctx.lib.ph_policy_act_host(
-            self.ctx.handle, C.byref(self.spec), self.params.data_ptr(), rows.ctypes.data, n, es.ctypes.data, self._seed,
-            self._counter, int(bool(deterministic)), acts.ctypes.data, values.ctypes.data, logp.ctypes.data,
-            C.byref(rb.c_struct()), int(rb.pos), int(self.gemm_mode)))
-        rb.pos += 1
+        rc = self.ctx.lib.ph_policy_act_host(
+            self.ctx.handle, hs.spec_ref, hs.params_ptr, hs.rows_ptr, hs.n, hs.es_ptr, self._seed, self._counter,
+            1 if deterministic else 0, hs.acts_ptr, hs.vals_ptr, hs.logp_ptr, rb.c_ref(), pos, int(self.gemm_mode))
+        if rc:
+            nat.check(rc)
+        rb.pos = pos + 1
         rb.full = rb.pos == rb.buffer_size
-        shaped = acts.astype(np.int64).reshape((-1,) + tuple(self.action_space.shape))
-        return shaped, th.from_numpy(values.copy()), th.from_numpy(logp.copy())
+        shaped = hs.acts_shaped.astype(np.int64)
+        if as_numpy:
+            return shaped, hs.vals.copy(), hs.logp.copy()
+        return shaped, th.from_numpy(hs.vals.copy()), th.from_numpy(hs.logp.copy())
 
     def evaluate_actions(self, obs, actions, action_mask=None):
         """-> (values (n,1), log_prob (n,), entropy (n,))  (modular/policies.py:364-383)."""
