@@ -21,13 +21,24 @@ from pantheonrl_amd.common.observation import Observation  # noqa: E402
 
 
 class _Lib:
+    """every native entry point returns success at once; `calls` keeps the names in order (tests/test_host_logic.py reads it)"""
+
+    def __init__(self):
+        self.calls = []
+
     def __getattr__(self, name):
-        return lambda *a: 0
+        def stub(*a):
+            self.calls.append(name)
+            return 0
+        return stub
 
 
 class _Ctx:
-    lib, handle = _Lib(), None
+    handle = None
     _bound_stream = None
+
+    def __init__(self):
+        self.lib = _Lib()
 
     def set_stream(self, s):
         if s != self._bound_stream:
@@ -66,10 +77,12 @@ def main():
             agent.get_action(obs[i & 63])
             agent.update(0.5, False)
     run(2000)
+    agent.model.policy.ctx.lib.calls.clear()
     t0 = time.perf_counter()
     n = 20000
     run(n)
     dt = (time.perf_counter() - t0) / n
+    assert len(agent.model.policy.ctx.lib.calls) == 2 * n      # one forward and one reward add per environment step, nothing else
     print(f"Python around the native calls: {dt * 1e6:.2f} us per get_action + update pair (native calls stubbed)")
     if "--profile" in sys.argv:
         pr = cProfile.Profile()

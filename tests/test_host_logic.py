@@ -1,5 +1,7 @@
 """not-gpu: the host-side mirror of pantheonrl.common -- Agent / OnPolicyAgent callbacks, MultiAgentEnv driving,
 partner selection, the two in-tree games -- exercised with scripted agents and an oracle-backed model."""
+import os
+
 import numpy as np
 import pytest
 import torch as th
@@ -547,3 +549,61 @@ def test_lds_swizzles_of_the_split_gradient_kernel_are_conflict_free_under_the_l
         a0, a1, a2, a3 = a & 1, (a >> 1) & 1, (a >> 2) & 1, (a >> 3) & 1
         assert s(a) == (a1 | ((a1 ^ a2) << 1) | ((a0 ^ a1 ^ a3) << 2))
         assert f(a) == ((a & 1) | (12 if a & 2 else 0))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the host step path's Python (agents.py:111-199 as ONE native call per callback), with the native library stubbed
+# ----------------------------------------------------------------------------------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stubbed_agent():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("host_step_overhead", os.path.join(ROOT, "scripts", "host_step_overhead.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build()
+
+
+def test_host_step_path_makes_one_native_call_per_callback():
+    from pantheonrl_amd.common.observation import Observation
+    agent = _stubbed_agent()
+    pol, rb = agent.model.policy, agent.model.rollout_buffer
+    calls = pol.ctx.lib.calls
+    rng = np.random.default_rng(0)
+    kept = []
+    for t in range(6):
+        act = agent.get_action(Observation(rng.standard_normal(62)))        # float64 in: converted while staging
+        kept.append(agent.values)
+        agent.update(0.25 * t, t == 3)
+        assert np.asarray(act).shape == () and rb.pos == t + 1 and agent.n_steps == t + 1
+    assert calls == ["ph_policy_act_host", "ph_buffer_add_reward_const"] * 6
+    assert agent._last_episode_starts == [False] and len(agent.model.ep_info_buffer) == 2   # one episode ended at t == 3
+    assert agent.model.ep_info_buffer[0] == {"r": 0.25 * (0 + 1 + 2 + 3), "l": 4}
+    assert agent.model.ep_info_buffer[1] == {"r": 0.25 * (4 + 5), "l": 2}
+    # results are copies of the staging arrays, one staging record per observation shape
+    assert all(isinstance(v, np.ndarray) and v.shape == (1, 1) for v in kept)
+    assert len({v.ctypes.data for v in kept[-2:]}) == 2 and len(pol._host_out) == 1
+    hs = pol._host_out[(1, 62)]
+    assert hs.rows.dtype == np.float32 and hs.es[0] == 0.0                  # the last step's episode_start was False
+    # a numpy scalar reward takes the general entry point (same native call), a per-env array the array form
+    agent.update(np.float32(1.0), False)
+    rb.n_envs = 1
+    assert calls[-1] == "ph_buffer_add_reward_const"
+
+
+def test_host_step_path_refuses_a_full_buffer_and_restages_on_a_new_shape():
+    from pantheonrl_amd import _native as nat
+    agent = _stubbed_agent()
+    pol, rb = agent.model.policy, agent.model.rollout_buffer
+    a, v, lp = pol.forward_and_store_host(np.zeros((3, 62)), rb, [True, False, True])
+    assert a.shape == (3,) and a.dtype == np.int64 and tuple(v.shape) == (3, 1) and tuple(lp.shape) == (3,)
+    assert hasattr(v, "numpy")                                              # tensors unless as_numpy
+    assert set(pol._host_out) == {(3, 62)} and list(pol._host_out[(3, 62)].es) == [1.0, 0.0, 1.0]
+    pol.forward_and_store_host(np.zeros((1, 62)), rb, [False], as_numpy=True)
+    assert set(pol._host_out) == {(3, 62), (1, 62)} and rb.pos == 2
+    with pytest.raises(ValueError):
+        pol.forward_and_store_host(np.zeros((1, 61)), rb, [False])
+    rb.buffer_size = 2
+    with pytest.raises(nat.NativeError):
+        pol.forward_and_store_host(np.zeros((1, 62)), rb, [False])
