@@ -621,7 +621,7 @@ class PPO:
         for t in range(self.n_steps):
             if forced_uniforms is None and getattr(pol, "host_step_path", False) and isinstance(self._last_obs, np.ndarray):
                 # host environment: one native call per step (stage in, forward + row write, results out)
-                act_np, _, _ = pol.forward_and_store_host(self._last_obs, rb, self._last_episode_starts)
+                act_np, _, _ = pol.forward_and_store_host(self._last_obs, rb, self._last_episode_starts, as_numpy=True)
                 actions = act_np
             else:
                 actions, _, _ = pol.forward_and_store(self._last_obs, rb, self._last_episode_starts,
