@@ -1,13 +1,17 @@
 #!/bin/bash
 # A/B builds of libpantheon_hip.so with extra -D flags: scripts/build_variants.sh name1:"-DFOO -DBAR" name2:"" ...
-# -> pantheonrl_amd/csrc/variants/<name>.so (git-ignored, travels to the GPU box); select with PANTHEON_HIP_LIB=<path>
+# -> pantheonrl_amd/csrc/variants/<name>.so (git-ignored, travels to the GPU box); select with PANTHEON_HIP_LIB=<path>.
+# One variant after the other: each one's translation units already compile in parallel (csrc/build.py).
 set -e
-cd "$(dirname "$0")/../pantheonrl_amd/csrc"
-mkdir -p variants
-SRCS="ph_abi.hip ph_policy.hip ph_gae.hip ph_ppo.hip ph_ppo_fast.hip ph_ppo_split.hip ph_envs.hip ph_agent.hip ph_bc.hip ph_adap.hip ph_modular.hip ph_adapmult.hip"
+cd "$(dirname "$0")/.."
+mkdir -p pantheonrl_amd/csrc/variants
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
-  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I ../../include -I . -Wall -Wno-unused-function $flags \
-      -o variants/$name.so $SRCS -ldl > variants/$name.log 2>&1 && echo "built $name [$flags]" || (echo "FAILED $name"; tail -5 variants/$name.log) ) &
+  python - "$name" "$flags" <<'PY'
+import sys
+from pantheonrl_amd.csrc import build as b
+name, flags = sys.argv[1], sys.argv[2]
+b.build(lib=b.HERE + "/variants/" + name + ".so", extra_flags=flags, verbose=False)
+print("built", name, "[" + flags + "]")
+PY
 done
-wait
