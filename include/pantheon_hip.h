@@ -33,12 +33,13 @@
 extern "C" {
 #endif
 
-#define PH_ABI_VERSION 5   /* 2: + ph_agent_*, ph_bc_*, ph_adap_*, ph_scripted_rollout, ph_liar_selfplay_rollout, ph_roundrobin_env_step,
+#define PH_ABI_VERSION 6   /* 2: + ph_agent_*, ph_bc_*, ph_adap_*, ph_scripted_rollout, ph_liar_selfplay_rollout, ph_roundrobin_env_step,
                                   ph_buffer_compact_columns (additions only: every v1 signature is unchanged)
                               3: + ph_selfplay_rollout_persistent, PH_STEP_FIX_ILLEGAL / _MASK_ENV_ONLY, ph_modular_*, ph_roundrobin_*_iteration
                                   (additions only)
                               4: + ph_selfplay_rollout_persistent_capacity, ph_ppo_train's gradient pack (no signature changed)
-                              5: + ph_policy_act_host, ph_buffer_add_reward_const, ph_adapmult_*, ph_ctx_set_joint_reward_rule (additions only) */
+                              5: + ph_policy_act_host, ph_buffer_add_reward_const, ph_adapmult_*, ph_ctx_set_joint_reward_rule (additions only)
+                              6: + ph_bench_train_kernels (addition only) */
 #define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
 #define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
 #define PH_MAX_LOGITS 64 /* max total policy logits L */
@@ -687,6 +688,27 @@ int ph_bench_ppo_grad(ph_ctx *ctx, const ph_spec *spec, const float *params, con
 /* same for the GAE kernel (mode as in ph_gae); advantages/returns are overwritten with the same values each rep */
 int ph_bench_gae(ph_ctx *ctx, const ph_rollout *rb, const float *last_values, const float *dones, double gamma,
                  double gae_lambda, int mode, int reps, float *avg_ms_out /* host */);
+
+/* Measurement hook for bench.py's HBM-side roofline lines (K1 buffer write, K3 minibatch gather, K6 reduction):
+ * the kernels of one PPO.train() call OTHER than the gradient kernel, each enqueued `reps` times between two HIP events on the ctx
+ * stream; us_out[slot] = mean launch duration in microseconds (0 = the kernel does not run for this spec).  Runs the preparation of
+ * a train() call with the in-kernel permutation, one gradient launch (so that the slabs hold a real minibatch), then the timed
+ * launches; `opt` must be a SCRATCH copy of the optimizer state -- the reduction / Adam launches advance it.  Synchronises. */
+enum {
+  PH_BENCH_WEIGHT_IMAGE = 0, /* weight_image_kernel (split gradient kernel only) */
+  PH_BENCH_OBS_PLANES = 1,   /* obs_planes_kernel: the call's observation planes + per-row scalar table (split only) */
+  PH_BENCH_ADV_STATS = 2,    /* adv_stats_kernel + adv_finalize_kernel: all n_epochs x n_minibatches of the call */
+  PH_BENCH_REDUCE = 3,       /* ppo_reduce_kernel, the shape used beside another learner's gradient launch */
+  PH_BENCH_REDUCE_WIDE = 4,  /* ppo_reduce_kernel, the 16-byte-load shape of a learner alone on its device */
+  PH_BENCH_ADAM = 5,         /* ppo_adam_kernel */
+  PH_BENCH_STEP_FUSED = 6,   /* ppo_step_kernel (reduce + clip + Adam as one launch), 0 if its grid is not resident at once */
+  PH_BENCH_BUFFER_ADD = 7,   /* buffer_add_kernel: RolloutBuffer.add of one step (row 1 <- row 0) */
+  PH_BENCH_SLAB_FLOATS = 8,  /* not a time: floats of gradient slabs one minibatch writes (and the reduction reads) */
+  PH_BENCH_NKERN = 9
+};
+int ph_bench_train_kernels(ph_ctx *ctx, const ph_spec *spec, const ph_opt_state *scratch_opt, const ph_rollout *rb,
+                           const ph_ppo_hyper *hyper /* host */, int n_epochs, int batch_size, int reps, int gemm_mode,
+                           float *us_out /* host, PH_BENCH_NKERN */);
 
 /* Host-side evaluation of the keyed Feistel permutation ph_ppo_train uses when perms == NULL: writes
  * out[i] = perm_epoch(start + i) for i < count (env-major indices in [0, n)).  Pure CPU, needs no device;

@@ -266,6 +266,8 @@ SIGNATURES = {
     "ph_bench_ppo_grad": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(PhRollout), C.POINTER(PhPpoHyper), _i, _i, _i,
                           C.POINTER(C.c_float)],
     "ph_bench_gae": [_vp, C.POINTER(PhRollout), _vp, _vp, _d, _d, _i, _i, C.POINTER(C.c_float)],
+    "ph_bench_train_kernels": [_vp, C.POINTER(PhSpec), C.POINTER(PhOptState), C.POINTER(PhRollout), C.POINTER(PhPpoHyper),
+                               _i, _i, _i, _i, C.POINTER(C.c_float)],
     "ph_feistel_indices": [_i, _ull, _i, _i, _i, C.POINTER(_i)],
     "ph_bc_layout_of": [C.POINTER(PhSpec), C.POINTER(PhBcLayout)],
     "ph_bc_forward": [_vp, C.POINTER(PhSpec), _vp, _vp, _i, _vp, _vp, _vp, _ull, _ull, _i, _vp, _vp, _vp, _vp, _vp],
@@ -313,7 +315,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.argtypes = argtypes
         fn.restype = C.c_char_p if name in ("ph_last_error", "ph_agent_last_error") else C.c_int
-    if lib.ph_abi_version() != 5:
+    if lib.ph_abi_version() != 6:
         raise NativeError("libpantheon_hip.so ABI version mismatch")
     _lib = lib
     return lib

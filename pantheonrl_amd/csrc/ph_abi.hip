@@ -1774,10 +1774,35 @@ int adap_launch(ph_ctx* ctx, const ph::NetDims& nd, const float* params, const p
   return 0;
 }
 
+// the advantage-statistics launch of a train() call: statistics of every minibatch, the minibatch order, the row records
+void train_adv_args(const TrainPlan& t, bool need_idx, ph::AdvStatArgs& aa) {
+  ph_ctx* ctx = t.ctx;
+  aa.clear_flag = ctx->stop_flag;    // the call's KL stop flag starts at 0 (no launch of its own: nothing reads it before the first gradient launch)
+  aa.rb_adv = t.rb->advantages;
+  aa.T = t.rb->T;
+  aa.E = t.rb->E;
+  aa.perms = t.perms;
+  aa.perm_n = (uint32_t)t.N;
+  aa.perm_hb = ph::feistel_half_bits((uint32_t)t.N);
+  aa.perm_seed = t.perm_seed;
+  aa.epoch = ctx->rng_epoch;
+  aa.N = t.N;
+  aa.batch = t.batch_size;
+  aa.n_mb = t.n_mb;
+  aa.out = ctx->advstats;
+  aa.partial = ctx->advpart;
+  aa.idx_out = t.perms ? nullptr : ctx->perm_idx;
+  aa.phys_out = ctx->perm_phys;      // the order once more as physical rows: the tile walk then has no index arithmetic
+  // the split kernel reads the row records only: the materialised order (8 of the launch's 40 bytes per element) is written
+  // for whoever else walks it -- the other gradient kernels, ADAP's context launch (need_idx)
+  if (t.nd.split && !need_idx) aa.idx_out = aa.phys_out = nullptr;
+  fill_adv_records(aa, ctx, t.nd, t.rb);
+}
+
 // validation, workspace, stop-flag reset and the advantage statistics / minibatch order of every minibatch
 int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const ph_rollout* rb,
                   const ph_ppo_hyper* hp, int n_epochs, int batch_size, const int* perms, unsigned long long perm_seed,
-                  float* stats, int gemm_mode) {
+                  float* stats, int gemm_mode, bool need_idx = false) {
   if (!ctx) return fail("null ctx");
   if (!opt || !opt->params || !opt->adam_m || !opt->adam_v || !opt->step) return fail("ph_ppo_train: null optimizer state");
   if ((uintptr_t)opt->params % 16 != 0) return fail("ph_ppo_train: params must be 16-byte aligned");
@@ -1808,23 +1833,7 @@ int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_s
   if (build_grad_pack(ctx, t.nd, rb, (size_t)n_epochs * t.N)) return 1;
   t.hb = ph::feistel_half_bits((uint32_t)t.N);
   ph::AdvStatArgs aa;
-  aa.clear_flag = ctx->stop_flag;    // the call's KL stop flag starts at 0 (no launch of its own: nothing reads it before the first gradient launch)
-  aa.rb_adv = rb->advantages;
-  aa.T = rb->T;
-  aa.E = rb->E;
-  aa.perms = perms;
-  aa.perm_n = (uint32_t)t.N;
-  aa.perm_hb = t.hb;
-  aa.perm_seed = perm_seed;
-  aa.epoch = ctx->rng_epoch;
-  aa.N = t.N;
-  aa.batch = batch_size;
-  aa.n_mb = t.n_mb;
-  aa.out = ctx->advstats;
-  aa.partial = ctx->advpart;
-  aa.idx_out = perms ? nullptr : ctx->perm_idx;
-  aa.phys_out = ctx->perm_phys;      // the order once more as physical rows: the tile walk then has no index arithmetic
-  fill_adv_records(aa, ctx, t.nd, rb);
+  train_adv_args(t, need_idx, aa);
   PH_HIP(ph::launch_adv_stats(aa, n_epochs * t.n_mb, s));
   return 0;
 }
@@ -1933,7 +1942,7 @@ int train_run(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const p
               int n_epochs, int batch_size, const int* perms, unsigned long long perm_seed, float* stats, int gemm_mode,
               const ph_adap_loss* adap) {
   TrainPlan t;
-  if (train_prepare(t, ctx, spec, opt, rb, hp, n_epochs, batch_size, perms, perm_seed, stats, gemm_mode)) return 1;
+  if (train_prepare(t, ctx, spec, opt, rb, hp, n_epochs, batch_size, perms, perm_seed, stats, gemm_mode, adap != nullptr)) return 1;
   if (adap && adap_check(ctx, t.nd, adap, "ph_adap_train")) return 1;
   t.adap = adap;
   for (int mbi = 0; mbi < n_epochs * t.n_mb; ++mbi) {
@@ -2468,8 +2477,8 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   aa.n_mb = n_mb;
   aa.out = ctx->advstats;
   aa.partial = ctx->advpart;
-  aa.idx_out = ctx->perm_idx;   // as in ph_ppo_train: the grad launches read the materialised order
-  aa.phys_out = ctx->perm_phys;
+  aa.idx_out = nd.split ? nullptr : ctx->perm_idx;   // as in ph_ppo_train: the grad launches read the materialised order,
+  aa.phys_out = nd.split ? nullptr : ctx->perm_phys; // the split kernel the row records
   fill_adv_records(aa, ctx, nd, rb);
   PH_HIP(ph::launch_adv_stats(aa, n_mb, s));
   ph::GradArgs g;
@@ -2520,6 +2529,68 @@ int ph_bench_gae(ph_ctx* ctx, const ph_rollout* rb, const float* last_values, co
   float ms = 0.f;
   PH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   *avg_ms_out = ms / (float)reps;
+  return 0;
+}
+
+int ph_bench_train_kernels(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const ph_rollout* rb,
+                           const ph_ppo_hyper* hp, int n_epochs, int batch_size, int reps, int gemm_mode, float* us_out) {
+  DevGuard dev_guard(ctx);
+  if (!us_out) return fail("ph_bench_train_kernels: null argument");
+  if (reps <= 0) return fail("ph_bench_train_kernels: reps must be positive");
+  for (int i = 0; i < PH_BENCH_NKERN; ++i) us_out[i] = 0.f;
+  TrainPlan t;
+  if (train_prepare(t, ctx, spec, opt, rb, hp, n_epochs, batch_size, nullptr, 12345ull, nullptr, gemm_mode)) return 1;
+  hipStream_t s = ctx->stream;
+  int rc = 0;
+  auto timed = [&](int slot, auto&& fn) -> int {
+    if (fn()) return 1;   // warm
+    PH_HIP(hipEventRecord(ctx->ev0, s));
+    for (int i = 0; i < reps; ++i)
+      if (fn()) return 1;
+    PH_HIP(hipEventRecord(ctx->ev1, s));
+    PH_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    PH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    us_out[slot] = 1e3f * ms / (float)reps;
+    return 0;
+  };
+  auto hip = [&](hipError_t e) -> int {
+    if (e != hipSuccess) { rc = fail(std::string("ph_bench_train_kernels: ") + hipGetErrorString(e)); return 1; }
+    return 0;
+  };
+  if (t.nd.split) {
+    if (timed(PH_BENCH_WEIGHT_IMAGE, [&] { return rebuild_weight_image(ctx, t.nd, opt->params); })) return 1;
+    if (timed(PH_BENCH_OBS_PLANES, [&] { return build_grad_pack(ctx, t.nd, rb, (size_t)n_epochs * t.N); })) return 1;
+  }
+  ph::AdvStatArgs aa;
+  train_adv_args(t, false, aa);
+  if (timed(PH_BENCH_ADV_STATS, [&] { return hip(ph::launch_adv_stats(aa, n_epochs * t.n_mb, s)); })) return rc ? rc : 1;
+  MbPlan pl;
+  if (train_launch_grad(t, 0, &pl)) return 1;   // slabs and partial statistics of minibatch 0 for the reduction to read
+  ph::ReduceArgs r;
+  ph::AdamArgs ad;
+  fill_step_args(t, 0, pl, r, ad);
+  r.wide = 0;
+  if (timed(PH_BENCH_REDUCE, [&] { return hip(ph::launch_ppo_reduce(r, s)); })) return rc ? rc : 1;
+  r.wide = 1;
+  if (timed(PH_BENCH_REDUCE_WIDE, [&] { return hip(ph::launch_ppo_reduce(r, s)); })) return rc ? rc : 1;
+  if (timed(PH_BENCH_ADAM, [&] { return hip(ph::launch_ppo_adam(ad, s)); })) return rc ? rc : 1;
+  if (ctx->step_words && ctx->step_gen && ph::step_fused_fits(ph::reduce_blocks(slab_len_of(t.nd)), slab_len_of(t.nd), ctx->num_cu)) {
+    if (timed(PH_BENCH_STEP_FUSED, [&] {
+          return hip(ph::launch_ppo_step(r, ad, ctx->step_words, ctx->step_gen, ctx->step_gen + 1, STEP_WAIT_TICKS, s));
+        }))
+      return rc ? rc : 1;
+  }
+  if (rb->T >= 2) {   // RolloutBuffer.add of one step (row 1 <- row 0): buffer_add_kernel
+    const size_t E = (size_t)rb->E;
+    if (timed(PH_BENCH_BUFFER_ADD, [&] {
+          return hip(ph::launch_buffer_add(rb->observations + E * t.nd.D, rb->actions + E * t.nd.A, rb->rewards + E,
+                                           rb->episode_starts + E, rb->values + E, rb->log_probs + E, rb->observations,
+                                           rb->actions, rb->episode_starts, rb->values, rb->log_probs, rb->E, t.nd.D, t.nd.A, s));
+        }))
+      return rc ? rc : 1;
+  }
+  us_out[PH_BENCH_SLAB_FLOATS] = (float)((double)pl.nwg * slab_len_of(t.nd));
   return 0;
 }
 

@@ -188,6 +188,14 @@ hipError_t launch_gae(const float* rew, const float* val, const float* es, const
     return hipGetLastError();
   }
   // lanes per workgroup = min(ceil(T/LC), 1024/32) * 32
+  static int lc_env = -1;   // PH_GAE_LC = 8 | 16 | 32: measurement override of the steps per lane
+  if (lc_env < 0) {
+    const char* e = getenv("PH_GAE_LC");
+    lc_env = e ? atoi(e) : 0;
+  }
+  if (lc_env == 8) return launch_scan<8, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
+  if (lc_env == 16) return launch_scan<16, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
+  if (lc_env == 32) return launch_scan<32, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
   if (T <= 256) return launch_scan<8, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
   if (T <= 512) return launch_scan<16, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
   return launch_scan<32, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);

@@ -153,7 +153,6 @@ struct GradArgs {
   int ximg_zero_row;       // N
   const uint4* rec_pi;     // this minibatch: {physical row, advantage, old log-prob, action} per position
   const uint4* rec_vf;     // this minibatch: {physical row, return, old value, -}
-  int net_base;            // 0; experiments launch the two nets separately (net = blockIdx.y + net_base)
 };
 
 // What the joint action of a SimultaneousEnv step adds to an agent's reward (multiagentenv.py:395-409 hands every agent ITS reward):

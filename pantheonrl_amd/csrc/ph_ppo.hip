@@ -830,6 +830,19 @@ hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_
 }
 
 // ---- advantage statistics of every minibatch of a train() call: mean and unbiased std (torch .mean()/.std()) ----
+// a 16-byte row record is written once and read once, launches later, by ONE gradient workgroup: a streaming store (the 42 MB of a
+// call's records otherwise displace the per-row table the kernel gathers from out of the L2)
+#ifndef PH_ADV_STORE
+#define PH_ADV_STORE 1
+#endif
+__device__ __forceinline__ void st_rec(uint4* p, const uint4& v) {
+#if PH_ADV_STORE == 1
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store((u32x4_t){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(p));
+#else
+  *p = v;
+#endif
+}
 __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
   __shared__ double sh[2][1024 / 64];
   const int mb = blockIdx.x / ADV_SPLIT, seg = blockIdx.x - mb * ADV_SPLIT;   // ADV_SPLIT workgroups share a minibatch
@@ -857,14 +870,14 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
       const uint4 rp = a.rowrec[2 * (size_t)phys], rv = a.rowrec[2 * (size_t)phys + 1];
       const size_t o = (size_t)ep * a.N + start + i;
       adv = __uint_as_float(rp.x);
-      a.rec_pi_out[o] = make_uint4((unsigned)phys, rp.x, rp.y, rp.z);
-      a.rec_vf_out[o] = make_uint4((unsigned)phys, rv.x, rv.y, 0u);
+      st_rec(a.rec_pi_out + o, make_uint4((unsigned)phys, rp.x, rp.y, rp.z));
+      st_rec(a.rec_vf_out + o, make_uint4((unsigned)phys, rv.x, rv.y, 0u));
     } else {
       adv = a.rb_adv[phys];
       if (a.rec_pi_out) {   // the five per-row scalars of the gradient launches, gathered once per train() instead of once per launch
         const size_t o = (size_t)ep * a.N + start + i;
-        a.rec_pi_out[o] = make_uint4((unsigned)phys, __float_as_uint(adv), __float_as_uint(a.rb_logp[phys]), __float_as_uint(a.rb_act[phys]));
-        a.rec_vf_out[o] = make_uint4((unsigned)phys, __float_as_uint(a.rb_ret[phys]), __float_as_uint(a.rb_val[phys]), 0u);
+        st_rec(a.rec_pi_out + o, make_uint4((unsigned)phys, __float_as_uint(adv), __float_as_uint(a.rb_logp[phys]), __float_as_uint(a.rb_act[phys])));
+        st_rec(a.rec_vf_out + o, make_uint4((unsigned)phys, __float_as_uint(a.rb_ret[phys]), __float_as_uint(a.rb_val[phys]), 0u));
       }
     }
     return (double)adv;

@@ -33,29 +33,17 @@
 #include "ph_head.h"
 #include "ph_split.h"
 
-#ifndef PH_SPLIT_HEAD_PAIRS
-#define PH_SPLIT_HEAD_PAIRS 1
-#endif
-// 1: W1's fragments are fetched from the (L2-resident) weight image at the top of every tile, under the row commit, instead of
-// staying in registers from the prologue on: 24 registers less across the tile walk (212 instead of 238 VGPRs once the staged
-// observation planes take 24 registers), which keeps room on every SIMD for a wave of another learner's reduce / Adam kernel
-#ifndef PH_SPLIT_W1_PER_TILE
-#define PH_SPLIT_W1_PER_TILE 1
-#endif
-// how the 32 KB of weight-gradient accumulators of a workgroup go to its slab: 0 plain stores (the lines stay dirty in the XCD's
-// L2 and the end-of-kernel release writes 17.9 MB back behind the last workgroup), 1 write-through (sc1) stores that leave
-// while other workgroups still compute (MI355X_MICROARCH.md, "publish-large"), 2 nontemporal
-#ifndef PH_SPLIT_SLAB_STORE
-#define PH_SPLIT_SLAB_STORE 1
-#endif
-// 1: a workgroup's weight-gradient accumulators leave for its slab as soon as they are final -- dW2 (and d b2) after the LAST tile's
-// dW2 product, under that tile's dH1 / dZ1 / dW1 work, and dW1 block by block inside the last dW1 product (which then runs
-// block-outer) -- instead of as one 32 KB burst per workgroup after the last barrier, when all 512 workgroups finish together and
-// 17.9 MB hit the fabric at once (measured: the slab stores cost 5.7 of 26 us, scripts/ab_variants: PH_EXP_NO_SLABS)
-#ifndef PH_SPLIT_EARLY_SLABS
-#define PH_SPLIT_EARLY_SLABS 1
-#endif
-// experiments only (wrong results): PH_EXP_NO_SLABS skips the slab stores, PH_EXP_NO_XROWS reads every row from the zero row
+// Settled by same-box A/B (CHANGELOG round 3 / 4), no longer switches:
+//  * W1's fragments are fetched from the (L2-resident) weight image at the top of every tile, under the row commit, instead of
+//    staying in registers from the prologue on: 24 registers less across the tile walk, which keeps room on every SIMD for a
+//    wave of another learner's reduce / Adam kernel;
+//  * the 32 KB of weight-gradient accumulators of a workgroup go to its slab as write-through (sc1) stores that leave while other
+//    workgroups still compute (MI355X_MICROARCH.md, "publish-large") -- plain stores stay dirty in the XCD's L2 and the
+//    end-of-kernel release writes 17.9 MB back behind the last workgroup;
+//  * they leave as soon as they are final -- dW2 (and d b2) after the LAST tile's dW2 product, under that tile's dH1 / dZ1 / dW1
+//    work, and dW1 block by block inside the last dW1 product (which therefore runs block-outer) -- instead of as one burst per
+//    workgroup after the last barrier, when all 512 workgroups finish together;
+//  * dH2 = dz act_W^T as packed FMAs over ADJACENT logits of one weight row.
 
 namespace ph {
 
@@ -111,17 +99,9 @@ __device__ __forceinline__ void split4(const float* x, bf16x4 (&p)[3]) {
   }
 }
 
-// 16-byte slab store (PH_SPLIT_SLAB_STORE)
+// 16-byte write-through slab store
 __device__ __forceinline__ void st_slab16(float* p, const f32x4& v) {
-#if defined(PH_EXP_NO_SLABS)
-  (void)p; (void)v;
-#elif PH_SPLIT_SLAB_STORE == 1
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#elif PH_SPLIT_SLAB_STORE == 2
-  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
-#else
-  *reinterpret_cast<f32x4*>(p) = v;
-#endif
 }
 __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -220,9 +200,6 @@ struct XRows {
       const int r = 8 * i + (lane >> 3);
       int p = __builtin_amdgcn_ds_bpermute(4 * r, physv);
       p = p < 0 ? zero_row : p;
-#if defined(PH_EXP_NO_XROWS)
-      p = zero_row;
-#endif
       const uint4* src = ximg + (size_t)p * XIMG_ROW_U4 + (lane & 7);
 #pragma unroll
       for (int q = 0; q < 3; ++q) v[i * 3 + q] = ld_nt16(src + q * 8);
@@ -270,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
   float* ract = rold + R;                       // [R]
   int* rowphys = (int*)(ract + R);              // [R]
 
-  const int net = blockIdx.y + a.net_base;
+  const int net = blockIdx.y;
   const int oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
   const float inv_nb = 1.0f / (float)a.nb;
   const int nk = nd.L;
@@ -310,18 +287,6 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     meta = row_record(blockIdx.x, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
     // this wave's weight fragments arrive already split (ph_split.h: ppo_adam_kernel keeps the image in step with params)
-#if !PH_SPLIT_W1_PER_TILE
-    {
-      const uint4* img = reinterpret_cast<const uint4*>(a.wimage) + (size_t)((net * 4 + wave) * 18) * 64 + lane;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          W1f[c].p[p] = __builtin_bit_cast(bf16x8, img[((0 * 2 + c) * 3 + p) * 64]);
-        }
-      }
-    }
-#endif
     float bias1 = 0.f, bias2 = 0.f, hv0 = 0.f, hv1 = 0.f, hb = 0.f;
     if (tid < HID) {
       bias1 = a.params[oB1 + tid];
@@ -376,12 +341,8 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
 #pragma unroll
   for (int k = 0; k < NSTATP; ++k) st[k] = 0.f;
 
-#if defined(PH_EXP_NET_ONLY)
-  float* const rslab = a.slabs + ((size_t)(blockIdx.x % 128) * 2 + net) * RS_NET;   // timing experiment: keep the small stores inside the workspace
-#else
   float* const rslab = a.slabs + ((size_t)blockIdx.x * 2 + net) * RS_NET;
-#endif
-  bool slabs_out = false;   // dW1 / dW2 / d b2 already stored by the last tile (PH_SPLIT_EARLY_SLABS)
+  bool slabs_out = false;   // dW1 / dW2 / d b2 already stored by the last tile
   bool first = true;
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, first = false) {
     int tidv = threadIdx.x;
@@ -391,7 +352,6 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     const bool has_next = tile + (int)gridDim.x < a.ntiles;
     const int unit = 16 * wave + j;   // this lane's column of every 16x16 result
 
-#if PH_SPLIT_W1_PER_TILE
     {   // W1 by (feature, unit): B of S1, six L2-resident 16-byte loads per lane, in flight under the row commit
       const uint4* img = reinterpret_cast<const uint4*>(a.wimage) + (size_t)((net * 4 + wave) * 18) * 64 + lane;
 #pragma unroll
@@ -399,7 +359,6 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) W1f[c].p[p] = __builtin_bit_cast(bf16x8, img[(c * 3 + p) * 64]);
     }
-#endif
     // ---- T0: this tile's rows land in LDS as planes ----
     if (lane < 16) {
       const int row = wave * 16 + lane;
@@ -574,7 +533,6 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
           o[0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
           if constexpr (NK > 4) o[1] = make_float4(dz[4], dz[5], dz[6], dz[7]);
         }
-#if PH_SPLIT_HEAD_PAIRS
         // dH2[m] = sum_k dz[k] act_W[m][k] as packed FMAs over ADJACENT logits of one weight row (the register pairs a 16-byte
         // LDS read delivers): left to itself the vectoriser pairs two ROWS instead and pays a v_mov per packed operand
         typedef float hp2 __attribute__((ext_vector_type(2)));
@@ -588,15 +546,6 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
           if constexpr (NK > 6) acc = __builtin_elementwise_fma((hp2){w1.z, w1.w}, dzp[3], acc);
           dzv[m] = (acc.x + acc.y) * (1.0f - h[m] * h[m]);
         });
-#else
-        for_head_rows<NK>(hw, q, [&](int m, const float4& w0, const float4& w1) {
-          const float wk[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-          float d = dz[0] * wk[0];
-#pragma unroll
-          for (int k = 1; k < NK; ++k) d = __builtin_fmaf(dz[k], wk[k], d);
-          dzv[m] = d * (1.0f - h[m] * h[m]);
-        });
-#endif
       } else {
         float wv[16];
         float v = 0.f;
@@ -709,13 +658,11 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
           gW2[b] = mma6(h1, dz, gW2[b]);
         }
       }
-#if PH_SPLIT_EARLY_SLABS
       if (!has_next) {   // dW2 and d b2 are final: their 16 KB leave under the rest of this tile
 #pragma unroll
         for (int b = 0; b < 4; ++b) st_slab16(rslab + RS_W2 + ((wave * 4 + b) * 64 + lane) * 4, gW2[b]);
         if (lane < 16) rslab[RS_B2 + 16 * wave + lane] = gB2[0];   // every row of the ones product is the column sum
       }
-#endif
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -743,7 +690,6 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     meta = meta_next;
     if (has_next) xt.issue(meta.phys, a.ximg, a.ximg_zero_row, lane);
     {
-#if PH_SPLIT_EARLY_SLABS
       // block-outer: dW1 block b (features 16b .. +15) is final after its two chunks, and on the last tile it leaves at once
       const Frag3 dz0 = ld_plain(smem, pb0, H1T + wave * 16 * PL_ROW);   // B: DZ1T row (unit) 16w + j, rows 8kg .. / 32 + 8kg ..
       const Frag3 dz1 = ld_plain(smem, pb1, H1T + wave * 16 * PL_ROW);
@@ -762,18 +708,6 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
           if (lane < 16) rslab[RS_B1 + 16 * wave + lane] = gB1[0];
         slabs_out = true;
       }
-#else
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const Frag3 dz = ld_plain(smem, c == 0 ? pb0 : pb1, H1T + wave * 16 * PL_ROW);   // B: DZ1T row (unit) 16w + j, rows 32c + 8kg ..
-        if constexpr (!FOLD) gB1 = mma_ones(dz, gB1);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const Frag3 x = ld_trf(XT, c, b);     // A: features 16b + i (lane), tile rows 32c + 8kg .. (contraction): transposing reads of X
-          gW1[b] = mma6(x, dz, gW1[b]);
-        }
-      }
-#endif
     }
     lds_barrier();  // XT / H1T / row scalars are free for the next tile
     if (first) PH_STAMP(a.prof, 7);
@@ -828,9 +762,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     }
     if (net == 0 && tid < 8) rslab[RS_HB + tid] = wsum(1, tid);
     if (net == 1 && tid == 0) rslab[RS_HB] = wsum(1, 0);
-#if !defined(PH_EXP_NET_ONLY)
     if (tid < NSTATP) a.statpart[((size_t)net * gridDim.x + blockIdx.x) * NSTATP + tid] = wsum(2, tid);
-#endif
   }
   PH_STAMP(a.prof, 13);
 }
@@ -862,17 +794,6 @@ static hipError_t launch_split_inst(const GradArgs& a, int nwg, hipStream_t s) {
     if (e != hipSuccess) return e;
     allowed = true;
   }
-#if defined(PH_EXP_NET_ONLY)   // experiment: ONE net per launch (PH_EXP_NET_ONLY = 0 | 1 | 2 = both, one after the other)
-  {
-    GradArgs b = a;
-    for (int net = 0; net < 2; ++net) {
-      if (PH_EXP_NET_ONLY != 2 && PH_EXP_NET_ONLY != net) continue;
-      b.net_base = net;
-      hipLaunchKernelGGL((ppo_grad_split_kernel<NK, FOLD>), dim3(a.ntiles, 1), dim3(256), lds, s, b);   // one tile per workgroup, two resident per CU: a CU works on ONE net (timing only: build with PH_EXP_NO_SLABS)
-    }
-    return hipGetLastError();
-  }
-#endif
   hipLaunchKernelGGL((ppo_grad_split_kernel<NK, FOLD>), dim3(nwg, 2), dim3(256), lds, s, a);
   return hipGetLastError();
 }

@@ -169,11 +169,7 @@ __device__ __forceinline__ float reduce_positions(const ReduceArgs& a, float (*g
   const int wave = __builtin_amdgcn_readfirstlane(tid >> RED_SHIFT);
   const int lp = lane % LP, gw = lane / LP;
   const int p0 = blk * RED_PARAMS + lp * VEC;   // first of this lane's VEC positions (slab_len % VEC == 0: all in or all out)
-#if defined(PH_EXP_REDUCE_NO_LOADS)
-  const int per = 0;
-#else
   const int per = (a.nslab + RED_SUB - 1) / RED_SUB;
-#endif
   const bool full = per * RED_SUB == a.nslab;          // no ragged range (every bench shape): no predicates
   const unsigned stride = (unsigned)a.slab_len * (unsigned)sizeof(float);   // nslab * stride < 4 GB (the launcher checks)
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.slabs), 0, (int)((unsigned)a.nslab * stride), 0x00020000);
