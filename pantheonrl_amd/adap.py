@@ -115,6 +115,8 @@ class AdapPolicyMult(AdapPolicy):
 
     # reference module names (policies.py:207-236) -> (weight offset, bias offset, fan in, fan out); gains: SB3's init_weights loop
     # reaches every Linear of mlp_extractor with sqrt(2) (modular/policies.py:229-241 is the same loop)
+    fused_mlp_kernels = False   # parameters follow ph_adapmult_layout: only ADAP's own launches (ph_adapmult_*) may read them
+
     _MODS = (("mlp_extractor.agent_branch_1.0", "pi_W1", "pi_b1"), ("mlp_extractor.agent_scaling.0", "pi_Ws", "pi_bs"),
              ("mlp_extractor.agent_branch_2.0", "pi_W2", "pi_b2"), ("mlp_extractor.value_branch_1.0", "vf_W1", "vf_b1"),
              ("mlp_extractor.value_scaling.0", "vf_Ws", "vf_bs"), ("mlp_extractor.value_branch_2.0", "vf_W2", "vf_b2"),

@@ -56,6 +56,7 @@ class ActionExchange:
         self.p2p = None             # _native.PhP2P once the peer-to-peer route is attached (attach_p2p)
         self._p2p_slots = None      # [parity] -> (n_seats, n_envs) int32 tensor view of this rank's receive area
         self._p2p_keep = []
+        self.attach_generation = 0  # advanced by every attach_p2p call (all ranks call it together): keys cached verdicts
 
     # -- peer-to-peer route ---------------------------------------------------------------------------------------------
     def attach_p2p(self, ctx, epoch_word: th.Tensor, n_steps: int, timeout_s: Optional[float] = None) -> bool:
@@ -66,6 +67,7 @@ class ActionExchange:
         above any healthy hand-off -- ranks that time-slice one GPU, or a rank still instantiating its graphs, can be seconds
         late to a step)."""
         import ctypes as C
+        self.attach_generation += 1
         if timeout_s is None:
             timeout_s = float(os.environ.get("PH_P2P_TIMEOUT_S", "10"))
 

@@ -42,6 +42,7 @@ class ModularPolicy(ActorCriticPolicy):
     ph_layout order of a (Box(64), same action space) network; `state_dict()` uses the reference's module names."""
 
     host_step_path = False   # the composed forward (main + partner towers) has its own launches
+    fused_mlp_kernels = False   # main network + per-partner modules in one vector: ph_modular_* only
 
     def __init__(self, observation_space, action_space, lr: float = 3e-4, device="cuda", ortho_init: bool = True,
                  seed: Optional[int] = None, sampling_stream: int = 0, num_partners: int = 1, baseline: bool = False,

@@ -201,6 +201,10 @@ class ActorCriticPolicy:
     # OnPolicyAgent.get_action may use forward_and_store_host (one native call per environment step) for host observations;
     # subclasses that build their rows on the device (AdapPolicy appends the context there) switch it off
     host_step_path = True
+    # the parameter vector is the plain 64-64 MLP in ph_layout order, i.e. what the fused MLP kernels read (ph_ppo_train_multi, the
+    # 16-row rollout forwards, the exchange / round-robin engines).  Policies with another network (AdapPolicyMult, ModularPolicy)
+    # carry the same `spec` for their rollout buffer but a different vector: they say False and those entry points refuse them
+    fused_mlp_kernels = True
 
     def __init__(self, observation_space, action_space, lr: float = 3e-4, device="cuda",
                  ortho_init: bool = True, seed: Optional[int] = None, sampling_stream: int = 0):
@@ -394,6 +398,13 @@ class ActorCriticPolicy:
         return None
 
 
+def require_mlp_kernels(policy, who: str) -> None:
+    """refuse a policy whose parameter vector is not the plain MLP's before an engine path would read it as one"""
+    if not getattr(policy, "fused_mlp_kernels", True):
+        raise nat.NativeError(f"{who}: {type(policy).__name__} does not run on the fused MLP kernels (its parameter vector has "
+                              "another layout); use its own algorithm class")
+
+
 class _SingleEnvVec:
     """What SB3 wraps a lone env into: DummyVecEnv([Monitor(env)]) (trainer.py:119) -- batch of one, auto-reset on
     done, episode return/length reported through info['episode']."""
@@ -575,6 +586,7 @@ class PPO:
     def _train_call(self, keep: list) -> "nat.PhTrainCall":
         """this learner's train() arguments as a ph_train_call (device permutations; statistics stay on the device)"""
         rb, pol = self.rollout_buffer, self.policy
+        require_mlp_kernels(pol, "PPO.train_joint")
         N = rb.buffer_size * rb.n_envs
         n_mb = (N + self.batch_size - 1) // self.batch_size
         stats = getattr(self, "_stats_dev", None)

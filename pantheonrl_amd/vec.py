@@ -20,7 +20,7 @@ import numpy as np
 import torch as th
 
 from . import _native as nat
-from .ppo import PPO
+from .ppo import PPO, require_mlp_kernels
 
 
 class VecOnPolicyAgent:
@@ -29,6 +29,7 @@ class VecOnPolicyAgent:
     def __init__(self, model: PPO):
         self.model = model
         pol, rb = model.policy, model.rollout_buffer
+        require_mlp_kernels(pol, type(self).__name__)
         E, lay, dev = rb.n_envs, pol.layout, pol.device
         self.E = E
         self._last_episode_starts = th.ones(E, dtype=th.float32, device=dev)   # D-6: starts True
@@ -395,19 +396,26 @@ class FusedSelfPlayRollout:
         inputs differ (an environment variable, uneven ranks per GPU) takes the others to the per-step form with it."""
         import os
         ex = self.exchange
-        key = (id(ex.p2p), getattr(ex, "route", None))
+        # keyed on the exchange's attach generation (a counter the exchange advances at every (re-)attach on every rank), not on
+        # the identity of the attached object: an id() can come back after a re-attach
+        key = (getattr(ex, "attach_generation", 0), ex.p2p is not None, getattr(ex, "route", None))
         if getattr(self, "_persistent_verdict", None) is not None and self._persistent_verdict[0] == key:
             return self._persistent_verdict[1]
         ok = not (self.want_persistent is False or os.environ.get("PH_EXCHANGE_PERSISTENT", "1") == "0" or ex.p2p is None)
         if ok:
-            lay = self.agents[0].model.policy.layout
-            E = self.agents[0].E
-            ok = lay.F <= 64 and lay.A == 1 and lay.L <= 8 and E < 16384
-            ok = ok and not (ex.p2p.T < self.T or ex.p2p.ll_slots < 2 * ex.p2p.T)
-            if ok:
-                cap = C.c_int(0)
-                nat.check(self._lib.ph_selfplay_rollout_persistent_capacity(self._h, C.byref(cap)))
-                ok = len(self.agents) * 2 * ((E + 15) // 16) * max(getattr(ex, "ranks_on_device", 1), 1) <= cap.value
+            # whatever goes wrong locally (a failing occupancy query included) becomes this rank's "no": every rank must reach
+            # the collective below, a raise here would leave the others waiting in it
+            try:
+                lay = self.agents[0].model.policy.layout
+                E = self.agents[0].E
+                ok = lay.F <= 64 and lay.A == 1 and lay.L <= 8 and E < 16384
+                ok = ok and not (ex.p2p.T < self.T or ex.p2p.ll_slots < 2 * ex.p2p.T)
+                if ok:
+                    cap = C.c_int(0)
+                    nat.check(self._lib.ph_selfplay_rollout_persistent_capacity(self._h, C.byref(cap)))
+                    ok = len(self.agents) * 2 * ((E + 15) // 16) * max(getattr(ex, "ranks_on_device", 1), 1) <= cap.value
+            except Exception:  # noqa: BLE001 -- the verdict is "no", agreed with the other ranks below
+                ok = False
         if getattr(ex, "world", 1) > 1 and hasattr(ex, "_everyone"):
             ok = ex._everyone(bool(ok))
         self._persistent_verdict = (key, bool(ok))
