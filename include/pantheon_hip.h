@@ -39,7 +39,7 @@ extern "C" {
                                   (additions only)
                               4: + ph_selfplay_rollout_persistent_capacity, ph_ppo_train's gradient pack (no signature changed)
                               5: + ph_policy_act_host, ph_buffer_add_reward_const, ph_adapmult_*, ph_ctx_set_joint_reward_rule (additions only)
-                              6: + ph_bench_train_kernels (addition only) */
+                              6: + ph_bench_train_kernels, ph_debug_split_oh_tables (additions only) */
 #define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
 #define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
 #define PH_MAX_LOGITS 64 /* max total policy logits L */
@@ -144,6 +144,10 @@ int ph_layout_of(const ph_spec *spec /* host */, ph_layout *out /* host */);
  * index (plane 0) of the weight-fragment image backed by parameter p (-1 = none).  *eligible = 0 (tables untouched) for specs
  * the kernel does not take. */
 int ph_debug_split_tables(const ph_spec *spec, int *slab_map, int *image_map, int *eligible);
+/* the same for the one-hot-observation kernel of gemm_mode 2 (ppo_grad_split_oh_kernel): *slab_len_out = ints slab_map needs
+ * (a slab's floats, both nets), *image_elems_out = bf16 elements of its weight image; slab_map / image_map may be NULL (sizes only) */
+int ph_debug_split_oh_tables(const ph_spec *spec, int *slab_map, int *image_map, int *slab_len_out, int *image_elems_out,
+                             int *eligible);
 
 /* ---- K1: rollout buffer writes --------------------------------------------------------------------------- */
 /* RolloutBuffer.add(obs, action, reward=0, episode_start, value, log_prob) at row `pos` <- agents.py:172-179.

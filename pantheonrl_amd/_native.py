@@ -195,6 +195,7 @@ SIGNATURES = {
     "ph_timer_stop": [_vp, C.POINTER(C.c_float)],
     "ph_layout_of": [C.POINTER(PhSpec), C.POINTER(PhLayout)],
     "ph_debug_split_tables": [C.POINTER(PhSpec), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "ph_debug_split_oh_tables": [C.POINTER(PhSpec), _vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
     "ph_buffer_add": [_vp, C.POINTER(PhSpec), C.POINTER(PhRollout), _i, _vp, _vp, _vp, _vp, _vp],
     "ph_buffer_add_reward": [_vp, C.POINTER(PhRollout), _i, _vp, _vp],
     "ph_buffer_add_reward_joint": [_vp, C.POINTER(PhRollout), _i, _vp, _vp, _i, _i, _vp, C.c_float],

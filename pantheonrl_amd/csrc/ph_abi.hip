@@ -39,6 +39,10 @@ struct SpecCache {
   int* slab_map = nullptr; // device: slab position -> parameter index for register-order gradient slabs, or null
   int* slab_map_split = nullptr;  // device: the same table for the split-bf16 gradient kernel, or null
   int* wimage_map = nullptr;      // device: parameter -> weight fragment image elements of the split kernel (ph_split.h), or null
+  int split_kind = 0;             // 1 ppo_grad_split_kernel, 2 ppo_grad_split_oh_kernel, 0 neither takes the spec
+  int slab_len_split = 0;         // floats per slab in that kernel's order
+  int wimage_elems = 0;           // bf16 elements of its weight image
+  int id = 0;                     // 1, 2, ..: position in the context's cache, never reused
 };
 
 }  // namespace
@@ -68,7 +72,8 @@ struct ph_ctx {
   unsigned int act_seq = 0;
   unsigned int* fwd_host_done = nullptr;
   int joint_reward_rule = 0;     // ph_ctx_set_joint_reward_rule: how a step's joint action enters the agents' rewards
-  const int* wimage_zeroed_for = nullptr;   // the map (= spec) the weight image's unbacked elements were last zeroed for
+  int wimage_zeroed_for = 0;                // spec-cache id the weight image's unbacked elements were last zeroed for (ids are never reused)
+  size_t wimage_cap = 0;                    // elements allocated
   bool exclusive = false;             // ph_set_exclusive_device: nothing else runs on the device beside this context's launches
   unsigned short* wimage = nullptr;   // split gradient kernel: pre-split weight fragments of the policy being trained (ph_split.h)
   double* advpart = nullptr;     // per-segment partial sums of the advantage statistics
@@ -241,9 +246,28 @@ int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd) {
           ph::grad_weight_image_map(nd->lay, ph::grad_fast_fold(probe), wm.data());
           PH_HIP(hipMalloc((void**)&c.wimage_map, wm.size() * sizeof(int)));
           PH_HIP(hipMemcpy(c.wimage_map, wm.data(), wm.size() * sizeof(int), hipMemcpyHostToDevice));
+          c.split_kind = 1;
+          c.slab_len_split = 2 * ph::RS_NET;
+          c.wimage_elems = ph::WIMG_ELEMS;
+        }
+      } else {
+        probe.D = nd->lay.D;
+        if (ph::grad_split_oh_eligible(probe)) {   // one-hot observations: the wide split kernel's tables
+          std::vector<int> m((size_t)ph::grad_split_oh_slab_len(probe));
+          ph::grad_slab_map_split_oh(nd->lay, probe.nchunk, m.data());
+          PH_HIP(hipMalloc((void**)&c.slab_map_split, m.size() * sizeof(int)));
+          PH_HIP(hipMemcpy(c.slab_map_split, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice));
+          std::vector<int> wm(2 * (size_t)nd->lay.P);
+          ph::grad_weight_image_map_oh(nd->lay, probe.nchunk, wm.data());
+          PH_HIP(hipMalloc((void**)&c.wimage_map, wm.size() * sizeof(int)));
+          PH_HIP(hipMemcpy(c.wimage_map, wm.data(), wm.size() * sizeof(int), hipMemcpyHostToDevice));
+          c.split_kind = 2;
+          c.slab_len_split = ph::grad_split_oh_slab_len(probe);
+          c.wimage_elems = ph::grad_split_oh_wimage_elems(probe);
         }
       }
     }
+    c.id = (int)ctx->specs.size() + 1;
     ctx->specs.push_back(c);
     hit = &ctx->specs.back();
   }
@@ -251,6 +275,10 @@ int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd) {
   nd->slab_map_split = hit->slab_map_split;
   nd->wimage_map = hit->wimage_map;
   nd->split = 0;
+  nd->split_kind = hit->split_kind;
+  nd->slab_len_split = hit->slab_len_split;
+  nd->wimage_elems = hit->wimage_elems;
+  nd->spec_id = hit->id;
   nd->obs_kind = spec->obs.kind;
   nd->D = nd->lay.D;
   nd->F = nd->lay.F;
@@ -486,6 +514,31 @@ int ph_debug_split_tables(const ph_spec* spec, int* slab_map /* 2 * 8960 */, int
   if (!*eligible) return 0;
   ph::grad_slab_map_split(lay, slab_map, ph::grad_fast_fold(probe));
   ph::grad_weight_image_map(lay, ph::grad_fast_fold(probe), image_map);
+  return 0;
+}
+
+// The same for ppo_grad_split_oh_kernel (one-hot observations): *slab_len_out = floats per slab (both nets), *image_elems_out = bf16
+// elements of its weight image; slab_map needs *slab_len_out ints (call once with slab_map = image_map = null to learn the sizes).
+int ph_debug_split_oh_tables(const ph_spec* spec, int* slab_map, int* image_map /* 2 * P */, int* slab_len_out, int* image_elems_out,
+                             int* eligible) {
+  if (!spec || !slab_len_out || !image_elems_out || !eligible) return fail("ph_debug_split_oh_tables: null argument");
+  ph_layout lay;
+  if (layout_of(spec, &lay)) return 1;
+  ph::NetDims probe;
+  std::memset(&probe, 0, sizeof(probe));
+  probe.lay = lay;
+  probe.nchunk = (lay.F + PH_HIDDEN - 1) / PH_HIDDEN;
+  probe.A = lay.A;
+  probe.L = lay.L;
+  probe.F = lay.F;
+  probe.D = lay.D;
+  probe.obs_kind = spec->obs.kind;
+  *eligible = ph::grad_split_oh_eligible(probe) ? 1 : 0;
+  if (!*eligible) return 0;
+  *slab_len_out = ph::grad_split_oh_slab_len(probe);
+  *image_elems_out = ph::grad_split_oh_wimage_elems(probe);
+  if (slab_map) ph::grad_slab_map_split_oh(lay, probe.nchunk, slab_map);
+  if (image_map) ph::grad_weight_image_map_oh(lay, probe.nchunk, image_map);
   return 0;
 }
 
@@ -1587,16 +1640,19 @@ void fill_grad_args(ph::GradArgs& g, const ph::NetDims& nd, const float* params,
 // of every train() / gradient call, whatever happened to the parameters in between; ppo_adam_kernel keeps it current afterwards
 int rebuild_weight_image(ph_ctx* ctx, const ph::NetDims& nd, const float* params) {
   if (!nd.split) return 0;
-  if (!ctx->wimage) {
+  if ((size_t)nd.wimage_elems > ctx->wimage_cap) {
     if (ctx->capturing) return fail("first split-kernel use inside graph capture: call it once outside capture first");
-    PH_HIP(hipMalloc((void**)&ctx->wimage, (size_t)ph::WIMG_ELEMS * sizeof(unsigned short)));
+    if (ensure(ctx->wimage, ctx->wimage_cap, (size_t)nd.wimage_elems)) return 1;
+    ctx->wimage_zeroed_for = 0;
   }
   // Elements no parameter backs are written by nobody (weight_image_kernel / ppo_adam_kernel go through the map), so they are
-  // zeroed when the image starts serving a spec, i.e. a map, not before every call (a 4.5 us fill node in every iteration graph)
-  if (ctx->wimage_zeroed_for != nd.wimage_map) {
+  // zeroed when the image starts serving a spec, not before every call (a 4.5 us fill node in every iteration graph).  The fill
+  // and every later user of the image are enqueued on the context's stream of that moment; a context whose stream is switched
+  // (ph_ctx_set_stream) is synchronised by its owner at the switch, as for every other piece of workspace.
+  if (ctx->wimage_zeroed_for != nd.spec_id) {
     if (ctx->capturing) return fail("the weight image changes its spec inside graph capture: run the same call once outside capture first");
-    PH_HIP(hipMemsetAsync(ctx->wimage, 0, (size_t)ph::WIMG_ELEMS * sizeof(unsigned short), ctx->stream));
-    ctx->wimage_zeroed_for = nd.wimage_map;
+    PH_HIP(hipMemsetAsync(ctx->wimage, 0, (size_t)nd.wimage_elems * sizeof(unsigned short), ctx->stream));
+    ctx->wimage_zeroed_for = nd.spec_id;
   }
   PH_HIP(ph::launch_weight_image(params, ctx->wimage, nd.wimage_map, nd.lay.P, ctx->stream));
   return 0;
@@ -1606,7 +1662,7 @@ int rebuild_weight_image(ph_ctx* ctx, const ph::NetDims& nd, const float* params
 // image itself (obs_planes_kernel) -- built at the start of every train() / gradient call from the observations as they are
 // then.  The row records are written by the advantage-statistics launch that follows (fill_adv_records).
 int build_grad_pack(ph_ctx* ctx, const ph::NetDims& nd, const ph_rollout* rb, size_t n_rec) {
-  if (!nd.split) return 0;
+  if (nd.split != 1) return 0;   // the one-hot kernel gathers its rows itself (D integers per row: nothing to split ahead)
   const size_t rows = (size_t)rb->T * rb->E;
   const size_t need_img = (rows + 1) * ph::XIMG_ROW_U4;
   if (ctx->capturing) {
@@ -1627,9 +1683,9 @@ int build_grad_pack(ph_ctx* ctx, const ph::NetDims& nd, const ph_rollout* rb, si
   return 0;
 }
 void fill_adv_records(ph::AdvStatArgs& aa, const ph_ctx* ctx, const ph::NetDims& nd, const ph_rollout* rb) {
-  aa.rec_pi_out = nd.split ? ctx->rec_pi : nullptr;
-  aa.rec_vf_out = nd.split ? ctx->rec_vf : nullptr;
-  aa.rowrec = (nd.split && rb->advantages && rb->log_probs && rb->actions && rb->returns && rb->values) ? ctx->rowrec : nullptr;
+  aa.rec_pi_out = nd.split == 1 ? ctx->rec_pi : nullptr;
+  aa.rec_vf_out = nd.split == 1 ? ctx->rec_vf : nullptr;
+  aa.rowrec = (nd.split == 1 && rb->advantages && rb->log_probs && rb->actions && rb->returns && rb->values) ? ctx->rowrec : nullptr;
   aa.rb_logp = rb->log_probs;
   aa.rb_act = rb->actions;
   aa.rb_ret = rb->returns;
@@ -1639,12 +1695,12 @@ void fill_adv_records(ph::AdvStatArgs& aa, const ph_ctx* ctx, const ph::NetDims&
 // gemm_mode 2 (products as six bf16 MFMA terms over three-plane operands, float32 accuracy) applies to the gradient launches
 // of specs ppo_grad_split_kernel takes; everywhere else it means 0.  The split kernel's slabs have their own order.
 void select_gemm(ph::NetDims& nd, int gemm_mode) {
-  nd.split = (gemm_mode == 2 && nd.slab_map_split != nullptr) ? 1 : 0;
+  nd.split = (gemm_mode == 2 && nd.slab_map_split != nullptr) ? nd.split_kind : 0;
   if (nd.split) nd.slab_map = nd.slab_map_split;
 }
 
-// floats per gradient slab: the canonical parameter layout, or the register-order layout of ppo_grad_fast_kernel
-int slab_len_of(const ph::NetDims& nd) { return nd.slab_map ? 2 * ph::RS_NET : nd.lay.P; }
+// floats per gradient slab: the canonical parameter layout, the register-order layout of ppo_grad_fast_kernel, or a split kernel's
+int slab_len_of(const ph::NetDims& nd) { return nd.split ? nd.slab_len_split : (nd.slab_map ? 2 * ph::RS_NET : nd.lay.P); }
 
 int ensure_train_ws(ph_ctx* ctx, int P, int slab_len, int nwg_max, int n_mb_total, size_t n_idx = 0, size_t n_phys = 0) {
   if (ctx->capturing) {
@@ -1795,7 +1851,7 @@ void train_adv_args(const TrainPlan& t, bool need_idx, ph::AdvStatArgs& aa) {
   aa.phys_out = ctx->perm_phys;      // the order once more as physical rows: the tile walk then has no index arithmetic
   // the split kernel reads the row records only: the materialised order (8 of the launch's 40 bytes per element) is written
   // for whoever else walks it -- the other gradient kernels, ADAP's context launch (need_idx)
-  if (t.nd.split && !need_idx) aa.idx_out = aa.phys_out = nullptr;
+  if (t.nd.split == 1 && !need_idx) aa.idx_out = aa.phys_out = nullptr;
   fill_adv_records(aa, ctx, t.nd, t.rb);
 }
 
@@ -1854,7 +1910,7 @@ int train_launch_grad(const TrainPlan& t, int mbi, MbPlan* pl_out) {
   fill_grad_args(g, t.nd, t.opt->params, t.rb, t.hp, ctx);
   g.idx = (t.perms ? t.perms : ctx->perm_idx) + (size_t)ep * t.N + start;
   g.idx_phys = ctx->perm_phys + (size_t)ep * t.N + start;
-  if (t.nd.split) {
+  if (t.nd.split == 1) {
     g.rec_pi = ctx->rec_pi + (size_t)ep * t.N + start;
     g.rec_vf = ctx->rec_vf + (size_t)ep * t.N + start;
   }
@@ -2477,8 +2533,8 @@ int ph_bench_ppo_grad(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   aa.n_mb = n_mb;
   aa.out = ctx->advstats;
   aa.partial = ctx->advpart;
-  aa.idx_out = nd.split ? nullptr : ctx->perm_idx;   // as in ph_ppo_train: the grad launches read the materialised order,
-  aa.phys_out = nd.split ? nullptr : ctx->perm_phys; // the split kernel the row records
+  aa.idx_out = nd.split == 1 ? nullptr : ctx->perm_idx;   // as in ph_ppo_train: the grad launches read the materialised order,
+  aa.phys_out = nd.split == 1 ? nullptr : ctx->perm_phys; // the split kernel the row records
   fill_adv_records(aa, ctx, nd, rb);
   PH_HIP(ph::launch_adv_stats(aa, n_mb, s));
   ph::GradArgs g;

@@ -204,7 +204,12 @@ struct NetDims {
   const int* slab_map; // device: slab position -> parameter index when the spec runs on register-order slabs, else nullptr
   const int* slab_map_split;  // device: the same for ppo_grad_split_kernel's accumulator order, or nullptr (spec not eligible)
   const int* wimage_map;      // device: parameter -> weight-image elements of the split kernel (ph_split.h), or nullptr
-  int split;           // 1: this call runs the split-bf16 gradient kernel (gemm_mode 2 on an eligible spec); slab_map then IS slab_map_split
+  int split;           // this call's gradient kernel under gemm_mode 2 (slab_map then IS slab_map_split): 0 none (exact f32), 1 ppo_grad_split_kernel
+                       // (Box observations <= 64 features, one small Discrete head), 2 ppo_grad_split_oh_kernel (one-hot observations)
+  int split_kind;      // which of the two the SPEC is eligible for (0 neither): what `split` becomes when gemm_mode 2 is asked for
+  int slab_len_split;  // floats per gradient slab in that kernel's accumulator order
+  int wimage_elems;    // bf16 elements of its weight fragment image
+  int spec_id;         // the spec-cache entry this record was resolved from (> 0; identifies a spec across calls)
   ph_layout lay;
 };
 

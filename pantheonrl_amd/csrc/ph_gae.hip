@@ -168,7 +168,13 @@ template <int LC, int EB>
 static hipError_t launch_scan(const float* rew, const float* val, const float* es, const float* lv, const float* dn,
                               float* adv, float* ret, int T, int E, float g, float gl, hipStream_t s) {
   int NCH = (T + LC - 1) / LC;
-  const int maxch = 1024 / EB;
+  int maxch = 1024 / EB;
+  static int nch_env = -1;   // PH_GAE_NCH: measurement override of the chunk count cap (workgroup size = NCH * EB lanes)
+  if (nch_env < 0) {
+    const char* e = getenv("PH_GAE_NCH");
+    nch_env = e ? atoi(e) : 0;
+  }
+  if (nch_env > 0 && nch_env < maxch) maxch = nch_env;
   if (NCH > maxch) NCH = maxch;
   dim3 grid((E + EB - 1) / EB), block(NCH * EB);
   const size_t lds = sizeof(float) * (2 * NCH * EB + EB);

@@ -190,7 +190,14 @@ __device__ __forceinline__ int minibatch_row(const GradArgs& a, int gi) {
   return env_major_to_phys(n, a.T, a.E);
 }
 
-constexpr int ADV_SPLIT = 8;   // workgroups per minibatch in the advantage-statistics pass
+#ifndef PH_ADV_SPLIT
+#define PH_ADV_SPLIT 8
+#endif
+#ifndef PH_ADV_THREADS
+#define PH_ADV_THREADS 1024
+#endif
+constexpr int ADV_SPLIT = PH_ADV_SPLIT;      // workgroups per minibatch in the advantage-statistics pass
+constexpr int ADV_THREADS = PH_ADV_THREADS;  // lanes of one of them
 struct AdvStatArgs {
   const float* rb_adv;
   int T, E;
@@ -465,6 +472,14 @@ bool step_fused_fits(int nblk, int slab_len, int num_cu);
 hipError_t launch_ppo_step(const ReduceArgs& r, const AdamArgs& ad, unsigned long long* words, unsigned int* gen,
                            unsigned int* sweep_error, unsigned long long timeout, hipStream_t st);
 hipError_t launch_ppo_adam(const AdamArgs& a, hipStream_t s);
+// the split-bf16 gradient kernel for one-hot (Discrete / MultiDiscrete) observations (ph_ppo_split_oh.hip): several feature
+// chunks, heads of up to 32 logits in up to four components; slabs in its accumulator order, weight fragments from its own image
+bool grad_split_oh_eligible(const NetDims& nd);
+int grad_split_oh_slab_len(const NetDims& nd);
+int grad_split_oh_wimage_elems(const NetDims& nd);
+void grad_weight_image_map_oh(const ph_layout& lay, int nch, int* map /* host, P x 2 */);
+void grad_slab_map_split_oh(const ph_layout& lay, int nch, int* map /* host, grad_split_oh_slab_len */);
+hipError_t launch_ppo_grad_split_oh(const GradArgs& a, int nwg, hipStream_t s);
 hipError_t launch_set_int(int* p, int v, hipStream_t s);
 // behavioural cloning on the shared 32-32 policy (ph_bc.hip)
 size_t bc_train_lds_bytes(int F, int L, int P, int A);

@@ -821,6 +821,7 @@ void grad_plan(const NetDims& nd, int nb, int num_cu, int* ntiles, int* nwg) {
 }
 
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s) {
+  if (a.nd.split == 2) return launch_ppo_grad_split_oh(a, nwg, s);   // gemm_mode 2 on one-hot observations
   if (a.nd.split) return launch_ppo_grad_split(a, nwg, s);   // gemm_mode 2 on a spec the split kernel takes (ph_abi.hip: select_gemm)
   if (grad_fast_eligible(a.nd)) return launch_ppo_grad_fast(a, nwg, gemm_mode, s);
   if (a.nd.Lp != 32 && a.nd.Lp != 64) return hipErrorInvalidValue;
@@ -843,8 +844,8 @@ __device__ __forceinline__ void st_rec(uint4* p, const uint4& v) {
   *p = v;
 #endif
 }
-__global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
-  __shared__ double sh[2][1024 / 64];
+__global__ __launch_bounds__(ADV_THREADS) void adv_stats_kernel(AdvStatArgs a) {
+  __shared__ double sh[2][ADV_THREADS / 64];
   const int mb = blockIdx.x / ADV_SPLIT, seg = blockIdx.x - mb * ADV_SPLIT;   // ADV_SPLIT workgroups share a minibatch
   const int ep = mb / a.n_mb, k = mb - ep * a.n_mb;
   const int start = k * a.batch;
@@ -884,8 +885,8 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
   };
   // one pass: sum and sum of squares in fp64 (exact products of f32 values), 4 independent gathers per round
   double s = 0.0, q = 0.0;
-  for (int i = lo + tid; i < hi; i += 4 * 1024) {
-    const double v0 = value(i), v1 = value(i + 1024), v2 = value(i + 2048), v3 = value(i + 3072);
+  for (int i = lo + tid; i < hi; i += 4 * ADV_THREADS) {
+    const double v0 = value(i), v1 = value(i + ADV_THREADS), v2 = value(i + 2 * ADV_THREADS), v3 = value(i + 3 * ADV_THREADS);
     s += (v0 + v1) + (v2 + v3);
     q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
   }
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(AdvStatArgs a) {
   __syncthreads();
   if (tid == 0) {
     double ts = 0.0, tq = 0.0;
-    for (int w = 0; w < 1024 / 64; ++w) {
+    for (int w = 0; w < ADV_THREADS / 64; ++w) {
       ts += sh[0][w];
       tq += sh[1][w];
     }
@@ -927,7 +928,7 @@ __global__ void adv_finalize_kernel(AdvStatArgs a, int n_total) {
   a.out[2 * mb + 1] = (float)sqrt(var);
 }
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s) {
-  hipLaunchKernelGGL(adv_stats_kernel, dim3(n_total * ADV_SPLIT), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(n_total * ADV_SPLIT), dim3(ADV_THREADS), 0, s, a);
   hipLaunchKernelGGL(adv_finalize_kernel, dim3((n_total + 63) / 64), dim3(64), 0, s, a, n_total);
   return hipGetLastError();
 }
@@ -979,7 +980,13 @@ __global__ __launch_bounds__(256) void obs_planes_kernel(const float* __restrict
     pl[2][e] = l;
   }
 #pragma unroll
-  for (int p = 0; p < 3; ++p) image[row * XIMG_ROW_U4 + p * 8 + g] = __builtin_bit_cast(uint4, pl[p]);
+  for (int p = 0; p < 3; ++p) {
+#if defined(PH_OBS_STORE_NT)
+    st_rec(image + row * XIMG_ROW_U4 + p * 8 + g, __builtin_bit_cast(uint4, pl[p]));
+#else
+    image[row * XIMG_ROW_U4 + p * 8 + g] = __builtin_bit_cast(uint4, pl[p]);
+#endif
+  }
 }
 hipError_t launch_obs_planes(const float* obs, int n, int D, int F, int fold, uint4* image, const float* adv, const float* logp,
                              const float* act, const float* ret, const float* val, uint4* rowrec, hipStream_t s) {

@@ -1,0 +1,191 @@
+// Tile helpers of the split-bf16 gradient kernels (ph_ppo_split.hip, ph_ppo_split_oh.hip): three-plane bf16 operands in LDS, each in
+// ONE layout -- 128-byte plane rows of 64 bf16, 16-byte granules swizzled by the row -- read either along the row (ds_read_b128)
+// or across rows (ds_read_b64_tr_b16, the hardware 4x4 transpose), and products as v_mfma_f32_16x16x32_bf16 terms accumulated in
+// float32.
+#pragma once
+#include "ph_head.h"
+#include "ph_split.h"
+
+namespace ph {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 tr_bf16x4;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte streaming load (each granule is read once per launch and net: keep it out of L1)
+__device__ __forceinline__ uint4 ld_nt16(const uint4* p) {
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+#define PH_LDS_AS __attribute__((address_space(3)))
+
+constexpr int PL_ROW = 128;             // bytes of one plane row: 64 bf16 = 8 granules of 16 bytes
+constexpr int PL_BYTES = 64 * PL_ROW;   // one plane
+constexpr int PB_BYTES = 3 * PL_BYTES;  // a plane buffer: planes h, m, l
+
+// 16-byte granule g of plane row a sits at granule g ^ pl_swz(a), pl_swz linear over the low four row bits.  The map was
+// chosen by exhaustive search over the 4096 linear candidates against a model of the LDS lane groups (MI355X_MICROARCH.md,
+// LDS table; the model reproduces the SQ_LDS_BANK_CONFLICT count of the first layout to 4 %): ds_read_b128 is serviced in four
+// NON-contiguous 16-lane groups over 64 banks, ds_read_b64_tr_b16 in two 32-lane groups over 64 banks, the 8- and 16-byte
+// stores in contiguous 16- / 8-lane groups over 32 banks (so consecutive rows must differ in the granule they write: the map
+// uses row bit 0 as well).  With it the operand reads (plain and transposing), the X commit and the dZ2 commit are
+// conflict-free; the 8-byte C-layout stores keep a 2-way conflict (sixteen rows, one 8-byte half: inherent at 16-byte granules).
+__device__ __forceinline__ int pl_swz(int a) {
+  const int a0 = a & 1, a1 = (a >> 1) & 1, a2 = (a >> 2) & 1, a3 = (a >> 3) & 1;
+  return a1 | ((a1 ^ a2) << 1) | ((a0 ^ a1 ^ a3) << 2);
+}
+
+struct Frag3 {
+  bf16x8 p[3];
+};
+
+__device__ __forceinline__ void split8(const float* x, Frag3& f) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    __bf16 h, m, l;
+    split1(x[e], h, m, l);
+    f.p[0][e] = h;
+    f.p[1][e] = m;
+    f.p[2][e] = l;
+  }
+}
+__device__ __forceinline__ void split4(const float* x, bf16x4 (&p)[3]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    __bf16 h, m, l;
+    split1(x[e], h, m, l);
+    p[0][e] = h;
+    p[1][e] = m;
+    p[2][e] = l;
+  }
+}
+
+// 16-byte write-through slab store.  The two wait states after it are part of the instruction as far as this file is concerned: a
+// store of more than 64 bits reads its data registers late, and a vector write to them in the next cycle changes what is stored
+// (the VMEM store-data hazard).  The compiler's hazard recognizer covers the stores it emits, not the body of an asm statement --
+// it re-used the first two data registers for the next store's address right behind one of these (round 5: dW2's last block
+// came out wrong in lanes 12..15 of every row group).
+__device__ __forceinline__ void st_slab16(float* p, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// acc += (ah + am + al)(bh + bm + bl) without the three smallest cross terms, small terms first
+__device__ __forceinline__ f32x4 mma6(const Frag3& a, const Frag3& b, f32x4 acc) {
+  acc = mfma16(a.p[0], b.p[2], acc);
+  acc = mfma16(a.p[2], b.p[0], acc);
+  acc = mfma16(a.p[1], b.p[1], acc);
+  acc = mfma16(a.p[0], b.p[1], acc);
+  acc = mfma16(a.p[1], b.p[0], acc);
+  acc = mfma16(a.p[0], b.p[0], acc);
+  return acc;
+}
+// column sums: every row of the 16x16 result is sum_k b[k][col]
+__device__ __forceinline__ f32x4 mma_ones(const Frag3& b, f32x4 acc) {
+  bf16x8 one;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) one[e] = (__bf16)1.0f;
+  acc = mfma16(one, b.p[2], acc);
+  acc = mfma16(one, b.p[1], acc);
+  acc = mfma16(one, b.p[0], acc);
+  return acc;
+}
+
+// eight k-contiguous elements of plane row `a`: one ds_read_b128 per plane.  base = byte offset of (row, logical granule) with
+// the swizzle applied (see plain_base); `imm` = compile-time displacement (16-row block, buffer)
+template <int PS = PL_BYTES>   // PS: byte distance between the planes of a buffer
+__device__ __forceinline__ Frag3 ld_plain(const char* smem, int base, int imm) {
+  Frag3 f;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) f.p[p] = *reinterpret_cast<const bf16x8*>(smem + base + imm + p * PS);
+  return f;
+}
+__device__ __forceinline__ bf16x4 ld_tr4(const char* smem, int off) {
+  const tr_bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((PH_LDS_AS tr_bf16x4*)(smem + off));
+  return __builtin_bit_cast(bf16x4, v);
+}
+// eight elements along the plane-ROW index (rows k0 .. k0+7) of one column per lane: two transposing reads per plane.
+// lo / hi = byte offsets of the lane's 8-byte piece in rows k0 + (t>>2) and k0 + 4 + (t>>2) (see tr_base)
+template <int PS = PL_BYTES>
+__device__ __forceinline__ Frag3 ld_tr(const char* smem, int lo, int hi, int imm_lo, int imm_hi) {
+  Frag3 f;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const bf16x4 a = ld_tr4(smem, lo + imm_lo + p * PS), b = ld_tr4(smem, hi + imm_hi + p * PS);
+    f.p[p] = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  return f;
+}
+
+// lane (i = lane & 15, kg = lane >> 4) of an MFMA operand read with ld_plain: plane row 16*blk + i (blk through imm), elements
+// 32*c + 8*kg .. +7  ->  logical granule 4c + kg
+__device__ __forceinline__ int plain_base(int i, int kg, int c) { return i * PL_ROW + (((4 * c + kg) ^ pl_swz(i)) << 4); }
+// lane (t = lane & 15, kg) of an operand read with ld_tr: column 16*mblk + t, plane rows 32*c + 8*kg + 4*half + 0..3.  The lane
+// addresses the 8-byte piece (row +(t>>2), columns 16*mblk + 4*(t&3) .. +3) and receives column t of the 4 x 16 block.
+__device__ __forceinline__ int tr_base(int t, int kg, int c, int half, int mblk) {
+  const int a = 32 * c + 8 * kg + 4 * half + (t >> 2);
+  const int g = 2 * mblk + ((t & 3) >> 1);
+  return a * PL_ROW + ((g ^ pl_swz(a)) << 4) + 8 * (t & 1);
+}
+// b64 store of rows 16*blk + 4*kg .. +3 of plane row a (the C layout of a 16x16 tile: lane column, four consecutive rows)
+__device__ __forceinline__ int cstore_off(int a, int blk, int kg) {
+  return a * PL_ROW + (((2 * blk + (kg >> 1)) ^ pl_swz(a)) << 4) + 8 * (kg & 1);
+}
+__device__ __forceinline__ void st_planes4(char* smem, int off, const bf16x4 (&p)[3]) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(smem + off + q * PL_BYTES) = p[q];
+}
+template <int PS = PL_BYTES>
+__device__ __forceinline__ void st_planes8(char* smem, int off, const Frag3& f) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(smem + off + q * PS) = f.p[q];
+}
+// order this wave's LDS accesses around a hand-off between its own lanes (LDS instructions of one wave execute in order; this
+// keeps the compiler from moving accesses across the point and drains the queue)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- single-plane operands: a value that IS a bf16 (a one-hot observation feature: 0 or 1) needs no m / l planes, and its
+// product with a three-plane operand is three terms, small first
+__device__ __forceinline__ bf16x8 ld_plain1(const char* smem, int base, int imm) {
+  return *reinterpret_cast<const bf16x8*>(smem + base + imm);
+}
+__device__ __forceinline__ bf16x8 ld_tr1(const char* smem, int lo, int hi, int imm_lo, int imm_hi) {
+  const bf16x4 a = ld_tr4(smem, lo + imm_lo), b = ld_tr4(smem, hi + imm_hi);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ f32x4 mma3(const bf16x8& a, const Frag3& b, f32x4 acc) {
+  acc = mfma16(a, b.p[2], acc);
+  acc = mfma16(a, b.p[1], acc);
+  acc = mfma16(a, b.p[0], acc);
+  return acc;
+}
+
+// sum / max over the four lanes {j, j + 16, j + 32, j + 48} of a wave, the same bits in all four: v_permlane16_swap exchanges the
+// odd 16-lane rows of its first operand with the even rows of the second, v_permlane32_swap the upper half of the first with the
+// lower half of the second -- with both operands a copy of v, (first op second) is the pairwise result in every lane.
+// (Inline assembly: the compiler's builtin for these gfx950 instructions returns its first result twice, hipcc 7.2.)
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float kg_sum(float v) {
+  float a = v, b = v;
+  permlane16_swap(a, b);
+  v = a + b;
+  a = v, b = v;
+  permlane32_swap(a, b);
+  return a + b;
+}
+__device__ __forceinline__ float kg_max(float v) {
+  float a = v, b = v;
+  permlane16_swap(a, b);
+  v = fmaxf(a, b);
+  a = v, b = v;
+  permlane32_swap(a, b);
+  return fmaxf(a, b);
+}
+
+}  // namespace ph

@@ -388,6 +388,42 @@ def test_split_bf16_gradient_matches_autograd(name, T, E, nb):
     _assert_grads(g, g_ref, lay)
 
 
+@pytest.mark.parametrize("name,T,E,nb", [("liar", 16, 6, 77), ("liar", 16, 8, 128), ("liar", 8, 8, 1), ("onehot32", 16, 8, 90),
+                                          ("discrete20", 16, 8, 64), ("onehot128", 16, 8, 128), ("onehot17", 16, 6, 77),
+                                          ("liar", 64, 8, 321)])
+def test_split_bf16_one_hot_gradient_matches_autograd(name, T, E, nb):
+    """gemm_mode 2 on one-hot observations (ppo_grad_split_oh_kernel: single-plane X, weight fragments from the image, the head as
+    MFMA tiles): Liar's Dice (F = 270 in five chunks, components 7 + 12), three components filling all 32 logit slots, a 20-way
+    Discrete head (two 16-logit blocks), two feature chunks, a 17-way component across the block boundary; partial tiles, a
+    single row, workgroups with a second tile -- against autograd at the exact-f32 kernels' tolerance, and against the exact-f32
+    general kernel at float32 rounding level"""
+    rng = np.random.default_rng(nb)
+    idx = rng.permutation(T * E)[:nb]
+    for hp in (orc.PPOHyper(), orc.PPOHyper(clip_range=0.1, clip_range_vf=0.3, ent_coef=0.01, vf_coef=0.7, normalize_advantage=False)):
+        g2, g_ref, st, st_ref, lay = _grad_pair(name, T, E, idx, hp, gemm_mode=2)
+        _assert_grads(g2, g_ref, lay)
+        for i, k in enumerate(("policy_loss", "value_loss", "entropy_loss", "clip_fraction", "approx_kl", "loss")):
+            assert abs(st[i] - st_ref[k]) <= 1e-5 + 1e-4 * abs(st_ref[k]), (k, st[i], st_ref[k])
+        g0 = _grad_pair(name, T, E, idx, hp, gemm_mode=0)[0]
+        assert np.abs(g2 - g0).max() <= 2e-6 * max(np.abs(g0).max(), 1e-3), (np.abs(g2 - g0).max(), np.abs(g0).max())
+
+
+def test_split_one_hot_kernel_weight_image_tracks_the_parameters_through_adam_steps():
+    """the one-hot kernel's weight fragment image (W1 in five chunks, W2 twice, the head twice) after a train() of several Adam
+    steps equals what the parameters split to"""
+    import ctypes as C
+    from pantheonrl_amd import _native as nat
+    hp = orc.PPOHyper(batch_size=40, n_epochs=2)
+    model, orac, stats_ref = _train_pair("liar", 16, 6, hp)
+    pol = model.policy
+    assert pol.gemm_mode == 2
+    bad = C.c_int(-2)
+    nat.check(pol.ctx.lib.ph_debug_weight_image_mismatches(pol.ctx.handle, C.byref(pol.spec), pol.params.data_ptr(), C.byref(bad)))
+    assert bad.value == 0, bad.value
+    p, p_ref = pol.get_flat_params(), orac.flat_params()
+    assert np.abs(p - p_ref).max() <= 2e-6 * len(stats_ref) + 1e-6, np.abs(p - p_ref).max()
+
+
 @pytest.mark.parametrize("name,T,E,nb", [("box1", 8, 8, 64), ("box64", 16, 8, 128), ("box64", 8, 8, 1), ("box63", 16, 8, 65),
                                           ("box63", 8, 4, 31), ("mpe8", 64, 8, 257)])
 def test_split_bf16_gradient_corner_shapes(name, T, E, nb):
@@ -1623,7 +1659,8 @@ def test_peer_to_peer_exchange_between_processes(world):
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,T,E,nb,gemm_mode", [("overcooked", 128, 1024, 32768, 0), ("overcooked", 128, 1024, 32768, 2),
                                                     ("liar", 128, 256, 8192, 0), ("adap_oc", 128, 256, 32768, 0),
-                                                    ("liar", 128, 256, 32768, 0)])
+                                                    ("liar", 128, 256, 32768, 0), ("liar", 128, 256, 8192, 2),
+                                                    ("liar", 128, 256, 32768, 2)])
 def test_full_size_minibatch_gradient_matches_autograd(name, T, E, nb, gemm_mode):
     """One whole minibatch of BASELINE configs 3 and 2 at their real sizes (32 768 rows of Overcooked-simple; 8 192 rows of
     Liar's Dice with F = 270 one-hot features and two action components) against autograd on the oracle.  A sum over nb

@@ -161,3 +161,73 @@ def test_split_kernel_tables_cover_every_parameter_exactly_as_documented():
     dummy = (C.c_int * 4)()
     nat.check(lib.ph_debug_split_tables(C.byref(spec), dummy, dummy, C.byref(ok)))
     assert ok.value == 0
+
+
+def test_one_hot_split_kernel_tables_cover_every_parameter():
+    """Host-only check of ppo_grad_split_oh_kernel's two tables (ph_debug_split_oh_tables) on Liar's Dice (F = 270: five chunks,
+    19 logits) and on a two-chunk / 20-logit shape: a slab holds every parameter exactly once; dW2 / dW1 positions follow
+    ((wave 4 + blk) 64 + lane) 4 + r = element (k = 16 blk + 4 (lane / 16) + r, col = 16 wave + lane % 16), chunk by chunk; head
+    positions ((lb 4 + wave) 64 + lane) 4 + r = (unit 16 wave + 4 (lane / 16) + r, logit 16 lb + lane % 16); the image backs W1
+    once, W2 and the head twice, the biases never, no element twice, everything inside the image."""
+    import ctypes as C
+
+    import numpy as np
+
+    from pantheonrl_amd import _native as nat, spaces as sp
+    lib = nat.load()
+    for obs, act in ((sp.MultiDiscrete([7] * 6 + [7, 12] * 12), sp.MultiDiscrete([7, 12])),
+                     (sp.MultiDiscrete([32, 32, 32, 32]), sp.Discrete(20)), (sp.Discrete(5), sp.Discrete(20))):
+        spec = sp.make_spec(obs, act)
+        lay = nat.layout_of(spec)
+        nch = (lay.F + 63) // 64
+        n, ne, ok = C.c_int(0), C.c_int(0), C.c_int(0)
+        nat.check(lib.ph_debug_split_oh_tables(C.byref(spec), None, None, C.byref(n), C.byref(ne), C.byref(ok)))
+        assert ok.value == 1 and n.value % 8 == 0
+        nfrag = 8 * nch + 24
+        assert ne.value == 2 * nfrag * 3 * 512
+        slab = (C.c_int * n.value)()
+        img = (C.c_int * (2 * lay.P))()
+        nat.check(lib.ph_debug_split_oh_tables(C.byref(spec), slab, img, C.byref(n), C.byref(ne), C.byref(ok)))
+        rsn = n.value // 2
+        assert rsn == 4096 * (1 + nch) + 128 + 2048 + 32
+        slab, img = np.array(slab).reshape(2, rsn), np.array(img).reshape(lay.P, 2)
+        assert sorted(slab[slab >= 0].tolist()) == list(range(lay.P))
+        for net, (oW1, oB1, oW2, oB2, oHW, oHB, Lh) in enumerate(((lay.pi_W1, lay.pi_b1, lay.pi_W2, lay.pi_b2, lay.act_W, lay.act_b, lay.L),
+                                                                   (lay.vf_W1, lay.vf_b1, lay.vf_W2, lay.vf_b2, lay.val_W, lay.val_b, 1))):
+            for wave, blk, lane, r in ((0, 0, 0, 0), (3, 3, 63, 3), (1, 2, 37, 1), (2, 3, 48, 3)):
+                pos = ((wave * 4 + blk) * 64 + lane) * 4 + r
+                k, col = 16 * blk + 4 * (lane >> 4) + r, 16 * wave + (lane & 15)
+                assert slab[net, pos] == oW2 + k * 64 + col
+                for ch in range(nch):
+                    want = oW1 + (64 * ch + k) * 64 + col if 64 * ch + k < lay.F else -1
+                    assert slab[net, 4096 * (1 + ch) + pos] == want
+            b1 = 4096 * (1 + nch)
+            assert np.array_equal(slab[net, b1:b1 + 64], oB1 + np.arange(64)) and np.array_equal(slab[net, b1 + 64:b1 + 128], oB2 + np.arange(64))
+            hw = b1 + 128
+            for lb, wave, lane, r in ((0, 0, 0, 0), (1, 3, 63, 3), (0, 2, 21, 1), (1, 1, 3, 2)):
+                u, l = 16 * wave + 4 * (lane >> 4) + r, 16 * lb + (lane & 15)
+                assert slab[net, hw + ((lb * 4 + wave) * 64 + lane) * 4 + r] == (oHW + u * Lh + l if l < Lh else -1)
+            assert np.array_equal(slab[net, hw + 2048:hw + 2048 + Lh], oHB + np.arange(Lh))
+
+            def elem(frag, lane, e):
+                return ((net * nfrag + frag) * 3) * 512 + lane * 8 + e
+            for f, n_ in ((0, 0), (lay.F - 1, 63), (min(lay.F - 1, 70), 42)):
+                k = f & 63
+                assert img[oW1 + f * 64 + n_].tolist() == [elem(((n_ >> 4) * nch + (f >> 6)) * 2 + (k >> 5), ((k >> 3) & 3) * 16 + (n_ & 15), k & 7), -1]
+            for k, n_ in ((0, 0), (63, 63), (21, 40)):
+                fwd = elem(8 * nch + (n_ >> 4) * 2 + (k >> 5), ((k >> 3) & 3) * 16 + (n_ & 15), k & 7)
+                bwd = elem(8 * nch + 8 + (k >> 4) * 2 + (n_ >> 5), ((n_ >> 3) & 3) * 16 + (k & 15), n_ & 7)
+                assert img[oW2 + k * 64 + n_].tolist() == [fwd, bwd]
+            for u, l in ((0, 0), (63, Lh - 1), (37, min(Lh - 1, 17))):
+                hz = elem(8 * nch + 16 + (l >> 4) * 2 + (u >> 5), ((u >> 3) & 3) * 16 + (l & 15), u & 7)
+                hd = elem(8 * nch + 20 + (u >> 4), ((l >> 3) & 3) * 16 + (u & 15), l & 7)
+                assert img[oHW + u * Lh + l].tolist() == [hz, hd]
+            for o in (oB1, oB2):
+                assert (img[o:o + 64] == -1).all()
+            assert (img[oHB:oHB + Lh] == -1).all()
+        backed = img[img >= 0]
+        assert len(set(backed.tolist())) == len(backed) and backed.max() + 2 * 512 < ne.value
+    spec = sp.make_spec(sp.Box(-np.inf, np.inf, (62,)), sp.Discrete(6))   # Box observations: not this kernel's
+    ok = C.c_int(1)
+    nat.check(lib.ph_debug_split_oh_tables(C.byref(spec), None, None, C.byref(n), C.byref(ne), C.byref(ok)))
+    assert ok.value == 0
