@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
   const int oB1 = net == 0 ? lay.pi_b1 : lay.vf_b1, oB2 = net == 0 ? lay.pi_b2 : lay.vf_b2;
   const float inv_nb = 1.0f / (float)a.nb;
   const int lbn = net == 0 ? LB : 1;                  // 16-logit blocks of this net's head
+  const int f_last = nd.F - 64 * (NCH - 1);           // features of the last chunk (1 .. 64)
   const bool norm = net == 0 && a.norm_adv && a.nb > 1;
   const float* advp = a.advstats ? a.advstats : a.params;
   const float adv0 = __builtin_nontemporal_load(advp), adv1 = __builtin_nontemporal_load(advp + 1);
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
     return g;
   };
   // X of the tile in LDS: the row's four lanes zero its NCH plane rows, then set the hot features (same wave: in order)
-  auto commit_rows = [&](const RowGather& g) {
+  auto zero_rows = [&]() {   // independent of the gather: issued while its loads travel
     const int tid = threadIdx.x, row = tid >> 2, q = tid & 3;
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -156,6 +157,9 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
       xrow[q] = zero;
       xrow[q + 4] = zero;
     }
+  };
+  auto commit_rows = [&](const RowGather& g) {
+    const int tid = threadIdx.x, row = tid >> 2, q = tid & 3;
     wave_lds_sync();
     const int sw = pl_swz(row);
 #pragma unroll
@@ -177,28 +181,43 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
   };
 
   // ---- prologue ----
-  RowGather rg = gather_rows(blockIdx.x);
+  // W1's fragments of every chunk (this wave's 16 columns: NCH x 2 x 3 sixteen-byte loads per lane, L2-resident image) go out
+  // first -- they depend on nothing, and behind the row gather's two dependent round trips they were a third one in front of S1
+  Frag3 W1f[NCH][2];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) W1f[ch][c] = ld_frag(oh_frag_w1(NCH, threadIdx.x >> 6, ch, c));
+  // ... then everything else that depends on nothing (biases, the action components' logit ranges), then the row gather; the
+  // rows' X planes are zeroed while the loads travel
+  float bias1 = 0.f, bias2 = 0.f, hb = 0.f;
   {
     const int tid = threadIdx.x;
-    float bias1 = 0.f, bias2 = 0.f, hb = 0.f;
     if (tid < HID) {
       bias1 = a.params[oB1 + tid];
       bias2 = a.params[oB2 + tid];
     }
     if (tid < 32) hb = net == 0 ? (tid < nd.L ? a.params[lay.act_b + tid] : 0.f) : (tid == 0 ? a.params[lay.val_b] : 0.f);
-    if (stop_now) return;
+  }
+  int alo[4], ahi[4];   // policy: component c's logits are [alo[c], ahi[c])
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    alo[c] = (net == 0 && c < nd.A) ? nd.act_off[c] : 0;
+    ahi[c] = (net == 0 && c < nd.A) ? nd.act_off[c + 1] : 0;
+  }
+  __builtin_amdgcn_sched_barrier(0);   // (left to itself the scheduler sinks these loads to their first use, behind the gather)
+  PH_STAMP(a.prof, 8);
+  if (stop_now) return;
+  zero_rows();
+  RowGather rg = gather_rows(blockIdx.x);
+  PH_STAMP(a.prof, 9);
+  {
+    const int tid = threadIdx.x;
     if (tid < HID) {
       b1s[tid] = bias1;
       b2s[tid] = bias2;
     }
     if (tid < 32) hbs[tid] = hb;
-  }
-  // action components' logit ranges (policy): [alo[c], ahi[c])
-  int alo[4], ahi[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    alo[c] = (net == 0 && c < nd.A) ? nd.act_off[c] : 0;
-    ahi[c] = (net == 0 && c < nd.A) ? nd.act_off[c + 1] : 0;
   }
 
   f32x4 gW2[4];
@@ -223,11 +242,17 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
     const bool has_next = tile + (int)gridDim.x < a.ntiles;
 
     // ---- T0: rows -> X (one-hot plane), scalars ----
-    if (!first) rg = gather_rows(tile);
-    commit_rows(rg);
-    Frag3 W1f[2];
+    if (!first) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) W1f[c] = ld_frag(oh_frag_w1(NCH, wave, 0, c));
+      for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) W1f[ch][c] = ld_frag(oh_frag_w1(NCH, wave, ch, c));
+      zero_rows();
+      rg = gather_rows(tile);
+    }
+    if (first) PH_STAMP(a.prof, 10);
+    commit_rows(rg);
+    if (first) PH_STAMP(a.prof, 11);
     lds_barrier();
     if (first) PH_STAMP(a.prof, 1);
 
@@ -256,27 +281,28 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
       f32x4 acc[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      bf16x8 xa[4], xb[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        xa[b] = ld_plain1(smem, pb0, XOH + b * 16 * PL_ROW);
+        xb[b] = ld_plain1(smem, pb1, XOH + b * 16 * PL_ROW);
+      }
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
-        Frag3 nx[2];
-        if (ch + 1 < NCH) {   // the next chunk's fragments travel under this chunk's products
 #pragma unroll
-          for (int c = 0; c < 2; ++c) nx[c] = ld_frag(oh_frag_w1(NCH, wave, ch + 1, c));
-        }
-        bf16x8 xa[4], xb[4];
+        for (int p = 2; p >= 0; --p)   // four independent accumulator chains, interleaved
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          xa[b] = ld_plain1(smem, pb0, XOH + ch * PL_BYTES + b * 16 * PL_ROW);
-          xb[b] = ld_plain1(smem, pb1, XOH + ch * PL_BYTES + b * 16 * PL_ROW);
-        }
+          for (int b = 0; b < 4; ++b) acc[b] = mfma16(xa[b], W1f[ch][0].p[p], acc[b]);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          acc[b] = mma3(xa[b], W1f[0], acc[b]);
-          acc[b] = mma3(xb[b], W1f[1], acc[b]);
-        }
+        for (int p = 2; p >= 0; --p)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[b] = mfma16(xb[b], W1f[ch][1].p[p], acc[b]);
         if (ch + 1 < NCH) {
-          W1f[0] = nx[0];
-          W1f[1] = nx[1];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            xa[b] = ld_plain1(smem, pb0, XOH + (ch + 1) * PL_BYTES + b * 16 * PL_ROW);
+            xb[b] = ld_plain1(smem, pb1, XOH + (ch + 1) * PL_BYTES + b * 16 * PL_ROW);
+          }
         }
       }
       const float bb = b1s[unit];
@@ -300,6 +326,13 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
     if (first) PH_STAMP(a.prof, 2);
 
     // ---- S2: H2 = tanh(H1 W2 + b2) -> H2 planes [row][unit] (roles swapped: result lane = row, registers = units) ----
+    // (every fragment set is requested one phase ahead of its product: the image sits in L2, a microsecond away)
+    Frag3 HZf[OH_LBMAX][2];
+#pragma unroll
+    for (int lb = 0; lb < OH_LBMAX; ++lb)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        if (lb < LB) HZf[lb][c] = ld_frag(oh_frag_hz(NCH, lb, c));
     f32x4 d2[4];
     {
       const float4 bb = *reinterpret_cast<const float4*>(b2s + 16 * wave + 4 * kg);
@@ -326,6 +359,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
     if (first) PH_STAMP(a.prof, 3);
 
     // ---- HZ: head forward of this wave's 16 rows, loss, dL/dz -> dz planes ----
+    const Frag3 hd = ld_frag(oh_frag_hd(NCH, wave));   // A of dH2^T (HD): act_W rows (units) 16 w + i, logits 8 kg ..
     {
       const int row = 16 * wave + j;
       const bool valid = rowphys[row] >= 0;
@@ -339,10 +373,10 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
         const Frag3 h0 = ld_plain(smem, pb0, H2B + wave * 16 * PL_ROW), h1 = ld_plain(smem, pb1, H2B + wave * 16 * PL_ROW);
 #pragma unroll
         for (int lb = 0; lb < OH_LBMAX; ++lb) {
-          if (lb < lbn) {
+          if (lb < LB && lb < lbn) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = mma6(ld_frag(oh_frag_hz(NCH, lb, 0)), h0, acc);
-            acc = mma6(ld_frag(oh_frag_hz(NCH, lb, 1)), h1, acc);
+            acc = mma6(HZf[lb][0], h0, acc);
+            acc = mma6(HZf[lb][1], h1, acc);
             const float4 hb = *reinterpret_cast<const float4*>(hbs + 16 * lb + 4 * kg);
             z[lb][0] = acc[0] + hb.x;
             z[lb][1] = acc[1] + hb.y;
@@ -467,6 +501,9 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
     if (first) PH_STAMP(a.prof, 4);
 
     // ---- HD: d head weights (this wave's 16 units), d head bias, dH2 -> dZ2 planes over this wave's columns of H2 ----
+    Frag3 W2b[2];   // B of dH1 (S6a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) W2b[c] = ld_frag(oh_frag_w2b(NCH, wave, c));
     {
       // dz read across the rows: lane (t = j, kg) addresses the 8-byte piece (row a + t / 4, logits 16 lb + 4 (t % 4) ..)
       auto dz_tr = [&](int lb, int c) -> Frag3 {
@@ -498,7 +535,6 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
         }
       }
       wave_lds_sync();   // this wave's H2 columns are consumed (its own reads above were their last): dZ2 goes over them
-      const Frag3 hd = ld_frag(oh_frag_hd(NCH, wave));   // A: act_W rows (units) 16 w + i, logits 8 kg ..
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         Frag3 zb;   // B: dz row 16 b + j, logits 8 kg .. +7
@@ -522,9 +558,6 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
     // ---- S6a: dW2 += H1^T dZ2, d b2; dH1 = dZ2 W2^T -> dZ1 (registers) ----
     f32x4 dh1[4];
     {
-      Frag3 W2b[2];
-#pragma unroll
-      for (int c = 0; c < 2; ++c) W2b[c] = ld_frag(oh_frag_w2b(NCH, wave, c));
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const Frag3 dzf = ld_tr(smem, tlo_w, thi_w, H2B + 32 * c * PL_ROW, H2B + (32 * c + 4) * PL_ROW);   // B: dZ2 columns 16 w .., rows 32 c + 8 kg ..
@@ -564,18 +597,47 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
       const Frag3 dz1 = ld_plain(smem, pb1, H1T + wave * 16 * PL_ROW);
       gB1 = mma_ones(dz0, gB1);
       gB1 = mma_ones(dz1, gB1);
+      // chunk by chunk: the four blocks' operands are read together (and the next chunk's before this chunk's stores), the four
+      // accumulator chains run interleaved, then the four 16-byte stores leave
+      bf16x8 xa[4], xb[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {   // A: features 64 ch + 16 b + i (lane), tile rows 8 kg .. (contraction): transposing reads of the one-hot plane
+        xa[b] = ld_tr1(smem, trb[b], trb[b ^ 1], XOH, XOH + 4 * PL_ROW);
+        xb[b] = ld_tr1(smem, trb[b], trb[b ^ 1], XOH + 32 * PL_ROW, XOH + 36 * PL_ROW);
+      }
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
+        float* const dst = rslab + oh_rs_w1(ch) + (wave * 4 * 64 + lane) * 4;
+        f32x4 g[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          float* dst = rslab + oh_rs_w1(ch) + ((wave * 4 + b) * 64 + lane) * 4;
-          f32x4 g = {0.f, 0.f, 0.f, 0.f};
-          if (!first) g = *reinterpret_cast<const f32x4*>(dst);
-          // A: features 64 ch + 16 b + i (lane), tile rows 8 kg .. (contraction): transposing reads of the one-hot plane
-          g = mma3(ld_tr1(smem, trb[b], trb[b ^ 1], XOH + ch * PL_BYTES, XOH + ch * PL_BYTES + 4 * PL_ROW), dz0, g);
-          g = mma3(ld_tr1(smem, trb[b], trb[b ^ 1], XOH + ch * PL_BYTES + 32 * PL_ROW, XOH + ch * PL_BYTES + 36 * PL_ROW), dz1, g);
-          if (has_next) *reinterpret_cast<f32x4*>(dst) = g;   // re-read by this workgroup's next tile
-          else st_slab16(dst, g);
+          g[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (!first) g[b] = *reinterpret_cast<const f32x4*>(dst + b * 256);
+        }
+        // blocks of the last chunk beyond F are padding: no parameter behind them (the slab map says -1), so they are not stored --
+        // the slab stores are what bounds this phase (27 MB per launch at NCH = 5).  Their products still run: a branch around
+        // them splits the basic block and with it the interleaving of the four chains (measured: + 1.4 k cycles).
+        const int nb_live = (ch + 1 < NCH) ? 4 : (f_last + 15) >> 4;
+#pragma unroll
+        for (int p = 2; p >= 0; --p)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) g[b] = mfma16(xa[b], dz0.p[p], g[b]);
+#pragma unroll
+        for (int p = 2; p >= 0; --p)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) g[b] = mfma16(xb[b], dz1.p[p], g[b]);
+        if (ch + 1 < NCH) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            xa[b] = ld_tr1(smem, trb[b], trb[b ^ 1], XOH + (ch + 1) * PL_BYTES, XOH + (ch + 1) * PL_BYTES + 4 * PL_ROW);
+            xb[b] = ld_tr1(smem, trb[b], trb[b ^ 1], XOH + (ch + 1) * PL_BYTES + 32 * PL_ROW, XOH + (ch + 1) * PL_BYTES + 36 * PL_ROW);
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (b >= nb_live) continue;
+          if (has_next) *reinterpret_cast<f32x4*>(dst + b * 256) = g[b];   // re-read by this workgroup's next tile
+          else st_slab16(dst + b * 256, g[b]);
         }
       }
     }

@@ -65,8 +65,15 @@ __device__ __forceinline__ void split4(const float* x, bf16x4 (&p)[3]) {
 // (the VMEM store-data hazard).  The compiler's hazard recognizer covers the stores it emits, not the body of an asm statement --
 // it re-used the first two data registers for the next store's address right behind one of these (round 5: dW2's last block
 // came out wrong in lanes 12..15 of every row group).
+// No "memory" clobber: nothing in these kernels reads a slab position after this store wrote it (a later tile's accumulator
+// re-load is ordered by its register dependence), and with the clobber every LDS operand read behind a store waited for it -- the
+// block-by-block epilogues ran read - product - store, one block at a time.
 __device__ __forceinline__ void st_slab16(float* p, const f32x4& v) {
+#if defined(PH_SLAB_STORE_CLOBBER)   // A/B only
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v));
+#endif
 }
 __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);

@@ -83,6 +83,20 @@ else:
     report("ppo_grad", nwg, 2, ["prologue+S0 meta", "S1 X+W1 load", "S1 mma", "Wo load+H1 tanh", "S2 mma+tanh",
                                 "S3 head/value", "S4 loss", "S5a dWo", "S5b dH2/dZ2", "S6a dW2+dH1", "S6b dZ1",
                                 "S7 dW1 (+rest of tiles)", "stats"])
+if LIAR:
+    for rep in range(2):
+        stamps.zero_()
+        nat.check(lib.ph_bench_ppo_grad(h, C.byref(pol.spec), pol.params.data_ptr(), C.byref(rb.c_struct()), C.byref(hp),
+                                        int(model.batch_size), 20 if rep == 0 else 1, 2, C.byref(ms)))
+        th.cuda.synchronize()
+        if rep == 0:
+            print(f"ppo_grad_split_oh: {ms.value * 1e3:.1f} us per launch (20 back-to-back launches)")
+    report("ppo_grad_split_oh prologue", nwg, 2, ["kernel entry -> W1 fragment loads issued", "row gather (order -> observations, scalars) arrived",
+                                                  "biases, action ranges, accumulators", "X zero + hot features + scalars to LDS", "barrier"],
+           slots=[0, 8, 9, 10, 11, 1])
+    report("ppo_grad_split_oh", nwg, 2, ["prologue + T0 (gather, one-hot X)", "S1 X W1 (chunks), tanh, split", "S2 mma+tanh+split",
+                                         "HZ head forward, loss, dz", "HD d head, dH2 -> dZ2", "S6a dW2, dH1", "S6b dZ1 + S7 dW1 (chunks)",
+                                         "remaining tiles", "epilogue"], slots=[0, 1, 2, 3, 4, 5, 6, 7, 12, 13])
 if not LIAR:
     stamps.zero_()
     nat.check(lib.ph_bench_ppo_grad(h, C.byref(pol.spec), pol.params.data_ptr(), C.byref(rb.c_struct()), C.byref(hp),
