@@ -122,7 +122,8 @@ def build_agents(args, device):
         model = PPO("MlpPolicy", env, n_steps=args.n_steps, n_envs=args.n_envs, batch_size=args.batch_size,
                     n_epochs=args.n_epochs, seed=seed, device=device)
         model.device_permutations = True
-        if args.agents_per_gpu == 1 and os.environ.get("PH_EXCLUSIVE_DEVICE", "1") != "0":
+        shared = int(os.environ.get("WORLD_SIZE", "1")) > max(th.cuda.device_count(), 1)   # several ranks on one device (functional tests)
+        if args.agents_per_gpu == 1 and not shared and os.environ.get("PH_EXCLUSIVE_DEVICE", "1") != "0":
             # one learner per GPU (north_star's layout, config 5): its update launches have the device to themselves, so the slab
             # reduction may use the wide blocks (same summation tree, same results: include/pantheon_hip.h)
             model.policy.ctx.set_exclusive_device(True)
@@ -670,6 +671,9 @@ def main():
                    "efficiency_base": "python bench.py (N=1, launch_mode graph, rollout scripted); per-GPU work is fixed "
                                       "(agents_per_gpu learners x n_envs x n_steps per iteration)"},
     }
+    sweep_errors = sum(a.model.policy.ctx.step_errors() for a in agents)
+    if sweep_errors:
+        raise SystemExit(f"bench.py: rank {rank}: {sweep_errors} waits of the one-launch optimizer step expired -- the run is invalid")
     if exchange is not None and hasattr(exchange, "route") and exchange.p2p_timeouts() != 0:
         raise SystemExit(f"bench.py: rank {rank}: {exchange.p2p_timeouts()} peer-to-peer polls timed out -- the run is invalid; "
                          f"first: {exchange.p2p_timeout_record()}")

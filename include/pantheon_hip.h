@@ -39,7 +39,7 @@ extern "C" {
                                   (additions only)
                               4: + ph_selfplay_rollout_persistent_capacity, ph_ppo_train's gradient pack (no signature changed)
                               5: + ph_policy_act_host, ph_buffer_add_reward_const, ph_adapmult_*, ph_ctx_set_joint_reward_rule (additions only)
-                              6: + ph_bench_train_kernels, ph_debug_split_oh_tables (additions only) */
+                              6: + ph_bench_train_kernels, ph_debug_split_oh_tables, ph_ctx_step_errors (additions only) */
 #define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
 #define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
 #define PH_MAX_LOGITS 64 /* max total policy logits L */
@@ -133,6 +133,12 @@ int ph_debug_weight_image_mismatches(ph_ctx *ctx, const ph_spec *spec, const flo
  * blocks (it sits on the critical path) instead of the 256-lane blocks sized to run BESIDE another learner's gradient launch;
  * both walk the same summation tree, so results do not depend on the hint.  Default 0. */
 int ph_set_exclusive_device(ph_ctx *ctx, int exclusive);
+/* The one-launch reduce + clip + Adam step an exclusive learner uses (ppo_step_kernel) makes its blocks wait for each other's
+ * partial results; a wait that runs into its bound (~2 s: never on a healthy, truly exclusive device) leaves that block's
+ * parameters unchanged, marks the minibatch's statistics record (stats[7] = -1) and counts here.  *count_out = waits that expired
+ * since the context was created; a non-zero count means an optimizer step was applied only in part: treat the run as invalid.
+ * Synchronises the context's stream. */
+int ph_ctx_step_errors(ph_ctx *ctx, unsigned int *count_out /* host */);
 /* HIP-event timing on the ctx stream (bench.py roofline: events must sit on the stream the kernels run on) */
 int ph_timer_start(ph_ctx *ctx);
 int ph_timer_stop(ph_ctx *ctx, float *ms_out /* host */); /* synchronises */

@@ -190,6 +190,7 @@ SIGNATURES = {
     "ph_rng_epoch_advance": [_vp],
     "ph_debug_set_profile_buffer": [_vp, _vp],
     "ph_set_exclusive_device": [_vp, _i],
+    "ph_ctx_step_errors": [_vp, C.POINTER(C.c_uint)],
     "ph_debug_weight_image_mismatches": [_vp, C.POINTER(PhSpec), _vp, C.POINTER(C.c_int)],
     "ph_timer_start": [_vp],
     "ph_timer_stop": [_vp, C.POINTER(C.c_float)],
@@ -366,6 +367,7 @@ class Context:
         check(self.lib.ph_ctx_create(int(device_index), C.byref(h)))
         self.handle = h
         self.device_index = int(device_index)
+        self.exclusive_hint = False
 
     def set_stream(self, raw_stream: int) -> None:
         # every engine call binds the caller's current stream first; the native call is skipped while the stream stays the same
@@ -382,9 +384,16 @@ class Context:
         (the synthetic driver), "rps" = bonus * rock-paper-scissors payoff (rps.py:41-45)"""
         check(self.lib.ph_ctx_set_joint_reward_rule(self.handle, {"match": 0, "rps": 1}[rule]))
 
+    def step_errors(self) -> int:
+        """expired waits of the one-launch optimizer step (ph_ctx_step_errors); synchronises the context's stream"""
+        n = C.c_uint(0)
+        check(self.lib.ph_ctx_step_errors(self.handle, C.byref(n)))
+        return int(n.value)
+
     def set_exclusive_device(self, exclusive: bool) -> None:
         """scheduling hint (ph_set_exclusive_device): this context's training launches have the device to themselves"""
         check(self.lib.ph_set_exclusive_device(self.handle, int(bool(exclusive))))
+        self.exclusive_hint = bool(exclusive)
 
     def close(self) -> None:
         if getattr(self, "handle", None):

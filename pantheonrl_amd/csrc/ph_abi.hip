@@ -478,6 +478,16 @@ int ph_set_exclusive_device(ph_ctx* ctx, int exclusive) {
   return 0;
 }
 
+int ph_ctx_step_errors(ph_ctx* ctx, unsigned int* count_out) {
+  DevGuard dev_guard(ctx);
+  if (!ctx || !count_out) return fail("ph_ctx_step_errors: null argument");
+  *count_out = 0u;
+  if (!ctx->step_gen) return 0;   // the fused step never ran on this context
+  PH_HIP(hipMemcpyAsync(count_out, ctx->step_gen + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+  PH_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
 int ph_timer_start(ph_ctx* ctx) {
   DevGuard dev_guard(ctx);
   if (!ctx) return fail("null ctx");

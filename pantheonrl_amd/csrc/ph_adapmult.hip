@@ -7,7 +7,7 @@
 // then action_net / value_net as in MlpPolicy.  This is NOT the 64-64 MLP the engine's fused kernels are built around, and ADAP is
 // off the bench path (SURVEY.md 2 marks it out of scope as a feature), so the network is laid out as a CHAIN OF SMALL LAUNCHES over
 // dense [rows][width] intermediates in HBM -- one dense layer, one elementwise step or one weight-gradient product per launch, each
-// a few lines whose arithmetic can be read off -- not as a fused tile kernel: correctness and the reference's semantics first
+// a few lines whose arithmetic can be read off (the products as f32 MFMA tiles) -- not as a fused tile kernel: correctness and the reference's semantics first
 // (forward, PPO minibatch gradient, ADAP's context term; oracle: oracle/sb3_oracle.py AdapMultPolicyOracle).  tanh / exp / log are
 // the engine's own definitions (ph_device.h), shared with every other kernel, so the rollout's log-probabilities and the
 // update's agree as they do for MlpPolicy.  Sampling, log-prob and the fused RolloutBuffer.add are ph_rowtail.h's row tails.
@@ -17,12 +17,15 @@
 namespace ph {
 
 // ---- primitives -----------------------------------------------------------------------------------------------------------------
+// The three products below run on the matrix pipe as 32x32 v_mfma_f32_32x32x2_f32 tiles on LDS operands (ph_device.h: tile_mma,
+// one tile per wave of a 64 x 64 block) -- bit for bit the k-ordered fmaf chain per output element, i.e. the
+// numbers of the register-tile fmaf loops these kernels were first written as.
 // Y[r][n] = act(b[n] + sum_k X[r * ldx + k] W[k * N + n]), r < rows, n < N, K <= 64; act: 0 none, 1 tanh.  A block owns 64 rows x
-// 64 columns, a thread 4 x 4 of them; X (transposed to [k][row]) and W's columns pass through LDS once; k ascending per entry.
+// 64 columns; X (transposed to [k][row]) and W's columns pass through LDS once, zero-padded to 64; k ascending per entry.
 __global__ __launch_bounds__(256) void am_dense_kernel(const float* __restrict__ X, int ldx, int K, const float* __restrict__ W,
                                                        const float* __restrict__ b, int N, float* __restrict__ Y, int rows, int act) {
   __shared__ __attribute__((aligned(16))) float xt[64][68], ws[64][68];
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
   for (int e = tid; e < 64 * 64; e += 256) {
     const int rl = e >> 6, k = e & 63;   // consecutive lanes read consecutive k of one row of X
@@ -31,30 +34,18 @@ __global__ __launch_bounds__(256) void am_dense_kernel(const float* __restrict__
     ws[kk][c] = (kk < K && n0 + c < N) ? W[(size_t)kk * N + n0 + c] : 0.f;
   }
   __syncthreads();
-  float acc[4][4];
+  const int mt = wave >> 1, nt = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int n = n0 + nt * 32 + li;
+  const float bv = n < N ? b[n] : 0.f;
+  f32x16 acc;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float bv = (n0 + 4 * tx + j < N) ? b[n0 + 4 * tx + j] : 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = bv;
+  acc = tile_mma<true, false, false>(&xt[0][0], 68, &ws[0][0], 68, mt * 32, nt * 32, 0, 64, acc, lane);   // rows k >= K are zero
+  if (n < N) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i][j] = bv;
-  }
-  for (int k = 0; k < K; ++k) {
-    const float4 a4 = *reinterpret_cast<const float4*>(&xt[k][4 * ty]);
-    const float4 b4 = *reinterpret_cast<const float4*>(&ws[k][4 * tx]);
-    const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bw[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bw[j], acc[i][j]);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = r0 + 4 * ty + i;
-    if (r >= rows) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + 4 * tx + j;
-      if (n < N) Y[(size_t)r * N + n] = act ? fast_tanh(acc[i][j]) : acc[i][j];
+    for (int r = 0; r < 16; ++r) {
+      const int row = r0 + mt * 32 + drow(r, lh);
+      if (row < rows) Y[(size_t)row * N + n] = act ? fast_tanh(acc[r]) : acc[r];
     }
   }
 }
@@ -76,45 +67,40 @@ __global__ void am_contract_kernel(const float* __restrict__ x, const float* __r
   y[e] = v;
 }
 
-// dX[r][k] (+)= sum_n dY[r][n] W[k * N + n]   (dX = dY W^T), K = 64.  16 rows per block; dY and W pass through LDS in chunks of
-// 64 columns (W's chunk transposed to [n][k]: a lane's four k are contiguous), n in ascending order per entry.
+// dX[r][k] (+)= sum_n dY[r][n] W[k * N + n]   (dX = dY W^T), K = 64.  64 rows per block; dY and W pass through LDS in chunks of
+// 64 columns (W's chunk transposed to [n][k]), n in ascending order per entry; one 32 x 32 output tile per wave.
 __global__ __launch_bounds__(256) void am_dense_dx_kernel(const float* __restrict__ dY, const float* __restrict__ W, int N, int K,
                                                           float* __restrict__ dX, int rows, int accumulate) {
-  __shared__ float ds[16][65];
-  __shared__ __attribute__((aligned(16))) float wt[64][68];   // [n][k]
-  const int tid = threadIdx.x, rr = tid >> 4, kq = tid & 15;
-  const int r0 = blockIdx.x * 16, r = r0 + rr;
-  float acc[4];
+  __shared__ __attribute__((aligned(16))) float ds[64][68], wt[64][68];   // [row][n], [n][k]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int mt = wave >> 1, nt = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int r0 = blockIdx.x * 64, k = nt * 32 + li;
+  f32x16 acc;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = (accumulate && r < rows) ? dX[(size_t)r * K + 4 * kq + i] : 0.f;
+  for (int r = 0; r < 16; ++r) {
+    const int row = r0 + mt * 32 + drow(r, lh);
+    acc[r] = (accumulate && row < rows) ? dX[(size_t)row * K + k] : 0.f;
+  }
   for (int n0 = 0; n0 < N; n0 += 64) {
     const int nn = (N - n0 < 64) ? N - n0 : 64;
     __syncthreads();
-    for (int e = tid; e < 16 * 64; e += 256) {
+    for (int e = tid; e < 64 * 64; e += 256) {
       const int rl = e >> 6, n = e & 63;
       ds[rl][n] = (r0 + rl < rows && n < nn) ? dY[(size_t)(r0 + rl) * N + n0 + n] : 0.f;
-    }
-    for (int e = tid; e < 64 * 64; e += 256) {
-      const int k = e >> 6, n = e & 63;      // consecutive lanes read consecutive n of one row k of W
-      wt[n][k] = (n < nn) ? W[(size_t)k * N + n0 + n] : 0.f;
+      const int kk = e >> 6;                 // consecutive lanes read consecutive n of one row kk of W
+      wt[n][kk] = (n < nn) ? W[(size_t)kk * N + n0 + n] : 0.f;
     }
     __syncthreads();
-    for (int n = 0; n < nn; ++n) {
-      const float d = ds[rr][n];
-      const float4 w4 = *reinterpret_cast<const float4*>(&wt[n][4 * kq]);
-      acc[0] = fmaf(d, w4.x, acc[0]);
-      acc[1] = fmaf(d, w4.y, acc[1]);
-      acc[2] = fmaf(d, w4.z, acc[2]);
-      acc[3] = fmaf(d, w4.w, acc[3]);
-    }
+    acc = tile_mma<false, false, false>(&ds[0][0], 68, &wt[0][0], 68, mt * 32, nt * 32, 0, 64, acc, lane);   // columns n >= nn are zero
   }
-  if (r < rows) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dX[(size_t)r * K + 4 * kq + i] = acc[i];
+  for (int r = 0; r < 16; ++r) {
+    const int row = r0 + mt * 32 + drow(r, lh);
+    if (row < rows) dX[(size_t)row * K + k] = acc[r];
   }
 }
 static hipError_t dense_dx(const float* dY, const float* W, int N, int K, float* dX, int rows, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(am_dense_dx_kernel, dim3((rows + 15) / 16), dim3(256), 0, s, dY, W, N, K, dX, rows, accumulate);
+  hipLaunchKernelGGL(am_dense_dx_kernel, dim3((rows + 63) / 64), dim3(256), 0, s, dY, W, N, K, dX, rows, accumulate);
   return hipGetLastError();
 }
 
@@ -136,63 +122,45 @@ __global__ void am_contract_bwd_kernel(const float* __restrict__ dy, const float
 }
 
 // slab k (rows [k * per, (k + 1) * per) of the minibatch): slab[woff + kk * N + n] = sum_r X[r * ldx + kk] dY[r * N + n] and
-// slab[boff + n] = sum_r dY[r * N + n].  A block owns a 64 (kk) x 64 (n) tile of the product for its slab, a thread 4 x 4 entries;
-// X and dY pass through LDS 16 rows at a time; every entry adds its rows in ascending order (a fixed summation order).
+// slab[boff + n] = sum_r dY[r * N + n].  A block owns a 64 (kk) x 64 (n) tile of the product for its slab, a wave one 32 x 32 tile of
+// it; X and dY pass through LDS 32 rows at a time; every entry adds its rows in ascending order (a fixed summation order).
 __global__ __launch_bounds__(256) void am_dense_dw_kernel(const float* __restrict__ X, int ldx, int K, const float* __restrict__ dY,
                                                           int N, float* __restrict__ slabs, int slab_len, int woff, int boff, int rows,
                                                           int per) {
-  __shared__ __attribute__((aligned(16))) float xs[16][68], ds[16][68];
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  __shared__ __attribute__((aligned(16))) float xs[32][68], ds[32][68];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int mt = wave >> 1, nt = wave & 1, li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.y * 64;
   const int r0 = blockIdx.x * per, r1 = (r0 + per < rows) ? r0 + per : rows;
-  float acc[4][4], bsum[4];
+  f32x16 acc;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    bsum[i] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  }
-  for (int rb = r0; rb < r1; rb += 16) {
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;   // tid < 64: column n0 + tid of dY
+  for (int rb = r0; rb < r1; rb += 32) {
     __syncthreads();
-    for (int e = tid; e < 16 * 64; e += 256) {
+    for (int e = tid; e < 32 * 64; e += 256) {
       const int rl = e >> 6, c = e & 63;
       const bool live = rb + rl < r1;
       xs[rl][c] = (live && c < K) ? X[(size_t)(rb + rl) * ldx + c] : 0.f;
       ds[rl][c] = (live && n0 + c < N) ? dY[(size_t)(rb + rl) * N + n0 + c] : 0.f;
     }
     __syncthreads();
-#pragma unroll 4
-    for (int rl = 0; rl < 16; ++rl) {
-      const float4 a4 = *reinterpret_cast<const float4*>(&xs[rl][4 * ty]);
-      const float4 b4 = *reinterpret_cast<const float4*>(&ds[rl][4 * tx]);
-      const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-      if (ty == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bsum[j] += b[j];
-      }
+    acc = tile_mma<true, false, false>(&xs[0][0], 68, &ds[0][0], 68, mt * 32, nt * 32, 0, 32, acc, lane);   // rows past r1 are zero
+    if (tid < 64) {
+#pragma unroll 8
+      for (int rl = 0; rl < 32; ++rl) bsum += ds[rl][tid];
     }
   }
   float* slab = slabs + (size_t)blockIdx.x * slab_len;
+  const int n = n0 + nt * 32 + li;
+  if (n < N) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int kk = 4 * ty + i;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + 4 * tx + j;
-      if (kk < K && n < N) slab[woff + kk * N + n] = acc[i][j];
+    for (int r = 0; r < 16; ++r) {
+      const int kk = mt * 32 + drow(r, lh);
+      if (kk < K) slab[woff + kk * N + n] = acc[r];
     }
   }
-  if (ty == 0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + 4 * tx + j;
-      if (n < N) slab[boff + n] = bsum[j];
-    }
-  }
+  if (tid < 64 && n0 + tid < N) slab[boff + n0 + tid] = bsum;
 }
 static hipError_t dense_dw(const float* X, int ldx, int K, const float* dY, int N, float* slabs, int nslab, int slab_len, int woff,
                            int boff, int rows, hipStream_t s) {

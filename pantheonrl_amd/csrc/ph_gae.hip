@@ -202,9 +202,11 @@ hipError_t launch_gae(const float* rew, const float* val, const float* es, const
   if (lc_env == 8) return launch_scan<8, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
   if (lc_env == 16) return launch_scan<16, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
   if (lc_env == 32) return launch_scan<32, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
+  // Longer T: 16 steps per lane as well.  32 steps per lane (120 VGPRs, one 1024-lane workgroup per CU whose load, scan and store
+  // phases do not overlap with anything) measured 4.19 TB/s at E = 16384, T = 2048; 16 steps per lane (72 VGPRs) 4.57 TB/s; 8 steps
+  // (51 VGPRs, two workgroups per CU, twice the LDS scan rounds per element) 4.37 TB/s -- profiles/r05_b_gae_lc_sweep.txt
   if (T <= 256) return launch_scan<8, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
-  if (T <= 512) return launch_scan<16, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
-  return launch_scan<32, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
+  return launch_scan<16, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
 }
 
 // ---- K1: RolloutBuffer.add / reward += / reset -----------------------------------------------------------------------

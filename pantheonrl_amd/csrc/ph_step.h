@@ -325,10 +325,13 @@ __device__ __forceinline__ void step_finish(const StepArgs& s, int nblk, unsigne
     if ((unsigned long long)(wall_clock64() - t0) > s.timeout) break;
     __builtin_amdgcn_s_sleep(4);
   }
-  if (!ok) {   // never on a healthy device; the parameters stay as they are
+  if (!ok) {   // never on a healthy device; this block's parameters stay as they are, the host is told (ph_ctx_step_errors)
     if (lane == 0) {
       atomicAdd(s.sweep_error, 1u);
-      if (first && a.stats_out) a.stats_out[7] = -1.f;
+      if (first) {
+        if (a.stats_out) a.stats_out[7] = -1.f;
+        *s.gen = tag;   // the next launch gets a new tag: words this launch left behind can never satisfy its sweep
+      }
     }
     return;
   }

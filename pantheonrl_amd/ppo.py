@@ -556,6 +556,9 @@ class PPO:
         self._stats_dev = stats
         if sync_stats:
             st = stats.cpu().numpy()
+            if (st[:, 7] < 0).any() or (pol.ctx.exclusive_hint and pol.ctx.step_errors()):
+                raise nat.NativeError("PPO.train: a wait of the one-launch optimizer step expired (is the device really this "
+                                      "learner's alone? ph_set_exclusive_device): the update was applied only in part")
             self.last_train_stats = st
             applied = st[:, 7] > 0
             # SB3 appends a minibatch's losses BEFORE the KL check (adap_learn.py:282-327), so the minibatch that triggers the
