@@ -675,23 +675,52 @@ __device__ __forceinline__ void head_tail32(const FwdArgs& a, const NetDims& nd,
 // FUSED: called from a 512-thread workgroup whose lower half runs the policy net and whose upper half runs the value net of
 // the same 16 rows (liar_rollout_kernel): tid / net / row0 / LDS base come from the caller, and the value half executes the
 // barrier the policy half has around its logits so that both halves reach every workgroup barrier.
-template <bool VALU, bool FUSED = false>
+// RES (persistent rollouts): one net's weights of one agent staged into LDS ONCE per launch (stage_resident_net) instead of by every
+// forward -- the layout the forward itself stages (W2 [64][LDH], b2, the head's bias), the head's weights with a narrower leading
+// dimension (RES_LDO: only 32 logit columns exist), and b1, which the per-launch form reads from global memory.  Same values in the
+// same operand positions: the forward's arithmetic does not change.
+constexpr int RES_LDO = 33;
+constexpr int RES_NET_FLOATS = HID * LDH + HID * RES_LDO + HID + HID + 32;
+struct ResidentNet {
+  float* w2s;   // [64][LDH]
+  float* wos;   // policy: act_W [64][RES_LDO], columns >= L zero | value: val_W [64]
+  float* b1s;   // [64]
+  float* b2s;   // [64]
+  float* hbs;   // act_b [32] | val_b
+};
+__device__ __forceinline__ ResidentNet resident_net_at(float* base) {
+  ResidentNet r;
+  r.w2s = base;
+  r.wos = r.w2s + HID * LDH;
+  r.b1s = r.wos + HID * RES_LDO;
+  r.b2s = r.b1s + HID;
+  r.hbs = r.b2s + HID;
+  return r;
+}
+// scratch of one half (one net) of a fused forward in RES form: xs, hs, outs, feat, aoff, seg, ridxs (see the body)
+constexpr int RES_SCRATCH_FLOATS = 2 * 16 * LDH + 16 * 33 + 16 * 64 + 40 + 96 + 2 * 16 + 8;
+
+template <bool VALU, bool FUSED = false, bool RES = false>
 __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in = 0, int net_in = 0, int tid_in = 0,
-                                                   float* smem_in = nullptr, int row_end_in = 0) {
+                                                   float* smem_in = nullptr, int row_end_in = 0,
+                                                   const ResidentNet resv = ResidentNet{nullptr, nullptr, nullptr, nullptr, nullptr},
+                                                   const int* ooff = nullptr) {
+  const ResidentNet* const res = &resv;   // (by value: a pointer to a caller's record would pin it in scratch memory)
   extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
   float* smem = FUSED ? smem_in : smem_dyn;
   constexpr int R = 16, NT = 256, LDO = 33, FS = 64;
+  constexpr int LDW = RES ? RES_LDO : LDH;   // leading dimension of the head's weights
   const NetDims& nd = a.nd;
   float* xs = smem;                 // [16][LDH]  H2
   float* hs = xs + R * LDH;         // [16][LDH]  H1
-  float* w2s = hs + R * LDH;        // [64][LDH]
-  float* wos = w2s + HID * LDH;     // policy: act_W [64][LDH], columns >= L zero | value: val_W [64]
-  float* outs = wos + HID * LDH;    // [16][LDO] logits
-  float* b2s = outs + R * LDO;      // [64]
-  float* hbs = b2s + HID;           // act_b [32] | val_b
-  int* feat = (int*)(hbs + 32);     // [16][FS] hot row of W1 per (row, component), -1 = none
+  float* w2s = RES ? res->w2s : hs + R * LDH;        // [64][LDH]
+  float* wos = RES ? res->wos : w2s + HID * LDH;     // policy: act_W [64][LDW], columns >= L zero | value: val_W [64]
+  float* outs = RES ? hs + R * LDH : wos + HID * LDH;    // [16][LDO] logits
+  float* b2s = RES ? res->b2s : outs + R * LDO;      // [64]
+  float* hbs = RES ? res->hbs : b2s + HID;           // act_b [32] | val_b
+  int* feat = (int*)(RES ? outs + R * LDO : hbs + 32);     // [16][FS] hot row of W1 per (row, component), -1 = none
   int* aoff = feat + R * FS;        // [40] prefix sums of the action nvec (A + 1 entries)
-  int* seg = aoff + 40;             // [3][32] per logit: first / last lane of its component, component index
+  int* seg = aoff + 40;             // [3][32] per logit: first / last lane of its component, component index (RES: filled once per launch)
   long long* ridxs = (long long*)(seg + 96);          // [16] rollout-buffer row of each observation row (-1 = not recorded)
 
   const int tid = FUSED ? tid_in : (int)threadIdx.x;
@@ -719,7 +748,8 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
     const int e = tid + NT * i, r = e >> 6, comp = e & 63, row = row0 + r;
     int f = -1;
     if (comp < D && row < n_end) {
-      const int lo = nd.obs_off[comp], nn = nd.obs_off[comp + 1] - lo;
+      const int* off = RES ? ooff : nd.obs_off;   // RES: the prefix sums sit in LDS for the launch
+      const int lo = off[comp], nn = off[comp + 1] - lo;
       int x = (int)a.obs[(size_t)row * D + comp];
       x = x < 0 ? 0 : (x >= nn ? nn - 1 : x);
       f = lo + x;
@@ -729,25 +759,30 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   long long ridxv = -1;
   if (net == 0 && tid < R && row0 + tid < n_end && (a.rb_act || a.rb_logp)) ridxv = rb_row(a, row0 + tid);
   WStage<NT> w2r;
-  w2r.issue(W2, 0, HID, tid);
   const int gr = tid >> 4, gl = tid & 15;   // gather: row gr, hidden units 4*gl .. 4*gl+3
   float b1v[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) b1v[i] = B1[4 * gl + i];
   float bias2 = 0.f, hb = 0.f, hv[8];
   int aoffv = 0;
-  if (tid < HID) bias2 = B2[tid];
-  if (net == 0) {
-    if (tid <= nd.A) aoffv = nd.act_off[tid];
+  if constexpr (!RES) {
+    w2r.issue(W2, 0, HID, tid);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {   // act_W [64][L] -> [64][32], zero padded
-      const int e = tid + NT * i, j = e >> 5, k = e & 31;
-      hv[i] = (k < nd.L) ? a.params[lay.act_W + j * nd.L + k] : 0.f;
+    for (int i = 0; i < 4; ++i) b1v[i] = B1[4 * gl + i];
+    if (tid < HID) bias2 = B2[tid];
+    if (net == 0) {
+      if (tid <= nd.A) aoffv = nd.act_off[tid];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {   // act_W [64][L] -> [64][32], zero padded
+        const int e = tid + NT * i, j = e >> 5, k = e & 31;
+        hv[i] = (k < nd.L) ? a.params[lay.act_W + j * nd.L + k] : 0.f;
+      }
+      if (tid < 32) hb = (tid < nd.L) ? a.params[lay.act_b + tid] : 0.f;
+    } else {
+      hv[0] = (tid < HID) ? a.params[lay.val_W + tid] : 0.f;
+      if (tid == 0) hb = a.params[lay.val_b];
     }
-    if (tid < 32) hb = (tid < nd.L) ? a.params[lay.act_b + tid] : 0.f;
   } else {
-    hv[0] = (tid < HID) ? a.params[lay.val_W + tid] : 0.f;
-    if (tid == 0) hb = a.params[lay.val_b];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b1v[i] = res->b1s[4 * gl + i];
   }
   // commits, in issue order
 #pragma unroll
@@ -767,19 +802,21 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
     const int f = fr[u];
     w[u] = (f >= 0) ? *reinterpret_cast<const float4*>(w1l + (size_t)f * HID) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  w2r.commit(w2s, tid);
-  if (tid < HID) b2s[tid] = bias2;
-  if (net == 0) {
+  if constexpr (!RES) {
+    w2r.commit(w2s, tid);
+    if (tid < HID) b2s[tid] = bias2;
+    if (net == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int e = tid + NT * i;
-      wos[(e >> 5) * LDH + (e & 31)] = hv[i];
+      for (int i = 0; i < 8; ++i) {
+        const int e = tid + NT * i;
+        wos[(e >> 5) * LDH + (e & 31)] = hv[i];
+      }
+      if (tid < 32) hbs[tid] = hb;
+      if (tid <= nd.A) aoff[tid] = aoffv;
+    } else {
+      if (tid < HID) wos[tid] = hv[0];
+      if (tid == 0) hbs[0] = hb;
     }
-    if (tid < 32) hbs[tid] = hb;
-    if (tid <= nd.A) aoff[tid] = aoffv;
-  } else {
-    if (tid < HID) wos[tid] = hv[0];
-    if (tid == 0) hbs[0] = hb;
   }
   {
 #pragma unroll
@@ -812,7 +849,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   }
   lds_only_barrier();
   PH_STAMP(a.prof, 3);
-  if (net == 0 && tid < 32) {   // component of logit `tid` (read by the head after two more barriers)
+  if (!RES && net == 0 && tid < 32) {   // component of logit `tid` (read by the head after two more barriers)
     int lo = tid, last = tid, comp = -1;
     for (int cc = 0; cc < nd.A; ++cc) {
       const int l0 = aoff[cc], l1 = aoff[cc + 1];
@@ -828,15 +865,15 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   }
 
   // one 16x16 output tile per wave: D[row 4g+r][col col0 + c] = sum_k A[row][k] W[k][col]; two accumulator chains
-  auto layer = [&](const float* A, const float* W, int col0) -> f32x4 {
+  auto layer = [&](const float* A, const float* W, int col0, int ldb) -> f32x4 {
     f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
     const float* ap = A + c * LDH + g;
-    const float* bp = W + g * LDH + col0 + c;
+    const float* bp = W + g * ldb + col0 + c;
     float av[16], bv[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       av[s] = ap[4 * s];
-      bv[s] = bp[4 * s * LDH];
+      bv[s] = bp[4 * s * ldb];
     }
     // keep all 32 operand reads ahead of the products: left to itself the scheduler (in the 512-thread rollout kernel) emits
     // read - wait - MFMA sixteen times, one LDS latency per product
@@ -849,7 +886,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
     return e + o;
   };
   {
-    const f32x4 z2 = layer(hs, w2s, 16 * wave);
+    const f32x4 z2 = layer(hs, w2s, 16 * wave, LDH);
     const float b = b2s[16 * wave + c];
 #pragma unroll
     for (int r = 0; r < 4; ++r) xs[(4 * g + r) * LDH + 16 * wave + c] = fast_tanh(z2[r] + b);
@@ -860,7 +897,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   if (net == 0) {
     // ---- policy head: logits [16][32] as two 16x16 tiles (waves 0, 1), then one lane per row ----
     if (wave < 2) {
-      const f32x4 z3 = layer(xs, wos, 16 * wave);
+      const f32x4 z3 = layer(xs, wos, 16 * wave, LDW);
       const float b = hbs[16 * wave + c];
 #pragma unroll
       for (int r = 0; r < 4; ++r) outs[(4 * g + r) * LDO + 16 * wave + c] = z3[r] + b;
@@ -906,6 +943,31 @@ __global__ __launch_bounds__(256) void policy_fwd16h_kernel(FwdArgs a) {
 
 static size_t fwd16h_lds_bytes() {
   return sizeof(float) * (size_t)(2 * 16 * LDH + 2 * HID * LDH + 16 * 33 + HID + 32 + 16 * 64 + 40 + 96 + 2 * 16);
+}
+
+// one net (policy: net 0, value: net 1) of `params` into a resident set, by the 256 lanes of the half that runs that net -- the very
+// loads and LDS positions the per-launch forward stages (policy_fwd16h_body), with the head's weights at leading dimension RES_LDO
+__device__ __forceinline__ void stage_resident_net(const ResidentNet& rn, const float* params, const NetDims& nd, int net, int tid) {
+  constexpr int NT = 256;
+  const ph_layout& lay = nd.lay;
+  WStage<NT> w2r;
+  w2r.issue(params + (net == 0 ? lay.pi_W2 : lay.vf_W2), 0, HID, tid);
+  w2r.commit(rn.w2s, tid);
+  if (tid < HID) {
+    rn.b1s[tid] = params[(net == 0 ? lay.pi_b1 : lay.vf_b1) + tid];
+    rn.b2s[tid] = params[(net == 0 ? lay.pi_b2 : lay.vf_b2) + tid];
+  }
+  if (net == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {   // act_W [64][L] -> [64][32], zero padded
+      const int e = tid + NT * i, j = e >> 5, k = e & 31;
+      rn.wos[j * RES_LDO + k] = (k < nd.L) ? params[lay.act_W + j * nd.L + k] : 0.f;
+    }
+    if (tid < 32) rn.hbs[tid] = (tid < nd.L) ? params[lay.act_b + tid] : 0.f;
+  } else {
+    if (tid < HID) rn.wos[tid] = params[lay.val_W + tid];
+    if (tid == 0) rn.hbs[0] = params[lay.val_b];
+  }
 }
 
 // ---- persistent Liar's Dice self-play rollout ------------------------------------------------------------------------------------
@@ -963,7 +1025,9 @@ __device__ __forceinline__ T* rebase(T* mirror, int row0, int per) { return mirr
 __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, int half_floats, int rpw) {
   extern __shared__ __attribute__((aligned(16))) float smem_roll[];
   const int tid512 = threadIdx.x, half = tid512 >> 8, tid = tid512 & 255;
+  // per half (net): the forward's scratch, then the weights of that net for the ego and for the partner, resident for the launch
   float* sm = smem_roll + (size_t)half * half_floats;
+  const ResidentNet res_ego = resident_net_at(sm + RES_SCRATCH_FLOATS), res_alt = resident_net_at(sm + RES_SCRATCH_FLOATS + RES_NET_FLOATS);
   const int row0 = blockIdx.x * rpw;            // rpw <= 16 tables per workgroup (the forward's tile is 16 rows, the rest padding)
   const ph_liar_selfplay& g = r.s;              // the global arrays
   const int nrow = (g.n - row0 < rpw) ? g.n - row0 : rpw;
@@ -971,7 +1035,7 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
   // ---- mirror in ----
   LiarMirror m;
   {
-    int* ip = (int*)(smem_roll + 2 * (size_t)half_floats);     // 16-byte aligned: half_floats is a multiple of 4
+    int* ip = (int*)(smem_roll + 2 * (size_t)half_floats) + 80;   // 16-byte aligned: half_floats is a multiple of 4; 80 ints: the obs prefix sums
     m.hands = ip;
     m.history = m.hands + 16 * 12;
     m.nmoves = m.history + 16 * 24;
@@ -1039,6 +1103,36 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
   s.done = rebase(m.u8 + 11 * 16, row0, 1);
   __syncthreads();
 
+  // ---- what every forward of the launch reads and no step changes: both agents' weights of this half's net, the observation
+  //      and action prefix sums, the logit -> component table of the head (policy half) ----
+  int* const ooff = (int*)(smem_roll + 2 * (size_t)half_floats);     // [D + 1 <= 65]
+  {
+    const NetDims& nd = r.ego.nd;
+    stage_resident_net(res_ego, r.ego.params, nd, half, tid);
+    stage_resident_net(res_alt, r.reply.params, nd, half, tid);
+    if (tid512 <= nd.D) ooff[tid512] = nd.obs_off[tid512];
+    if (half == 0) {   // aoff / seg of the policy half's scratch (policy_fwd16h_body's layout)
+      int* aoff = (int*)(sm + 2 * 16 * LDH + 16 * 33) + 16 * 64;
+      int* seg = aoff + 40;
+      if (tid < 32) {
+        int lo = tid, last = tid, comp = -1;
+        for (int cc = 0; cc < nd.A; ++cc) {
+          const int l0 = nd.act_off[cc], l1 = nd.act_off[cc + 1];
+          if (tid >= l0 && tid < l1) {
+            lo = l0;
+            last = l1 - 1;
+            comp = cc;
+          }
+        }
+        seg[tid] = lo;
+        seg[32 + tid] = last;
+        seg[64 + tid] = comp;
+      }
+      if (tid <= nd.A) aoff[tid] = nd.act_off[tid];
+    }
+  }
+  __syncthreads();
+
   const int e = row0 + tid512;                  // the table lane tid512 < 16 keeps the books of
   const bool keeper = tid512 < nrow;
   // one inlined copy of the forward body: the three forwards of a step are a loop whose argument record is selected with
@@ -1093,7 +1187,13 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
         a.pos_env = s.alt_pos;
         a.rec_mask = s.can;
       }
-      policy_fwd16h_body<false, true>(a, row0, half, tid, sm, row0 + nrow);
+      ResidentNet rn;   // the acting agent's set, pointer by pointer (scalar selects)
+      rn.w2s = f == 0 ? res_ego.w2s : res_alt.w2s;
+      rn.wos = f == 0 ? res_ego.wos : res_alt.wos;
+      rn.b1s = f == 0 ? res_ego.b1s : res_alt.b1s;
+      rn.b2s = f == 0 ? res_ego.b2s : res_alt.b2s;
+      rn.hbs = f == 0 ? res_ego.hbs : res_alt.hbs;
+      policy_fwd16h_body<false, true, true>(a, row0, half, tid, sm, row0 + nrow, rn, ooff);
       __syncthreads();
     }
     PH_STAMP(prof, 9 + 2 * f);
@@ -1153,7 +1253,9 @@ hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, co
   r.alt_rewards = s.alt_rb->rewards;
   r.alt_T = s.alt_rb->T;
   r.ego_rew_row0 = ego_rew_row0;
-  const size_t half = (fwd16h_lds_bytes() + 15) & ~(size_t)15, lds = 2 * half + ((LIAR_MIRROR_BYTES + 15) & ~15);
+  if (reply.params != opening.params) return hipErrorInvalidValue;   // the partner's two forwards share one resident weight set
+  const size_t half = (sizeof(float) * (size_t)(RES_SCRATCH_FLOATS + 2 * RES_NET_FLOATS) + 15) & ~(size_t)15;
+  const size_t lds = 2 * half + 80 * sizeof(int) + ((LIAR_MIRROR_BYTES + 15) & ~15);
   static bool allowed[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
