@@ -15,8 +15,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ("pantheonrl_amd/csrc/ph_ppo_split.hip", "pantheonrl_amd/csrc/ph_head.h", "pantheonrl_amd/csrc/ph_device.h",
-                  "pantheonrl_amd/csrc/ph_launch.h:struct GradArgs")
+KERNEL_SOURCES = ("pantheonrl_amd/csrc/ph_ppo_split.hip", "pantheonrl_amd/csrc/ph_split_tile.h", "pantheonrl_amd/csrc/ph_split.h",
+                  "pantheonrl_amd/csrc/ph_head.h", "pantheonrl_amd/csrc/ph_device.h", "pantheonrl_amd/csrc/ph_launch.h:struct GradArgs")
 
 
 def kernel_source_sha256(root: str = ROOT) -> str:

@@ -135,3 +135,16 @@ def test_bench_fusedstep_on_one_gpu_runs_the_one_launch_exchange_rollout():
     d = _json_line(r.stdout)
     assert d["config"]["launch_mode"] == "fusedstep" and d["config"]["rollout"] == "persistent"
     assert d["config"]["exchange"]["route"] == "p2p" and d["config"]["exchange"]["p2p_timeouts"] == 0
+
+
+def test_bench_fusedstep_at_the_full_headline_size_takes_the_one_launch_form():
+    """The N > 1 layout at the HEADLINE size (two learners x 2 nets x 64 workgroups = 256 workgroups of the exchange rollout kernel,
+    exactly what one device keeps resident after the hold-back): the rank-agreed verdict must say "persistent" -- a shortfall would
+    silently drop every rank of a scaling run to one launch per step"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--mode", "fusedstep",
+                        "--no-roofline", "--no-cpu-baseline", "--headline-only"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["config"]["workload"].startswith("Overcooked") or "overcooked" in json.dumps(d["config"]).lower()
+    assert d["config"]["launch_mode"] == "fusedstep" and d["config"]["rollout"] == "persistent", d["config"]
+    assert d["config"]["exchange"]["p2p_timeouts"] == 0
