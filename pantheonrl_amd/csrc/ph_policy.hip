@@ -485,7 +485,12 @@ __global__ __launch_bounds__(256) void policy_fwd16_multi_kernel(FwdMulti m) {
 // policy workgroup of 16 environments stores each sampled action as one stamped 8-byte word into every rank's receive area and
 // the value workgroup of the NEXT step polls exactly the two words it consumes.  Policy workgroups never wait, so no cycle of
 // waits exists as long as every workgroup of the launch is resident (the launcher's caller checks the grid against the chip).
-__global__ __launch_bounds__(256) void policy_fwd16_exchange_rollout_kernel(FwdMulti m, ScriptedMulti sm) {
+// Three waves per SIMD (168 VGPRs; eight registers -- pointer pairs of the row tails -- live in scratch): the runtime then admits three
+// workgroups per CU, two after the hold-back (exchange_rollout_blocks_per_cu), i.e. 512 resident workgroups on the chip against the
+// 256 the default N > 1 layout needs -- at two waves per SIMD (192 VGPRs) the margin was zero, and any shortfall drops every rank to
+// one launch per step.  Same-box A/B of the two builds: 101.3 vs 102.0 M agent-steps/s in --mode fusedstep (within the spread);
+// two ranks sharing ONE device keep the one-launch form: 68.8 M against 42.2 M (profiles/r05_r_exchange_launch_bounds_ab.txt).
+__global__ __launch_bounds__(256, 3) void policy_fwd16_exchange_rollout_kernel(FwdMulti m, ScriptedMulti sm) {
   policy_fwd16_body<false>(m.a[blockIdx.z], m.px.x, 0, m.px.a_local, blockIdx.z, &sm.sc[blockIdx.z], 1);
 }
 
