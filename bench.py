@@ -730,6 +730,42 @@ def main():
                                       "steps": k2, "note": "one launch per environment step inside the iteration graphs "
                                       "(--rollout stepwise): what an environment that lives on the host or on another node forces; the N>1 layouts of this bench "
                                               "hand actions over in-kernel and launch a rollout once, like the default"}
+    if mode == "graph" and world == 1 and not args.headline_only:
+        # The same iteration when the boundary hands over HOST buffers (the owning-handle ABI's situation): every learner's rollout
+        # inputs -- observations, rewards, dones of the n_steps x n_envs transitions -- cross PCIe from pinned host memory before its
+        # graph runs, its sampled actions cross back after.  Never `value`: that is measured with the inputs resident in HBM.
+        try:
+            hosts = [(d.obs.cpu().pin_memory(), d.rewards.cpu().pin_memory(), d.dones.cpu().pin_memory()) for d in datas]
+            acts_host = [th.empty_like(a.model.rollout_buffer.actions, device="cpu").pin_memory() for a in agents]
+
+            def host_iteration():
+                for a, d, st, h in zip(agents, datas, streams, hosts):
+                    with th.cuda.stream(st):
+                        d.obs.copy_(h[0], non_blocking=True)
+                        d.rewards.copy_(h[1], non_blocking=True)
+                        d.dones.copy_(h[2], non_blocking=True)
+                iteration()
+                for a, st, ah in zip(agents, streams, acts_host):
+                    with th.cuda.stream(st):
+                        ah.copy_(a.model.rollout_buffer.actions, non_blocking=True)
+            for _ in range(2):
+                host_iteration()
+            barrier()
+            kh = max(1, min(args.steps, 10))
+            t1 = time.perf_counter()
+            for _ in range(kh):
+                host_iteration()
+            barrier()
+            dth = time.perf_counter() - t1
+            h2d = sum(sum(t.numel() * t.element_size() for t in h) for h in hosts)
+            d2h = sum(t.numel() * t.element_size() for t in acts_host)
+            result["host_buffers_pcie_inclusive"] = {
+                "value": steps_per_iter * kh / dth, "unit": "agent-steps/s", "ms_per_step": 1e3 * dth / kh, "steps": kh,
+                "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": d2h,
+                "note": "the timed iteration with every learner's rollout inputs copied from pinned host memory first and its actions "
+                        "copied back after (async copies on the learner's stream): the rate when the caller owns host arrays; not `value`"}
+        except Exception as exc:  # noqa: BLE001 -- an extra figure, never fatal
+            result["host_buffers_pcie_inclusive"] = {"error": str(exc)}
     if mode == "graph" and world == 1 and args.agents_per_gpu != 1 and args.rollout in ("scripted", "stepwise") and not args.headline_only:
         # north_star's literal layout -- ONE learner per GPU ("8 agents on 8 GPUs") -- on this GPU: the N = 1 base a scaling curve of
         # `--agents-per-gpu 1` runs is measured against.  Nothing overlaps the learner's reduce / Adam then, so each minibatch's

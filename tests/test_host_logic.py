@@ -607,3 +607,20 @@ def test_host_step_path_refuses_a_full_buffer_and_restages_on_a_new_shape():
     rb.buffer_size = 2
     with pytest.raises(nat.NativeError):
         pol.forward_and_store_host(np.zeros((1, 62)), rb, [False])
+
+
+def test_policies_with_another_parameter_layout_are_refused_on_the_fused_mlp_paths():
+    """AdapPolicyMult / ModularPolicy carry the plain MlpPolicy `spec` for their rollout buffer but a different parameter vector:
+    the entry points that hand `params` to the fused MLP kernels (VecOnPolicyAgent, PPO.train_joint, the exchange / round-robin
+    engines behind them) refuse them instead of training the wrong network silently (no GPU: the check runs before any native call)"""
+    import pytest
+
+    from pantheonrl_amd import _native as nat
+    from pantheonrl_amd.adap import AdapPolicyMult
+    from pantheonrl_amd.modular import ModularPolicy
+    from pantheonrl_amd.ppo import ActorCriticPolicy, require_mlp_kernels
+    assert ActorCriticPolicy.fused_mlp_kernels and not AdapPolicyMult.fused_mlp_kernels and not ModularPolicy.fused_mlp_kernels
+    require_mlp_kernels(type("P", (), {})(), "x")                       # a plain policy object passes
+    for cls in (AdapPolicyMult, ModularPolicy):
+        with pytest.raises(nat.NativeError, match="fused MLP kernels"):
+            require_mlp_kernels(cls.__new__(cls), "VecOnPolicyAgent")
