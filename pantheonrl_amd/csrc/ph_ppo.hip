@@ -818,6 +818,9 @@ void grad_plan(const NetDims& nd, int nb, int num_cu, int* ntiles, int* nwg) {
   // 64-row tiles; 2 nets x nwg workgroups, two resident per CU: nwg = #CUs covers the chip, more tiles are walked
   *ntiles = (nb + 63) / 64;
   *nwg = *ntiles < num_cu ? *ntiles : num_cu;
+  // the wide split kernel holds ONE workgroup per CU (its LDS): #CUs / 2 workgroups per net are all resident at once and walk more
+  // tiles each -- one prologue and one set of slabs per CU instead of two
+  if (nd.split == 2 && *nwg > num_cu / 2 && num_cu >= 2) *nwg = num_cu / 2;
 }
 
 hipError_t launch_ppo_grad(const GradArgs& a, int nwg, int gemm_mode, hipStream_t s) {

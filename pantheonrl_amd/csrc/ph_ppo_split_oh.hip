@@ -56,14 +56,40 @@ __host__ __device__ constexpr int oh_rs_net(int nch) { return oh_rs_hb(nch) + 16
 __device__ __forceinline__ int dzl_swz(int a) { return (a >> 2) & 3; }
 }  // namespace
 
-template <int NCH, int LB>
+// X fragment of one (block, half chunk): one plane for one-hot observations, three for Box observations
+template <bool BOX>
+struct XFrag {
+  bf16x8 p[BOX ? 3 : 1];
+};
+// acc[b] += X_b W for the four row (or feature) blocks b, the chains interleaved; small terms first
+template <bool BOX>
+__device__ __forceinline__ void xmma4(f32x4 (&acc)[4], const XFrag<BOX> (&x)[4], const Frag3& w) {
+  if constexpr (BOX) {
+    constexpr int TX[6] = {0, 2, 1, 0, 1, 0}, TW[6] = {2, 0, 1, 1, 0, 0};   // mma6's term order
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[b] = mfma16(x[b].p[TX[t]], w.p[TW[t]], acc[b]);
+  } else {
+#pragma unroll
+    for (int p = 2; p >= 0; --p)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[b] = mfma16(x[b].p[0], w.p[p], acc[b]);
+  }
+}
+
+// BOX: the same kernel for Box observations of 1 .. 4 feature chunks that the single-chunk / small-head kernels do not take (the
+// reference's Overcooked + ADAP pairing: 62 + 3 = 65 features; MultiDiscrete heads): X is three planes per chunk, split here from
+// the float32 rows (once per tile; no plane image), and its two products are six terms like every other.
+template <int NCH, int LB, bool BOX>
 __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
   const int stop_now = __builtin_nontemporal_load(a.stop_flag);
   PH_STAMP(a.prof, 0);
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   char* smem = reinterpret_cast<char*>(smem_f);
   constexpr int R = 64;
-  constexpr int XOH = 0, H1T = NCH * PL_BYTES, H2B = H1T + PB_BYTES, DZL = H2B + PB_BYTES, SC = DZL + 3 * DZL_PLANE;
+  constexpr int XPL = BOX ? 3 : 1, XCH = XPL * PL_BYTES;   // planes and bytes of one chunk of X
+  constexpr int XOH = 0, H1T = NCH * XCH, H2B = H1T + PB_BYTES, DZL = H2B + PB_BYTES, SC = DZL + 3 * DZL_PLANE;
   float* b1s = reinterpret_cast<float*>(smem + SC);   // [64]
   float* b2s = b1s + HID;                             // [64]
   float* hbs = b2s + HID;                             // [32] head bias (policy: act_b, zero beyond L | value: val_b)
@@ -97,35 +123,38 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
 
   // ---- a tile's rows: lane (row = tid / 4, q = tid % 4) gathers the row's scalars and components q, q + 4, .. of its observation ----
   constexpr int MAXC = 16;                              // components per lane: D <= 64
+  // what the gather LOADS, untouched: nothing here waits for a load, so a gather issued under another phase's products (the next
+  // tile's, at the start of S7) costs that phase nothing; the arithmetic on the values happens at the commit
   struct RowGather {
     int phys;
-    int hot[MAXC];      // feature index of component q + 4 i, or -1
+    float x[MAXC];      // component q + 4 i of the observation (one-hot observations), as stored
+    int lo[MAXC], n[MAXC];   // its first feature and its number of categories (n = 0: no such component)
     float s0, s1;       // q == 0: advantage | return, old log-prob | old value
-    int act0, act1;     // q == 1: action components 0, 1;  q == 2: components 2, 3
+    float act0, act1;   // q == 1: action components 0, 1;  q == 2: components 2, 3 (as stored)
   };
-  auto gather_rows = [&](int tile) -> RowGather {
-    const int tid = threadIdx.x, row = tid >> 2, q = tid & 3;
-    const int gi = tile * R + row;
+  auto load_phys = [&](int tile) -> int {   // the row's place in the rollout buffer (first of the gather's two dependent trips)
+    const int gi = tile * R + ((int)threadIdx.x >> 2);
+    return gi < a.nb ? (a.idx_phys ? a.idx_phys[gi] : minibatch_row(a, gi)) : -1;
+  };
+  auto gather_rows = [&](int phys) -> RowGather {
+    const int tid = threadIdx.x, q = tid & 3;
     RowGather g;
-    g.phys = -1;
-    g.s0 = g.s1 = 0.f;
-    g.act0 = g.act1 = 0;
+    g.phys = phys;
+    g.s0 = g.s1 = g.act0 = g.act1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) g.hot[i] = -1;
-    if (gi < a.nb) g.phys = a.idx_phys ? a.idx_phys[gi] : minibatch_row(a, gi);
+    for (int i = 0; i < MAXC; ++i) {
+      g.x[i] = 0.f;
+      g.lo[i] = g.n[i] = 0;
+    }
     if (g.phys >= 0) {
       const size_t ph_row = (size_t)g.phys;
-      int lo[MAXC], n[MAXC];
-      float x[MAXC];
 #pragma unroll
       for (int i = 0; i < MAXC; ++i) {
         const int comp = q + 4 * i;
-        lo[i] = n[i] = 0;
-        x[i] = 0.f;
-        if (comp < nd.D) {
-          lo[i] = nd.obs_off[comp];
-          n[i] = nd.obs_off[comp + 1] - lo[i];
-          x[i] = a.rb_obs[ph_row * nd.D + comp];
+        if (!BOX && comp < nd.D) {
+          g.lo[i] = nd.obs_off[comp];
+          g.n[i] = nd.obs_off[comp + 1] - g.lo[i];
+          g.x[i] = a.rb_obs[ph_row * nd.D + comp];
         }
       }
       if (q == 0) {
@@ -133,41 +162,65 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
         g.s1 = net == 0 ? a.rb_logp[ph_row] : a.rb_val[ph_row];
       } else if (net == 0 && q <= 2) {
         const int c0 = 2 * (q - 1);
-        if (c0 < nd.A) g.act0 = (int)a.rb_act[ph_row * nd.A + c0];
-        if (c0 + 1 < nd.A) g.act1 = (int)a.rb_act[ph_row * nd.A + c0 + 1];
-      }
-#pragma unroll
-      for (int i = 0; i < MAXC; ++i) {
-        if (q + 4 * i < nd.D) {
-          int v = (int)x[i];
-          v = v < 0 ? 0 : (v >= n[i] ? n[i] - 1 : v);
-          g.hot[i] = lo[i] + v;
-        }
+        if (c0 < nd.A) g.act0 = a.rb_act[ph_row * nd.A + c0];
+        if (c0 + 1 < nd.A) g.act1 = a.rb_act[ph_row * nd.A + c0 + 1];
       }
     }
     return g;
   };
+  // BOX: the row's float32 features instead of hot positions -- lane q takes granules q and q + 4 (eight features each) of every chunk
+  struct BoxRow {
+    float x[BOX ? NCH : 1][2][8];
+  };
+  auto gather_box = [&](int phys) -> BoxRow {
+    BoxRow bx;
+    const int q = threadIdx.x & 3;
+#pragma unroll
+    for (int ch = 0; ch < (BOX ? NCH : 1); ++ch)
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int f = 64 * ch + 8 * (q + 4 * gi) + e;
+          bx.x[ch][gi][e] = (BOX && phys >= 0 && f < nd.F) ? a.rb_obs[(size_t)phys * nd.D + f] : 0.f;
+        }
+    return bx;
+  };
   // X of the tile in LDS: the row's four lanes zero its NCH plane rows, then set the hot features (same wave: in order)
   auto zero_rows = [&]() {   // independent of the gather: issued while its loads travel
+    if constexpr (BOX) return;   // (every granule of a Box row is written by the commit)
     const int tid = threadIdx.x, row = tid >> 2, q = tid & 3;
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      uint4* xrow = reinterpret_cast<uint4*>(smem + XOH + ch * PL_BYTES + row * PL_ROW);
+      uint4* xrow = reinterpret_cast<uint4*>(smem + XOH + ch * XCH + row * PL_ROW);
       xrow[q] = zero;
       xrow[q + 4] = zero;
     }
   };
-  auto commit_rows = [&](const RowGather& g) {
+  auto commit_rows = [&](const RowGather& g, const BoxRow& bx) {
     const int tid = threadIdx.x, row = tid >> 2, q = tid & 3;
     wave_lds_sync();
     const int sw = pl_swz(row);
+    if constexpr (BOX) {   // split the row's features into their three planes: one 16-byte store per plane and granule
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int f = g.hot[i];
-      if (f >= 0) {
-        const int ch = f >> 6, k = f & 63;
-        *reinterpret_cast<unsigned short*>(smem + XOH + ch * PL_BYTES + row * PL_ROW + ((((k >> 3) ^ sw)) << 4) + 2 * (k & 7)) = 0x3F80;   // bf16 1.0
+      for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+          Frag3 f3;
+          split8(bx.x[ch][gi], f3);
+          st_planes8(smem, XOH + ch * XCH + row * PL_ROW + ((((q + 4 * gi) ^ sw)) << 4), f3);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        if (g.n[i] > 0) {   // a live row's component: its category, clamped, is the hot feature
+          int v = (int)g.x[i];
+          v = v < 0 ? 0 : (v >= g.n[i] ? g.n[i] - 1 : v);
+          const int f = g.lo[i] + v;
+          const int ch = f >> 6, k = f & 63;
+          *reinterpret_cast<unsigned short*>(smem + XOH + ch * XCH + row * PL_ROW + ((((k >> 3) ^ sw)) << 4) + 2 * (k & 7)) = 0x3F80;   // bf16 1.0
+        }
       }
     }
     if (q == 0) {
@@ -175,8 +228,8 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
       radv[row] = (norm && g.phys >= 0) ? (g.s0 - adv_mean) / adv_den : g.s0;
       rold[row] = g.s1;
     } else if (q <= 2) {
-      ract[row * 4 + 2 * (q - 1)] = g.act0;
-      ract[row * 4 + 2 * (q - 1) + 1] = g.act1;
+      ract[row * 4 + 2 * (q - 1)] = (int)g.act0;
+      ract[row * 4 + 2 * (q - 1) + 1] = (int)g.act1;
     }
   };
 
@@ -209,7 +262,8 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
   PH_STAMP(a.prof, 8);
   if (stop_now) return;
   zero_rows();
-  RowGather rg = gather_rows(blockIdx.x);
+  RowGather rg = gather_rows(load_phys(blockIdx.x));
+  BoxRow bxr = gather_box(rg.phys);
   PH_STAMP(a.prof, 9);
   {
     const int tid = threadIdx.x;
@@ -247,11 +301,10 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
       for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
         for (int c = 0; c < 2; ++c) W1f[ch][c] = ld_frag(oh_frag_w1(NCH, wave, ch, c));
-      zero_rows();
-      rg = gather_rows(tile);
+      zero_rows();   // (the tile's rows were gathered under the previous tile's last phase)
     }
     if (first) PH_STAMP(a.prof, 10);
-    commit_rows(rg);
+    commit_rows(rg, bxr);
     if (first) PH_STAMP(a.prof, 11);
     lds_barrier();
     if (first) PH_STAMP(a.prof, 1);
@@ -281,27 +334,28 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
       f32x4 acc[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      bf16x8 xa[4], xb[4];
+      // a block's X fragment: rows 16 b + i, features 32 c + 8 kg .. of chunk ch (one plane, or three)
+      auto x_plain = [&](int ch, int c, int b) -> XFrag<BOX> {
+        XFrag<BOX> f;
+#pragma unroll
+        for (int p = 0; p < XPL; ++p) f.p[p] = ld_plain1(smem, c == 0 ? pb0 : pb1, XOH + ch * XCH + p * PL_BYTES + b * 16 * PL_ROW);
+        return f;
+      };
+      XFrag<BOX> xa[4], xb[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        xa[b] = ld_plain1(smem, pb0, XOH + b * 16 * PL_ROW);
-        xb[b] = ld_plain1(smem, pb1, XOH + b * 16 * PL_ROW);
+        xa[b] = x_plain(0, 0, b);
+        xb[b] = x_plain(0, 1, b);
       }
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
-#pragma unroll
-        for (int p = 2; p >= 0; --p)   // four independent accumulator chains, interleaved
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[b] = mfma16(xa[b], W1f[ch][0].p[p], acc[b]);
-#pragma unroll
-        for (int p = 2; p >= 0; --p)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[b] = mfma16(xb[b], W1f[ch][1].p[p], acc[b]);
+        xmma4<BOX>(acc, xa, W1f[ch][0]);   // four independent accumulator chains, interleaved
+        xmma4<BOX>(acc, xb, W1f[ch][1]);
         if (ch + 1 < NCH) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
-            xa[b] = ld_plain1(smem, pb0, XOH + (ch + 1) * PL_BYTES + b * 16 * PL_ROW);
-            xb[b] = ld_plain1(smem, pb1, XOH + (ch + 1) * PL_BYTES + b * 16 * PL_ROW);
+            xa[b] = x_plain(ch + 1, 0, b);
+            xb[b] = x_plain(ch + 1, 1, b);
           }
         }
       }
@@ -325,6 +379,11 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
     lds_barrier();
     if (first) PH_STAMP(a.prof, 2);
 
+    // the next tile's rows: their places in the buffer are requested here, the rows themselves at the start of S7 (under its
+    // products), and they are committed at the next tile's T0 -- a workgroup that walks several tiles pays the gather's two
+    // dependent round trips once
+    int phys_next = -1;
+    if (has_next) phys_next = load_phys(tile + (int)gridDim.x);
     // ---- S2: H2 = tanh(H1 W2 + b2) -> H2 planes [row][unit] (roles swapped: result lane = row, registers = units) ----
     // (every fragment set is requested one phase ahead of its product: the image sits in L2, a microsecond away)
     Frag3 HZf[OH_LBMAX][2];
@@ -592,6 +651,10 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
     wave_lds_sync();
 
     // ---- S7: dW1 = X^T dZ1 chunk by chunk, block by block, straight to the slab; d b1 ----
+    if (has_next) {
+      rg = gather_rows(phys_next);
+      bxr = gather_box(phys_next);
+    }
     {
       const Frag3 dz0 = ld_plain(smem, pb0, H1T + wave * 16 * PL_ROW);   // B: DZ1T row (unit) 16 w + j, rows 8 kg .. / 32 + 8 kg ..
       const Frag3 dz1 = ld_plain(smem, pb1, H1T + wave * 16 * PL_ROW);
@@ -599,11 +662,19 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
       gB1 = mma_ones(dz1, gB1);
       // chunk by chunk: the four blocks' operands are read together (and the next chunk's before this chunk's stores), the four
       // accumulator chains run interleaved, then the four 16-byte stores leave
-      bf16x8 xa[4], xb[4];
+      // A: features 64 ch + 16 b + i (lane), tile rows 32 c + 8 kg .. (contraction): transposing reads of X's plane(s)
+      auto x_tr = [&](int ch, int c, int b) -> XFrag<BOX> {
+        XFrag<BOX> f;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {   // A: features 64 ch + 16 b + i (lane), tile rows 8 kg .. (contraction): transposing reads of the one-hot plane
-        xa[b] = ld_tr1(smem, trb[b], trb[b ^ 1], XOH, XOH + 4 * PL_ROW);
-        xb[b] = ld_tr1(smem, trb[b], trb[b ^ 1], XOH + 32 * PL_ROW, XOH + 36 * PL_ROW);
+        for (int p = 0; p < XPL; ++p)
+          f.p[p] = ld_tr1(smem, trb[b], trb[b ^ 1], XOH + ch * XCH + p * PL_BYTES + 32 * c * PL_ROW, XOH + ch * XCH + p * PL_BYTES + (32 * c + 4) * PL_ROW);
+        return f;
+      };
+      XFrag<BOX> xa[4], xb[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        xa[b] = x_tr(0, 0, b);
+        xb[b] = x_tr(0, 1, b);
       }
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
@@ -618,19 +689,13 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
         // the slab stores are what bounds this phase (27 MB per launch at NCH = 5).  Their products still run: a branch around
         // them splits the basic block and with it the interleaving of the four chains (measured: + 1.4 k cycles).
         const int nb_live = (ch + 1 < NCH) ? 4 : (f_last + 15) >> 4;
-#pragma unroll
-        for (int p = 2; p >= 0; --p)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) g[b] = mfma16(xa[b], dz0.p[p], g[b]);
-#pragma unroll
-        for (int p = 2; p >= 0; --p)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) g[b] = mfma16(xb[b], dz1.p[p], g[b]);
+        xmma4<BOX>(g, xa, dz0);
+        xmma4<BOX>(g, xb, dz1);
         if (ch + 1 < NCH) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
-            xa[b] = ld_tr1(smem, trb[b], trb[b ^ 1], XOH + (ch + 1) * PL_BYTES, XOH + (ch + 1) * PL_BYTES + 4 * PL_ROW);
-            xb[b] = ld_tr1(smem, trb[b], trb[b ^ 1], XOH + (ch + 1) * PL_BYTES + 32 * PL_ROW, XOH + (ch + 1) * PL_BYTES + 36 * PL_ROW);
+            xa[b] = x_tr(ch + 1, 0, b);
+            xb[b] = x_tr(ch + 1, 1, b);
           }
         }
 #pragma unroll
@@ -680,11 +745,12 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
-static size_t grad_split_oh_lds_bytes(int nch) {
-  return (size_t)nch * PL_BYTES + 2 * PB_BYTES + 3 * DZL_PLANE + sizeof(float) * (HID + HID + 32 + 64 + 64 + 4 * 64 + 64);
+static size_t grad_split_oh_lds_bytes(int nch, bool box) {
+  return (size_t)nch * (box ? 3 : 1) * PL_BYTES + 2 * PB_BYTES + 3 * DZL_PLANE + sizeof(float) * (HID + HID + 32 + 64 + 64 + 4 * 64 + 64);
 }
 
-// one-hot observations of up to five feature chunks and D <= 64 components, up to four action components and 32 logits
+// one-hot observations of up to five feature chunks and D <= 64 components, or Box observations of up to four chunks that the
+// single-chunk / small-head kernels do not take; up to four action components and 32 logits
 // (PH_GRAD_SPLIT_OH=0 switches the kernel off: the exact-f32 general kernel then takes the shape)
 bool grad_split_oh_eligible(const NetDims& nd) {
   static int enabled = -1;
@@ -692,30 +758,37 @@ bool grad_split_oh_eligible(const NetDims& nd) {
     const char* e = getenv("PH_GRAD_SPLIT_OH");
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
-  return enabled && nd.obs_kind != PH_SPACE_BOX && nd.nchunk >= 1 && nd.nchunk <= 5 && nd.D <= 64 && nd.A >= 1 && nd.A <= 4 &&
-         nd.L <= 16 * OH_LBMAX && !grad_fast_eligible(nd);
+  if (!enabled || nd.A < 1 || nd.A > 4 || nd.L > 16 * OH_LBMAX || nd.nchunk < 1 || grad_fast_eligible(nd)) return false;
+  if (nd.obs_kind == PH_SPACE_BOX) return nd.nchunk <= 4;
+  return nd.nchunk <= 5 && nd.D <= 64;
 }
 int grad_split_oh_slab_len(const NetDims& nd) { return 2 * oh_rs_net(nd.nchunk); }
 int grad_split_oh_wimage_elems(const NetDims& nd) { return 2 * oh_nfrag(nd.nchunk) * 3 * WIMG_PLANE; }
 
-template <int NCH, int LB>
+template <int NCH, int LB, bool BOX>
 static hipError_t launch_split_oh_inst(const GradArgs& a, int nwg, hipStream_t s) {
-  const size_t lds = grad_split_oh_lds_bytes(NCH);
+  const size_t lds = grad_split_oh_lds_bytes(NCH, BOX);
   static bool allowed_dev[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   bool& allowed = allowed_dev[(dev >= 0 && dev < 64) ? dev : 0];
   if (!allowed) {
-    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_split_oh_kernel<NCH, LB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_split_oh_kernel<NCH, LB, BOX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     allowed = true;
   }
-  hipLaunchKernelGGL((ppo_grad_split_oh_kernel<NCH, LB>), dim3(nwg, 2), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((ppo_grad_split_oh_kernel<NCH, LB, BOX>), dim3(nwg, 2), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 template <int NCH>
 static hipError_t launch_split_oh_nch(const GradArgs& a, int nwg, hipStream_t s) {
-  return a.nd.L <= 16 ? launch_split_oh_inst<NCH, 1>(a, nwg, s) : launch_split_oh_inst<NCH, 2>(a, nwg, s);
+  const bool box = a.nd.obs_kind == PH_SPACE_BOX;
+  if constexpr (NCH <= 4) {
+    if (box) return a.nd.L <= 16 ? launch_split_oh_inst<NCH, 1, true>(a, nwg, s) : launch_split_oh_inst<NCH, 2, true>(a, nwg, s);
+  } else {
+    if (box) return hipErrorInvalidValue;
+  }
+  return a.nd.L <= 16 ? launch_split_oh_inst<NCH, 1, false>(a, nwg, s) : launch_split_oh_inst<NCH, 2, false>(a, nwg, s);
 }
 hipError_t launch_ppo_grad_split_oh(const GradArgs& a, int nwg, hipStream_t s) {
   switch (a.nd.nchunk) {

@@ -32,6 +32,9 @@ CONFIGS = {
     "box1": (SpaceSpec("box", dim=1), SpaceSpec("discrete", nvec=(2,))),
     "box64": (SpaceSpec("box", dim=64), SpaceSpec("discrete", nvec=(8,))),
     "box63": (SpaceSpec("box", dim=63), SpaceSpec("discrete", nvec=(2,))),
+    # Box observations of three and four feature chunks with heads inside the wide split kernel's class (<= 32 logits)
+    "box130": (SpaceSpec("box", dim=130), SpaceSpec("multidiscrete", nvec=(5, 16, 11))),
+    "box200": (SpaceSpec("box", dim=200), SpaceSpec("discrete", nvec=(20,))),
 }
 
 

@@ -390,13 +390,15 @@ def test_split_bf16_gradient_matches_autograd(name, T, E, nb):
 
 @pytest.mark.parametrize("name,T,E,nb", [("liar", 16, 6, 77), ("liar", 16, 8, 128), ("liar", 8, 8, 1), ("onehot32", 16, 8, 90),
                                           ("discrete20", 16, 8, 64), ("onehot128", 16, 8, 128), ("onehot17", 16, 6, 77),
-                                          ("liar", 64, 8, 321)])
+                                          ("liar", 64, 8, 321), ("adap_oc", 16, 8, 100), ("adap_multi", 16, 6, 70),
+                                          ("box130", 16, 8, 128), ("box200", 8, 8, 37), ("adap_oc", 64, 8, 321)])
 def test_split_bf16_one_hot_gradient_matches_autograd(name, T, E, nb):
     """gemm_mode 2 on one-hot observations (ppo_grad_split_oh_kernel: single-plane X, weight fragments from the image, the head as
     MFMA tiles): Liar's Dice (F = 270 in five chunks, components 7 + 12), three components filling all 32 logit slots, a 20-way
     Discrete head (two 16-logit blocks), two feature chunks, a 17-way component across the block boundary; partial tiles, a
     single row, workgroups with a second tile -- against autograd at the exact-f32 kernels' tolerance, and against the exact-f32
-    general kernel at float32 rounding level"""
+    general kernel at float32 rounding level.  The same kernel in its Box form (three-plane X split per tile): the reference's
+    Overcooked + ADAP row (65 features: two chunks), a 24-feature row with a three-component head, three and four chunks."""
     rng = np.random.default_rng(nb)
     idx = rng.permutation(T * E)[:nb]
     # (non-default hyper-parameters -- value clipping, entropy and value coefficients, raw advantages -- on every second case)
@@ -1661,7 +1663,7 @@ def test_peer_to_peer_exchange_between_processes(world):
 @pytest.mark.parametrize("name,T,E,nb,gemm_mode", [("overcooked", 128, 1024, 32768, 0), ("overcooked", 128, 1024, 32768, 2),
                                                     ("liar", 128, 256, 8192, 0), ("adap_oc", 128, 256, 32768, 0),
                                                     ("liar", 128, 256, 32768, 0), ("liar", 128, 256, 8192, 2),
-                                                    ("liar", 128, 256, 32768, 2)])
+                                                    ("liar", 128, 256, 32768, 2), ("adap_oc", 128, 256, 32768, 2)])
 def test_full_size_minibatch_gradient_matches_autograd(name, T, E, nb, gemm_mode):
     """One whole minibatch of BASELINE configs 3 and 2 at their real sizes (32 768 rows of Overcooked-simple; 8 192 rows of
     Liar's Dice with F = 270 one-hot features and two action components) against autograd on the oracle.  A sum over nb
