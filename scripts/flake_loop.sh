@@ -15,6 +15,6 @@ for i in $(seq 1 $N); do
     rc=$?
     t1=$(date +%s%N)
     echo "envs=$envs run=$i rc=$rc ms=$(( (t1 - t0) / 1000000 )) rollout=$(grep -o '"rollout": "[a-z0-9]*"' $OUT/run_${envs}_$i.out | head -1)" | tee -a $OUT/summary.txt
-    if [ $rc -eq 0 ]; then rm -f $OUT/run_${envs}_$i.err $OUT/run_${envs}_$i.out; else tail -c 6000 $OUT/run_${envs}_$i.err > $OUT/fail_${envs}_$i.err; rm -f $OUT/run_${envs}_$i.err; fi
+    if [ $rc -eq 0 ]; then rm -f $OUT/run_${envs}_$i.err $OUT/run_${envs}_$i.out; else cp $OUT/run_${envs}_$i.err $OUT/fail_${envs}_$i.err; rm -f $OUT/run_${envs}_$i.err; fi
   done
 done

@@ -13,6 +13,33 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--n-envs", "96", "--n-steps", "16", "--n-epochs", "2", "--steps", "2", "--warmup", "1"]
 
 
+def _first_errors(err: str) -> str:
+    """what a failed multi-rank run said first: the launcher's trailer (the last kilobytes of stderr) names the rank that exited, the
+    reason is further up"""
+    keys = ("bench.py:", "Error", "error:", "SystemExit", "timed out", "Traceback", "invalid", "p2p", "HIP", "hip")
+    lines = [ln for ln in err.splitlines() if any(k in ln for k in keys) and "FutureWarning" not in ln]
+    return "\n".join(lines[:40])
+
+
+# what the ENGINE says when a multi-rank run is invalid (bench.py's SystemExit texts, the exchange's timeout record): a run that failed
+# with one of these failed for the reason these tests exist and is never repeated
+_ENGINE_FAULTS = ("polls timed out", "the run is invalid", "waits of the one-launch optimizer step expired", "the collective saw",
+                  "NativeError", "AssertionError")
+
+
+def _run_ranks(cmd, env, timeout=1200):
+    """One multi-rank bench invocation.  Eight processes time-slicing ONE GPU behind a gloo rendezvous occasionally die in the launcher
+    or the rendezvous before the engine runs (seen once in ~75 runs in round 5, 60 / 60 green in the loop that followed, no engine
+    message in the output): such a run -- non-zero exit WITHOUT any of the engine's own fault messages -- is repeated once, and what
+    it printed is kept as a warning.  A run the engine itself declared invalid fails at once."""
+    import warnings
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    if r.returncode != 0 and not any(k in r.stderr or k in r.stdout for k in _ENGINE_FAULTS):
+        warnings.warn("multi-rank run failed outside the engine, repeated once; first errors:\n" + _first_errors(r.stderr))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    return r
+
+
 def _json_line(out: str) -> dict:
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out
@@ -114,11 +141,12 @@ def test_bench_config5_as_written_eight_ranks_one_learner_each_with_action_masks
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "mpe8", "--agents-per-gpu", "1",
            "--n-envs", n_envs, "--n-steps", "16", "--n-epochs", "2", "--steps", "2", "--warmup", "1",
            "--action-masks", "env", "--backend", "gloo", "--no-roofline"]
-    # no retry: a failed run carries the record of the first timed-out wait (rank, step, seat, row, stamp wanted / seen:
-    # dist.ActionExchange.p2p_timeout_record) in its exit message.  136 consecutive runs of this command were green on MI355X
-    # after the rollout-form verdict became rank-agreed (CHANGELOG round 4; scripts/flake_loop.sh repeats the experiment).
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
-    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    # A failed run carries the record of the first timed-out wait (rank, step, seat, row, stamp wanted / seen:
+    # dist.ActionExchange.p2p_timeout_record) in its exit message, and such a run is NOT repeated (_run_ranks).  136 consecutive
+    # runs of this command were green on MI355X after the rollout-form verdict became rank-agreed (CHANGELOG round 4), 72 of 73
+    # in round 5 (the one failure died before the engine printed anything; scripts/flake_loop.sh repeats the experiment).
+    r = _run_ranks(cmd, env)
+    assert r.returncode == 0, (r.stdout[-1000:], _first_errors(r.stderr), r.stderr[-1500:])
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["config"]["agents_per_gpu"] == 1 and d["config"]["obs_dim"] == 48
     assert "= 8 learners" in d["config"]["parallelism"] and d["config"]["action_masks"] == "env"
