@@ -236,9 +236,17 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
   // ---- prologue ----
   // W1's fragments of every chunk (this wave's 16 columns: NCH x 2 x 3 sixteen-byte loads per lane, L2-resident image) go out
   // first -- they depend on nothing, and behind the row gather's two dependent round trips they were a third one in front of S1
-  Frag3 W1f[NCH][2];
+  // Chunks of W1 fragments in flight: a ring of two, refilled inside S1 (chunk ch + 2 requested when chunk ch's products are
+  // issued).  All NCH up front is as fast alone (20.3 vs 20.0 us) but takes the kernel from 427 to 499 VGPRs -- and at 427 a wave of
+  // the OTHER learner's reduce / Adam kernels (64 VGPRs) still fits on every SIMD beside this kernel's one wave, so the two
+  // learners' updates overlap: 4.2 -> 4.0 ms per Liar's Dice iteration (profiles/r05_z_liar_grad_w1_slots_ab.txt).
+#ifndef PH_OH_W1_SLOTS
+#define PH_OH_W1_SLOTS 2
+#endif
+  constexpr int W1S = NCH < PH_OH_W1_SLOTS ? NCH : PH_OH_W1_SLOTS;
+  Frag3 W1f[W1S][2];
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch)
+  for (int ch = 0; ch < W1S; ++ch)
 #pragma unroll
     for (int c = 0; c < 2; ++c) W1f[ch][c] = ld_frag(oh_frag_w1(NCH, threadIdx.x >> 6, ch, c));
   // ... then everything else that depends on nothing (biases, the action components' logit ranges), then the row gather; the
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
     // ---- T0: rows -> X (one-hot plane), scalars ----
     if (!first) {
 #pragma unroll
-      for (int ch = 0; ch < NCH; ++ch)
+      for (int ch = 0; ch < W1S; ++ch)
 #pragma unroll
         for (int c = 0; c < 2; ++c) W1f[ch][c] = ld_frag(oh_frag_w1(NCH, wave, ch, c));
       zero_rows();   // (the tile's rows were gathered under the previous tile's last phase)
@@ -349,8 +357,12 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
       }
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
-        xmma4<BOX>(acc, xa, W1f[ch][0]);   // four independent accumulator chains, interleaved
-        xmma4<BOX>(acc, xb, W1f[ch][1]);
+        xmma4<BOX>(acc, xa, W1f[ch % W1S][0]);   // four independent accumulator chains, interleaved
+        xmma4<BOX>(acc, xb, W1f[ch % W1S][1]);
+        if (ch + W1S < NCH) {   // this slot of the ring is free: chunk ch + W1S's fragments
+#pragma unroll
+          for (int c = 0; c < 2; ++c) W1f[ch % W1S][c] = ld_frag(oh_frag_w1(NCH, wave, ch + W1S, c));
+        }
         if (ch + 1 < NCH) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) {

@@ -65,6 +65,24 @@ def test_split_gradient_kernel_has_no_scratch_and_leaves_room_for_the_update_ker
         assert 2 * grad_lds + other["LDS Size"] <= 160 * 1024, (grad_lds, other)
 
 
+def test_one_hot_gradient_kernel_leaves_a_wave_of_the_update_kernels_on_every_simd(ppo, tmp_path_factory):
+    """ppo_grad_split_oh_kernel holds ONE workgroup per CU (its LDS), i.e. one wave per SIMD: the other learner's reduce / Adam
+    launches overlap its gradient launch only while one of THEIR waves still fits into the SIMD's 512 registers beside it -- all five
+    chunks of W1 fragments in flight took Liar's Dice's instantiation to 499 registers and the iteration from 4.0 to 4.2 ms
+    (profiles/r05_z_liar_grad_w1_slots_ab.txt).  No scratch in any one-hot instantiation."""
+    oh = _usage("ph_ppo_split_oh.hip", tmp_path_factory)
+    inst = {n: k for n, k in oh.items() if "ppo_grad_split_oh_kernel" in n}
+    assert len(inst) == 18, sorted(inst)                      # NCH = 1..5 x LB = 1, 2 one-hot, NCH = 1..4 x LB Box
+    reduce_k = ppo["_ZN2ph17ppo_reduce_kernelILi2EEEvNS_10ReduceArgsE"]
+    adam_k = ppo["_ZN2ph15ppo_adam_kernelENS_8AdamArgsE"]
+    for n, k in inst.items():
+        assert k["ScratchSize"] == 0, (n, k)
+        if n.endswith("Lb0EEEvNS_8GradArgsE"):               # the one-hot form (config 2's is <5, 2, false>)
+            assert k["VGPRs Spill"] == 0, (n, k)
+            for other in (reduce_k, adam_k):
+                assert _alloc(k) + _alloc(other) <= 512, (n, k, other)
+
+
 def test_general_and_fast_gradient_kernels_have_no_scratch(ppo, tmp_path_factory):
     fast = _usage("ph_ppo_fast.hip", tmp_path_factory)
     for n, k in list(fast.items()) + [(n, k) for n, k in ppo.items() if "ppo_grad_kernel" in n]:
