@@ -122,5 +122,11 @@ def test_rollout_kernels_have_no_scratch(tmp_path_factory):
         hit = {n: k for n, k in pol.items() if w in n}
         assert hit, (w, sorted(pol))
         for n, k in hit.items():
+            if "exchange_rollout" in w:
+                # built for THREE waves per SIMD since round 5 (168 registers: 512 resident workgroups on the chip instead of 256, the
+                # N > 1 layout's residency margin): eight registers -- pointer pairs the row tails reload -- live in scratch, measured
+                # at no cost (same-box A/B, profiles/r05_r_exchange_launch_bounds_ab.txt).  More than that would be a regression.
+                assert _alloc(k) <= 168 and k["VGPRs Spill"] <= 8 and k["ScratchSize"] <= 64, (n, k)
+                continue
             assert k["ScratchSize"] == 0 and k["VGPRs Spill"] == 0, (n, k)
 
