@@ -31,6 +31,9 @@ __device__ __forceinline__ void liar_load(LiarTable& t, int e, const int* hands,
   t.nm = nmoves[e];
 }
 __device__ __forceinline__ void liar_store_history(const LiarTable& t, int e, int* history, int* nmoves) {
+#if defined(PH_LX_NO_HIST)
+  return;
+#endif
   int4* qp = reinterpret_cast<int4*>(history + (size_t)e * 24);
 #pragma unroll
   for (int i = 0; i < 6; ++i) qp[i] = make_int4(t.hist[4 * i], t.hist[4 * i + 1], t.hist[4 * i + 2], t.hist[4 * i + 3]);
@@ -44,6 +47,9 @@ __device__ __forceinline__ void liar_store_hands(const LiarTable& t, int e, int*
 
 // LiarEnv.getObs (liar.py:53-56): a player's hand + the history padded with the null move [6, 0]; o = 30 floats, 8-byte aligned
 __device__ __forceinline__ void liar_write_obs(const LiarTable& t, bool ego, float* o) {
+#if defined(PH_LX_NO_OBS)
+  return;
+#endif
   float2* o2 = reinterpret_cast<float2*>(o);
 #pragma unroll
   for (int k = 0; k < 3; ++k)
@@ -55,8 +61,13 @@ __device__ __forceinline__ void liar_write_obs(const LiarTable& t, bool ego, flo
 // One move of Liar's Dice in table e (state in t, written back when it changes).
 //   actions (n, 2)  int32 : raw (side, count-1) proposed by whoever moves; `ego` says who that is
 // Outputs: obs_next (n, 30) f32 = observation of the OTHER player (liar.py:53-56), rew (n, 2) f32 (ego, partner),
-//          done (n) u8.  History / nmoves are updated in place.
-__device__ __forceinline__ void liar_move(LiarTable& t, int e, int* history, int* nmoves, const int* actions, bool ego,
+//          done (n) u8.  History / nmoves are updated in place.  What was written to rew / done is also returned: a caller
+//          that goes on with it must not read it back (a load behind a store waits for the store's acknowledgement).
+struct LiarOutcome {
+  float r_ego, r_alt;
+  bool done;
+};
+__device__ __forceinline__ LiarOutcome liar_move(LiarTable& t, int e, int* history, int* nmoves, const int* actions, bool ego,
                                           float* obs_next, float* rew, unsigned char* done) {
   const int nm = t.nm;
   const int2 act = *reinterpret_cast<const int2*>(actions + 2 * (size_t)e);
@@ -96,12 +107,13 @@ __device__ __forceinline__ void liar_move(LiarTable& t, int e, int* history, int
   liar_write_obs(t, !ego, obs_next + (size_t)e * 30);  // getObs(not isego)
   *reinterpret_cast<float2*>(rew + 2 * (size_t)e) = make_float2(r_ego, r_alt);
   done[e] = d;
+  return LiarOutcome{r_ego, r_alt, d != 0};
 }
 
 // LiarEnv.multi_reset of table e: N_DICE dice per player from Philox4x32-10 (one 24-bit draw per die, like the reference's
 // randint per die: die d is word d%4 of Philox block d/4 keyed (seed, counter, e)), empty history, first mover ~
 // Bernoulli(probegostart) from word 0 of block 100
-__device__ __forceinline__ void liar_deal(LiarTable& t, int e, int* hands, int* history, int* nmoves, unsigned char* ego_first,
+__device__ __forceinline__ bool liar_deal(LiarTable& t, int e, int* hands, int* history, int* nmoves, unsigned char* ego_first,
                                           uint64_t seed, uint64_t counter, float probegostart) {
 #pragma unroll
   for (int k = 0; k < 12; ++k) t.hand[k] = 0;
@@ -123,7 +135,9 @@ __device__ __forceinline__ void liar_deal(LiarTable& t, int e, int* hands, int* 
   t.nm = 0;
   liar_store_hands(t, e, hands);
   liar_store_history(t, e, history, nmoves);
-  ego_first[e] = philox_uniform(seed, counter, (uint32_t)e, 100u) < probegostart ? 1 : 0;
+  const bool first = philox_uniform(seed, counter, (uint32_t)e, 100u) < probegostart;
+  ego_first[e] = first ? 1 : 0;
+  return first;   // = ego_first[e]
 }
 
 // ---- vectorised Liar's Dice self-play: the step loop's book-keeping, one lane per table ------------------------------------
@@ -131,36 +145,63 @@ __device__ __forceinline__ void liar_deal(LiarTable& t, int e, int* hands, int* 
 // applied to n tables; the partner's rollout rows are ragged: table e writes row alt_pos[e]).  A table's state is touched
 // by its own lane only, so everything between two policy forwards is ONE launch: a vectorised step is
 //   ego forward | after_ego | partner forward | after_reply | partner forward (openers) | after_opening
+//
+// Each pass reads what it needs of the table's book-keeping ONCE, at its top (the loads are independent of each other: one
+// round trip), carries it in registers (LiarSeat) and stores what changed: on this target loads and stores return in issue
+// order, so a read-back of a flag behind a store -- or behind the late-reward atomic to HBM -- waits for that store's
+// acknowledgement, and a pass written as "store the flag, read the flag" pays one such wait per flag.
 __device__ __forceinline__ void liar_add_f32(float* p, float v) {
+#if defined(PH_LX_NO_ATOMICS)
+  return;
+#endif
   (void)__builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)p, v);
 }
-__device__ __forceinline__ void liar_sp_credit(const ph_liar_selfplay& s, float* alt_rewards, int alt_T, int e, float r, bool done,
-                                               bool credited) {
-  const bool m = credited && s.alt_open[e];
-  if (m) {
-    const int p = s.alt_pos[e];
-    // no-return float atomic: the address is this table's alone, so the sum is the plain "+=" -- but the lane does not wait a
-    // round trip to HBM for the old value in the middle of its book-keeping
-    if (p >= 1 && p <= alt_T) liar_add_f32(alt_rewards + (size_t)(p - 1) * s.n + e, r);
+// the partner's side of table e: where its next rollout row goes and the state of the reward window of its last recorded row
+struct LiarSeat {
+  int pos;         // alt_pos: rows recorded in this table's column so far
+  bool boundary;   // alt_boundary: a game ended since the last recorded row (its episode_start)
+  bool open;       // alt_open: the last forward was recorded, later rewards belong to it
+  bool acted;      // alt_acted: the partner has moved in the current game
+};
+__device__ __forceinline__ LiarSeat liar_seat_load(const ph_liar_selfplay& s, int e) {
+  LiarSeat q;
+  q.pos = s.alt_pos[e];
+  q.boundary = s.alt_boundary[e] != 0;
+  q.open = s.alt_open[e] != 0;
+  q.acted = s.alt_acted[e] != 0;
+  return q;
+}
+// a reward r / an episode end that follows the partner's last forward (credited: that forward happened in this game)
+__device__ __forceinline__ void liar_sp_credit(const ph_liar_selfplay& s, LiarSeat& q, float* alt_rewards, int alt_T, int e, float r,
+                                               bool done, bool credited) {
+  const bool m = credited && q.open;
+  // no-return float atomic: the address is this table's alone, so the sum is the plain "+=" -- but the lane does not wait a
+  // round trip to HBM for the old value in the middle of its book-keeping
+  if (m && q.pos >= 1 && q.pos <= alt_T) liar_add_f32(alt_rewards + (size_t)(q.pos - 1) * s.n + e, r);
+  if (done) {
+    s.alt_boundary[e] = 1;
+    q.boundary = true;
   }
-  if (done) s.alt_boundary[e] = 1;
   if (m && done) s.alt_term[e] = 1;
 }
 // what the partner's next forward records: a row where it is asked to move and its column still has room
-__device__ __forceinline__ void liar_sp_prepare(const ph_liar_selfplay& s, int alt_T, int e, bool requested) {
-  s.can[e] = (requested && s.alt_pos[e] < alt_T) ? 1 : 0;
-  s.es_alt[e] = s.alt_boundary[e] ? 1.f : 0.f;
+__device__ __forceinline__ void liar_sp_prepare(const ph_liar_selfplay& s, const LiarSeat& q, int alt_T, int e, bool requested) {
+  s.can[e] = (requested && q.pos < alt_T) ? 1 : 0;
+  s.es_alt[e] = q.boundary ? 1.f : 0.f;
 }
-// after a partner forward: advance the recorded column, open / close the reward window, mark the partner as having acted
-__device__ __forceinline__ void liar_sp_commit(const ph_liar_selfplay& s, int e) {
-  if (s.can[e]) {
-    s.alt_pos[e] += 1;
+// after a partner forward (can: it recorded a row): advance the recorded column, open / close the reward window, mark the
+// partner as having acted
+__device__ __forceinline__ void liar_sp_commit(const ph_liar_selfplay& s, LiarSeat& q, int e, bool can) {
+  if (can) {
+    q.pos += 1;
+    s.alt_pos[e] = q.pos;
     s.alt_boundary[e] = 0;
+    q.boundary = false;
     s.alt_term[e] = 0;
-    s.alt_open[e] = 1;
-  } else {
-    s.alt_open[e] = 0;     // the column is full: a later reward belongs to a row that was not recorded
   }
+  q.open = can;            // a full column: a later reward belongs to a row that was not recorded
+  s.alt_open[e] = can ? 1 : 0;
+  q.acted = true;
   s.alt_acted[e] = 1;
 }
 
@@ -169,11 +210,11 @@ __device__ __forceinline__ void liar_sp_commit(const ph_liar_selfplay& s, int e)
 __device__ __forceinline__ void liar_sp_after_ego_lane(const ph_liar_selfplay& s, int e, float* alt_rewards, int alt_T) {
   LiarTable t;
   liar_load(t, e, s.hands, s.history, s.nmoves);
-  liar_move(t, e, s.history, s.nmoves, s.ego_actions, true, s.obs_next, s.rew1, s.done1);
-  const bool d1 = s.done1[e] != 0;
-  liar_sp_credit(s, alt_rewards, alt_T, e, s.rew1[2 * e + 1], d1, s.alt_acted[e] != 0);
-  s.running[e] = d1 ? 0 : 1;
-  liar_sp_prepare(s, alt_T, e, !d1);
+  LiarSeat q = liar_seat_load(s, e);
+  const LiarOutcome o1 = liar_move(t, e, s.history, s.nmoves, s.ego_actions, true, s.obs_next, s.rew1, s.done1);
+  liar_sp_credit(s, q, alt_rewards, alt_T, e, o1.r_alt, o1.done, q.acted);
+  s.running[e] = o1.done ? 0 : 1;
+  liar_sp_prepare(s, q, alt_T, e, !o1.done);
 }
 // the partner has replied where the game went on: play that move, credit both, the ego's reward row / episode flags /
 // next observation; then (also the whole of a deal-only call) re-deal the finished tables, find who opens the new games
@@ -183,33 +224,35 @@ __device__ __forceinline__ void liar_sp_after_reply_lane(const ph_liar_selfplay&
                                                          int deal_only) {
   LiarTable t;
   liar_load(t, e, s.hands, s.history, s.nmoves);
+  LiarSeat q = liar_seat_load(s, e);
+  bool ego_first = s.ego_first[e] != 0;    // of the game in progress; a re-deal below replaces it
+  bool fresh = s.done[e] != 0;             // a deal-only call: the caller's flags
   if (!deal_only) {
-    const bool run = s.running[e] != 0;
+    const bool run = s.running[e] != 0, can = s.can[e] != 0, d1 = s.done1[e] != 0;
+    const float r1_ego = s.rew1[2 * e];
+    LiarOutcome o2{0.f, 0.f, false};
     if (run) {
-      liar_sp_commit(s, e);
-      liar_move(t, e, s.history, s.nmoves, s.alt_actions, false, s.obs_next, s.rew2, s.done2);
+      liar_sp_commit(s, q, e, can);
+      o2 = liar_move(t, e, s.history, s.nmoves, s.alt_actions, false, s.obs_next, s.rew2, s.done2);
     }
-    const bool d2 = run && s.done2[e] != 0;
-    liar_sp_credit(s, alt_rewards, alt_T, e, s.rew2[2 * e + 1], d2, run);
-    const bool done = s.done1[e] != 0 || d2;
-    liar_add_f32(ego_rew_row + e, s.rew1[2 * e] + (run ? s.rew2[2 * e] : 0.f));   // both transitions of the step (agents.py:44-47)
+    const bool d2 = run && o2.done;
+    liar_sp_credit(s, q, alt_rewards, alt_T, e, o2.r_alt, d2, run);
+    const bool done = d1 || d2;
+    liar_add_f32(ego_rew_row + e, r1_ego + (run ? o2.r_ego : 0.f));   // both transitions of the step (agents.py:44-47)
     s.ego_episode_start[e] = done ? 1.f : 0.f;
     if (run && !d2) liar_write_obs(t, true, s.obs_ego + (size_t)e * 30);   // = obs_next of the move just played
     s.done[e] = done ? 1 : 0;
-    if (done) {
-      s.alt_acted[e] = 0;
-      atomicAdd(s.episodes, 1ull);
-    }
+    if (done) atomicAdd(s.episodes, 1ull);
+    fresh = done;
   }
-  const bool fresh = s.done[e] != 0;
-  if (fresh)
-    liar_deal(t, e, s.hands, s.history, s.nmoves, s.ego_first, s.dice_seed, counter + (epoch ? (uint64_t)(*epoch) << 32 : 0ull),
-              s.probegostart);
-  const bool ego_first = s.ego_first[e] != 0;
+  if (fresh) {
+    ego_first = liar_deal(t, e, s.hands, s.history, s.nmoves, s.ego_first, s.dice_seed,
+                          counter + (epoch ? (uint64_t)(*epoch) << 32 : 0ull), s.probegostart);
+    s.alt_acted[e] = 0;
+  }
   s.alt_opens[e] = (fresh && !ego_first) ? 1 : 0;
   s.ego_opens[e] = (fresh && ego_first) ? 1 : 0;
-  if (fresh) s.alt_acted[e] = 0;
-  liar_sp_prepare(s, alt_T, e, fresh && !ego_first);
+  liar_sp_prepare(s, q, alt_T, e, fresh && !ego_first);
   if (fresh && !ego_first) liar_write_obs(t, false, s.obs_alt + (size_t)e * 30);
 }
 // the partner has opened the new games it starts: play that move; the ego's observation of every fresh table
@@ -219,8 +262,9 @@ __device__ __forceinline__ void liar_sp_after_opening_lane(const ph_liar_selfpla
   LiarTable t;
   liar_load(t, e, s.hands, s.history, s.nmoves);
   if (alt_opens) {
-    liar_sp_commit(s, e);
-    liar_move(t, e, s.history, s.nmoves, s.alt_actions, false, s.obs_next, s.rew2, s.done2);
+    LiarSeat q = liar_seat_load(s, e);
+    liar_sp_commit(s, q, e, s.can[e] != 0);
+    (void)liar_move(t, e, s.history, s.nmoves, s.alt_actions, false, s.obs_next, s.rew2, s.done2);
   }
   liar_write_obs(t, true, s.obs_ego + (size_t)e * 30);   // after the partner's opening move, or of the fresh deal
 }

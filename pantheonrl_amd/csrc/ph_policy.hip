@@ -7,7 +7,7 @@
 // 1 -> value net workgroup (values + the observation copy into the rollout buffer).  Each workgroup keeps the
 // 64x64 weight blocks in LDS and runs every layer as 32x32 v_mfma_f32_32x32x2_f32 tiles, one tile per wave.
 #include "ph_rowtail.h"
-#include "ph_liar.h"
+#include "ph_liar_group.h"
 
 namespace ph {
 
@@ -747,19 +747,30 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   // caches: each dependent round trip costs ~1 us at this occupancy).  The observation -> feature-row loads go first.
   // (Staging the whole of W1 -- 69 KB per net for Liar's Dice -- into LDS so that the gather stays on the CU measured
   // slower: +3.4 k cycles of staging against -1.7 k in the gather.)
+  // (unconditional loads at clamped positions, then selects: a load under `if (comp < D && row < n_end)` is a basic block of its
+  // own, and the four of a lane then go out one after the other, each behind the wait for the one before)
   int fv[R * FS / NT];
+  {
+    const int* off = RES ? ooff : nd.obs_off;   // RES: the prefix sums sit in LDS for the launch
+    int lo[R * FS / NT], hi[R * FS / NT];
+    float xo[R * FS / NT];
 #pragma unroll
-  for (int i = 0; i < R * FS / NT; ++i) {
-    const int e = tid + NT * i, r = e >> 6, comp = e & 63, row = row0 + r;
-    int f = -1;
-    if (comp < D && row < n_end) {
-      const int* off = RES ? ooff : nd.obs_off;   // RES: the prefix sums sit in LDS for the launch
-      const int lo = off[comp], nn = off[comp + 1] - lo;
-      int x = (int)a.obs[(size_t)row * D + comp];
-      x = x < 0 ? 0 : (x >= nn ? nn - 1 : x);
-      f = lo + x;
+    for (int i = 0; i < R * FS / NT; ++i) {
+      const int e = tid + NT * i, r = e >> 6, comp = e & 63, row = row0 + r;
+      const bool ok = comp < D && row < n_end;
+      const int cs = ok ? comp : 0, rs = ok ? row : row0;
+      lo[i] = off[cs];
+      hi[i] = off[cs + 1];
+      xo[i] = a.obs[(size_t)rs * D + cs];
     }
-    fv[i] = f;
+#pragma unroll
+    for (int i = 0; i < R * FS / NT; ++i) {
+      const int e = tid + NT * i, r = e >> 6, comp = e & 63, row = row0 + r;
+      const int nn = hi[i] - lo[i];
+      int x = (int)xo[i];
+      x = x < 0 ? 0 : (x >= nn ? nn - 1 : x);
+      fv[i] = (comp < D && row < n_end) ? lo[i] + x : -1;
+    }
   }
   long long ridxv = -1;
   if (net == 0 && tid < R && row0 + tid < n_end && (a.rb_act || a.rb_logp)) ridxv = rb_row(a, row0 + tid);
@@ -800,12 +811,35 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   // gather loads are in flight ----
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* w1l = W1 + 4 * gl;
+  const char* w1b = reinterpret_cast<const char*>(W1);
   const int* fr = feat + gr * FS;
+  // feat[row][u] >= 0 exactly where the row is live and u < D: the row's lanes load under ONE exec mask and the component test is
+  // scalar.  (Written as `f >= 0 ? load : 0` per component, every load is a basic block with its own feat read in front, and the
+  // 32 gathers go out one LDS latency apart: 4.2 k of this phase's 5.2 k cycles in the rollout kernel.)
+  const bool row_live = row0 + gr < n_end;
   float4 w[32];
 #pragma unroll
-  for (int u = 0; u < 32; ++u) {
-    const int f = fr[u];
-    w[u] = (f >= 0) ? *reinterpret_cast<const float4*>(w1l + (size_t)f * HID) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int u = 0; u < 32; ++u) w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {   // sixteen positions at a time (all 32 at once cost registers the rollout kernel does not have)
+    int fu[16];
+    const int4* fr4 = reinterpret_cast<const int4*>(fr) + 4 * hb;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int4 q = fr4[u];
+      fu[4 * u] = q.x;
+      fu[4 * u + 1] = q.y;
+      fu[4 * u + 2] = q.z;
+      fu[4 * u + 3] = q.w;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(fu[u]));   // in registers before the first gather of the batch is addressed
+    if (row_live) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (16 * hb + u < D)   // uniform base + 32-bit byte offset: one address register per gather
+          w[16 * hb + u] = *reinterpret_cast<const float4*>(w1b + ((unsigned)fu[u] * (unsigned)(HID * sizeof(float)) + 16u * (unsigned)gl));
+    }
   }
   if constexpr (!RES) {
     w2r.commit(w2s, tid);
@@ -833,10 +867,17 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
     }
     for (int c0 = 32; c0 < D; c0 += 32) {   // more than 32 components: further batches
       float4 w2[32];
+      int fu2[32];
 #pragma unroll
-      for (int u = 0; u < 32; ++u) {
-        const int f = fr[c0 + u];
-        w2[u] = (f >= 0) ? *reinterpret_cast<const float4*>(w1l + (size_t)f * HID) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < 32; ++u) fu2[u] = fr[c0 + u];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) asm volatile("" : "+v"(fu2[u]));
+#pragma unroll
+      for (int u = 0; u < 32; ++u) w2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row_live) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+          if (c0 + u < D) w2[u] = *reinterpret_cast<const float4*>(w1l + (size_t)fu2[u] * HID);
       }
 #pragma unroll
       for (int u = 0; u < 32; ++u) {
@@ -1003,27 +1044,7 @@ static size_t fwd16h_lds_bytes();
 // argument records get pointers REBASED into the mirror (mirror - row0 * stride, so that the unchanged code indexes them with the
 // global table number through generic addressing), and everything is written back at the end.  What still goes to HBM per step
 // is what must: the rollout-buffer rows, the partner's late rewards and the value / log-prob outputs.
-struct LiarMirror {
-  // element counts per table
-  static constexpr int I_HANDS = 12, I_HIST = 24, F_OBS = 30;
-  int* hands;      // [16][12]
-  int* history;    // [16][24]
-  int* nmoves;     // [16]
-  int* alt_pos;    // [16]
-  int* ego_act;    // [16][2]
-  int* alt_act;    // [16][2]
-  float* obs_ego;  // [16][30]
-  float* obs_alt;
-  float* obs_next;
-  float* rew1;     // [16][2]
-  float* rew2;
-  float* es_alt;   // [16]
-  float* es_ego;   // [16]
-  unsigned char* u8;   // [12][16]: ego_first, alt_boundary, alt_term, alt_open, alt_acted, done1, done2, running, can,
-                       //           alt_opens, ego_opens, done
-};
-constexpr int LIAR_MIRROR_BYTES = 16 * (12 + 24 + 1 + 1 + 2 + 2) * 4 + 16 * (3 * 30 + 2 + 2 + 1 + 1) * 4 + 12 * 16;
-
+// (LiarMirror: ph_liar_group.h)
 template <typename T>
 __device__ __forceinline__ T* rebase(T* mirror, int row0, int per) { return mirror - (size_t)row0 * per; }
 
@@ -1138,8 +1159,16 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
   }
   __syncthreads();
 
-  const int e = row0 + tid512;                  // the table lane tid512 < 16 keeps the books of
-  const bool keeper = tid512 < nrow;
+  // book-keeping: table i of the workgroup on the 32 lanes of group i (ph_liar_group.h)
+  const int grp = tid512 >> 5, gl = tid512 & 31;
+  const bool keeper = grp < nrow;
+  LiarGroupCtx gc;
+  gc.n = g.n;
+  gc.alt_rewards = r.alt_rewards;
+  gc.alt_T = r.alt_T;
+  gc.episodes = g.episodes;
+  gc.dice_seed = g.dice_seed;
+  gc.probegostart = g.probegostart;
   // one inlined copy of the forward body: the three forwards of a step are a loop whose argument record is selected with
   // scalar selects (three inlined copies cost 1.4 KB of scratch per lane and 649 spilled SGPRs)
   // the RNG epoch is constant for the launch: read once here instead of by every forward's sampling tail and every re-deal
@@ -1203,13 +1232,13 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
     }
     PH_STAMP(prof, 9 + 2 * f);
     if (keeper) {
-      // the table number is made opaque per pass: otherwise the per-lane addresses of the book-keeping (64-bit pairs into the
+      // the group / lane numbers are made opaque per pass: otherwise the per-lane addresses of the book-keeping (a dozen into the
       // mirror) are hoisted out of the rollout loop and held -- spilled -- across the forwards
-      int ek = e;
-      asm volatile("" : "+v"(ek));
-      if (f == 0) liar_sp_after_ego_lane(s, ek, r.alt_rewards, r.alt_T);
-      else if (f == 1) liar_sp_after_reply_lane(s, ek, r.alt_rewards, r.alt_T, r.ego_rew_row0 + row, counter + epoch_hi, nullptr, 0);
-      else liar_sp_after_opening_lane(s, ek);
+      int gi = grp, gk = gl;
+      asm volatile("" : "+v"(gi), "+v"(gk));
+      if (f == 0) liar_grp_after_ego(m, gc, gi, row0 + gi, gk);
+      else if (f == 1) liar_grp_after_reply(m, gc, gi, row0 + gi, gk, r.ego_rew_row0 + row, counter + epoch_hi);
+      else liar_grp_after_opening(m, gi, gk);
     }
     __syncthreads();
     PH_STAMP(prof, 10 + 2 * f);

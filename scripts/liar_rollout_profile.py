@@ -44,3 +44,8 @@ print(f"  W1 row gather + staging commits + tanh + barrier {med(1, 3):6.0f}")
 print(f"  layer 2 + barrier                              {med(3, 5):8.0f}")
 print(f"  head products + barrier                        {med(5, 6):8.0f}")
 print(f"  row tails (softmax, sample, buffer rows)       {med(6, 7):8.0f}")
+print("around the reply forward (workgroups whose last forward of the step it was):")
+rep = st[(st[:, 0] > st[:, 10]) & (st[:, 7] < st[:, 11])]
+if len(rep):
+    print(f"  {len(rep)} workgroups: book-keeping end -> forward body {np.median(rep[:, 0] - rep[:, 10]):6.0f}, "
+          f"policy tail end -> after the closing barrier {np.median(rep[:, 11] - rep[:, 7]):6.0f}")
