@@ -627,8 +627,13 @@ __device__ __forceinline__ float sum32_upper(float v) {
   v += dpp_f<0x128>(v);   // row_ror 8
   return v + dpp_f<0x142>(v);
 }
+// u_drawn: the lane's sampling uniform (head_draw32), drawn by the caller ahead of the logits
+__device__ __forceinline__ bool head_draws(const FwdArgs& a) { return !a.given_actions && !a.deterministic && !a.uniforms; }
+__device__ __forceinline__ float head_draw32(const FwdArgs& a, int g, bool row_ok, int comp, uint64_t ctr) {
+  return (row_ok && comp >= 0) ? philox_uniform(a.seed, ctr, (uint32_t)g, (uint32_t)comp) : 0.f;
+}
 __device__ __forceinline__ void head_tail32(const FwdArgs& a, const NetDims& nd, int g, bool row_ok, long long ridx, float z,
-                                            int k, int lo, int last, int comp, uint64_t ctr) {
+                                            int k, int lo, int last, int comp, float u_drawn) {
   const bool own = row_ok && comp >= 0;     // this lane holds a real logit of a real row
   const int nk = last - lo + 1;
   if (own && a.mask) z = z - 30.0f * (1.0f - (float)(a.mask[(size_t)g * nd.L + k] != 0));  // modular/policies.py:330-333
@@ -649,7 +654,7 @@ __device__ __forceinline__ void head_tail32(const FwdArgs& a, const NetDims& nd,
     act = bits ? __ffs(bits) - 1 : 0;
   } else {                                  // inverse CDF: count the prefix sums <= u among the first nk-1
     float u = 0.f;
-    if (own) u = a.uniforms ? a.uniforms[(size_t)g * nd.A + comp] : philox_uniform(a.seed, ctr, (uint32_t)g, (uint32_t)comp);
+    if (own) u = a.uniforms ? a.uniforms[(size_t)g * nd.A + comp] : u_drawn;
     const unsigned long long b = __ballot(own && k < last && u >= s * inv);
     const unsigned bits = ((unsigned)(b >> (32 * half)) >> lo) & (nk >= 32 ? 0xffffffffu : ((1u << nk) - 1u));
     act = __popc(bits);
@@ -684,6 +689,8 @@ __device__ __forceinline__ void head_tail32(const FwdArgs& a, const NetDims& nd,
 // forward -- the layout the forward itself stages (W2 [64][LDH], b2, the head's bias), the head's weights with a narrower leading
 // dimension (RES_LDO: only 32 logit columns exist), and b1, which the per-launch form reads from global memory.  Same values in the
 // same operand positions: the forward's arithmetic does not change.
+// a row of W1 that is all zeros: what the layer-1 gather reads where an observation row has no feature (see the body)
+__device__ float ph_zero_row[HID];
 constexpr int RES_LDO = 33;
 constexpr int RES_NET_FLOATS = HID * LDH + HID * RES_LDO + HID + HID + 32;
 struct ResidentNet {
@@ -703,7 +710,7 @@ __device__ __forceinline__ ResidentNet resident_net_at(float* base) {
   return r;
 }
 // scratch of one half (one net) of a fused forward in RES form: xs, hs, outs, feat, aoff, seg, ridxs (see the body)
-constexpr int RES_SCRATCH_FLOATS = 2 * 16 * LDH + 16 * 33 + 16 * 64 + 40 + 96 + 2 * 16 + 8;
+constexpr int RES_SCRATCH_FLOATS = 2 * 16 * LDH + 16 * 33 + 2 * 16 * 64 + 40 + 96 + 2 * 16 + 8;
 
 template <bool VALU, bool FUSED = false, bool RES = false>
 __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in = 0, int net_in = 0, int tid_in = 0,
@@ -723,8 +730,9 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   float* outs = RES ? hs + R * LDH : wos + HID * LDH;    // [16][LDO] logits
   float* b2s = RES ? res->b2s : outs + R * LDO;      // [64]
   float* hbs = RES ? res->hbs : b2s + HID;           // act_b [32] | val_b
-  int* feat = (int*)(RES ? outs + R * LDO : hbs + 32);     // [16][FS] hot row of W1 per (row, component), -1 = none
-  int* aoff = feat + R * FS;        // [40] prefix sums of the action nvec (A + 1 entries)
+  // [16][FS] per (row, component): the hot row of W1, or ph_zero_row where there is none (padding rows, components >= D)
+  const float** feat = (const float**)(RES ? outs + R * LDO : hbs + 32);
+  int* aoff = (int*)(feat + R * FS);   // [40] prefix sums of the action nvec (A + 1 entries)
   int* seg = aoff + 40;             // [3][32] per logit: first / last lane of its component, component index (RES: filled once per launch)
   long long* ridxs = (long long*)(seg + 96);          // [16] rollout-buffer row of each observation row (-1 = not recorded)
 
@@ -749,7 +757,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   // slower: +3.4 k cycles of staging against -1.7 k in the gather.)
   // (unconditional loads at clamped positions, then selects: a load under `if (comp < D && row < n_end)` is a basic block of its
   // own, and the four of a lane then go out one after the other, each behind the wait for the one before)
-  int fv[R * FS / NT];
+  const float* fv[R * FS / NT];
   {
     const int* off = RES ? ooff : nd.obs_off;   // RES: the prefix sums sit in LDS for the launch
     int lo[R * FS / NT], hi[R * FS / NT];
@@ -769,7 +777,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
       const int nn = hi[i] - lo[i];
       int x = (int)xo[i];
       x = x < 0 ? 0 : (x >= nn ? nn - 1 : x);
-      fv[i] = (comp < D && row < n_end) ? lo[i] + x : -1;
+      fv[i] = (comp < D && row < n_end) ? W1 + (size_t)(lo[i] + x) * HID : ph_zero_row;
     }
   }
   long long ridxv = -1;
@@ -810,36 +818,34 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   // ---- layer 1: gather-sum of W1 rows in component order; everything staged for the later layers is committed while the
   // gather loads are in flight ----
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* w1l = W1 + 4 * gl;
-  const char* w1b = reinterpret_cast<const char*>(W1);
-  const int* fr = feat + gr * FS;
-  // feat[row][u] >= 0 exactly where the row is live and u < D: the row's lanes load under ONE exec mask and the component test is
-  // scalar.  (Written as `f >= 0 ? load : 0` per component, every load is a basic block with its own feat read in front, and the
-  // 32 gathers go out one LDS latency apart: 4.2 k of this phase's 5.2 k cycles in the rollout kernel.)
-  const bool row_live = row0 + gr < n_end;
+  float u_tail[2] = {0.f, 0.f};   // sampling uniforms of this lane's two tail rows
+  const float* const* fr = feat + gr * FS;
+  // Every position of feat is a readable row (ph_zero_row where the observation has no feature there), so the gathers of a wave
+  // are straight-line code: no per-component exec mask, no zero-filled registers behind a skipped load, nothing for the adds to
+  // skip (x + 0.f = x: the accumulator starts at +0 and is never -0).  What remains conditional is scalar: a wave none of whose
+  // four rows is live gathers nothing, and components go in groups of eight up to D.  (Written as `f >= 0 ? load : 0` per
+  // component, every load is a basic block with its own feat read in front: 32 gathers one LDS latency apart, 4.2 k of this
+  // phase's 5.2 k cycles in the rollout kernel; the zero-fills of the masked form were another ~260 v_mov.)
+  const bool wave_live = row0 + 4 * __builtin_amdgcn_readfirstlane(wave) < n_end;
   float4 w[32];
+  typedef const f32x4 __attribute__((address_space(1))) * global_row4;   // (a pointer read from LDS would load through `flat`)
+  auto gather8 = [&](float4* dst, int c0) {   // components c0 .. c0 + 7 of this lane's row
+    ulonglong2 q[4];
+    const ulonglong2* fr2 = reinterpret_cast<const ulonglong2*>(fr + c0);
 #pragma unroll
-  for (int u = 0; u < 32; ++u) w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < 4; ++u) q[u] = fr2[u];
 #pragma unroll
-  for (int hb = 0; hb < 2; ++hb) {   // sixteen positions at a time (all 32 at once cost registers the rollout kernel does not have)
-    int fu[16];
-    const int4* fr4 = reinterpret_cast<const int4*>(fr) + 4 * hb;
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(q[u].x), "+v"(q[u].y));   // one batch of reads, then the gathers
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int4 q = fr4[u];
-      fu[4 * u] = q.x;
-      fu[4 * u + 1] = q.y;
-      fu[4 * u + 2] = q.z;
-      fu[4 * u + 3] = q.w;
+    for (int u = 0; u < 8; ++u) {
+      const f32x4 v = *(global_row4)(((u & 1) ? q[u >> 1].y : q[u >> 1].x) + 16ull * (unsigned)gl);
+      dst[u] = make_float4(v[0], v[1], v[2], v[3]);
     }
+  };
+  if (wave_live) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(fu[u]));   // in registers before the first gather of the batch is addressed
-    if (row_live) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u)
-        if (16 * hb + u < D)   // uniform base + 32-bit byte offset: one address register per gather
-          w[16 * hb + u] = *reinterpret_cast<const float4*>(w1b + ((unsigned)fu[u] * (unsigned)(HID * sizeof(float)) + 16u * (unsigned)gl));
-    }
+    for (int q = 0; q < 4; ++q)
+      if (8 * q < D) gather8(w + 8 * q, 8 * q);
   }
   if constexpr (!RES) {
     w2r.commit(w2s, tid);
@@ -858,33 +864,53 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
     }
   }
   {
-#pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      acc.x += w[u].x;
-      acc.y += w[u].y;
-      acc.z += w[u].z;
-      acc.w += w[u].w;
-    }
-    for (int c0 = 32; c0 < D; c0 += 32) {   // more than 32 components: further batches
-      float4 w2[32];
-      int fu2[32];
-#pragma unroll
-      for (int u = 0; u < 32; ++u) fu2[u] = fr[c0 + u];
-#pragma unroll
-      for (int u = 0; u < 32; ++u) asm volatile("" : "+v"(fu2[u]));
-#pragma unroll
-      for (int u = 0; u < 32; ++u) w2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row_live) {
-#pragma unroll
-        for (int u = 0; u < 32; ++u)
-          if (c0 + u < D) w2[u] = *reinterpret_cast<const float4*>(w1l + (size_t)fu2[u] * HID);
+    // The sampling uniforms of the row tails (Philox: a chain of ~100 dependent instructions that needs no logit) are drawn here,
+    // under the gathers' latency.  RES: the logit -> component table is in LDS for the launch; otherwise from the prefix sums.
+    if (net == 0 && head_draws(a)) {
+      const int k = tid & 31;
+      int comp = -1;
+      if constexpr (RES) {
+        comp = seg[64 + k];
+      } else {
+        for (int cc = 0; cc < nd.A; ++cc)
+          if (k >= nd.act_off[cc] && k < nd.act_off[cc + 1]) comp = cc;
       }
+      const uint64_t ctr = fwd_counter(a);
+      const int r0 = row0 + (tid >> 5);
+      u_tail[0] = head_draw32(a, r0, r0 < n_end, comp, ctr);
+      u_tail[1] = (row0 + 8 < n_end) ? head_draw32(a, r0 + 8, r0 + 8 < n_end, comp, ctr) : 0.f;
+    }
+    if (wave_live) {
+      // (w[0] opaque: otherwise "0 + w[0]" moves into the block of the first gathers, with a full wait behind them; the uniforms
+      // ride along so that they are computed in front of that wait)
+      asm volatile("" : "+v"(w[0].x), "+v"(w[0].y), "+v"(w[0].z), "+v"(w[0].w), "+v"(u_tail[0]), "+v"(u_tail[1]));
 #pragma unroll
-      for (int u = 0; u < 32; ++u) {
-        acc.x += w2[u].x;
-        acc.y += w2[u].y;
-        acc.z += w2[u].z;
-        acc.w += w2[u].w;
+      for (int q = 0; q < 4; ++q)
+        if (8 * q < D) {
+#pragma unroll
+          for (int u = 8 * q; u < 8 * q + 8; ++u) {
+            acc.x += w[u].x;
+            acc.y += w[u].y;
+            acc.z += w[u].z;
+            acc.w += w[u].w;
+          }
+        }
+      for (int c0 = 32; c0 < D; c0 += 32) {   // more than 32 components: further batches
+        float4 w2[32];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (c0 + 8 * q < D) gather8(w2 + 8 * q, c0 + 8 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (c0 + 8 * q < D) {
+#pragma unroll
+            for (int u = 8 * q; u < 8 * q + 8; ++u) {
+              acc.x += w2[u].x;
+              acc.y += w2[u].y;
+              acc.z += w2[u].z;
+              acc.w += w2[u].w;
+            }
+          }
       }
     }
     float* h = hs + gr * LDH + 4 * gl;
@@ -956,7 +982,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
       for (int pass = 0; pass < 2; ++pass) {   // 32 lanes per row, 8 rows per pass
         if (pass == 1 && row0 + 8 >= n_end) break;   // no live row in the second pass (workgroup-uniform)
         const int r = pass * 8 + (tid >> 5);
-        head_tail32(a, nd, row0 + r, row0 + r < n_end, ridxs[r], outs[r * LDO + k], k, lo, last, comp, fwd_counter(a));
+        head_tail32(a, nd, row0 + r, row0 + r < n_end, ridxs[r], outs[r * LDO + k], k, lo, last, comp, u_tail[pass]);
       }
     }
   } else {
@@ -988,7 +1014,7 @@ __global__ __launch_bounds__(256) void policy_fwd16h_kernel(FwdArgs a) {
 }
 
 static size_t fwd16h_lds_bytes() {
-  return sizeof(float) * (size_t)(2 * 16 * LDH + 2 * HID * LDH + 16 * 33 + HID + 32 + 16 * 64 + 40 + 96 + 2 * 16);
+  return sizeof(float) * (size_t)(2 * 16 * LDH + 2 * HID * LDH + 16 * 33 + HID + 32 + 2 * 16 * 64 + 40 + 96 + 2 * 16);
 }
 
 // one net (policy: net 0, value: net 1) of `params` into a resident set, by the 256 lanes of the half that runs that net -- the very
@@ -1138,7 +1164,7 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
     stage_resident_net(res_alt, r.reply.params, nd, half, tid);
     if (tid512 <= nd.D) ooff[tid512] = nd.obs_off[tid512];
     if (half == 0) {   // aoff / seg of the policy half's scratch (policy_fwd16h_body's layout)
-      int* aoff = (int*)(sm + 2 * 16 * LDH + 16 * 33) + 16 * 64;
+      int* aoff = (int*)(sm + 2 * 16 * LDH + 16 * 33) + 2 * 16 * 64;
       int* seg = aoff + 40;
       if (tid < 32) {
         int lo = tid, last = tid, comp = -1;
@@ -1204,6 +1230,7 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
       FwdArgs a = (f == 0) ? r.ego : ((f == 1) ? r.reply : r.opening);
       a.counter = ((f == 0) ? counter : 2ull * counter + (unsigned long long)(f - 1)) + epoch_hi;
       a.epoch = nullptr;
+      a.prof = (f == 0) ? prof : nullptr;   // the body's stamps: the ego forward of the stamped step
       if (f == 0) {
         a.rb_obs += row * a.nd.D;
         a.rb_act += row * a.nd.A;

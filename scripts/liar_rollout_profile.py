@@ -38,14 +38,11 @@ print(f"  book-keeping after reply   {med(11, 12):8.0f}")
 print(f"  opening forward            {med(12, 13):8.0f}")
 print(f"  book-keeping after opening {med(13, 14):8.0f}")
 print(f"  whole step                 {med(8, 14):8.0f}")
-print("ego forward of the last step, by phase (policy half):")
+print("ego forward of that step, by phase (policy half):")
+print(f"  step top -> forward body (argument record)     {med(8, 0):8.0f}")
 print(f"  loads issued, hot positions -> LDS + barrier   {med(0, 1):8.0f}")
 print(f"  W1 row gather + staging commits + tanh + barrier {med(1, 3):6.0f}")
 print(f"  layer 2 + barrier                              {med(3, 5):8.0f}")
 print(f"  head products + barrier                        {med(5, 6):8.0f}")
 print(f"  row tails (softmax, sample, buffer rows)       {med(6, 7):8.0f}")
-print("around the reply forward (workgroups whose last forward of the step it was):")
-rep = st[(st[:, 0] > st[:, 10]) & (st[:, 7] < st[:, 11])]
-if len(rep):
-    print(f"  {len(rep)} workgroups: book-keeping end -> forward body {np.median(rep[:, 0] - rep[:, 10]):6.0f}, "
-          f"policy tail end -> after the closing barrier {np.median(rep[:, 11] - rep[:, 7]):6.0f}")
+print(f"  tails done -> behind the closing barrier       {med(7, 9):8.0f}")
