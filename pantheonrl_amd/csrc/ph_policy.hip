@@ -6,6 +6,8 @@
 // Grid: (row tiles of R rows, 2).  blockIdx.y = 0 -> policy net workgroup (logits, sampling, log-prob),
 // 1 -> value net workgroup (values + the observation copy into the rollout buffer).  Each workgroup keeps the
 // 64x64 weight blocks in LDS and runs every layer as 32x32 v_mfma_f32_32x32x2_f32 tiles, one tile per wave.
+#include <cstring>
+#include <initializer_list>
 #include "ph_rowtail.h"
 #include "ph_liar_group.h"
 
@@ -764,7 +766,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
     float xo[R * FS / NT];
 #pragma unroll
     for (int i = 0; i < R * FS / NT; ++i) {
-      const int e = tid + NT * i, r = e >> 6, comp = e & 63, row = row0 + r;
+      const int r = 4 * wave + i, comp = lane, row = row0 + r;   // the rows this wave gathers below
       const bool ok = comp < D && row < n_end;
       const int cs = ok ? comp : 0, rs = ok ? row : row0;
       lo[i] = off[cs];
@@ -773,7 +775,7 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
     }
 #pragma unroll
     for (int i = 0; i < R * FS / NT; ++i) {
-      const int e = tid + NT * i, r = e >> 6, comp = e & 63, row = row0 + r;
+      const int r = 4 * wave + i, comp = lane, row = row0 + r;   // the rows this wave gathers below
       const int nn = hi[i] - lo[i];
       int x = (int)xo[i];
       x = x < 0 ? 0 : (x >= nn ? nn - 1 : x);
@@ -810,9 +812,13 @@ __device__ __forceinline__ void policy_fwd16h_body(const FwdArgs& a, int row0_in
   }
   // commits, in issue order
 #pragma unroll
-  for (int i = 0; i < R * FS / NT; ++i) feat[tid + NT * i] = fv[i];
+  for (int i = 0; i < R * FS / NT; ++i) feat[(4 * wave + i) * FS + lane] = fv[i];
   if (net == 0 && tid < R) ridxs[tid] = ridxv;
-  lds_only_barrier();  // feat visible
+  // a wave gathers the four rows whose positions it has just written: no workgroup barrier, its own LDS writes only
+  // (ridxs is read behind three more barriers)
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
   PH_STAMP(a.prof, 1);
 
   // ---- layer 1: gather-sum of W1 rows in component order; everything staged for the later layers is committed while the
@@ -1227,34 +1233,41 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
       }
     }
     if (need) {
-      FwdArgs a = (f == 0) ? r.ego : ((f == 1) ? r.reply : r.opening);
-      a.counter = ((f == 0) ? counter : 2ull * counter + (unsigned long long)(f - 1)) + epoch_hi;
+      // The three argument records share everything but the fields below (ph_liar_selfplay_rollout builds them: same spec, same
+      // table count; launch_liar_rollout checks what this relies on).  Selecting whole records -- three kernarg reads of ~1 KB and a
+      // few hundred scalar selects per forward -- cost 2.2 k cycles of a 29.7 k-cycle step.
+      FwdArgs a = r.ego;
+      const bool ego_f = f == 0;
+      a.params = ego_f ? r.ego.params : r.reply.params;
+      a.seed = ego_f ? r.ego.seed : r.reply.seed;
+      a.values = ego_f ? r.ego.values : r.reply.values;
+      a.logp = ego_f ? r.ego.logp : r.reply.logp;
+      a.rb_obs = ego_f ? r.ego.rb_obs + row * r.ego.nd.D : r.reply.rb_obs;
+      a.rb_act = ego_f ? r.ego.rb_act + row * r.ego.nd.A : r.reply.rb_act;
+      a.rb_rew = ego_f ? r.ego.rb_rew + row : r.reply.rb_rew;
+      a.rb_es = ego_f ? r.ego.rb_es + row : r.reply.rb_es;
+      a.rb_val = ego_f ? r.ego.rb_val + row : r.reply.rb_val;
+      a.rb_logp = ego_f ? r.ego.rb_logp + row : r.reply.rb_logp;
+      a.rb_T = ego_f ? r.ego.rb_T : r.reply.rb_T;
+      a.counter = (ego_f ? counter : 2ull * counter + (unsigned long long)(f - 1)) + epoch_hi;
       a.epoch = nullptr;
-      a.prof = (f == 0) ? prof : nullptr;   // the body's stamps: the ego forward of the stamped step
-      if (f == 0) {
-        a.rb_obs += row * a.nd.D;
-        a.rb_act += row * a.nd.A;
-        a.rb_rew += row;
-        a.rb_es += row;
-        a.rb_val += row;
-        a.rb_logp += row;
-        a.obs = s.obs_ego;
-        a.es_in = s.ego_episode_start;
-        a.act_i32 = s.ego_actions;
-      } else {
-        a.obs = (f == 1) ? s.obs_next : s.obs_alt;
-        a.es_in = s.es_alt;
-        a.act_i32 = s.alt_actions;
-        a.pos_env = s.alt_pos;
-        a.rec_mask = s.can;
-      }
+      a.prof = ego_f ? prof : nullptr;   // the body's stamps: the ego forward of the stamped step
+      a.obs = ego_f ? s.obs_ego : ((f == 1) ? s.obs_next : s.obs_alt);
+      a.es_in = ego_f ? s.ego_episode_start : s.es_alt;
+      a.act_i32 = ego_f ? s.ego_actions : s.alt_actions;
+      a.pos_env = ego_f ? nullptr : s.alt_pos;
+      a.rec_mask = ego_f ? nullptr : s.can;
       ResidentNet rn;   // the acting agent's set, pointer by pointer (scalar selects)
       rn.w2s = f == 0 ? res_ego.w2s : res_alt.w2s;
       rn.wos = f == 0 ? res_ego.wos : res_alt.wos;
       rn.b1s = f == 0 ? res_ego.b1s : res_alt.b1s;
       rn.b2s = f == 0 ? res_ego.b2s : res_alt.b2s;
       rn.hbs = f == 0 ? res_ego.hbs : res_alt.hbs;
-      policy_fwd16h_body<false, true, true>(a, row0, half, tid, sm, row0 + nrow, rn, ooff);
+      // (the lane number opaque per forward: what the body derives from it -- a few dozen LDS addresses -- is then computed where it
+      // is used instead of once in front of the rollout loop and held, spilled, through every phase of every step)
+      int tid_f = tid;
+      asm volatile("" : "+v"(tid_f));
+      policy_fwd16h_body<false, true, true>(a, row0, half, tid_f, sm, row0 + nrow, rn, ooff);
       __syncthreads();
     }
     PH_STAMP(prof, 9 + 2 * f);
@@ -1315,6 +1328,20 @@ hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, co
   r.alt_T = s.alt_rb->T;
   r.ego_rew_row0 = ego_rew_row0;
   if (reply.params != opening.params) return hipErrorInvalidValue;   // the partner's two forwards share one resident weight set
+  {   // the kernel patches one record per forward: everything outside the patched fields must agree
+    FwdArgs e = ego, p = reply, o = opening;
+    for (FwdArgs* x : {&e, &p, &o}) {
+      x->params = nullptr; x->seed = 0; x->values = nullptr; x->logp = nullptr;
+      x->rb_obs = nullptr; x->rb_act = nullptr; x->rb_rew = nullptr; x->rb_es = nullptr; x->rb_val = nullptr; x->rb_logp = nullptr;
+      x->rb_T = 0; x->counter = 0; x->epoch = nullptr; x->prof = nullptr;
+      x->obs = nullptr; x->es_in = nullptr; x->act_i32 = nullptr; x->pos_env = nullptr; x->rec_mask = nullptr;
+    }
+    if (std::memcmp(&e, &p, sizeof(FwdArgs)) != 0 || std::memcmp(&p, &o, sizeof(FwdArgs)) != 0) return hipErrorInvalidValue;
+    if (reply.seed != opening.seed || reply.values != opening.values || reply.logp != opening.logp || reply.rb_obs != opening.rb_obs ||
+        reply.rb_act != opening.rb_act || reply.rb_rew != opening.rb_rew || reply.rb_es != opening.rb_es || reply.rb_val != opening.rb_val ||
+        reply.rb_logp != opening.rb_logp || reply.rb_T != opening.rb_T)
+      return hipErrorInvalidValue;
+  }
   const size_t half = (sizeof(float) * (size_t)(RES_SCRATCH_FLOATS + 2 * RES_NET_FLOATS) + 15) & ~(size_t)15;
   const size_t lds = 2 * half + 80 * sizeof(int) + ((LIAR_MIRROR_BYTES + 15) & ~15);
   static bool allowed[64] = {false};
