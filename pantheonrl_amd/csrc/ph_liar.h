@@ -31,9 +31,6 @@ __device__ __forceinline__ void liar_load(LiarTable& t, int e, const int* hands,
   t.nm = nmoves[e];
 }
 __device__ __forceinline__ void liar_store_history(const LiarTable& t, int e, int* history, int* nmoves) {
-#if defined(PH_LX_NO_HIST)
-  return;
-#endif
   int4* qp = reinterpret_cast<int4*>(history + (size_t)e * 24);
 #pragma unroll
   for (int i = 0; i < 6; ++i) qp[i] = make_int4(t.hist[4 * i], t.hist[4 * i + 1], t.hist[4 * i + 2], t.hist[4 * i + 3]);
@@ -47,9 +44,6 @@ __device__ __forceinline__ void liar_store_hands(const LiarTable& t, int e, int*
 
 // LiarEnv.getObs (liar.py:53-56): a player's hand + the history padded with the null move [6, 0]; o = 30 floats, 8-byte aligned
 __device__ __forceinline__ void liar_write_obs(const LiarTable& t, bool ego, float* o) {
-#if defined(PH_LX_NO_OBS)
-  return;
-#endif
   float2* o2 = reinterpret_cast<float2*>(o);
 #pragma unroll
   for (int k = 0; k < 3; ++k)
@@ -151,9 +145,6 @@ __device__ __forceinline__ bool liar_deal(LiarTable& t, int e, int* hands, int* 
 // order, so a read-back of a flag behind a store -- or behind the late-reward atomic to HBM -- waits for that store's
 // acknowledgement, and a pass written as "store the flag, read the flag" pays one such wait per flag.
 __device__ __forceinline__ void liar_add_f32(float* p, float v) {
-#if defined(PH_LX_NO_ATOMICS)
-  return;
-#endif
   (void)__builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)p, v);
 }
 // the partner's side of table e: where its next rollout row goes and the state of the reward window of its last recorded row

@@ -1048,6 +1048,211 @@ __device__ __forceinline__ void stage_resident_net(const ResidentNet& rn, const 
   }
 }
 
+// ---- the one-hot forward of at most four rows: one net on ONE wave, no workgroup barrier inside -------------------------------
+// policy_fwd16h_body pads its rows to a 16-row MFMA tile and spreads a layer over four waves, with a workgroup barrier behind every
+// phase; with one to four live rows (the persistent rollout of a 256-table game: ONE table per workgroup) that is a chain of
+// five barriers and 15 padding rows per product.  Here lane j owns hidden unit / logit j of every row: layer 1 is the same
+// component-ordered sum of W1 rows (one coalesced 256-byte load per component), layers 2 / 3 are fmaf chains over k with the
+// activations broadcast from LDS.  v_mfma_f32_16x16x4_f32 IS a k-ordered fmaf chain (test_mfma_and_valu_tiles_agree_bitwise), and
+// the chains here are split exactly like the body's two accumulators (k blocks 0, 2, 4, .. and 1, 3, 5, ..; then their sum), so
+// every logit and value is bitwise what the 16-row body computes for that row.  The row tails are the body's (head_tail32,
+// value_row_tail).  NR: rows held (1, 2 or 4); rows >= n_end are padding.
+template <int NR>
+__device__ __forceinline__ void policy_fwd_rows_wave(const FwdArgs& a, int net, int row0, int n_end, int lane, float* smem,
+                                                     const ResidentNet rn, const int* ooff) {
+  constexpr int R = 16, LDO = 33, FS = 64, TP = (NR + 1) / 2;   // the scratch layout is the body's (RES form)
+  const NetDims& nd = a.nd;
+  float* xs = smem;                 // [16][LDH]  H2 (rows < NR)
+  float* hs = xs + R * LDH;         // [16][LDH]  H1
+  float* outs = hs + R * LDH;
+  const float** feat = (const float**)(outs + R * LDO);
+  int* aoff = (int*)(feat + R * FS);
+  int* seg = aoff + 40;
+  long long* ridxs = (long long*)(seg + 96);
+  const ph_layout& lay = nd.lay;
+  const float* W1 = a.params + (net == 0 ? lay.pi_W1 : lay.vf_W1);
+  const int D = nd.D;
+  auto wave_sync = [] {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  PH_STAMP(a.prof, 0);
+  // ---- hot row of W1 per (row, component): lane = component ----
+  {
+    const float* fv[NR];
+    int lo[NR], hi[NR];
+    float xo[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const bool ok = lane < D && row0 + r < n_end;
+      const int cs = ok ? lane : 0, rs = ok ? row0 + r : row0;
+      lo[r] = ooff[cs];
+      hi[r] = ooff[cs + 1];
+      xo[r] = a.obs[(size_t)rs * D + cs];
+    }
+    long long ridxv = -1;
+    if (net == 0 && lane < NR && row0 + lane < n_end && (a.rb_act || a.rb_logp)) ridxv = rb_row(a, row0 + lane);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int nn = hi[r] - lo[r];
+      int x = (int)xo[r];
+      x = x < 0 ? 0 : (x >= nn ? nn - 1 : x);
+      fv[r] = (lane < D && row0 + r < n_end) ? W1 + (size_t)(lo[r] + x) * HID : ph_zero_row;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) feat[r * FS + lane] = fv[r];
+    if (net == 0 && lane < NR) ridxs[lane] = ridxv;
+  }
+  wave_sync();
+  PH_STAMP(a.prof, 1);
+
+  // ---- layer 1: lane j sums element j of the rows' hot W1 rows, in component order ----
+  typedef const float __attribute__((address_space(1))) * global_f32;
+  float acc[NR];
+  float u_tail[TP];
+#pragma unroll
+  for (int t = 0; t < TP; ++t) u_tail[t] = 0.f;
+  {
+    float w[NR][32];
+    auto gather8 = [&](float* dst, int r, int c0) {   // components c0 .. c0 + 7 of row r (the pointers are wave-uniform: broadcast reads)
+      ulonglong2 q[4];
+      const ulonglong2* fr2 = reinterpret_cast<const ulonglong2*>(feat + r * FS + c0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = fr2[u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(q[u].x), "+v"(q[u].y));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dst[u] = *(global_f32)(((u & 1) ? q[u >> 1].y : q[u >> 1].x) + 4ull * (unsigned)lane);
+    };
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+      if (row0 + r < n_end) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (8 * q < D) gather8(w[r] + 8 * q, r, 8 * q);
+      }
+    if (net == 0 && head_draws(a)) {   // the tails' sampling uniforms, under the gathers' latency
+      const int k = lane & 31, comp = seg[64 + k];
+      const uint64_t ctr = fwd_counter(a);
+#pragma unroll
+      for (int t = 0; t < TP; ++t) {
+        const int r = (lane >> 5) + 2 * t;
+        u_tail[t] = head_draw32(a, row0 + r, r < NR && row0 + r < n_end, comp, ctr);
+      }
+    }
+    float b1 = rn.b1s[lane];
+    asm volatile("" : "+v"(b1));
+#pragma unroll
+    for (int t = 0; t < TP; ++t) asm volatile("" : "+v"(u_tail[t]));   // drawn in front of the wait for the gathers
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      acc[r] = 0.f;
+      if (row0 + r < n_end) {
+        asm volatile("" : "+v"(w[r][0]));   // (otherwise "0 + w[r][0]" moves into the block of the first gathers, with a full wait there)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (8 * q < D) {
+#pragma unroll
+            for (int u = 8 * q; u < 8 * q + 8; ++u) acc[r] += w[r][u];
+          }
+        for (int c0 = 32; c0 < D; c0 += 32) {   // more than 32 components: further batches
+          float w2[32];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (c0 + 8 * q < D) gather8(w2 + 8 * q, r, c0 + 8 * q);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (c0 + 8 * q < D) {
+#pragma unroll
+              for (int u = 8 * q; u < 8 * q + 8; ++u) acc[r] += w2[u];
+            }
+        }
+      }
+      hs[r * LDH + lane] = fast_tanh(acc[r] + b1);
+    }
+  }
+  wave_sync();
+  PH_STAMP(a.prof, 3);
+
+  // out[r][col] = e + o: e takes the k blocks 0, 2, .. of four, o the blocks 1, 3, .. -- the body's two MFMA accumulator chains
+  auto dense = [&](const float* A, const int* arow, int nrows, const float* W, int ldw, int col, float* out) {
+    float e[TP > NR ? TP : NR], o[TP > NR ? TP : NR];
+#pragma unroll
+    for (int r = 0; r < (TP > NR ? TP : NR); ++r) e[r] = o[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float wv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wv[i] = W[(4 * q + i) * ldw + col];
+#pragma unroll
+      for (int r = 0; r < (TP > NR ? TP : NR); ++r) {
+        if (r >= nrows) continue;   // (compile-time)
+        const float4 h = *reinterpret_cast<const float4*>(A + arow[r] * LDH + 4 * q);
+        float& c = (q & 1) ? o[r] : e[r];
+        c = __builtin_fmaf(h.x, wv[0], c);
+        c = __builtin_fmaf(h.y, wv[1], c);
+        c = __builtin_fmaf(h.z, wv[2], c);
+        c = __builtin_fmaf(h.w, wv[3], c);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < (TP > NR ? TP : NR); ++r)
+      if (r < nrows) out[r] = e[r] + o[r];
+  };
+  {
+    int rows[NR];
+    float z2[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) rows[r] = r;
+    dense(hs, rows, NR, rn.w2s, LDH, lane, z2);
+    const float b2 = rn.b2s[lane];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) xs[r * LDH + lane] = fast_tanh(z2[r] + b2);
+  }
+  wave_sync();
+  PH_STAMP(a.prof, 5);
+
+  if (net == 0) {
+    // ---- policy head: the 32 lanes of a half wave hold the 32 logits of a row -- head_tail32's layout: rows (lane >> 5) + 2 t ----
+    const int k = lane & 31, lo = seg[k], last = seg[32 + k], comp = seg[64 + k];
+    int rows[TP];
+    float z3[TP];
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+      const int r = (lane >> 5) + 2 * t;
+      rows[t] = r < NR ? r : 0;
+    }
+    dense(xs, rows, TP, rn.wos, RES_LDO, k, z3);
+    const float hb = rn.hbs[k];
+    PH_STAMP(a.prof, 6);
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+      const int r = (lane >> 5) + 2 * t;
+      if (2 * t >= NR || row0 + 2 * t >= n_end) break;   // no live row in this pass (wave-uniform)
+      head_tail32(a, nd, row0 + r, r < NR && row0 + r < n_end, ridxs[rows[t]], z3[t] + hb, k, lo, last, comp, u_tail[t]);
+    }
+  } else {
+    // ---- value head: four lanes per row, quad-DPP reduction (the body's); then the observation rows of the buffer ----
+    const int r = lane >> 2, q = lane & 3;
+    float v = 0.f, hx[16], hw[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int j = 8 * q + (m & 7) + 32 * (m >> 3);
+      hx[m] = xs[(r < NR ? r : 0) * LDH + j];
+      hw[m] = rn.wos[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v = __builtin_fmaf(hx[m], hw[m], v);
+    v = quad_sum_f(v) + rn.hbs[0];
+    if (q == 0 && r < NR && row0 + r < n_end) value_row_tail(a, row0 + r, v);
+    copy_obs_rows(a, row0, (n_end - row0 < NR) ? n_end - row0 : NR, nd.D, lane, 64);
+  }
+  PH_STAMP(a.prof, 7);
+}
+
 // ---- persistent Liar's Dice self-play rollout ------------------------------------------------------------------------------------
 // n_steps vectorised MultiAgentEnv.step calls of ph_liar_selfplay_step in ONE launch: tables are independent, so one 512-thread
 // workgroup owns up to 16 tables (launch_liar_rollout: as few as spreads them over every CU) for the whole rollout -- ego forward -> move -> partner reply -> move / credit / re-deal -> partner
@@ -1080,6 +1285,9 @@ static size_t fwd16h_lds_bytes();
 template <typename T>
 __device__ __forceinline__ T* rebase(T* mirror, int row0, int per) { return mirror - (size_t)row0 * per; }
 
+// NR: 0 = the 16-row forward (policy_fwd16h_body on the two halves of the workgroup); 1 / 2 / 4 = at most that many tables per
+// workgroup, each net's forward on one wave (policy_fwd_rows_wave)
+template <int NR>
 __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, int half_floats, int rpw) {
   extern __shared__ __attribute__((aligned(16))) float smem_roll[];
   const int tid512 = threadIdx.x, half = tid512 >> 8, tid = tid512 & 255;
@@ -1257,17 +1465,28 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
       a.act_i32 = ego_f ? s.ego_actions : s.alt_actions;
       a.pos_env = ego_f ? nullptr : s.alt_pos;
       a.rec_mask = ego_f ? nullptr : s.can;
-      ResidentNet rn;   // the acting agent's set, pointer by pointer (scalar selects)
-      rn.w2s = f == 0 ? res_ego.w2s : res_alt.w2s;
-      rn.wos = f == 0 ? res_ego.wos : res_alt.wos;
-      rn.b1s = f == 0 ? res_ego.b1s : res_alt.b1s;
-      rn.b2s = f == 0 ? res_ego.b2s : res_alt.b2s;
-      rn.hbs = f == 0 ? res_ego.hbs : res_alt.hbs;
-      // (the lane number opaque per forward: what the body derives from it -- a few dozen LDS addresses -- is then computed where it
-      // is used instead of once in front of the rollout loop and held, spilled, through every phase of every step)
-      int tid_f = tid;
-      asm volatile("" : "+v"(tid_f));
-      policy_fwd16h_body<false, true, true>(a, row0, half, tid_f, sm, row0 + nrow, rn, ooff);
+      if constexpr (NR == 0) {
+        ResidentNet rn;   // the acting agent's set, pointer by pointer (scalar selects)
+        rn.w2s = f == 0 ? res_ego.w2s : res_alt.w2s;
+        rn.wos = f == 0 ? res_ego.wos : res_alt.wos;
+        rn.b1s = f == 0 ? res_ego.b1s : res_alt.b1s;
+        rn.b2s = f == 0 ? res_ego.b2s : res_alt.b2s;
+        rn.hbs = f == 0 ? res_ego.hbs : res_alt.hbs;
+        // (the lane number opaque per forward: what the body derives from it -- a few dozen LDS addresses -- is then computed where
+        // it is used instead of once in front of the rollout loop and held, spilled, through every phase of every step)
+        int tid_f = tid;
+        asm volatile("" : "+v"(tid_f));
+        policy_fwd16h_body<false, true, true>(a, row0, half, tid_f, sm, row0 + nrow, rn, ooff);
+      } else {
+        const int wv = __builtin_amdgcn_readfirstlane(tid512 >> 6);   // waves 0 / 1: the policy / the value net; the others wait
+        if (wv < 2) {
+          float* smn = smem_roll + (size_t)wv * half_floats;
+          const ResidentNet rn = resident_net_at(smn + RES_SCRATCH_FLOATS + (f == 0 ? 0 : RES_NET_FLOATS));
+          int lane_f = tid512 & 63;
+          asm volatile("" : "+v"(lane_f));
+          policy_fwd_rows_wave<NR>(a, wv, row0, row0 + nrow, lane_f, smn, rn, ooff);
+        }
+      }
       __syncthreads();
     }
     PH_STAMP(prof, 9 + 2 * f);
@@ -1344,15 +1563,9 @@ hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, co
   }
   const size_t half = (sizeof(float) * (size_t)(RES_SCRATCH_FLOATS + 2 * RES_NET_FLOATS) + 15) & ~(size_t)15;
   const size_t lds = 2 * half + 80 * sizeof(int) + ((LIAR_MIRROR_BYTES + 15) & ~15);
-  static bool allowed[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   dev = (dev >= 0 && dev < 64) ? dev : 0;
-  if (!allowed[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)liar_rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    allowed[dev] = true;
-  }
   // Tables per workgroup.  The forward's tile is 16 rows, but its one-hot first layer gathers D rows of W1 (256 B each) per
   // table, forward and net through ONE CU's L2 port, and a 256-table game on a 256-CU part leaves 240 CUs idle at 16 tables
   // per workgroup: spread the tables over as many CUs as there are (3.58 -> 2.99 ms per 128-step rollout of 256 tables;
@@ -1371,7 +1584,26 @@ hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, co
   }
   int rpw = forced ? forced : (s.n + cus[dev] - 1) / cus[dev];
   rpw = rpw < 1 ? 1 : (rpw > 16 ? 16 : rpw);
-  hipLaunchKernelGGL(liar_rollout_kernel, dim3((s.n + rpw - 1) / rpw), dim3(512), lds, st, r, (int)(half / sizeof(float)), rpw);
+  // the forward's form: one wave per net for up to four tables per workgroup, the 16-row tile above that (bitwise the same rows)
+  const char* e_form = getenv("PH_LIAR_WAVE_FORWARD");
+  const bool wave_form = !(e_form && e_form[0] == '0');
+  const int form = !wave_form ? 0 : (rpw == 1 ? 1 : (rpw == 2 ? 2 : (rpw <= 4 ? 3 : 0)));
+  static bool allowed[64][4] = {};
+  const void* fn = form == 1 ? (const void*)liar_rollout_kernel<1> : form == 2 ? (const void*)liar_rollout_kernel<2>
+                   : form == 3 ? (const void*)liar_rollout_kernel<4> : (const void*)liar_rollout_kernel<0>;
+  if (!allowed[dev][form]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    allowed[dev][form] = true;
+  }
+  const dim3 grid((s.n + rpw - 1) / rpw), block(512);
+  const int hf = (int)(half / sizeof(float));
+  switch (form) {
+    case 1: hipLaunchKernelGGL(liar_rollout_kernel<1>, grid, block, lds, st, r, hf, rpw); break;
+    case 2: hipLaunchKernelGGL(liar_rollout_kernel<2>, grid, block, lds, st, r, hf, rpw); break;
+    case 3: hipLaunchKernelGGL(liar_rollout_kernel<4>, grid, block, lds, st, r, hf, rpw); break;
+    default: hipLaunchKernelGGL(liar_rollout_kernel<0>, grid, block, lds, st, r, hf, rpw); break;
+  }
   return hipGetLastError();
 }
 
