@@ -1077,6 +1077,7 @@ __device__ __forceinline__ void policy_fwd_rows_wave(const FwdArgs& a, int net, 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   };
+  auto hpos = [](int k) { return 8 * (k >> 3) + 2 * (k & 3) + ((k >> 2) & 1); };   // see dense() below
 
   PH_STAMP(a.prof, 0);
   // ---- hot row of W1 per (row, component): lane = component ----
@@ -1170,36 +1171,40 @@ __device__ __forceinline__ void policy_fwd_rows_wave(const FwdArgs& a, int net, 
             }
         }
       }
-      hs[r * LDH + lane] = fast_tanh(acc[r] + b1);
+      hs[r * LDH + hpos(lane)] = fast_tanh(acc[r] + b1);
     }
   }
   wave_sync();
   PH_STAMP(a.prof, 3);
 
-  // out[r][col] = e + o: e takes the k blocks 0, 2, .. of four, o the blocks 1, 3, .. -- the body's two MFMA accumulator chains
+  // out[r][col] = e + o: e takes the k blocks 0, 2, .. of four, o the blocks 1, 3, .. -- the body's two MFMA accumulator chains,
+  // here the two halves of one packed fmaf chain.  A (this function's own H1 / H2 rows) is stored with unit k at position hpos(k), so
+  // that units k and k + 4 of a block pair are neighbours: a 16-byte broadcast read is two ready-made operand pairs.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   auto dense = [&](const float* A, const int* arow, int nrows, const float* W, int ldw, int col, float* out) {
-    float e[TP > NR ? TP : NR], o[TP > NR ? TP : NR];
+    constexpr int MR = TP > NR ? TP : NR;
+    f32x2 eo[MR];
 #pragma unroll
-    for (int r = 0; r < (TP > NR ? TP : NR); ++r) e[r] = o[r] = 0.f;
+    for (int r = 0; r < MR; ++r) eo[r] = f32x2{0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      float wv[4];
+    for (int P = 0; P < 8; ++P) {
+      f32x2 wv[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wv[i] = W[(4 * q + i) * ldw + col];
+      for (int i = 0; i < 4; ++i) wv[i] = f32x2{W[(8 * P + i) * ldw + col], W[(8 * P + 4 + i) * ldw + col]};
 #pragma unroll
-      for (int r = 0; r < (TP > NR ? TP : NR); ++r) {
+      for (int r = 0; r < MR; ++r) {
         if (r >= nrows) continue;   // (compile-time)
-        const float4 h = *reinterpret_cast<const float4*>(A + arow[r] * LDH + 4 * q);
-        float& c = (q & 1) ? o[r] : e[r];
-        c = __builtin_fmaf(h.x, wv[0], c);
-        c = __builtin_fmaf(h.y, wv[1], c);
-        c = __builtin_fmaf(h.z, wv[2], c);
-        c = __builtin_fmaf(h.w, wv[3], c);
+        const float4 ha = *reinterpret_cast<const float4*>(A + arow[r] * LDH + 8 * P);
+        const float4 hb = *reinterpret_cast<const float4*>(A + arow[r] * LDH + 8 * P + 4);
+        eo[r] = __builtin_elementwise_fma(f32x2{ha.x, ha.y}, wv[0], eo[r]);
+        eo[r] = __builtin_elementwise_fma(f32x2{ha.z, ha.w}, wv[1], eo[r]);
+        eo[r] = __builtin_elementwise_fma(f32x2{hb.x, hb.y}, wv[2], eo[r]);
+        eo[r] = __builtin_elementwise_fma(f32x2{hb.z, hb.w}, wv[3], eo[r]);
       }
     }
 #pragma unroll
-    for (int r = 0; r < (TP > NR ? TP : NR); ++r)
-      if (r < nrows) out[r] = e[r] + o[r];
+    for (int r = 0; r < MR; ++r)
+      if (r < nrows) out[r] = eo[r][0] + eo[r][1];
   };
   {
     int rows[NR];
@@ -1209,7 +1214,7 @@ __device__ __forceinline__ void policy_fwd_rows_wave(const FwdArgs& a, int net, 
     dense(hs, rows, NR, rn.w2s, LDH, lane, z2);
     const float b2 = rn.b2s[lane];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) xs[r * LDH + lane] = fast_tanh(z2[r] + b2);
+    for (int r = 0; r < NR; ++r) xs[r * LDH + hpos(lane)] = fast_tanh(z2[r] + b2);
   }
   wave_sync();
   PH_STAMP(a.prof, 5);
@@ -1240,7 +1245,7 @@ __device__ __forceinline__ void policy_fwd_rows_wave(const FwdArgs& a, int net, 
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       const int j = 8 * q + (m & 7) + 32 * (m >> 3);
-      hx[m] = xs[(r < NR ? r : 0) * LDH + j];
+      hx[m] = xs[(r < NR ? r : 0) * LDH + hpos(j)];
       hw[m] = rn.wos[j];
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1419,6 +1424,7 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
     const size_t row = (size_t)t * g.n;
     long long* prof = (t == 2) ? r.ego.prof : nullptr;   // debug stamps of the third step (scripts/liar_rollout_profile.py)
     if (f == 0) PH_STAMP(prof, 8);
+    if (ph == 0) PH_STAMP(r.ego.prof, 15);   // start of step 0: (slot 8 - slot 15) / 2 = a step without stamps
     // A partner forward none of this workgroup's tables asks for is skipped: the reply where every game ended with the ego's
     // move (running = 0), the opening where no fresh game starts with the partner (alt_opens = 0).  For such tables the
     // launch-by-launch walk computes a forward whose only outputs are scratch (alt_actions / the log-prob cache of a table
@@ -1503,6 +1509,7 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
     PH_STAMP(prof, 10 + 2 * f);
   }
 
+  PH_STAMP(r.ego.prof, 2);   // end of the last step: (slot 2 - slot 15) / n_steps = the average step, stamped step included
   // ---- mirror out ----
   auto copy_out = [&](auto* dst, const auto* src, int per) {
     for (int i = tid512; i < nrow * per; i += 512) dst[(size_t)row0 * per + i] = src[i];

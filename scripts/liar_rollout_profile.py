@@ -38,6 +38,7 @@ print(f"  book-keeping after reply   {med(11, 12):8.0f}")
 print(f"  opening forward            {med(12, 13):8.0f}")
 print(f"  book-keeping after opening {med(13, 14):8.0f}")
 print(f"  whole step                 {med(8, 14):8.0f}")
+print(f"  a step without stamps (steps 0 and 1) {med(15, 8) / 2:8.0f}; average over the {T} steps {med(15, 2) / T:8.0f}")
 print("ego forward of that step, by phase (policy half):")
 print(f"  step top -> forward body (argument record)     {med(8, 0):8.0f}")
 print(f"  loads issued, hot positions -> LDS + barrier   {med(0, 1):8.0f}")
