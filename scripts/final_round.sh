@@ -6,7 +6,7 @@ TAG=${1:-rXX}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 420 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1
+timeout 900 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1
 grep -E "passed|failed|error" $OUT/gpu_tests.log | tail -2
 timeout 150 python bench.py > $OUT/bench_stdout.json 2> $OUT/bench.log
 tail -c 300 $OUT/bench_stdout.json | head -c 0
