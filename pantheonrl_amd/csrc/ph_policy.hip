@@ -1061,6 +1061,7 @@ template <int NR>
 __device__ __forceinline__ void policy_fwd_rows_wave(const FwdArgs& a, int net, int row0, int n_end, int lane, float* smem,
                                                      const ResidentNet rn, const int* ooff) {
   constexpr int R = 16, LDO = 33, FS = 64, TP = (NR + 1) / 2;   // the scratch layout is the body's (RES form)
+  constexpr int LDR = 68;   // row stride of this function's own H1 / H2 rows (inside the body's [16][LDH] areas): 16-byte aligned rows
   const NetDims& nd = a.nd;
   float* xs = smem;                 // [16][LDH]  H2 (rows < NR)
   float* hs = xs + R * LDH;         // [16][LDH]  H1
@@ -1171,7 +1172,7 @@ __device__ __forceinline__ void policy_fwd_rows_wave(const FwdArgs& a, int net, 
             }
         }
       }
-      hs[r * LDH + hpos(lane)] = fast_tanh(acc[r] + b1);
+      hs[r * LDR + hpos(lane)] = fast_tanh(acc[r] + b1);
     }
   }
   wave_sync();
@@ -1194,8 +1195,8 @@ __device__ __forceinline__ void policy_fwd_rows_wave(const FwdArgs& a, int net, 
 #pragma unroll
       for (int r = 0; r < MR; ++r) {
         if (r >= nrows) continue;   // (compile-time)
-        const float4 ha = *reinterpret_cast<const float4*>(A + arow[r] * LDH + 8 * P);
-        const float4 hb = *reinterpret_cast<const float4*>(A + arow[r] * LDH + 8 * P + 4);
+        const float4 ha = *reinterpret_cast<const float4*>(A + arow[r] * LDR + 8 * P);
+        const float4 hb = *reinterpret_cast<const float4*>(A + arow[r] * LDR + 8 * P + 4);
         eo[r] = __builtin_elementwise_fma(f32x2{ha.x, ha.y}, wv[0], eo[r]);
         eo[r] = __builtin_elementwise_fma(f32x2{ha.z, ha.w}, wv[1], eo[r]);
         eo[r] = __builtin_elementwise_fma(f32x2{hb.x, hb.y}, wv[2], eo[r]);
@@ -1214,7 +1215,7 @@ __device__ __forceinline__ void policy_fwd_rows_wave(const FwdArgs& a, int net, 
     dense(hs, rows, NR, rn.w2s, LDH, lane, z2);
     const float b2 = rn.b2s[lane];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) xs[r * LDH + hpos(lane)] = fast_tanh(z2[r] + b2);
+    for (int r = 0; r < NR; ++r) xs[r * LDR + hpos(lane)] = fast_tanh(z2[r] + b2);
   }
   wave_sync();
   PH_STAMP(a.prof, 5);
@@ -1245,7 +1246,7 @@ __device__ __forceinline__ void policy_fwd_rows_wave(const FwdArgs& a, int net, 
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       const int j = 8 * q + (m & 7) + 32 * (m >> 3);
-      hx[m] = xs[(r < NR ? r : 0) * LDH + hpos(j)];
+      hx[m] = xs[(r < NR ? r : 0) * LDR + hpos(j)];
       hw[m] = rn.wos[j];
     }
     __builtin_amdgcn_sched_barrier(0);
