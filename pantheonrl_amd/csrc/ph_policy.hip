@@ -1451,7 +1451,10 @@ __global__ __launch_bounds__(512) void liar_rollout_kernel(LiarRolloutArgs r, in
       // The three argument records share everything but the fields below (ph_liar_selfplay_rollout builds them: same spec, same
       // table count; launch_liar_rollout checks what this relies on).  Selecting whole records -- three kernarg reads of ~1 KB and a
       // few hundred scalar selects per forward -- cost 2.2 k cycles of a 29.7 k-cycle step.
-      FwdArgs a = r.ego;
+      FwdArgs a;
+      __builtin_memset(&a, 0, sizeof(a));   // every field not set below IS zero in the three records (checked at the launch): the
+      a.nd = r.ego.nd;                      // tails' optional paths (masks, given actions, logits out, ...) fold away
+      a.n = r.ego.n;
       const bool ego_f = f == 0;
       a.params = ego_f ? r.ego.params : r.reply.params;
       a.seed = ego_f ? r.ego.seed : r.reply.seed;
@@ -1564,6 +1567,11 @@ hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, co
       x->obs = nullptr; x->es_in = nullptr; x->act_i32 = nullptr; x->pos_env = nullptr; x->rec_mask = nullptr;
     }
     if (std::memcmp(&e, &p, sizeof(FwdArgs)) != 0 || std::memcmp(&p, &o, sizeof(FwdArgs)) != 0) return hipErrorInvalidValue;
+    FwdArgs z;   // ... and be zero apart from the spec and the table count (the kernel builds its record from exactly these)
+    std::memset(&z, 0, sizeof(z));
+    z.nd = ego.nd;
+    z.n = ego.n;
+    if (std::memcmp(&e, &z, sizeof(FwdArgs)) != 0) return hipErrorInvalidValue;
     if (reply.seed != opening.seed || reply.values != opening.values || reply.logp != opening.logp || reply.rb_obs != opening.rb_obs ||
         reply.rb_act != opening.rb_act || reply.rb_rew != opening.rb_rew || reply.rb_es != opening.rb_es || reply.rb_val != opening.rb_val ||
         reply.rb_logp != opening.rb_logp || reply.rb_T != opening.rb_T)
