@@ -1,5 +1,5 @@
 #!/bin/bash
-# on the GPU box: the 8-rank config-5 bench invocation of tests/test_gpu_bench.py, N times per rollout form, every run's exit
+# on the GPU box: the 8-rank config-5 bench invocation of tests/test_gpu_zz_bench.py, N times per rollout form, every run's exit
 # code, wall time and (on failure) stderr kept: scripts/flake_loop.sh [N=10] [budget_seconds=600] -> gpurun_out/flake/
 cd "$(dirname "$0")/.."
 N=${1:-10}; BUDGET=${2:-600}
