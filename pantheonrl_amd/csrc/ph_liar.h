@@ -1,6 +1,7 @@
 // Liar's Dice on the device: a table's state, the game rules (pantheonrl/envs/liargym/liar.py:53-102) and the per-table
-// book-keeping of the vectorised self-play step as lane functions -- shared by the per-step kernels (ph_envs.hip) and the
-// persistent rollout kernel (ph_policy.hip: liar_rollout_kernel), which therefore run the same integer code.
+// book-keeping of the vectorised self-play step as lane functions (one lane per table): what the per-step kernels run
+// (ph_envs.hip).  The persistent rollout kernel (ph_policy.hip: liar_rollout_kernel) runs the same rules with a table spread over
+// 32 lanes (ph_liar_group.h); tests hold the two forms bitwise equal.
 #pragma once
 #include "ph_launch.h"
 

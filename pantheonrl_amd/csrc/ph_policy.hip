@@ -1262,10 +1262,11 @@ __device__ __forceinline__ void policy_fwd_rows_wave(const FwdArgs& a, int net, 
 // ---- persistent Liar's Dice self-play rollout ------------------------------------------------------------------------------------
 // n_steps vectorised MultiAgentEnv.step calls of ph_liar_selfplay_step in ONE launch: tables are independent, so one 512-thread
 // workgroup owns up to 16 tables (launch_liar_rollout: as few as spreads them over every CU) for the whole rollout -- ego forward -> move -> partner reply -> move / credit / re-deal -> partner
-// opening -> move -- with workgroup barriers where the launch-by-launch walk has kernel boundaries.  The lower half of the
-// workgroup runs the policy net of the acting agent, the upper half its value net (policy_fwd16h_body<.., FUSED>), sixteen lanes
-// run the per-table book-keeping (ph_liar.h: the very functions of the per-step kernels), so every number that is read again
-// (game state, observations, both buffers, book-keeping, cached values) is bitwise what 6 x n_steps launches produce; what
+// opening -> move -- with workgroup barriers where the launch-by-launch walk has kernel boundaries.  With more than four tables per
+// workgroup its lower half runs the policy net of the acting agent, its upper half the value net (policy_fwd16h_body<.., FUSED>); with
+// up to four, each net runs on one wave (policy_fwd_rows_wave: the same rows bit for bit).  A table's book-keeping runs on the 32 lanes
+// of a half wave (ph_liar_group.h: the rules of ph_liar.h's per-step lane functions, restated for that layout), so every number that is
+// read again (game state, observations, both buffers, book-keeping, cached values) is bitwise what 6 x n_steps launches produce; what
 // disappears is their ~1 us per dependent cold-cache round trip, the launch boundaries, and the partner forwards whose outputs
 // would be scratch (see the loop).
 struct LiarRolloutArgs {
