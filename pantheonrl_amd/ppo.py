@@ -115,7 +115,7 @@ class RolloutBuffer:
 
     def add_reward(self, reward, env_mask=None, pos: Optional[int] = None) -> None:
         """buf.rewards[pos-1][e] += reward[e] <- Agent.update, agents.py:198 (vectorised over envs)."""
-        row = self.pos - 1 if pos is None else pos
+        row = (self.pos - 1) % self.buffer_size if pos is None else pos   # rewards[pos - 1]: numpy's wrap at pos == 0 (agents.py:198)
         if (env_mask is None and self.n_envs == 1 and isinstance(reward, np.ndarray) and reward.size == 1):
             reward = float(reward.reshape(-1)[0])
         if env_mask is None and isinstance(reward, (int, float, np.floating, np.integer)):
@@ -158,7 +158,7 @@ class RolloutBuffer:
     def add_reward_scalar(self, reward: float) -> None:
         """add_reward for Agent.update's own signature -- one float for the last row written -- without the dispatch around it"""
         self._bind()
-        rc = self.ctx.lib.ph_buffer_add_reward_const(self.ctx.handle, self.c_ref(), self.pos - 1, reward)
+        rc = self.ctx.lib.ph_buffer_add_reward_const(self.ctx.handle, self.c_ref(), (self.pos - 1) % self.buffer_size, reward)
         if rc:
             nat.check(rc)
 

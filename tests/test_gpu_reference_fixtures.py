@@ -1,0 +1,237 @@
+"""gpu: the reference-generated fixtures (tests/golden/ref_*.json, ref_adap_context.npz -- produced by the REFERENCE's own Python text,
+tests/golden/make_reference_fixtures.py) replayed through the DEVICE path: `pantheonrl_amd.common` classes around gfx950-backed PPO
+learners, and `ph_adap_minibatch_grad` for ADAP's context term.
+
+What the policy samples differs from what the reference's recording model scripted, so the comparison is on everything that does not
+depend on the sampled action: the stream the ego sees, the callback sequence every partner receives, the rows (observations,
+episode starts, late additive rewards -- f32 adds in the reference's order, bit-exact) each device buffer holds when GAE is asked
+for, what GAE is handed (the cached values of the previous call, the last update's done), and the train / reset order.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch as th
+
+from tests import refdrive as rd
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _json(name):
+    with open(os.path.join(GOLDEN, name)) as fh:
+        return json.load(fh)
+
+
+def _device_ppo(D, n_act, n_steps, seed):
+    from pantheonrl_amd import PPO
+    from pantheonrl_amd import spaces as sp
+    env = type("E", (), dict(observation_space=sp.Box(-np.inf, np.inf, (D,)), action_space=sp.Discrete(n_act),
+                             _is_dummy_space_env=True))()
+    return PPO("MlpPolicy", env, n_steps=n_steps, batch_size=n_steps, n_epochs=1, seed=seed)
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if isinstance(x, th.Tensor) else np.asarray(x)
+
+
+class _Tap:
+    """a partner seat that logs in RecordingAgent's format and forwards to the real device learner"""
+
+    def __init__(self, agent):
+        self.agent, self.log, self.acts = agent, [], []
+
+    def get_action(self, obs, record=True):
+        self.log.append(["act", rd.plain(obs.obs), rd.plain(obs.state), rd.plain(obs.action_mask), bool(record)])
+        a = self.agent.get_action(obs, record)
+        self.acts.append(int(a))
+        return a
+
+    def update(self, reward, done):
+        self.log.append(["upd", rd.plain(reward), bool(done)])
+        self.agent.update(reward, done)
+
+
+def _rows_from_log(log):
+    """the buffer rows the reference's OnPolicyAgent would hold after this callback sequence (agents.py:172-179,197-198): per recorded
+    action its observation, the done of the update before it (first row: True, :98), and the f32 running sum of its rewards"""
+    obs, starts, rew, last = [], [], [], True
+    for e in log:
+        if e[0] == "act":
+            obs.append(e[1])
+            starts.append(float(last))
+            rew.append(np.float32(0))
+        else:
+            rew[-1] = np.float32(rew[-1] + np.float32(e[1]))
+            last = e[2]
+    return np.asarray(obs, np.float32), np.asarray(starts, np.float32), np.asarray(rew, np.float32)
+
+
+def test_round_robin_partners_on_the_device_receive_the_reference_callbacks():
+    """BASELINE config 4's host logic (multiagentenv.py:118-125,149-243) with three gfx950-backed OnPolicyAgent partners: the ego's
+    stream and every partner's callback log equal the reference-generated ones; each device buffer then holds exactly the rows that
+    callback sequence implies"""
+    from pantheonrl_amd.common import OnPolicyAgent, SimultaneousEnv
+    ref = _json("ref_multiagent.json")["simultaneous"]
+    T, K = 120, 3
+
+    class Env(rd._SimGame, SimultaneousEnv):
+        def __init__(self):
+            SimultaneousEnv.__init__(self)
+            rd._SimGame.__init__(self, 0, T)
+
+    env = Env()
+    taps = [_Tap(OnPolicyAgent(_device_ppo(3, 4, 64, seed=k))) for k in range(K)]
+    for t in taps:
+        env.add_partner_agent(t)
+    ego = json.loads(json.dumps(rd._ego_loop(env, T)))
+    assert ego == ref["ego"]
+    for k, t in enumerate(taps):
+        assert json.loads(json.dumps(t.log)) == ref["partners"][k], f"partner {k}"
+        obs, starts, rew = _rows_from_log(ref["partners"][k])
+        n = len(obs)
+        assert 10 < n <= 64 and t.agent.model.rollout_buffer.pos == n and t.agent.iteration == 0
+        got = t.agent.model.rollout_buffer.host()
+        assert np.array_equal(got["observations"][:n, 0], obs)
+        assert np.array_equal(got["episode_starts"][:n, 0], starts)
+        assert np.array_equal(got["rewards"][:n, 0], rew), (got["rewards"][:n, 0] - rew)
+        assert np.array_equal(got["actions"][:n, 0, 0].astype(int), np.asarray(t.acts))
+        assert 0 <= min(t.acts) and max(t.acts) < 4
+    # the joint action the game received: the ego's 0 and whatever the seated partner played
+    flat = [a for t in taps for a in t.acts]
+    assert sorted(j[1] for j in env.joint) == sorted(flat)
+
+
+def test_onpolicy_agent_on_the_device_follows_the_reference_schedule():
+    """agents.py:111-203 with a gfx950-backed PPO under the fixture's stream of (observation, updates): at every buffer fill GAE is
+    handed the PREVIOUS call's values and the last update's done, the buffer holds the reference's rows, train and reset follow in
+    that order, and the agent's counters / ep_info_buffer equal the reference's after every call"""
+    from pantheonrl_amd.common import Observation, OnPolicyAgent
+    kw = rd.RECORDED_ONLY
+    ref = _json("ref_onpolicy_agent.json")["recorded_only"]
+    model = _device_ppo(kw["D"], 3, kw["n_steps"], seed=0)
+    agent = OnPolicyAgent(model, tb_log_name="fixture_agent")
+    buf, events = model.rollout_buffer, []
+    real_gae, real_train, real_reset = buf.compute_returns_and_advantage, model.train, buf.reset
+
+    def gae(last_values, dones):
+        th.cuda.synchronize()
+        h = buf.host()
+        events.append(["gae", _np(last_values).copy(), dones, h["rewards"][:, 0].copy(), h["observations"][:, 0].copy(),
+                       h["episode_starts"][:, 0].copy()])
+        real_gae(last_values=last_values, dones=dones)
+
+    def train(*a, **k):
+        events.append(["train", buf.host()["advantages"][:, 0].copy()])
+        real_train(*a, **k)
+
+    def reset():
+        events.append(["reset"])
+        real_reset()
+    buf.compute_returns_and_advantage, model.train, buf.reset = gae, train, reset
+
+    ref_ev = ref["events"]
+    ref_states = [e for e in ref_ev if e[0] == "state"]
+    ref_updated = [e for e in ref_ev if e[0] == "updated"]
+    ref_adds = [e for e in ref_ev if e[0] == "add"]
+    values_seen, n_upd = [], 0
+    for i, (obs, record, upd) in enumerate(rd.onpolicy_script(kw["seed"], kw["n_calls"], kw["D"], kw["p_skip"])):
+        events.append(["get_action", record])
+        act = agent.get_action(Observation(obs), record=record)
+        assert 0 <= int(act) < 3
+        values_seen.append(_np(agent.values).reshape(-1).copy())
+        st = ref_states[i]
+        assert [agent.n_steps, agent.num_timesteps, agent.iteration] == st[1:4] and rd.plain(agent._last_episode_starts) == st[4]
+        assert rd.plain(list(model.ep_info_buffer)) == st[6]
+        for r, d in upd:
+            agent.update(r, d)
+            u = ref_updated[n_upd]
+            n_upd += 1
+            th.cuda.synchronize()
+            assert np.array_equal(buf.rewards[:, 0].cpu().numpy(), np.asarray(u[3], np.float32)), (i, u)
+            assert rd.plain(agent._last_episode_starts) == u[4] and rd.plain(list(model.ep_info_buffer)) == u[5]
+    skeleton = [e[0] for e in events]
+    assert skeleton == [e[0] for e in ref_ev if e[0] in ("get_action", "gae", "train", "reset")]
+    assert skeleton.count("train") == 5
+    gaes, ref_gaes, call = [e for e in events if e[0] == "gae"], [e for e in ref_ev if e[0] == "gae"], -1
+    fill = 0
+    for e in events:
+        if e[0] == "get_action":
+            call += 1
+        if e[0] != "gae":
+            continue
+        r = ref_gaes[fill]
+        assert np.array_equal(e[1].reshape(-1), values_seen[call - 1])                 # D-1: V of the PREVIOUS observation
+        assert e[2] == r[2] and isinstance(e[2], bool)                                # the last update's done
+        assert np.array_equal(e[3], np.asarray(r[3], np.float32))                     # rewards, bit for bit
+        rows = ref_adds[fill * kw["n_steps"]:(fill + 1) * kw["n_steps"]]
+        assert np.array_equal(e[4], np.asarray([a[2][0] for a in rows], np.float32))
+        assert np.array_equal(e[5], np.asarray([float(a[5][0]) for a in rows], np.float32))
+        fill += 1
+    assert fill == len(gaes) == len(ref_gaes)
+    adv = [e[1] for e in events if e[0] == "train"]
+    assert all(np.isfinite(a).all() and np.abs(a).max() > 0 for a in adv)             # GAE ran before train
+
+
+ADAP_SPEC = {"discrete6": ("discrete", (6,)), "multi_7_12": ("multidiscrete", (7, 12)), "two_contexts": ("discrete", (5,))}
+
+
+@pytest.mark.parametrize("name", list(ADAP_SPEC))
+def test_device_context_term_matches_the_reference_function(name):
+    """`ph_adap_minibatch_grad` against the REFERENCE's get_context_kl_loss (adap/util.py:97-131) on the states and contexts the
+    reference drew: the reported loss within 1e-5, and coef * d(loss)/d(params) -- isolated as g(coef) - g(0) -- within
+    2e-6 + 2e-4 * coef * max|g_ref| (f32 sums in another order; v_exp / v_rcp tanh and softmax)"""
+    from pantheonrl_amd import _native as nat
+    from pantheonrl_amd import spaces as sp
+    from pantheonrl_amd.ppo import PPO, ActorCriticPolicy, RolloutBuffer
+    from oracle import sb3_oracle as orc
+    from tests.golden.make_reference_fixtures import ADAP_CASES
+    c = ADAP_CASES[name]
+    z = np.load(os.path.join(GOLDEN, "ref_adap_context.npz"))
+    obs, params = z[f"{name}.observations"], z[f"{name}.params"]
+    sidx, ctxs = z[f"{name}.state_idx"], z[f"{name}.contexts"]
+    B, cs = c["B"], c["ctx"]
+    obs_space = sp.Box(-np.inf, np.inf, (c["F"] + cs,))
+    act_space = sp.Discrete(c["nvec"][0]) if len(c["nvec"]) == 1 else sp.MultiDiscrete(list(c["nvec"]))
+    pol = ActorCriticPolicy(obs_space, act_space, device="cuda", seed=0)
+    pol.set_flat_params(params)
+    buf = RolloutBuffer(B, obs_space, act_space, pol.device, pol.ctx, pol.spec, n_envs=1)      # env-major flat row = t
+    rng = np.random.default_rng(0)
+    buf.observations.copy_(th.as_tensor(obs).reshape(B, 1, -1))
+    buf.actions.copy_(th.as_tensor(np.stack([rng.integers(0, n, B) for n in c["nvec"]], 1).astype(np.float32)).reshape(B, 1, -1))
+    for k in ("advantages", "returns", "values", "log_probs"):
+        getattr(buf, k).copy_(th.as_tensor(rng.standard_normal((B, 1)).astype(np.float32) * (0.1 if k == "log_probs" else 1.0)))
+    buf.pos, buf.full = B, True
+    model = PPO.__new__(PPO)
+    for k, v in vars(orc.PPOHyper()).items():
+        setattr(model, k, v)
+    hp = PPO.hyper(model)
+    idx = th.arange(B, dtype=th.int32, device="cuda")
+    coef = 5.0
+
+    def grad(coefficient):
+        ad = nat.PhAdapLoss()
+        ad.context_size, ad.num_context_samples, ad.num_state_samples = cs, c["n_ctx"], c["n_states"]
+        ad.sampler, ad.context_loss_coeff, ad.seed = nat.CONTEXT_SAMPLERS[c["sampler"]], coefficient, 0
+        s = np.full(c["n_states"], -1, np.int32)
+        s[:len(sidx)] = sidx
+        keep = [th.as_tensor(s[None]).cuda(), th.as_tensor(np.ascontiguousarray(ctxs[None], np.float32)).cuda(), th.zeros(1, device="cuda")]
+        ad.state_idx, ad.contexts, ad.context_loss = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
+        g = th.zeros(pol.layout.P, device="cuda")
+        st = th.zeros(nat.PH_NSTAT, device="cuda")
+        pol._bind()
+        nat.check(pol.ctx.lib.ph_adap_minibatch_grad(pol.ctx.handle, C.byref(pol.spec), pol.params.data_ptr(), C.byref(buf.c_struct()),
+                                                     C.byref(hp), idx.data_ptr(), B, g.data_ptr(), st.data_ptr(), 0, C.byref(ad)))
+        th.cuda.synchronize()
+        return g.cpu().numpy(), float(keep[2].item())
+
+    g0, _ = grad(0.0)
+    g1, loss = grad(coef)
+    assert abs(loss - float(z[f"{name}.loss"])) <= 1e-5, (loss, float(z[f"{name}.loss"]))
+    g_ref = coef * z[f"{name}.grad"]
+    err = np.abs((g1 - g0) - g_ref)
+    assert err.max() <= 2e-6 + 2e-4 * np.abs(g_ref).max(), (err.max(), np.abs(g_ref).max())
+    assert np.abs(g_ref).max() > 1e-3
