@@ -542,6 +542,7 @@ def main():
         # per-step all-gather route: auto = time engine-side RCCL against direct peer-to-peer stores on this node, keep the faster
         exchange.requested_route = os.environ.get("PANTHEON_EXCHANGE", "auto")
 
+    rollout_requested = args.rollout
     if mode == "graph":
         if args.rollout == "scripted":
             lay = agents[0].model.policy.layout
@@ -665,6 +666,9 @@ def main():
                    # launch per environment step
                    "rollout": (args.rollout if mode == "graph" else getattr(steps, "last_rollout_mode", "stepwise")
                                if mode == "fusedstep" else "stepwise"),
+                   # what --rollout asked for: differs from "rollout" when the workload's shapes are outside the one-launch
+                   # rollout's class (F <= 64, one action component, <= 8 logits) and the run fell back to one launch per step
+                   "rollout_requested": rollout_requested,
                    # Weak-scaling efficiency is value(N) / (N * value(1)) of the DEFAULT invocations: N = 1 runs the scripted
                    # one-launch rollout without any exchange, N > 1 the persistent one-launch exchange rollout, so both ends of the
                    # ratio launch a rollout once; `stepwise_rollout` is the base to use if a run fell back to one launch per step.

@@ -177,11 +177,12 @@ __global__ __launch_bounds__(64) void p2p_wait_kernel(ph_p2p x, int t) {
   const long long t0 = wall_clock64();
   bool ok = false;
   unsigned long long seen = 0ull;
+  int polls = 0;
   while (true) {
     seen = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (seen >= want) { ok = true; break; }
     if ((unsigned long long)(wall_clock64() - t0) > x.timeout_cycles) break;
-    __builtin_amdgcn_s_sleep(8);
+    poll_backoff(polls);
   }
   if (!ok) p2p_note_timeout(x.error, 3, t, (unsigned long long)src, want, seen);
   __threadfence_system();
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void p2p_ll_unpack_kernel(ph_p2p x, int t, int
   const unsigned long long* word = x.ll[x.rank] + (size_t)slot * x.world * x.count + i;
   const long long t0 = wall_clock64();
   unsigned long long v;
+  int polls = 0;
   while (true) {
     v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((unsigned)(v >> 32) == want) break;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void p2p_ll_unpack_kernel(ph_p2p x, int t, int
       p2p_note_timeout(x.error, 2, t, (unsigned long long)i, want, v);
       break;
     }
-    __builtin_amdgcn_s_sleep(2);
+    poll_backoff(polls);
   }
   x.joint[t & 1][x.rank][i] = (int)(unsigned)v;
 }
@@ -239,6 +241,7 @@ hipError_t launch_p2p_ll_unpack(const ph_p2p& x, int t, hipStream_t s, int slot)
 __device__ __forceinline__ bool rr_wait(const unsigned long long* flag, unsigned long long want, unsigned long long timeout,
                                         unsigned long long* error) {
   const long long t0 = wall_clock64();
+  int polls = 0;
   while (true) {
     const unsigned long long seen = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (seen >= want) return true;
@@ -246,7 +249,7 @@ __device__ __forceinline__ bool rr_wait(const unsigned long long* flag, unsigned
       p2p_note_timeout(error, 4, 0, 0ull, want, seen);
       return false;
     }
-    __builtin_amdgcn_s_sleep(8);
+    poll_backoff(polls);
   }
 }
 

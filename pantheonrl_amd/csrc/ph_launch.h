@@ -23,6 +23,19 @@ __device__ __forceinline__ void p2p_note_timeout(unsigned long long* error, int 
   }
 }
 
+// Back-off of a bounded in-kernel wait for a word another process (or block) writes.  The first polls are ~60 ns apart (a healthy
+// peer answers within a few); then the wave backs off, up to ~4 us between polls: a waiter that shares its device with the rank it
+// waits for (test boxes: N ranks on one GPU) must not take the issue slots and the fabric bandwidth the peer's stores need.
+__device__ __forceinline__ void poll_backoff(int& polls) {
+  if (polls < 16) __builtin_amdgcn_s_sleep(2);
+  else if (polls < 64) __builtin_amdgcn_s_sleep(16);
+  else __builtin_amdgcn_s_sleep(127);
+  ++polls;
+}
+
+// NOTE for new fields: liar_rollout_kernel (ph_policy.hip) rebuilds its three records from {nd, n} plus the fields
+// launch_liar_rollout lists as patched, and the launcher refuses records whose other bytes are not zero -- a field added here must
+// either stay zero on that path or join both lists.
 struct FwdArgs {
   NetDims nd;
   const float* params;

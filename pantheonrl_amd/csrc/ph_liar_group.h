@@ -80,9 +80,14 @@ __device__ __forceinline__ LiarOutcome liar_grp_move(const LiarMirror& m, int i,
   int a0 = act[2 * i], a1 = act[2 * i + 1];
   const int h0 = hist[0], h1 = hist[1];
   const int j = l - 6;                                       // history word of observation element l
-  const int w_m2 = hist[(l >= 2 && l < 24) ? l - 2 : 0], w_0 = hist[l < 24 ? l : 0];
-  const int o_m2 = hist[(j >= 2 && j < 24) ? j - 2 : 0], o_0 = hist[(j >= 0 && j < 24) ? j : 0];
-  const int hand = m.hands[12 * i + (ego ? 6 : 0) + (l < 6 ? l : 0)];   // the other player's hand (getObs(not isego))
+  const int w_m2_ld = hist[(l >= 2 && l < 24) ? l - 2 : 0], w_0_ld = hist[l < 24 ? l : 0];
+  const int o_m2_ld = hist[(j >= 2 && j < 24) ? j - 2 : 0], o_0_ld = hist[(j >= 0 && j < 24) ? j : 0];
+  int hand = m.hands[12 * i + (ego ? 6 : 0) + (l < 6 ? l : 0)];   // the other player's hand (getObs(not isego))
+  int w_m2 = w_m2_ld, w_0 = w_0_ld, o_m2 = o_m2_ld, o_0 = o_0_ld;
+  // Other lanes overwrite the words this lane just read (lane l - 2 stores hist[l - 2] below; obs_next / obs2 may alias what a
+  // caller reads next).  Per thread those addresses do not alias, so nothing but this keeps the loads above the stores: the values
+  // are made opaque (they must be in registers here) and no memory access may move across.
+  asm volatile("" : "+v"(w_m2), "+v"(w_0), "+v"(o_m2), "+v"(o_0), "+v"(hand) : : "memory");
   bool call = false;
   if (nm > 0) {
     if (a1 <= h1 || a0 == LD_SIDES) call = true;

@@ -1560,7 +1560,11 @@ hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, co
   r.ego_rew_row0 = ego_rew_row0;
   if (reply.params != opening.params) return hipErrorInvalidValue;   // the partner's two forwards share one resident weight set
   {   // the kernel patches one record per forward: everything outside the patched fields must agree
-    FwdArgs e = ego, p = reply, o = opening;
+    // (byte copies: struct assignment need not carry padding bytes, and the records are compared as bytes below)
+    FwdArgs e, p, o;
+    std::memcpy(&e, &ego, sizeof(FwdArgs));
+    std::memcpy(&p, &reply, sizeof(FwdArgs));
+    std::memcpy(&o, &opening, sizeof(FwdArgs));
     for (FwdArgs* x : {&e, &p, &o}) {
       x->params = nullptr; x->seed = 0; x->values = nullptr; x->logp = nullptr;
       x->rb_obs = nullptr; x->rb_act = nullptr; x->rb_rew = nullptr; x->rb_es = nullptr; x->rb_val = nullptr; x->rb_logp = nullptr;
@@ -1570,7 +1574,7 @@ hipError_t launch_liar_rollout(const ph_liar_selfplay& s, const FwdArgs& ego, co
     if (std::memcmp(&e, &p, sizeof(FwdArgs)) != 0 || std::memcmp(&p, &o, sizeof(FwdArgs)) != 0) return hipErrorInvalidValue;
     FwdArgs z;   // ... and be zero apart from the spec and the table count (the kernel builds its record from exactly these)
     std::memset(&z, 0, sizeof(z));
-    z.nd = ego.nd;
+    std::memcpy(&z.nd, &ego.nd, sizeof(z.nd));
     z.n = ego.n;
     if (std::memcmp(&e, &z, sizeof(FwdArgs)) != 0) return hipErrorInvalidValue;
     if (reply.seed != opening.seed || reply.values != opening.values || reply.logp != opening.logp || reply.rb_obs != opening.rb_obs ||

@@ -20,6 +20,7 @@ __device__ __forceinline__ long long rb_row(const FwdArgs& a, int g) {
 __device__ __forceinline__ int ll_read(const FwdArgs& a, const unsigned long long* word) {
   const unsigned want = p2p_stamp32(*a.ll_epoch, a.ll_T, a.ll_t);
   const long long t0 = wall_clock64();
+  int polls = 0;
   while (true) {
     const unsigned long long v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((unsigned)(v >> 32) == want) return (int)(unsigned)v;
@@ -27,7 +28,7 @@ __device__ __forceinline__ int ll_read(const FwdArgs& a, const unsigned long lon
       p2p_note_timeout(a.ll_error, 1, a.ll_t, a.joint_ll ? (unsigned long long)(word - a.joint_ll) : 0ull, want, v);
       return (int)(unsigned)v;
     }
-    __builtin_amdgcn_s_sleep(2);
+    poll_backoff(polls);
   }
 }
 

@@ -328,10 +328,9 @@ __device__ __forceinline__ void step_finish(const StepArgs& s, int nblk, unsigne
   if (!ok) {   // never on a healthy device; this block's parameters stay as they are, the host is told (ph_ctx_step_errors)
     if (lane == 0) {
       atomicAdd(s.sweep_error, 1u);
-      if (first) {
-        if (a.stats_out) a.stats_out[7] = -1.f;
-        *s.gen = tag;   // the next launch gets a new tag: words this launch left behind can never satisfy its sweep
-      }
+      // (the generation is left alone: every later launch of this context bails out on *sweep_error before it sweeps --
+      // ppo_step_kernel -- so words this launch's late blocks still publish are never taken for a later launch's)
+      if (first && a.stats_out) a.stats_out[7] = -1.f;
     }
     return;
   }

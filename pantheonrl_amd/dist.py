@@ -31,6 +31,25 @@ def init_from_env(backend: Optional[str] = None) -> bool:
     return True
 
 
+def ranks_sharing_device(device, group=None) -> int:
+    """how many ranks of the group run on this rank's GPU (1 on a real multi-GPU node; > 1 when ranks time-slice one device, as
+    the one-GPU test boxes do) -- the persistent rollout's residency bound and the in-kernel wait bounds need it.  A collective:
+    every rank of the group calls it."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 1
+    world = dist.get_world_size(group)
+    try:                                      # local work only: the collective below is reached by every rank
+        props = th.cuda.get_device_properties(device)
+        me = f"{os.uname().nodename}:{getattr(props, 'uuid', th.device(device).index)}"
+    except Exception:  # noqa: BLE001
+        me = None                             # "unknown": counted as sharing with everybody, on every rank alike
+    ids = [None] * world
+    dist.all_gather_object(ids, me, group=group)
+    if any(v is None for v in ids):
+        return world                          # the same (pessimistic) answer everywhere
+    return max(1, sum(1 for v in ids if v == me))
+
+
 _generation = {"p2p": 0, "rccl": 0}   # per-process rendezvous counters: every attach uses fresh store keys (ranks attach in
                                         # lockstep, so the n-th attach of every rank meets under the same key)
 
@@ -64,12 +83,13 @@ class ActionExchange:
         and build the ph_p2p descriptor.  `epoch_word` is the device word the engine advances once per iteration
         (ph_rng_epoch_advance); stamps are epoch * n_steps + t + 1.  Returns False if anything fails.
         `timeout_s` bounds ONE in-kernel wait for a peer's word (default PH_P2P_TIMEOUT_S or 10 s: a bound for lost peers, far
-        above any healthy hand-off -- ranks that time-slice one GPU, or a rank still instantiating its graphs, can be seconds
-        late to a step)."""
+        above any healthy hand-off).  The bound is per device SHARE: when k ranks run on this rank's GPU (`ranks_on_device`; 1 on a
+        real node, k on the one-GPU test boxes) a waiting kernel holds the device while the peer it waits for may not be scheduled,
+        and the peer can be k - 1 scheduler turns away, so the bound is k times the base."""
         import ctypes as C
         self.attach_generation += 1
         if timeout_s is None:
-            timeout_s = float(os.environ.get("PH_P2P_TIMEOUT_S", "10"))
+            timeout_s = float(os.environ.get("PH_P2P_TIMEOUT_S", "10")) * max(int(getattr(self, "ranks_on_device", 1)), 1)
 
         from . import _native as nat
         if not self.local.is_cuda or self.world > nat.PH_MAX_RANKS:
@@ -223,20 +243,7 @@ class ActionExchange:
         return route
 
     def _ranks_on_device(self) -> int:
-        """how many ranks of the group run on this rank's GPU (1 on a real multi-GPU node; > 1 when ranks time-slice one
-        device, as the one-GPU test boxes do) -- the persistent rollout's residency bound needs it"""
-        if self.world == 1 or not self.local.is_cuda:
-            return 1
-        try:                                      # local work only: the collective below is reached by every rank
-            props = th.cuda.get_device_properties(self.local.device)
-            me = f"{os.uname().nodename}:{getattr(props, 'uuid', self.local.device.index)}"
-        except Exception:  # noqa: BLE001
-            me = None                             # "unknown": counted as sharing with everybody, on every rank alike
-        ids = [None] * self.world
-        dist.all_gather_object(ids, me, group=self.group)
-        if any(v is None for v in ids):
-            return self.world                     # the same (pessimistic) answer everywhere
-        return max(1, sum(1 for v in ids if v == me))
+        return ranks_sharing_device(self.local.device, self.group) if self.local.is_cuda else 1
 
     def _torch_gather(self) -> th.Tensor:
         """all-gather of `self.local` through torch.distributed alone (the route of last resort and the yardstick the native

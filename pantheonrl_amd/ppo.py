@@ -433,6 +433,52 @@ class _SingleEnvVec:
         return (np.asarray(obs)[None], np.asarray([rew], np.float32), np.asarray([done]), [info])
 
 
+class UnsupportedPolicyConfig(ValueError):
+    """A `policy_kwargs` entry (trainer.py:108-126,196-203 splat `--ego-config` / `--alt-config` JSON into the constructor) or a space
+    asks for a network the gfx950 kernels do not implement.  Raised at construction, never at the first forward."""
+
+
+def check_policy_kwargs(policy_kwargs: Optional[Dict[str, Any]]) -> Dict[str, Any]:
+    """What the kernels implement is SB3 1.7.0's MlpPolicy default and nothing else: FlattenExtractor, separate towers
+    `net_arch=[dict(pi=[64, 64], vf=[64, 64])]`, Tanh, no gSDE (modular/policies.py:112-114,214-218).  `policy_kwargs` may restate that
+    default (and pick `ortho_init`); any other entry is refused by name.  -> the keyword arguments for ActorCriticPolicy"""
+    out: Dict[str, Any] = {}
+    for key, val in dict(policy_kwargs or {}).items():
+        if key == "net_arch":
+            arch = val[0] if isinstance(val, (list, tuple)) and len(val) == 1 else val
+            ok = isinstance(arch, dict) and sorted(arch) == ["pi", "vf"] and all(list(arch[k]) == [64, 64] for k in ("pi", "vf"))
+            if not ok:
+                raise UnsupportedPolicyConfig(
+                    f"policy_kwargs['net_arch'] = {val!r}: the MI355X engine implements net_arch=[dict(pi=[64, 64], vf=[64, 64])] "
+                    "only (SB3 1.7.0's MlpPolicy default, reference pantheonrl/algos/modular/policies.py:112-114)")
+        elif key == "activation_fn":
+            name = val if isinstance(val, str) else getattr(val, "__name__", repr(val))
+            if name.lower() != "tanh":
+                raise UnsupportedPolicyConfig(f"policy_kwargs['activation_fn'] = {name}: the kernels implement Tanh only "
+                                              "(reference pantheonrl/algos/modular/policies.py:54)")
+        elif key == "ortho_init":
+            out["ortho_init"] = bool(val)
+        elif key in ("use_sde", "squash_output", "use_expln", "full_std") and not val:
+            continue
+        elif key in ("optimizer_class", "optimizer_kwargs", "features_extractor_class", "features_extractor_kwargs",
+                     "normalize_images", "log_std_init", "sde_net_arch", "use_sde", "squash_output", "use_expln", "full_std"):
+            raise UnsupportedPolicyConfig(f"policy_kwargs[{key!r}]: the engine's policy is fixed to FlattenExtractor + Adam(eps=1e-5) + "
+                                          "categorical heads (reference pantheonrl/algos/modular/policies.py:84-88,112-114)")
+        else:
+            raise UnsupportedPolicyConfig(f"policy_kwargs[{key!r}] is not an ActorCriticPolicy argument this engine knows")
+    return out
+
+
+def check_action_space(action_space) -> None:
+    """Box (continuous) actions need a DiagGaussian head and `clip_actions`' np.clip (reference pantheonrl/common/util.py:84-99);
+    the engine's heads are Categorical / MultiCategorical"""
+    kind = type(action_space).__name__
+    if kind not in ("Discrete", "MultiDiscrete"):
+        raise UnsupportedPolicyConfig(
+            f"action space {action_space!r}: the MI355X engine implements Discrete / MultiDiscrete action heads; a {kind} action space "
+            "would need SB3's DiagGaussian / Bernoulli head and the clipping of reference pantheonrl/common/util.py:84-99")
+
+
 class PPO:
     """Drop-in for `stable_baselines3.PPO` on the surface PantheonRL uses (see module docstring)."""
 
@@ -442,11 +488,15 @@ class PPO:
                  ent_coef: float = 0.0, vf_coef: float = 0.5, max_grad_norm: float = 0.5,
                  target_kl: Optional[float] = None, tensorboard_log: Optional[str] = None, verbose: int = 0,
                  seed: Optional[int] = None, device="cuda", n_envs: Optional[int] = None, use_sde: bool = False,
-                 sde_sample_freq: int = -1, _init_setup_model: bool = True, sampling_stream: int = 0):
+                 sde_sample_freq: int = -1, _init_setup_model: bool = True, sampling_stream: int = 0,
+                 policy_kwargs: Optional[Dict[str, Any]] = None):
         if policy not in ("MlpPolicy", ActorCriticPolicy):
-            raise ValueError("the MI355X engine implements SB3's MlpPolicy")
+            raise UnsupportedPolicyConfig("the MI355X engine implements SB3's MlpPolicy")
         if use_sde:
-            raise ValueError("gSDE is not on the categorical PPO path")
+            raise UnsupportedPolicyConfig("gSDE is not on the categorical PPO path")
+        self._policy_args = check_policy_kwargs(policy_kwargs)
+        if env is not None and hasattr(env, "action_space"):
+            check_action_space(env.action_space)
         self.device = _require_cuda(device)
         self.learning_rate, self.n_steps, self.batch_size, self.n_epochs = learning_rate, n_steps, batch_size, n_epochs
         self.gamma, self.gae_lambda, self.clip_range, self.clip_range_vf = gamma, gae_lambda, clip_range, clip_range_vf
@@ -491,8 +541,10 @@ class PPO:
         self.n_envs = int(n_envs or getattr(self.env, "num_envs", 1))
 
     def _setup_model(self) -> None:
+        check_action_space(self.action_space)
         self.policy = ActorCriticPolicy(self.observation_space, self.action_space, lr=self.learning_rate,
-                                        device=self.device, seed=self.seed, sampling_stream=self.sampling_stream)
+                                        device=self.device, seed=self.seed, sampling_stream=self.sampling_stream,
+                                        **getattr(self, "_policy_args", {}))
         self.rollout_buffer = RolloutBuffer(self.n_steps, self.observation_space, self.action_space, self.device,
                                             self.policy.ctx, self.policy.spec, gae_lambda=self.gae_lambda,
                                             gamma=self.gamma, n_envs=self.n_envs)
@@ -556,7 +608,10 @@ class PPO:
         self._stats_dev = stats
         if sync_stats:
             st = stats.cpu().numpy()
-            if (st[:, 7] < 0).any() or (pol.ctx.exclusive_hint and pol.ctx.step_errors()):
+            # ph_ctx_step_errors counts over the context's life: only expiries since the previous train() condemn THIS update
+            expired = pol.ctx.step_errors() if pol.ctx.exclusive_hint else 0
+            seen, self._step_errors_seen = getattr(self, "_step_errors_seen", 0), expired
+            if (st[:, 7] < 0).any() or expired > seen:
                 raise nat.NativeError("PPO.train: a wait of the one-launch optimizer step expired (is the device really this "
                                       "learner's alone? ph_set_exclusive_device): the update was applied only in part")
             self.last_train_stats = st
@@ -582,6 +637,7 @@ class PPO:
 
     def _train_native(self, pol, opt, rb, hp, perm_t, stats) -> None:
         """the update itself; subclasses with an additional loss term (ADAP) issue their own entry point here"""
+        require_mlp_kernels(pol, "PPO.train")
         nat.check(pol.ctx.lib.ph_ppo_train(pol.ctx.handle, C.byref(pol.spec), C.byref(opt), C.byref(rb.c_struct()),
                                            C.byref(hp), int(self.n_epochs), int(self.batch_size), nat.ptr(perm_t),
                                            int(self.permutation_seed), stats.data_ptr(), int(pol.gemm_mode)))

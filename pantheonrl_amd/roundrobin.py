@@ -54,8 +54,9 @@ class RoundRobinLink:
     def __init__(self, ctx, n_partners: int, n_envs: int, obs_dim: int, device, timeout_s: Optional[float] = None):
         import ctypes as C
         import os
-        if timeout_s is None:      # one bound for every in-kernel wait of the package (dist.ActionExchange.attach_p2p)
-            timeout_s = float(os.environ.get("PH_P2P_TIMEOUT_S", "10"))
+        if timeout_s is None:      # one bound for every in-kernel wait of the package, per device share (dist.ActionExchange.attach_p2p)
+            from .dist import ranks_sharing_device
+            timeout_s = float(os.environ.get("PH_P2P_TIMEOUT_S", "10")) * ranks_sharing_device(device)
         self.ctx, self.device = ctx, device
         rank, world = dist.get_rank(), dist.get_world_size()
         store = dist.distributed_c10d._get_default_store()

@@ -624,3 +624,59 @@ def test_policies_with_another_parameter_layout_are_refused_on_the_fused_mlp_pat
     for cls in (AdapPolicyMult, ModularPolicy):
         with pytest.raises(nat.NativeError, match="fused MLP kernels"):
             require_mlp_kernels(cls.__new__(cls), "VecOnPolicyAgent")
+
+
+def test_policy_kwargs_are_accepted_for_the_default_network_and_refused_by_name_otherwise():
+    """trainer.py:108-126,196-203 splat --ego-config / --alt-config JSON into the constructor: `policy_kwargs` is a constructor argument,
+    the MlpPolicy default (modular/policies.py:112-114) passes, anything else is a named refusal AT CONSTRUCTION (no GPU needed: the
+    check runs before the device is touched)"""
+    import pytest
+
+    from pantheonrl_amd import _native as nat
+    from pantheonrl_amd.ppo import PPO, UnsupportedPolicyConfig, check_policy_kwargs
+    ok = [None, {}, {"net_arch": [dict(pi=[64, 64], vf=[64, 64])]}, {"net_arch": dict(vf=[64, 64], pi=[64, 64])},
+          {"activation_fn": "tanh"}, {"activation_fn": th.nn.Tanh, "ortho_init": False}, {"use_sde": False}]
+    for kw in ok:
+        out = check_policy_kwargs(kw)
+        assert out == ({"ortho_init": False} if kw and "ortho_init" in kw else {})
+    bad = [({"net_arch": [32, 32]}, "net_arch"), ({"net_arch": [dict(pi=[64, 64], vf=[32])]}, "net_arch"),
+           ({"net_arch": [dict(pi=[64, 64, 64], vf=[64, 64])]}, "net_arch"), ({"activation_fn": th.nn.ReLU}, "activation_fn"),
+           ({"use_sde": True}, "use_sde"), ({"features_extractor_class": object}, "features_extractor_class"),
+           ({"optimizer_kwargs": {"eps": 1e-8}}, "optimizer_kwargs"), ({"num_partners": 2}, "num_partners")]
+    for kw, name in bad:
+        with pytest.raises(UnsupportedPolicyConfig, match=name):
+            check_policy_kwargs(kw)
+        with pytest.raises(UnsupportedPolicyConfig, match=name):       # the constructor itself, as `PPO(policy='MlpPolicy', **config)` reaches it
+            PPO("MlpPolicy", None, policy_kwargs=kw, device="cuda")
+    # a supported configuration gets past the check and fails only for want of a GPU here (no CPU fallback)
+    if not th.cuda.is_available():
+        with pytest.raises(nat.NativeError, match="no CPU fallback"):
+            PPO("MlpPolicy", None, policy_kwargs=ok[2], device="cuda")
+
+
+def test_box_action_spaces_are_refused_at_construction_with_the_reference_line():
+    """util.py:84-99 (`clip_actions`) is the only place the reference treats Box actions; the engine's heads are categorical"""
+    import pytest
+
+    from pantheonrl_amd import spaces as sp
+    from pantheonrl_amd.ppo import PPO, UnsupportedPolicyConfig, check_action_space
+    check_action_space(sp.Discrete(6))
+    check_action_space(sp.MultiDiscrete([7, 12]))
+    env = type("E", (), dict(observation_space=sp.Box(-1, 1, (4,)), action_space=sp.Box(-1, 1, (2,)), _is_dummy_space_env=True))()
+    for make in (lambda: check_action_space(env.action_space), lambda: PPO("MlpPolicy", env, device="cuda"),
+                 lambda: check_action_space(sp.MultiBinary(3))):
+        with pytest.raises(UnsupportedPolicyConfig, match=r"util\.py:84-99"):
+            make()
+    # clip_actions itself keeps the reference's behaviour for a Box-shaped policy object (StaticPolicyAgent over a foreign policy)
+    from pantheonrl_amd.common.util import clip_actions
+    pol = type("P", (), dict(action_space=sp.Box(-1, 1, (2,))))()
+    assert np.array_equal(clip_actions(np.array([[-3.0, 0.5]], np.float32), pol), [[-1.0, 0.5]])
+
+
+def test_bench_reports_the_rollout_form_that_was_asked_for():
+    """bench.py downgrades --rollout scripted to stepwise for shapes outside the one-launch rollout's class: the JSON line says so
+    (config.rollout vs config.rollout_requested), not only stderr"""
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    assert 'rollout_requested = args.rollout' in src and '"rollout_requested": rollout_requested' in src
+    assert src.index('rollout_requested = args.rollout') < src.index('args.rollout = "stepwise"')
