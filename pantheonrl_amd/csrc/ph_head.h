@@ -25,6 +25,11 @@ __device__ __forceinline__ int head_unit(int q, int m) { return 8 * q + (m & 7) 
 // on different banks while keeping 16-byte alignment
 __device__ __forceinline__ int head_row(int j) { return 8 * (j + (j >> 3)); }
 constexpr int HW_FLOATS = 8 * (HID + HID / 8);
+// head_row(head_unit(q, m)) with the lane part and the constant part apart: j = 8q + (m & 7) + 32 (m >> 3) has j >> 3 = q + 4 (m >> 3)
+// (0 <= q < 4), so the row sits at 72 q + [8 (m & 7) + 288 (m >> 3)] -- one per-lane base, sixteen immediate offsets.  Written through
+// head_row the compiler does not see that and rebuilds every row's address (a multiply-add and a shift-add per row and pass).
+__device__ __forceinline__ int head_row_base(int q) { return 72 * q; }
+constexpr int head_row_imm(int m) { return 8 * (m & 7) + 288 * (m >> 3); }
 
 // Calls f(m, w0, w1) for the 16 head-weight rows of lane q, four rows per group, the next group's ds_read_b128s issued
 // before the current group's arithmetic (the scheduler otherwise emits read-wait-use per row: 16 LDS round trips).
@@ -33,9 +38,10 @@ template <int NK = 8, class F>
 __device__ __forceinline__ void for_head_rows(const float* hw, int q, F&& f) {
   constexpr int G = 2;  // rows per group
   float4 wa[2][G], wb[2][G];
+  const float* hwq = hw + head_row_base(q);
 #pragma unroll
   for (int i = 0; i < G; ++i) {
-    const float4* w = reinterpret_cast<const float4*>(hw + head_row(head_unit(q, i)));
+    const float4* w = reinterpret_cast<const float4*>(hwq + head_row_imm(i));
     wa[0][i] = w[0];
     if constexpr (NK > 4) wb[0][i] = w[1];
     else wb[0][i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -45,7 +51,7 @@ __device__ __forceinline__ void for_head_rows(const float* hw, int q, F&& f) {
     if (g + 1 < 16 / G) {
 #pragma unroll
       for (int i = 0; i < G; ++i) {
-        const float4* w = reinterpret_cast<const float4*>(hw + head_row(head_unit(q, G * (g + 1) + i)));
+        const float4* w = reinterpret_cast<const float4*>(hwq + head_row_imm(G * (g + 1) + i));
         wa[(g + 1) & 1][i] = w[0];
         if constexpr (NK > 4) wb[(g + 1) & 1][i] = w[1];
         else wb[(g + 1) & 1][i] = make_float4(0.f, 0.f, 0.f, 0.f);

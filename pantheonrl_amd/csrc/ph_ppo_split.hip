@@ -206,7 +206,10 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
   float* const rslab = a.slabs + ((size_t)blockIdx.x * 2 + net) * RS_NET;
   bool slabs_out = false;   // dW1 / dW2 / d b2 already stored by the last tile
   bool first = true;
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, first = false) {
+  // every workgroup owns at least one tile (launch_ppo_grad_split refuses a grid wider than the tile count): a loop entered
+  // unconditionally -- with a guarded loop the accumulators are zeroed for the skip path and COPIED into the loop's registers
+  int tile = blockIdx.x;
+  do {
     int tidv = threadIdx.x;
     asm volatile("" : "+v"(tidv));
     const int tid = tidv, lane = tid & 63, wave = tid >> 6;
@@ -288,6 +291,8 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
           v[r] = fast_tanh(FOLD ? acc[r] : acc[r] + bb);
           d1[b][r] = 1.0f - v[r] * v[r];
         }
+        // the split consumes v in place (v_dot2c accumulates into its input): d1 first, or every v is copied for it
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "v"(d1[b][0]), "v"(d1[b][1]), "v"(d1[b][2]), "v"(d1[b][3]));
         bf16x4 p[3];
         split4(v, p);
         st_planes4(smem, H1T + csb[b], p);
@@ -406,7 +411,11 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
           if constexpr (NK > 2) acc = __builtin_elementwise_fma((hp2){w0.z, w0.w}, dzp[1], acc);
           if constexpr (NK > 4) acc = __builtin_elementwise_fma((hp2){w1.x, w1.y}, dzp[2], acc);
           if constexpr (NK > 6) acc = __builtin_elementwise_fma((hp2){w1.z, w1.w}, dzp[3], acc);
-          dzv[m] = (acc.x + acc.y) * (1.0f - h[m] * h[m]);
+          // the horizontal add as ONE scalar v_add_f32: left to the vectoriser, two rows' sums become a packed add fed by three
+          // v_movs that transpose the pairs (2 instructions per row instead of 1)
+          float hsum;
+          asm("v_add_f32 %0, %1, %2" : "=v"(hsum) : "v"(acc.x), "v"(acc.y));
+          dzv[m] = hsum * (1.0f - h[m] * h[m]);
         });
       } else {
         float wv[16];
@@ -466,10 +475,17 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
       if (lane < NK) ghb += lds_sum16(dzs + wave * 16 * 8 + lane, 8);
     } else {
       float hv[16], dv[16];
+      // (wave * 16 + i) * DZ_ROW written as a per-wave base plus a compile-time row displacement: from the sum the compiler makes an
+      // OR (wave * 16 has no low bits), multiplies that, and every row's address becomes arithmetic instead of an offset field
+      const char* hrow = smem + DZ2 + wave * (16 * DZ_ROW);
+      const float* drow = dzs + wave * 16;
+      int col4[4];   // h2_swz(i) depends on i & 3 only: four per-lane column offsets (bytes)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) col4[i] = ((((lane >> 2) ^ h2_swz(i)) << 2) | (lane & 3)) * 4;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        hv[i] = *(reinterpret_cast<const float*>(smem + DZ2 + (wave * 16 + i) * DZ_ROW) + ((((lane >> 2) ^ h2_swz(i)) << 2) | (lane & 3)));
-        dv[i] = dzs[wave * 16 + i];
+        hv[i] = *reinterpret_cast<const float*>(hrow + i * DZ_ROW + col4[i & 3]);
+        dv[i] = drow[i];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -521,8 +537,11 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
         }
       }
       if (!has_next) {   // dW2 and d b2 are final: their 16 KB leave under the rest of this tile
-#pragma unroll
-        for (int b = 0; b < 4; ++b) st_slab16(rslab + RS_W2 + ((wave * 4 + b) * 64 + lane) * 4, gW2[b]);
+        float* const w2o = rslab + RS_W2 + (wave * 4 * 64 + lane) * 4;   // block b: + 1 KB, as an immediate
+        st_slab16<0>(w2o, gW2[0]);
+        st_slab16<1024>(w2o, gW2[1]);
+        st_slab16<2048>(w2o, gW2[2]);
+        st_slab16<3072>(w2o, gW2[3]);
         if (lane < 16) rslab[RS_B2 + 16 * wave + lane] = gB2[0];   // every row of the ones product is the column sum
       }
 #pragma unroll
@@ -559,11 +578,17 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
         gB1 = mma_ones(dz0, gB1);
         gB1 = mma_ones(dz1, gB1);
       }
+      float* const w1o = rslab + RS_W1 + (wave * 4 * 64 + lane) * 4;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         gW1[b] = mma6(ld_trf(XT, 0, b), dz0, gW1[b]);   // A: features 16b + i (lane), tile rows 8kg .. (contraction): transposing reads of X
         gW1[b] = mma6(ld_trf(XT, 1, b), dz1, gW1[b]);
-        if (!has_next) st_slab16(rslab + RS_W1 + ((wave * 4 + b) * 64 + lane) * 4, gW1[b]);
+        if (!has_next) {
+          if (b == 0) st_slab16<0>(w1o, gW1[0]);
+          else if (b == 1) st_slab16<1024>(w1o, gW1[1]);
+          else if (b == 2) st_slab16<2048>(w1o, gW1[2]);
+          else st_slab16<3072>(w1o, gW1[3]);
+        }
       }
       if (!has_next) {
         if constexpr (!FOLD)
@@ -573,19 +598,19 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     }
     lds_barrier();  // XT / H1T / row scalars are free for the next tile
     if (first) PH_STAMP(a.prof, 7);
-  }
+    tile += gridDim.x;
+    first = false;
+  } while (tile < a.ntiles);
   PH_STAMP(a.prof, 12);
 
   // ---- epilogue: accumulators -> slab (once), cross-wave sums in a fixed order ----
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!slabs_out) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int o = ((wave * 4 + b) * 64 + lane) * 4;
-        st_slab16(rslab + RS_W2 + o, gW2[b]);
-        st_slab16(rslab + RS_W1 + o, gW1[b]);
-      }
+      float* const w2o = rslab + RS_W2 + (wave * 4 * 64 + lane) * 4;
+      float* const w1o = rslab + RS_W1 + (wave * 4 * 64 + lane) * 4;
+      st_slab16<0>(w2o, gW2[0]); st_slab16<1024>(w2o, gW2[1]); st_slab16<2048>(w2o, gW2[2]); st_slab16<3072>(w2o, gW2[3]);
+      st_slab16<0>(w1o, gW1[0]); st_slab16<1024>(w1o, gW1[1]); st_slab16<2048>(w1o, gW1[2]); st_slab16<3072>(w1o, gW1[3]);
       if (lane < 16) {   // every row of the ones products is the column sum
         rslab[RS_B2 + 16 * wave + lane] = gB2[0];
         if constexpr (!FOLD) rslab[RS_B1 + 16 * wave + lane] = gB1[0];
@@ -665,6 +690,7 @@ static hipError_t launch_split_nk(const GradArgs& a, int nwg, hipStream_t s) {
 }
 
 hipError_t launch_ppo_grad_split(const GradArgs& a, int nwg, hipStream_t s) {
+  if (nwg < 1 || nwg > a.ntiles) return hipErrorInvalidValue;   // the kernel's tile walk is entered unconditionally (grad_plan: nwg <= ntiles)
   switch (a.nd.L) {
     case 1: return launch_split_nk<1>(a, nwg, s);
     case 2: return launch_split_nk<2>(a, nwg, s);

@@ -31,32 +31,48 @@ constexpr int PB_BYTES = 3 * PL_BYTES;  // a plane buffer: planes h, m, l
 // uses row bit 0 as well).  With it the operand reads (plain and transposing), the X commit and the dZ2 commit are
 // conflict-free; the 8-byte C-layout stores keep a 2-way conflict (sixteen rows, one 8-byte half: inherent at 16-byte granules).
 __device__ __forceinline__ int pl_swz(int a) {
-  const int a0 = a & 1, a1 = (a >> 1) & 1, a2 = (a >> 2) & 1, a3 = (a >> 3) & 1;
-  return a1 | ((a1 ^ a2) << 1) | ((a0 ^ a1 ^ a3) << 2);
+  // a1 | ((a1 ^ a2) << 1) | ((a0 ^ a1 ^ a3) << 2) as a sixteen-nibble table: shift, mask (three instructions instead of eight;
+  // the kernels rebuild their per-lane bases at the top of every tile to keep them out of the register file across tiles)
+  return (int)(0x5126730415623740ull >> ((a & 15) << 2)) & 7;
 }
 
 struct Frag3 {
   bf16x8 p[3];
 };
 
+// Two values -> their three planes, packed.  One v_cvt_pk_bf16_f32 per plane (both values at once) and ONE v_dot2c_f32_bf16 per
+// residual: r = x - bf16(x) is dot2c(acc = x, {h0, h1}, {-1, 0}) -- the packed plane word is consumed as it is, no widening of
+// a bf16 back to float32 (a shift or a mask per value and level) and no separate subtract.  Bitwise the subtract form on every
+// input class scripts/ubench/split_dot2_probe.hip walks (the residual is exactly representable, so any faithful sum returns it).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float x0, float x1, bf16x2& h, bf16x2& m, bf16x2& l) {
+  bf16x2 lo, hi;
+  lo[0] = (__bf16)-1.0f; lo[1] = (__bf16)0.0f;
+  hi[0] = (__bf16)0.0f;  hi[1] = (__bf16)-1.0f;
+  h[0] = (__bf16)x0; h[1] = (__bf16)x1;
+  const float r0 = __builtin_amdgcn_fdot2_f32_bf16(h, lo, x0, false), r1 = __builtin_amdgcn_fdot2_f32_bf16(h, hi, x1, false);
+  m[0] = (__bf16)r0; m[1] = (__bf16)r1;
+  const float s0 = __builtin_amdgcn_fdot2_f32_bf16(m, lo, r0, false), s1 = __builtin_amdgcn_fdot2_f32_bf16(m, hi, r1, false);
+  l[0] = (__bf16)s0; l[1] = (__bf16)s1;
+}
 __device__ __forceinline__ void split8(const float* x, Frag3& f) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    __bf16 h, m, l;
-    split1(x[e], h, m, l);
-    f.p[0][e] = h;
-    f.p[1][e] = m;
-    f.p[2][e] = l;
+  for (int e = 0; e < 8; e += 2) {
+    bf16x2 h, m, l;
+    split_pair(x[e], x[e + 1], h, m, l);
+    f.p[0][e] = h[0]; f.p[0][e + 1] = h[1];
+    f.p[1][e] = m[0]; f.p[1][e + 1] = m[1];
+    f.p[2][e] = l[0]; f.p[2][e + 1] = l[1];
   }
 }
 __device__ __forceinline__ void split4(const float* x, bf16x4 (&p)[3]) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    __bf16 h, m, l;
-    split1(x[e], h, m, l);
-    p[0][e] = h;
-    p[1][e] = m;
-    p[2][e] = l;
+  for (int e = 0; e < 4; e += 2) {
+    bf16x2 h, m, l;
+    split_pair(x[e], x[e + 1], h, m, l);
+    p[0][e] = h[0]; p[0][e + 1] = h[1];
+    p[1][e] = m[0]; p[1][e + 1] = m[1];
+    p[2][e] = l[0]; p[2][e + 1] = l[1];
   }
 }
 
@@ -68,12 +84,12 @@ __device__ __forceinline__ void split4(const float* x, bf16x4 (&p)[3]) {
 // No "memory" clobber: nothing in these kernels reads a slab position after this store wrote it (a later tile's accumulator
 // re-load is ordered by its register dependence), and with the clobber every LDS operand read behind a store waited for it -- the
 // block-by-block epilogues ran read - product - store, one block at a time.
+// OFF: compile-time byte displacement (0 .. 4095) folded into the instruction -- the four blocks of an accumulator set sit 1 KB apart, so
+// one address register pair serves all four stores of a set.
+template <int OFF = 0>
 __device__ __forceinline__ void st_slab16(float* p, const f32x4& v) {
-#if defined(PH_SLAB_STORE_CLOBBER)   // A/B only
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#else
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v));
-#endif
+  static_assert(OFF >= 0 && OFF < 4096, "global_store immediate offset");
+  asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 1" ::"v"(p), "v"(v), "n"(OFF));
 }
 __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
