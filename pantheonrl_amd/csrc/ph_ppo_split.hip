@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     int tidv = threadIdx.x;
     asm volatile("" : "+v"(tidv));
     const int tid = tidv, lane = tid & 63, wave = tid >> 6;
+    const SplitSel ssel = split_sel();   // the split's two selector words (ph_split_tile.h), rebuilt per tile
     const int j = lane & 15, kg = lane >> 4;
     const bool has_next = tile + (int)gridDim.x < a.ntiles;
     const int unit = 16 * wave + j;   // this lane's column of every 16x16 result
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
         // the split consumes v in place (v_dot2c accumulates into its input): d1 first, or every v is copied for it
         asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "v"(d1[b][0]), "v"(d1[b][1]), "v"(d1[b][2]), "v"(d1[b][3]));
         bf16x4 p[3];
-        split4(v, p);
+        split4(ssel, v, p);
         st_planes4(smem, H1T + csb[b], p);
       }
     }
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {   // units 8q .. 8q+7 (granule q) and 32 + 8q .. (granule 4 + q)
         Frag3 f;
-        split8(dzv + 8 * g, f);
+        split8(ssel, dzv + 8 * g, f);
         st_planes8<DZ_PL>(smem, DZ2 + hr * DZ_ROW + (((4 * g + hq) ^ sw) << 4), f);
       }
     }
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_split_kernel(GradArgs a) {
     for (int b = 0; b < 4; ++b) {
       float v[4] = {dh1[b][0], dh1[b][1], dh1[b][2], dh1[b][3]};
       bf16x4 p[3];
-      split4(v, p);
+      split4(ssel, v, p);
       st_planes4(smem, H1T + csb[b], p);
     }
     wave_lds_sync();

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
   };
   auto commit_rows = [&](const RowGather& g, const BoxRow& bx) {
     const int tid = threadIdx.x, row = tid >> 2, q = tid & 3;
+    [[maybe_unused]] const SplitSel ssel = split_sel();
     wave_lds_sync();
     const int sw = pl_swz(row);
     if constexpr (BOX) {   // split the row's features into their three planes: one 16-byte store per plane and granule
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
           Frag3 f3;
-          split8(bx.x[ch][gi], f3);
+          split8(ssel, bx.x[ch][gi], f3);
           st_planes8(smem, XOH + ch * XCH + row * PL_ROW + ((((q + 4 * gi) ^ sw)) << 4), f3);
         }
     } else {
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
     int tidv = threadIdx.x;
     asm volatile("" : "+v"(tidv));
     const int tid = tidv, lane = tid & 63, wave = tid >> 6;
+    const SplitSel ssel = split_sel();   // the split's two selector words (ph_split_tile.h), rebuilt per tile
     const int j = lane & 15, kg = lane >> 4;
     const int unit = 16 * wave + j;   // this lane's column of every 16x16 result in the [k][unit] orientation
     const bool has_next = tile + (int)gridDim.x < a.ntiles;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
           d1[b][r] = 1.0f - v[r] * v[r];
         }
         bf16x4 p[3];
-        split4(v, p);
+        split4(ssel, v, p);
         st_planes4(smem, H1T + csb[b], p);
       }
     }
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
           d2[b][r] = 1.0f - v[r] * v[r];
         }
         bf16x4 p[3];
-        split4(v, p);
+        split4(ssel, v, p);
         st_planes4(smem, H2B + b * 16 * PL_ROW + rst, p);
       }
     }
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
 #pragma unroll
       for (int lb = 0; lb < OH_LBMAX; ++lb) {
         bf16x4 p[3];
-        split4(dz[lb], p);
+        split4(ssel, dz[lb], p);
 #pragma unroll
         for (int q = 0; q < 3; ++q)
           *reinterpret_cast<bf16x4*>(smem + DZL + q * DZL_PLANE + row * DZL_ROW + (((2 * lb + (kg >> 1)) ^ sw) << 4) + 8 * (kg & 1)) = p[q];
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[r] * d2[b][r];
         bf16x4 p[3];
-        split4(v, p);
+        split4(ssel, v, p);
         st_planes4(smem, H2B + b * 16 * PL_ROW + rst, p);
       }
     }
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_oh_kernel(GradArgs a) {
     for (int b = 0; b < 4; ++b) {
       float v[4] = {dh1[b][0], dh1[b][1], dh1[b][2], dh1[b][3]};
       bf16x4 p[3];
-      split4(v, p);
+      split4(ssel, v, p);
       st_planes4(smem, H1T + csb[b], p);
     }
     wave_lds_sync();

@@ -44,36 +44,52 @@ struct Frag3 {
 // residual: r = x - bf16(x) is dot2c(acc = x, {h0, h1}, {-1, 0}) -- the packed plane word is consumed as it is, no widening of
 // a bf16 back to float32 (a shift or a mask per value and level) and no separate subtract.  Bitwise the subtract form on every
 // input class scripts/ubench/split_dot2_probe.hip walks (the residual is exactly representable, so any faithful sum returns it).
+// The two selectors {-1, 0} / {0, -1} must be REGISTER operands: as immediates hipcc 7.2 encodes {-1, 0} = 0x0000BF80 as the
+// inline constant -1.0, which the hardware expands to 0xBF800000 = {0, -1} for this instruction (the probe's INLINE_SELECTORS
+// build: every residual taken from the wrong half).  split_sel() hands them out behind an opaque statement.
+// The pair's planes travel as packed 32-bit words {bf16 of value 0, bf16 of value 1}.  Both instructions come from the compiler
+// (a two-element conversion and the dot2 builtin on bit-cast words), NOT from inline assembly: a DOT result read by another VALU
+// instruction inside three wait states is stale, and only the compiler's hazard recognizer pads that -- an asm body is opaque to it
+// (the probe's VARIANT 1: 88 % of the planes wrong; VARIANT 0, this form, and VARIANT 2, padding written out: 0 of 6 x 2^26).
+struct SplitSel {
+  unsigned lo, hi;   // {-1, 0} and {0, -1} as packed bf16 pairs
+};
+__device__ __forceinline__ SplitSel split_sel() {
+  SplitSel s;
+  s.lo = 0x0000BF80u;
+  s.hi = 0xBF800000u;
+  asm("" : "+v"(s.lo), "+v"(s.hi));
+  return s;
+}
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_pair(float x0, float x1, bf16x2& h, bf16x2& m, bf16x2& l) {
-  bf16x2 lo, hi;
-  lo[0] = (__bf16)-1.0f; lo[1] = (__bf16)0.0f;
-  hi[0] = (__bf16)0.0f;  hi[1] = (__bf16)-1.0f;
-  h[0] = (__bf16)x0; h[1] = (__bf16)x1;
-  const float r0 = __builtin_amdgcn_fdot2_f32_bf16(h, lo, x0, false), r1 = __builtin_amdgcn_fdot2_f32_bf16(h, hi, x1, false);
-  m[0] = (__bf16)r0; m[1] = (__bf16)r1;
-  const float s0 = __builtin_amdgcn_fdot2_f32_bf16(m, lo, r0, false), s1 = __builtin_amdgcn_fdot2_f32_bf16(m, hi, r1, false);
-  l[0] = (__bf16)s0; l[1] = (__bf16)s1;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // {bf16(a), bf16(b)}, round to nearest even: v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
 }
-__device__ __forceinline__ void split8(const float* x, Frag3& f) {
-#pragma unroll
-  for (int e = 0; e < 8; e += 2) {
-    bf16x2 h, m, l;
-    split_pair(x[e], x[e + 1], h, m, l);
-    f.p[0][e] = h[0]; f.p[0][e + 1] = h[1];
-    f.p[1][e] = m[0]; f.p[1][e + 1] = m[1];
-    f.p[2][e] = l[0]; f.p[2][e + 1] = l[1];
-  }
+__device__ __forceinline__ float dot2c_bf16(float acc, unsigned a, unsigned b) {   // acc + a.lo * b.lo + a.hi * b.hi: v_dot2c_f32_bf16
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), acc, false);
 }
-__device__ __forceinline__ void split4(const float* x, bf16x4 (&p)[3]) {
+__device__ __forceinline__ void split_pair(const SplitSel& sel, float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = cvt_pk_bf16(x0, x1);
+  const float r0 = dot2c_bf16(x0, h, sel.lo), r1 = dot2c_bf16(x1, h, sel.hi);
+  m = cvt_pk_bf16(r0, r1);
+  const float s0 = dot2c_bf16(r0, m, sel.lo), s1 = dot2c_bf16(r1, m, sel.hi);
+  l = cvt_pk_bf16(s0, s1);
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8(const SplitSel& sel, const float* x, Frag3& f) {
+  unsigned w[3][4];
 #pragma unroll
-  for (int e = 0; e < 4; e += 2) {
-    bf16x2 h, m, l;
-    split_pair(x[e], x[e + 1], h, m, l);
-    p[0][e] = h[0]; p[0][e + 1] = h[1];
-    p[1][e] = m[0]; p[1][e + 1] = m[1];
-    p[2][e] = l[0]; p[2][e + 1] = l[1];
-  }
+  for (int e = 0; e < 4; ++e) split_pair(sel, x[2 * e], x[2 * e + 1], w[0][e], w[1][e], w[2][e]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) f.p[p] = __builtin_bit_cast(bf16x8, (u32x4){w[p][0], w[p][1], w[p][2], w[p][3]});
+}
+__device__ __forceinline__ void split4(const SplitSel& sel, const float* x, bf16x4 (&p)[3]) {
+  unsigned w[3][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) split_pair(sel, x[2 * e], x[2 * e + 1], w[0][e], w[1][e], w[2][e]);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) p[q] = __builtin_bit_cast(bf16x4, (u32x2){w[q][0], w[q][1]});
 }
 
 // 16-byte write-through slab store.  The two wait states after it are part of the instruction as far as this file is concerned: a
@@ -89,7 +105,12 @@ __device__ __forceinline__ void split4(const float* x, bf16x4 (&p)[3]) {
 template <int OFF = 0>
 __device__ __forceinline__ void st_slab16(float* p, const f32x4& v) {
   static_assert(OFF >= 0 && OFF < 4096, "global_store immediate offset");
-  asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 1" ::"v"(p), "v"(v), "n"(OFF));
+  // ... and the wait states IN FRONT of it are part of it too: the data are MFMA results, and a VMEM instruction that reads a
+  // register an MFMA wrote needs passes + 3 wait states behind that MFMA on gfx950 (7 for the 4-pass 16x16x32, 11 if it were 8).
+  // The hazard recognizer pads the compiler's own instructions, never an asm body: while every store had its own address
+  // arithmetic in front, those VALU instructions happened to be the padding (round 6: with the address hoisted the first block
+  // of dW1 left before its last MFMA had written back).
+  asm volatile("s_nop 7\n\ts_nop 3\n\tglobal_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 1" ::"v"(p), "v"(v), "n"(OFF));
 }
 __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);

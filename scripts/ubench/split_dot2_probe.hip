@@ -5,7 +5,6 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 __device__ inline void split_ref(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
   const __bf16 hb = (__bf16)x;
@@ -17,16 +16,65 @@ __device__ inline void split_ref(float x, unsigned short& h, unsigned short& m, 
   m = __builtin_bit_cast(unsigned short, mb);
   l = __builtin_bit_cast(unsigned short, lb);
 }
-// two values at a time: one v_cvt_pk_bf16_f32 per plane, one v_dot2c per residual
-__device__ inline void split_dot2(float x0, float x1, bf16x2& h, bf16x2& m, bf16x2& l) {
-  bf16x2 lo, hi;
-  lo[0] = (__bf16)-1.0f; lo[1] = (__bf16)0.0f;
-  hi[0] = (__bf16)0.0f;  hi[1] = (__bf16)-1.0f;
-  h[0] = (__bf16)x0; h[1] = (__bf16)x1;
-  const float r0 = __builtin_amdgcn_fdot2_f32_bf16(h, lo, x0, false), r1 = __builtin_amdgcn_fdot2_f32_bf16(h, hi, x1, false);
-  m[0] = (__bf16)r0; m[1] = (__bf16)r1;
-  const float s0 = __builtin_amdgcn_fdot2_f32_bf16(m, lo, r0, false), s1 = __builtin_amdgcn_fdot2_f32_bf16(m, hi, r1, false);
-  l[0] = (__bf16)s0; l[1] = (__bf16)s1;
+// two values at a time: one v_cvt_pk_bf16_f32 per plane, one v_dot2c per residual, planes as packed words.  Three ways to get there
+// (-DVARIANT=0 / 1 / 2): 0 = compiler builtins (the hazard recognizer pads the DOT results), 1 = bare inline assembly (nothing
+// pads: a DOT result read by another VALU instruction inside three wait states is stale), 2 = inline assembly with the padding
+// written out, two pairs per statement so that the second pair's instructions are most of the padding.
+#ifndef VARIANT
+#define VARIANT 0
+#endif
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ inline unsigned cvt_pk_bf16(float a, float b) {
+#if VARIANT == 0
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+#else
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#endif
+}
+__device__ inline float dot2c_bf16(float acc, unsigned a, unsigned b) {
+#if VARIANT == 0
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), acc, false);
+#else
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+  return acc;
+#endif
+}
+__device__ inline void split_dot2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  unsigned lo = 0x0000BF80u, hi = 0xBF800000u;   // {-1, 0}, {0, -1}: register operands (as immediates the inline constant -1.0 is mis-expanded)
+  asm("" : "+v"(lo), "+v"(hi));
+  h = cvt_pk_bf16(x0, x1);
+  const float r0 = dot2c_bf16(x0, h, lo), r1 = dot2c_bf16(x1, h, hi);
+  m = cvt_pk_bf16(r0, r1);
+  const float s0 = dot2c_bf16(r0, m, lo), s1 = dot2c_bf16(r1, m, hi);
+  l = cvt_pk_bf16(s0, s1);
+}
+// VARIANT 2: pairs A = (a0, a1) and B = (b0, b1) in one statement; a DOT result is read by v_cvt_pk three wait states after it
+__device__ inline void split_two_pairs(float a0, float a1, float b0, float b1, unsigned (&h)[2], unsigned (&m)[2], unsigned (&l)[2]) {
+  unsigned lo = 0x0000BF80u, hi = 0xBF800000u;
+  asm("" : "+v"(lo), "+v"(hi));
+  asm("v_cvt_pk_bf16_f32 %0, %6, %7\n\t"
+      "v_cvt_pk_bf16_f32 %1, %8, %9\n\t"
+      "v_dot2c_f32_bf16 %6, %0, %10\n\t"
+      "v_dot2c_f32_bf16 %7, %0, %11\n\t"
+      "v_dot2c_f32_bf16 %8, %1, %10\n\t"
+      "v_dot2c_f32_bf16 %9, %1, %11\n\t"
+      "s_nop 0\n\t"
+      "v_cvt_pk_bf16_f32 %2, %6, %7\n\t"
+      "s_nop 0\n\t"
+      "v_cvt_pk_bf16_f32 %3, %8, %9\n\t"
+      "v_dot2c_f32_bf16 %6, %2, %10\n\t"
+      "v_dot2c_f32_bf16 %7, %2, %11\n\t"
+      "v_dot2c_f32_bf16 %8, %3, %10\n\t"
+      "v_dot2c_f32_bf16 %9, %3, %11\n\t"
+      "s_nop 0\n\t"
+      "v_cvt_pk_bf16_f32 %4, %6, %7\n\t"
+      "s_nop 0\n\t"
+      "v_cvt_pk_bf16_f32 %5, %8, %9"
+      : "=&v"(h[0]), "=&v"(h[1]), "=&v"(m[0]), "=&v"(m[1]), "=&v"(l[0]), "=&v"(l[1]), "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)
+      : "v"(lo), "v"(hi));
 }
 
 __device__ inline uint32_t mix(uint32_t z) {
@@ -49,18 +97,27 @@ __global__ void probe(int mode, unsigned long long* bad, float* first_bad) {
     if (!(v == v) || __builtin_isinf(v)) v = 1.0f;
     x[k] = v;
   }
-  bf16x2 h, m, l;
+  unsigned h, m, l;
+#if VARIANT == 2
+  unsigned hh[2], mm[2], ll[2];
+  split_two_pairs(x[0], x[1], x[1], x[0], hh, mm, ll);   // second pair: the same values swapped (checked through the first)
+  h = hh[0]; m = mm[0]; l = ll[0];
+  if (hh[1] != ((hh[0] >> 16) | (hh[0] << 16)) || mm[1] != ((mm[0] >> 16) | (mm[0] << 16)) || ll[1] != ((ll[0] >> 16) | (ll[0] << 16)))
+    if (atomicAdd(bad, 1ull) == 0ull) *first_bad = x[0];
+#else
   split_dot2(x[0], x[1], h, m, l);
+#endif
   for (int k = 0; k < 2; ++k) {
     unsigned short rh, rm, rl;
     split_ref(x[k], rh, rm, rl);
-    const bool same = rh == __builtin_bit_cast(unsigned short, h[k]) && rm == __builtin_bit_cast(unsigned short, m[k]) &&
-                      rl == __builtin_bit_cast(unsigned short, l[k]);
+    const unsigned sh = 16 * k;
+    const bool same = rh == (unsigned short)(h >> sh) && rm == (unsigned short)(m >> sh) && rl == (unsigned short)(l >> sh);
     if (!same && atomicAdd(bad, 1ull) == 0ull) *first_bad = x[k];
   }
 }
 
 int main() {
+  printf("VARIANT %d\n", VARIANT);
   unsigned long long* bad;
   float* fb;
   hipMalloc(&bad, 8);
