@@ -494,6 +494,103 @@ def bench_roundrobin(args, device, rank, world, json_fd, tdist):
     tdist.destroy_process_group()
 
 
+def bench_liar(args, device, json_fd):
+    """BASELINE config 2 as a device-resident game: LiarsDice-v0 PPO-vs-PPO, n_envs tables dealt, played and scored on the GPU
+    (`ph_liar_selfplay_rollout`: one launch per rollout; rules pantheonrl/envs/liargym/liar.py:18-19,53-102, bit-exact against the
+    reference-generated traces in tests/golden/game_traces.npz), the ego's rectangular buffer and the partner's ragged one (a game may
+    end on either player's move), both learners training -- the ego's update from a hipGraph, the partner's beside it on a second
+    stream whenever all its columns are full (pantheonrl_amd/envs/vec.py: LiarIterationGraph).  One "step" = one such iteration."""
+    from pantheonrl_amd import PPO, _native as nat
+    from pantheonrl_amd.envs.vec import LiarIterationGraph, RaggedVecOnPolicyAgent, VecLiarsDice, VecLiarSelfPlay
+    from pantheonrl_amd.vec import VecOnPolicyAgent
+    E, T = args.n_envs, args.n_steps
+    spaces = type("S", (), dict(observation_space=VecLiarsDice.observation_space, action_space=VecLiarsDice.action_space,
+                                _is_dummy_space_env=True))()
+    models = [PPO("MlpPolicy", spaces, n_steps=T, n_envs=E, batch_size=args.batch_size, n_epochs=args.n_epochs, seed=sd, device=device)
+              for sd in (0, 1)]
+    for m in models:
+        m.device_permutations = True
+    ego, alt = VecOnPolicyAgent(models[0]), RaggedVecOnPolicyAgent(models[1])
+    sp = VecLiarSelfPlay(E, ego, alt, seed=3, native=True)
+    sp.rollout_and_learn(T)                       # launch by launch once: workspaces, first launches
+    th.cuda.synchronize(device)
+    g = LiarIterationGraph(sp, T)
+    for _ in range(max(args.warmup, 1)):
+        g.launch()
+    th.cuda.synchronize(device)
+
+    def partner_rows():
+        return alt.iteration * E * T + int(alt.pos.sum().item())
+    rows0, ep0, it0 = partner_rows(), sp.episodes, alt.iteration
+    evs = [th.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    th.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    evs[0].record(g.stream)
+    for k in range(args.steps):
+        g.launch()
+        evs[k + 1].record(g.stream)
+    th.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    per = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps))
+    rows1, ep1 = partner_rows(), sp.episodes
+    ego_steps, alt_steps = E * T * args.steps, rows1 - rows0
+    result = {
+        "metric": "env-steps/sec (all agents) LiarsDice-v0 PPO-vs-PPO self-play", "value": (ego_steps + alt_steps) / dt,
+        "unit": "agent-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ego_steps_per_s": ego_steps / dt, "partner_steps_per_s": alt_steps / dt,
+        "episodes_per_iteration": (ep1 - ep0) / args.steps, "partner_updates": alt.iteration - it0,
+        "iteration_ms": {"min": per[0], "median": per[len(per) // 2], "max": per[-1], "source": "HIP events on the iteration stream"},
+        "config": {"workload": "LiarsDice-v0 PPO-vs-PPO self-play, the game itself on the device (dice Philox-keyed, rules bit-exact "
+                               "against reference-generated traces), random-init policies",
+                   "n_envs": E, "n_steps": T, "obs_dim": 30, "features": 270, "n_logits": 19, "batch_size": args.batch_size,
+                   "n_epochs": args.n_epochs, "agents_per_gpu": 2, "parallelism": "ego + partner on one gpu (single process)",
+                   "launch_mode": "persistent rollout launch + ego-update graph || partner update on a second stream",
+                   "gemm_mode": int(getattr(models[0].policy, "gemm_mode", 0)), "rollout": "persistent" if sp.persistent else "stepwise",
+                   "rollout_requested": "persistent"},
+    }
+    # the rollout alone (one launch for n_steps vector steps)
+    if sp.persistent:
+        alt_pos = alt.pos.clone()
+        th.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        sp.rollout_persistent(T, 1, 0)
+        th.cuda.synchronize(device)
+        result["rollout_ms"] = 1e3 * (time.perf_counter() - t1)
+        alt.pos.copy_(alt_pos)
+        ego.model.rollout_buffer.pos = 0
+    if not args.no_roofline:
+        pol, rb, model = models[0].policy, models[0].rollout_buffer, models[0]
+        lay, hp, ms = pol.layout, models[0].hyper(), C.c_float(0)
+        gm = int(getattr(pol, "gemm_mode", 0))
+        rb.pos = T
+        pol._bind()
+        nat.check(pol.ctx.lib.ph_bench_ppo_grad(pol.ctx.handle, C.byref(pol.spec), pol.params.data_ptr(), C.byref(rb.c_struct()),
+                                                C.byref(hp), int(model.batch_size), 20, gm, C.byref(ms)))
+        rb.pos = 0
+        macs = 2 * (lay.F * 64 + 64 * 64) + 64 * lay.L + 64
+        nb = min(model.batch_size, E * T)
+        flops = 6.0 * macs * nb
+        tiles = (nb + 63) // 64
+        # what the matrix pipe executes (hipcc's assembly of ppo_grad_split_oh_kernel<5, 2, false>: 480 v_mfma_f32_16x16x32_bf16 per
+        # wave and tile -- X is ONE bf16 plane, so the two first-layer products are three terms per block, the rest six)
+        executed = 2.0 * tiles * 4 * 480 * (16 * 16 * 32 * 2)
+        result["roofline"] = {
+            "bound": "mfma", "kernel": "ppo_grad_split_oh_kernel<5, 2, false>", "achieved": flops / (ms.value * 1e-3) / 1e12,
+            "peak": 157.3, "unit": "TFLOP/s", "frac": flops / (ms.value * 1e-3) / 1e12 / 157.3, "traffic": None,
+            "launch_ms": ms.value, "flops_per_launch": flops, "gemm_mode": gm,
+            "frac_basis": "dense convention (SURVEY.md 8d: 6 M per row with the 270-feature first layer counted as SB3 executes it), "
+                          "isolated launches, live HIP events",
+            "executed": {"flops_per_launch": executed, "achieved": executed / (ms.value * 1e-3) / 1e12, "peak": 2500.0,
+                         "unit": "TFLOP/s (bf16 dense)", "frac": executed / (ms.value * 1e-3) / 1e12 / 2500.0,
+                         "note": "the matrix-pipe work the kernel issues: one-hot X as one bf16 plane (three terms per first-layer "
+                                 "block), six terms elsewhere"}}
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args)
+    os.write(json_fd, (json.dumps(result) + "\n").encode())
+    return 0
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -527,6 +624,9 @@ def main():
 
     if args.mode == "roundrobin":
         return bench_roundrobin(args, device, rank, world, json_fd, tdist)
+    if args.workload == "liar" and world == 1 and args.mode == "auto":
+        # BASELINE config 2: the game itself runs on the device (an explicit --mode keeps the synthetic-transition path of the shapes)
+        return bench_liar(args, device, json_fd)
     from pantheonrl_amd.vec import IterationGraph, run_iteration_eager
     log(f"building {args.agents_per_gpu} agents, n_envs={args.n_envs}, n_steps={args.n_steps}, batch={args.batch_size}")
     agents, datas = build_agents(args, device)

@@ -50,8 +50,28 @@ def test_bench_single_gpu_contract():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["dtype"] == "f32" and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["rollout_requested"] == "scripted" and d["config"]["rollout"] == "scripted"
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+
+
+def test_bench_liar_line_runs_the_device_game():
+    """`bench.py --workload liar` (BASELINE config 2) plays the game itself on the device -- not synthetic transitions of its shapes --
+    and carries the gradient kernel's roofline in both conventions (dense 6 M per row, and the executed matrix-pipe work)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "liar", "--n-envs", "64", "--n-steps", "32",
+                        "--n-epochs", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "ego_steps_per_s", "partner_steps_per_s", "rollout_ms"):
+        assert k in d, k
+    assert "LiarsDice" in d["metric"] and d["config"]["features"] == 270 and d["config"]["rollout"] == "persistent"
+    assert d["value"] == pytest.approx(d["ego_steps_per_s"] + d["partner_steps_per_s"], rel=1e-9)
+    assert d["ego_steps_per_s"] > 0 and 0 < d["partner_steps_per_s"] <= d["ego_steps_per_s"] and d["episodes_per_iteration"] > 0
+    rf = d["roofline"]
+    assert rf["kernel"].startswith("ppo_grad_split_oh_kernel") and 0 < rf["frac"] < 1 and 0 < rf["executed"]["frac"] < 1
+    assert rf["executed"]["flops_per_launch"] > rf["flops_per_launch"] / 6            # bf16 terms: more issued work than the dense f32 count / 6
 
 
 def test_bench_two_ranks_agent_per_rank_path():
