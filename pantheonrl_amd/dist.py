@@ -348,7 +348,11 @@ class ActionExchange:
         from . import _native as nat
         if not self.local.is_cuda:
             return False
-        if self.world > 1 and (self.group is not None or dist.get_backend() != "nccl"):
+        # (PANTHEON_RCCL_WITH_GLOO=1: attempt the communicator although the rendezvous group is gloo -- the unique id travels through
+        # the store either way.  tests/scripts/rccl_two_rank.py uses it to make first contact with ncclCommInitRank at nranks = 2 on
+        # whatever the box has: two GPUs -> a real two-rank all-gather; one GPU -> RCCL's duplicate-device refusal and the demotion)
+        if self.world > 1 and (self.group is not None or
+                               (dist.get_backend() != "nccl" and os.environ.get("PANTHEON_RCCL_WITH_GLOO") != "1")):
             return False
         try:
             ident = (C.c_ubyte * 128)()

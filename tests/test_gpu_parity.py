@@ -1657,6 +1657,30 @@ def test_peer_to_peer_exchange_between_processes(world):
     assert out.returncode == 0 and out.stdout.count("P2P_OK") == world, (out.stdout[-1500:], out.stderr[-3000:])
 
 
+def test_rccl_first_contact_with_two_ranks_on_this_box():
+    """ncclCommInitRank with nranks = 2 is attempted for real (tests/scripts/rccl_two_rank.py): on a box with two GPUs the engine-side
+    all-gather must verify against torch.distributed's; on a one-GPU box RCCL refuses the duplicate device and BOTH ranks must come back
+    (no hang), agree that the native route is out and land on the same fallback, which then carries a real exchange.  Until round 6
+    the communicator had only ever been created with one rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "tests", "scripts", "rccl_two_rank.py")]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, out.stdout[-1500:]
+    d = json.loads(line[0])
+    if d["ranks_on_device"] > 1:
+        assert d["rccl_verified"] is False and d["route"] in ("p2p", "torch")
+        assert "native RCCL exchange unavailable" in out.stderr            # the refusal was reported, by name
+    else:
+        assert d["rccl_verified"] is True and d["route"] in ("rccl", "p2p")
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # round 2: sizes and chains the round-1 suite only property-tested, reference-semantics run, truncation bootstrap
 # ----------------------------------------------------------------------------------------------------------------
