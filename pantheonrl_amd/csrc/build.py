@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 INCLUDE = os.path.join(ROOT, "include")
-SOURCES = ["ph_abi.hip", "ph_policy.hip", "ph_gae.hip", "ph_ppo.hip", "ph_ppo_fast.hip", "ph_ppo_split.hip", "ph_ppo_split8.hip", "ph_ppo_split_oh.hip", "ph_envs.hip", "ph_agent.hip", "ph_bc.hip", "ph_adap.hip", "ph_modular.hip", "ph_adapmult.hip"]
+SOURCES = ["ph_abi.hip", "ph_policy.hip", "ph_gae.hip", "ph_ppo.hip", "ph_ppo_fast.hip", "ph_ppo_split.hip", "ph_ppo_split_oh.hip", "ph_envs.hip", "ph_agent.hip", "ph_bc.hip", "ph_adap.hip", "ph_modular.hip", "ph_adapmult.hip"]
 LIB = os.path.join(HERE, "libpantheon_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", HERE, "-Wall", "-Wno-unused-function"]

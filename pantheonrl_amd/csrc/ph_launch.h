@@ -472,7 +472,6 @@ hipError_t launch_weight_image_check(const float* params, const unsigned short* 
                                      hipStream_t s);
 void grad_slab_map_split(const ph_layout& lay, int* map /* host, 2 * RS_NET */, bool fold);
 hipError_t launch_ppo_grad_split(const GradArgs& a, int nwg, hipStream_t s);
-hipError_t launch_ppo_grad_split8(const GradArgs& a, int nwg, size_t lds, hipStream_t s);   // ph_ppo_split8.hip: eight waves per tile
 hipError_t launch_adv_stats(const AdvStatArgs& a, int n_total, hipStream_t s);
 // observation rows (n, D) f32 -> the split kernel's plane image [n + 1][3][64] bf16 (features >= F zero; with `fold` feature 63 is
 // 1: the first layer's bias rides as a feature; row n all zero)

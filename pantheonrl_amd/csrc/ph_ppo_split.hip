@@ -693,19 +693,8 @@ static hipError_t launch_split_nk(const GradArgs& a, int nwg, hipStream_t s) {
   return grad_fast_fold(a.nd) ? launch_split_inst<NK, true>(a, nwg, s) : launch_split_inst<NK, false>(a, nwg, s);
 }
 
-// PH_GRAD_SPLIT8=1: the eight-waves-per-tile form (ph_ppo_split8.hip); same slabs, same image, same LDS request
-static bool grad_split8_enabled() {
-  static int enabled = -1;
-  if (enabled < 0) {
-    const char* e = getenv("PH_GRAD_SPLIT8");
-    enabled = (e && e[0] == '1') ? 1 : 0;
-  }
-  return enabled == 1;
-}
-
 hipError_t launch_ppo_grad_split(const GradArgs& a, int nwg, hipStream_t s) {
   if (nwg < 1 || nwg > a.ntiles) return hipErrorInvalidValue;   // the kernel's tile walk is entered unconditionally (grad_plan: nwg <= ntiles)
-  if (grad_split8_enabled()) return launch_ppo_grad_split8(a, nwg, grad_split_lds_bytes(), s);
   switch (a.nd.L) {
     case 1: return launch_split_nk<1>(a, nwg, s);
     case 2: return launch_split_nk<2>(a, nwg, s);
