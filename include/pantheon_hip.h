@@ -24,7 +24,7 @@
  * Parameter vector layout (float32, P = ph_layout.P entries; H = 64), weights input-major [in][out]
  * (the transpose of torch.nn.Linear.weight):
  *   pi_W1[F][H] pi_b1[H] pi_W2[H][H] pi_b2[H]  vf_W1[F][H] vf_b1[H] vf_W2[H][H] vf_b2[H]
- *   act_W[H][L] act_b[L]  val_W[H] val_b[1]
+ *   act_W[H][L] act_b[L]  val_W[H] val_b[1]  (Box action spaces: + log_std[A], and L = A)
  */
 #ifndef PANTHEON_HIP_H
 #define PANTHEON_HIP_H
@@ -43,6 +43,7 @@ extern "C" {
 #define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
 #define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
 #define PH_MAX_LOGITS 64 /* max total policy logits L */
+#define PH_MAX_BOX_ACT 16 /* max dimensions of a Box (continuous) action space: DiagGaussian head, general kernels */
 #define PH_NSTAT 8       /* per-minibatch stats record, see ph_ppo_train */
 #define PH_MOD_MAX 8     /* max partner modules of a ModularPolicy (ph_modular_*) */
 #define PH_MAX_RANKS 16   /* ranks of one node in the peer-to-peer exchange layouts */
@@ -60,7 +61,11 @@ typedef struct ph_space {
 
 typedef struct ph_spec { /* observation_space / action_space of one agent (multiagentenv.py:72-79) */
   ph_space obs;
-  ph_space act; /* must be PH_SPACE_DISCRETE: the categorical family PPO uses in every BASELINE config */
+  ph_space act; /* PH_SPACE_DISCRETE: the categorical family PPO uses in every BASELINE config (every entry point).
+                   PH_SPACE_BOX (n <= PH_MAX_BOX_ACT): SB3's DiagGaussianDistribution -- the head's n outputs are the means, log_std[n]
+                   follows val_b in the parameter vector (ph_layout.P counts it); actions are float32 rows, clipped to the Box by the caller
+                   (pantheonrl/common/util.py:84-99); ph_policy_forward, ph_ppo_minibatch_grad and ph_ppo_train only -- every other entry
+                   point refuses the spec */
 } ph_spec;
 
 typedef struct ph_layout {

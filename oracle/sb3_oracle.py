@@ -186,7 +186,8 @@ class MlpPolicyOracle(nn.Module):
 
     def __init__(self, obs_space: SpaceSpec, act_space: SpaceSpec, lr: float = 3e-4, ortho_init: bool = True):
         super().__init__()
-        assert act_space.kind in ("discrete", "multidiscrete"), "PPO hot path here is the categorical family"
+        assert act_space.kind in ("discrete", "multidiscrete") or isinstance(self, GaussianMlpPolicyOracle), \
+            "categorical family here; Box action spaces: GaussianMlpPolicyOracle"
         self.obs_space, self.act_space = obs_space, act_space
         Fdim, L = obs_space.flat_len, act_space.flat_len
         self.policy_net = nn.Sequential(nn.Linear(Fdim, HIDDEN), nn.Tanh(), nn.Linear(HIDDEN, HIDDEN), nn.Tanh())
@@ -301,6 +302,61 @@ class MlpPolicyOracle(nn.Module):
         out += [self.action_net.weight.grad.t().contiguous().reshape(-1), self.action_net.bias.grad,
                 self.value_net.weight.grad.reshape(-1), self.value_net.bias.grad]
         return th.cat(out).numpy().astype(np.float32).copy()
+
+
+class GaussianMlpPolicyOracle(MlpPolicyOracle):
+    """SB3 1.7.0 ``ActorCriticPolicy`` over a Box action space **[SB3-mem]**: ``DiagGaussianDistribution`` --
+    ``proba_distribution_net`` = (``Linear(latent_pi, A)`` for the means, ``log_std = nn.Parameter(ones(A) * log_std_init)``,
+    ``log_std_init = 0``); ``action_net`` keeps the 0.01 orthogonal gain.  ``log_prob`` / ``entropy`` are ``Normal``'s summed over
+    the action dimensions (``sum_independent_dims``); actions are NOT squashed or clipped inside the policy -- the caller clips what
+    the environment gets (reference ``pantheonrl/common/util.py:84-99``), the rollout buffer keeps the raw sample.
+    Flat parameter vector: MlpPolicyOracle's, then ``log_std`` (include/pantheon_hip.h)."""
+
+    def __init__(self, obs_space: SpaceSpec, act_space: SpaceSpec, lr: float = 3e-4, ortho_init: bool = True):
+        assert act_space.kind == "box"
+        super().__init__(obs_space, act_space, lr=lr, ortho_init=ortho_init)
+        self.log_std = nn.Parameter(th.zeros(act_space.dim))
+        self.optimizer = th.optim.Adam(self.parameters(), lr=lr, eps=1e-5)
+
+    def _dist(self, latent_pi: th.Tensor):
+        mean = self.action_net(latent_pi)
+        return th.distributions.Normal(mean, th.ones_like(mean) * self.log_std.exp())
+
+    def forward(self, obs: th.Tensor, deterministic: bool = False, uniforms: Optional[th.Tensor] = None,
+                action_mask: Optional[th.Tensor] = None):
+        """-> (actions (n, A) float32, values (n,1), log_prob (n,)).  ``uniforms`` (n, A) teacher-forces the STANDARD-NORMAL
+        draws (actions = mean + std * eps); without it ``Normal.rsample()`` like SB3."""
+        assert action_mask is None
+        latent_pi, latent_vf = self._latents(obs)
+        values = self.value_net(latent_vf)
+        dist = self._dist(latent_pi)
+        if deterministic:
+            a = dist.mean
+        elif uniforms is not None:
+            a = dist.mean + dist.stddev * uniforms.float()
+        else:
+            a = dist.rsample()
+        return a, values, dist.log_prob(a).sum(dim=1)
+
+    def evaluate_actions(self, obs: th.Tensor, actions: th.Tensor, action_mask: Optional[th.Tensor] = None):
+        assert action_mask is None
+        latent_pi, latent_vf = self._latents(obs)
+        dist = self._dist(latent_pi)
+        actions = actions.float().reshape(obs.shape[0], -1)
+        return self.value_net(latent_vf), dist.log_prob(actions).sum(dim=1), dist.entropy().sum(dim=1)
+
+    def flat_params(self) -> np.ndarray:
+        return np.concatenate([super().flat_params(), self.log_std.detach().numpy().astype(np.float32)])
+
+    def load_flat_params(self, flat: np.ndarray) -> None:
+        flat = np.asarray(flat, np.float32)
+        A = self.act_space.dim
+        super().load_flat_params(flat[:-A])
+        with th.no_grad():
+            self.log_std.copy_(th.as_tensor(flat[-A:]))
+
+    def flat_grads(self) -> np.ndarray:
+        return np.concatenate([super().flat_grads(), self.log_std.grad.numpy().astype(np.float32)])
 
 
 class AdapMultPolicyOracle(MlpPolicyOracle):

@@ -12,6 +12,7 @@ from typing import Optional, Sequence
 PH_HIDDEN = 64
 PH_MAX_COMP = 256
 PH_MAX_LOGITS = 64
+PH_MAX_BOX_ACT = 16
 PH_NSTAT = 8
 PH_SPACE_BOX = 0
 PH_SPACE_DISCRETE = 1

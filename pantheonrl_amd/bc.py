@@ -29,6 +29,9 @@ class FeedForward32Policy:
     def __init__(self, observation_space, action_space, device="cuda", ortho_init: bool = True, seed: Optional[int] = None):
         self.device = _require_cuda(device)
         self.observation_space, self.action_space = observation_space, action_space
+        if type(action_space).__name__ == "Box":
+            raise ValueError("BC's FeedForward32Policy clones categorical (Discrete / MultiDiscrete) actions (reference bc.py:291-303 "
+                             "on the engine's heads); Box action spaces are PPO's GaussianActorCriticPolicy only")
         self.spec = sp.make_spec(observation_space, action_space)
         self.ctx = nat.Context(self.device.index)
         self.layout = nat.PhBcLayout()

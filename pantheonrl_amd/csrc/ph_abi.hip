@@ -177,7 +177,8 @@ int layout_of(const ph_spec* spec, ph_layout* o) {
   if (!spec || !o) return fail("null spec/layout");
   if (check_space(spec->obs, "observation space")) return 1;
   if (check_space(spec->act, "action space")) return 1;
-  if (spec->act.kind != PH_SPACE_DISCRETE) return fail("action space must be Discrete/MultiDiscrete (categorical PPO path)");
+  const bool gauss = spec->act.kind == PH_SPACE_BOX;   // Box actions: DiagGaussian head, A means + log_std[A] (general kernels only)
+  if (gauss && spec->act.n > PH_MAX_BOX_ACT) return fail("Box action spaces: at most PH_MAX_BOX_ACT dimensions");
   o->D = spec->obs.n;
   o->F = 0;
   if (spec->obs.kind == PH_SPACE_BOX) o->F = spec->obs.n;
@@ -185,7 +186,9 @@ int layout_of(const ph_spec* spec, ph_layout* o) {
     for (int i = 0; i < spec->obs.n; ++i) o->F += spec->obs.nvec[i];
   o->A = spec->act.n;
   o->L = 0;
-  for (int i = 0; i < spec->act.n; ++i) o->L += spec->act.nvec[i];
+  if (gauss) o->L = spec->act.n;   // the head's outputs are the A means
+  else
+    for (int i = 0; i < spec->act.n; ++i) o->L += spec->act.nvec[i];
   if (o->L > PH_MAX_LOGITS) return fail("too many logits (PH_MAX_LOGITS)");
   const int H = PH_HIDDEN;
   int off = 0;
@@ -201,13 +204,20 @@ int layout_of(const ph_spec* spec, ph_layout* o) {
   o->act_b = off; off += o->L;
   o->val_W = off; off += H;
   o->val_b = off; off += 1;
+  if (gauss) off += o->A;   // log_std[A] (SB3 DiagGaussianDistribution.proba_distribution_net's nn.Parameter), behind val_b
   o->P = off;
   return 0;
 }
 
 // device-resident prefix sums of the nvec arrays, cached per distinct spec
-int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd) {
+// box_act_ok: the caller's kernels know the DiagGaussian head (the general forward / gradient kernels: ph_policy_forward,
+// ph_ppo_minibatch_grad, ph_ppo_train); every other entry point refuses a Box action space here
+int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd, bool box_act_ok = false) {
   if (layout_of(spec, &nd->lay)) return 1;
+  const bool gauss = spec->act.kind == PH_SPACE_BOX;
+  if (gauss && !box_act_ok)
+    return fail("Box (continuous) action spaces run on ph_policy_forward / ph_ppo_minibatch_grad / ph_ppo_train only "
+                "(the DiagGaussian head lives in the general kernels)");
   SpecCache* hit = nullptr;
   for (auto& c : ctx->specs)
     if (std::memcmp(&c.spec, spec, sizeof(ph_spec)) == 0) { hit = &c; break; }
@@ -216,7 +226,7 @@ int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd) {
     SpecCache c;
     std::memcpy(&c.spec, spec, sizeof(ph_spec));
     std::vector<int> ao(spec->act.n + 1, 0);
-    for (int i = 0; i < spec->act.n; ++i) ao[i + 1] = ao[i] + spec->act.nvec[i];
+    for (int i = 0; i < spec->act.n; ++i) ao[i + 1] = ao[i] + (gauss ? 1 : spec->act.nvec[i]);
     PH_HIP(hipMalloc((void**)&c.act_off, ao.size() * sizeof(int)));
     PH_HIP(hipMemcpy(c.act_off, ao.data(), ao.size() * sizeof(int), hipMemcpyHostToDevice));
     if (spec->obs.kind == PH_SPACE_DISCRETE) {
@@ -233,6 +243,7 @@ int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd) {
       probe.L = nd->lay.L;
       probe.F = nd->lay.F;
       probe.obs_kind = spec->obs.kind;
+      probe.gauss = gauss ? 1 : 0;
       if (ph::grad_uses_reg_slabs(probe)) {
         std::vector<int> m(2 * ph::RS_NET);
         ph::grad_slab_map(nd->lay, m.data(), ph::grad_fast_fold(probe));
@@ -280,14 +291,15 @@ int resolve(ph_ctx* ctx, const ph_spec* spec, ph::NetDims* nd) {
   nd->wimage_elems = hit->wimage_elems;
   nd->spec_id = hit->id;
   nd->obs_kind = spec->obs.kind;
+  nd->gauss = gauss ? 1 : 0;
   nd->D = nd->lay.D;
   nd->F = nd->lay.F;
   nd->A = nd->lay.A;
   nd->L = nd->lay.L;
   nd->Lp = ((nd->L + 31) / 32) * 32;
   nd->nchunk = (nd->F + PH_HIDDEN - 1) / PH_HIDDEN;
-  nd->head16 = spec->act.n <= 4;
-  for (int i = 0; i < spec->act.n && i < 4; ++i) nd->head16 = nd->head16 && spec->act.nvec[i] <= 16;
+  nd->head16 = !gauss && spec->act.n <= 4;
+  for (int i = 0; i < spec->act.n && i < 4 && !gauss; ++i) nd->head16 = nd->head16 && spec->act.nvec[i] <= 16;
   nd->obs_off = hit->obs_off;
   nd->act_off = hit->act_off;
   return 0;
@@ -800,7 +812,8 @@ int ph_policy_forward(ph_ctx* ctx, const ph_spec* spec, const float* params, con
   if (n <= 0) return fail("ph_policy_forward: n must be positive");
   ph::FwdArgs a;
   std::memset(&a, 0, sizeof(a));
-  if (resolve(ctx, spec, &a.nd)) return 1;
+  if (resolve(ctx, spec, &a.nd, true)) return 1;
+  if (a.nd.gauss && action_mask) return fail("ph_policy_forward: action masks belong to the categorical heads");
   a.params = params;
   a.obs = obs;
   a.n = n;
@@ -1875,7 +1888,7 @@ int train_prepare(TrainPlan& t, ph_ctx* ctx, const ph_spec* spec, const ph_opt_s
   if (!hp) return fail("ph_ppo_train: null hyper-parameters");
   if (check_rb(rb)) return 1;
   if (n_epochs <= 0 || batch_size <= 0) return fail("ph_ppo_train: n_epochs and batch_size must be positive");
-  if (resolve(ctx, spec, &t.nd)) return 1;
+  if (resolve(ctx, spec, &t.nd, true)) return 1;
   select_gemm(t.nd, gemm_mode);
   t.ctx = ctx;
   t.opt = opt;
@@ -2009,6 +2022,7 @@ int train_run(ph_ctx* ctx, const ph_spec* spec, const ph_opt_state* opt, const p
               const ph_adap_loss* adap) {
   TrainPlan t;
   if (train_prepare(t, ctx, spec, opt, rb, hp, n_epochs, batch_size, perms, perm_seed, stats, gemm_mode, adap != nullptr)) return 1;
+  if (adap && t.nd.gauss) return fail("ph_adap_train: the context term is written for the categorical heads");
   if (adap && adap_check(ctx, t.nd, adap, "ph_adap_train")) return 1;
   t.adap = adap;
   for (int mbi = 0; mbi < n_epochs * t.n_mb; ++mbi) {
@@ -2106,7 +2120,7 @@ int minibatch_grad_run(ph_ctx* ctx, const ph_spec* spec, const float* params, co
   if (check_rb(rb)) return 1;
   if (nb <= 0) return fail("ph_ppo_minibatch_grad: nb must be positive");
   ph::NetDims nd;
-  if (resolve(ctx, spec, &nd)) return 1;
+  if (resolve(ctx, spec, &nd, adap == nullptr)) return 1;
   select_gemm(nd, gemm_mode);
   const int P = nd.lay.P;
   const MbPlan pl = plan_minibatch(ctx, nd, nb);

@@ -210,6 +210,8 @@ struct NetDims {
   int slab_len_split;  // floats per gradient slab in that kernel's accumulator order
   int wimage_elems;    // bf16 elements of its weight fragment image
   int spec_id;         // the spec-cache entry this record was resolved from (> 0; identifies a spec across calls)
+  int gauss;           // 1: Box action space -- DiagGaussian head (SB3 DiagGaussianDistribution): the A head outputs are the means, log_std[A]
+                       // sits behind val_b in the parameter vector (lay.val_b + 1); 0 (also of a zeroed record): the categorical family
   ph_layout lay;
 };
 

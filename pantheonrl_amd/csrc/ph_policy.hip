@@ -18,14 +18,43 @@ namespace ph {
 // offset, logits output, then per action component sampling / argmax / given action, log-prob, entropy and the
 // rollout-buffer writes (Discrete and MultiDiscrete; Discrete with <= 8 logits takes the register path)
 __device__ __forceinline__ void general_row_tail(const FwdArgs& a, const NetDims& nd, int g, float* z, uint64_t ctr) {
-  const bool small = nd.A == 1 && nd.L <= 8;
+  const bool small = !nd.gauss && nd.A == 1 && nd.L <= 8;
   if (a.mask && !small) {  // modular/policies.py:330-333 : logits - 30*(~mask)
     for (int k = 0; k < nd.L; ++k) z[k] = z[k] - 30.0f * (1.0f - (float)(a.mask[(size_t)g * nd.L + k] != 0));
   }
   if (a.logits && !small)
     for (int k = 0; k < nd.L; ++k) a.logits[(size_t)g * nd.L + k] = z[k];
   float logp = 0.f, ent = 0.f;
-  if (small) {
+  if (nd.gauss) {
+    // Box action space: SB3's DiagGaussianDistribution -- z[0..A) are the means, log_std[A] follows val_b in the parameter vector.
+    // action = mean + exp(log_std) * eps; log-prob and entropy are the sums over the dimensions of Normal's.  `uniforms` carries
+    // the STANDARD-NORMAL draws eps when given (teacher forcing), else Box-Muller over two Philox uniforms per dimension.
+    const float* ls = a.params + nd.lay.val_b + 1;
+    for (int c = 0; c < nd.A; ++c) {
+      const float mu = z[c], lsd = ls[c];
+      float act;
+      if (a.given_actions) act = a.given_actions[(size_t)g * nd.A + c];
+      else if (a.deterministic) act = mu;
+      else {
+        float eps;
+        if (a.uniforms) eps = a.uniforms[(size_t)g * nd.A + c];
+        else {
+          const float u1 = philox_uniform(a.seed, ctr, (uint32_t)g, (uint32_t)c);
+          const float u2 = philox_uniform(a.seed, ctr, (uint32_t)g, (uint32_t)(c + 128));
+          eps = __builtin_sqrtf(-2.0f * fast_log(fmaxf(u1, 1.0e-30f))) * __builtin_cosf(6.28318530717958647692f * u2);
+        }
+        act = mu + fast_exp(lsd) * eps;
+      }
+      const float d = (act - mu) * fast_exp(-lsd);
+      logp += (-0.5f * d * d - lsd) - 0.91893853320467274178f;   // - log sqrt(2 pi)
+      ent += 1.41893853320467274178f + lsd;                       // 0.5 + 0.5 log(2 pi) + log_std
+      if (a.act_f32) a.act_f32[(size_t)g * nd.A + c] = act;
+      if (a.rb_act) {
+        const long long ridx = rb_row(a, g);
+        if (ridx >= 0) a.rb_act[(size_t)ridx * nd.A + c] = act;
+      }
+    }
+  } else if (small) {
     // fast path (Discrete action space, <= 8 logits): the row lives in registers, one exp per logit
     float zr[8];
 #pragma unroll
@@ -511,7 +540,7 @@ bool fwd16_eligible(const NetDims& nd, int n) {
     const char* e = getenv("PH_FWD16");
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
-  return enabled && nd.nchunk == 1 && nd.A == 1 && nd.L <= 8 && n < 16384;
+  return enabled && !nd.gauss && nd.nchunk == 1 && nd.A == 1 && nd.L <= 8 && n < 16384;
 }
 
 template <bool VALU>
@@ -1635,7 +1664,7 @@ static bool fwd16h_eligible(const NetDims& nd, int n) {
     const char* e = getenv("PH_FWD16H");
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
-  return enabled && nd.obs_kind != PH_SPACE_BOX && nd.obs_off && nd.D <= 64 && nd.Lp == 32 && n < 16384;
+  return enabled && !nd.gauss && nd.obs_kind != PH_SPACE_BOX && nd.obs_off && nd.D <= 64 && nd.Lp == 32 && n < 16384;
 }
 
 template <bool VALU>

@@ -437,6 +437,40 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
         const int phys = rowphys[tid];
         if (phys < 0) {
           for (int k = 0; k < Lp; ++k) z[k] = 0.f;
+        } else if (nd.gauss) {
+          // Box action space (SB3 DiagGaussianDistribution; A <= 16 <= Lp / 2): z[0..A) are the means.  log-prob and entropy as in
+          // general_row_tail; dL/dmean_c = g_lp (a - mu) / sigma^2 goes over z[c] (the head's dOut), dL/dlog_std_c =
+          // g_lp (((a - mu) / sigma)^2 - 1) + g_en to column 16 + c of the row: S5a sums that column over the rows like a bias
+          // gradient, the head products see it times Wo's zero padding columns
+          const float* ls = a.params + lay.val_b + 1;
+          float logp = 0.f, ent = 0.f;
+          for (int c = 0; c < nd.A; ++c) {
+            const float lsd = ls[c];
+            const float d = (a.rb_act[(size_t)phys * nd.A + c] - z[c]) * fast_exp(-lsd);
+            logp += (-0.5f * d * d - lsd) - 0.91893853320467274178f;
+            ent += 1.41893853320467274178f + lsd;
+          }
+          const float adv = radv[tid];
+          const float lr = logp - rold[tid];
+          const float ratio = fast_exp(lr);
+          const float lo_c = 1.0f - a.clip, hi_c = 1.0f + a.clip;
+          const float rc = fminf(fmaxf(ratio, lo_c), hi_c);
+          const float pl1 = adv * ratio, pl2 = adv * rc;
+          const float inr = (ratio >= lo_c && ratio <= hi_c) ? 1.f : 0.f;
+          const float gate = (pl1 < pl2) ? 1.f : ((pl1 > pl2) ? inr : 0.5f + 0.5f * inr);
+          const float g_lp = -inv_nb * adv * ratio * gate;
+          const float g_en = -a.ent_coef * inv_nb;
+          st[0] += -fminf(pl1, pl2);
+          st[2] += -ent;
+          st[3] += (fabsf(ratio - 1.0f) > a.clip) ? 1.f : 0.f;
+          st[4] += (ratio - 1.0f) - lr;
+          for (int k = nd.A; k < Lp; ++k) z[k] = 0.f;
+          for (int c = 0; c < nd.A; ++c) {
+            const float is = fast_exp(-ls[c]);
+            const float d = (a.rb_act[(size_t)phys * nd.A + c] - z[c]) * is;
+            z[16 + c] = g_lp * (d * d - 1.0f) + g_en;
+            z[c] = g_lp * d * is;
+          }
         } else if (nd.A == 1 && nd.L <= 8) {
           // fast path (Discrete action space, <= 8 logits: every BASELINE config but Liar's Dice): the row lives in
           // registers, one LDS read and one LDS write per logit, one exp per logit
@@ -577,6 +611,11 @@ __global__ __launch_bounds__(R * 4, 2) void ppo_grad_kernel(GradArgs a) {
         float s = first ? 0.f : slab[lay.act_b + k];
         s = lds_colsum<R>(outs + k, LDO, s);
         slab[lay.act_b + k] = s;
+      } else if (nd.gauss && tid >= NT - 64 + 16 && tid - (NT - 64 + 16) < nd.A) {  // d log_std: column 16 + c of the rows (S4)
+        const int k = tid - (NT - 64 + 16);
+        float s = first ? 0.f : slab[lay.val_b + 1 + k];
+        s = lds_colsum<R>(outs + 16 + k, LDO, s);
+        slab[lay.val_b + 1 + k] = s;
       }
       __syncthreads();
       if (first) PH_STAMP(a.prof, 8);

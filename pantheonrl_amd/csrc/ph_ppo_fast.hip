@@ -537,7 +537,7 @@ bool grad_fast_eligible(const NetDims& nd) {
     const char* e = getenv("PH_GRAD_FAST");
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
-  return enabled && nd.nchunk == 1 && nd.A == 1 && nd.L <= 8;
+  return enabled && !nd.gauss && nd.nchunk == 1 && nd.A == 1 && nd.L <= 8;
 }
 
 // FOLD variant: Box observations with a free 64th feature column

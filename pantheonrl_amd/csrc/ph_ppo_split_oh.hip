@@ -772,7 +772,7 @@ bool grad_split_oh_eligible(const NetDims& nd) {
     const char* e = getenv("PH_GRAD_SPLIT_OH");
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
-  if (!enabled || nd.A < 1 || nd.A > 4 || nd.L > 16 * OH_LBMAX || nd.nchunk < 1 || grad_fast_eligible(nd)) return false;
+  if (!enabled || nd.gauss || nd.A < 1 || nd.A > 4 || nd.L > 16 * OH_LBMAX || nd.nchunk < 1 || grad_fast_eligible(nd)) return false;
   if (nd.obs_kind == PH_SPACE_BOX) return nd.nchunk <= 4;
   return nd.nchunk <= 5 && nd.D <= 64;
 }

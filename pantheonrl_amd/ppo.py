@@ -208,6 +208,10 @@ class ActorCriticPolicy:
 
     def __init__(self, observation_space, action_space, lr: float = 3e-4, device="cuda",
                  ortho_init: bool = True, seed: Optional[int] = None, sampling_stream: int = 0):
+        if type(action_space).__name__ == "Box" and not getattr(self, "gaussian_head", False):
+            # (UnsupportedPolicyConfig is defined below; this is the same refusal, raised before the device is touched)
+            raise UnsupportedPolicyConfig(f"{type(self).__name__} is written for the categorical heads (Discrete / MultiDiscrete "
+                                          "actions); Box action spaces run on PPO's GaussianActorCriticPolicy (DiagGaussian head)")
         self.device = _require_cuda(device)
         self.observation_space, self.action_space = observation_space, action_space
         self.spec = sp.make_spec(observation_space, action_space)
@@ -398,6 +402,68 @@ class ActorCriticPolicy:
         return None
 
 
+class GaussianActorCriticPolicy(ActorCriticPolicy):
+    """SB3's MlpPolicy over a Box (continuous) action space: the same two 64-64 tanh towers, `action_net` gives the A means and
+    `log_std` (A entries, initialised to 0: SB3's log_std_init) is a free parameter -- DiagGaussianDistribution.  Actions are float32
+    rows, stored UNclipped in the rollout buffer; `clip_actions` (reference pantheonrl/common/util.py:84-99) clips what the
+    environment gets.  Runs on the general forward / gradient kernels (ph_policy_forward, ph_ppo_train); the 16-row rollout
+    forwards, the one-launch rollouts and the split-bf16 gradient kernels are written for the categorical heads and refuse the
+    spec in the library.  `uniforms` of forward() teacher-forces the STANDARD-NORMAL draws here."""
+
+    host_step_path = False   # ph_policy_act_host returns int32 actions
+    gaussian_head = True
+    # the vectorised agents, the one-launch rollouts and the joint update hand int32 action rows around: they refuse this policy by
+    # require_mlp_kernels; PPO.train()'s own entry point (ph_ppo_train: the general gradient kernel) knows the head
+    fused_mlp_kernels = False
+
+    def _init_weights(self, ortho_init: bool) -> None:
+        super()._init_weights(ortho_init)          # log_std stays 0 behind val_b
+        lay = self.layout
+        assert lay.P == lay.val_b + 1 + lay.A
+
+    def log_std(self) -> th.Tensor:
+        lay = self.layout
+        return self.params[lay.val_b + 1:lay.val_b + 1 + lay.A]
+
+    def state_dict(self) -> Dict[str, th.Tensor]:
+        out = super().state_dict()
+        out["log_std"] = self.log_std().detach().cpu().clone()
+        return out
+
+    def load_state_dict(self, sd: Dict[str, th.Tensor]) -> None:
+        super().load_state_dict(sd)
+        lay = self.layout
+        self.params[lay.val_b + 1:lay.val_b + 1 + lay.A] = th.as_tensor(sd["log_std"]).float().reshape(-1).to(self.device)
+
+    def _launch(self, obs_t, *, mask=None, uniforms=None, given=None, deterministic=False, want_logits=False,
+                want_entropy=False, rb: Optional[RolloutBuffer] = None, pos: int = 0, episode_start=None):
+        if mask is not None:
+            raise nat.NativeError("action masks belong to the categorical heads")
+        n, lay, dev = obs_t.shape[0], self.layout, self.device
+        acts = th.empty((n, lay.A), dtype=th.float32, device=dev)
+        values = th.empty((n, 1), dtype=th.float32, device=dev)
+        logp = th.empty((n,), dtype=th.float32, device=dev)
+        means = th.empty((n, lay.L), dtype=th.float32, device=dev) if want_logits else None
+        ent = th.empty((n,), dtype=th.float32, device=dev) if want_entropy else None
+        u = None if uniforms is None else _f32_dev(uniforms, dev, (n, lay.A))
+        g = None if given is None else _f32_dev(given, dev, (n, lay.A))
+        es = None if episode_start is None else _f32_dev(episode_start, dev, (n,))
+        self._bind()
+        self._counter += 1
+        nat.check(self.ctx.lib.ph_policy_forward(
+            self.ctx.handle, C.byref(self.spec), self.params.data_ptr(), obs_t.data_ptr(), n, None, nat.ptr(u),
+            nat.ptr(g), self._seed, self._counter, int(bool(deterministic)), None, acts.data_ptr(), values.data_ptr(),
+            logp.data_ptr(), nat.ptr(ent), nat.ptr(means), C.byref(rb.c_struct()) if rb is not None else None,
+            int(pos), nat.ptr(es), None, int(self.gemm_mode)))
+        return acts, values, logp, ent, means
+
+    def _shape_actions(self, acts: th.Tensor) -> th.Tensor:
+        return acts.reshape((-1,) + tuple(self.action_space.shape))
+
+    def forward_and_store_host(self, *a, **k):
+        raise nat.NativeError("GaussianActorCriticPolicy: the one-call host step returns integer actions; use forward_and_store")
+
+
 def require_mlp_kernels(policy, who: str) -> None:
     """refuse a policy whose parameter vector is not the plain MLP's before an engine path would read it as one"""
     if not getattr(policy, "fused_mlp_kernels", True):
@@ -470,13 +536,19 @@ def check_policy_kwargs(policy_kwargs: Optional[Dict[str, Any]]) -> Dict[str, An
 
 
 def check_action_space(action_space) -> None:
-    """Box (continuous) actions need a DiagGaussian head and `clip_actions`' np.clip (reference pantheonrl/common/util.py:84-99);
-    the engine's heads are Categorical / MultiCategorical"""
+    """the engine's heads: Categorical / MultiCategorical (every kernel) and DiagGaussian for one-dimensional Box spaces
+    (GaussianActorCriticPolicy: general kernels; `clip_actions`' np.clip is reference pantheonrl/common/util.py:84-99)"""
     kind = type(action_space).__name__
+    if kind == "Box":
+        shape = tuple(getattr(action_space, "shape", ()))
+        if len(shape) != 1 or shape[0] > nat.PH_MAX_BOX_ACT:
+            raise UnsupportedPolicyConfig(f"action space {action_space!r}: Box action spaces of one dimension and at most "
+                                          f"{nat.PH_MAX_BOX_ACT} components (DiagGaussian head, general kernels)")
+        return
     if kind not in ("Discrete", "MultiDiscrete"):
         raise UnsupportedPolicyConfig(
-            f"action space {action_space!r}: the MI355X engine implements Discrete / MultiDiscrete action heads; a {kind} action space "
-            "would need SB3's DiagGaussian / Bernoulli head and the clipping of reference pantheonrl/common/util.py:84-99")
+            f"action space {action_space!r}: the MI355X engine implements Discrete / MultiDiscrete (categorical) and Box (DiagGaussian, "
+            f"clipped by reference pantheonrl/common/util.py:84-99) action heads; a {kind} action space would need SB3's Bernoulli head")
 
 
 class PPO:
@@ -542,9 +614,10 @@ class PPO:
 
     def _setup_model(self) -> None:
         check_action_space(self.action_space)
-        self.policy = ActorCriticPolicy(self.observation_space, self.action_space, lr=self.learning_rate,
-                                        device=self.device, seed=self.seed, sampling_stream=self.sampling_stream,
-                                        **getattr(self, "_policy_args", {}))
+        policy_cls = GaussianActorCriticPolicy if type(self.action_space).__name__ == "Box" else ActorCriticPolicy
+        self.policy = policy_cls(self.observation_space, self.action_space, lr=self.learning_rate,
+                                 device=self.device, seed=self.seed, sampling_stream=self.sampling_stream,
+                                 **getattr(self, "_policy_args", {}))
         self.rollout_buffer = RolloutBuffer(self.n_steps, self.observation_space, self.action_space, self.device,
                                             self.policy.ctx, self.policy.spec, gae_lambda=self.gae_lambda,
                                             gamma=self.gamma, n_envs=self.n_envs)
@@ -637,7 +710,8 @@ class PPO:
 
     def _train_native(self, pol, opt, rb, hp, perm_t, stats) -> None:
         """the update itself; subclasses with an additional loss term (ADAP) issue their own entry point here"""
-        require_mlp_kernels(pol, "PPO.train")
+        if not getattr(pol, "gaussian_head", False):
+            require_mlp_kernels(pol, "PPO.train")
         nat.check(pol.ctx.lib.ph_ppo_train(pol.ctx.handle, C.byref(pol.spec), C.byref(opt), C.byref(rb.c_struct()),
                                            C.byref(hp), int(self.n_epochs), int(self.batch_size), nat.ptr(perm_t),
                                            int(self.permutation_seed), stats.data_ptr(), int(pol.gemm_mode)))
@@ -698,6 +772,8 @@ class PPO:
                 actions, _, _ = pol.forward_and_store(self._last_obs, rb, self._last_episode_starts,
                                                       uniforms=None if forced_uniforms is None else forced_uniforms[t])
                 act_np = actions.cpu().numpy()
+            if type(self.action_space).__name__ == "Box":   # SB3 collect_rollouts: the environment gets the clipped action,
+                act_np = np.clip(act_np, self.action_space.low, self.action_space.high)   # the buffer row keeps the raw sample
             new_obs, rewards, dones, infos = env.step(act_np)
             self.num_timesteps += self.n_envs
             if callback is not None and hasattr(callback, "on_step"):

@@ -106,14 +106,16 @@ def action_dim(space) -> int:
         return 1
     if k == "MultiDiscrete":
         return len(space.nvec)
-    raise SpaceException("the MI355X PPO path implements the categorical family (Discrete / MultiDiscrete actions)")
+    if k == "Box" and len(space.shape) == 1:
+        return int(space.shape[0])        # SB3 get_action_dim: Box -> int(np.prod(shape)); one-dimensional shapes only here
+    raise SpaceException("the MI355X PPO path implements Discrete / MultiDiscrete and one-dimensional Box action spaces")
 
 
 def to_native_space(space, role: str) -> nat.PhSpace:
     k = _kind(space)
     if k == "Box":
-        if role == "act":
-            raise SpaceException("Box action spaces are not on the categorical PPO path")
+        if role == "act" and (len(space.shape) != 1 or int(space.shape[0]) > nat.PH_MAX_BOX_ACT):
+            raise SpaceException(f"Box action spaces: one dimension of at most {nat.PH_MAX_BOX_ACT} components (DiagGaussian head)")
         return nat.make_space(nat.PH_SPACE_BOX, int(np.prod(space.shape)))
     if k == "Discrete":
         return nat.make_space(nat.PH_SPACE_DISCRETE, 1, [space.n])

@@ -4,7 +4,7 @@ from __future__ import annotations
 import numpy as np
 import torch as th
 
-from oracle.sb3_oracle import MlpPolicyOracle, PPOHyper, RolloutBufferOracle, SpaceSpec
+from oracle.sb3_oracle import GaussianMlpPolicyOracle, MlpPolicyOracle, PPOHyper, RolloutBufferOracle, SpaceSpec
 
 # BASELINE.json configs: name -> (obs SpaceSpec, act SpaceSpec)
 CONFIGS = {
@@ -35,13 +35,20 @@ CONFIGS = {
     # Box observations of three and four feature chunks with heads inside the wide split kernel's class (<= 32 logits)
     "box130": (SpaceSpec("box", dim=130), SpaceSpec("multidiscrete", nvec=(5, 16, 11))),
     "box200": (SpaceSpec("box", dim=200), SpaceSpec("discrete", nvec=(20,))),
+    # Box (continuous) action spaces: SB3's DiagGaussian head on the general kernels -- one dimension on the shape the categorical
+    # fast kernels would take, MPE's continuous 5-vector, two feature chunks, one-hot observations, the widest head (16)
+    "gauss1": (SpaceSpec("box", dim=62), SpaceSpec("box", dim=1)),
+    "gauss5": (SpaceSpec("box", dim=48), SpaceSpec("box", dim=5)),
+    "gauss_wide": (SpaceSpec("box", dim=70), SpaceSpec("box", dim=3)),
+    "gauss_onehot": (SpaceSpec("multidiscrete", nvec=(3, 4, 5, 2, 6)), SpaceSpec("box", dim=2)),
+    "gauss16": (SpaceSpec("box", dim=8), SpaceSpec("box", dim=16)),
 }
 
 
-def to_space(spec: SpaceSpec):
+def to_space(spec: SpaceSpec, role: str = "obs"):
     from pantheonrl_amd import spaces as sp
     if spec.kind == "box":
-        return sp.Box(-np.inf, np.inf, (spec.dim,))
+        return sp.Box(-np.inf, np.inf, (spec.dim,)) if role == "obs" else sp.Box(-1.0, 1.0, (spec.dim,))
     if spec.kind == "discrete":
         return sp.Discrete(spec.nvec[0])
     return sp.MultiDiscrete(list(spec.nvec))
@@ -57,7 +64,7 @@ def oracle_policy(name: str, seed: int = 0, perturb: float = 0.3) -> MlpPolicyOr
     """seeded oracle policy; biases and the 0.01-gain action head are perturbed so logits are not ~uniform."""
     th.manual_seed(seed)
     obs_s, act_s = CONFIGS[name]
-    pol = MlpPolicyOracle(obs_s, act_s)
+    pol = (GaussianMlpPolicyOracle if act_s.kind == "box" else MlpPolicyOracle)(obs_s, act_s)
     g = th.Generator().manual_seed(seed + 1)
     with th.no_grad():
         for p in pol.parameters():
@@ -68,9 +75,10 @@ def oracle_policy(name: str, seed: int = 0, perturb: float = 0.3) -> MlpPolicyOr
 
 
 def device_policy(name: str, oracle: MlpPolicyOracle):
-    from pantheonrl_amd.ppo import ActorCriticPolicy
+    from pantheonrl_amd.ppo import ActorCriticPolicy, GaussianActorCriticPolicy
     obs_s, act_s = CONFIGS[name]
-    pol = ActorCriticPolicy(to_space(obs_s), to_space(act_s), device="cuda", seed=0)
+    cls = GaussianActorCriticPolicy if act_s.kind == "box" else ActorCriticPolicy
+    pol = cls(to_space(obs_s), to_space(act_s, "act"), device="cuda", seed=0)
     pol.set_flat_params(oracle.flat_params())
     return pol
 
@@ -106,7 +114,7 @@ def upload_buffer(dev_buf, ob: RolloutBufferOracle) -> None:
 def make_device_buffer(name: str, pol, T: int, E: int):
     from pantheonrl_amd.ppo import RolloutBuffer
     obs_s, act_s = CONFIGS[name]
-    return RolloutBuffer(T, to_space(obs_s), to_space(act_s), pol.device, pol.ctx, pol.spec, n_envs=E)
+    return RolloutBuffer(T, to_space(obs_s), to_space(act_s, "act"), pol.device, pol.ctx, pol.spec, n_envs=E)
 
 
 __all__ = ["CONFIGS", "PPOHyper", "to_space", "sample_obs", "oracle_policy", "device_policy",

@@ -122,7 +122,7 @@ def test_gae_full_size_closed_forms():
 # ----------------------------------------------------------------------------------------------------------------
 # K4 forward / evaluate
 # ----------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", list(H.CONFIGS))
+@pytest.mark.parametrize("name", [c for c in H.CONFIGS if H.CONFIGS[c][1].kind != "box"])   # (Box actions: test_gpu_gaussian.py)
 @pytest.mark.parametrize("n", [1, 31, 33, 256, 1000])
 def test_forward_matches_oracle(name, n):
     orac = H.oracle_policy(name, seed=3)

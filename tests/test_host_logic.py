@@ -654,23 +654,67 @@ def test_policy_kwargs_are_accepted_for_the_default_network_and_refused_by_name_
             PPO("MlpPolicy", None, policy_kwargs=ok[2], device="cuda")
 
 
-def test_box_action_spaces_are_refused_at_construction_with_the_reference_line():
-    """util.py:84-99 (`clip_actions`) is the only place the reference treats Box actions; the engine's heads are categorical"""
+def test_action_space_limits_are_stated_at_construction():
+    """Box action spaces of ONE dimension and <= 16 components get the DiagGaussian head (general kernels; `clip_actions`,
+    util.py:84-99, clips what the environment gets); anything else is refused by name before the device is touched"""
     import pytest
 
-    from pantheonrl_amd import spaces as sp
+    from pantheonrl_amd import _native as nat, spaces as sp
     from pantheonrl_amd.ppo import PPO, UnsupportedPolicyConfig, check_action_space
     check_action_space(sp.Discrete(6))
     check_action_space(sp.MultiDiscrete([7, 12]))
-    env = type("E", (), dict(observation_space=sp.Box(-1, 1, (4,)), action_space=sp.Box(-1, 1, (2,)), _is_dummy_space_env=True))()
-    for make in (lambda: check_action_space(env.action_space), lambda: PPO("MlpPolicy", env, device="cuda"),
-                 lambda: check_action_space(sp.MultiBinary(3))):
-        with pytest.raises(UnsupportedPolicyConfig, match=r"util\.py:84-99"):
-            make()
-    # clip_actions itself keeps the reference's behaviour for a Box-shaped policy object (StaticPolicyAgent over a foreign policy)
+    check_action_space(sp.Box(-1, 1, (2,)))
+    check_action_space(sp.Box(-1, 1, (nat.PH_MAX_BOX_ACT,)))
+    assert sp.action_dim(sp.Box(-1, 1, (5,))) == 5
+    spec = sp.make_spec(sp.Box(-1, 1, (4,)), sp.Box(-2, 2, (3,)))
+    assert (spec.act.kind, spec.act.n) == (nat.PH_SPACE_BOX, 3)
+    lay, lay_d = nat.layout_of(spec), nat.layout_of(sp.make_spec(sp.Box(-1, 1, (4,)), sp.MultiDiscrete([1, 1, 1])))
+    assert (lay.A, lay.L) == (3, 3) and lay.P == lay.val_b + 1 + 3 == lay_d.P + 3     # log_std[A] behind val_b
+    for bad in (sp.Box(-1, 1, (2, 2)), sp.Box(-1, 1, (nat.PH_MAX_BOX_ACT + 1,))):
+        env = type("E", (), dict(observation_space=sp.Box(-1, 1, (4,)), action_space=bad, _is_dummy_space_env=True))()
+        for make in (lambda: check_action_space(bad), lambda: PPO("MlpPolicy", env, device="cuda")):
+            with pytest.raises(UnsupportedPolicyConfig, match="DiagGaussian"):
+                make()
+    with pytest.raises(UnsupportedPolicyConfig, match=r"util\.py:84-99"):
+        check_action_space(sp.MultiBinary(3))
     from pantheonrl_amd.common.util import clip_actions
     pol = type("P", (), dict(action_space=sp.Box(-1, 1, (2,))))()
     assert np.array_equal(clip_actions(np.array([[-3.0, 0.5]], np.float32), pol), [[-1.0, 0.5]])
+
+
+def test_gaussian_oracle_is_torch_normal_summed_over_dimensions():
+    """the DiagGaussian checker against closed forms: log N(a; mu, sigma) and 0.5 + 0.5 log(2 pi) + log sigma per dimension"""
+    import torch as th
+
+    from oracle import sb3_oracle as orc
+    pol = orc.GaussianMlpPolicyOracle(orc.SpaceSpec("box", dim=4), orc.SpaceSpec("box", dim=3))
+    assert pol.flat_params().size == orc.MlpPolicyOracle(orc.SpaceSpec("box", dim=4), orc.SpaceSpec("discrete", nvec=(3,))).flat_params().size + 3
+    with th.no_grad():
+        pol.log_std.copy_(th.tensor([0.3, -0.7, 0.0]))
+    flat = pol.flat_params()
+    assert np.array_equal(flat[-3:], np.float32([0.3, -0.7, 0.0]))
+    pol.load_flat_params(flat)
+    obs = th.randn(5, 4, generator=th.Generator().manual_seed(0))
+    eps = th.randn(5, 3, generator=th.Generator().manual_seed(1))
+    with th.no_grad():
+        a, v, lp = pol.forward(obs, uniforms=eps)
+        mu = pol.forward(obs, deterministic=True)[0]
+        v2, lp2, ent = pol.evaluate_actions(obs, a)
+    sd = pol.log_std.detach().exp()
+    np.testing.assert_allclose(a.numpy(), (mu + sd * eps).numpy(), atol=1e-6)
+    ref = (-0.5 * eps ** 2 - pol.log_std.detach() - 0.5 * np.log(2 * np.pi)).sum(1)
+    np.testing.assert_allclose(lp.numpy(), ref.numpy(), atol=1e-5)
+    np.testing.assert_allclose(lp2.numpy(), lp.numpy(), atol=1e-6)
+    np.testing.assert_allclose(ent.numpy(), np.full(5, (0.5 + 0.5 * np.log(2 * np.pi)) * 3 + float(pol.log_std.detach().sum())), atol=1e-5)
+    assert th.equal(v, v2)
+    mb = dict(observations=obs, actions=a, advantages=th.randn(5), old_log_prob=lp - 0.1, old_values=v.flatten(), returns=th.randn(5))
+    hp = orc.PPOHyper()
+    hp.ent_coef = 0.01
+    loss, _ = orc.ppo_minibatch_loss(pol, mb, hp)
+    pol.optimizer.zero_grad()
+    loss.backward()
+    g = pol.flat_grads()
+    assert g.size == flat.size and np.all(np.isfinite(g)) and np.abs(g[-3:]).max() > 0
 
 
 def test_bench_reports_the_rollout_form_that_was_asked_for():

@@ -51,8 +51,15 @@ def test_layout_matches_survey_parameter_counts(obs, act, expect):
 
 
 def test_bad_specs_are_rejected_with_a_message():
-    with pytest.raises(sp.SpaceException):
-        sp.make_spec(sp.Box(-1, 1, (3,)), sp.Box(-1, 1, (2,)))
+    for bad in (sp.Box(-1, 1, (2, 2)), sp.Box(-1, 1, (nat.PH_MAX_BOX_ACT + 1,)), sp.MultiBinary(3)):
+        with pytest.raises(sp.SpaceException):
+            sp.make_spec(sp.Box(-1, 1, (3,)), bad)
+    spec = sp.make_spec(sp.Box(-1, 1, (3,)), sp.Box(-1, 1, (2,)))      # Box actions: the A means + log_std[A] behind val_b
+    lay = nat.layout_of(spec)
+    assert (lay.A, lay.L, lay.P) == (2, 2, lay.val_b + 1 + 2)
+    spec.act.n = nat.PH_MAX_BOX_ACT + 1
+    with pytest.raises(nat.NativeError, match="PH_MAX_BOX_ACT"):
+        nat.layout_of(spec)
     spec = sp.make_spec(sp.Box(-1, 1, (3,)), sp.Discrete(4))
     spec.act.nvec[0] = 0
     with pytest.raises(nat.NativeError, match="nvec"):

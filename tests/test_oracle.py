@@ -82,6 +82,8 @@ def test_policy_shapes_param_counts_and_roundtrip(name):
     pol = H.oracle_policy(name, seed=1)
     F, L = obs_s.flat_len, act_s.flat_len
     expected = 2 * (F * 64 + 64 + 64 * 64 + 64) + 64 * L + L + 65
+    if act_s.kind == "box":
+        expected += act_s.dim          # DiagGaussian: log_std[A] beside the A-output action_net
     assert sum(p.numel() for p in pol.parameters()) == expected == len(pol.flat_params())
     if name == "overcooked":
         assert expected == 16839
@@ -95,7 +97,7 @@ def test_policy_shapes_param_counts_and_roundtrip(name):
         a, v, lp = pol.forward(obs, uniforms=th.rand(5, act_s.stored_len))
         v2, lp2, ent = pol.evaluate_actions(obs, a)
     assert a.shape == (5, act_s.stored_len) and v.shape == (5, 1) and lp.shape == (5,)
-    assert th.allclose(lp, lp2) and th.equal(v, v2) and (ent > 0).all()
+    assert th.allclose(lp, lp2) and th.equal(v, v2) and (act_s.kind == "box" or (ent > 0).all())
 
 
 def test_orthogonal_init_gains():
