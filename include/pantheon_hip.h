@@ -33,13 +33,15 @@
 extern "C" {
 #endif
 
-#define PH_ABI_VERSION 6   /* 2: + ph_agent_*, ph_bc_*, ph_adap_*, ph_scripted_rollout, ph_liar_selfplay_rollout, ph_roundrobin_env_step,
+#define PH_ABI_VERSION 7   /* 2: + ph_agent_*, ph_bc_*, ph_adap_*, ph_scripted_rollout, ph_liar_selfplay_rollout, ph_roundrobin_env_step,
                                   ph_buffer_compact_columns (additions only: every v1 signature is unchanged)
                               3: + ph_selfplay_rollout_persistent, PH_STEP_FIX_ILLEGAL / _MASK_ENV_ONLY, ph_modular_*, ph_roundrobin_*_iteration
                                   (additions only)
                               4: + ph_selfplay_rollout_persistent_capacity, ph_ppo_train's gradient pack (no signature changed)
                               5: + ph_policy_act_host, ph_buffer_add_reward_const, ph_adapmult_*, ph_ctx_set_joint_reward_rule (additions only)
-                              6: + ph_bench_train_kernels, ph_debug_split_oh_tables, ph_ctx_step_errors (additions only) */
+                              6: + ph_bench_train_kernels, ph_debug_split_oh_tables, ph_ctx_step_errors (additions only)
+                              7: ph_spec.act may be PH_SPACE_BOX on ph_layout_of / ph_policy_forward / ph_ppo_minibatch_grad / ph_ppo_train
+                                  (an error before; no signature or struct changed) */
 #define PH_HIDDEN 64     /* SB3 MlpPolicy default net_arch pi=[64,64], vf=[64,64] (modular/policies.py:112-114) */
 #define PH_MAX_COMP 256  /* max MultiDiscrete components per space */
 #define PH_MAX_LOGITS 64 /* max total policy logits L */
@@ -276,6 +278,11 @@ int ph_gae(ph_ctx *ctx, const ph_rollout *rb, const float *last_values /* (E) */
  *  uniforms (n,A) or NULL       : teacher-forced inverse-CDF sampling; NULL = Philox4x32-10 keyed (seed, counter, row, comp)
  *  given_actions (n,A) f32 or NULL : evaluate these instead of sampling (evaluate_actions, modular/policies.py:364-383)
  *  deterministic != 0           : argmax
+ * Box action spaces (spec->act.kind == PH_SPACE_BOX; SB3 DiagGaussianDistribution, L = A): the head's outputs are the means,
+ *  action = mean + exp(log_std) * eps with eps ~ N(0, 1) -- `uniforms` (n,A) then carries the STANDARD-NORMAL draws eps (NULL:
+ *  Box-Muller over two Philox uniforms per dimension), deterministic = the mean, log_prob / entropy = Normal's summed over the
+ *  dimensions; actions leave through actions_f32 only (UNclipped: the caller clips for the environment, util.py:84-99),
+ *  `logits` returns the means, action_mask must be NULL.
  * Outputs (any may be NULL): actions_i32 (n,A), actions_f32 (n,A), values (n), log_probs (n), entropy (n), logits (n,L).
  * When rb != NULL the transition is also written at row `pos` of the rollout buffer (fused RolloutBuffer.add with
  * reward 0 and episode_start = episode_start_in) -- n must equal rb->E; if pending_reward (E) is also given, it is

@@ -318,7 +318,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.argtypes = argtypes
         fn.restype = C.c_char_p if name in ("ph_last_error", "ph_agent_last_error") else C.c_int
-    if lib.ph_abi_version() != 6:
+    if lib.ph_abi_version() != 7:
         raise NativeError("libpantheon_hip.so ABI version mismatch")
     _lib = lib
     return lib

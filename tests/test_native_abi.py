@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in DECLARED:
         assert hasattr(lib, name), f"{name} declared in include/pantheon_hip.h but not exported"
     assert set(DECLARED) == set(nat.SIGNATURES), set(DECLARED) ^ set(nat.SIGNATURES)
-    assert lib.ph_abi_version() == 6
+    assert lib.ph_abi_version() == 7
     assert int(re.search(r"#define PH_NSTAT (\d+)", HEADER).group(1)) == nat.PH_NSTAT
     assert int(re.search(r"#define PH_MAX_COMP (\d+)", HEADER).group(1)) == nat.PH_MAX_COMP
 
