@@ -63,6 +63,16 @@ __global__ __launch_bounds__(64) void gae_serial_kernel(const float* __restrict_
 // coefficient products in registers, the NCH chunk composites are suffix-scanned through LDS (Hillis-Steele,
 // log2 NCH rounds), each lane fixes up its LC outputs with the carried-in advantage, and the advantage at the first
 // step of the super-chunk is carried to the next one.  One HBM read + one write per element, any T.
+#ifndef PH_GAE_NT
+#define PH_GAE_NT 1   // streaming (nontemporal) loads and stores of the five arrays -- every element is read once and written once:
+                      // 4.40 -> 4.64 TB/s at E = 16384, T = 2048 (profiles/r06_w_gae_nontemporal_and_chunk_sweep.txt); 0 = plain accesses
+#endif
+__device__ __forceinline__ float gae_ld(const float* p) { return PH_GAE_NT ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void gae_st(float* p, float v) {
+  if (PH_GAE_NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 template <int LC, int EB>
 __global__ __launch_bounds__(1024) void gae_scan_kernel(const float* __restrict__ rew, const float* __restrict__ val,
                                                         const float* __restrict__ es,
@@ -101,9 +111,9 @@ __global__ __launch_bounds__(1024) void gae_scan_kernel(const float* __restrict_
       for (int k = 0; k < LC; ++k) {
         const int t = t0 + k;
         const size_t o = (size_t)(t >= 0 ? t : 0) * E + e;
-        r[k] = rew[o];
-        vv[k] = val[o];
-        s[k] = es[o];
+        r[k] = gae_ld(rew + o);
+        vv[k] = gae_ld(val + o);
+        s[k] = gae_ld(es + o);
       }
       float A = 0.f, Pacc = 1.f;
 #pragma unroll
@@ -156,8 +166,8 @@ __global__ __launch_bounds__(1024) void gae_scan_kernel(const float* __restrict_
         if (t >= 0) {
           const size_t o = (size_t)t * E + e;
           const float A = a[k] + cp[k] * Ain;
-          adv[o] = A;
-          ret[o] = A + vv[k];
+          gae_st(adv + o, A);
+          gae_st(ret + o, A + vv[k]);
         }
       }
     }
@@ -166,9 +176,9 @@ __global__ __launch_bounds__(1024) void gae_scan_kernel(const float* __restrict_
 
 template <int LC, int EB>
 static hipError_t launch_scan(const float* rew, const float* val, const float* es, const float* lv, const float* dn,
-                              float* adv, float* ret, int T, int E, float g, float gl, hipStream_t s) {
+                              float* adv, float* ret, int T, int E, float g, float gl, hipStream_t s, int max_chunks = 1024 / EB) {
   int NCH = (T + LC - 1) / LC;
-  int maxch = 1024 / EB;
+  int maxch = max_chunks < 1024 / EB ? max_chunks : 1024 / EB;
   static int nch_env = -1;   // PH_GAE_NCH: measurement override of the chunk count cap (workgroup size = NCH * EB lanes)
   if (nch_env < 0) {
     const char* e = getenv("PH_GAE_NCH");
@@ -205,8 +215,13 @@ hipError_t launch_gae(const float* rew, const float* val, const float* es, const
   // Longer T: 16 steps per lane as well.  32 steps per lane (120 VGPRs, one 1024-lane workgroup per CU whose load, scan and store
   // phases do not overlap with anything) measured 4.19 TB/s at E = 16384, T = 2048; 16 steps per lane (72 VGPRs) 4.57 TB/s; 8 steps
   // (51 VGPRs, two workgroups per CU, twice the LDS scan rounds per element) 4.37 TB/s -- profiles/r05_b_gae_lc_sweep.txt
+  // Round 6: a rollout longer than one super-chunk walks it with EIGHT chunks per workgroup (256 lanes, 128 steps per super-chunk):
+  // several such workgroups share a CU (72 VGPRs) and their load / chain / scan / store phases overlap, which one 1024-lane
+  // workgroup per CU cannot do with itself -- 4.64 -> 5.0 TB/s with the streaming accesses (32 chunks: 4.64, 16: 4.73, 4: 4.53,
+  // profiles/r06_w_gae_nontemporal_and_chunk_sweep.txt).  T <= 256 is ONE super-chunk of T / 8 chunks: a 3.9 us launch at
+  // BASELINE's sizes, where splitting it in two costs a second pass (5.1 us).
   if (T <= 256) return launch_scan<8, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
-  return launch_scan<16, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
+  return launch_scan<16, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s, 8);
 }
 
 // ---- K1: RolloutBuffer.add / reward += / reset -----------------------------------------------------------------------

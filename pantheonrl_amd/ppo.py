@@ -460,6 +460,11 @@ class GaussianActorCriticPolicy(ActorCriticPolicy):
     def _shape_actions(self, acts: th.Tensor) -> th.Tensor:
         return acts.reshape((-1,) + tuple(self.action_space.shape))
 
+    def predict(self, obs, deterministic: bool = False):
+        """SB3 BasePolicy.predict: Box actions are clipped to the space (the policy does not squash)"""
+        acts, _, _ = self.forward(obs, deterministic=deterministic)
+        return np.clip(acts.cpu().numpy(), self.action_space.low, self.action_space.high), None
+
     def forward_and_store_host(self, *a, **k):
         raise nat.NativeError("GaussianActorCriticPolicy: the one-call host step returns integer actions; use forward_and_store")
 

@@ -134,6 +134,9 @@ def test_gaussian_agent_stores_the_raw_sample_and_hands_the_environment_the_clip
         assert a.shape == (3,) and a.dtype == np.float32
         outs.append(a)
     outs = np.stack(outs)
+    x = rng.standard_normal((5, 6)).astype(np.float32)
+    pa, _ = model.predict(x)                                         # SB3 BasePolicy.predict clips Box actions
+    assert pa.shape == (5, 3) and np.abs(pa).max() <= 0.05
     stored = model.rollout_buffer.actions.cpu().numpy().reshape(8, 3)
     assert np.abs(stored).max() > 0.05                              # log_std = 0: the raw samples leave the tiny box ...
     assert np.array_equal(outs, np.clip(stored, -0.05, 0.05))       # ... the environment's copy never does
