@@ -25,8 +25,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch as th
+# the host driver of the GPU boxes supports dmabuf IPC only: without this RCCL / cross-process device-memory sharing fails with
+# `hipIpcGetMemHandle: invalid argument`.  Set before the first HIP call (the ROCm runtime reads it when it initialises).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch as th  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
