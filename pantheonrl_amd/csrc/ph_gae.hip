@@ -221,6 +221,18 @@ hipError_t launch_gae(const float* rew, const float* val, const float* es, const
   // profiles/r06_w_gae_nontemporal_and_chunk_sweep.txt).  T <= 256 is ONE super-chunk of T / 8 chunks: a 3.9 us launch at
   // BASELINE's sizes, where splitting it in two costs a second pass (5.1 us).
   if (T <= 256) return launch_scan<8, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s);
+  // Round 6, third session: at E >= 16384 a workgroup takes 64 environments (one 256-byte segment per row and array, a wave's load
+  // one contiguous piece) and sixteen chunks: 5.07-5.16 -> 5.33-5.36 TB/s at E = 16384, T = 2048 (profiles/r06_ae_gae_*).  Below that
+  // the grid of 64-environment workgroups no longer covers the CUs.  128 environments: 4.4 TB/s; requesting the next super-chunk's
+  // elements ahead of the scan (a second register set): SLOWER, 4.6 against 4.9-5.4 (profiles/r06_ad_gae_explicit_prefetch_ab.txt).
+  static int eb_env = -1;   // PH_GAE_EB = 32 | 64 | 128: measurement override of the environments per workgroup
+  if (eb_env < 0) {
+    const char* e = getenv("PH_GAE_EB");
+    eb_env = e ? atoi(e) : 0;
+  }
+  const int eb = eb_env ? eb_env : (E >= 16384 ? 64 : 32);
+  if (eb == 64) return launch_scan<16, 64>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s, 16);
+  if (eb == 128) return launch_scan<16, 128>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s, 8);
   return launch_scan<16, 32>(rew, val, es, lv, dn, adv, ret, T, E, g, gl, s, 8);
 }
 

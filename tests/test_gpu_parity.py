@@ -90,6 +90,24 @@ def test_gae_scan_within_fp32_tolerance(T, E):
         assert np.abs(a - a64).max() <= 4 * max(np.abs(a_ref - a64).max(), 1e-6)
 
 
+@pytest.mark.parametrize("T,E", [(257, 16384), (300, 16397), (1030, 16384 + 64 + 5)])
+def test_gae_scan_wide_workgroups_match_the_serial_kernel(T, E):
+    """At E >= 16384 and T > 256 the scan walks 64 environments and sixteen chunks per workgroup (csrc/ph_gae.hip: launch_gae);
+    the checker is the serial kernel, which the tests above pin bit for bit to the numpy loop (SB3 buffers.py GAE,
+    SURVEY.md A.2).  Ragged E (a last workgroup with 13 / 5 live environments) and a first super-chunk that starts below 0."""
+    r, v, s, lv, dn = _gae_inputs(T, E, seed=T + E)
+    a1, r1 = _run_gae(r, v, s, lv, dn, mode=1)
+    idx = np.random.default_rng(0).choice(E, 24, replace=False)
+    a_ref, ret_ref = orc.gae_reference(r[:, idx], v[:, idx], s[:, idx], lv[idx], dn[idx])
+    assert np.array_equal(a1[:, idx], a_ref) and np.array_equal(r1[:, idx], ret_ref)
+    a2, r2 = _run_gae(r, v, s, lv, dn, mode=2)
+    tol = 2e-5 * (1 + np.abs(a1).max())
+    assert np.abs(a2 - a1).max() <= tol
+    assert np.abs(r2 - r1).max() <= tol
+    a32, _ = _run_gae(r[:, :96], v[:, :96], s[:, :96], lv[:96], dn[:96], mode=2)   # the 32-environment form on the same columns
+    assert np.abs(a32 - a1[:, :96]).max() <= tol
+
+
 def test_gae_no_episode_boundaries_and_all_boundaries():
     T, E = 256, 48
     r, v, s, lv, dn = _gae_inputs(T, E, seed=5)
