@@ -269,13 +269,55 @@ __device__ __forceinline__ float quad_sum_f(float v) {
 // step gone; the single-step launch loses the 33 KB weight staging that was 40 % of its time).  The head is a third 16x16x4 MFMA
 // product (wave 0: z = H2 act_W, or H2 val_W in column 0) instead of 128 FMAs per lane over LDS-resident weights; its 16 x 8
 // result goes through 512 bytes of LDS so that lane r < 16 owns row r for the distribution tail.
-template <bool VALU>
+// LEAN: the launch was checked (fwd_args_lean) to use none of the optional paths of the argument record -- no masks, no teacher-forced
+// uniforms or actions, no logits / entropy / float-action outputs, a rectangular buffer with the fused add, no joint-action reward, no
+// host doorbell, no debug stamps.  The copy of the record the body works on then carries those fields as CONSTANTS: every
+// `if (a.mask)` of the row tails folds away instead of being a basic block of its own behind a restored scalar register (the
+// headline rollout's step held ~200 v_readlane restores and ~60 such blocks, 8 copies of the tail apart), and the record no longer
+// competes for the 100 scalar registers.  Same arithmetic, same stores: bitwise the general form (the rollout tests run both).
+__device__ __forceinline__ void fwd_args_pin_lean(FwdArgs& a) {
+  a.mask = nullptr;
+  a.uniforms = nullptr;
+  a.given_actions = nullptr;
+  a.deterministic = 0;
+  a.act_f32 = nullptr;
+  a.entropy = nullptr;
+  a.logits = nullptr;
+  a.prof = nullptr;
+  a.pos_env = nullptr;
+  a.rec_mask = nullptr;
+  a.joint = nullptr;
+  a.joint_ll = nullptr;
+  a.env_mask = nullptr;
+  a.host_done = nullptr;
+  __builtin_assume(a.rb_obs != nullptr);
+  __builtin_assume(a.rb_act != nullptr);
+  __builtin_assume(a.rb_rew != nullptr);
+  __builtin_assume(a.rb_es != nullptr);
+  __builtin_assume(a.rb_val != nullptr);
+  __builtin_assume(a.rb_logp != nullptr);
+  __builtin_assume(a.es_in != nullptr);
+}
+bool fwd_args_lean(const FwdArgs& a) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("PH_ROLLOUT_LEAN");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  return enabled && !a.mask && !a.uniforms && !a.given_actions && !a.deterministic && !a.act_f32 && !a.entropy && !a.logits && !a.prof &&
+         !a.pos_env && !a.rec_mask && !a.joint && !a.joint_ll && !a.env_mask && !a.host_done && a.rb_obs && a.rb_act && a.rb_rew &&
+         a.rb_es && a.rb_val && a.rb_logp && a.es_in;
+}
+
+template <bool VALU, bool LEAN = false>
 __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2p* px = nullptr, int px_t = 0, int px_a_local = 0,
                                                   int agent = 0, const ScriptedSteps* sc = nullptr, int px_persistent = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16, NT = 256;
   const NetDims& nd = a0.nd;
   FwdArgs a = a0;
+  if constexpr (LEAN) fwd_args_pin_lean(a);
+  long long* const prof0 = LEAN ? nullptr : a0.prof;
   float* xs = smem;                 // [16][LDH]  X, later H2
   float* hs = xs + R * LDH;         // [16][LDH]  H1
   float* zs = hs + R * LDH;         // [16][8]    head output incl. bias: policy logits | value in column 0
@@ -337,7 +379,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   // (scripted rollouts) the sampling uniform of step t + 1 is a function of (seed, counter + t + 1, row) alone: wave 1, idle
   // during the head phase of the policy workgroup, draws it a step ahead, so the ten Philox rounds leave the one lane per row
   // that walks softmax -> inverse CDF -> log-prob.  Same call, same value: the rollout stays bitwise the launch-by-launch walk.
-  const bool draw_ahead = sc && net == 0 && !a0.uniforms && !a0.deterministic && !a0.given_actions;
+  const bool draw_ahead = sc && net == 0 && !a.uniforms && !a.deterministic && !a.given_actions;   // (launch constants: a0's, or LEAN's)
   auto draw_uniforms = [&](int t1) {
     if (lane < R && row0 + lane < a0.n)
       upre[(t1 & 1) * R + lane] = philox_uniform(a0.seed, a0.counter + (unsigned long long)t1 + epoch_hi, (uint32_t)(row0 + lane), 0u);
@@ -361,7 +403,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
 
   for (int t = 0; t < n_steps; ++t) {
   // debug stamps of ONE step in the middle of a scripted rollout (slots 8..15: scripts/rollout_phase.py)
-  long long* const pstep = (sc && t == 8) ? a0.prof : nullptr;
+  long long* const pstep = (sc && t == 8) ? prof0 : nullptr;
   PH_STAMP(pstep, 8);
   if (t > 0) {   // (scripted rollout) the next step's argument record and observation rows; the weights stay where they are
     const size_t row = (size_t)t * a0.n;
@@ -376,8 +418,10 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
     a.es_in = sc->done_seq + (row - a0.n);          // Agent.update(reward, done) of the previous step:
     a.pending_reward = sc->rew_seq + (row - a0.n);  //   last_episode_starts = done, rewards[pos - 1] += reward
     a.prev_rew = a0.rb_rew + (row - a0.n);
-    a.mask = (sc->mask_seq && sc->mask_policy) ? sc->mask_seq + row * nd.L : nullptr;
-    a.env_mask = (sc->mask_seq && sc->mask_env) ? sc->mask_seq + row * nd.L : nullptr;
+    if constexpr (!LEAN) {
+      a.mask = (sc->mask_seq && sc->mask_policy) ? sc->mask_seq + row * nd.L : nullptr;
+      a.env_mask = (sc->mask_seq && sc->mask_env) ? sc->mask_seq + row * nd.L : nullptr;
+    }
     if (px_persistent && a0.joint) {   // the joint action of step t - 1 as stamp-in-band words (value_row_tail polls them)
       a.joint = a0.joint;
       a.joint_ll = px->ll[px->rank] + (size_t)p2p_persistent_slot(px_epoch, px->T, t - 1) * px->world * px->count;
@@ -504,9 +548,9 @@ __global__ __launch_bounds__(256) void policy_fwd16_kernel(FwdArgs a) {
     if (threadIdx.x == 0) __hip_atomic_store(a.host_done + blockIdx.y, a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
-template <bool VALU>
+template <bool VALU, bool LEAN>
 __global__ __launch_bounds__(256) void policy_fwd16_rollout_kernel(FwdArgs a, ScriptedSteps sc) {
-  policy_fwd16_body<VALU>(a, nullptr, 0, 0, 0, &sc);
+  policy_fwd16_body<VALU, LEAN>(a, nullptr, 0, 0, 0, &sc);
 }
 __global__ __launch_bounds__(256) void policy_fwd16_multi_kernel(FwdMulti m) {
   policy_fwd16_body<false>(m.a[blockIdx.z], m.px.x, m.px.t, m.px.a_local, blockIdx.z);
@@ -583,20 +627,21 @@ static size_t rollout_lds_bytes(int nwg_total) {
 hipError_t launch_policy_fwd16_rollout(const FwdArgs& a, const ScriptedSteps& sc, int gemm_mode, hipStream_t s) {
   dim3 grid((a.n + 15) / 16, 2), block(256);
   const size_t lds = rollout_lds_bytes((int)(grid.x * grid.y));
+  const int variant = gemm_mode == 1 ? 1 : ((fwd_args_lean(a) && !sc.mask_seq) ? 2 : 0);   // 1: VALU cross-check, 2: lean, 0: general
+  const void* fn = variant == 1 ? (const void*)policy_fwd16_rollout_kernel<true, false>
+                                : (variant == 2 ? (const void*)policy_fwd16_rollout_kernel<false, true> : (const void*)policy_fwd16_rollout_kernel<false, false>);
   if (lds > 64 * 1024) {   // dynamic LDS above 64 KiB is opt-in, per kernel and device
-    static bool allowed_dev[2][64] = {{false}};
-    bool& allowed = allowed_dev[gemm_mode == 1 ? 1 : 0][current_device_slot()];
+    static bool allowed_dev[3][64] = {{false}};
+    bool& allowed = allowed_dev[variant][current_device_slot()];
     if (!allowed) {
-      hipError_t e = gemm_mode == 1 ? hipFuncSetAttribute((const void*)policy_fwd16_rollout_kernel<true>,
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                                    : hipFuncSetAttribute((const void*)policy_fwd16_rollout_kernel<false>,
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       allowed = true;
     }
   }
-  if (gemm_mode == 1) hipLaunchKernelGGL((policy_fwd16_rollout_kernel<true>), grid, block, lds, s, a, sc);
-  else hipLaunchKernelGGL((policy_fwd16_rollout_kernel<false>), grid, block, lds, s, a, sc);
+  if (variant == 1) hipLaunchKernelGGL((policy_fwd16_rollout_kernel<true, false>), grid, block, lds, s, a, sc);
+  else if (variant == 2) hipLaunchKernelGGL((policy_fwd16_rollout_kernel<false, true>), grid, block, lds, s, a, sc);
+  else hipLaunchKernelGGL((policy_fwd16_rollout_kernel<false, false>), grid, block, lds, s, a, sc);
   return hipGetLastError();
 }
 

@@ -12,6 +12,7 @@ the exact-float32 kernels and none was changed for it.  Tests that pin a mode pa
 bitwise VALU restatement, 2 = split).
 """
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -2077,6 +2078,18 @@ def test_scripted_rollout_is_bitwise_the_per_step_walk(E, T, name):
         for key in a:
             assert np.array_equal(a[key], b[key]), key
     assert not np.array_equal(runs[0][0]["params"], runs[0][1]["params"])
+
+
+def test_scripted_rollout_general_form_is_still_bitwise_the_per_step_walk():
+    """The one-launch rollout takes its LEAN form by default (csrc/ph_policy.hip: fwd_args_lean -- the optional fields of the argument
+    record pinned to constants); the general form of the same kernel, which masks / debug stamps select, is checked by the same
+    bitwise test in a process that switches the lean form off."""
+    import subprocess, sys
+    env = dict(os.environ, PH_ROLLOUT_LEAN="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_scripted_rollout_is_bitwise_the_per_step_walk and (96-12 or 40-7 or 64-9)"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "3 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_scripted_rollout_refuses_other_shapes_and_a_used_buffer():
