@@ -283,7 +283,9 @@ __device__ __forceinline__ void fwd_args_pin_lean(FwdArgs& a) {
   a.act_f32 = nullptr;
   a.entropy = nullptr;
   a.logits = nullptr;
+#ifndef PH_LEAN_PROF   // (scripts/rollout_phase.py's view of the lean form: a -DPH_LEAN_PROF build keeps the stamp pointer)
   a.prof = nullptr;
+#endif
   a.pos_env = nullptr;
   a.rec_mask = nullptr;
   a.joint = nullptr;
@@ -304,7 +306,12 @@ bool fwd_args_lean(const FwdArgs& a) {
     const char* e = getenv("PH_ROLLOUT_LEAN");
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
-  return enabled && !a.mask && !a.uniforms && !a.given_actions && !a.deterministic && !a.act_f32 && !a.entropy && !a.logits && !a.prof &&
+#ifdef PH_LEAN_PROF
+  constexpr bool lean_prof = true;
+#else
+  constexpr bool lean_prof = false;
+#endif
+  return enabled && !a.mask && !a.uniforms && !a.given_actions && !a.deterministic && !a.act_f32 && !a.entropy && !a.logits && (lean_prof || !a.prof) &&
          !a.pos_env && !a.rec_mask && !a.joint && !a.joint_ll && !a.env_mask && !a.host_done && a.rb_obs && a.rb_act && a.rb_rew &&
          a.rb_es && a.rb_val && a.rb_logp && a.es_in;
 }
@@ -317,7 +324,11 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   const NetDims& nd = a0.nd;
   FwdArgs a = a0;
   if constexpr (LEAN) fwd_args_pin_lean(a);
+#ifdef PH_LEAN_PROF
+  long long* const prof0 = a0.prof;
+#else
   long long* const prof0 = LEAN ? nullptr : a0.prof;
+#endif
   float* xs = smem;                 // [16][LDH]  X, later H2
   float* hs = xs + R * LDH;         // [16][LDH]  H1
   float* zs = hs + R * LDH;         // [16][8]    head output incl. bias: policy logits | value in column 0
@@ -393,6 +404,12 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
     float av[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) av[s] = ap[4 * s];
+    // all sixteen operand reads in flight before the first MFMA: left alone, the scheduler sinks each ds_read2 in front of the two
+    // MFMAs that use it and recycles ONE register pair -- read, wait, two MFMAs, eight times per product: eight exposed LDS round
+    // trips per layer of a step whose whole point is latency (round 6: one-launch rollout 0.333 -> 0.307 ms, profiles/r06_ah_*)
+#ifndef PH_FWD16_NO_HOIST   // (A/B switch: scripts/build_variants.sh)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int s = 0; s < 16; s += 2) {
       e = mma16<VALU>(av[s], bw[s], e, lane);
