@@ -275,6 +275,7 @@ __device__ __forceinline__ float quad_sum_f(float v) {
 // `if (a.mask)` of the row tails folds away instead of being a basic block of its own behind a restored scalar register (the
 // headline rollout's step held ~200 v_readlane restores and ~60 such blocks, 8 copies of the tail apart), and the record no longer
 // competes for the 100 scalar registers.  Same arithmetic, same stores: bitwise the general form (the rollout tests run both).
+template <bool KEEP_JOINT>
 __device__ __forceinline__ void fwd_args_pin_lean(FwdArgs& a) {
   a.mask = nullptr;
   a.uniforms = nullptr;
@@ -288,8 +289,10 @@ __device__ __forceinline__ void fwd_args_pin_lean(FwdArgs& a) {
 #endif
   a.pos_env = nullptr;
   a.rec_mask = nullptr;
-  a.joint = nullptr;
-  a.joint_ll = nullptr;
+  if constexpr (!KEEP_JOINT) {   // (the exchange rollout's value rows read the joint action: LEAN = 2 keeps those fields)
+    a.joint = nullptr;
+    a.joint_ll = nullptr;
+  }
   a.env_mask = nullptr;
   a.host_done = nullptr;
   __builtin_assume(a.rb_obs != nullptr);
@@ -300,7 +303,7 @@ __device__ __forceinline__ void fwd_args_pin_lean(FwdArgs& a) {
   __builtin_assume(a.rb_logp != nullptr);
   __builtin_assume(a.es_in != nullptr);
 }
-bool fwd_args_lean(const FwdArgs& a) {
+bool fwd_args_lean(const FwdArgs& a, bool joint_ok = false) {
   static int enabled = -1;
   if (enabled < 0) {
     const char* e = getenv("PH_ROLLOUT_LEAN");
@@ -312,18 +315,19 @@ bool fwd_args_lean(const FwdArgs& a) {
   constexpr bool lean_prof = false;
 #endif
   return enabled && !a.mask && !a.uniforms && !a.given_actions && !a.deterministic && !a.act_f32 && !a.entropy && !a.logits && (lean_prof || !a.prof) &&
-         !a.pos_env && !a.rec_mask && !a.joint && !a.joint_ll && !a.env_mask && !a.host_done && a.rb_obs && a.rb_act && a.rb_rew &&
+         !a.pos_env && !a.rec_mask && (joint_ok || (!a.joint && !a.joint_ll)) && !a.env_mask && !a.host_done && a.rb_obs && a.rb_act && a.rb_rew &&
          a.rb_es && a.rb_val && a.rb_logp && a.es_in;
 }
 
-template <bool VALU, bool LEAN = false>
+template <bool VALU, int LEAN = 0>
 __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2p* px = nullptr, int px_t = 0, int px_a_local = 0,
                                                   int agent = 0, const ScriptedSteps* sc = nullptr, int px_persistent = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16, NT = 256;
   const NetDims& nd = a0.nd;
   FwdArgs a = a0;
-  if constexpr (LEAN) fwd_args_pin_lean(a);
+  if constexpr (LEAN == 1) fwd_args_pin_lean<false>(a);
+  if constexpr (LEAN == 2) fwd_args_pin_lean<true>(a);
 #ifdef PH_LEAN_PROF
   long long* const prof0 = a0.prof;
 #else
@@ -553,24 +557,27 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   }
 }
 
-template <bool VALU>
+template <bool VALU, bool LEAN = false>
 __global__ __launch_bounds__(256) void policy_fwd16_kernel(FwdArgs a) {
-  policy_fwd16_body<VALU>(a);
+  policy_fwd16_body<VALU, LEAN ? 1 : 0>(a);
   // ph_policy_act_host waits on two host words instead of on the stream: a stream wait goes through the runtime's completion
   // signal (interrupt or a polled signal, then its bookkeeping), the words arrive with the outputs.  Every lane's stores are
   // ordered before the word by its own system-scope fence; the barrier orders all lanes' fences before lane 0's store.
-  if (a.host_done) {
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(a.host_done + blockIdx.y, a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if constexpr (!LEAN) {
+    if (a.host_done) {
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(a.host_done + blockIdx.y, a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 template <bool VALU, bool LEAN>
 __global__ __launch_bounds__(256) void policy_fwd16_rollout_kernel(FwdArgs a, ScriptedSteps sc) {
-  policy_fwd16_body<VALU, LEAN>(a, nullptr, 0, 0, 0, &sc);
+  policy_fwd16_body<VALU, LEAN ? 1 : 0>(a, nullptr, 0, 0, 0, &sc);
 }
+template <bool LEAN>
 __global__ __launch_bounds__(256) void policy_fwd16_multi_kernel(FwdMulti m) {
-  policy_fwd16_body<false>(m.a[blockIdx.z], m.px.x, m.px.t, m.px.a_local, blockIdx.z);
+  policy_fwd16_body<false, LEAN ? 2 : 0>(m.a[blockIdx.z], m.px.x, m.px.t, m.px.a_local, blockIdx.z);
 }
 // The N > 1 counterpart of policy_fwd16_rollout_kernel: every local agent's T steps in one launch, with what crosses ranks at
 // every SimultaneousEnv step (multiagentenv.py:149-170: each seat's action to everyone who needs it) done in-kernel -- the
@@ -582,8 +589,11 @@ __global__ __launch_bounds__(256) void policy_fwd16_multi_kernel(FwdMulti m) {
 // 256 the default N > 1 layout needs -- at two waves per SIMD (192 VGPRs) the margin was zero, and any shortfall drops every rank to
 // one launch per step.  Same-box A/B of the two builds: 101.3 vs 102.0 M agent-steps/s in --mode fusedstep (within the spread);
 // two ranks sharing ONE device keep the one-launch form: 68.8 M against 42.2 M (profiles/r05_r_exchange_launch_bounds_ab.txt).
+// LEAN: every local agent's record passed fwd_args_lean(.., joint_ok) and no step carries action masks (the launcher checks):
+// the default N > 1 layout.  Config 5 (masks) takes the general form.
+template <bool LEAN>
 __global__ __launch_bounds__(256, 3) void policy_fwd16_exchange_rollout_kernel(FwdMulti m, ScriptedMulti sm) {
-  policy_fwd16_body<false>(m.a[blockIdx.z], m.px.x, 0, m.px.a_local, blockIdx.z, &sm.sc[blockIdx.z], 1);
+  policy_fwd16_body<false, LEAN ? 2 : 0>(m.a[blockIdx.z], m.px.x, 0, m.px.a_local, blockIdx.z, &sm.sc[blockIdx.z], 1);
 }
 
 // index of the current device into the per-device "LDS opt-in done" tables of the launchers below
@@ -615,7 +625,8 @@ static hipError_t launch_fwd16_variant(const FwdArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     allowed = true;
   }
-  hipLaunchKernelGGL((policy_fwd16_kernel<VALU>), dim3((a.n + 15) / 16, 2), dim3(256), lds, s, a);
+  if (!VALU && fwd_args_lean(a)) hipLaunchKernelGGL((policy_fwd16_kernel<false, true>), dim3((a.n + 15) / 16, 2), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((policy_fwd16_kernel<VALU>), dim3((a.n + 15) / 16, 2), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 
@@ -665,7 +676,8 @@ hipError_t launch_policy_fwd16_rollout(const FwdArgs& a, const ScriptedSteps& sc
 hipError_t exchange_rollout_blocks_per_cu(int* blocks_out) {
   const size_t lds = fwd16_lds_bytes();
   int api = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, (const void*)policy_fwd16_exchange_rollout_kernel, 256, lds);
+  // (the general form: the lean form of the same kernel needs no more registers)
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, (const void*)policy_fwd16_exchange_rollout_kernel<false>, 256, lds);
   if (e != hipSuccess) return e;
   const int by_lds = (int)((size_t)160 * 1024 / lds);
   int blocks = api < 8 ? api : 8;
@@ -678,8 +690,11 @@ hipError_t exchange_rollout_blocks_per_cu(int* blocks_out) {
 }
 
 hipError_t launch_policy_fwd16_exchange_rollout(const FwdMulti& m, const ScriptedMulti& sm, int n_agents, hipStream_t s) {
-  hipLaunchKernelGGL(policy_fwd16_exchange_rollout_kernel, dim3((m.a[0].n + 15) / 16, 2, n_agents), dim3(256), fwd16_lds_bytes(),
-                     s, m, sm);
+  bool lean = true;
+  for (int i = 0; i < n_agents; ++i) lean = lean && fwd_args_lean(m.a[i], true) && !sm.sc[i].mask_seq;
+  const dim3 grid((m.a[0].n + 15) / 16, 2, n_agents);
+  if (lean) hipLaunchKernelGGL(policy_fwd16_exchange_rollout_kernel<true>, grid, dim3(256), fwd16_lds_bytes(), s, m, sm);
+  else hipLaunchKernelGGL(policy_fwd16_exchange_rollout_kernel<false>, grid, dim3(256), fwd16_lds_bytes(), s, m, sm);
   return hipGetLastError();
 }
 
@@ -1791,7 +1806,11 @@ static hipError_t launch_fwd_multi_variant(const FwdMulti& m, int n_agents, hipS
 // all records must share n and the padded logit count (checked by the ABI layer)
 hipError_t launch_policy_fwd_multi(const FwdMulti& m, int n_agents, hipStream_t s) {
   if (fwd16_eligible(m.a[0].nd, m.a[0].n)) {
-    hipLaunchKernelGGL(policy_fwd16_multi_kernel, dim3((m.a[0].n + 15) / 16, 2, n_agents), dim3(256), fwd16_lds_bytes(), s, m);
+    bool lean = true;
+    for (int i = 0; i < n_agents; ++i) lean = lean && fwd_args_lean(m.a[i], true);
+    const dim3 grid((m.a[0].n + 15) / 16, 2, n_agents);
+    if (lean) hipLaunchKernelGGL(policy_fwd16_multi_kernel<true>, grid, dim3(256), fwd16_lds_bytes(), s, m);
+    else hipLaunchKernelGGL(policy_fwd16_multi_kernel<false>, grid, dim3(256), fwd16_lds_bytes(), s, m);
     return hipGetLastError();
   }
   const bool big = m.a[0].n >= 16384;

@@ -117,7 +117,7 @@ def test_rollout_kernels_have_no_scratch(tmp_path_factory):
     per step.  (The Liar's Dice rollout once kept 31 spilled registers: per-lane mirror addresses hoisted out of its loop.)"""
     pol = _usage("ph_policy.hip", tmp_path_factory)
     want = ["liar_rollout_kernel", "policy_fwd16_rollout_kernelILb0ELb0E", "policy_fwd16_rollout_kernelILb0ELb1E", "policy_fwd16_exchange_rollout_kernel",
-            "policy_fwd16_multi_kernel", "policy_fwd16_kernelILb0E", "policy_fwd16h_kernelILb0E"]
+            "policy_fwd16_multi_kernel", "policy_fwd16_kernelILb0ELb0E", "policy_fwd16_kernelILb0ELb1E", "policy_fwd16h_kernelILb0E"]
     for w in want:
         hit = {n: k for n, k in pol.items() if w in n}
         assert hit, (w, sorted(pol))
