@@ -246,6 +246,8 @@ __device__ __forceinline__ void policy_fwd_body(const FwdArgs& a) {
 // waves one 16-column output tile of a layer: 16 v_mfma_f32_16x16x4_f32 in two interleaved accumulator chains per
 // layer, twice the workgroups, and the head runs as a register-resident VALU phase (four lanes per row) in one wave.
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// s_waitcnt vmcnt(0) as the BUILTIN (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15): the wait-insertion pass accounts for it
+__device__ __forceinline__ void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_quad_f(float v) {
@@ -380,6 +382,11 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   if (sc) a.obs = sc->obs_seq;
   xr.issue(rowphys, a.obs, nd, 0);
   xr.commit(xs, rowphys, a.obs, nd, 0);
+  // Every load issued so far (weights, biases, the first rows) is waited for HERE, once, as an instruction the compiler's wait
+  // insertion can see: otherwise the registers loaded ahead of the step loop stay "pending" at its header, and every step waits
+  // `vmcnt(k)` inside layer 1 and `vmcnt(0)` before the bias adds -- which, with ONE counter for loads and stores on gfx950, drains
+  // the previous step's STORES in the middle of the products (round 6, third session: profiles/r06_al_*)
+  vm_drain();
   lds_only_barrier();
   PH_STAMP(a.prof, 1);
 
@@ -452,6 +459,8 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
     lds_only_barrier();   // the previous step's head is done with xs (H2)
     xr.issue(rowphys, a.obs, nd, 0);
     xr.commit(xs, rowphys, a.obs, nd, 0);
+    vm_drain();   // the rows are in (the commit waited for them): say so, or the observation copy at the end of the step waits
+                  // `vmcnt(0)` for registers that arrived a microsecond ago and drains the row tail's stores instead
     lds_only_barrier();
   }
   PH_STAMP(pstep, 9);
