@@ -469,7 +469,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   // fetched here, under the layers; RolloutBuffer.add's observation copy of Box rows goes out straight from the staged registers
   // (the row was read once: no second trip to the observation)
   const bool pre_ok = net == 1 && wave == 0 && lane < R && row0 + lane < a.n && !a.pos_env && a.rb_val;
-  ValuePre vpre = {0.f, 0.f, 0.f};
+  ValuePre vpre = {0.f, 0.f, 0.f, 0ull, 0ull, 0u, 0, 0};
   if (pre_ok) vpre = value_row_preload(a, row0 + lane);
   const bool copy_from_regs = net == 1 && a.rb_obs && !a.pos_env && nd.obs_kind == PH_SPACE_BOX;
   {
@@ -491,6 +491,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
 
   // ---- head: wave 0, a third product (columns = logits, or the value in column 0); the other waves copy observations ----
   if (wave == 0) {
+    if (pre_ok) value_row_preload_words(a, row0 + lane, vpre);   // (exchange rollouts: the joint action's words, under the head product)
     const f32x4 zh = product(xs, bwh);
     PH_STAMP(pstep, 12);
     if (c < 8) {

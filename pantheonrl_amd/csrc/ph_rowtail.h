@@ -32,22 +32,67 @@ __device__ __forceinline__ int ll_read(const FwdArgs& a, const unsigned long lon
   }
 }
 
+// both words of a joint action at once: the two reads travel together (one behind the other each was a round trip of its own)
+__device__ __forceinline__ void ll_read2(const FwdArgs& a, const unsigned long long* w0, const unsigned long long* w1, int& v0, int& v1) {
+  const unsigned want = p2p_stamp32(*a.ll_epoch, a.ll_T, a.ll_t);
+  const long long t0 = wall_clock64();
+  int polls = 0;
+  while (true) {
+    const unsigned long long x0 = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long x1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    v0 = (int)(unsigned)x0;
+    v1 = (int)(unsigned)x1;
+    const bool ok0 = (unsigned)(x0 >> 32) == want, ok1 = (unsigned)(x1 >> 32) == want;
+    if (ok0 && ok1) return;
+    if ((unsigned long long)(wall_clock64() - t0) > a.ll_timeout) {
+      const unsigned long long* w = ok0 ? w1 : w0;
+      p2p_note_timeout(a.ll_error, 1, a.ll_t, a.joint_ll ? (unsigned long long)(w - a.joint_ll) : 0ull, want, ok0 ? x1 : x0);
+      return;
+    }
+    poll_backoff(polls);
+  }
+}
+
 // What the value-net tail of row g READS from global memory (rectangular rollouts): fetched at the top of a step, under the
 // layers, so that the tail is stores only -- three dependent round trips less at the end of every step of a rollout
+// ... and, for the exchange rollouts, room for the two stamped words of the previous step's joint action (own seat, partner seat),
+// which value_row_preload_words requests ahead of the tail.  A word that is not there yet is polled in the tail (both together).
 struct ValuePre {
   float es, pend, prev;
+  unsigned long long w_mine, w_theirs;
+  unsigned want;
+  int partner, has_words;
 };
 __device__ __forceinline__ ValuePre value_row_preload(const FwdArgs& a, int g) {
   ValuePre p;
   p.es = a.es_in ? a.es_in[g] : 0.f;
   p.pend = a.pending_reward ? a.pending_reward[g] : 0.f;
   p.prev = (a.pending_reward && a.prev_rew) ? a.prev_rew[g] : 0.f;
+  p.w_mine = p.w_theirs = 0ull;
+  p.want = 0u;
+  p.partner = 0;
+  p.has_words = 0;
   return p;
+}
+
+// the two words of the previous step's joint action, requested ahead of the tail (callers: just before the head product -- by then
+// the words were pushed two layers ago, and the read completes under the product)
+__device__ __forceinline__ void value_row_preload_words(const FwdArgs& a, int g, ValuePre& p) {
+  if (a.pending_reward && a.joint && a.joint_ll) {
+    int q = *a.partner_seat;
+    q = q < 0 ? 0 : (q >= a.n_seats ? a.n_seats - 1 : q);
+    p.partner = q;
+    p.want = p2p_stamp32(*a.ll_epoch, a.ll_T, a.ll_t);
+    p.w_mine = __hip_atomic_load(a.joint_ll + (size_t)a.seat * a.n + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    p.w_theirs = __hip_atomic_load(a.joint_ll + (size_t)q * a.n + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    p.has_words = 1;
+  }
 }
 
 // value-net tail of one row: cache V, write the rollout-buffer row scalars, fold the previous step's late reward in
 // (has_pre: `pre` holds the row's inputs, fetched ahead by value_row_preload -- rectangular rollouts only)
-__device__ __forceinline__ void value_row_tail(const FwdArgs& a, int g, float v, bool has_pre = false, ValuePre pre = ValuePre{0.f, 0.f, 0.f}) {
+__device__ __forceinline__ void value_row_tail(const FwdArgs& a, int g, float v, bool has_pre = false,
+                                               ValuePre pre = ValuePre{0.f, 0.f, 0.f, 0ull, 0ull, 0u, 0, 0}) {
   const long long ridx = a.rb_val ? rb_row(a, g) : -1;
   if (a.values && (!a.pos_env || ridx >= 0)) a.values[g] = v;  // ragged: V of the last RECORDED action is cached
   if (ridx >= 0) {
@@ -60,8 +105,14 @@ __device__ __forceinline__ void value_row_tail(const FwdArgs& a, int g, float v,
         int p = *a.partner_seat;
         p = p < 0 ? 0 : (p >= a.n_seats ? a.n_seats - 1 : p);
         if (a.joint_ll) {
-          const int mine = ll_read(a, a.joint_ll + (size_t)a.seat * a.n + g);
-          const int theirs = ll_read(a, a.joint_ll + (size_t)p * a.n + g);
+          int mine, theirs;
+          if (has_pre && pre.has_words && pre.partner == p && (unsigned)(pre.w_mine >> 32) == pre.want &&
+              (unsigned)(pre.w_theirs >> 32) == pre.want) {   // both arrived with the early read
+            mine = (int)(unsigned)pre.w_mine;
+            theirs = (int)(unsigned)pre.w_theirs;
+          } else {
+            ll_read2(a, a.joint_ll + (size_t)a.seat * a.n + g, a.joint_ll + (size_t)p * a.n + g, mine, theirs);
+          }
           add += joint_reward(mine, theirs, a.bonus, a.reward_rule);
         } else {
           add += joint_reward(a.joint[(size_t)a.seat * a.n + g], a.joint[(size_t)p * a.n + g], a.bonus, a.reward_rule);
