@@ -340,6 +340,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   float* zs = hs + R * LDH;         // [16][8]    head output incl. bias: policy logits | value in column 0
   int* rowphys = (int*)(zs + R * 8);      // [16]
   float* upre = (float*)(rowphys + 16);   // [2][16] sampling uniforms of the rows, drawn a step ahead (scripted rollouts)
+  unsigned long long** pxll = (unsigned long long**)(upre + 32);   // [PH_MAX_RANKS] every rank's receive area (exchange forms)
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -355,6 +356,22 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   PH_STAMP(a.prof, 0);
   // every global load of the kernel is issued here; row indices are trivial (row0 + r), so X needs no metadata pass
   if (tid < R) rowphys[tid] = (row0 + tid < a.n) ? row0 + tid : -1;
+  // The exchange descriptor lives in DEVICE memory (P2PStep): every `px->field` is a global load, and inside the step loop the
+  // compiler cannot hoist them past the loop's own global stores -- the policy rows' push walked four dependent round trips per
+  // step (world, count, rank, ll[p]).  Its scalars are read once here, the peers' area pointers staged in LDS.
+  // (LEAN forms only: the general form of the exchange rollout is built for three waves per SIMD and has no register to spare)
+  constexpr bool PXH = LEAN != 0;
+  const int pxw_h = (PXH && px) ? px->world : 0, pxc_h = (PXH && px) ? px->count : 0, pxr_h = (PXH && px) ? px->rank : 0;
+  const int pxT_h = (PXH && px) ? px->T : 1, pxslots_h = (PXH && px) ? px->ll_slots : 1;
+  unsigned long long* const ll_self_h = (PXH && px) ? px->ll[pxr_h] : nullptr;
+  if (PXH && px && tid < pxw_h && tid < PH_MAX_RANKS) pxll[tid] = px->ll[tid];
+#define pxw (PXH ? pxw_h : px->world)
+#define pxc (PXH ? pxc_h : px->count)
+#define pxr (PXH ? pxr_h : px->rank)
+#define pxT (PXH ? pxT_h : px->T)
+#define pxslots (PXH ? pxslots_h : px->ll_slots)
+#define ll_self (PXH ? ll_self_h : px->ll[px->rank])
+#define PXLL(p) (PXH ? pxll[p] : px->ll[p])
   float bw1[16], bw2[16], bwh[16];   // B operands: element [g + 4s][this lane's column] of W1, W2 and the head
   const int col = 16 * wave + c;
 #pragma unroll
@@ -452,7 +469,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
     }
     if (px_persistent && a0.joint) {   // the joint action of step t - 1 as stamp-in-band words (value_row_tail polls them)
       a.joint = a0.joint;
-      a.joint_ll = px->ll[px->rank] + (size_t)p2p_persistent_slot(px_epoch, px->T, t - 1) * px->world * px->count;
+      a.joint_ll = ll_self + (size_t)p2p_persistent_slot(px_epoch, pxT, t - 1) * pxw * pxc;
       a.ll_t = t - 1;
     }
     a.prof = nullptr;
@@ -522,12 +539,12 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
         }
         if (px) {  // push: (stamp << 32 | action) as one 8-byte store into every rank's receive area, slot t mod ll_slots
           const int pt = px_t + t;
-          const int slot = px_persistent ? p2p_persistent_slot(px_epoch, px->T, pt) : pt % px->ll_slots;
-          const size_t off = (size_t)slot * px->world * px->count + (size_t)(px->rank * px_a_local + agent) * a.n + grow;
+          const int slot = px_persistent ? p2p_persistent_slot(px_epoch, pxT, pt) : pt % pxslots;
+          const size_t off = (size_t)slot * pxw * pxc + (size_t)(pxr * px_a_local + agent) * a.n + grow;
           const unsigned long long w =
-              ((unsigned long long)p2p_stamp32(px_persistent ? px_epoch : *px->epoch, px->T, pt) << 32) | (unsigned long long)(unsigned)act;
-          for (int p = 0; p < px->world; ++p)
-            __hip_atomic_store(px->ll[p] + off, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              ((unsigned long long)p2p_stamp32(px_persistent ? px_epoch : *px->epoch, pxT, pt) << 32) | (unsigned long long)(unsigned)act;
+          for (int p = 0; p < pxw; ++p)
+            __hip_atomic_store(PXLL(p) + off, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       } else {
         const float v = zs[r * 8];
@@ -537,7 +554,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
           float add = sc->rew_seq[(size_t)t * a0.n + grow];
           if (px_persistent && a0.joint) {   // ph_buffer_add_reward_joint of the launch-by-launch walk: base + bonus * [own == partner's]
             FwdArgs b = a;
-            b.joint_ll = px->ll[px->rank] + (size_t)p2p_persistent_slot(px_epoch, px->T, t) * px->world * px->count;
+            b.joint_ll = ll_self + (size_t)p2p_persistent_slot(px_epoch, pxT, t) * pxw * pxc;
             b.ll_t = t;
             int p = *a0.partner_seat;
             p = p < 0 ? 0 : (p >= a0.n_seats ? a0.n_seats - 1 : p);
@@ -566,6 +583,14 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   PH_STAMP(pstep, 15);
   }
 }
+
+#undef pxw
+#undef pxc
+#undef pxr
+#undef pxT
+#undef pxslots
+#undef ll_self
+#undef PXLL
 
 template <bool VALU, bool LEAN = false>
 __global__ __launch_bounds__(256) void policy_fwd16_kernel(FwdArgs a) {
@@ -613,7 +638,7 @@ static int current_device_slot() {
   return (dev >= 0 && dev < 64) ? dev : 0;
 }
 
-static size_t fwd16_lds_bytes() { return sizeof(float) * (size_t)(2 * 16 * LDH + 16 * 8 + 16 + 32); }
+static size_t fwd16_lds_bytes() { return sizeof(float) * (size_t)(2 * 16 * LDH + 16 * 8 + 16 + 32) + sizeof(void*) * PH_MAX_RANKS; }
 
 bool fwd16_eligible(const NetDims& nd, int n) {
   static int enabled = -1;
