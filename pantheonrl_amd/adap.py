@@ -302,7 +302,10 @@ class ADAP(PPO):
             applied = st[:, 7] > 0
             n_used = max(int(applied.sum()) + (1 if not applied.all() else 0), 1)
             self.last_context_losses = cl
-            self.logger.record("train/context_kl_loss", float(cl[:n_used].mean()))   # adap_learn.py:359
+            # adap_learn.py:359 -- of the LAST epoch that ran: `context_kl_divs` is emptied at the top of every epoch (:250)
+            rb = self.rollout_buffer
+            n_mb = -(-(rb.buffer_size * rb.n_envs) // self.batch_size)
+            self.logger.record("train/context_kl_loss", float(cl[((n_used - 1) // n_mb) * n_mb:n_used].mean()))
 
     # -- ADAP.collect_rollouts (adap_learn.py:375-473): a fresh context for every column whose episode ended ----------
     def _after_step(self, dones) -> None:

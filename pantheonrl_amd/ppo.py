@@ -706,7 +706,9 @@ class PPO:
             lg.record("train/entropy_loss", float(used[:, 2].mean()))
             lg.record("train/policy_gradient_loss", float(used[:, 0].mean()))
             lg.record("train/value_loss", float(used[:, 1].mean()))
-            lg.record("train/approx_kl", float(used[:, 4].mean()))
+            # ... except approx_kl: `approx_kl_divs` is emptied at the top of every epoch (adap_learn.py:248-250), so the logged mean is
+            # over the minibatches of the LAST epoch that ran (reference-generated fixture tests/golden/ref_ppo_train.npz)
+            lg.record("train/approx_kl", float(used[((len(used) - 1) // n_mb) * n_mb:, 4].mean()))
             lg.record("train/clip_fraction", float(used[:, 3].mean()))
             lg.record("train/loss", float(used[-1, 5]))
             lg.record("train/n_updates", self._n_updates, exclude="tensorboard")

@@ -2,7 +2,8 @@
 Build container only: `/root/reference` never travels, the fixtures this script writes do.
 
     python tests/golden/make_reference_fixtures.py            # regenerate in memory, compare byte for byte with the committed files
-    python tests/golden/make_reference_fixtures.py --write    # (re)write tests/golden/ref_*.json, ref_transitions.npz, ref_adap_context.npz
+    python tests/golden/make_reference_fixtures.py --write    # (re)write tests/golden/ref_*.json, ref_transitions.npz, ref_adap_context.npz,
+                                                              # ref_ppo_train.npz
 
 What runs is the reference's source, imported from where it lies (nothing is copied into this repository):
 
@@ -13,6 +14,9 @@ What runs is the reference's source, imported from where it lies (nothing is cop
     pantheonrl/common/wrappers.py        HistoryQueue, the frame-stack wrappers, the recorders
     pantheonrl/common/trajsaver.py       TransitionsMinimal / TurnBasedTransitions / SimultaneousTransitions (.npy wire format)
     pantheonrl/algos/adap/util.py        SAMPLERS, kl_divergence, get_context_kl_loss
+    pantheonrl/algos/adap/adap_learn.py  ADAP.train (:229-371) -- the in-tree text of SB3's PPO.train() loop (+ the context term): SURVEY.md
+                                         section 8 row a8's arithmetic and row f4's ADAP variant
+    pantheonrl/algos/adap/policies.py    AdapPolicy.__init__/set_context/get_context/_get_latent/evaluate_actions (:20-135)
 
 `pantheonrl/__init__.py` (which registers gym environments) is bypassed by pre-seating an empty package object whose __path__ is the
 reference's directory.  Those files import `gym` and `stable_baselines3`, absent here; they are satisfied by INERT stand-ins for
@@ -29,6 +33,21 @@ exactly the names imported, none of which contributes a rule or arithmetic to wh
     stable_baselines3.common.distributions.{Distribution,CategoricalDistribution,MultiCategoricalDistribution}
                                               holders of `.distribution` (torch.distributions.Categorical objects built by the TEST's model)
     stable_baselines3.common.buffers.RolloutBufferSamples       the namedtuple of that name (fields as SB3 1.7.0 publishes them)
+
+For ADAP.train / AdapPolicy (fixture ref_ppo_train.npz) additionally -- names for imports, annotations and base classes, plus exactly
+four pieces of behaviour, each SB3 1.7.0's published definition restated in one line and listed here because it is NOT the reference's text:
+
+    stable_baselines3.common.{type_aliases,vec_env,callbacks,torch_layers}, buffers.RolloutBuffer, utils.{get_schedule_fn,get_device}
+                                              NAMES only (never called by train / evaluate_actions)
+    stable_baselines3.common.policies.ActorCriticPolicy        base class whose __init__ accepts and ignores AdapPolicy's keyword arguments;
+                                              the network (MlpExtractor 64-64 tanh, action_net, value_net, Adam(eps=1e-5)) is the TEST's
+                                              torch module (oracle.MlpPolicyOracle), attached by the test's subclass
+    stable_baselines3.common.utils.explained_variance          returns {"explained_variance_of": shapes}: logged only, arithmetic NOT done here
+    CategoricalDistribution.log_prob / .entropy                 self.distribution.log_prob(actions) / self.distribution.entropy()
+    MultiCategoricalDistribution.log_prob / .entropy            stack over the components (actions unbound along dim 1), summed along dim 1
+    algo._update_learning_rate(optimizer)                       sets every param group's lr to the constant the case names (SB3 with a constant schedule)
+    algo.rollout_buffer.get(batch_size)                         env-major flattening + slicing of the per-epoch index orders the TEST provides
+                                              (np.random.permutation teacher-forced), yielding RolloutBufferSamples of torch tensors
 
 The scenarios themselves (scripted games, recording partners, the recording model) are tests/refdrive.py -- shared with the tests
 that replay them through pantheonrl_amd.common.
@@ -111,23 +130,117 @@ def _stand_ins() -> dict:
         def __init__(self, distribution=None):
             self.distribution = distribution
 
+    class CategoricalDistribution(Distribution):              # SB3 1.7.0 distributions.py: log_prob / entropy delegate to torch's Categorical
+        def log_prob(self, actions):
+            return self.distribution.log_prob(actions)
+
+        def entropy(self):
+            return self.distribution.entropy()
+
+    class MultiCategoricalDistribution(Distribution):         # ... and the MultiCategorical sums its components' along dim 1
+        def log_prob(self, actions):
+            return th.stack([d.log_prob(a) for d, a in zip(self.distribution, th.unbind(actions, dim=1))], dim=1).sum(dim=1)
+
+        def entropy(self):
+            return th.stack([d.entropy() for d in self.distribution], dim=1).sum(dim=1)
+
+    class ActorCriticPolicy:                                  # base of AdapPolicy: takes (and ignores) its constructor's keyword arguments
+        def __init__(self, *args, **kwargs):
+            pass
+
+    # -- ModularPolicy (modular/policies.py) BUILDS its network from SB3 classes: each restated below in its SB3 1.7.0 definition --
+    def _categorical_init(self, arg=None):                    # CategoricalDistribution(action_dim) | the holder form used above
+        if isinstance(arg, (int, np.integer)):
+            self.action_dim, self.distribution = int(arg), None
+        else:
+            self.distribution = arg
+    CategoricalDistribution.__init__ = _categorical_init
+    CategoricalDistribution.proba_distribution_net = lambda self, latent_dim: th.nn.Linear(latent_dim, self.action_dim)
+
+    def _proba_distribution(self, action_logits):
+        self.distribution = th.distributions.Categorical(logits=action_logits)
+        return self
+    CategoricalDistribution.proba_distribution = _proba_distribution
+
+    def make_proba_distribution(action_space, use_sde=False, dist_kwargs=None):
+        assert isinstance(action_space, spaces.Discrete) and not use_sde
+        return CategoricalDistribution(action_space.n)
+
+    class BasePolicy(th.nn.Module):
+        def __init__(self, observation_space, action_space, features_extractor_class=None, features_extractor_kwargs=None,
+                     features_extractor=None, normalize_images=True, optimizer_class=th.optim.Adam, optimizer_kwargs=None,
+                     squash_output=False):
+            super().__init__()
+            self.observation_space, self.action_space = observation_space, action_space
+            self.features_extractor_class, self.features_extractor_kwargs = features_extractor_class, features_extractor_kwargs or {}
+            self.optimizer_class, self.optimizer_kwargs, self.optimizer = optimizer_class, optimizer_kwargs or {}, None
+
+        device = property(lambda self: th.device("cpu"))
+
+        @staticmethod
+        def init_weights(module, gain=1):                     # SB3 BasePolicy.init_weights
+            if isinstance(module, (th.nn.Linear, th.nn.Conv2d)):
+                th.nn.init.orthogonal_(module.weight, gain=gain)
+                if module.bias is not None:
+                    module.bias.data.fill_(0.0)
+
+        def extract_features(self, obs):                      # preprocess_obs of a Box observation (obs.float()), then the extractor
+            return self.features_extractor(obs.float())
+
+    class FlattenExtractor(th.nn.Module):
+        def __init__(self, observation_space):
+            super().__init__()
+            self.features_dim, self.flatten = int(np.prod(observation_space.shape)), th.nn.Flatten()
+
+        def forward(self, observations):
+            return self.flatten(observations)
+
+    class MlpExtractor(th.nn.Module):                         # net_arch [dict(pi=[..], vf=[..])]: two separate towers, nothing shared
+        def __init__(self, feature_dim, net_arch, activation_fn, device="auto"):
+            super().__init__()
+            assert len(net_arch) == 1 and isinstance(net_arch[0], dict)
+
+            def tower(widths):
+                layers, d = [], feature_dim
+                for w in widths:
+                    layers += [th.nn.Linear(d, w), activation_fn()]
+                    d = w
+                return th.nn.Sequential(*layers), d
+            self.policy_net, self.latent_dim_pi = tower(net_arch[0]["pi"])
+            self.value_net, self.latent_dim_vf = tower(net_arch[0]["vf"])
+
+        def forward(self, features):
+            return self.policy_net(features), self.value_net(features)
+
     utils = mod("stable_baselines3.common.utils",
                 configure_logger=lambda *a, **k: None,
                 safe_mean=lambda arr: {"safe_mean_of": rd.plain(list(arr))},
                 obs_as_tensor=lambda obs, device: th.as_tensor(obs).to(device),
-                should_collect_more_steps=None)
-    policies = mod("stable_baselines3.common.policies", ActorCriticPolicy=name_only("ActorCriticPolicy"))
+                should_collect_more_steps=None, get_schedule_fn=None, get_device=None, is_vectorized_observation=None,
+                explained_variance=lambda y_pred, y_true: {"explained_variance_of": [list(np.shape(y_pred)), list(np.shape(y_true))]})
+    policies = mod("stable_baselines3.common.policies", ActorCriticPolicy=ActorCriticPolicy, BasePolicy=BasePolicy)
     onp = mod("stable_baselines3.common.on_policy_algorithm", OnPolicyAlgorithm=name_only("OnPolicyAlgorithm"))
     offp = mod("stable_baselines3.common.off_policy_algorithm", OffPolicyAlgorithm=name_only("OffPolicyAlgorithm"))
     base = mod("stable_baselines3.common.base_class", BaseAlgorithm=name_only("BaseAlgorithm"))
     dist = mod("stable_baselines3.common.distributions", Distribution=Distribution,
-               CategoricalDistribution=type("CategoricalDistribution", (Distribution,), {}),
-               MultiCategoricalDistribution=type("MultiCategoricalDistribution", (Distribution,), {}))
-    bufs = mod("stable_baselines3.common.buffers", RolloutBufferSamples=namedtuple(
+               CategoricalDistribution=CategoricalDistribution, MultiCategoricalDistribution=MultiCategoricalDistribution,
+               make_proba_distribution=make_proba_distribution, DiagGaussianDistribution=name_only("DiagGaussianDistribution"),
+               BernoulliDistribution=name_only("BernoulliDistribution"),
+               StateDependentNoiseDistribution=name_only("StateDependentNoiseDistribution"))
+    bufs = mod("stable_baselines3.common.buffers", RolloutBuffer=name_only("RolloutBuffer"), RolloutBufferSamples=namedtuple(
         "RolloutBufferSamples", ["observations", "actions", "old_values", "old_log_prob", "advantages", "returns"]))
+    aliases = mod("stable_baselines3.common.type_aliases", GymEnv=name_only("GymEnv"), MaybeCallback=name_only("MaybeCallback"),
+                  Schedule=name_only("Schedule"))
+    vec_env = mod("stable_baselines3.common.vec_env", VecEnv=name_only("VecEnv"), VecTransposeImage=name_only("VecTransposeImage"))
+    sb3_logger = mod("stable_baselines3.common.logger")
+    callbacks = mod("stable_baselines3.common.callbacks", BaseCallback=name_only("BaseCallback"))
+    layers = mod("stable_baselines3.common.torch_layers", BaseFeaturesExtractor=name_only("BaseFeaturesExtractor"),
+                 FlattenExtractor=FlattenExtractor, MlpExtractor=MlpExtractor, create_mlp=None, NatureCNN=name_only("NatureCNN"))
+    prep = mod("stable_baselines3.common.preprocessing", preprocess_obs=None, is_image_space=None, get_action_dim=None)
     common = mod("stable_baselines3.common", utils=utils, policies=policies, on_policy_algorithm=onp, off_policy_algorithm=offp,
-                 base_class=base, distributions=dist, buffers=bufs)
-    mod("stable_baselines3", common=common)
+                 base_class=base, distributions=dist, buffers=bufs, type_aliases=aliases, vec_env=vec_env, callbacks=callbacks,
+                 torch_layers=layers, preprocessing=prep, logger=sb3_logger)
+    mod("stable_baselines3", common=common, PPO=name_only("PPO"))
     pkg = types.ModuleType("pantheonrl")
     pkg.__path__ = [os.path.join(REFERENCE, "pantheonrl")]        # the reference's files, in place; its __init__.py is not run
     mods["pantheonrl"] = pkg
@@ -138,7 +251,7 @@ class ReferenceModules:
     """context manager: the reference's modules importable under `pantheonrl.*`, sys.modules restored afterwards"""
 
     NAMES = ("common.observation", "common.util", "common.trajsaver", "common.agents", "common.multiagentenv", "common.wrappers",
-             "algos.adap.util")
+             "algos.adap.util", "algos.adap.policies", "algos.adap.adap_learn", "algos.modular.policies", "algos.modular.learn")
 
     def __enter__(self):
         self._stand = _stand_ins()
@@ -253,6 +366,357 @@ def adap_sampler_run(util_mod) -> dict:
     return out
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (vi) the reference's ADAP.train TEXT (adap_learn.py:229-371 = SB3's PPO.train loop + the context term) and AdapPolicy's
+#      evaluate_actions / _get_latent TEXT (adap/policies.py:97-135), run on a network, a buffer and index orders the TEST provides
+# ---------------------------------------------------------------------------------------------------------------------------
+TRAIN_CASES = {
+    # context_loss_coeff = 0: the loss is PPO's (policy + ent_coef * entropy + vf_coef * value; the term's gradient is exactly 0) -- what
+    # pantheonrl_amd.PPO.train computes on a Box(F + ctx) observation
+    "ppo_discrete6": dict(F=9, ctx=3, nvec=(6,), T=16, E=4, batch=16, epochs=3, lr=3e-4, clip=0.2, clip_vf=None, ent=0.01, vf=0.5,
+                          max_norm=0.5, target_kl=None, coef=0.0, n_ctx=5, n_states=32, sampler="l2", seed=21),
+    # value clipping, a learning rate that moves the ratio out of the clip range, and the KL early stop at the second minibatch of epoch 2 (approx_kl 0.0845 > 1.5 x 0.052 after 0.0737 passed)
+    "ppo_clipvf_klstop": dict(F=17, ctx=3, nvec=(5,), T=12, E=8, batch=32, epochs=4, lr=3e-3, clip=0.1, clip_vf=0.2, ent=0.0, vf=0.5,
+                              max_norm=0.5, target_kl=0.052, coef=0.0, n_ctx=2, n_states=4, sampler="l2", seed=22),
+    # ADAP as the reference constructs it (adap_learn.py:111-116 defaults), a ragged last minibatch (96 = 40 + 40 + 16)
+    "adap_discrete6": dict(F=9, ctx=3, nvec=(6,), T=16, E=6, batch=40, epochs=3, lr=3e-4, clip=0.2, clip_vf=None, ent=0.0, vf=0.5,
+                           max_norm=0.5, target_kl=None, coef=0.1, n_ctx=5, n_states=32, sampler="l2", seed=23),
+    "adap_multi_7_12": dict(F=12, ctx=4, nvec=(7, 12), T=10, E=6, batch=30, epochs=2, lr=1e-3, clip=0.2, clip_vf=None, ent=0.01, vf=0.5,
+                            max_norm=0.5, target_kl=None, coef=1.0, n_ctx=4, n_states=16, sampler="unit_square", seed=24),
+}
+
+
+def train_case_inputs(c: dict):
+    """-> (network, its flat parameters, a full RolloutBufferOracle as the data holder, per-epoch index orders).  Seeded test inputs:
+    rollout rows are N(0, 1) features ++ the environment's current context (resampled at episode starts, adap_learn.py:448-458), actions /
+    values / log-probs are the network's own on those rows, rewards N(0, 1); advantages / returns by the buffer's GAE."""
+    from oracle import sb3_oracle as orc
+    th.manual_seed(c["seed"])
+    D, A = c["F"] + c["ctx"], len(c["nvec"])
+    act = orc.SpaceSpec("discrete", nvec=c["nvec"]) if A == 1 else orc.SpaceSpec("multidiscrete", nvec=c["nvec"])
+    net = orc.MlpPolicyOracle(orc.SpaceSpec("box", dim=D), act, lr=c["lr"])
+    rng = np.random.default_rng(c["seed"])
+    flat = (net.flat_params() + 0.2 * rng.standard_normal(net.flat_params().shape)).astype(np.float32)
+    net.load_flat_params(flat)
+    T, E = c["T"], c["E"]
+    buf = orc.RolloutBufferOracle(T, E, D, A)
+    starts = np.ones(E, np.float32)
+    ctx = np.zeros((E, c["ctx"]), np.float32)
+    values = None
+    for _ in range(T):
+        for e in np.nonzero(starts)[0]:
+            ctx[e] = orc.adap_sample_contexts(c["sampler"], c["ctx"], 1, rng.random((1, c["ctx"])))[0]
+        obs = np.concatenate([rng.standard_normal((E, c["F"])).astype(np.float32), ctx], axis=1)
+        with th.no_grad():
+            actions, values, logp = net.forward(th.as_tensor(obs), uniforms=th.as_tensor(rng.random((E, A)).astype(np.float32)))
+        buf.add(obs, actions.numpy(), rng.standard_normal(E).astype(np.float32), starts, values, logp)
+        starts = (rng.random(E) < 0.1).astype(np.float32)
+    buf.compute_returns_and_advantage(values, starts)
+    perms = np.stack([rng.permutation(T * E) for _ in range(c["epochs"])]).astype(np.int64)
+    return net, flat, buf, perms
+
+
+def train_reference_run(ref: "ReferenceModules", c: dict) -> dict:
+    learn_mod, pol_mod = ref.m["algos.adap.adap_learn"], ref.m["algos.adap.policies"]
+    dist_mod = sys.modules["stable_baselines3.common.distributions"]
+    Samples = sys.modules["stable_baselines3.common.buffers"].RolloutBufferSamples
+    net, flat, buf, perms = train_case_inputs(c)
+    cs, A = c["ctx"], len(c["nvec"])
+    cur = {"features": None, "calls": 0}
+    seen = {"state_idx": [], "contexts": []}
+
+    class Policy(pol_mod.AdapPolicy):
+        """the reference's AdapPolicy TEXT (set_context / get_context / _get_latent / evaluate_actions) over the test's network"""
+
+        def __init__(self):
+            pol_mod.AdapPolicy.__init__(self, None, None, None, context_size=cs)       # reference text: keeps context_size, calls the base
+            self.sde_features_extractor = None
+            self.value_net = net.value_net
+            self.context = th.zeros(1, cs)                                             # the rollout's context (restored by util.py:127)
+
+        def extract_features(self, obs):                   # FlattenExtractor on a flat Box observation: the identity
+            if cur["calls"] > 0:                            # call 0 of a minibatch is evaluate_actions; 1.. are get_context_kl_loss's
+                feats = obs.detach().numpy()
+                if cur["calls"] == 1:
+                    rows = [int(np.nonzero((cur["features"] == f).all(axis=1))[0][0]) for f in feats]
+                    seen["state_idx"][-1][:len(rows)] = rows
+                seen["contexts"][-1].append(self.context.detach().numpy().reshape(-1).copy())
+            cur["calls"] += 1
+            return obs
+
+        def mlp_extractor(self, features):                  # SB3's default MlpExtractor: two 64-64 tanh towers
+            return net.policy_net(features), net.value_net_mlp(features)
+
+        def _get_action_dist_from_latent(self, latent_pi, latent_sde=None):
+            logits = net.action_net(latent_pi)
+            if A == 1:
+                return dist_mod.CategoricalDistribution(th.distributions.Categorical(logits=logits))
+            return dist_mod.MultiCategoricalDistribution([th.distributions.Categorical(logits=z) for z in net._split(logits)])
+
+        def parameters(self):
+            return net.parameters()
+
+    steps = {"params": [], "grads": []}
+
+    class OptimizerTap:                                     # torch.optim.Adam(eps=1e-5) of the network, every step recorded
+        param_groups = net.optimizer.param_groups
+
+        def zero_grad(self):
+            net.optimizer.zero_grad()
+
+        def step(self):
+            steps["grads"].append(net.flat_grads())         # after clip_grad_norm_
+            net.optimizer.step()
+            steps["params"].append(net.flat_params())
+
+    class Buffer:                                           # sampling only: env-major flattening, the test's index orders, slicing
+        values, returns = buf.values, buf.returns
+
+        def __init__(self):
+            self.epoch = 0
+
+        def get(self, batch_size):
+            order = perms[self.epoch]
+            self.epoch += 1
+            for mb in buf.get(batch_size, order):
+                cur["features"], cur["calls"] = mb["observations"].numpy()[:, :-cs], 0
+                seen["state_idx"].append(np.full(c["n_states"], -1, np.int32))
+                seen["contexts"].append([])
+                yield Samples(mb["observations"], mb["actions"], mb["old_values"], mb["old_log_prob"], mb["advantages"], mb["returns"])
+
+    class Logger:
+        def __init__(self):
+            self.kv = {}
+
+        def record(self, key, value, exclude=None):
+            self.kv[key] = value
+
+    policy = Policy()
+    policy.optimizer = OptimizerTap()
+
+    def set_lr(optimizer):
+        for g in optimizer.param_groups:
+            g["lr"] = c["lr"]
+
+    space = ref.spaces.Discrete(c["nvec"][0]) if A == 1 else ref.spaces.MultiDiscrete(list(c["nvec"]))
+    algo = types.SimpleNamespace(
+        policy=policy, rollout_buffer=Buffer(), n_epochs=c["epochs"], batch_size=c["batch"], action_space=space, use_sde=False,
+        ent_coef=c["ent"], vf_coef=c["vf"], context_loss_coeff=c["coef"], target_kl=c["target_kl"], verbose=0, max_grad_norm=c["max_norm"],
+        _n_updates=0, logger=Logger(), clip_range=lambda progress: c["clip"],
+        clip_range_vf=None if c["clip_vf"] is None else (lambda progress: c["clip_vf"]), _current_progress_remaining=1.0,
+        _update_learning_rate=set_lr, context_size=cs, num_context_samples=c["n_ctx"], num_state_samples=c["n_states"],
+        context_sampler=c["sampler"])
+    th.manual_seed(1000 + c["seed"])
+    learn_mod.ADAP.train(algo)                              # <- the reference's text
+    n_steps, n_mb_seen = len(steps["params"]), len(seen["state_idx"])
+    assert n_steps >= 2 and algo._n_updates == c["epochs"]
+    flatbuf = buf.flat()
+    out = {"params0": flat, "perms": perms, "n_steps": np.int64(n_steps), "n_minibatches_seen": np.int64(n_mb_seen),
+           "observations": buf.observations, "actions": buf.actions, "values": buf.values, "log_probs": buf.log_probs,
+           "advantages": buf.advantages, "returns": buf.returns, "rewards": buf.rewards, "episode_starts": buf.episode_starts,
+           "params_step1": steps["params"][0], "grads_step1": steps["grads"][0], "params_final": steps["params"][-1],
+           "state_idx": np.stack(seen["state_idx"]),
+           "contexts": np.stack([np.stack(x) for x in seen["contexts"]]).astype(np.float32)}
+    assert out["contexts"].shape == (n_mb_seen, c["n_ctx"], cs) and flatbuf["observations"].shape[0] == c["T"] * c["E"]
+    for k, v in algo.logger.kv.items():
+        if isinstance(v, dict):                             # explained_variance's marker: nothing to keep
+            continue
+        out["log." + k] = np.float64(v)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (vii) the reference's ModularPolicy TEXT (modular/policies.py:57-395: constructor defaults, _build, do_init_weights' gains,
+#       evaluate_actions, the mask offset of _get_action_dist_from_latent, get_action_logits_from_obs) and ModularAlgorithm.train
+#       TEXT (modular/learn.py:221-351: the PPO terms per partner + the marginal regulariser, the per-epoch KL rule)
+# ---------------------------------------------------------------------------------------------------------------------------
+MODULAR_CASES = {
+    "two_partners": dict(D=20, n_act=6, K=2, T=8, E=8, batch=16, epochs=2, lr=3e-4, clip=0.2, clip_vf=None, ent=0.01, vf=0.5,
+                         max_norm=0.5, target_kl=None, coef=0.5, kw={}, seed=31),
+    # lr moves the policy fast: partner 0's second epoch exceeds 1.5 x target_kl and ends ITS epochs; partners 1, 2 start afresh
+    "three_partners_klstop": dict(D=12, n_act=5, K=3, T=8, E=6, batch=24, epochs=4, lr=3e-3, clip=0.2, clip_vf=0.3, ent=0.0, vf=0.5,
+                                  max_norm=0.5, target_kl=0.02, coef=0.0, kw={}, seed=32),
+    "nomain": dict(D=9, n_act=4, K=2, T=8, E=4, batch=32, epochs=2, lr=1e-3, clip=0.2, clip_vf=None, ent=0.01, vf=0.5,
+                   max_norm=0.5, target_kl=None, coef=0.4, kw={"nomain": True}, seed=33),
+}
+
+
+def modular_flat(pol, grads: bool = False) -> np.ndarray:
+    """parameters of a REFERENCE ModularPolicy in the product's order: main network [pi_W1 pi_b1 pi_W2 pi_b2 vf_W1 vf_b1 vf_W2 vf_b2
+    act_W act_b val_W val_b], then the same twelve blocks per partner module; weights input-major"""
+    def vec(t, transpose):
+        x = t.grad if grads else t.detach()
+        x = th.zeros_like(t) if x is None else x
+        return (x.t() if transpose else x).contiguous().reshape(-1)
+
+    def module(ext, act, val):
+        out = []
+        for seq in (ext.policy_net, ext.value_net):
+            for i in (0, 2):
+                out += [vec(seq[i].weight, True), vec(seq[i].bias, False)]
+        return out + [vec(act.weight, True), vec(act.bias, False), vec(val.weight, False), vec(val.bias, False)]
+    out = module(pol.mlp_extractor, pol.action_net, pol.value_net)
+    for k in range(pol.num_partners):
+        out += module(pol.partner_mlp_extractor[k], pol.partner_action_net[k], pol.partner_value_net[k])
+    return th.cat(out).numpy().astype(np.float32).copy()
+
+
+def load_modular_oracle(c: dict, flat: np.ndarray):
+    """an oracle.ModularPolicyOracle holding `flat` (modular_flat's order)"""
+    from oracle import sb3_oracle as orc
+    net = orc.ModularPolicyOracle(orc.SpaceSpec("box", dim=c["D"]), orc.SpaceSpec("discrete", nvec=(c["n_act"],)), num_partners=c["K"],
+                                  lr=c["lr"], **c["kw"])
+    t, o = th.as_tensor(flat), 0
+
+    def take(p, transpose):
+        nonlocal o
+        n = p.numel()
+        v = t[o:o + n]
+        o += n
+        with th.no_grad():
+            p.copy_(v.reshape(p.shape[1], p.shape[0]).t() if transpose else v.reshape(p.shape))
+
+    def module(pi, vf, act, val):
+        for seq in (pi, vf):
+            for i in (0, 2):
+                take(seq[i].weight, True)
+                take(seq[i].bias, False)
+        take(act.weight, True)
+        take(act.bias, False)
+        take(val.weight, False)
+        take(val.bias, False)
+    module(net.policy_net, net.value_net_mlp, net.action_net, net.value_net)
+    for pm in net.partners:
+        module(pm["pi"], pm["vf"], pm["act"], pm["val"])
+    assert o == t.numel()
+    return net
+
+
+def modular_reference_run(ref: "ReferenceModules", c: dict) -> dict:
+    import contextlib
+    from oracle import sb3_oracle as orc
+    pol_mod, learn_mod = ref.m["algos.modular.policies"], ref.m["algos.modular.learn"]
+    Samples = sys.modules["stable_baselines3.common.buffers"].RolloutBufferSamples
+    spaces = ref.spaces
+    K, D, T, E = c["K"], c["D"], c["T"], c["E"]
+    th.manual_seed(c["seed"])
+    with contextlib.redirect_stdout(io.StringIO()):            # (the constructor prints "CUDA: ...")
+        pol = pol_mod.ModularPolicy(spaces.Box(-np.inf, np.inf, (D,)), spaces.Discrete(c["n_act"]), lambda progress: c["lr"],
+                                    num_partners=K, **c["kw"])  # <- the reference's text: defaults, _build, do_init_weights
+    # what _build + do_init_weights left (policies.py:221-267): per Linear layer, in modular_flat's module order, the extreme singular
+    # values of its weight (an orthogonal init with gain g has all of them = g) and the largest |bias|; Adam's eps (:84-88)
+    lins = []
+    for ext, act, val in [(pol.mlp_extractor, pol.action_net, pol.value_net)] + [
+            (pol.partner_mlp_extractor[k], pol.partner_action_net[k], pol.partner_value_net[k]) for k in range(K)]:
+        lins += [ext.policy_net[0], ext.policy_net[2], ext.value_net[0], ext.value_net[2], act, val]
+    sv = [th.linalg.svdvals(m.weight.detach().double()).numpy() for m in lins]
+    out = {"init.sv_min": np.asarray([x.min() for x in sv]), "init.sv_max": np.asarray([x.max() for x in sv]),
+           "init.bias_max": np.asarray([float(m.bias.detach().abs().max()) for m in lins]),
+           "init.shapes": np.asarray([list(m.weight.shape) for m in lins], np.int64),
+           "adam_eps": np.float64(pol.optimizer.defaults["eps"])}
+    g = th.Generator().manual_seed(c["seed"] + 1)
+    with th.no_grad():                                          # biases and the 0.01-gain heads perturbed: logits / values not ~0
+        for p in pol.parameters():
+            if p.ndim == 1:
+                p.add_(0.3 * th.randn(p.shape, generator=g))
+        for head in [pol.action_net] + list(pol.partner_action_net):
+            head.weight.add_(0.3 * th.randn(head.weight.shape, generator=g))
+    out["params0"] = modular_flat(pol)
+
+    # forward family: evaluate_actions with and without a mask, get_action_logits_from_obs, on rows the test draws
+    rng = np.random.default_rng(c["seed"])
+    n = 37
+    obs = rng.standard_normal((n, D)).astype(np.float32)
+    acts = rng.integers(0, c["n_act"], n)
+    mask = rng.random((n, c["n_act"])) < 0.7
+    mask[np.arange(n), acts] = True
+    out.update({"fwd.obs": obs, "fwd.actions": acts.astype(np.int64), "fwd.mask": mask})
+    with th.no_grad():
+        for k in range(K):
+            v, lp, ent = pol.evaluate_actions(th.as_tensor(obs), th.as_tensor(acts), partner_idx=k)
+            vm, lpm, entm = pol.evaluate_actions(th.as_tensor(obs), th.as_tensor(acts), partner_idx=k, action_mask=th.as_tensor(mask))
+            zm, zp = pol.get_action_logits_from_obs(th.as_tensor(obs), partner_idx=k)
+            for key, val in (("values", v), ("log_prob", lp), ("entropy", ent), ("masked_log_prob", lpm), ("masked_entropy", entm),
+                             ("main_logits", zm), ("partner_logits", zp)):
+                out[f"fwd.{key}.{k}"] = val.numpy().astype(np.float32)
+            assert np.array_equal(v.numpy(), vm.numpy())
+
+    # one rollout buffer per partner (learn.py:134-144), filled by the policy's own forward on seeded rows
+    bufs = []
+    for k in range(K):
+        buf = orc.RolloutBufferOracle(T, E, D, 1)
+        starts = np.ones(E, np.float32)
+        for _ in range(T):
+            o_t = rng.standard_normal((E, D)).astype(np.float32)
+            a_t = rng.integers(0, c["n_act"], E)
+            with th.no_grad():
+                v, lp, _ = pol.evaluate_actions(th.as_tensor(o_t), th.as_tensor(a_t), partner_idx=k)
+            buf.add(o_t, a_t.astype(np.float32), rng.standard_normal(E).astype(np.float32), starts, v.flatten(), lp)
+            starts = (rng.random(E) < 0.1).astype(np.float32)
+        buf.compute_returns_and_advantage(rng.standard_normal(E).astype(np.float32), starts)
+        bufs.append(buf)
+    perms = np.stack([np.stack([rng.permutation(T * E) for _ in range(c["epochs"])]) for _ in range(K)]).astype(np.int64)
+
+    steps = {"params": [], "partner": []}
+    current = {"partner": -1}
+    adam = pol.optimizer
+
+    class OptimizerTap:
+        param_groups = adam.param_groups
+
+        def zero_grad(self):                                   # the reference pins torch==1.13.1 (setup.py:15): set_to_none defaults to False
+            adam.zero_grad(set_to_none=False)
+
+        def step(self):
+            adam.step()
+            steps["params"].append(modular_flat(pol))
+            steps["partner"].append(current["partner"])
+
+    class Buffer:
+        def __init__(self, k):
+            self.k, self.epoch = k, 0
+
+        def get(self, batch_size):
+            current["partner"] = self.k
+            order = perms[self.k][self.epoch]
+            self.epoch += 1
+            for mb in bufs[self.k].get(batch_size, order):
+                yield Samples(mb["observations"], mb["actions"], mb["old_values"], mb["old_log_prob"], mb["advantages"], mb["returns"])
+
+    class Logger:
+        def __init__(self):
+            self.kv = {}
+
+        def record(self, key, value, exclude=None):
+            self.kv[key] = value
+
+    def set_lr(optimizer):
+        for grp in optimizer.param_groups:
+            grp["lr"] = c["lr"]
+
+    pol.optimizer = OptimizerTap()
+    buffers = [Buffer(k) for k in range(K)]
+    algo = types.SimpleNamespace(
+        policy=pol, rollout_buffer=buffers, n_epochs=c["epochs"], batch_size=c["batch"], action_space=spaces.Discrete(c["n_act"]),
+        use_sde=False, ent_coef=c["ent"], vf_coef=c["vf"], marginal_reg_coef=c["coef"], target_kl=c["target_kl"], max_grad_norm=c["max_norm"],
+        _n_updates=0, logger=Logger(), clip_range=lambda progress: c["clip"],
+        clip_range_vf=None if c["clip_vf"] is None else (lambda progress: c["clip_vf"]), _current_progress_remaining=1.0,
+        _update_learning_rate=set_lr)
+    with contextlib.redirect_stdout(io.StringIO()):            # ("Early stopping at step ..." goes to stdout)
+        learn_mod.ModularAlgorithm.train(algo)                  # <- the reference's text
+    n_steps = len(steps["params"])
+    assert n_steps >= 2 and algo._n_updates == c["epochs"]
+    out.update({"perms": perms, "n_steps": np.int64(n_steps), "step_partner": np.asarray(steps["partner"], np.int64),
+                "epochs_run": np.asarray([b.epoch for b in buffers], np.int64),
+                "params_final": steps["params"][-1]})
+    for k, buf in enumerate(bufs):
+        for name in ("observations", "actions", "values", "log_probs", "advantages", "returns", "rewards", "episode_starts"):
+            out[f"buf{k}.{name}"] = getattr(buf, name)
+    for key, val in algo.logger.kv.items():
+        out["log." + key] = np.float64(val)
+    return out
+
 # ---------------------------------------------------------------------------------------------------------------------------
 def generate() -> dict:
     """-> {file name: bytes} of every reference-generated fixture"""
@@ -276,10 +740,19 @@ def generate() -> dict:
                 adap[f"{name}.{k}"] = v
         for k, v in adap_sampler_run(util_mod).items():
             adap["sampler." + k] = v
+        train = {}
+        for name, c in TRAIN_CASES.items():
+            for k, v in train_reference_run(ref, c).items():
+                train[f"{name}.{k}"] = np.asarray(v)
+        modular = {}
+        for name, c in MODULAR_CASES.items():
+            for k, v in modular_reference_run(ref, c).items():
+                modular[f"{name}.{k}"] = np.asarray(v)
     out = {}
     for name, obj in files.items():
         out[name] = (json.dumps(obj, indent=None, separators=(",", ":"), sort_keys=True) + "\n").encode()
-    for name, arrays in (("ref_transitions.npz", npy), ("ref_adap_context.npz", adap)):
+    for name, arrays in (("ref_transitions.npz", npy), ("ref_adap_context.npz", adap), ("ref_ppo_train.npz", train),
+                         ("ref_modular.npz", modular)):
         f = io.BytesIO()
         np.savez(f, **{k: arrays[k] for k in sorted(arrays)})       # uncompressed + sorted: byte-reproducible
         out[name] = f.getvalue()

@@ -235,3 +235,144 @@ def test_device_context_term_matches_the_reference_function(name):
     err = np.abs((g1 - g0) - g_ref)
     assert err.max() <= 2e-6 + 2e-4 * np.abs(g_ref).max(), (err.max(), np.abs(g_ref).max())
     assert np.abs(g_ref).max() > 1e-3
+
+
+# ---- the reference's PPO update loop on the device (tests/golden/ref_ppo_train.npz) --------------------------------------------------------
+TRAIN_NAMES = ["ppo_discrete6", "ppo_clipvf_klstop", "adap_discrete6", "adap_multi_7_12"]
+
+
+@pytest.mark.parametrize("gemm_mode", [0, 2])
+@pytest.mark.parametrize("name", TRAIN_NAMES)
+def test_device_train_matches_the_reference_train_loop(name, gemm_mode):
+    """`ph_ppo_train` / `ph_adap_train` (through pantheonrl_amd.PPO.train / ADAP.train, both product matrix-product modes) against what the
+    REFERENCE's own ADAP.train text (pantheonrl/algos/adap/adap_learn.py:229-371 -- the in-tree copy of SB3's PPO.train loop -- over
+    AdapPolicy.evaluate_actions, adap/policies.py:97-135) did to the same parameters on the same buffer, index orders and, for the
+    context term, the states and contexts the reference drew.  context_loss_coeff = 0 cases run as PLAIN PPO on the device.
+    Tolerances: parameters 2e-6 per optimizer step + 1e-6 (f32 sums in another order, v_exp / v_rcp tanh and softmax; Adam
+    normalises, so one step moves a parameter by about lr whatever the gradient's scale); logged means 2e-4 + 2e-3 relative;
+    the number of optimizer steps (KL early stop) exact."""
+    from pantheonrl_amd import PPO
+    from pantheonrl_amd import spaces as sp
+    from pantheonrl_amd.adap import ADAP
+    from tests.golden.make_reference_fixtures import TRAIN_CASES
+    c = TRAIN_CASES[name]
+    z = np.load(os.path.join(GOLDEN, "ref_ppo_train.npz"))
+    g = {k[len(name) + 1:]: z[k] for k in z.files if k.startswith(name + ".")}
+    cs, T, E = c["ctx"], c["T"], c["E"]
+    act_space = sp.Discrete(c["nvec"][0]) if len(c["nvec"]) == 1 else sp.MultiDiscrete(list(c["nvec"]))
+    kw = dict(n_steps=T, n_envs=E, batch_size=c["batch"], n_epochs=c["epochs"], learning_rate=c["lr"], clip_range=c["clip"],
+              clip_range_vf=c["clip_vf"], ent_coef=c["ent"], vf_coef=c["vf"], max_grad_norm=c["max_norm"], target_kl=c["target_kl"], seed=0)
+    adap = c["coef"] != 0
+    if adap:    # the environment's observation is the features; the stored rows carry the context behind them (adap_learn.py:448-452)
+        env = type("E", (), dict(observation_space=sp.Box(-np.inf, np.inf, (c["F"],)), action_space=act_space, _is_dummy_space_env=True))()
+        model = ADAP("AdapPolicy", env, context_loss_coeff=c["coef"], context_size=cs, num_context_samples=c["n_ctx"],
+                     num_state_samples=c["n_states"], context_sampler=c["sampler"], **kw)
+    else:
+        env = type("E", (), dict(observation_space=sp.Box(-np.inf, np.inf, (c["F"] + cs,)), action_space=act_space,
+                                 _is_dummy_space_env=True))()
+        model = PPO("MlpPolicy", env, **kw)
+    model.policy.gemm_mode = gemm_mode
+    model.policy.set_flat_params(g["params0"])
+    rb = model.rollout_buffer
+    for k in ("observations", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns"):
+        getattr(rb, k).copy_(th.as_tensor(g[k]))
+    rb.pos, rb.full = rb.buffer_size, True
+    n_mb = -(-T * E // c["batch"])
+    n_seen, n_steps = int(g["n_minibatches_seen"]), int(g["n_steps"])
+    if adap:
+        sidx = np.zeros((c["epochs"] * n_mb, c["n_states"]), np.int32)
+        sidx[:n_seen] = np.where(g["state_idx"] >= 0, g["state_idx"], 0)
+        ctxs = np.zeros((c["epochs"] * n_mb, c["n_ctx"], cs), np.float32)
+        ctxs[:n_seen] = g["contexts"]
+        model.train(perms=g["perms"], state_idx=sidx, contexts=ctxs)
+    else:
+        model.train(perms=g["perms"])
+    st = model.last_train_stats
+    assert int((st[:, 7] > 0).sum()) == n_steps, (st[:, 7], n_steps)                      # optimizer steps applied: exact
+    p = model.policy.get_flat_params()
+    err = np.abs(p - g["params_final"]).max()
+    assert err <= 2e-6 * n_steps + 1e-6, err
+    assert np.abs(g["params_final"] - g["params0"]).max() > 1e-3
+    logged = model.logger.name_to_value
+    keys = ["train/entropy_loss", "train/policy_gradient_loss", "train/value_loss", "train/clip_fraction", "train/approx_kl", "train/loss"]
+    if adap:
+        keys.append("train/context_kl_loss")
+    for k in keys:
+        want = float(g["log." + k])
+        tol = 2e-4 + 2e-3 * abs(want)
+        if k == "train/clip_fraction":                                                    # a count of rows over a threshold: one row may flip
+            tol = 1.0 / c["batch"] / max(n_seen, 1) + 1e-6
+        assert abs(float(logged[k]) - want) <= tol, (k, float(logged[k]), want)
+    assert logged["train/n_updates"] == int(g["log.train/n_updates"])
+
+
+# ---- the reference's ModularPolicy / ModularAlgorithm.train text on the device (tests/golden/ref_modular.npz) ---------------------------------
+MODULAR_NAMES = ["two_partners", "three_partners_klstop", "nomain"]
+
+
+@pytest.mark.parametrize("name", MODULAR_NAMES)
+def test_device_modular_train_matches_the_reference_train_loop(name):
+    """`ph_modular_train` (through pantheonrl_amd.ModularAlgorithm.train) against what the REFERENCE's ModularAlgorithm.train text
+    (pantheonrl/algos/modular/learn.py:221-351) did over its own ModularPolicy text (modular/policies.py:57-395) to the same parameters,
+    per-partner buffers and index orders: how many optimizer steps every partner got (the per-epoch KL rule, exact), the parameters
+    after the last one within 2e-6 per step, the three logged means within 2e-4 + 2e-3 relative."""
+    from pantheonrl_amd import spaces as sp
+    from pantheonrl_amd.modular import ModularAlgorithm
+    from tests.golden.make_reference_fixtures import MODULAR_CASES
+    c = MODULAR_CASES[name]
+    z = np.load(os.path.join(GOLDEN, "ref_modular.npz"))
+    g = {k[len(name) + 1:]: z[k] for k in z.files if k.startswith(name + ".")}
+    K, T, E = c["K"], c["T"], c["E"]
+    env = type("E", (), dict(observation_space=sp.Box(-np.inf, np.inf, (c["D"],)), action_space=sp.Discrete(c["n_act"]),
+                             _is_dummy_space_env=True))()
+    model = ModularAlgorithm("ModularPolicy", env, n_steps=T, n_envs=E, batch_size=c["batch"], n_epochs=c["epochs"], learning_rate=c["lr"],
+                             clip_range=c["clip"], clip_range_vf=c["clip_vf"], ent_coef=c["ent"], vf_coef=c["vf"],
+                             max_grad_norm=c["max_norm"], target_kl=c["target_kl"], seed=0, marginal_reg_coef=c["coef"],
+                             policy_kwargs=dict(num_partners=K, **c["kw"]))
+    assert g["params0"].size == model.policy.P_total
+    model.policy.set_flat_params(g["params0"])
+    for k, rb in enumerate(model.rollout_buffer):
+        for f in ("observations", "actions", "rewards", "episode_starts", "values", "log_probs", "advantages", "returns"):
+            getattr(rb, f).copy_(th.as_tensor(g[f"buf{k}.{f}"]))
+        rb.pos, rb.full = rb.buffer_size, True
+    model.train(perms=g["perms"])
+    n_steps, n_mb = int(g["n_steps"]), -(-T * E // c["batch"])
+    st = model.last_train_stats                                                            # (K, n_epochs * n_mb, 8); rows that ran are non-zero
+    ran = [int((np.abs(st[k]).sum(1) > 0).sum()) for k in range(K)]
+    assert ran == [int((g["step_partner"] == k).sum()) for k in range(K)], (ran, g["step_partner"])
+    assert [r // n_mb for r in ran] == g["epochs_run"].tolist()
+    assert int(model.policy.opt_step.item()) == n_steps
+    err = np.abs(model.policy.get_flat_params() - g["params_final"]).max()
+    assert err <= 2e-6 * n_steps + 1e-6, err
+    logged = model.logger.name_to_value
+    for key in ("train/entropy_loss", "train/policy_gradient_loss", "train/value_loss"):
+        want = float(g["log." + key])
+        assert abs(float(logged[key]) - want) <= 2e-4 + 2e-3 * abs(want), (key, float(logged[key]), want)
+
+
+@pytest.mark.parametrize("name", MODULAR_NAMES)
+def test_device_modular_forward_matches_the_reference_policy_text(name):
+    """`ph_modular_forward` (through ModularPolicy.evaluate_actions / get_action_logits_from_obs on the device) against the reference's
+    ModularPolicy.evaluate_actions -- with and without the action mask of policies.py:330-333 -- and get_action_logits_from_obs on the
+    same parameters and rows: values, log-probabilities, entropies and both logit sets within 2e-5 (the tolerance of the forward
+    tests against the oracle: v_exp / v_rcp tanh and softmax)"""
+    from pantheonrl_amd import spaces as sp
+    from pantheonrl_amd.modular import ModularPolicy
+    from tests.golden.make_reference_fixtures import MODULAR_CASES
+    c = MODULAR_CASES[name]
+    z = np.load(os.path.join(GOLDEN, "ref_modular.npz"))
+    g = {k[len(name) + 1:]: z[k] for k in z.files if k.startswith(name + ".")}
+    pol = ModularPolicy(sp.Box(-np.inf, np.inf, (c["D"],)), sp.Discrete(c["n_act"]), device="cuda", seed=0, num_partners=c["K"], **c["kw"])
+    assert g["params0"].size == pol.P_total
+    pol.set_flat_params(g["params0"])
+    obs, acts, mask = g["fwd.obs"], g["fwd.actions"].astype(np.float32).reshape(-1, 1), g["fwd.mask"]
+    for k in range(c["K"]):
+        v, lp, ent = pol.evaluate_actions(obs, acts, partner_idx=k)
+        vm, lpm, entm = pol.evaluate_actions(obs, acts, partner_idx=k, action_mask=mask)
+        zm, zp = pol.get_action_logits_from_obs(obs, partner_idx=k)
+        for key, val in (("values", v), ("log_prob", lp), ("entropy", ent), ("masked_log_prob", lpm), ("masked_entropy", entm),
+                         ("main_logits", zm), ("partner_logits", zp)):
+            want = g[f"fwd.{key}.{k}"]
+            got = _np(val).reshape(want.shape)
+            assert np.abs(got - want).max() <= 2e-5, (k, key, np.abs(got - want).max())
+        assert np.array_equal(_np(v), _np(vm))                                             # the mask does not touch the value
