@@ -17,6 +17,12 @@ What runs is the reference's source, imported from where it lies (nothing is cop
     pantheonrl/algos/adap/adap_learn.py  ADAP.train (:229-371) -- the in-tree text of SB3's PPO.train() loop (+ the context term): SURVEY.md
                                          section 8 row a8's arithmetic and row f4's ADAP variant
     pantheonrl/algos/adap/policies.py    AdapPolicy.__init__/set_context/get_context/_get_latent/evaluate_actions (:20-135)
+    pantheonrl/algos/modular/policies.py ModularPolicy: constructor defaults, _build, do_init_weights, evaluate_actions, _get_action_dist_from_latent
+                                         (mask offset), get_action_logits_from_obs (:57-395)
+    pantheonrl/algos/modular/learn.py    ModularAlgorithm.train (:221-351)
+    pantheonrl/algos/bc.py               BC.__init__ (optimizer construction), set_expert_data_loader, _calculate_loss, train,
+                                         EpochOrBatchIteratorWithProgress (:67-365); common/util.py FeedForward32Policy (:114-123);
+                                         common/trajsaver.py TransitionsMinimal.__getitem__ / transitions_collate_fn under torch's DataLoader
 
 `pantheonrl/__init__.py` (which registers gym environments) is bypassed by pre-seating an empty package object whose __path__ is the
 reference's directory.  Those files import `gym` and `stable_baselines3`, absent here; they are satisfied by INERT stand-ins for
@@ -49,6 +55,20 @@ four pieces of behaviour, each SB3 1.7.0's published definition restated in one 
     algo.rollout_buffer.get(batch_size)                         env-major flattening + slicing of the per-epoch index orders the TEST provides
                                               (np.random.permutation teacher-forced), yielding RolloutBufferSamples of torch tensors
 
+For ModularPolicy (fixture ref_modular.npz), which BUILDS its network from SB3 classes, those classes are restated (SB3 1.7.0's definitions):
+
+    policies.BasePolicy                       nn.Module keeping the spaces / optimizer class + kwargs; init_weights = orthogonal_(weight, gain) and
+                                              bias 0 for Linear layers; extract_features = features_extractor(obs.float()); device = cpu
+    torch_layers.FlattenExtractor             features_dim = prod(shape), nn.Flatten
+    torch_layers.MlpExtractor                 net_arch [dict(pi=[..], vf=[..])] -> two separate Linear + activation towers, latent_dim_pi / _vf
+    distributions.make_proba_distribution     Discrete(n) -> CategoricalDistribution(n); .proba_distribution_net = nn.Linear(latent, n);
+                                              .proba_distribution(action_logits) = torch Categorical(logits=...)
+    optimizer.zero_grad()                     forwarded as zero_grad(set_to_none=False): the default of the torch the reference pins (setup.py:15)
+
+For BC (fixture ref_bc.npz): utils.get_device -> cpu; the module-level `log` (utils.configure_logger's result) is replaced by a recorder;
+the policy class handed to BC is the TEST's subclass of the reference's FeedForward32Policy over oracle.FeedForward32Oracle (SB3's
+`net_arch=[32, 32]` = a shared 32-32 tanh trunk: the constructor argument the reference's text passes up is recorded and checked).
+
 The scenarios themselves (scripted games, recording partners, the recording model) are tests/refdrive.py -- shared with the tests
 that replay them through pantheonrl_amd.common.
 """
@@ -71,6 +91,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 REFERENCE = os.environ.get("PANTHEON_REFERENCE", "/root/reference")
+os.environ.setdefault("TQDM_DISABLE", "1")      # bc.py's progress bars (read when tqdm is first imported)
 
 from tests import refdrive as rd  # noqa: E402
 
@@ -121,7 +142,7 @@ def _stand_ins() -> dict:
 
     spaces = inert_spaces()
     mods["gym.spaces"] = spaces
-    mod("gym", Env=type("Env", (), {}), spaces=spaces)
+    mod("gym", Env=type("Env", (), {}), spaces=spaces, Space=spaces.Space)
 
     def name_only(n):
         return type(n, (), {})
@@ -144,9 +165,9 @@ def _stand_ins() -> dict:
         def entropy(self):
             return th.stack([d.entropy() for d in self.distribution], dim=1).sum(dim=1)
 
-    class ActorCriticPolicy:                                  # base of AdapPolicy: takes (and ignores) its constructor's keyword arguments
-        def __init__(self, *args, **kwargs):
-            pass
+    class ActorCriticPolicy:                                  # base of AdapPolicy / FeedForward32Policy: takes its constructor's arguments
+        def __init__(self, *args, **kwargs):                  # and only KEEPS them (what the subclass's text handed up is checked by tests)
+            self.init_args, self.init_kwargs = args, kwargs
 
     # -- ModularPolicy (modular/policies.py) BUILDS its network from SB3 classes: each restated below in its SB3 1.7.0 definition --
     def _categorical_init(self, arg=None):                    # CategoricalDistribution(action_dim) | the holder form used above
@@ -216,7 +237,8 @@ def _stand_ins() -> dict:
                 configure_logger=lambda *a, **k: None,
                 safe_mean=lambda arr: {"safe_mean_of": rd.plain(list(arr))},
                 obs_as_tensor=lambda obs, device: th.as_tensor(obs).to(device),
-                should_collect_more_steps=None, get_schedule_fn=None, get_device=None, is_vectorized_observation=None,
+                should_collect_more_steps=None, get_schedule_fn=None, get_device=lambda device="auto": th.device("cpu"),
+                is_vectorized_observation=None,
                 explained_variance=lambda y_pred, y_true: {"explained_variance_of": [list(np.shape(y_pred)), list(np.shape(y_true))]})
     policies = mod("stable_baselines3.common.policies", ActorCriticPolicy=ActorCriticPolicy, BasePolicy=BasePolicy)
     onp = mod("stable_baselines3.common.on_policy_algorithm", OnPolicyAlgorithm=name_only("OnPolicyAlgorithm"))
@@ -251,7 +273,8 @@ class ReferenceModules:
     """context manager: the reference's modules importable under `pantheonrl.*`, sys.modules restored afterwards"""
 
     NAMES = ("common.observation", "common.util", "common.trajsaver", "common.agents", "common.multiagentenv", "common.wrappers",
-             "algos.adap.util", "algos.adap.policies", "algos.adap.adap_learn", "algos.modular.policies", "algos.modular.learn")
+             "algos.adap.util", "algos.adap.policies", "algos.adap.adap_learn", "algos.modular.policies", "algos.modular.learn",
+             "algos.bc")
 
     def __enter__(self):
         self._stand = _stand_ins()
@@ -717,6 +740,80 @@ def modular_reference_run(ref: "ReferenceModules", c: dict) -> dict:
         out["log." + key] = np.float64(val)
     return out
 
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (viii) the reference's BC TEXT (pantheonrl/algos/bc.py): constructor (Adam with torch's defaults), the DataLoader over its
+#        TransitionsMinimal, _calculate_loss, train -- on a network the TEST provides
+# ---------------------------------------------------------------------------------------------------------------------------
+BC_CASES = {"discrete6": dict(D=20, nvec=(6,), N=100, epochs=3, ent=1e-3, l2=0.0, seed=41),
+            "l2_ragged": dict(D=9, nvec=(5,), N=77, epochs=2, ent=1e-2, l2=1e-3, seed=42)}
+
+
+def bc_case_inputs(c: dict):
+    from oracle import sb3_oracle as orc
+    th.manual_seed(c["seed"])
+    net = orc.FeedForward32Oracle(orc.SpaceSpec("box", dim=c["D"]), orc.SpaceSpec("discrete", nvec=c["nvec"]))
+    g = th.Generator().manual_seed(c["seed"] + 1)
+    with th.no_grad():
+        for p in net.parameters():
+            p.add_(0.2 * th.randn(p.shape, generator=g) * (1.0 if p.ndim == 1 else 0.3))
+    rng = np.random.default_rng(c["seed"])
+    obs = rng.standard_normal((c["N"], c["D"])).astype(np.float32)
+    acts = rng.integers(0, c["nvec"][0], c["N"]).astype(np.float32)
+    return net, net.flat_params(), obs, acts
+
+
+def bc_reference_run(ref: "ReferenceModules", c: dict) -> dict:
+    bc_mod, util_mod, traj_mod = ref.m["algos.bc"], ref.m["common.util"], ref.m["common.trajsaver"]
+    net, flat, obs, acts = bc_case_inputs(c)
+    seen = {"batches": []}
+
+    class Policy(util_mod.FeedForward32Policy):             # the reference's class text; the layers are the test's
+        def to(self, device):
+            return self
+
+        def parameters(self):
+            return net.parameters()
+
+        def evaluate_actions(self, o, a):
+            rows = [int(np.nonzero((obs == r).all(axis=1))[0][0]) for r in o.numpy()]
+            assert np.array_equal(acts[rows], a.numpy().reshape(-1))
+            seen["batches"].append(rows)
+            return net.evaluate_actions(o, a)
+
+    class Recorder:
+        def __init__(self):
+            self.kv, self.dumps = {}, []
+
+        def record(self, k, v):
+            self.kv[k] = v
+
+        def dump(self, step):
+            self.dumps.append((step, dict(self.kv)))
+            self.kv = {}
+
+    bc_mod.log = Recorder()
+    spaces = ref.spaces
+    th.manual_seed(2000 + c["seed"])                          # the DataLoader's shuffles
+    clone = bc_mod.BC(spaces.Box(-np.inf, np.inf, (c["D"],)), spaces.Discrete(c["nvec"][0]), policy_class=Policy,
+                      expert_data=traj_mod.TransitionsMinimal(obs.copy(), acts.copy()), ent_weight=c["ent"], l2_weight=c["l2"])
+    assert isinstance(clone.expert_data_loader, th.utils.data.DataLoader) and clone.expert_data_loader.batch_size == 32
+    import contextlib
+    with contextlib.redirect_stderr(io.StringIO()):           # (tqdm's progress bars)
+        clone.train(n_epochs=c["epochs"], log_interval=1)    # <- the reference's text
+    n_b = -(-c["N"] // 32)
+    assert len(seen["batches"]) == c["epochs"] * n_b == len(bc_mod.log.dumps)
+    orders = np.asarray([sum(seen["batches"][e * n_b:(e + 1) * n_b], []) for e in range(c["epochs"])], np.int64)
+    assert all(sorted(o.tolist()) == list(range(c["N"])) for o in orders)
+    keys = ("neglogp", "entropy", "ent_loss", "prob_true_act", "l2_norm", "l2_loss", "loss")
+    stats = np.asarray([[d[k] for k in keys] for _, d in bc_mod.log.dumps], np.float64)
+    progress = np.asarray([[d["epoch_num"], d["batch_num"], d["samples_so_far"]] for _, d in bc_mod.log.dumps], np.int64)
+    dflt = clone.optimizer.defaults
+    return {"params0": flat, "obs": obs, "acts": acts, "orders": orders, "stats": stats, "progress": progress,
+            "params_final": net.flat_params(), "adam": np.asarray([dflt["lr"], dflt["betas"][0], dflt["betas"][1], dflt["eps"],
+                                                                    dflt["weight_decay"]], np.float64),
+            "net_arch": np.asarray(clone.policy.init_kwargs["net_arch"], np.int64)}
+
 # ---------------------------------------------------------------------------------------------------------------------------
 def generate() -> dict:
     """-> {file name: bytes} of every reference-generated fixture"""
@@ -748,11 +845,15 @@ def generate() -> dict:
         for name, c in MODULAR_CASES.items():
             for k, v in modular_reference_run(ref, c).items():
                 modular[f"{name}.{k}"] = np.asarray(v)
+        bc = {}
+        for name, c in BC_CASES.items():
+            for k, v in bc_reference_run(ref, c).items():
+                bc[f"{name}.{k}"] = np.asarray(v)
     out = {}
     for name, obj in files.items():
         out[name] = (json.dumps(obj, indent=None, separators=(",", ":"), sort_keys=True) + "\n").encode()
     for name, arrays in (("ref_transitions.npz", npy), ("ref_adap_context.npz", adap), ("ref_ppo_train.npz", train),
-                         ("ref_modular.npz", modular)):
+                         ("ref_modular.npz", modular), ("ref_bc.npz", bc)):
         f = io.BytesIO()
         np.savez(f, **{k: arrays[k] for k in sorted(arrays)})       # uncompressed + sorted: byte-reproducible
         out[name] = f.getvalue()

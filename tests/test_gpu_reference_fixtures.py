@@ -376,3 +376,31 @@ def test_device_modular_forward_matches_the_reference_policy_text(name):
             got = _np(val).reshape(want.shape)
             assert np.abs(got - want).max() <= 2e-5, (k, key, np.abs(got - want).max())
         assert np.array_equal(_np(v), _np(vm))                                             # the mask does not touch the value
+
+
+# ---- the reference's BC text on the device (tests/golden/ref_bc.npz) -------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["discrete6", "l2_ragged"])
+def test_device_bc_train_matches_the_reference_bc_text(name):
+    """`ph_bc_train` (through pantheonrl_amd.bc.BC.train) against what the REFERENCE's BC.train / _calculate_loss text (pantheonrl/algos/
+    bc.py:270-353) did over torch's DataLoader in the batch order it drew: every batch's seven statistics within 2e-5 + 2e-4 relative.
+    Parameters: Adam with torch's defaults (lr 1e-3, eps 1e-8 -- what the reference's constructor builds) moves an entry by ~lr per
+    step whatever its gradient, so f32 noise in a near-zero gradient entry can flip that entry's step: median |d| <= 2e-6, at most 1 %
+    of the entries beyond 1e-4, none beyond 2.5 steps (the bound of tests/test_gpu_bc.py against the oracle)."""
+    from pantheonrl_amd import spaces as sp
+    from pantheonrl_amd.bc import BC
+    from pantheonrl_amd.common import TransitionsMinimal
+    from tests.golden.make_reference_fixtures import BC_CASES
+    c = BC_CASES[name]
+    z = np.load(os.path.join(GOLDEN, "ref_bc.npz"))
+    g = {k[len(name) + 1:]: z[k] for k in z.files if k.startswith(name + ".")}
+    clone = BC(sp.Box(-np.inf, np.inf, (c["D"],)), sp.Discrete(c["nvec"][0]), expert_data=TransitionsMinimal(g["obs"], g["acts"]),
+               ent_weight=c["ent"], l2_weight=c["l2"])
+    clone.policy.set_flat_params(g["params0"])
+    st = clone.train(n_epochs=c["epochs"], orders=g["orders"])
+    assert st.shape[0] == len(g["stats"]) and int(clone.opt_step.item()) == len(g["stats"])
+    for i in range(len(g["stats"])):
+        for j, k in enumerate(("neglogp", "entropy", "ent_loss", "prob_true_act", "l2_norm", "l2_loss", "loss")):
+            want = g["stats"][i, j]
+            assert abs(st[i, j] - want) <= 2e-5 + 2e-4 * abs(want), (i, k, st[i, j], want)
+    d = np.abs(clone.policy.get_flat_params() - g["params_final"])
+    assert np.median(d) <= 2e-6 and d.max() <= 2.5e-3 and (d > 1e-4).mean() <= 0.01, (np.median(d), d.max(), (d > 1e-4).mean())
