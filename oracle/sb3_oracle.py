@@ -12,9 +12,19 @@ forward / evaluate_actions and ``PPO.train()``, plus PantheonRL's own ADAP conte
 term (``pantheonrl/algos/adap/util.py:97-131``, whose module imports gym / SB3) and -- ahead of any device path --
 ``ModularPolicy`` / ``ModularAlgorithm.train`` (``pantheonrl/algos/modular``).
 
-PARITY UNPINNED.  stable-baselines3 is not vendored under /root/reference and
-is not installed in this image, and the reference has no tests or golden
-vectors.  The restatement therefore follows
+PARITY UNPINNED FOR THE SB3 CLASSES (RolloutBuffer incl. GAE, the plain
+ActorCriticPolicy assembly, the distribution wrappers, collect_rollouts):
+stable-baselines3 is not vendored under /root/reference and is not installed in
+this image, and the reference has no tests or golden vectors (SURVEY.md section
+4, 8c).  PINNED to the reference's own executable text, through fixtures that
+tests/golden/make_reference_fixtures.py generates by RUNNING that text from
+/root/reference (tests/test_reference_fixtures.py compares this module with them
+to 1e-6): ``ppo_train`` / ``ppo_minibatch_loss`` / ``AdapTerm`` against ADAP.train
+(adap_learn.py:229-371, the in-tree copy of SB3's PPO.train loop) over
+AdapPolicy.evaluate_actions; ``adap_context_loss`` and the samplers against
+adap/util.py; ``ModularPolicyOracle`` / ``modular_train`` against ModularPolicy /
+ModularAlgorithm.train (incl. init gains, Adam eps, the mask offset);
+``bc_loss`` / ``bc_train`` against pantheonrl/algos/bc.py.  The restatement follows
 
 * the in-tree copies of the SB3 code that PantheonRL carries:
   ``pantheonrl/algos/adap/adap_learn.py:229-371`` (PPO.train),

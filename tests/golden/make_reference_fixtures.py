@@ -1,9 +1,10 @@
-"""Pins the host-side rows of the hot path to the REFERENCE's own Python text.
+"""Pins the host-side rows of the hot path AND the update loops (a7, a8, f4: ADAP.train = SB3's
+PPO.train loop, ModularAlgorithm.train, BC.train, with their policies' text) to the REFERENCE's own Python text.
 Build container only: `/root/reference` never travels, the fixtures this script writes do.
 
     python tests/golden/make_reference_fixtures.py            # regenerate in memory, compare byte for byte with the committed files
     python tests/golden/make_reference_fixtures.py --write    # (re)write tests/golden/ref_*.json, ref_transitions.npz, ref_adap_context.npz,
-                                                              # ref_ppo_train.npz
+                                                              # ref_ppo_train.npz, ref_modular.npz, ref_bc.npz
 
 What runs is the reference's source, imported from where it lies (nothing is copied into this repository):
 
