@@ -269,8 +269,13 @@ __device__ __forceinline__ float quad_sum_f(float v) {
 // W2[g + 4s][16 wave + c] and, in wave 0, the head's weights [g + 4s][c] -- do not depend on the step: they are fetched from the
 // parameters once per launch into 48 registers (the scripted rollouts keep them for all n_steps steps: 32 LDS reads per layer and
 // step gone; the single-step launch loses the 33 KB weight staging that was 40 % of its time).  The head is a third 16x16x4 MFMA
-// product (wave 0: z = H2 act_W, or H2 val_W in column 0) instead of 128 FMAs per lane over LDS-resident weights; its 16 x 8
-// result goes through 512 bytes of LDS so that lane r < 16 owns row r for the distribution tail.
+// product (z = H2 act_W, or H2 val_W in column 0) instead of 128 FMAs per lane over LDS-resident weights.  Round 6, fourth session:
+// it is split over the four waves' K quarters (wave w: units 16 w .. 16 w + 15, four MFMAs) instead of running as a sixteen-deep
+// chain in wave 0 beside three waiting waves; the four 16 x 8 partial tiles go through 2 KB of LDS and lane r < 16 of wave 0 adds
+// them in one fixed order, (p0 + p1) + (p2 + p3), and owns row r for the distribution tail.  The head phase's barrier is also the
+// point behind which nobody reads H2, so the barrier at the top of the next step is gone.  Every form of the kernel (per step,
+// one launch, exchange; MFMA and VALU cross-check) shares the code, so they stay bitwise one another; per-step launches gain most
+// (twelve fewer weight registers to fetch per launch as well): stepwise 92.9 -> 99.9 M agent-steps/s (profiles/r06_bd_*).
 // LEAN: the launch was checked (fwd_args_lean) to use none of the optional paths of the argument record -- no masks, no teacher-forced
 // uniforms or actions, no logits / entropy / float-action outputs, a rectangular buffer with the fused add, no joint-action reward, no
 // host doorbell, no debug stamps.  The copy of the record the body works on then carries those fields as CONSTANTS: every
@@ -321,6 +326,13 @@ bool fwd_args_lean(const FwdArgs& a, bool joint_ok = false) {
          a.rb_es && a.rb_val && a.rb_logp && a.es_in;
 }
 
+// The head product of the 16-row forward split over the four waves' K quarters (1) or as one sixteen-MFMA chain in wave 0 (0: the
+// form up to round 6's third session; A/B switch, scripts/build_variants.sh)
+#ifndef PH_FWD16_HEAD_KSPLIT
+#define PH_FWD16_HEAD_KSPLIT 1
+#endif
+constexpr int ZS_FLOATS = (PH_FWD16_HEAD_KSPLIT ? 4 : 1) * 16 * 8;   // the head's output tile(s) in LDS
+
 template <bool VALU, int LEAN = 0>
 __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2p* px = nullptr, int px_t = 0, int px_a_local = 0,
                                                   int agent = 0, const ScriptedSteps* sc = nullptr, int px_persistent = 0) {
@@ -337,8 +349,9 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
 #endif
   float* xs = smem;                 // [16][LDH]  X, later H2
   float* hs = xs + R * LDH;         // [16][LDH]  H1
-  float* zs = hs + R * LDH;         // [16][8]    head output incl. bias: policy logits | value in column 0
-  int* rowphys = (int*)(zs + R * 8);      // [16]
+  float* zs = hs + R * LDH;         // [4][16][8] head output, one partial per wave (its quarter of the units; wave 0's carries the bias):
+                                    //            policy logits | value in column 0
+  int* rowphys = (int*)(zs + ZS_FLOATS);  // [16]
   float* upre = (float*)(rowphys + 16);   // [2][16] sampling uniforms of the rows, drawn a step ahead (scripted rollouts)
   unsigned long long** pxll = (unsigned long long**)(upre + 32);   // [PH_MAX_RANKS] every rank's receive area (exchange forms)
 
@@ -372,15 +385,27 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
 #define pxslots (PXH ? pxslots_h : px->ll_slots)
 #define ll_self (PXH ? ll_self_h : px->ll[px->rank])
 #define PXLL(p) (PXH ? pxll[p] : px->ll[p])
-  float bw1[16], bw2[16], bwh[16];   // B operands: element [g + 4s][this lane's column] of W1, W2 and the head
+  // B operands: element [g + 4s][this lane's column] of W1 and W2; of the head, the K quarter of this wave (PH_FWD16_HEAD_KSPLIT):
+  // units 16 wave + g + 4j, j < 4 -- the head product is then four MFMAs in every wave instead of sixteen in wave 0 with three
+  // waves waiting, its partial tiles meet in LDS (zs) and are added in ONE fixed order by the row's lane
+#if PH_FWD16_HEAD_KSPLIT
+  constexpr int NBH = 4;
+#else
+  constexpr int NBH = 16;
+#endif
+  float bw1[16], bw2[16], bwh[NBH];
   const int col = 16 * wave + c;
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
     const int k = g + 4 * s;
     bw1[s] = (k < nd.F) ? W1[k * HID + col] : 0.f;
     bw2[s] = W2[k * HID + col];
+  }
+#pragma unroll
+  for (int s = 0; s < NBH; ++s) {
+    const int k = g + 4 * (PH_FWD16_HEAD_KSPLIT ? 4 * wave + s : s);
     bwh[s] = 0.f;
-    if (wave == 0) {
+    if (PH_FWD16_HEAD_KSPLIT || wave == 0) {
       if (net == 0) {
         if (c < nk) bwh[s] = a.params[lay.act_W + k * nk + c];
       } else if (c == 0) {
@@ -473,7 +498,9 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
       a.ll_t = t - 1;
     }
     a.prof = nullptr;
+#if !PH_FWD16_HEAD_KSPLIT
     lds_only_barrier();   // the previous step's head is done with xs (H2)
+#endif                    // (K-split head: every wave read its part of H2 before the head phase's own barrier)
     xr.issue(rowphys, a.obs, nd, 0);
     xr.commit(xs, rowphys, a.obs, nd, 0);
     vm_drain();   // the rows are in (the commit waited for them): say so, or the observation copy at the end of the step waits
@@ -506,7 +533,50 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
   PH_STAMP(a.prof, 5);
   PH_STAMP(pstep, 11);
 
-  // ---- head: wave 0, a third product (columns = logits, or the value in column 0); the other waves copy observations ----
+  // ---- head: a third product (columns = logits, or the value in column 0) ----
+#if PH_FWD16_HEAD_KSPLIT
+  {   // every wave: its K quarter (four MFMAs, two chains), the partial tile to zs[wave]; wave 0's partial carries the bias
+    if (wave == 0 && pre_ok) value_row_preload_words(a, row0 + lane, vpre);   // (exchange rollouts: the joint action's words, under the product)
+    const float* ap = xs + c * LDH + g + 16 * wave;
+    float av[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) av[j] = ap[4 * j];
+    f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+    e = mma16<VALU>(av[0], bwh[0], e, lane);
+    o = mma16<VALU>(av[1], bwh[1], o, lane);
+    e = mma16<VALU>(av[2], bwh[2], e, lane);
+    o = mma16<VALU>(av[3], bwh[3], o, lane);
+    const f32x4 zh = e + o;
+    if (c < 8) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zs[(wave * R + 4 * g + r) * 8 + c] = zh[r] + hbias;   // (hbias is 0 outside wave 0)
+    }
+  }
+  lds_only_barrier();   // the four partial tiles are in; nobody reads xs (H2) behind this point
+  PH_STAMP(pstep, 12);
+  if (wave == 0) {
+    PH_STAMP(pstep, 13);
+    const int r = lane, grow = row0 + lane;   // lane r < 16 owns row r
+    if (r < R && grow < a.n) {
+      // the row's logits: (partial 0 + partial 1) + (partial 2 + partial 3), the same tree in every form of this kernel
+      float z[8];
+      {
+        float4 q[4][2];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          q[w][0] = *reinterpret_cast<const float4*>(zs + (w * R + r) * 8);
+          q[w][1] = *reinterpret_cast<const float4*>(zs + (w * R + r) * 8 + 4);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          z[4 * h + 0] = (q[0][h].x + q[1][h].x) + (q[2][h].x + q[3][h].x);
+          z[4 * h + 1] = (q[0][h].y + q[1][h].y) + (q[2][h].y + q[3][h].y);
+          z[4 * h + 2] = (q[0][h].z + q[1][h].z) + (q[2][h].z + q[3][h].z);
+          z[4 * h + 3] = (q[0][h].w + q[1][h].w) + (q[2][h].w + q[3][h].w);
+        }
+      }
+      if (net == 0) {
+#else
   if (wave == 0) {
     if (pre_ok) value_row_preload_words(a, row0 + lane, vpre);   // (exchange rollouts: the joint action's words, under the head product)
     const f32x4 zh = product(xs, bwh);
@@ -524,6 +594,7 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
       if (net == 0) {
         const float4 z0 = *reinterpret_cast<const float4*>(zs + r * 8), z1 = *reinterpret_cast<const float4*>(zs + r * 8 + 4);
         float z[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+#endif
         const float* up = draw_ahead ? upre + (t & 1) * R + r : nullptr;
         const uint64_t ctr = fwd_counter(a);
         int act;
@@ -547,7 +618,11 @@ __device__ __forceinline__ void policy_fwd16_body(const FwdArgs& a0, const ph_p2
             __hip_atomic_store(PXLL(p) + off, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       } else {
+#if PH_FWD16_HEAD_KSPLIT
+        const float v = z[0];
+#else
         const float v = zs[r * 8];
+#endif
         value_row_tail(a, grow, v, pre_ok, vpre);
         // (scripted rollout) the last step's own reward: the flush that precedes GAE on the launch-by-launch path
         if (sc && t == n_steps - 1) {
@@ -638,7 +713,7 @@ static int current_device_slot() {
   return (dev >= 0 && dev < 64) ? dev : 0;
 }
 
-static size_t fwd16_lds_bytes() { return sizeof(float) * (size_t)(2 * 16 * LDH + 16 * 8 + 16 + 32) + sizeof(void*) * PH_MAX_RANKS; }
+static size_t fwd16_lds_bytes() { return sizeof(float) * (size_t)(2 * 16 * LDH + ZS_FLOATS + 16 + 32) + sizeof(void*) * PH_MAX_RANKS; }
 
 bool fwd16_eligible(const NetDims& nd, int n) {
   static int enabled = -1;
