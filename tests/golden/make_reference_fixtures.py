@@ -27,7 +27,8 @@ What runs is the reference's source, imported from where it lies (nothing is cop
 
 `pantheonrl/__init__.py` (which registers gym environments) is bypassed by pre-seating an empty package object whose __path__ is the
 reference's directory.  Those files import `gym` and `stable_baselines3`, absent here; they are satisfied by INERT stand-ins for
-exactly the names imported, none of which contributes a rule or arithmetic to what is recorded:
+exactly the names imported.  For the host-side rows (fixtures ref_*.json, ref_transitions.npz, ref_adap_context.npz) none of them
+contributes a rule or arithmetic to what is recorded:
 
     gym.Env                                   empty base class
     gym.spaces.{Space,Box,Discrete,MultiBinary,MultiDiscrete}   holders of .low/.high/.shape/.dtype/.n/.nvec (constructor arguments kept)
@@ -44,9 +45,10 @@ exactly the names imported, none of which contributes a rule or arithmetic to wh
 For ADAP.train / AdapPolicy (fixture ref_ppo_train.npz) additionally -- names for imports, annotations and base classes, plus exactly
 four pieces of behaviour, each SB3 1.7.0's published definition restated in one line and listed here because it is NOT the reference's text:
 
-    stable_baselines3.common.{type_aliases,vec_env,callbacks,torch_layers}, buffers.RolloutBuffer, utils.{get_schedule_fn,get_device}
-                                              NAMES only (never called by train / evaluate_actions)
-    stable_baselines3.common.policies.ActorCriticPolicy        base class whose __init__ accepts and ignores AdapPolicy's keyword arguments;
+    stable_baselines3.common.{type_aliases,vec_env,callbacks,torch_layers,preprocessing,logger}, stable_baselines3.PPO, gym.Space,
+    buffers.RolloutBuffer, utils.{get_schedule_fn,is_vectorized_observation}, distributions.{DiagGaussian,Bernoulli,StateDependentNoise}Distribution
+                                              NAMES only (imports, annotations, isinstance checks that are false here; never called)
+    stable_baselines3.common.policies.ActorCriticPolicy        base class whose __init__ only KEEPS the arguments the subclass's text hands up;
                                               the network (MlpExtractor 64-64 tanh, action_net, value_net, Adam(eps=1e-5)) is the TEST's
                                               torch module (oracle.MlpPolicyOracle), attached by the test's subclass
     stable_baselines3.common.utils.explained_variance          returns {"explained_variance_of": shapes}: logged only, arithmetic NOT done here
