@@ -37,7 +37,10 @@ class EnvException(Exception):
 
 
 def input_check(args) -> None:
-    """reject combinations the engine cannot honour, with the reference's error class (trainer.py:41-63)"""
+    """reject combinations the engine cannot honour, with the reference's error class, and complete the configs the way the
+    reference's does (trainer.py:41-63: one `{}` per partner when no --alt-config was given, `verbose = 1` for the ego unless its
+    config says otherwise, --tensorboard-log and --tensorboard-name together or not at all).  --share-latent's check is the caller's
+    next step, as in the reference's main (trainer.py:399-403); pinned to the reference's text by tests/golden/ref_trainer_cli.json"""
     if args.env not in _envs.REGISTRY:
         raise EnvException(f"unknown or out-of-scope environment {args.env!r}; available: {sorted(_envs.REGISTRY)}")
     for name in [args.ego] + list(args.alt):
@@ -48,10 +51,14 @@ def input_check(args) -> None:
     for name in args.alt:
         if name not in PARTNER_LIST:
             raise EnvException(f"partners must be among {PARTNER_LIST}")
-    if len(args.alt_config) != len(args.alt):
-        raise EnvException("number of partners is different from number of --alt-config")
-    if args.share_latent:
-        latent_check(args)
+    if args.alt_config is None:                         # trainer.py:50-52
+        args.alt_config = [{} for _ in args.alt]
+    elif len(args.alt_config) != len(args.alt):
+        raise EnvException("Number of partners is different from number of configs")
+    if "verbose" not in args.ego_config:                # trainer.py:57-59
+        args.ego_config["verbose"] = 1
+    if (args.tensorboard_log is not None) != (args.tensorboard_name is not None):       # trainer.py:61-63
+        raise EnvException("Must define log and names for tensorboard")
     if args.framestack > 1 and args.env_config.get("framestack_incompatible", False):
         raise EnvException("this environment cannot be frame-stacked")
 
@@ -193,16 +200,17 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("ego", help="algorithm of the ego agent")
     p.add_argument("alt", nargs="+", help="algorithm(s) of the partner agent(s)")
     p.add_argument("--total-timesteps", "-t", type=int, default=500000)
-    p.add_argument("--device", "-d", default="cuda")
+    p.add_argument("--device", "-d", default="auto")     # (the reference's default; the engine takes it as "cuda": there is no other device)
     p.add_argument("--seed", "-s", type=int)
     p.add_argument("--ego-config", type=json.loads, default={})
-    p.add_argument("--alt-config", type=json.loads, action="append")
+    # the reference's form is ONE flag with a JSON string per partner (nargs='*', trainer.py:356-359); repeating the flag works as well
+    p.add_argument("--alt-config", type=json.loads, nargs="*", action="extend")
     p.add_argument("--env-config", type=json.loads, default={})
     p.add_argument("--framestack", "-f", type=int, default=1)
     p.add_argument("--record", "-r")
     p.add_argument("--ego-save")
     p.add_argument("--alt-save")
-    p.add_argument("--share-latent", action="store_true")
+    p.add_argument("--share-latent", "-l", action="store_true")
     p.add_argument("--tensorboard-log")
     p.add_argument("--tensorboard-name")
     p.add_argument("--verbose-partner", action="store_true")
@@ -275,14 +283,22 @@ def run_vectorised(args):
     return models[0], [alt], env
 
 
-def run(argv=None):
-    """parse, build the graph, learn, save -- returns (ego, partners, env) for callers and tests"""
+def parse_cli(argv=None):
+    """argv -> the checked and completed arguments, in the order of the reference's main (trainer.py:395-403): parse, preset,
+    input_check, latent_check when --share-latent"""
     args = build_parser().parse_args(argv)
-    if args.alt_config is None:
-        args.alt_config = [{} for _ in args.alt]
-    input_check(args)
+    args.ego_config, args.env_config = dict(args.ego_config), dict(args.env_config)     # (argparse hands out its default objects)
     if args.preset:
         args = preset(args, args.preset)
+    input_check(args)
+    if args.share_latent:
+        latent_check(args)
+    return args
+
+
+def run(argv=None):
+    """parse, build the graph, learn, save -- returns (ego, partners, env) for callers and tests"""
+    args = parse_cli(argv)
     print(f"Arguments: {args}")
     if args.n_envs > 1:
         return run_vectorised(args)

@@ -21,6 +21,8 @@ What runs is the reference's source, imported from where it lies (nothing is cop
     pantheonrl/algos/modular/policies.py ModularPolicy: constructor defaults, _build, do_init_weights, evaluate_actions, _get_action_dist_from_latent
                                          (mask offset), get_action_logits_from_obs (:57-395)
     pantheonrl/algos/modular/learn.py    ModularAlgorithm.train (:221-351)
+    trainer.py (as __main__)             argument parser, preset, input_check, latent_check; generate_env / generate_ego / gen_partner /
+                                         generate_partners and the learn / record / save tail on recording doubles (:41-432)
     pantheonrl/algos/bc.py               BC.__init__ (optimizer construction), set_expert_data_loader, _calculate_loss, train,
                                          EpochOrBatchIteratorWithProgress (:67-365); common/util.py FeedForward32Policy (:114-123);
                                          common/trajsaver.py TransitionsMinimal.__getitem__ / transitions_collate_fn under torch's DataLoader
@@ -817,6 +819,203 @@ def bc_reference_run(ref: "ReferenceModules", c: dict) -> dict:
                                                                     dflt["weight_decay"]], np.float64),
             "net_arch": np.asarray(clone.policy.init_kwargs["net_arch"], np.int64)}
 
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (ix) the reference's trainer.py TEXT as a script: the argument parser, preset, input_check, latent_check (trainer.py:41-89,231-405)
+#      -- run as __main__ on an argv list, stopped where it would build the environment (gym.make is a stand-in that stops the run)
+# ---------------------------------------------------------------------------------------------------------------------------
+TRAINER_ARGVS = {
+    "rps_ppo_ppo": ["RPS-v0", "PPO", "PPO"],
+    "rps_seed_steps": ["RPS-v0", "PPO", "PPO", "-s", "7", "-t", "10000"],
+    "preset1": ["RPS-v0", "PPO", "PPO", "--preset", "1", "--seed", "0", "-t", "10000"],
+    "preset1_keeps_given_names": ["LiarsDice-v0", "PPO", "DEFAULT", "--preset", "1", "--seed", "3", "--ego-save", "mine", "--tensorboard-log", "tb",
+                                  "--tensorboard-name", "run"],
+    "liar_default_partner": ["LiarsDice-v0", "PPO", "DEFAULT", "--env-config", '{"probegostart": 0.3}'],
+    "rps_default_with_config": ["RPS-v0", "PPO", "DEFAULT", "--alt-config", '{"r": 2, "p": 1, "s": 1}'],
+    "two_partners_one_flag": ["RPS-v0", "ModularAlgorithm", "PPO", "PPO", "--alt-config", '{"n_steps": 64}', '{"n_steps": 32}',
+                              "--ego-config", '{"n_steps": 64, "marginal_reg_coef": 0.5}'],
+    "three_kinds_of_partner": ["RPS-v0", "PPO", "PPO", "DEFAULT", "FIXED", "--alt-config", "{}", '{"r": 1}',
+                               '{"type": "PPO", "location": "models/old"}'],
+    "adap_shared_latent_short_flag": ["RPS-v0", "ADAP", "ADAP", "-l"],
+    "adap_mult_shared_latent_configs": ["RPS-v0", "ADAP_MULT", "ADAP", "ADAP_MULT", "--share-latent", "--ego-config",
+                                        '{"context_size": 4, "context_sampler": "unit_square"}', "--alt-config", "{}", '{"context_size": 4}'],
+    "adap_not_shared": ["LiarsDice-v0", "ADAP", "PPO"],
+    "load_ego": ["RPS-v0", "LOAD", "PPO", "--ego-config", '{"type": "PPO", "location": "models/ego"}'],
+    "framestack_record": ["LiarsDice-v0", "PPO", "PPO", "-f", "3", "-r", "trajs/x"],
+    "tensorboard_both_verbose_partner": ["RPS-v0", "PPO", "PPO", "--tensorboard-log", "logs", "--tensorboard-name", "n", "--verbose-partner"],
+    "ego_verbose_given": ["RPS-v0", "PPO", "PPO", "--ego-config", '{"verbose": 0}', "-d", "cuda"],
+    "saves": ["RPS-v0", "PPO", "PPO", "--ego-save", "m/e", "--alt-save", "m/a"],
+    # rejected
+    "bad_tensorboard_log_only": ["RPS-v0", "PPO", "PPO", "--tensorboard-log", "logs"],
+    "bad_tensorboard_name_only": ["RPS-v0", "PPO", "PPO", "--tensorboard-name", "n"],
+    "bad_config_count": ["RPS-v0", "PPO", "PPO", "--alt-config", "{}", "{}"],
+    "bad_share_latent_ppo_partner": ["RPS-v0", "ADAP", "PPO", "-l"],
+    "bad_share_latent_ppo_ego": ["RPS-v0", "PPO", "ADAP", "--share-latent"],
+    "bad_share_latent_context_size": ["RPS-v0", "ADAP", "ADAP", "-l", "--alt-config", '{"context_size": 2}'],
+    "bad_share_latent_sampler": ["RPS-v0", "ADAP", "ADAP", "-l", "--alt-config", '{"context_sampler": "categorical"}'],
+    "bad_ego_choice": ["RPS-v0", "SAC", "PPO"],
+    "bad_partner_choice": ["RPS-v0", "PPO", "LOAD"],
+    "bad_env_choice": ["Pong-v0", "PPO", "PPO"],
+    "bad_overcooked_without_layout": ["OvercookedMultiEnv-v0", "PPO", "PPO"],
+    "bad_overcooked_layout": ["OvercookedMultiEnv-v0", "PPO", "PPO", "--env-config", '{"layout_name": "nowhere"}'],
+}
+
+
+def trainer_cli_reference_run() -> dict:
+    """{case: {"args": vars(args) where the script would call gym.make} | {"rejected": exception class name}}"""
+    import contextlib
+    path = os.path.join(REFERENCE, "trainer.py")
+    with open(path) as fh:
+        code = compile(fh.read(), path, "exec")             # executed from where it lies; nothing of it is kept
+
+    class StopBeforeTheEnvironment(Exception):
+        pass
+
+    def stop(*a, **k):
+        raise StopBeforeTheEnvironment()
+
+    def names(modname, *ns, **attrs):
+        m = types.ModuleType(modname)
+        for n in ns:
+            setattr(m, n, type(n, (), {}))
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+    extra = {
+        "stable_baselines3.common.monitor": names("stable_baselines3.common.monitor", "Monitor"),
+        "pantheonrl.envs": names("pantheonrl.envs"),
+        "pantheonrl.envs.rpsgym": names("pantheonrl.envs.rpsgym"),
+        "pantheonrl.envs.rpsgym.rps": names("pantheonrl.envs.rpsgym.rps", "RPSEnv", "RPSWeightedAgent"),
+        "pantheonrl.envs.liargym": names("pantheonrl.envs.liargym"),
+        "pantheonrl.envs.liargym.liar": names("pantheonrl.envs.liargym.liar", "LiarEnv", "LiarDefaultAgent"),
+        "pantheonrl.envs.blockworldgym": names("pantheonrl.envs.blockworldgym", simpleblockworld=names("simpleblockworld"),
+                                               blockworld=names("blockworld")),
+        "overcookedgym": names("overcookedgym", __path__=[os.path.join(REFERENCE, "overcookedgym")]),   # its __init__ is not run:
+    }                                                                                                  # overcooked_utils.py is plain lists
+    out = {}
+    with ReferenceModules() as ref:
+        saved = {k: sys.modules.get(k) for k in extra}
+        sys.modules.update(extra)
+        sys.modules["stable_baselines3.common.vec_env"].DummyVecEnv = type("DummyVecEnv", (), {})
+        sys.modules["gym"].make = stop
+        argv0 = sys.argv
+        try:
+            for case, argv in TRAINER_ARGVS.items():
+                ns = {"__name__": "__main__", "__file__": path}
+                sys.argv = ["trainer.py"] + list(argv)
+                try:
+                    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                        exec(code, ns)
+                    raise AssertionError("the script ran past gym.make")
+                except StopBeforeTheEnvironment:
+                    out[case] = {"args": rd.plain(vars(ns["args"]))}
+                except SystemExit as e:                                   # argparse: a value outside `choices`
+                    out[case] = {"rejected": "SystemExit", "code": int(e.code)}
+                except Exception as e:  # noqa: BLE001
+                    assert type(e).__name__ == "EnvException", (case, repr(e))
+                    out[case] = {"rejected": "EnvException"}
+        finally:
+            sys.argv = argv0
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+            for k in [k for k in sys.modules if k.startswith("overcookedgym")]:
+                sys.modules.pop(k, None)
+    return out
+
+
+# (ix, continued) the same script run to its END on recording doubles (tests/refdrive.TrainerDoubles): which environments, wrappers,
+# learners and agents a command line constructs with which arguments, who is registered as whose partner, learn / record / save calls
+TRAINER_GRAPH_ARGVS = {k: TRAINER_ARGVS[k] for k in (
+    "rps_ppo_ppo", "rps_seed_steps", "preset1", "liar_default_partner", "rps_default_with_config", "two_partners_one_flag",
+    "adap_shared_latent_short_flag", "adap_mult_shared_latent_configs", "adap_not_shared", "load_ego", "framestack_record",
+    "tensorboard_both_verbose_partner", "saves")}
+TRAINER_GRAPH_ARGVS.update({
+    "fixed_partners": ["RPS-v0", "PPO", "FIXED", "FIXED", "--alt-config", '{"type": "PPO", "location": "models/old"}',
+                       '{"type": "ADAP", "location": "models/adap", "latent_val": [0.5, -0.5, 0.25]}', "--alt-save", "m/a"],
+    "load_modular_ego_three_partners": ["LiarsDice-v0", "LOAD", "PPO", "PPO", "DEFAULT", "--ego-config",
+                                        '{"type": "ModularAlgorithm", "location": "models/mod"}', "--seed", "5", "--ego-save", "m/e",
+                                        "--alt-save", "m/a"],
+})
+# (not in the matrix: `LiarsDice-v0 PPO DEFAULT -f 2` -- the reference's gen_default tests isinstance(altenv, LiarEnv) on the frame-stack
+# WRAPPER and raises "No default policy available", trainer.py:165-179; the product unwraps down to the game first)
+
+
+def trainer_graph_reference_run() -> dict:
+    import contextlib
+    path = os.path.join(REFERENCE, "trainer.py")
+    with open(path) as fh:
+        code = compile(fh.read(), path, "exec")
+
+    def module(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+    out = {}
+    argv0 = sys.argv
+    for case, argv in TRAINER_GRAPH_ARGVS.items():
+        d = rd.TrainerDoubles()
+
+        class Monitor:
+            def __init__(self, env):
+                self.label = f"monitor({env.label})"
+
+        class DummyVecEnv:
+            def __init__(self, fns):
+                self.label = f"vec({fns[0]().label})"
+
+        class BCShell:
+            def __init__(self, policy):
+                self.policy = policy
+        mods = dict(_stand_ins())
+        mods.pop("pantheonrl")
+        overlay = {
+            "gym": module("gym", make=d.make, spaces=mods["gym.spaces"]),
+            "stable_baselines3": module("stable_baselines3", PPO=d.PPO),
+            "stable_baselines3.common": module("stable_baselines3.common"),
+            "stable_baselines3.common.vec_env": module("stable_baselines3.common.vec_env", DummyVecEnv=DummyVecEnv),
+            "stable_baselines3.common.monitor": module("stable_baselines3.common.monitor", Monitor=Monitor),
+            "pantheonrl": module("pantheonrl"), "pantheonrl.common": module("pantheonrl.common"),
+            "pantheonrl.common.wrappers": module("pantheonrl.common.wrappers", frame_wrap=d.frame_wrap, recorder_wrap=d.recorder_wrap),
+            "pantheonrl.common.agents": module("pantheonrl.common.agents", OnPolicyAgent=d.OnPolicyAgent, StaticPolicyAgent=d.StaticPolicyAgent),
+            "pantheonrl.algos": module("pantheonrl.algos"), "pantheonrl.algos.adap": module("pantheonrl.algos.adap"),
+            "pantheonrl.algos.adap.adap_learn": module("pantheonrl.algos.adap.adap_learn", ADAP=d.ADAP),
+            "pantheonrl.algos.adap.policies": module("pantheonrl.algos.adap.policies", AdapPolicyMult=d.AdapPolicyMult, AdapPolicy=d.AdapPolicy),
+            "pantheonrl.algos.adap.agent": module("pantheonrl.algos.adap.agent", AdapAgent=d.AdapAgent),
+            "pantheonrl.algos.modular": module("pantheonrl.algos.modular"),
+            "pantheonrl.algos.modular.learn": module("pantheonrl.algos.modular.learn", ModularAlgorithm=d.ModularAlgorithm),
+            "pantheonrl.algos.modular.policies": module("pantheonrl.algos.modular.policies", ModularPolicy=d.ModularPolicy),
+            "pantheonrl.algos.bc": module("pantheonrl.algos.bc", BCShell=BCShell, reconstruct_policy=None),
+            "pantheonrl.envs": module("pantheonrl.envs"), "pantheonrl.envs.rpsgym": module("pantheonrl.envs.rpsgym"),
+            "pantheonrl.envs.rpsgym.rps": module("pantheonrl.envs.rpsgym.rps", RPSEnv=d.RPSEnv, RPSWeightedAgent=d.RPSWeightedAgent),
+            "pantheonrl.envs.liargym": module("pantheonrl.envs.liargym"),
+            "pantheonrl.envs.liargym.liar": module("pantheonrl.envs.liargym.liar", LiarEnv=d.LiarEnv, LiarDefaultAgent=d.LiarDefaultAgent),
+            "pantheonrl.envs.blockworldgym": module("pantheonrl.envs.blockworldgym",
+                                                    simpleblockworld=module("simpleblockworld", PartnerEnv=object()),
+                                                    blockworld=module("blockworld", PartnerEnv=object())),
+            "overcookedgym": module("overcookedgym", __path__=[os.path.join(REFERENCE, "overcookedgym")]),
+        }
+        saved = {k: sys.modules.get(k) for k in overlay}
+        sys.modules.update(overlay)
+        sys.argv = ["trainer.py"] + list(argv)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                exec(code, {"__name__": "__main__", "__file__": path})      # <- the reference's text, to its last line
+        finally:
+            sys.argv = argv0
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+            for k in [k for k in sys.modules if k.startswith("overcookedgym")]:
+                sys.modules.pop(k, None)
+        out[case] = rd.plain(d.events)
+    return out
+
 # ---------------------------------------------------------------------------------------------------------------------------
 def generate() -> dict:
     """-> {file name: bytes} of every reference-generated fixture"""
@@ -852,6 +1051,8 @@ def generate() -> dict:
         for name, c in BC_CASES.items():
             for k, v in bc_reference_run(ref, c).items():
                 bc[f"{name}.{k}"] = np.asarray(v)
+    files["ref_trainer_cli.json"] = trainer_cli_reference_run()
+    files["ref_trainer_graph.json"] = trainer_graph_reference_run()
     out = {}
     for name, obj in files.items():
         out[name] = (json.dumps(obj, indent=None, separators=(",", ":"), sort_keys=True) + "\n").encode()

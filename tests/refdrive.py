@@ -10,6 +10,7 @@ flags), agents and models only record what they are handed.  A "framework" is an
 from __future__ import annotations
 
 import io
+import json
 from collections import deque
 from types import SimpleNamespace
 from typing import Any, List
@@ -430,3 +431,182 @@ def drive_observation(fw) -> dict:
     return {"default_state_is_obs": o1.state is o1.obs, "default_mask": o1.action_mask,
             "extract_obs": plain(fw.extract_obs(o2)), "extract_partial": plain(fw.extract_partial_obs(o2)),
             "state": plain(o2.state)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (ix) trainer.py: recording doubles for everything the script constructs -- the object graph of a run as an event list
+#      (reference trainer.py:92-228,407-432 run as a script; pantheonrl_amd.trainer.run with its names replaced by the same doubles)
+# ---------------------------------------------------------------------------------------------------------------------------
+class TrainerDoubles:
+    """`names()` -> {name the trainer module binds: double}.  Every construction / call that shapes the run lands in `events` with the
+    objects replaced by labels: ["env", id, config], ["frame_wrap", env, n], ["model", kind, policy, config], ["agent", class, ...],
+    ["add_partner", env, agent], ["learn", model, config], ["save", model, path], ..."""
+
+    def __init__(self):
+        self.events = []
+        ev = self.events
+
+        def lab(x):
+            if isinstance(x, (list, tuple)):
+                return [lab(v) for v in x]
+            if isinstance(x, dict):
+                return {k: lab(v) for k, v in x.items()}
+            if isinstance(x, type):
+                return getattr(x, "label", x.__name__)
+            return getattr(x, "label", plain(x))
+        self.lab = lab
+
+        class Env:
+            env_id = "?"
+
+            def __init__(self, **config):
+                self.label = self.env_id
+                ev.append(["env", self.env_id, lab(config)])
+
+            def getDummyEnv(self, player_num):
+                d = type(self).__new__(type(self))
+                d.label = f"dummy{player_num}({self.label})"
+                return d
+
+            def add_partner_agent(self, agent, player_num=1):
+                ev.append(["add_partner", self.label, lab(agent), player_num])
+
+            def get_transitions(self):
+                ev.append(["get_transitions", self.label])
+                return Transitions()
+
+        class Transitions:
+            label = "transitions"
+
+            def write_transition(self, path):
+                ev.append(["write_transition", path])
+
+        class Wrapped:
+            def __init__(self, kind, env, *extra):
+                self.env, self.label = env, f"{kind}({env.label})"
+                ev.append([kind, env.label] + [plain(x) for x in extra])
+
+            def getDummyEnv(self, player_num):
+                d = Wrapped.__new__(Wrapped)
+                d.env, d.label = self.env.getDummyEnv(player_num), f"dummy{player_num}({self.label})"
+                return d
+
+            def add_partner_agent(self, agent, player_num=1):
+                ev.append(["add_partner", self.label, lab(agent), player_num])
+
+            def get_transitions(self):
+                ev.append(["get_transitions", self.label])
+                return Transitions()
+
+        class RPSEnv(Env):
+            env_id = "RPS-v0"
+
+        class LiarEnv(Env):
+            env_id = "LiarsDice-v0"
+        self.RPSEnv, self.LiarEnv, self.Wrapped = RPSEnv, LiarEnv, Wrapped
+
+        class Policy:
+            def __init__(self, owner):
+                self.label, self.owner, self.num_partners_set = f"{owner}.policy", owner, None
+
+            def set_context(self, value):
+                ev.append(["set_context", self.label, plain(np.asarray(value, np.float32))])
+
+            def do_init_weights(self, init_main=False, init_partner=False):      # reference, LOAD of a ModularAlgorithm ego (:121-123)
+                ev.append(["do_init_weights", self.label, bool(init_main), bool(init_partner)])
+
+            def __setattr__(self, k, v):
+                if k == "num_partners":
+                    ev.append(["num_partners", self.label, int(v)])
+                object.__setattr__(self, k, v)
+
+        counter = {}
+
+        def model_class(kind):
+            class Model:
+                label_kind = kind
+
+                def __init__(self, policy=None, **config):
+                    counter[kind] = counter.get(kind, 0) + 1
+                    self.label = f"{kind}#{counter[kind]}"
+                    self.policy = Policy(self.label)
+                    ev.append(["model", kind, lab(policy), lab(config), self.label])
+
+                @classmethod
+                def load(cls, location, **kw):
+                    m = cls.__new__(cls)
+                    counter[kind] = counter.get(kind, 0) + 1
+                    m.label = f"{kind}#{counter[kind]}"
+                    m.policy = Policy(m.label)
+                    ev.append(["load", kind, location, m.label])
+                    return m
+
+                def set_env(self, env):
+                    ev.append(["set_env", self.label, lab(env)])
+
+                def set_num_partners(self, n):                                    # the product's form of :121-123
+                    ev.append(["set_num_partners", self.label, int(n)])
+
+                def learn(self, **config):
+                    ev.append(["learn", self.label, lab(config)])
+
+                def save(self, path):
+                    ev.append(["save", self.label, path])
+            Model.__name__ = kind
+            return Model
+        self.PPO, self.ADAP, self.ModularAlgorithm = model_class("PPO"), model_class("ADAP"), model_class("ModularAlgorithm")
+
+        def agent_class(kind, has_model=True):
+            class AgentDouble:
+                def __init__(self, *args, **kw):
+                    counter[kind] = counter.get(kind, 0) + 1
+                    self.label = f"{kind}#{counter[kind]}"
+                    if has_model and args:
+                        self.model = args[0]
+                    ev.append(["agent", kind, lab(list(args)), lab(kw), self.label])
+            AgentDouble.__name__ = kind
+            return AgentDouble
+        self.OnPolicyAgent, self.AdapAgent = agent_class("OnPolicyAgent"), agent_class("AdapAgent")
+        self.StaticPolicyAgent = agent_class("StaticPolicyAgent", has_model=False)
+        self.RPSWeightedAgent, self.LiarDefaultAgent = agent_class("RPSWeightedAgent", False), agent_class("LiarDefaultAgent", False)
+
+        def policy_name(n):
+            return type(n, (), {"label": n})
+        self.AdapPolicy, self.AdapPolicyMult, self.ModularPolicy = policy_name("AdapPolicy"), policy_name("AdapPolicyMult"), policy_name("ModularPolicy")
+
+    def make(self, env_id, **config):
+        return {"RPS-v0": self.RPSEnv, "LiarsDice-v0": self.LiarEnv}[env_id](**config)
+
+    def frame_wrap(self, env, numframes):
+        return self.Wrapped("frame_wrap", env, numframes)
+
+    def recorder_wrap(self, env, numframes=None):
+        return self.Wrapped("recorder_wrap", env)
+
+
+def normalise_trainer_events(events, product: bool):
+    """the deliberate differences between the two scripts folded away, each named here:
+    * the product gives every partner model `sampling_stream = index + 1` (an action-sampling stream of its own under the shared seed);
+    * a LOADed ego: the reference wraps the environment as DummyVecEnv([Monitor(env)]) for set_env and re-initialises a
+      ModularAlgorithm's partner modules through policy.do_init_weights(init_partner=True) + policy.num_partners = n
+      (trainer.py:118-123); the product hands set_env the environment and calls set_num_partners(n);
+    * frame stacking: the reference wraps the partner-side dummy environment as well (trainer.py:98-99), the product asks the wrapped
+      environment for its dummy -- the same observation space either way;
+    * FIXED ADAP partners: latent_val goes through torch.tensor there, numpy here (compared as lists)."""
+    out = []
+    for e in events:
+        e = json.loads(json.dumps(e))
+        if e[0] == "model" and isinstance(e[3], dict):
+            e[3].pop("sampling_stream", None)
+            if isinstance(e[3].get("env"), str):
+                e[3]["env"] = e[3]["env"].replace("frame_wrap(dummy1(", "dummy1(frame_wrap(")
+        if e[0] == "frame_wrap" and e[1].startswith("dummy1("):
+            continue
+        if e[0] == "set_env" and e[2].startswith("vec(monitor("):
+            e[2] = e[2][len("vec(monitor("):-2]
+        if e[0] == "do_init_weights":
+            continue
+        if e[0] == "num_partners":
+            e = ["set_num_partners", e[1].replace(".policy", ""), e[2]]
+        out.append(e)
+    return out

@@ -287,25 +287,19 @@ def test_trainer_cli_surface_and_presets():
     args = trainer.preset(args, 1)
     assert args.tensorboard_log == "logs" and args.tensorboard_name == "RPS-v0-PPOPPO-7"
     assert args.ego_save == "models/RPS-v0-PPO-ego-7" and args.alt_save == "models/RPS-v0-PPO-alt-7"
-    trainer.input_check(p.parse_args(["RPS-v0", "ADAP_MULT", "ADAP", "--share-latent", "--alt-config", "{}"]))   # trainer.py:32-34,67-71
+    trainer.parse_cli(["RPS-v0", "ADAP_MULT", "ADAP", "--share-latent", "--alt-config", "{}"])   # trainer.py:32-34,67-71
     for bad in (["RPS-v0", "ADAP_MULT", "PPO", "--share-latent"], ["RPS-v0", "PPO", "BC"], ["OvercookedMultiEnv-v0", "PPO", "PPO"],
                 ["RPS-v0", "PPO", "PPO", "--share-latent"], ["RPS-v0", "ADAP", "PPO", "--share-latent"],
                 ["RPS-v0", "SAC", "PPO"]):
-        a = p.parse_args(bad)
-        a.alt_config = a.alt_config or [{} for _ in a.alt]
         with pytest.raises(trainer.EnvException):
-            trainer.input_check(a)
-    a = p.parse_args(["RPS-v0", "PPO", "PPO", "--alt-config", "{}", "--alt-config", "{}"])
+            trainer.parse_cli(bad)
     with pytest.raises(trainer.EnvException):
-        trainer.input_check(a)                      # two configs for one partner
+        trainer.parse_cli(["RPS-v0", "PPO", "PPO", "--alt-config", "{}", "--alt-config", "{}"])   # two configs for one partner
     # --share-latent: ADAP everywhere, partners inherit the ego's context settings (trainer.py:65-89)
-    a = p.parse_args(["RPS-v0", "ADAP", "ADAP", "--share-latent", "--ego-config", '{"context_size": 4}'])
-    a.alt_config = [{}]
-    trainer.input_check(a)
+    a = trainer.parse_cli(["RPS-v0", "ADAP", "ADAP", "--share-latent", "--ego-config", '{"context_size": 4}'])
     assert a.alt_config == [{"context_size": 4, "context_sampler": "l2"}] and a.ego_config["context_sampler"] == "l2"
-    a = p.parse_args(["RPS-v0", "ADAP", "ADAP", "--share-latent", "--alt-config", '{"context_size": 2}'])
     with pytest.raises(trainer.EnvException):
-        trainer.input_check(a)
+        trainer.parse_cli(["RPS-v0", "ADAP", "ADAP", "--share-latent", "--alt-config", '{"context_size": 2}'])
     # DEFAULT partners need no GPU: the graph builds up to the ego
     a = p.parse_args(["LiarsDice-v0", "PPO", "DEFAULT", "--framestack", "3"])
     a.alt_config = [{}]
