@@ -1027,7 +1027,8 @@ def generate() -> dict:
         files["ref_multiagent.json"] = logs
         files["ref_onpolicy_agent.json"] = {"verbose": rd.drive_onpolicy_agent(fw, spaces, verbose=1),
                                             "quiet": rd.drive_onpolicy_agent(fw, spaces, seed=8, n_steps=4, n_calls=19, verbose=0),
-                                            "recorded_only": rd.drive_onpolicy_agent(fw, spaces, **rd.RECORDED_ONLY)}
+                                            "recorded_only": rd.drive_onpolicy_agent(fw, spaces, **rd.RECORDED_ONLY),
+                                            "static_and_wrapper": rd.drive_static_and_wrapper(fw, spaces)}
         files["ref_framestack.json"] = {"history_queue": rd.drive_history_queue(fw), "wrappers": rd.drive_framestack(fw, spaces)}
         rec = rd.drive_recorders(fw, spaces)
         files["ref_recorders.json"] = rec["views"]

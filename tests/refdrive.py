@@ -610,3 +610,24 @@ def normalise_trainer_events(events, product: bool):
             e = ["set_num_partners", e[1].replace(".policy", ""), e[2]]
         out.append(e)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (ii, continued) StaticPolicyAgent (agents.py:54-79) and RecordingAgentWrapper (agents.py:365-413) over the recording policy
+# ---------------------------------------------------------------------------------------------------------------------------
+def drive_static_and_wrapper(fw, spaces, seed: int = 12, n_calls: int = 9, D: int = 3) -> dict:
+    obs_space = spaces.Box(-np.inf, np.inf, (D,), np.float32)
+    act_space = spaces.Discrete(3)
+    model = RecordingModel(obs_space, act_space, 4, seed)
+    static = fw.StaticPolicyAgent(model.policy)
+    wrapped = fw.RecordingAgentWrapper(static)
+    rng = np.random.default_rng(seed)
+    returned = []
+    for i in range(n_calls):
+        obs = rng.standard_normal(D).astype(np.float32)
+        agent = static if i % 3 == 0 else wrapped                     # both paths; only the wrapper's calls are recorded by it
+        returned.append(plain(agent.get_action(fw.Observation(obs), record=bool(i % 2))))
+        agent.update(float(i), bool(i % 4 == 3))                      # a no-op for the static agent, forwarded by the wrapper
+    tr = wrapped.get_transitions()
+    return {"events": model.events, "returned": returned, "transitions_class": type(tr).__name__, "obs": plain(tr.obs), "acts": plain(tr.acts),
+            "obs_dtype": str(np.asarray(tr.obs).dtype), "acts_dtype": str(np.asarray(tr.acts).dtype)}
