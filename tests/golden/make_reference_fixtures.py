@@ -23,6 +23,8 @@ What runs is the reference's source, imported from where it lies (nothing is cop
     pantheonrl/algos/modular/learn.py    ModularAlgorithm.train (:221-351)
     trainer.py (as __main__)             argument parser, preset, input_check, latent_check; generate_env / generate_ego / gen_partner /
                                          generate_partners and the learn / record / save tail on recording doubles (:41-432)
+    pantheonrl/envs/pettingzoo.py        PettingZooAECWrapper.__init__ / n_reset / n_step (:27-127): the action the environment is stepped with
+                                         when the sample is illegal under the mask (`gymnasium` = five space class NAMES; a scripted AEC env)
     pantheonrl/algos/bc.py               BC.__init__ (optimizer construction), set_expert_data_loader, _calculate_loss, train,
                                          EpochOrBatchIteratorWithProgress (:67-365); common/util.py FeedForward32Policy (:114-123);
                                          common/trajsaver.py TransitionsMinimal.__getitem__ / transitions_collate_fn under torch's DataLoader
@@ -1016,6 +1018,88 @@ def trainer_graph_reference_run() -> dict:
         out[case] = rd.plain(d.events)
     return out
 
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (x) the integer action-mask rule, from the reference's PettingZooAECWrapper TEXT (pantheonrl/envs/pettingzoo.py:27-127): what the
+#     base environment is stepped with when the acting agent's sample is illegal under the mask it was shown
+# ---------------------------------------------------------------------------------------------------------------------------
+MASK_CASES = {"mpe8_L5": dict(L=5, n=600, p_legal=0.8, n_players=8, seed=51), "wide_L20": dict(L=20, n=400, p_legal=0.3, n_players=3, seed=52)}
+
+
+def action_mask_reference_run(c: dict) -> dict:
+    """a scripted AEC environment behind the reference's wrapper: per step a Bernoulli(p_legal) mask with at least one legal action for
+    the agent that moves next, a uniformly random sample as that agent's action -> the action base_env.step received"""
+    def names(modname, *ns):
+        m = types.ModuleType(modname)
+        for n in ns:
+            setattr(m, n, type(n, (), {"__init__": lambda self, **kw: self.__dict__.update(kw)}))
+        return m
+    gymn = types.ModuleType("gymnasium")
+    gymn.spaces = types.ModuleType("gymnasium.spaces")
+    for sub, cls in (("box", "Box"), ("discrete", "Discrete"), ("multi_discrete", "MultiDiscrete"), ("multi_binary", "MultiBinary"), ("dict", "Dict")):
+        m = names("gymnasium.spaces." + sub, cls)
+        setattr(gymn.spaces, sub, m)
+    gymn.spaces.Space = type("Space", (), {})
+    rng = np.random.default_rng(c["seed"])
+    L, P = c["L"], c["n_players"]
+
+    class Base:                                                           # the AEC surface the wrapper touches
+        possible_agents = [f"agent_{i}" for i in range(P)]
+        max_num_agents = P
+
+        def __init__(self):
+            self.received, self.masks, self.t = [], [], 0
+            self.rewards = {a: 0.0 for a in self.possible_agents}
+            self.terminations = {a: False for a in self.possible_agents}
+            self.truncations = {a: False for a in self.possible_agents}
+            self.infos = {a: {} for a in self.possible_agents}
+
+        def action_space(self, agent):
+            return gymn.spaces.discrete.Discrete(n=L)
+
+        def observation_space(self, agent):
+            box = gymn.spaces.box.Box(low=np.zeros(4, np.float32), high=np.ones(4, np.float32), dtype=np.float32)
+            return gymn.spaces.dict.Dict(spaces={"observation": box})
+
+        def reset(self):
+            self.agent_selection = self.possible_agents[0]
+
+        def observe(self, agent):
+            mask = (rng.random(L) < c["p_legal"]).astype(np.int8)
+            if not mask.any():
+                mask[rng.integers(0, L)] = 1
+            self.masks.append(mask.copy())
+            return {"observation": rng.random(4).astype(np.float32), "action_mask": mask}
+
+        def step(self, act):
+            self.received.append(int(act))
+            self.t += 1
+            self.agent_selection = self.possible_agents[self.t % P]
+    with ReferenceModules() as ref:
+        saved = {k: sys.modules.get(k) for k in ("gymnasium", "pantheonrl.envs")}
+        sys.modules["gymnasium"] = gymn
+        envs_pkg = types.ModuleType("pantheonrl.envs")                       # its __init__.py (gym registrations) is not run
+        envs_pkg.__path__ = [os.path.join(REFERENCE, "pantheonrl", "envs")]
+        sys.modules["pantheonrl.envs"] = envs_pkg
+        try:
+            pz = importlib.import_module("pantheonrl.envs.pettingzoo")
+            assert os.path.abspath(pz.__file__).startswith(os.path.abspath(REFERENCE))
+            base = Base()
+            env = pz.PettingZooAECWrapper(base, ego_ind=0)                   # <- the reference's text
+            assert env.action_space.n == L and tuple(env.observation_space.shape) == (4,)
+            env.n_reset()
+            sampled = rng.integers(0, L, c["n"])
+            for a in sampled:
+                env.n_step([np.int64(a)])
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+    masks = np.stack(base.masks[:c["n"]]).astype(np.uint8)                   # mask i is what the agent acting at step i was shown
+    return {"masks": masks, "sampled": sampled.astype(np.int32), "stepped_with": np.asarray(base.received, np.int32)}
+
 # ---------------------------------------------------------------------------------------------------------------------------
 def generate() -> dict:
     """-> {file name: bytes} of every reference-generated fixture"""
@@ -1052,13 +1136,18 @@ def generate() -> dict:
         for name, c in BC_CASES.items():
             for k, v in bc_reference_run(ref, c).items():
                 bc[f"{name}.{k}"] = np.asarray(v)
+    masks = {}
+    for name, c in MASK_CASES.items():
+        for k, v in action_mask_reference_run(c).items():
+            masks[f"{name}.{k}"] = v
     files["ref_trainer_cli.json"] = trainer_cli_reference_run()
     files["ref_trainer_graph.json"] = trainer_graph_reference_run()
     out = {}
     for name, obj in files.items():
         out[name] = (json.dumps(obj, indent=None, separators=(",", ":"), sort_keys=True) + "\n").encode()
     for name, arrays in (("ref_transitions.npz", npy), ("ref_adap_context.npz", adap), ("ref_ppo_train.npz", train),
-                         ("ref_modular.npz", modular), ("ref_bc.npz", bc)):
+                         ("ref_modular.npz", modular), ("ref_bc.npz", bc),
+                         ("ref_action_mask.npz", masks)):
         f = io.BytesIO()
         np.savez(f, **{k: arrays[k] for k in sorted(arrays)})       # uncompressed + sorted: byte-reproducible
         out[name] = f.getvalue()

@@ -404,3 +404,23 @@ def test_device_bc_train_matches_the_reference_bc_text(name):
             assert abs(st[i, j] - want) <= 2e-5 + 2e-4 * abs(want), (i, k, st[i, j], want)
     d = np.abs(clone.policy.get_flat_params() - g["params_final"])
     assert np.median(d) <= 2e-6 and d.max() <= 2.5e-3 and (d > 1e-4).mean() <= 0.01, (np.median(d), d.max(), (d > 1e-4).mean())
+
+
+# ---- the integer action-mask rule on the device (tests/golden/ref_action_mask.npz: the reference's PettingZooAECWrapper text) ---------------
+@pytest.mark.parametrize("case", ["mpe8_L5", "wide_L20"])
+def test_device_illegal_action_repair_is_the_reference_wrappers(case):
+    """`ph_fix_illegal_actions` against what the REFERENCE's PettingZooAECWrapper.n_step (pantheonrl/envs/pettingzoo.py:78-84) stepped its
+    base environment with for the same (mask, sample) pairs: bit-exact (north_star: integer action masks)."""
+    from pantheonrl_amd import _native as nat
+    from pantheonrl_amd import spaces as sp
+    from pantheonrl_amd.ppo import ActorCriticPolicy
+    z = np.load(os.path.join(GOLDEN, "ref_action_mask.npz"))
+    masks, sampled, want = z[case + ".masks"], z[case + ".sampled"], z[case + ".stepped_with"]
+    n, L = masks.shape
+    pol = ActorCriticPolicy(sp.Box(-np.inf, np.inf, (4,)), sp.Discrete(L), device="cuda", seed=0)
+    acts = th.as_tensor(sampled.astype(np.int32)).cuda()
+    m_dev = th.as_tensor(np.ascontiguousarray(masks, np.uint8)).cuda()
+    pol._bind()
+    nat.check(pol.ctx.lib.ph_fix_illegal_actions(pol.ctx.handle, acts.data_ptr(), m_dev.data_ptr(), n, L))
+    th.cuda.synchronize()
+    assert np.array_equal(acts.cpu().numpy(), want)
