@@ -1100,6 +1100,43 @@ def action_mask_reference_run(c: dict) -> dict:
     masks = np.stack(base.masks[:c["n"]]).astype(np.uint8)                   # mask i is what the agent acting at step i was shown
     return {"masks": masks, "sampled": sampled.astype(np.int32), "stepped_with": np.asarray(base.received, np.int32)}
 
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (xi) the hand-made DEFAULT partners of trainer.py (gen_default, :165-179): LiarDefaultAgent (liargym/liar.py:29-42) and
+#      RPSWeightedAgent (rpsgym/rps.py:14-30), run from the reference's files (loader of tests/golden/check_against_reference.py)
+# ---------------------------------------------------------------------------------------------------------------------------
+def default_agents_reference_run() -> dict:
+    from tests.golden.check_against_reference import load_reference_games
+    liar_ns, rps_ns = load_reference_games(REFERENCE)
+    rng = np.random.default_rng(61)
+    agent = liar_ns["LiarDefaultAgent"]()
+    obs_rows, acts = [], []
+    for _ in range(400):
+        dice = rng.integers(0, 6, 6)
+        hand = [int((dice == f).sum()) for f in range(6)]
+        n_moves = int(rng.integers(0, 5))
+        hist = []
+        for _m in range(n_moves):
+            hist += [int(rng.integers(0, 6)), int(rng.integers(1, 13))]
+        hist += [6, 0] * (12 - n_moves)
+        o = np.asarray(hand + hist, np.int64)
+        obs_rows.append([int(v) for v in o])
+        acts.append([int(v) for v in np.asarray(agent.get_action(types.SimpleNamespace(obs=o))).reshape(-1)])
+        agent.update(0.0, False)
+
+    class Rolls:
+        def __init__(self, rolls):
+            self.rolls = list(rolls)
+
+        def rand(self):
+            return self.rolls.pop(0)
+    rps = []
+    rolls = [float(v) for v in np.round(rng.random(40), 6)] + [0.0, 1.0 / 3, 2.0 / 3, 0.25, 0.5, 0.75]
+    for r, p_, s_ in ((1, 1, 1), (2, 1, 1), (1, 0, 0), (0, 0, 0), (0, 3, 1), (5, 0, 5)):
+        a = rps_ns["RPSWeightedAgent"](r=r, p=p_, s=s_, np_random=Rolls(rolls))
+        rps.append({"weights": [r, p_, s_], "actions": [int(a.get_action(None)) for _ in rolls]})
+    return {"liar_obs": obs_rows, "liar_actions": acts, "rps_rolls": rolls, "rps": rps}
+
 # ---------------------------------------------------------------------------------------------------------------------------
 def generate() -> dict:
     """-> {file name: bytes} of every reference-generated fixture"""
@@ -1140,6 +1177,7 @@ def generate() -> dict:
     for name, c in MASK_CASES.items():
         for k, v in action_mask_reference_run(c).items():
             masks[f"{name}.{k}"] = v
+    files["ref_default_agents.json"] = default_agents_reference_run()
     files["ref_trainer_cli.json"] = trainer_cli_reference_run()
     files["ref_trainer_graph.json"] = trainer_graph_reference_run()
     out = {}
