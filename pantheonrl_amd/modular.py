@@ -384,6 +384,7 @@ class ModularAlgorithm(PPO):
                     lg.record("rollout/ep_rew_mean", float(np.mean([e["r"] for e in self.ep_info_buffer])))
                     lg.record("rollout/ep_len_mean", float(np.mean([e["l"] for e in self.ep_info_buffer])))
                 lg.record("time/fps", int(self.num_timesteps / max(time.time() - self.start_time, 1e-9)))
+                lg.record("time/time_elapsed", int(time.time() - self.start_time), exclude="tensorboard")      # learn.py:396
                 lg.record("time/total_timesteps", self.num_timesteps, exclude="tensorboard")
                 lg.dump(step=self.num_timesteps)
             self.train()

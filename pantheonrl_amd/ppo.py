@@ -866,6 +866,7 @@ class PPO:
                     lg.record("rollout/ep_rew_mean", float(np.mean([e["r"] for e in self.ep_info_buffer])))
                     lg.record("rollout/ep_len_mean", float(np.mean([e["l"] for e in self.ep_info_buffer])))
                 lg.record("time/fps", fps)
+                lg.record("time/time_elapsed", int(time.time() - self.start_time), exclude="tensorboard")   # (SB3's learn; witness modular/learn.py:396)
                 lg.record("time/total_timesteps", self.num_timesteps, exclude="tensorboard")
                 lg.dump(step=self.num_timesteps)
             self.train()

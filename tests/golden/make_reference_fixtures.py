@@ -87,7 +87,7 @@ import json
 import os
 import sys
 import types
-from collections import namedtuple
+from collections import deque, namedtuple
 from itertools import combinations
 
 import numpy as np
@@ -1137,6 +1137,50 @@ def default_agents_reference_run() -> dict:
         rps.append({"weights": [r, p_, s_], "actions": [int(a.get_action(None)) for _ in rolls]})
     return {"liar_obs": obs_rows, "liar_actions": acts, "rps_rolls": rolls, "rps": rps}
 
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (xii) the ego's loop on recording doubles (tests/refdrive.LoopDoubles): ModularAlgorithm.learn + collect_rollouts TEXT
+#       (modular/learn.py:157-219,353-403) and ADAP.collect_rollouts TEXT (adap_learn.py:377-473 = SB3's collect_rollouts + context lines)
+# ---------------------------------------------------------------------------------------------------------------------------
+LOOP_CASES = {"modular_two_partners": dict(kind="modular", K=2, n_steps=5, total=23, seed=71),
+              "modular_one_partner": dict(kind="modular", K=1, n_steps=4, total=9, seed=72),
+              "ppo_collect": dict(kind="adap", ctx=0, n_steps=7, rollouts=3, seed=73),
+              "adap_collect": dict(kind="adap", ctx=3, n_steps=6, rollouts=3, seed=74)}
+LOOP_D, LOOP_ACTIONS = 3, 4
+
+
+def loop_reference_run(ref: "ReferenceModules", c: dict) -> list:
+    import time
+    d = rd.LoopDoubles(c["seed"], LOOP_D, LOOP_ACTIONS, K=c.get("K", 1), ctx=c.get("ctx", 0))
+    algo = types.SimpleNamespace(policy=d.policy, env=d.env, n_steps=c["n_steps"], use_sde=False, sde_sample_freq=-1, device="cpu",
+                                 action_space=ref.spaces.Discrete(LOOP_ACTIONS), num_timesteps=0, _last_obs=None, logger=d.logger,
+                                 ep_info_buffer=deque(maxlen=100), train=d.train, start_time=time.time())
+
+    def update_info_buffer(infos, dones=None):                 # SB3's _update_info_buffer: the finished episodes' statistics
+        for info in infos:
+            if info.get("episode") is not None:
+                algo.ep_info_buffer.extend([info["episode"]])
+    algo._update_info_buffer = update_info_buffer
+    if c["kind"] == "modular":
+        cls = ref.m["algos.modular.learn"].ModularAlgorithm
+        algo.rollout_buffer = d.buffers
+        algo.collect_rollouts = types.MethodType(cls.collect_rollouts, algo)
+
+        def setup_learn(total_timesteps, eval_env, callback, *rest):       # SB3's _setup_learn: counters, clock, the first observation
+            algo.num_timesteps, algo.start_time, algo._last_obs = 0, time.time(), algo.env.reset()
+            return total_timesteps, callback
+        algo._setup_learn = setup_learn
+        algo._update_current_progress_remaining = lambda n, t: None
+        cls.learn(algo, total_timesteps=c["total"], callback=d.callback)   # <- the reference's text (learn and, through it, collect_rollouts)
+    else:
+        cls = ref.m["algos.adap.adap_learn"].ADAP
+        algo.context_size, algo.context_sampler, algo.full_obs_shape = c["ctx"], "l2", None
+        algo._last_obs, algo._last_episode_starts = algo.env.reset(), np.ones((1,), dtype=bool)
+        th.manual_seed(c["seed"])
+        for _ in range(c["rollouts"]):
+            assert cls.collect_rollouts(algo, algo.env, d.callback, d.buffers[0], n_rollout_steps=c["n_steps"]) is True   # <- the reference's text
+    return rd.plain(d.events)
+
 # ---------------------------------------------------------------------------------------------------------------------------
 def generate() -> dict:
     """-> {file name: bytes} of every reference-generated fixture"""
@@ -1178,6 +1222,8 @@ def generate() -> dict:
         for k, v in action_mask_reference_run(c).items():
             masks[f"{name}.{k}"] = v
     files["ref_default_agents.json"] = default_agents_reference_run()
+    with ReferenceModules() as ref:
+        files["ref_ego_loop.json"] = {name: loop_reference_run(ref, c) for name, c in LOOP_CASES.items()}
     files["ref_trainer_cli.json"] = trainer_cli_reference_run()
     files["ref_trainer_graph.json"] = trainer_graph_reference_run()
     out = {}

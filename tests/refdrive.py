@@ -631,3 +631,141 @@ def drive_static_and_wrapper(fw, spaces, seed: int = 12, n_calls: int = 9, D: in
     tr = wrapped.get_transitions()
     return {"events": model.events, "returned": returned, "transitions_class": type(tr).__name__, "obs": plain(tr.obs), "acts": plain(tr.acts),
             "obs_dtype": str(np.asarray(tr.obs).dtype), "acts_dtype": str(np.asarray(tr.acts).dtype)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# (xii) the ego's loop: learn() / collect_rollouts() on recording doubles -- reference modular/learn.py:157-219,353-403 and
+#       adap/adap_learn.py:377-473 (the in-tree copy of SB3's OnPolicyAlgorithm.collect_rollouts + the context lines)
+# ---------------------------------------------------------------------------------------------------------------------------
+class LoopDoubles:
+    """policy / per-partner buffers / one-environment vector env / callback that script their outputs from a seeded stream and log every
+    call.  A buffer row is logged ONCE, when it is complete: the reference completes it in `add(obs, actions, rewards, starts, values,
+    log_probs)`, the product in `forward_and_store(...)` + `add_reward(rewards)`."""
+
+    def __init__(self, seed: int, D: int, n_act: int, K: int = 1, ctx: int = 0, p_done: float = 0.2):
+        self.events = ev = []
+        rng = np.random.default_rng(seed)
+        loop = self
+
+        def outputs(n):
+            a = rng.integers(0, n_act, size=(n,))
+            v = rng.standard_normal((n, 1)).astype(np.float32)
+            lp = (-rng.random(n)).astype(np.float32)
+            return a, v, lp
+
+        class Policy:
+            num_partners = K
+            context = np.zeros((1, ctx), np.float32)
+
+            def forward(self, obs, partner_idx=None, deterministic=False):                 # the reference's call
+                o = obs.detach().cpu().numpy() if isinstance(obs, th.Tensor) else np.asarray(obs)
+                a, v, lp = outputs(o.reshape(1, -1).shape[0] if o.ndim == 1 else o.shape[0])
+                ev.append(["forward", plain(o.reshape(-1)), partner_idx])
+                return th.as_tensor(a), th.as_tensor(v), th.as_tensor(lp)
+
+            __call__ = forward
+
+            def forward_and_store(self, obs, rb, episode_start, partner_idx=None, uniforms=None, **kw):   # the product's fused call
+                o = np.asarray(obs, np.float32)
+                a, v, lp = outputs(1)
+                ev.append(["forward", plain(o.reshape(-1)), partner_idx])
+                rb.pending = [plain(o.reshape(-1)), plain(a), plain(np.asarray(episode_start, np.float32)), plain(v), plain(lp)]
+                return th.as_tensor(a), th.as_tensor(v), th.as_tensor(lp)
+
+            def predict_values(self, obs, partner_idx=None):                                # the product's bootstrap of the ego
+                o = np.asarray(obs, np.float32)
+                a, v, lp = outputs(1)
+                ev.append(["forward", plain(o.reshape(-1)), partner_idx])
+                return th.as_tensor(v)
+
+            def get_context(self):
+                return self.context
+
+            def set_context(self, c):
+                self.context = np.asarray(c.detach().cpu().numpy() if isinstance(c, th.Tensor) else c, np.float32).reshape(1, -1)
+                ev.append(["set_context", plain(self.context.reshape(-1))])
+
+            def reset_noise(self, n=1):
+                ev.append(["reset_noise", n])
+        self.policy = Policy()
+
+        class Buffer:
+            def __init__(self, k):
+                self.k, self.pending, self.obs_shape, self.pos, self.full = k, None, (D,), 0, False
+
+            def reset(self):
+                ev.append(["buffer.reset", self.k])
+                self.pos, self.full = 0, False
+
+            def add(self, obs, actions, rewards, starts, values, log_probs):               # reference: the whole row at once
+                none_to_zero = [0.0] if starts is None else starts                         # (learn.py:176,207: None on a rollout's first step)
+                ev.append(["row", self.k, plain(np.asarray(obs, np.float32).reshape(-1)), plain(np.asarray(actions).reshape(-1)),
+                           plain(np.asarray(rewards, np.float32).reshape(-1)), plain(np.asarray(none_to_zero, np.float32).reshape(-1)),
+                           plain(values), plain(log_probs)])
+
+            def add_reward(self, rewards):                                                  # product: the row's reward arrives after the step
+                o, a, es, v, lp = self.pending
+                ev.append(["row", self.k, o, a, plain(np.asarray(rewards, np.float32).reshape(-1)), es, v, lp])
+                self.pending = None
+
+            def compute_returns_and_advantage(self, last_values, dones):
+                ev.append(["gae", self.k, plain(last_values), plain(np.asarray(dones, np.float32).reshape(-1))])
+        self.buffers = [Buffer(k) for k in range(K)]
+
+        class Game:
+            def set_partnerid(self, k):
+                ev.append(["set_partnerid", int(k)])
+
+        class VecEnv:
+            num_envs = 1
+            envs = [Game()]
+
+            def reset(self):
+                ev.append(["env.reset"])
+                return rng.standard_normal((1, D)).astype(np.float32)
+
+            def step(self, actions):
+                ev.append(["env.step", plain(np.asarray(actions).reshape(-1))])
+                done = bool(rng.random() < p_done)
+                info = {"episode": {"r": float(np.float32(rng.standard_normal())), "l": int(rng.integers(1, 9))}} if done else {}
+                return (rng.standard_normal((1, D)).astype(np.float32), np.asarray([rng.standard_normal()], np.float32),
+                        np.asarray([done]), [info])
+        self.env = VecEnv()
+
+        class Callback:
+            def init_callback(self, model):
+                ev.append(["callback.init"])
+
+            def on_training_start(self, l, g):
+                ev.append(["callback.training_start"])
+
+            def on_rollout_start(self):
+                ev.append(["callback.rollout_start"])
+
+            def update_locals(self, l):
+                pass
+
+            def on_step(self):
+                ev.append(["callback.step"])
+                return True
+
+            def on_rollout_end(self):
+                ev.append(["callback.rollout_end"])
+
+            def on_training_end(self):
+                ev.append(["callback.training_end"])
+        self.callback = Callback()
+
+        class Logger:
+            def record(self, key, value, exclude=None):
+                if not key.startswith("time/") or key in ("time/iterations", "time/total_timesteps"):
+                    ev.append(["log", key, plain(value), exclude])
+                else:
+                    ev.append(["log", key, "<clock>", exclude])
+
+            def dump(self, step=0):
+                ev.append(["dump", plain(step)])
+        self.logger = Logger()
+
+    def train(self):
+        self.events.append(["train"])
