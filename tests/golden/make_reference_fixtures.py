@@ -1194,6 +1194,10 @@ def generate() -> dict:
                                             "quiet": rd.drive_onpolicy_agent(fw, spaces, seed=8, n_steps=4, n_calls=19, verbose=0),
                                             "recorded_only": rd.drive_onpolicy_agent(fw, spaces, **rd.RECORDED_ONLY),
                                             "static_and_wrapper": rd.drive_static_and_wrapper(fw, spaces)}
+        # (pantheonrl/algos/adap/agent.py's AdapAgent is NOT here: as written its get_action reshapes the observation ++ context row
+        # (D + context_size elements) to (1,) + policy.observation_space.shape = (1, D) and raises for every recorded call,
+        # agent.py:115-123 with util.py:75 fixing policy.observation_space to the environment's; the product stores the row the text
+        # evidently means -- tests/test_gpu_adap.py::test_adap_agent_partner_side against the oracle)
         files["ref_framestack.json"] = {"history_queue": rd.drive_history_queue(fw), "wrappers": rd.drive_framestack(fw, spaces)}
         rec = rd.drive_recorders(fw, spaces)
         files["ref_recorders.json"] = rec["views"]

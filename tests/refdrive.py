@@ -769,3 +769,4 @@ class LoopDoubles:
 
     def train(self):
         self.events.append(["train"])
+
