@@ -1079,18 +1079,13 @@ __global__ __launch_bounds__(RED_PARAMS * 4) void ppo_step_kernel(StepArgs s) {
   const int stopped = *s.r.stop_flag;
   const unsigned tag = *s.gen + 1u;
   const int step_new = *s.ad.step + 1;
-  if (*s.sweep_error != 0u) {
-    // an earlier wait of this context expired (ph_ctx_step_errors): blocks of that launch which could not be scheduled in time may
-    // still publish words -- tagged with a generation a later launch would reuse -- so nothing after the first expiry sweeps at all:
-    // the update is skipped and marked (stats[7] = -1), the host raises
-    if (blockIdx.x == 0 && threadIdx.x == 0 && s.r.stats_out) s.r.stats_out[7] = -1.f;
-    return;
-  }
-  if (stopped != 0) {  // a previous minibatch of this train() call hit the KL early stop (stable for the whole launch)
-    if (blockIdx.x == 0) step_stopped(s.r);
-    return;
-  }
-  step_body<VEC>(s, blockIdx.x, nblk, tag, step_new, gsum, part, means, nullptr);
+  const unsigned err = *s.sweep_error;
+#if !PH_STEP_LATE_CHECKS
+  if (step_refused(s.r, blockIdx.x, stopped, err)) return;
+#endif
+  // (the two reasons to do nothing -- an expired wait of this context, a KL early stop earlier in this train() call -- are tested
+  // inside, behind the slab walk: ph_step.h)
+  step_body<VEC>(s, blockIdx.x, nblk, tag, step_new, gsum, part, means, nullptr, stopped, err);
 }
 
 int reduce_blocks(int slab_len) { return (slab_len + RED_PARAMS - 1) / RED_PARAMS; }

@@ -386,13 +386,36 @@ __device__ __forceinline__ void step_stopped(const ReduceArgs& a) {
 }
 // The step of slab block `blk` of `nblk` (blk == nblk: the statistics block), 256 lanes.  tag = launch generation + 1 and
 // step_new = optimizer step + 1 were read by the caller before anything of this launch was published.
+// `stopped` (an earlier minibatch of this train() call hit the KL early stop) and `err` (an earlier wait of this context expired) are
+// the launch's two reasons to do nothing.  They arrive as VALUES the caller loaded at the top of the kernel and are TESTED here behind
+// the slab walk: tested at the top, every block waited for that round trip of scalar loads before its first slab load went out
+// (PH_STEP_LATE_CHECKS=0 restores the test at the top; same-box A/B profiles/r06_bl_*).  A block that walked for nothing publishes and
+// writes nothing; the statistics block, whose reduction has side effects, still tests first.
+#ifndef PH_STEP_LATE_CHECKS
+#define PH_STEP_LATE_CHECKS 1
+#endif
+__device__ __forceinline__ bool step_refused(const ReduceArgs& a, int blk, int stopped, unsigned err) {
+  if (err != 0u) {
+    // (ph_ctx_step_errors) blocks of the expired launch which could not be scheduled in time may still publish words -- tagged with a
+    // generation a later launch would reuse -- so nothing after the first expiry sweeps at all: the update is skipped and marked
+    // (stats[7] = -1), the host raises
+    if (blk == 0 && threadIdx.x == 0 && a.stats_out) a.stats_out[7] = -1.f;
+    return true;
+  }
+  if (stopped != 0) {  // (stable for the whole launch)
+    if (blk == 0) step_stopped(a);
+    return true;
+  }
+  return false;
+}
 template <int VEC, bool COH = false>
 __device__ __forceinline__ void step_body(const StepArgs& s, int blk, int nblk, unsigned tag, int step_new, float (*gsum)[RED_PARAMS],
-                                          float (*part)[NSTATP], float* means, const void* /*unused*/) {
+                                          float (*part)[NSTATP], float* means, const void* /*unused*/, int stopped = 0, unsigned err = 0u) {
   const ReduceArgs& a = s.r;
   const AdamArgs& ad = s.ad;
   const int tid = threadIdx.x;
   if (blk == nblk) {   // the extra block: statistics + KL decision while the slab blocks reduce; its word carries `stop`
+    if (step_refused(a, blk, stopped, err)) return;
     const bool stop = reduce_statistics<COH>(a, part, means, false);
     if (tid == 0)
       __hip_atomic_store(s.words + nblk, ((unsigned long long)tag << 32) | (stop ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -413,6 +436,7 @@ __device__ __forceinline__ void step_body(const StepArgs& s, int blk, int nblk, 
     }
   }
   const float g = reduce_positions<VEC, COH>(a, gsum, dst, blk);
+  if (step_refused(a, blk, stopped, err)) return;
   if (tid < 64) {
     float q = g * g;
     for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
