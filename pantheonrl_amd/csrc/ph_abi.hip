@@ -2005,6 +2005,12 @@ int train_launch_step(const TrainPlan& t, int mbi, const MbPlan& pl) {
     if (adap_launch(ctx, t.nd, t.opt->params, t.rb, t.adap, idx, pl.nb, mbi, &r)) return 1;
   }
   const bool fused = step_fused_wanted(ctx, slab_len_of(t.nd), t.alone != 0);
+#ifdef PH_EXPERIMENT_SKIP_STEP   // TIMING EXPERIMENTS ONLY (never in the default build; scripts/build_variants.sh): what the gradient launches
+  (void)fused;                   // of two learners cost each other WITHOUT the other learner's reduce / Adam kernels beside them
+  if (PH_EXPERIMENT_SKIP_STEP == 1) return 0;                                        // 1: neither kernel
+  if (PH_EXPERIMENT_SKIP_STEP == 2) { PH_HIP(ph::launch_ppo_reduce(r, s)); return 0; }   // 2: the reduction only
+  if (PH_EXPERIMENT_SKIP_STEP == 3) { PH_HIP(ph::launch_ppo_adam(ad, s)); return 0; }    // 3: clip + Adam only (on a stale gradient)
+#endif                           // (profiles/r06_bn_*)
   if (fused) {
     PH_HIP(ph::launch_ppo_step(r, ad, ctx->step_words, ctx->step_gen, ctx->step_gen + 1, STEP_WAIT_TICKS, s));
   } else {

@@ -1041,9 +1041,24 @@ hipError_t launch_obs_planes(const float* obs, int n, int D, int F, int fold, ui
 // (slab reduction, clip and Adam device code: ph_step.h)
 template <int VEC>
 __global__ __launch_bounds__(RED_PARAMS * 4) void ppo_reduce_kernel(ReduceArgs a) {
+  // ONE kilobyte of LDS, not two: a slab block uses gsum, the statistics block part / means -- never both.  Beside another learner's
+  // gradient launch that is the difference between fitting into what two resident gradient workgroups leave of a CU's LDS (2 x 79 680
+  // of ~160.7 KB usable: ~1.4 KB) and waiting for one of them to leave -- or, placed first, keeping the second one out for the
+  // reduction's 5.7 us (PH_REDUCE_LDS_UNION=0: the two arrays side by side, 2 112 bytes; same-box A/B profiles/r06_bn_*)
+#ifndef PH_REDUCE_LDS_UNION
+#define PH_REDUCE_LDS_UNION 1
+#endif
+#if PH_REDUCE_LDS_UNION
+  __shared__ float lds_union[4 * RED_PARAMS];
+  static_assert(4 * RED_PARAMS >= 32 * NSTATP + NSTATP || 4 * RED_PARAMS >= 32 * NSTATP, "statistics scratch within the slab scratch");
+  float (*gsum)[RED_PARAMS] = reinterpret_cast<float (*)[RED_PARAMS]>(lds_union);
+  float (*part)[NSTATP] = reinterpret_cast<float (*)[NSTATP]>(lds_union);
+  __shared__ float means[NSTATP];
+#else
   __shared__ float gsum[4][RED_PARAMS];
   __shared__ float part[32][NSTATP];
   __shared__ float means[NSTATP];
+#endif
   const int tid = threadIdx.x;
   if (*a.stop_flag != 0) {  // a previous minibatch of this train() call hit the KL early stop
     if (blockIdx.x == 0 && tid < PH_NSTAT && a.stats_out) a.stats_out[tid] = 0.f;

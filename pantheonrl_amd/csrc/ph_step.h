@@ -100,7 +100,10 @@ __device__ __forceinline__ void range_walk(const ReduceArgs& a, const RSRC& rsrc
     // buffer loads: descriptor + one 32-bit lane offset (range start + position) + a scalar offset (slab j of the range) --
     // no 64-bit address per load in flight (flat loads cost the 8-byte shape 32 VGPRs of addresses)
     const unsigned lane_off = (unsigned)k0 * stride + (unsigned)p0 * (unsigned)sizeof(float);
-    constexpr int AUX = COH ? 16 : 0;   // 16 = sc1
+#ifndef PH_REDUCE_NT
+#define PH_REDUCE_NT 0   // experiment (scripts/build_variants.sh): 1 = the slab walk's loads carry the nontemporal bit (each slab byte is read once)
+#endif
+    constexpr int AUX = COH ? 16 : (PH_REDUCE_NT ? 2 : 0);   // 16 = sc1, 2 = nt
     auto ld = [&](int j) -> VT {
       if constexpr (VEC == 4) return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, (unsigned)j * stride, AUX));
       else if constexpr (VEC == 2) return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_off, (unsigned)j * stride, AUX));
