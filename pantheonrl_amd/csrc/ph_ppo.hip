@@ -1060,6 +1060,12 @@ __global__ __launch_bounds__(RED_PARAMS * 4) void ppo_reduce_kernel(ReduceArgs a
   __shared__ float means[NSTATP];
 #endif
   const int tid = threadIdx.x;
+#ifdef PH_REDUCE_START_DELAY_TICKS   // experiment (scripts/build_variants.sh; 100 MHz ticks): the reduction's loads held back so that they do not
+  {                                  // meet the OTHER learner's gradient prologue, which starts when this learner's gradient launch ends
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (long long)(PH_REDUCE_START_DELAY_TICKS)) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   if (*a.stop_flag != 0) {  // a previous minibatch of this train() call hit the KL early stop
     if (blockIdx.x == 0 && tid < PH_NSTAT && a.stats_out) a.stats_out[tid] = 0.f;
     if (blockIdx.x == 0 && tid == 0) {
